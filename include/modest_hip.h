@@ -1,0 +1,195 @@
+/*
+ * modest_hip.h — C ABI of libmodest_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the seed-label hot path of YurongYou/MODEST
+ * (pre_compute_pp_score -> generate_mask -> gen_label_files).  Every entry
+ * point names the reference interface it replaces (paths relative to the
+ * reference checkout).  Conventions, all entry points:
+ *
+ *   - plain pointers and sizes; no torch / numpy types cross this boundary;
+ *   - pointers marked [dev] are device (HBM) pointers, [host] are host
+ *     pointers; the caller owns every buffer (reference convention:
+ *     generate_cluster_mask/utils/iou3d_nms/iou3d_nms_utils.py:47,103);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     work is enqueued on it, the call does not synchronise unless the
+ *     description says "blocking";
+ *   - return value: 0 = ok, <0 = error (never exit(); the reference's
+ *     CHECK_INPUT exits the process, src/iou3d_nms.cpp:14-26);
+ *     modest_last_error() returns a thread-local message;
+ *   - per-stream scratch lives in a modest_ctx (one per process x GPU).
+ */
+#ifndef MODEST_HIP_H
+#define MODEST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODEST_OK 0
+#define MODEST_ERR_ARG (-1)
+#define MODEST_ERR_HIP (-2)
+#define MODEST_ERR_CAPACITY (-3)
+#define MODEST_ERR_NODEVICE (-4)
+
+typedef struct modest_ctx modest_ctx;
+
+/* ---- library / context ------------------------------------------------ */
+int modest_version(void);
+const char *modest_last_error(void);
+/* Number of visible HIP devices (0 when no GPU; never fails). */
+int modest_device_count(void);
+int modest_ctx_create(int device, modest_ctx **out);
+int modest_ctx_destroy(modest_ctx *ctx);
+
+/* ---- a4  transform_points  (utils/pointcloud_utils.py:11-19) ----------
+ * out[i] = (x*T[r][0] (+fma) y*T[r][1] (+fma) z*T[r][2]) + T[r][3], float32,
+ * i.e. [p,1] @ T^T, rows 0..2.  `in_stride` is 3 or 4 floats per point
+ * (velodyne .bin frames are (n,4): load_velo_scan, pointcloud_utils.py:22-25).
+ * T16 is a host pointer to a row-major 4x4 float32 matrix.
+ * If remove_center != 0 (nuScenes, pre_compute_pp_score.py:48-52,141-142)
+ * points with x in [-1.15,1.75) and y in [-0.65,0.65) of the UNtransformed
+ * frame are dropped and the output is compacted in input order;
+ * *n_out_dev [dev] receives the number written (may be NULL when
+ * remove_center == 0).                                                     */
+int modest_transform_points(modest_ctx *ctx, const float *in_dev, int64_t n,
+                            int in_stride, const float *T16_host,
+                            int remove_center, float *out_xyz_dev,
+                            int64_t *n_out_dev, void *stream);
+
+/* ---- a6+a7  cKDTree build + count_neighbors ---------------------------
+ * (pre_compute_pp_score.py:54-60,188-193).  For every live point i and
+ * traversal t: counts[i*T+t] = #{ h in hist[t] : |p_i-h|^2 <= radius^2 },
+ * inclusive, predicate evaluated in float64 on the float32 coordinates
+ * exactly as scipy's cKDTree.query_ball_point does.
+ *   live_xyz [dev]  (n_live,3) f32, already in the common frame
+ *   hist_xyz [dev]  (M,3) f32 stacked traversals, already transformed
+ *   trav_offsets [host] (T+1) int64 prefix offsets into hist (points)
+ *   counts [dev] (n_live,T) int32 (the reference returns int64; values
+ *   are < 2^31 because M < 2^31 is required).                              */
+int modest_pp_count(modest_ctx *ctx, const float *live_xyz_dev, int n_live,
+                    const float *hist_xyz_dev, const int64_t *trav_offsets_host,
+                    int n_trav, double radius, int32_t *counts_dev,
+                    void *stream);
+
+/* ---- a8  compute_ephe_score (pre_compute_pp_score.py:68-75) ------------
+ * P = c/(sum_t c + 1e-8); H = sum_t -P ln(P+1e-8) / ln T, float64, stored
+ * as float32 (np.save(...astype(float32)), :195-196).                      */
+int modest_pp_entropy(modest_ctx *ctx, const int32_t *counts_dev, int n_live,
+                      int n_trav, float *H_dev, void *stream);
+
+/* a7+a8 fused: counts_dev may be NULL (scratch is used).                  */
+int modest_pp_score(modest_ctx *ctx, const float *live_xyz_dev, int n_live,
+                    const float *hist_xyz_dev, const int64_t *trav_offsets_host,
+                    int n_trav, double radius, int32_t *counts_dev,
+                    float *H_dev, void *stream);
+
+/* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
+ * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).
+ * Candidate selection: z<max_hs, xlo<x<xhi, ylo<y<yhi (strict), compacted in
+ * input order into cand_xyz [dev] (capacity n), *n_cand_dev [dev].          */
+int modest_plane_candidates(modest_ctx *ctx, const float *pts_dev, int n,
+                            int stride, float max_hs, float xlo, float xhi,
+                            float ylo, float yhi, float *cand_xyz_dev,
+                            int32_t *cand_idx_dev, int32_t *n_cand_dev,
+                            void *stream);
+/* MAD threshold: median(|z - median(z)|) over the candidates, float32
+ * arithmetic, numpy.median semantics (mean of the two middle values when n
+ * is even).  Blocking; result written to *mad_host.                         */
+int modest_mad_threshold(modest_ctx *ctx, const float *cand_xyz_dev,
+                         int n_cand, float *mad_host, void *stream);
+/* Score K trial models z = c0*x + c1*y + b (float32, pred = fma chain
+ * fmaf(y,c1,x*c0)+b) against all candidates in ONE launch:
+ *   n_inliers[k] = #{ |z - pred| <= thr },  sse[k], sy[k], syy[k] over the
+ *   inliers in float64 (for the R^2 tie-break).  models [host] (K,3) f32.
+ *   outputs [host], blocking.                                               */
+int modest_ransac_score_trials(modest_ctx *ctx, const float *cand_xyz_dev,
+                               int n_cand, const float *models_host, int K,
+                               float thr, int32_t *n_inliers_host,
+                               double *sse_host, double *sy_host,
+                               double *syy_host, void *stream);
+/* Least-squares refit of z ~ x,y over the inliers of `model` (float64
+ * normal equations, centred); out_model [host] (3) float64. Blocking.       */
+int modest_ransac_refit(modest_ctx *ctx, const float *cand_xyz_dev, int n_cand,
+                        const float *model_host, float thr,
+                        double *out_model_host, int32_t *n_inliers_host,
+                        void *stream);
+
+/* ---- a10+a11 above_plane & range mask (pointcloud_utils.py:68-81,
+ * generate_mask.py:57-65).  keep[i] = !(dist<offset && in only_range) &&
+ * (lx0 < x <= lx1) && (ly0 < y <= ly1); dist = (p . n + d)/|n| in float64.
+ * Compacts kept points (input order) to kept_xyz/kept_idx; mask is uint8.   */
+int modest_plane_range_mask(modest_ctx *ctx, const float *pts_dev, int n,
+                            int stride, const double *plane4_host,
+                            double offset, const double *only_range4_host,
+                            const double *limit_range4_host,
+                            uint8_t *mask_dev, float *kept_xyz_dev,
+                            int32_t *kept_idx_dev, int32_t *n_kept_dev,
+                            void *stream);
+
+/* ---- a12+a13 precompute_affinity_matrix('radius_mutual_knn','l1') +
+ * DBSCAN(metric='precomputed') (utils/clustering_utils.py:7-60,
+ * generate_mask.py:75-81), evaluated on the implicit graph:
+ *   edge(i,j) <=> d2(i,j) <= min(r2_k(i), r2_k(j), radius^2)   (float64 d2)
+ *                 and (double)(float)|pp_i - pp_j| <= eps
+ *   core(i)   <=> deg(i) + 1 >= min_samples
+ *   label     =  rank of the component's smallest core index; border point
+ *                -> smallest label among adjacent cores; noise -> -1.
+ * xyz [dev] (n,3) f32, pp [dev] (n) f32, labels [dev] (n) int32.
+ * kth_d2 [dev] (n) float64 optional output (squared distance to the k-th
+ * neighbour, +inf when fewer than k neighbours lie within radius).          */
+int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz_dev,
+                          const float *pp_dev, int n, int k_neighbors,
+                          double radius, double eps, int min_samples,
+                          int32_t *labels_dev, double *kth_d2_dev,
+                          int32_t *n_clusters_host, void *stream);
+
+/* ---- a16 closeness_rectangle angle search (pointcloud_utils.py:167-187)
+ * For each cluster c (points pts_xz[offsets[c]..offsets[c+1]) , float64 (x,z)
+ * pairs) and each of n_angles (cos,sin) table entries: beta = sum over points
+ * of 1/max(min(Dx,Dy),d0) accumulated in numpy's pairwise order; returns the
+ * index of the first strict maximum per cluster and the betas.               */
+int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz_dev,
+                               const int32_t *offsets_host, int n_clusters,
+                               const double *cossin_host, int n_angles,
+                               double d0, int32_t *best_angle_host,
+                               double *beta_host /* optional (C,n_angles) */,
+                               void *stream);
+
+/* ---- a17 get_lowest_point_rect (pointcloud_utils.py:278-290) ----------
+ * For each box b (cx,cz,l,w,ry float64) the max rect-y over all scan points
+ * strictly inside the rotated footprint; -inf when empty.                   */
+int modest_lowest_point(modest_ctx *ctx, const double *pts_rect_dev, int n,
+                        const double *boxes5_host, int n_boxes,
+                        double *bottom_host, void *stream);
+
+/* ---- a20 iou3d_nms_cuda (utils/iou3d_nms/src/iou3d_nms.h:9-12,
+ * iou3d_cpu.h:9, bound at src/iou3d_nms_api.cpp:11-17) -------------------
+ * boxes: (n,7) f32 [x,y,z,dx,dy,dz,heading], out: (n_a,n_b) f32 row-major. */
+int modest_boxes_overlap_bev(const float *boxes_a_dev, int n_a,
+                             const float *boxes_b_dev, int n_b,
+                             float *out_dev, void *stream);
+int modest_boxes_iou_bev(const float *boxes_a_dev, int n_a,
+                         const float *boxes_b_dev, int n_b, float *out_dev,
+                         void *stream);
+/* nms_gpu / nms_normal_gpu: boxes sorted by score [dev]; keep [host] int64
+ * (n); returns the number kept in *num_keep_host.  Blocking (the reference
+ * also blocks on a cudaMemcpy, src/iou3d_nms.cpp:111-112).                  */
+int modest_nms_bev(modest_ctx *ctx, const float *boxes_dev, int n,
+                   float thresh, int64_t *keep_host, int *num_keep_host,
+                   void *stream);
+int modest_nms_normal(modest_ctx *ctx, const float *boxes_dev, int n,
+                      float thresh, int64_t *keep_host, int *num_keep_host,
+                      void *stream);
+/* boxes_iou_bev_cpu (src/iou3d_cpu.cpp:232-252): host pointers in and out.
+ * Runs the same kernel through a staging copy (there is no CPU arithmetic
+ * path in this library).                                                    */
+int modest_boxes_iou_bev_host(modest_ctx *ctx, const float *boxes_a_host,
+                              int n_a, const float *boxes_b_host, int n_b,
+                              float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODEST_HIP_H */

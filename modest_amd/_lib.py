@@ -1,0 +1,117 @@
+"""ctypes binding of libmodest_hip.so (the C ABI declared in include/modest_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device
+is visible when a context is requested, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MODEST_HIP_LIB", _PKG / "lib" / "libmodest_hip.so"))
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+VP = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/modest_hip.h one to one.
+SIGNATURES = {
+    "modest_version": (C.c_int, []),
+    "modest_last_error": (C.c_char_p, []),
+    "modest_device_count": (C.c_int, []),
+    "modest_ctx_create": (C.c_int, [C.c_int, C.POINTER(VP)]),
+    "modest_ctx_destroy": (C.c_int, [VP]),
+    "modest_transform_points": (C.c_int, [VP, VP, C.c_int64, C.c_int, VP, C.c_int, VP, VP, VP]),
+    "modest_pp_count": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP]),
+    "modest_pp_entropy": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP]),
+    "modest_pp_score": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP, VP]),
+    "modest_plane_candidates": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, VP, VP, VP, VP]),
+    "modest_mad_threshold": (C.c_int, [VP, VP, C.c_int, VP, VP]),
+    "modest_ransac_score_trials": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_float, VP, VP, VP, VP, VP]),
+    "modest_ransac_refit": (C.c_int, [VP, VP, C.c_int, VP, C.c_float, VP, VP, VP]),
+    "modest_plane_range_mask": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_double, VP, VP, VP, VP, VP,
+                                          VP, VP]),
+    "modest_cluster_dbscan": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                        VP, VP, VP, VP]),
+    "modest_fit_boxes_closeness": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP, VP]),
+    "modest_lowest_point": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),
+    "modest_boxes_overlap_bev": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
+    "modest_boxes_iou_bev": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
+    "modest_nms_bev": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP]),
+    "modest_nms_normal": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP]),
+    "modest_boxes_iou_bev_host": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class ModestHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the library and attach prototypes (raises if it is not built)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise ModestHipError(
+                f"{LIB_PATH} is missing: build it with `python -m modest_amd.build` "
+                "(there is no CPU fallback for the MODEST hot path)")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().modest_last_error()
+        raise ModestHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+class Context:
+    """One scratch arena per process x GPU x stream (modest_ctx)."""
+
+    def __init__(self, device: int = 0):
+        lib = load()
+        self._h = VP()
+        check(lib.modest_ctx_create(int(device), C.byref(self._h)), "modest_ctx_create")
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            load().modest_ctx_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,54 @@
+// Shared host-side helpers for libmodest_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "modest_hip.h"
+
+struct modest_ctx {
+    int device;
+    char *scratch;          // grow-only device arena
+    size_t scratch_bytes;
+    char *pinned;           // grow-only pinned host staging
+    size_t pinned_bytes;
+    int num_cus;
+};
+
+void modest_set_error(const char *fmt, ...);
+
+#define MODEST_HIP_CHECK(expr)                                                  \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            modest_set_error("%s failed: %s (%s:%d)", #expr,                    \
+                             hipGetErrorString(_e), __FILE__, __LINE__);        \
+            return MODEST_ERR_HIP;                                              \
+        }                                                                       \
+    } while (0)
+
+#define MODEST_REQUIRE(cond, msg)                                               \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            modest_set_error("%s: requirement failed: %s (%s)", __func__, #cond, msg); \
+            return MODEST_ERR_ARG;                                              \
+        }                                                                       \
+    } while (0)
+
+// Ensure the context arena holds at least `bytes`; returns 0 or error code.
+int modest_ctx_reserve(modest_ctx *ctx, size_t bytes);
+int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes);
+
+// Bump allocator over the arena (256-byte aligned carves).
+struct Arena {
+    char *base;
+    size_t off;
+    explicit Arena(char *b) : base(b), off(0) {}
+    template <typename T> T *take(size_t count) {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255) & ~size_t(255);
+        return p;
+    }
+};
+static inline size_t arena_sz(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

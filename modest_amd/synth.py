@@ -1,0 +1,287 @@
+"""Deterministic synthetic multi-traversal LiDAR scenes.
+
+No dataset ships with the reference (its ``valid_idx_info.pkl`` blobs are
+missing), so tests and ``bench.py`` run on seeded synthetic scenes shaped like
+the data the reference processes: a static world (ground plane, walls, parked
+boxes) observed from an ego vehicle driving along +x, re-observed by T
+historical traversals of F frames each (2 m apart, lateral jitter), plus mobile
+boxes that exist only in the live scan.  Points are produced in each frame's
+KITTI-velodyne coordinates; poses are produced as ``oxts`` / ``l2e`` so that the
+whole CLI path (``get_relative_pose`` included) can be exercised.
+
+This is data generation, not part of the hot path.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+SENSOR_H = 1.7          # lidar height above the ground plane [m]
+ROAD_HALF_WIDTH = 12.0  # walls at y_w = +-12 m
+
+
+def rot_z(angle: float) -> np.ndarray:
+    t = np.eye(4)
+    c, s = np.cos(angle), np.sin(angle)
+    t[:2, :2] = [[c, -s], [s, c]]
+    return t
+
+
+def kitti2nu(nusc: bool) -> np.ndarray:
+    """4x4 rotation about z by pi (Lyft) or pi/2 (nuScenes)."""
+    return rot_z(np.pi / 2 if nusc else np.pi)
+
+
+@dataclass
+class World:
+    """Static surfaces, fixed for a scene seed."""
+    boxes: np.ndarray          # (B,6) cx,cy,cz,l,w,h  axis aligned, world frame
+    poles: np.ndarray          # (P,2) x,y
+    seed: int = 0
+
+
+def make_world(seed: int, length: float = 400.0) -> World:
+    rng = np.random.default_rng(10_000 + seed)
+    nb = 160
+    side = rng.choice([-1.0, 1.0], nb)
+    cx = rng.uniform(-100.0, length, nb)
+    cy = side * rng.uniform(5.5, 10.5, nb)
+    l = rng.uniform(3.5, 9.0, nb)
+    w = rng.uniform(1.6, 3.0, nb)
+    h = rng.uniform(1.3, 3.5, nb)
+    boxes = np.stack([cx, cy, h / 2, l, w, h], axis=1)
+    poles = np.stack([rng.uniform(-100.0, length, 120), rng.choice([-1.0, 1.0], 120) * rng.uniform(4.0, 11.5, 120)], 1)
+    return World(boxes=boxes, poles=poles, seed=seed)
+
+
+def _sample_box_surface(rng, box, m):
+    """m points on the 4 vertical faces + top of an axis-aligned box."""
+    cx, cy, cz, l, w, h = box
+    face = rng.integers(0, 5, m)
+    u = rng.uniform(-0.5, 0.5, m)
+    v = rng.uniform(-0.5, 0.5, m)
+    x = np.where(face == 0, -0.5, np.where(face == 1, 0.5, u)) * l + cx
+    y = np.where(face == 2, -0.5, np.where(face == 3, 0.5, np.where(face < 2, v, u * 0 + v))) * w + cy
+    z = np.where(face == 4, 0.5, rng.uniform(-0.5, 0.5, m)) * h + cz
+    return np.stack([x, y, z], 1)
+
+
+def _pose_matrix(x, y, yaw, roll=0.0, pitch=0.0):
+    t = np.eye(4)
+    t[:3, :3] = R.from_euler("xyz", [roll, pitch, yaw]).as_matrix()
+    t[:3, 3] = [x, y, 0.0]
+    return t
+
+
+def default_l2e() -> np.ndarray:
+    t = np.eye(4)
+    t[:3, 3] = [1.2, 0.0, SENSOR_H]
+    return t
+
+
+def sample_frame(world: World, seed: int, n: int, ego_pose: np.ndarray, l2e: np.ndarray,
+                 nusc: bool = False, mobiles: np.ndarray | None = None,
+                 max_range: float = 80.0) -> np.ndarray:
+    """One LiDAR frame, (n,4) float32 in KITTI-velodyne coordinates
+    (x forward, y left, z up; intensity in column 3)."""
+    rng = np.random.default_rng(seed)
+    sensor2world = ego_pose @ l2e @ kitti2nu(nusc)
+    world2sensor = np.linalg.inv(sensor2world)
+    origin = sensor2world[:3, 3]
+
+    n_mob = 0
+    if mobiles is not None and len(mobiles):
+        n_mob = int(0.06 * n)
+    n_wall = int(0.14 * n)
+    n_box = int(0.10 * n)
+    n_pole = int(0.02 * n)
+    n_ground = n - n_mob - n_wall - n_box - n_pole
+
+    parts = []
+    # ground: lidar-like polar sampling (log-uniform range, uniform azimuth)
+    rr = np.exp(rng.uniform(np.log(2.0), np.log(max_range), n_ground))
+    az = rng.uniform(-np.pi, np.pi, n_ground)
+    gx = origin[0] + rr * np.cos(az)
+    gy = origin[1] + rr * np.sin(az)
+    gz = 0.02 * rng.standard_normal(n_ground) + 0.004 * (gx - origin[0]) * 0  # flat world
+    parts.append(np.stack([gx, gy, gz], 1))
+    # walls (vertical sheets along the road)
+    wx = origin[0] + rng.uniform(-max_range, max_range, n_wall)
+    wy = rng.choice([-ROAD_HALF_WIDTH, ROAD_HALF_WIDTH], n_wall) + 0.02 * rng.standard_normal(n_wall)
+    wz = rng.uniform(0.0, 4.0, n_wall)
+    parts.append(np.stack([wx, wy, wz], 1))
+    # static boxes within range, sampled proportionally
+    d = np.abs(world.boxes[:, 0] - origin[0])
+    near = np.where(d < max_range * 0.9)[0]
+    if len(near) == 0:
+        near = np.arange(len(world.boxes))
+    which = rng.choice(near, n_box)
+    pts = np.empty((n_box, 3))
+    for b in np.unique(which):
+        sel = which == b
+        pts[sel] = _sample_box_surface(rng, world.boxes[b], int(sel.sum()))
+    pts += 0.01 * rng.standard_normal(pts.shape)
+    parts.append(pts)
+    # poles
+    dpole = np.abs(world.poles[:, 0] - origin[0])
+    nearp = np.where(dpole < max_range * 0.9)[0]
+    if len(nearp) == 0:
+        nearp = np.arange(len(world.poles))
+    wp = rng.choice(nearp, n_pole)
+    ang = rng.uniform(0, 2 * np.pi, n_pole)
+    parts.append(np.stack([world.poles[wp, 0] + 0.1 * np.cos(ang), world.poles[wp, 1] + 0.1 * np.sin(ang),
+                           rng.uniform(0, 5.0, n_pole)], 1))
+    # mobile objects (live scan only)
+    if n_mob:
+        dm = np.linalg.norm(mobiles[:, :2] - origin[None, :2], axis=1)
+        wgt = 1.0 / np.maximum(dm, 3.0) ** 1.5
+        wm = rng.choice(len(mobiles), n_mob, p=wgt / wgt.sum())
+        mp = np.empty((n_mob, 3))
+        for b in np.unique(wm):
+            sel = wm == b
+            mp[sel] = _sample_box_surface(rng, mobiles[b], int(sel.sum()))
+        mp += 0.01 * rng.standard_normal(mp.shape)
+        parts.append(mp)
+    pw = np.concatenate(parts, 0)
+    ps = pw @ world2sensor[:3, :3].T + world2sensor[:3, 3]
+    out = np.empty((n, 4), dtype=np.float32)
+    out[:, :3] = ps.astype(np.float32)
+    out[:, 3] = rng.uniform(0, 1, n).astype(np.float32)
+    return out[rng.permutation(n)]
+
+
+def make_mobiles(seed: int, ego_x: float, count: int = 16) -> np.ndarray:
+    rng = np.random.default_rng(20_000 + seed)
+    ncar = count * 2 // 3
+    nped = count - ncar
+    rows = []
+    for _ in range(ncar):
+        rows.append([ego_x + rng.uniform(-45, 60), rng.uniform(-4.0, 4.0), 0.75, 4.0, 1.8, 1.5])
+    for _ in range(nped):
+        rows.append([ego_x + rng.uniform(-25, 35), rng.uniform(-4.8, 4.8), 0.85, 0.6, 0.6, 1.7])
+    return np.asarray(rows)
+
+
+@dataclass
+class ScanInputs:
+    """Array-level inputs of one PP-score unit, already in the common frame."""
+    live_raw: np.ndarray              # (N,4) f32 KITTI-velodyne frame of the live scan
+    live_xyz: np.ndarray              # (N,3) f32 transformed into the first-history-frame system
+    hist: List[np.ndarray]            # T arrays (M_t,3) f32 transformed
+    frames: List[List[Tuple[np.ndarray, np.ndarray]]] = field(default_factory=list)  # raw frame + 4x4 f32
+
+
+def _transform_f32(pts_xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
+    hom = np.hstack((pts_xyz.astype(np.float32), np.ones((pts_xyz.shape[0], 1), dtype=np.float32)))
+    return np.dot(hom, np.transpose(T.astype(np.float32))).reshape(-1, 4)[:, 0:3]
+
+
+def relative_pose(fixed_l2e, fixed_ego, query_l2e, query_ego, K) -> np.ndarray:
+    return np.linalg.solve(K, np.linalg.solve(fixed_l2e, np.linalg.solve(fixed_ego, query_ego @ query_l2e @ K))
+                           ).astype(np.float32)
+
+
+def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: int = 36,
+              n_per_frame: int | None = None, nusc: bool = False, frame_gap: float = 2.0,
+              keep_frames: bool = False, world_seed: int = 0) -> ScanInputs:
+    """Seeds: live 1000+scan_id, history 2000+scan_id*1000+t*100+f."""
+    n_per_frame = n_live if n_per_frame is None else n_per_frame
+    world = make_world(world_seed)
+    ego_x = 5.0 * scan_id % 200.0
+    K = kitti2nu(nusc)
+    l2e = default_l2e()
+    live_pose = _pose_matrix(ego_x, 0.0, 0.01)
+    mobiles = make_mobiles(scan_id, ego_x)
+    live_raw = sample_frame(world, 1000 + scan_id, n_live, live_pose, l2e, nusc, mobiles)
+    first_pose = None
+    hist, frames = [], []
+    rngp = np.random.default_rng(30_000 + scan_id)
+    for t in range(n_trav):
+        lat = rngp.uniform(-1.5, 1.5)
+        yaw = rngp.uniform(-0.02, 0.02)
+        q, fr = [], []
+        for f in range(n_frames):
+            pose = _pose_matrix(ego_x + frame_gap * f + rngp.uniform(-0.5, 0.5), lat, yaw)
+            if first_pose is None:
+                first_pose = pose
+            raw = sample_frame(world, 2000 + scan_id * 1000 + t * 100 + f, n_per_frame, pose, l2e, nusc)
+            rel = relative_pose(l2e, first_pose, l2e, pose, K)
+            xyz = raw[:, :3]
+            if nusc:
+                m = (xyz[:, 0] < 1.75) & (xyz[:, 0] >= -1.15) & (xyz[:, 1] < 0.65) & (xyz[:, 1] >= -0.65)
+                xyz = xyz[~m]
+            q.append(_transform_f32(xyz, rel))
+            if keep_frames:
+                fr.append((raw, rel))
+        hist.append(np.concatenate(q).astype(np.float32))
+        frames.append(fr)
+    rel_live = relative_pose(l2e, first_pose, l2e, live_pose, K)
+    live_xyz = _transform_f32(live_raw[:, :3], rel_live)
+    return ScanInputs(live_raw=live_raw, live_xyz=np.ascontiguousarray(live_xyz), hist=hist, frames=frames)
+
+
+CALIB_TXT = (
+    "P0: 8.8e+02 0 6.12e+02 0 0 8.8e+02 5.12e+02 0 0 0 1 0\n"
+    "P1: 8.8e+02 0 6.12e+02 0 0 8.8e+02 5.12e+02 0 0 0 1 0\n"
+    "P2: 8.8e+02 0 6.12e+02 0 0 8.8e+02 5.12e+02 0 0 0 1 0\n"
+    "P3: 8.8e+02 0 6.12e+02 0 0 8.8e+02 5.12e+02 0 0 0 1 0\n"
+    "R0_rect: 1 0 0 0 1 0 0 0 1\n"
+    "Tr_velo_to_cam: 0 -1 0 0 0 0 -1 -0.3 1 0 0 -0.5\n"
+    "Tr_imu_to_velo: 1 0 0 0 0 1 0 0 0 0 1 0\n"
+)
+
+
+def write_kitti_tree(root: str, meta: str, n_seq: int = 3, n_frames: int = 12, n_pts: int = 8000,
+                     nusc: bool = False, world_seed: int = 0, origins: Tuple[int, ...] = (2,),
+                     hist_frames: int = 8) -> Dict[str, str]:
+    """Tiny KITTI-format tree + MODEST meta data (track list, valid idx info,
+    idx list) for CLI tests: sequence 0 holds the live scans (with mobile
+    objects), sequences 1.. are the historical traversals.
+    File formats: data_preprocessing/lyft/lyft2kitti.py:258-272,365-393."""
+    train = os.path.join(root, "training")
+    for d in ("velodyne", "oxts", "l2e", "calib"):
+        os.makedirs(os.path.join(train, d), exist_ok=True)
+    os.makedirs(meta, exist_ok=True)
+    world = make_world(world_seed)
+    l2e = default_l2e()
+    track, idx = [], 0
+    rng = np.random.default_rng(40_000 + world_seed)
+    for s in range(n_seq):
+        seq = []
+        lat = 0.0 if s == 0 else rng.uniform(-1.0, 1.0)
+        for f in range(n_frames):
+            ex = 2.0 * f + 0.3 * s
+            yaw = 0.01 * s
+            pose = _pose_matrix(ex, lat, yaw)
+            mob = make_mobiles(s * 100 + f, ex, 8) if (s == 0 and f in origins) else None
+            raw = sample_frame(world, 50_000 + 1000 * s + f, n_pts, pose, l2e, nusc, mob, max_range=60.0)
+            raw.tofile(os.path.join(train, "velodyne", f"{idx:06d}.bin"))
+            with open(os.path.join(train, "oxts", f"{idx:06d}.txt"), "w") as fh:
+                fh.write(f"{ex!r} {lat!r} 0.0 0.0 0.0 {yaw!r}")
+            np.save(os.path.join(train, "l2e", f"{idx:06d}.npy"), l2e)
+            with open(os.path.join(train, "calib", f"{idx:06d}.txt"), "w") as fh:
+                fh.write(CALIB_TXT)
+            seq.append(idx)
+            idx += 1
+        track.append(seq)
+    valid = {}
+    for o in origins:
+        hist = [(s, list(range(o, min(o + hist_frames, n_frames)))) for s in range(1, n_seq)]
+        valid[track[0][o]] = (0, o, hist)
+    paths = {
+        "track_path": os.path.join(meta, "track_list.pkl"),
+        "idx_info": os.path.join(meta, "valid_idx_info.pkl"),
+        "idx_list": os.path.join(meta, "train_idx.txt"),
+    }
+    with open(paths["track_path"], "wb") as fh:
+        pickle.dump(track, fh)
+    with open(paths["idx_info"], "wb") as fh:
+        pickle.dump(valid, fh)
+    with open(paths["idx_list"], "w") as fh:
+        fh.write("\n".join(f"{track[0][o]:06d}" for o in origins))
+    return paths
