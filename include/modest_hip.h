@@ -158,10 +158,13 @@ int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz_dev,
                                void *stream);
 
 /* ---- a17 get_lowest_point_rect (pointcloud_utils.py:278-290) ----------
- * For each box b (cx,cz,l,w,ry float64) the max rect-y over all scan points
- * strictly inside the rotated footprint; -inf when empty.                   */
+ * For each box b = (cx, cz, l, w, cos(ry), sin(ry)) float64 [host] the max
+ * rect-y over all scan points strictly inside the rotated footprint
+ * ([dx dz] @ [[c,-s],[s,c]]^T as an FMA chain); -inf when no point is
+ * inside (numpy raises there).  cos/sin come from the host so that the
+ * host's libm, not the device's, defines them.  Blocking.                   */
 int modest_lowest_point(modest_ctx *ctx, const double *pts_rect_dev, int n,
-                        const double *boxes5_host, int n_boxes,
+                        const double *boxes6_host, int n_boxes,
                         double *bottom_host, void *stream);
 
 /* ---- a20 iou3d_nms_cuda (utils/iou3d_nms/src/iou3d_nms.h:9-12,

@@ -1,0 +1,252 @@
+// Box fitting for gfx950: the 901-angle "closeness to edge" search
+// (utils/pointcloud_utils.py:167-187) and get_lowest_point_rect (:278-290).
+//
+// The reference runs a pure-Python loop of 901 angles per cluster (29 % of its
+// mask stage).  Here every (cluster, angle) pair is one lane; the cluster's
+// points are read as wave-uniform (broadcast) loads.  Arithmetic contract,
+// float64 throughout:
+//   projection  p0 = fma(z, s, x*c),  p1 = fma(z, c, x*(-s))   (the 2-term BLAS
+//               product [x z] @ [[c,s],[-s,c]]^T as an FMA chain)
+//   beta_i      = 1 / max(min(min(p0-minx, maxx-p0), min(p1-miny, maxy-p1)), d0)
+//   sum         in numpy's pairwise order (8 accumulators per <=128 block,
+//               halves split at a multiple of 8), so the first-strict-maximum
+//               over the angles is reproducible bit for bit.
+// The (cos, sin) table comes from the host so that device libm differences
+// cannot move the chosen angle.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+struct BetaCtx {
+    const double *pts;   // (n,2) x,z of this cluster
+    double c, s, ns;
+    double minx, maxx, miny, maxy, d0;
+};
+
+__device__ __forceinline__ double beta_at(const BetaCtx &B, int i) {
+    const double x = B.pts[2 * (size_t)i], z = B.pts[2 * (size_t)i + 1];
+    const double p0 = fma(z, B.s, x * B.c);
+    const double p1 = fma(z, B.c, x * B.ns);
+    const double dx = fmin(p0 - B.minx, B.maxx - p0);
+    const double dy = fmin(p1 - B.miny, B.maxy - p1);
+    double b = fmin(dx, dy);
+    b = fmax(b, B.d0);
+    return 1.0 / b;
+}
+
+// numpy pairwise-sum leaf: n <= 128
+__device__ double pw_leaf(const BetaCtx &B, int off, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += beta_at(B, off + i);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = beta_at(B, off + j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += beta_at(B, off + i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += beta_at(B, off + i);
+    return res;
+}
+
+// explicit-stack form of: n<=128 ? leaf : sum(a,n2) + sum(a+n2,n-n2), n2 = n/2 - (n/2)%8
+__device__ double pw_sum(const BetaCtx &B, int n) {
+    int f_off[32], f_n[32], f_stage[32];
+    double f_left[32];
+    int sp = 0;
+    f_off[0] = 0;
+    f_n[0] = n;
+    f_stage[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        const int off = f_off[sp], len = f_n[sp];
+        if (len <= 128) {
+            ret = pw_leaf(B, off, len);
+            --sp;
+            continue;
+        }
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if (f_stage[sp] == 0) {
+            f_stage[sp] = 1;
+            ++sp;
+            f_off[sp] = off;
+            f_n[sp] = n2;
+            f_stage[sp] = 0;
+        } else if (f_stage[sp] == 1) {
+            f_left[sp] = ret;
+            f_stage[sp] = 2;
+            ++sp;
+            f_off[sp] = off + n2;
+            f_n[sp] = len - n2;
+            f_stage[sp] = 0;
+        } else {
+            ret = f_left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+__global__ __launch_bounds__(128) void closeness_kernel(const double *__restrict__ pts,
+                                                        const int *__restrict__ offsets,
+                                                        const double *__restrict__ cossin,
+                                                        int n_angles, double d0,
+                                                        double *__restrict__ beta) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (a >= n_angles) return;
+    const int b = offsets[c], e = offsets[c + 1];
+    const int n = e - b;
+    BetaCtx B;
+    B.pts = pts + 2 * (size_t)b;
+    B.c = cossin[2 * a];
+    B.s = cossin[2 * a + 1];
+    B.ns = -B.s;
+    B.d0 = d0;
+    double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        const double x = B.pts[2 * (size_t)i], z = B.pts[2 * (size_t)i + 1];
+        const double p0 = fma(z, B.s, x * B.c);
+        const double p1 = fma(z, B.c, x * B.ns);
+        mnx = fmin(mnx, p0);
+        mxx = fmax(mxx, p0);
+        mny = fmin(mny, p1);
+        mxy = fmax(mxy, p1);
+    }
+    B.minx = mnx;
+    B.maxx = mxx;
+    B.miny = mny;
+    B.maxy = mxy;
+    beta[(size_t)c * n_angles + a] = (n > 0) ? pw_sum(B, n) : 0.0;
+}
+
+__global__ void argmax_kernel(const double *__restrict__ beta, int n_clusters, int n_angles,
+                              int *__restrict__ best) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clusters) return;
+    double mx = -INFINITY;
+    int arg = -1;
+    for (int a = 0; a < n_angles; ++a) {
+        const double v = beta[(size_t)c * n_angles + a];
+        if (v > mx) {   // first strict maximum (pointcloud_utils.py:185-187)
+            mx = v;
+            arg = a;
+        }
+    }
+    best[c] = arg;
+}
+
+struct Box6 {
+    double cx, cz, l, w, c, s;
+};
+
+__global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__ pts, int n,
+                                                      const Box6 *__restrict__ boxes,
+                                                      double *__restrict__ out) {
+    const Box6 b = boxes[blockIdx.x];
+    const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
+    double best = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double dx = pts[3 * (size_t)i] - b.cx, dz = pts[3 * (size_t)i + 2] - b.cz;
+        // [dx dz] @ [[c,-s],[s,c]]^T
+        const double q0 = fma(dz, ns, dx * b.c);
+        const double q1 = fma(dz, b.c, dx * b.s);
+        if (q0 > -hl && q0 < hl && q1 > -hw && q1 < hw) best = fmax(best, pts[3 * (size_t)i + 1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+    __shared__ double red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) best = fmax(best, red[k]);
+        out[blockIdx.x] = best;
+    }
+}
+
+}  // namespace
+
+extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
+                                          const int32_t *offsets_host, int n_clusters,
+                                          const double *cossin_host, int n_angles, double d0,
+                                          int32_t *best_angle_host, double *beta_host,
+                                          void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n_clusters >= 0 && n_angles >= 1 && n_angles <= 65536, "bad sizes");
+    if (n_clusters == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts_xz && offsets_host && cossin_host && best_angle_host, "NULL buffer");
+    MODEST_REQUIRE(n_clusters <= 65535, "too many clusters");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t b_off = arena_sz((size_t)(n_clusters + 1) * 4), b_cs = arena_sz((size_t)n_angles * 16);
+    const size_t b_beta = arena_sz((size_t)n_clusters * n_angles * 8), b_best = arena_sz((size_t)n_clusters * 4);
+    int rc = modest_ctx_reserve(ctx, b_off + b_cs + b_beta + b_best);
+    if (rc) return rc;
+    const size_t h_need = b_off + b_cs + b_best + (beta_host ? b_beta : 0);
+    rc = modest_ctx_reserve_pinned(ctx, h_need);
+    if (rc) return rc;
+    int *d_off = reinterpret_cast<int *>(ctx->scratch);
+    double *d_cs = reinterpret_cast<double *>(ctx->scratch + b_off);
+    double *d_beta = reinterpret_cast<double *>(ctx->scratch + b_off + b_cs);
+    int *d_best = reinterpret_cast<int *>(ctx->scratch + b_off + b_cs + b_beta);
+    int *h_off = reinterpret_cast<int *>(ctx->pinned);
+    double *h_cs = reinterpret_cast<double *>(ctx->pinned + b_off);
+    int *h_best = reinterpret_cast<int *>(ctx->pinned + b_off + b_cs);
+    double *h_beta = reinterpret_cast<double *>(ctx->pinned + b_off + b_cs + b_best);
+    for (int i = 0; i <= n_clusters; ++i) {
+        MODEST_REQUIRE(offsets_host[i] >= 0 && (i == 0 || offsets_host[i] >= offsets_host[i - 1]),
+                       "offsets must be non-decreasing");
+        h_off[i] = offsets_host[i];
+    }
+    for (int i = 0; i < 2 * n_angles; ++i) h_cs[i] = cossin_host[i];
+    MODEST_HIP_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(n_clusters + 1) * 4, hipMemcpyHostToDevice, stream));
+    MODEST_HIP_CHECK(hipMemcpyAsync(d_cs, h_cs, (size_t)n_angles * 16, hipMemcpyHostToDevice, stream));
+    dim3 grid((n_angles + 127) / 128, n_clusters);
+    closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
+    argmax_kernel<<<(n_clusters + 63) / 64, 64, 0, stream>>>(d_beta, n_clusters, n_angles, d_best);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_best, d_best, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
+    if (beta_host)
+        MODEST_HIP_CHECK(hipMemcpyAsync(h_beta, d_beta, (size_t)n_clusters * n_angles * 8,
+                                        hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_clusters; ++i) best_angle_host[i] = h_best[i];
+    if (beta_host)
+        for (size_t i = 0; i < (size_t)n_clusters * n_angles; ++i) beta_host[i] = h_beta[i];
+    return MODEST_OK;
+}
+
+extern "C" int modest_lowest_point(modest_ctx *ctx, const double *pts_rect, int n,
+                                   const double *boxes6_host, int n_boxes, double *bottom_host,
+                                   void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0 && n_boxes >= 0, "bad sizes");
+    if (n_boxes == 0) return MODEST_OK;
+    MODEST_REQUIRE(boxes6_host && bottom_host, "NULL buffer");
+    MODEST_REQUIRE(n == 0 || pts_rect, "NULL points");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t b_box = arena_sz((size_t)n_boxes * sizeof(Box6)), b_out = arena_sz((size_t)n_boxes * 8);
+    int rc = modest_ctx_reserve(ctx, b_box + b_out);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, b_box + b_out);
+    if (rc) return rc;
+    Box6 *d_box = reinterpret_cast<Box6 *>(ctx->scratch);
+    double *d_out = reinterpret_cast<double *>(ctx->scratch + b_box);
+    double *h_box = reinterpret_cast<double *>(ctx->pinned);
+    double *h_out = reinterpret_cast<double *>(ctx->pinned + b_box);
+    for (int i = 0; i < 6 * n_boxes; ++i) h_box[i] = boxes6_host[i];
+    MODEST_HIP_CHECK(hipMemcpyAsync(d_box, h_box, (size_t)n_boxes * sizeof(Box6), hipMemcpyHostToDevice, stream));
+    lowest_kernel<<<n_boxes, 1024, 0, stream>>>(pts_rect, n, d_box, d_out);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_boxes * 8, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_boxes; ++i) bottom_host[i] = h_out[i];
+    return MODEST_OK;
+}

@@ -1,0 +1,422 @@
+// PP-weighted mutual-kNN graph + DBSCAN on the implicit graph, for gfx950.
+//
+// Replaces precompute_affinity_matrix(..., 'radius_mutual_knn', 'l1', k, r)
+// (utils/clustering_utils.py:7-60: sklearn kneighbors_graph o transpose o
+// radius_neighbors_graph, then |pp_i - pp_j|) followed by
+// sklearn.cluster.DBSCAN(metric='precomputed', eps, min_samples)
+// (generate_mask.py:75-81).  No sparse matrix is materialised:
+//
+//   r2k(i)    = squared distance from i to its k-th nearest other point
+//               (+inf when fewer than k lie within `radius`)
+//   edge(i,j) = d2(i,j) <= min(r2k(i), r2k(j), radius^2)
+//               and (double)(float)|pp_i - pp_j| <= eps
+//   core(i)   = deg(i) + 1 >= min_samples          (DBSCAN counts the point itself)
+//   cluster   = connected component of the core-core edges, numbered by the
+//               rank of its smallest core index (sklearn's DFS visits points in
+//               index order); a border point takes the smallest cluster id among
+//               its adjacent cores (the first cluster that reaches it); else -1.
+//
+// d2 is the float64 sum dx*dx + dy*dy + dz*dz of float32 coordinates, the value
+// sklearn's KDTree (float64) compares.  Region queries run on a uniform grid
+// with cell edge = radius: one 64-lane wavefront per query point sweeps the 3x3
+// cell rows (contiguous in the cell-sorted array, so loads are coalesced).
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int CG = 128;              // grid is CG x CG cells
+constexpr int CG_CELLS = CG * CG;
+constexpr int WPB = 4;               // wavefronts per block
+constexpr double D_INF = __builtin_huge_val();
+
+struct CGrid {
+    double ox, oy, inv_c;
+};
+
+__device__ __forceinline__ int cg_coord(float v, double o, double inv_c) {
+    double f = floor(((double)v - o) * inv_c);
+    f = fmin(fmax(f, 0.0), (double)(CG - 1));
+    return (int)f;
+}
+
+__global__ __launch_bounds__(1024) void cg_bbox(const float *__restrict__ xyz, int n, double c, CGrid *g) {
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1];
+        mnx = fminf(mnx, x);
+        mxx = fmaxf(mxx, x);
+        mny = fminf(mny, y);
+        mxy = fmaxf(mxy, y);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mny = fminf(mny, __shfl_xor(mny, o));
+        mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+    }
+    __shared__ float s[4][16];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) {
+        s[0][w] = mnx;
+        s[1][w] = mxx;
+        s[2][w] = mny;
+        s[3][w] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) {
+            s[0][0] = fminf(s[0][0], s[0][k]);
+            s[1][0] = fmaxf(s[1][0], s[1][k]);
+            s[2][0] = fminf(s[2][0], s[2][k]);
+            s[3][0] = fmaxf(s[3][0], s[3][k]);
+        }
+        double cx = 0.5 * ((double)s[0][0] + (double)s[1][0]);
+        double cy = 0.5 * ((double)s[2][0] + (double)s[3][0]);
+        if (!(cx == cx) || fabs(cx) > 1e30) cx = 0.0;
+        if (!(cy == cy) || fabs(cy) > 1e30) cy = 0.0;
+        g->ox = cx - 0.5 * CG * c;
+        g->oy = cy - 0.5 * CG * c;
+        g->inv_c = 1.0 / c;
+    }
+}
+
+__global__ void cg_count(const float *__restrict__ xyz, int n, const CGrid *g, unsigned *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cx = cg_coord(xyz[3 * (size_t)i], g->ox, g->inv_c);
+    const int cy = cg_coord(xyz[3 * (size_t)i + 1], g->oy, g->inv_c);
+    atomicAdd(&cnt[cy * CG + cx], 1u);
+}
+
+// exclusive scan of `n` counters into out[0..n] by one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in,
+                                                 unsigned *__restrict__ out, int n) {
+    __shared__ unsigned part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    unsigned s = 0;
+    for (int k = b; k < e; ++k) s += in[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = (tid >= o) ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = part[tid] - s;
+    for (int k = b; k < e; ++k) {
+        const unsigned c = in[k];
+        out[k] = run;
+        run += c;
+    }
+    if (tid == 1023) out[n] = part[1023];
+}
+
+__global__ void cg_scatter(const float *__restrict__ xyz, const float *__restrict__ pp, int n,
+                           const CGrid *g, const unsigned *__restrict__ start, unsigned *fill,
+                           float4 *__restrict__ sorted, int *__restrict__ sidx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    const int cell = cg_coord(y, g->oy, g->inv_c) * CG + cg_coord(x, g->ox, g->inv_c);
+    const unsigned slot = start[cell] + atomicAdd(&fill[cell], 1u);
+    sorted[slot] = make_float4(x, y, z, pp[i]);
+    sidx[slot] = i;
+}
+
+__device__ __forceinline__ double dist2(const float4 &a, const float4 &b) {
+    const double dx = (double)a.x - (double)b.x;
+    const double dy = (double)a.y - (double)b.y;
+    const double dz = (double)a.z - (double)b.z;
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// Sweep helper: the three cell rows around (cx,cy) as contiguous [s,e) ranges.
+struct Rows {
+    unsigned s[3], e[3];
+    int n;
+};
+__device__ __forceinline__ Rows rows_of(const float4 &q, const CGrid *g, const unsigned *__restrict__ start) {
+    const int cx = cg_coord(q.x, g->ox, g->inv_c), cy = cg_coord(q.y, g->oy, g->inv_c);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, CG - 1);
+    Rows r;
+    r.n = 0;
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, CG - 1); ++yy) {
+        r.s[r.n] = start[yy * CG + x0];
+        r.e[r.n] = start[yy * CG + x1 + 1];
+        ++r.n;
+    }
+    return r;
+}
+
+// ---- pass A: k-th neighbour squared distance (wave-level radix select on the
+// float64 bit pattern; distances are recomputed in each of the 8 byte passes) --
+__global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restrict__ sorted, int n,
+                                                           const CGrid *g,
+                                                           const unsigned *__restrict__ start, int k,
+                                                           double r2, double *__restrict__ kthS) {
+    __shared__ unsigned hist_all[WPB][256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;   // whole wave exits together
+    unsigned *hist = hist_all[w];
+    const float4 q = sorted[s];
+    const Rows R = rows_of(q, g, start);
+    unsigned long long prefix = 0, mask = 0;
+    int kk = k - 1;
+    double result = D_INF;
+    bool done = false;
+    for (int shift = 56; shift >= 0 && !done; shift -= 8) {
+        for (int b = lane; b < 256; b += 64) hist[b] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < R.n; ++r)
+            for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+                if ((int)j == s) continue;
+                const double d2 = dist2(q, sorted[j]);
+                if (d2 <= r2) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(d2);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        // lane l owns bins 4l..4l+3
+        const unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2],
+                       c3 = hist[4 * lane + 3];
+        const unsigned mine = c0 + c1 + c2 + c3;
+        unsigned inc = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        const unsigned total = __shfl(inc, 63);
+        if (shift == 56 && total < (unsigned)k) {
+            done = true;   // fewer than k neighbours inside the radius
+            break;
+        }
+        const unsigned long long bal = __ballot(inc > (unsigned)kk);
+        const int owner = __ffsll((long long)bal) - 1;
+        const unsigned excl = __shfl(inc - mine, owner);
+        const unsigned o0 = __shfl(c0, owner), o1 = __shfl(c1, owner), o2 = __shfl(c2, owner);
+        int rem = kk - (int)excl;
+        int bin = 4 * owner;
+        if (rem >= (int)o0) {
+            rem -= o0;
+            ++bin;
+            if (rem >= (int)o1) {
+                rem -= o1;
+                ++bin;
+                if (rem >= (int)o2) {
+                    rem -= o2;
+                    ++bin;
+                }
+            }
+        }
+        kk = rem;
+        prefix |= (unsigned long long)bin << shift;
+        mask |= 255ULL << shift;
+        if (shift == 0) result = __longlong_as_double((long long)prefix);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) kthS[s] = result;
+}
+
+__device__ __forceinline__ bool edge_ok(const float4 &q, double kq, const float4 &c, double kc, double r2,
+                                        double eps) {
+    const double d2 = dist2(q, c);
+    const double lim = fmin(fmin(kq, kc), r2);
+    if (!(d2 <= lim)) return false;
+    const float w = fabsf(q.w - c.w);
+    return (double)w <= eps;
+}
+
+// ---- pass B: degrees / core flags ------------------------------------------------
+__global__ __launch_bounds__(64 * WPB) void degree_kernel(const float4 *__restrict__ sorted, int n,
+                                                          const CGrid *g,
+                                                          const unsigned *__restrict__ start,
+                                                          const double *__restrict__ kthS, double r2,
+                                                          double eps, int min_samples,
+                                                          unsigned char *__restrict__ coreS) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    const float4 q = sorted[s];
+    const double kq = kthS[s];
+    const Rows R = rows_of(q, g, start);
+    unsigned cnt = 0;
+    for (int r = 0; r < R.n; ++r)
+        for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+            if ((int)j == s) continue;
+            if (edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) ++cnt;
+        }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) coreS[s] = ((int)cnt + 1 >= min_samples) ? 1 : 0;
+}
+
+// ---- pass C: union-find over core-core edges (root = smallest original index) ----
+__device__ __forceinline__ int uf_load(int *p, int i) {
+    return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(int *parent, int x) {
+    int p = uf_load(parent, x);
+    while (p != x) {
+        x = p;
+        p = uf_load(parent, x);
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_unite(int *parent, int a, int b) {
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        // a < b: hang root b under a
+        const int old = atomicCAS(parent + b, b, a);
+        if (old == b) return;
+    }
+}
+
+__global__ void uf_init(int *parent, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = i;
+}
+
+__global__ __launch_bounds__(64 * WPB) void union_kernel(const float4 *__restrict__ sorted, int n,
+                                                         const CGrid *g,
+                                                         const unsigned *__restrict__ start,
+                                                         const double *__restrict__ kthS,
+                                                         const unsigned char *__restrict__ coreS,
+                                                         const int *__restrict__ sidx, double r2,
+                                                         double eps, int *parent) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    if (!coreS[s]) return;
+    const float4 q = sorted[s];
+    const double kq = kthS[s];
+    const int me = sidx[s];
+    const Rows R = rows_of(q, g, start);
+    for (int r = 0; r < R.n; ++r)
+        for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+            if ((int)j <= s) continue;          // each unordered pair once
+            if (!coreS[j]) continue;
+            if (edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) uf_unite(parent, me, sidx[j]);
+        }
+}
+
+__global__ void compress_kernel(int *parent, const unsigned char *__restrict__ coreS,
+                                const int *__restrict__ sidx, int n, int *__restrict__ root,
+                                unsigned *__restrict__ isroot) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = sidx[s];
+    const int r = uf_find(parent, i);
+    root[i] = r;
+    isroot[i] = (coreS[s] && r == i) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restrict__ sorted, int n,
+                                                         const CGrid *g,
+                                                         const unsigned *__restrict__ start,
+                                                         const double *__restrict__ kthS,
+                                                         const unsigned char *__restrict__ coreS,
+                                                         const int *__restrict__ sidx,
+                                                         const int *__restrict__ root,
+                                                         const unsigned *__restrict__ rank, double r2,
+                                                         double eps, int *__restrict__ labels) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    const int me = sidx[s];
+    if (coreS[s]) {
+        if (lane == 0) labels[me] = (int)rank[root[me]];
+        return;
+    }
+    const float4 q = sorted[s];
+    const double kq = kthS[s];
+    const Rows R = rows_of(q, g, start);
+    int best = 0x7fffffff;
+    for (int r = 0; r < R.n; ++r)
+        for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+            if ((int)j == s || !coreS[j]) continue;
+            if (edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) best = min(best, root[sidx[j]]);
+        }
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if (lane == 0) labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
+}
+
+__global__ void scatter_kth(const double *__restrict__ kthS, const int *__restrict__ sidx, int n,
+                            double *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) out[sidx[s]] = kthS[s];
+}
+
+}  // namespace
+
+extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const float *pp, int n,
+                                     int k_neighbors, double radius, double eps, int min_samples,
+                                     int32_t *labels, double *kth_d2, int32_t *n_clusters,
+                                     void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0, "n < 0");
+    MODEST_REQUIRE(k_neighbors >= 1 && radius > 0.0 && min_samples >= 1, "bad parameters");
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(xyz && pp && labels, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+
+    const size_t zero_words = (size_t)2 * CG_CELLS;
+    size_t need = arena_sz(sizeof(CGrid)) + arena_sz(zero_words * 4) + arena_sz((CG_CELLS + 1) * 4) +
+                  arena_sz((size_t)n * 16) + arena_sz((size_t)n * 4) + arena_sz((size_t)n * 8) +
+                  arena_sz((size_t)n) + arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4);
+    int rc = modest_ctx_reserve(ctx, need);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, 64);
+    if (rc) return rc;
+    Arena A(ctx->scratch);
+    CGrid *g = A.take<CGrid>(1);
+    unsigned *zeroed = A.take<unsigned>(zero_words);
+    unsigned *cnt = zeroed, *fill = zeroed + CG_CELLS;
+    unsigned *start = A.take<unsigned>(CG_CELLS + 1);
+    float4 *sorted = A.take<float4>(n);
+    int *sidx = A.take<int>(n);
+    double *kthS = A.take<double>(n);
+    unsigned char *coreS = A.take<unsigned char>(n);
+    int *parent = A.take<int>(n);
+    int *root = A.take<int>(n);
+    unsigned *isroot = A.take<unsigned>(n);
+    unsigned *rank = A.take<unsigned>(n + 1);
+
+    const double c = radius * (1.0 + 1.0 / 1024.0);
+    const double r2 = radius * radius;
+    const int nb = (n + 255) / 256, nw = (n + WPB - 1) / WPB;
+    MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
+    cg_bbox<<<1, 1024, 0, stream>>>(xyz, n, c, g);
+    cg_count<<<nb, 256, 0, stream>>>(xyz, n, g, cnt);
+    scan_u32<<<1, 1024, 0, stream>>>(cnt, start, CG_CELLS);
+    cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, start, fill, sorted, sidx);
+    knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
+    degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS);
+    uf_init<<<nb, 256, 0, stream>>>(parent, n);
+    union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
+    compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
+    scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
+    label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, r2, eps,
+                                             labels);
+    if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
+    MODEST_HIP_CHECK(hipGetLastError());
+    if (n_clusters) {
+        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        *n_clusters = (int32_t) * reinterpret_cast<unsigned *>(ctx->pinned);
+    }
+    return MODEST_OK;
+}

@@ -1,0 +1,443 @@
+// Ground-plane stage for gfx950: estimate_plane's candidate selection and the
+// RANSAC inner loops (utils/pointcloud_utils.py:44-65 -> sklearn
+// RANSACRegressor defaults: residual threshold = MAD(z), inliers = |z - pred|
+// <= thr, all float32), the final least-squares refit, and above_plane +
+// range mask (pointcloud_utils.py:68-81, generate_mask.py:57-65).
+//
+// The sequential accept rule and the random triplets stay on the host (they
+// are a few dozen scalar decisions); every O(N) or O(N*trials) loop is here,
+// with deterministic (fixed-order) reductions.
+#include "common.h"
+#include "compact.h"
+#include <cmath>
+#include <vector>
+
+using namespace modest;
+
+namespace {
+
+// ---- candidate selection -----------------------------------------------------
+__global__ __launch_bounds__(1024) void candidates_kernel(const float *__restrict__ pts, int n,
+                                                          int stride, float max_hs, float xlo,
+                                                          float xhi, float ylo, float yhi,
+                                                          float *__restrict__ cand,
+                                                          int *__restrict__ cand_idx,
+                                                          unsigned long long *state, int *n_cand) {
+    const unsigned blk = compact_ticket(state);
+    const long long i = (long long)blk * 1024 + threadIdx.x;
+    bool keep = false;
+    float x = 0, y = 0, z = 0;
+    if (i < n) {
+        const float *p = pts + i * stride;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+        keep = (z < max_hs) && (x > xlo) && (x < xhi) && (y > ylo) && (y < yhi);
+    }
+    const unsigned long long dst = compact_offset(keep, blk, gridDim.x, state, n_cand);
+    if (keep) {
+        cand[3 * dst + 0] = x;
+        cand[3 * dst + 1] = y;
+        cand[3 * dst + 2] = z;
+        if (cand_idx) cand_idx[dst] = (int)i;
+    }
+}
+
+// ---- exact k-th smallest of float32 values (radix select, one workgroup) -----
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// value(i) = MODE==0 ? z_i : |z_i - center|  (float32 arithmetic)
+template <int MODE>
+__device__ float select_kth(const float *__restrict__ cand, int n, int k, float center,
+                            unsigned *hist /* 256 LDS words */) {
+    unsigned prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            float v = cand[3 * (size_t)i + 2];
+            if (MODE == 1) v = fabsf(v - center);
+            const unsigned key = f2key(v);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // every thread walks the 256 bins identically (uniform result, no extra sync needed)
+        int acc = 0, bin = 0;
+        for (; bin < 256; ++bin) {
+            const int c = (int)hist[bin];
+            if (acc + c > k) break;
+            acc += c;
+        }
+        k -= acc;
+        prefix |= (unsigned)bin << shift;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    return key2f(prefix);
+}
+
+template <int MODE>
+__device__ float median_np(const float *cand, int n, float center, unsigned *hist) {
+    // numpy.median: odd -> middle element; even -> float32 mean of the two middle ones
+    if (n & 1) return select_kth<MODE>(cand, n, n / 2, center, hist);
+    const float a = select_kth<MODE>(cand, n, n / 2 - 1, center, hist);
+    const float b = select_kth<MODE>(cand, n, n / 2, center, hist);
+    return (a + b) / 2.0f;
+}
+
+__global__ __launch_bounds__(1024) void mad_kernel(const float *__restrict__ cand, int n,
+                                                   float *out /* [median, mad] */) {
+    __shared__ unsigned hist[256];
+    const float med = median_np<0>(cand, n, 0.f, hist);
+    const float mad = median_np<1>(cand, n, med, hist);
+    if (threadIdx.x == 0) {
+        out[0] = med;
+        out[1] = mad;
+    }
+}
+
+// ---- trial scoring -------------------------------------------------------------
+constexpr int SCORE_THREADS = 256;
+constexpr int SCORE_WAVES = SCORE_THREADS / 64;
+
+__device__ __forceinline__ float plane_pred(float x, float y, float c0, float c1, float b) {
+    // float32 X @ coef + intercept as the BLAS gemv rounds it: fma chain, then add
+    return fmaf(y, c1, x * c0) + b;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// partial[(blk*K + k)*4 + {0:count,1:sse,2:sy,3:syy}]
+__global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
+                                                              const float *__restrict__ models,
+                                                              int K, float thr,
+                                                              double *__restrict__ partial) {
+    __shared__ double red[SCORE_WAVES][4];
+    const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
+    const bool valid = i < n;
+    float x = 0, y = 0, z = 0;
+    if (valid) {
+        x = cand[3 * (size_t)i];
+        y = cand[3 * (size_t)i + 1];
+        z = cand[3 * (size_t)i + 2];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        const float c0 = models[3 * k], c1 = models[3 * k + 1], b = models[3 * k + 2];
+        const float res = fabsf(z - plane_pred(x, y, c0, c1, b));
+        const bool in = valid && (res <= thr);
+        const double r = in ? (double)res : 0.0, zz = in ? (double)z : 0.0;
+        const double cnt = wave_sum(in ? 1.0 : 0.0);
+        const double sse = wave_sum(r * r);
+        const double sy = wave_sum(zz);
+        const double syy = wave_sum(zz * zz);
+        if (lane == 0) {
+            red[w][0] = cnt;
+            red[w][1] = sse;
+            red[w][2] = sy;
+            red[w][3] = syy;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double s = 0.0;
+            for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][threadIdx.x];
+            partial[((size_t)blockIdx.x * K + k) * 4 + threadIdx.x] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void score_reduce_kernel(const double *__restrict__ partial, int nblocks, int K,
+                                    double *__restrict__ out /* K*4 */) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= K * 4) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * K * 4 + id];
+    out[id] = s;
+}
+
+// ---- refit ---------------------------------------------------------------------
+// pass 0: count, sum x, sum y, sum z over inliers; pass 1: centred 2nd moments
+// Sxx, Sxy, Syy, Sxz, Syz given the means.
+template <int PASS>
+__global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n,
+                                                              float c0, float c1, float b, float thr,
+                                                              const double *__restrict__ means,
+                                                              double *__restrict__ partial) {
+    constexpr int NV = PASS == 0 ? 4 : 5;
+    __shared__ double red[SCORE_WAVES][5];
+    const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
+    double v[5] = {0, 0, 0, 0, 0};
+    if (i < n) {
+        const float x = cand[3 * (size_t)i], y = cand[3 * (size_t)i + 1], z = cand[3 * (size_t)i + 2];
+        if (fabsf(z - plane_pred(x, y, c0, c1, b)) <= thr) {
+            if (PASS == 0) {
+                v[0] = 1.0;
+                v[1] = x;
+                v[2] = y;
+                v[3] = z;
+            } else {
+                const double dx = (double)x - means[0], dy = (double)y - means[1], dz = (double)z - means[2];
+                v[0] = dx * dx;
+                v[1] = dx * dy;
+                v[2] = dy * dy;
+                v[3] = dx * dz;
+                v[4] = dy * dz;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const double s = wave_sum(v[q]);
+        if (lane == 0) red[w][q] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        double s = 0.0;
+        for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][threadIdx.x];
+        partial[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
+    }
+}
+
+__global__ void refit_reduce_kernel(const double *__restrict__ partial, int nblocks, int pass,
+                                    double *__restrict__ acc /* [0..3] sums, [4..6] means, [8..12] moments */) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (pass == 0) {
+        double s[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nblocks; ++b)
+            for (int q = 0; q < 4; ++q) s[q] += partial[(size_t)b * 5 + q];
+        for (int q = 0; q < 4; ++q) acc[q] = s[q];
+        const double inv = s[0] > 0 ? 1.0 / s[0] : 0.0;
+        acc[4] = s[1] * inv;
+        acc[5] = s[2] * inv;
+        acc[6] = s[3] * inv;
+    } else {
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nblocks; ++b)
+            for (int q = 0; q < 5; ++q) s[q] += partial[(size_t)b * 5 + q];
+        for (int q = 0; q < 5; ++q) acc[8 + q] = s[q];
+    }
+}
+
+// ---- above_plane + range mask ----------------------------------------------------
+struct MaskParams {
+    double n0, n1, n2, d, norm, offset;
+    // range bounds are compared in float32, as numpy compares a float32 array
+    // with Python scalars (weak-scalar promotion)
+    float ox0, ox1, oy0, oy1;   // only_range (strict)
+    float lx0, lx1, ly0, ly1;   // limit_range (lo, hi]
+    int use_only_range;
+};
+
+__global__ __launch_bounds__(1024) void mask_kernel(const float *__restrict__ pts, int n, int stride,
+                                                    MaskParams P, unsigned char *__restrict__ mask,
+                                                    float *__restrict__ kept, int *__restrict__ kept_idx,
+                                                    unsigned long long *state, int *n_kept) {
+    const unsigned blk = compact_ticket(state);
+    const long long i = (long long)blk * 1024 + threadIdx.x;
+    bool keep = false;
+    float x = 0, y = 0, z = 0;
+    if (i < n) {
+        const float *p = pts + i * stride;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+        // ptc @ plane[:3] + plane[3], float64: x*n0, fma(y,n1,.), fma(z,n2,.), then + d, then / norm
+        double dist = (double)x * P.n0;
+        dist = fma((double)y, P.n1, dist);
+        dist = fma((double)z, P.n2, dist);
+        dist = dist + P.d;
+        dist = dist / P.norm;
+        bool below = dist < P.offset;
+        if (P.use_only_range)
+            below = below && (x < P.ox1) && (x > P.ox0) && (y < P.oy1) && (y > P.oy0);
+        const bool range = (x <= P.lx1) && (x > P.lx0) && (y <= P.ly1) && (y > P.ly0);
+        keep = (!below) && range;
+        mask[i] = keep ? 1 : 0;
+    }
+    const unsigned long long dst = compact_offset(keep, blk, gridDim.x, state, n_kept);
+    if (keep && kept) {
+        kept[3 * dst + 0] = x;
+        kept[3 * dst + 1] = y;
+        kept[3 * dst + 2] = z;
+        if (kept_idx) kept_idx[dst] = (int)i;
+    }
+}
+
+}  // namespace
+
+extern "C" int modest_plane_candidates(modest_ctx *ctx, const float *pts, int n, int stride,
+                                       float max_hs, float xlo, float xhi, float ylo, float yhi,
+                                       float *cand, int32_t *cand_idx, int32_t *n_cand,
+                                       void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0 && (stride == 3 || stride == 4), "bad n/stride");
+    MODEST_REQUIRE(n_cand != nullptr, "n_cand is NULL");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    MODEST_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(int32_t), stream));
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts && cand, "NULL buffer");
+    int rc = modest_ctx_reserve(ctx, 256);
+    if (rc) return rc;
+    unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
+    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, 16, stream));
+    candidates_kernel<<<(n + 1023) / 1024, 1024, 0, stream>>>(pts, n, stride, max_hs, xlo, xhi, ylo, yhi,
+                                                             cand, cand_idx, state, n_cand);
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
+
+extern "C" int modest_mad_threshold(modest_ctx *ctx, const float *cand, int n_cand, float *mad_host,
+                                    void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && mad_host != nullptr, "NULL argument");
+    MODEST_REQUIRE(n_cand >= 1, "need at least one candidate");
+    MODEST_REQUIRE(cand != nullptr, "cand is NULL");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = modest_ctx_reserve(ctx, 256);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, 64);
+    if (rc) return rc;
+    float *d = reinterpret_cast<float *>(ctx->scratch);
+    mad_kernel<<<1, 1024, 0, stream>>>(cand, n_cand, d);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, d, 8, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    *mad_host = reinterpret_cast<float *>(ctx->pinned)[1];
+    return MODEST_OK;
+}
+
+extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, int n_cand,
+                                          const float *models_host, int K, float thr,
+                                          int32_t *n_inliers, double *sse, double *sy, double *syy,
+                                          void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n_cand >= 1 && K >= 1 && K <= 4096, "bad n_cand / K");
+    MODEST_REQUIRE(cand && models_host && n_inliers, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
+    const size_t b_models = arena_sz((size_t)K * 12), b_part = arena_sz((size_t)nb * K * 32);
+    const size_t b_out = arena_sz((size_t)K * 32);
+    int rc = modest_ctx_reserve(ctx, b_models + b_part + b_out);
+    if (rc) return rc;
+    const size_t hoff = ((size_t)K * 12 + 63) & ~size_t(63);
+    rc = modest_ctx_reserve_pinned(ctx, hoff + (size_t)K * 32);
+    if (rc) return rc;
+    float *dm = reinterpret_cast<float *>(ctx->scratch);
+    double *dp = reinterpret_cast<double *>(ctx->scratch + b_models);
+    double *dout = reinterpret_cast<double *>(ctx->scratch + b_models + b_part);
+    float *hm = reinterpret_cast<float *>(ctx->pinned);
+    double *hout = reinterpret_cast<double *>(ctx->pinned + hoff);
+    for (int i = 0; i < K * 3; ++i) hm[i] = models_host[i];
+    MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12, hipMemcpyHostToDevice, stream));
+    score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K, thr, dp);
+    score_reduce_kernel<<<(K * 4 + 255) / 256, 256, 0, stream>>>(dp, nb, K, dout);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int k = 0; k < K; ++k) {
+        n_inliers[k] = (int32_t)hout[4 * k];
+        if (sse) sse[k] = hout[4 * k + 1];
+        if (sy) sy[k] = hout[4 * k + 2];
+        if (syy) syy[k] = hout[4 * k + 3];
+    }
+    return MODEST_OK;
+}
+
+extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_cand,
+                                   const float *model_host, float thr, double *out_model,
+                                   int32_t *n_inliers, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n_cand >= 1, "bad n_cand");
+    MODEST_REQUIRE(cand && model_host && out_model, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
+    const size_t b_part = arena_sz((size_t)nb * 40), b_acc = arena_sz(16 * 8);
+    int rc = modest_ctx_reserve(ctx, b_part + b_acc);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, 16 * 8);
+    if (rc) return rc;
+    double *dp = reinterpret_cast<double *>(ctx->scratch);
+    double *acc = reinterpret_cast<double *>(ctx->scratch + b_part);
+    const float c0 = model_host[0], c1 = model_host[1], b = model_host[2];
+    refit_kernel<0><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, nullptr, dp);
+    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 0, acc);
+    refit_kernel<1><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, acc + 4, dp);
+    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 1, acc);
+    MODEST_HIP_CHECK(hipGetLastError());
+    double *h = reinterpret_cast<double *>(ctx->pinned);
+    MODEST_HIP_CHECK(hipMemcpyAsync(h, acc, 16 * 8, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    const double cnt = h[0], mx = h[4], my = h[5], mz = h[6];
+    const double sxx = h[8], sxy = h[9], syy = h[10], sxz = h[11], syz = h[12];
+    if (n_inliers) *n_inliers = (int32_t)cnt;
+    const double det = sxx * syy - sxy * sxy;
+    if (!(cnt >= 3.0) || !(fabs(det) > 0.0)) {
+        modest_set_error("modest_ransac_refit: degenerate inlier set (n=%d)", (int)cnt);
+        return MODEST_ERR_ARG;
+    }
+    const double a0 = (sxz * syy - syz * sxy) / det;
+    const double a1 = (syz * sxx - sxz * sxy) / det;
+    out_model[0] = a0;
+    out_model[1] = a1;
+    out_model[2] = mz - a0 * mx - a1 * my;
+    return MODEST_OK;
+}
+
+extern "C" int modest_plane_range_mask(modest_ctx *ctx, const float *pts, int n, int stride,
+                                       const double *plane4, double offset,
+                                       const double *only_range4, const double *limit_range4,
+                                       uint8_t *mask, float *kept, int32_t *kept_idx,
+                                       int32_t *n_kept, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0 && (stride == 3 || stride == 4), "bad n/stride");
+    MODEST_REQUIRE(plane4 && limit_range4 && n_kept, "NULL argument");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    MODEST_HIP_CHECK(hipMemsetAsync(n_kept, 0, sizeof(int32_t), stream));
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts && mask, "NULL buffer");
+    MaskParams P;
+    P.n0 = plane4[0];
+    P.n1 = plane4[1];
+    P.n2 = plane4[2];
+    P.d = plane4[3];
+    // np.sqrt((plane[:3]**2).sum()): squares summed left to right (n < 8 -> sequential)
+    P.norm = sqrt((plane4[0] * plane4[0] + plane4[1] * plane4[1]) + plane4[2] * plane4[2]);
+    P.offset = offset;
+    P.use_only_range = only_range4 != nullptr;
+    if (only_range4) {
+        P.ox0 = (float)only_range4[0];
+        P.ox1 = (float)only_range4[1];
+        P.oy0 = (float)only_range4[2];
+        P.oy1 = (float)only_range4[3];
+    } else {
+        P.ox0 = P.ox1 = P.oy0 = P.oy1 = 0;
+    }
+    P.lx0 = (float)limit_range4[0];
+    P.lx1 = (float)limit_range4[1];
+    P.ly0 = (float)limit_range4[2];
+    P.ly1 = (float)limit_range4[3];
+    int rc = modest_ctx_reserve(ctx, 256);
+    if (rc) return rc;
+    unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
+    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, 16, stream));
+    mask_kernel<<<(n + 1023) / 1024, 1024, 0, stream>>>(pts, n, stride, P, mask, kept, kept_idx, state,
+                                                       n_kept);
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}

@@ -261,8 +261,8 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
         *extra = ctx->scratch + need;
         if (!counts) counts = static_cast<int32_t *>(*extra);
     }
-    MODEST_REQUIRE(counts != nullptr, "counts is NULL");
     if (n_live == 0) return MODEST_OK;
+    MODEST_REQUIRE(counts != nullptr, "counts is NULL");
     MODEST_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n_live * n_trav * sizeof(int32_t), stream));
     const long long m0 = tr.off[0], m1 = tr.off[n_trav];
     if (m1 == m0) return MODEST_OK;
@@ -302,7 +302,7 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
 extern "C" int modest_pp_count(modest_ctx *ctx, const float *live, int n_live, const float *hist,
                                const int64_t *trav_offsets, int n_trav, double radius,
                                int32_t *counts, void *stream_) {
-    MODEST_REQUIRE(counts != nullptr, "counts is NULL");
+    MODEST_REQUIRE(counts != nullptr || n_live == 0, "counts is NULL");
     return pp_count_impl(ctx, live, n_live, hist, trav_offsets, n_trav, radius, counts, stream_, 0,
                          nullptr);
 }

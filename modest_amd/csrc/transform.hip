@@ -1,0 +1,138 @@
+// transform_points (utils/pointcloud_utils.py:11-19) + remove_center
+// (pre_compute_pp_score.py:48-52) for gfx950: raw KITTI frames stay resident
+// in HBM as (n,4) float32 and are transformed into the common frame on the fly.
+//
+// Arithmetic contract (pinned by tests/golden/transform.npz): the reference's
+// float32 BLAS product [x y z 1] . T^T rounds as
+//     acc = x*T[r][0]; acc = fmaf(y,T[r][1],acc); acc = fmaf(z,T[r][2],acc);
+//     out = acc + T[r][3]
+// (the trailing 1*T[r][3] is an exact product, so that last fma is an add).
+#include "common.h"
+
+namespace {
+
+struct Mat34 {
+    float m[12];
+};
+
+__device__ __forceinline__ bool in_center(float x, float y) {
+    return (x < 1.75f) && (x >= -1.15f) && (y < 0.65f) && (y >= -0.65f);
+}
+
+__device__ __forceinline__ void apply(const Mat34 &T, float x, float y, float z, float *o) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float acc = x * T.m[4 * r + 0];
+        acc = fmaf(y, T.m[4 * r + 1], acc);
+        acc = fmaf(z, T.m[4 * r + 2], acc);
+        o[r] = acc + T.m[4 * r + 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void transform_kernel(const float *__restrict__ in, long long n,
+                                                        int stride, Mat34 T,
+                                                        float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float *p = in + i * stride;
+        float o[3];
+        apply(T, p[0], p[1], p[2], o);
+        out[3 * i + 0] = o[0];
+        out[3 * i + 1] = o[1];
+        out[3 * i + 2] = o[2];
+    }
+}
+
+// Order-preserving compaction (np boolean-mask semantics): per-block ballot
+// prefix + a chained global offset.  A block takes its LOGICAL index from a
+// ticket counter when it starts, so it only ever waits on blocks that are
+// already running: no assumption about dispatch order or residency.
+__global__ __launch_bounds__(1024) void transform_filter_kernel(const float *__restrict__ in,
+                                                                long long n, int stride, Mat34 T,
+                                                                float *__restrict__ out,
+                                                                unsigned long long *state,
+                                                                long long *n_out) {
+    __shared__ unsigned wave_cnt[16];
+    __shared__ unsigned long long base_s;
+    __shared__ unsigned ticket_s;
+    if (threadIdx.x == 0) ticket_s = atomicAdd(reinterpret_cast<unsigned *>(state + 1), 1u);
+    __syncthreads();
+    const unsigned blk = ticket_s;
+    const long long i = (long long)blk * 1024 + threadIdx.x;
+    bool keep = false;
+    float x = 0, y = 0, z = 0;
+    if (i < n) {
+        const float *p = in + i * stride;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+        keep = !in_center(x, y);
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned before = __popcll(bal & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wave_cnt[w] = __popcll(bal);
+    __syncthreads();
+    unsigned woff = 0, total = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w) woff += wave_cnt[k];
+        total += wave_cnt[k];
+    }
+    if (threadIdx.x == 0) {
+        // state = (#blocks published << 40) | running total ; blocks publish in index order
+        unsigned long long s;
+        do {
+            s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((s >> 40) != (unsigned long long)blk) __builtin_amdgcn_s_sleep(2);
+        } while ((s >> 40) != (unsigned long long)blk);
+        base_s = s & ((1ULL << 40) - 1ULL);
+        const unsigned long long ns = ((unsigned long long)(blk + 1) << 40) | (base_s + total);
+        __hip_atomic_store(state, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blk == gridDim.x - 1 && n_out) *n_out = (long long)(base_s + total);
+    }
+    __syncthreads();
+    if (keep) {
+        float o[3];
+        apply(T, x, y, z, o);
+        const unsigned long long dst = base_s + woff + before;
+        out[3 * dst + 0] = o[0];
+        out[3 * dst + 1] = o[1];
+        out[3 * dst + 2] = o[2];
+    }
+}
+
+}  // namespace
+
+extern "C" int modest_transform_points(modest_ctx *ctx, const float *in, int64_t n, int in_stride,
+                                       const float *T16, int remove_center, float *out,
+                                       int64_t *n_out, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0, "n < 0");
+    MODEST_REQUIRE(in_stride == 3 || in_stride == 4, "in_stride must be 3 or 4");
+    MODEST_REQUIRE(T16 != nullptr, "T16 is NULL");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    Mat34 T;
+    for (int k = 0; k < 12; ++k) T.m[k] = T16[k];
+    if (n == 0) {
+        if (remove_center && n_out) MODEST_HIP_CHECK(hipMemsetAsync(n_out, 0, sizeof(int64_t), stream));
+        return MODEST_OK;
+    }
+    MODEST_REQUIRE(in != nullptr && out != nullptr, "NULL point buffer");
+    if (!remove_center) {
+        long long blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        transform_kernel<<<(int)blocks, 256, 0, stream>>>(in, n, in_stride, T, out);
+    } else {
+        int rc = modest_ctx_reserve(ctx, 256);
+        if (rc) return rc;
+        unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
+        MODEST_HIP_CHECK(hipMemsetAsync(state, 0, 16, stream));  // [0] chain word, [1] ticket
+        const long long blocks = (n + 1023) / 1024;
+        MODEST_REQUIRE(blocks < (1 << 23), "frame too large for remove_center path");
+        transform_filter_kernel<<<(int)blocks, 1024, 0, stream>>>(in, n, in_stride, T, out, state,
+                                                                  reinterpret_cast<long long *>(n_out));
+    }
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
