@@ -87,3 +87,181 @@ def pp_score(live_xyz: torch.Tensor, hist_xyz: torch.Tensor, trav_offsets: Seque
                               float(radius), counts.data_ptr() if counts is not None else None,
                               H.data_ptr(), _stream()), "modest_pp_score")
     return (H, counts) if return_counts else H
+
+
+# --------------------------------------------------------------------------- transform
+def transform_points(pts: torch.Tensor, T: np.ndarray, remove_center: bool = False,
+                     ctx: Optional[Context] = None) -> torch.Tensor:
+    """transform_points (utils/pointcloud_utils.py:11-19) of an (n,3|4) float32 frame,
+    optionally preceded by remove_center (pre_compute_pp_score.py:48-52)."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    assert pts.ndim == 2 and pts.shape[1] in (3, 4)
+    n = pts.shape[0]
+    T16 = np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4))
+    out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    c = _ctx(ctx, pts)
+    if not remove_center:
+        check(lib.modest_transform_points(c.handle, pts.data_ptr(), n, pts.shape[1], _np_ptr(T16), 0,
+                                          out.data_ptr(), None, _stream()), "modest_transform_points")
+        return out
+    n_out = torch.zeros((1,), dtype=torch.int64, device=pts.device)
+    check(lib.modest_transform_points(c.handle, pts.data_ptr(), n, pts.shape[1], _np_ptr(T16), 1,
+                                      out.data_ptr(), n_out.data_ptr(), _stream()), "modest_transform_points")
+    return out[: int(n_out.item())]
+
+
+# --------------------------------------------------------------------------- plane / RANSAC
+def plane_candidates(pts: torch.Tensor, max_hs: float, ptc_range, ctx: Optional[Context] = None):
+    """Candidate mask of estimate_plane (pointcloud_utils.py:45-49), compacted in input order.
+    Returns (cand_xyz (m,3) f32, cand_idx (m,) i32)."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    n = pts.shape[0]
+    cand = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    idx = torch.empty((n,), dtype=torch.int32, device=pts.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=pts.device)
+    c = _ctx(ctx, pts)
+    (xlo, xhi), (ylo, yhi) = ptc_range
+    check(lib.modest_plane_candidates(c.handle, pts.data_ptr(), n, pts.shape[1], float(max_hs), float(xlo),
+                                      float(xhi), float(ylo), float(yhi), cand.data_ptr(), idx.data_ptr(),
+                                      cnt.data_ptr(), _stream()), "modest_plane_candidates")
+    m = int(cnt.item())
+    return cand[:m], idx[:m]
+
+
+def mad_threshold(cand: torch.Tensor, ctx: Optional[Context] = None) -> np.float32:
+    lib = load()
+    _dev(cand, torch.float32, "cand")
+    out = C.c_float(0)
+    c = _ctx(ctx, cand)
+    check(lib.modest_mad_threshold(c.handle, cand.data_ptr(), cand.shape[0], C.byref(out), _stream()),
+          "modest_mad_threshold")
+    return np.float32(out.value)
+
+
+def ransac_score_trials(cand: torch.Tensor, models: np.ndarray, thr: float, ctx: Optional[Context] = None):
+    """Inlier counts (+ SSE / sum z / sum z^2 over the inliers, float64) of K trial planes."""
+    lib = load()
+    _dev(cand, torch.float32, "cand")
+    models = np.ascontiguousarray(models, dtype=np.float32).reshape(-1, 3)
+    K = models.shape[0]
+    n_in = np.zeros(K, dtype=np.int32)
+    sse, sy, syy = (np.zeros(K, dtype=np.float64) for _ in range(3))
+    c = _ctx(ctx, cand)
+    check(lib.modest_ransac_score_trials(c.handle, cand.data_ptr(), cand.shape[0], _np_ptr(models), K,
+                                         float(np.float32(thr)), _np_ptr(n_in), _np_ptr(sse), _np_ptr(sy),
+                                         _np_ptr(syy), _stream()), "modest_ransac_score_trials")
+    return n_in, sse, sy, syy
+
+
+def ransac_refit(cand: torch.Tensor, model: np.ndarray, thr: float, ctx: Optional[Context] = None):
+    lib = load()
+    _dev(cand, torch.float32, "cand")
+    model = np.ascontiguousarray(model, dtype=np.float32).reshape(3)
+    out = np.zeros(3, dtype=np.float64)
+    n_in = C.c_int32(0)
+    c = _ctx(ctx, cand)
+    check(lib.modest_ransac_refit(c.handle, cand.data_ptr(), cand.shape[0], _np_ptr(model),
+                                  float(np.float32(thr)), _np_ptr(out), C.byref(n_in), _stream()),
+          "modest_ransac_refit")
+    return out, int(n_in.value)
+
+
+def plane_range_mask(pts: torch.Tensor, plane: np.ndarray, offset: float, only_range, limit_range,
+                     ctx: Optional[Context] = None):
+    """above_plane (pointcloud_utils.py:68-74) AND the limit_range mask (generate_mask.py:61-65).
+    Returns (mask (n,) bool device, kept_xyz (m,3) f32, kept_idx (m,) i32)."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    n = pts.shape[0]
+    plane = np.ascontiguousarray(plane, dtype=np.float64).reshape(4)
+    lim = np.ascontiguousarray(np.asarray(limit_range, dtype=np.float64).reshape(4))
+    onl = None if only_range is None else np.ascontiguousarray(np.asarray(only_range, dtype=np.float64).reshape(4))
+    mask = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+    kept = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    idx = torch.empty((n,), dtype=torch.int32, device=pts.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=pts.device)
+    c = _ctx(ctx, pts)
+    check(lib.modest_plane_range_mask(c.handle, pts.data_ptr(), n, pts.shape[1], _np_ptr(plane), float(offset),
+                                      None if onl is None else _np_ptr(onl), _np_ptr(lim), mask.data_ptr(),
+                                      kept.data_ptr(), idx.data_ptr(), cnt.data_ptr(), _stream()),
+          "modest_plane_range_mask")
+    m = int(cnt.item())
+    return mask.bool(), kept[:m], idx[:m]
+
+
+# --------------------------------------------------------------------------- clustering
+def cluster_dbscan(xyz: torch.Tensor, pp: torch.Tensor, n_neighbors: int = 70, radius: float = 2.0,
+                   eps: float = 0.1, min_samples: int = 10, return_kth: bool = False,
+                   ctx: Optional[Context] = None):
+    """radius_mutual_knn / l1 affinity graph + DBSCAN(precomputed) labels, (n,) int32 on device."""
+    lib = load()
+    _dev(xyz, torch.float32, "xyz")
+    _dev(pp, torch.float32, "pp")
+    n = xyz.shape[0]
+    assert pp.shape[0] == n
+    labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
+    kth = torch.empty((n,), dtype=torch.float64, device=xyz.device) if return_kth else None
+    ncl = C.c_int32(0)
+    c = _ctx(ctx, xyz)
+    check(lib.modest_cluster_dbscan(c.handle, xyz.data_ptr(), pp.data_ptr(), n, int(n_neighbors), float(radius),
+                                    float(eps), int(min_samples), labels.data_ptr(),
+                                    kth.data_ptr() if kth is not None else None, C.byref(ncl), _stream()),
+          "modest_cluster_dbscan")
+    return (labels, int(ncl.value), kth) if return_kth else (labels, int(ncl.value))
+
+
+# --------------------------------------------------------------------------- box fitting
+def fit_boxes_closeness(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np.ndarray, d0: float = 1e-2,
+                        return_beta: bool = False, ctx: Optional[Context] = None):
+    """Index of the first strict maximum of the closeness criterion per cluster."""
+    lib = load()
+    _dev(pts_xz, torch.float64, "pts_xz")
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+    cs = np.ascontiguousarray(cossin, dtype=np.float64).reshape(-1, 2)
+    ncl, na = off.shape[0] - 1, cs.shape[0]
+    best = np.full(ncl, -1, dtype=np.int32)
+    beta = np.zeros((ncl, na), dtype=np.float64) if return_beta else None
+    c = _ctx(ctx, pts_xz)
+    check(lib.modest_fit_boxes_closeness(c.handle, pts_xz.data_ptr(), _np_ptr(off), ncl, _np_ptr(cs), na,
+                                         float(d0), _np_ptr(best), _np_ptr(beta) if return_beta else None,
+                                         _stream()), "modest_fit_boxes_closeness")
+    return (best, beta) if return_beta else best
+
+
+def lowest_point(pts_rect: torch.Tensor, boxes6: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
+    lib = load()
+    _dev(pts_rect, torch.float64, "pts_rect")
+    b = np.ascontiguousarray(boxes6, dtype=np.float64).reshape(-1, 6)
+    out = np.zeros(b.shape[0], dtype=np.float64)
+    c = _ctx(ctx, pts_rect)
+    check(lib.modest_lowest_point(c.handle, pts_rect.data_ptr(), pts_rect.shape[0], _np_ptr(b), b.shape[0],
+                                  _np_ptr(out), _stream()), "modest_lowest_point")
+    return out
+
+
+# --------------------------------------------------------------------------- BEV IoU / NMS
+def boxes_iou_bev(a: torch.Tensor, b: torch.Tensor, overlap_only: bool = False) -> torch.Tensor:
+    lib = load()
+    _dev(a, torch.float32, "boxes_a")
+    _dev(b, torch.float32, "boxes_b")
+    assert a.shape[1] == 7 and b.shape[1] == 7
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    fn = lib.modest_boxes_overlap_bev if overlap_only else lib.modest_boxes_iou_bev
+    check(fn(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), _stream()),
+          "modest_boxes_iou_bev")
+    return out
+
+
+def nms(boxes: torch.Tensor, thresh: float, rotated: bool = True, ctx: Optional[Context] = None) -> np.ndarray:
+    """Greedy NMS over boxes already sorted by score; returns kept indices (int64, host)."""
+    lib = load()
+    _dev(boxes, torch.float32, "boxes")
+    n = boxes.shape[0]
+    keep = np.zeros(n, dtype=np.int64)
+    num = C.c_int(0)
+    c = _ctx(ctx, boxes)
+    fn = lib.modest_nms_bev if rotated else lib.modest_nms_normal
+    check(fn(c.handle, boxes.data_ptr(), n, float(thresh), _np_ptr(keep), C.byref(num), _stream()), "modest_nms")
+    return keep[: num.value]
