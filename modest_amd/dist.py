@@ -1,0 +1,100 @@
+"""Scan sharding across the GPUs of a node.
+
+The path is embarrassingly parallel: every scan's PP score, mask, boxes and
+label file depend only on that scan and its history frames, and the reference
+itself shards with ``np.array_split(idx_list, total_part)[part]``
+(``pre_compute_pp_score.py:114-116``, ``generate_mask.py:35-37``,
+``gen_label_files.py:36-38``).  One process per GPU (torchrun / torch.distributed,
+backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU-only hosts for tests);
+rank r of W takes ``np.array_split(part_list, W)[r]`` so the union of all ranks'
+output files equals a single-process run.  RCCL carries only a start/end
+barrier and one all-reduce of a few counters -- there is no data-path
+collective because there is no cross-scan data dependency.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+
+def world() -> tuple:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: Optional[str] = None) -> tuple:
+    """Initialise torch.distributed when launched with WORLD_SIZE > 1."""
+    rank, ws, local = world()
+    if ws > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        torch.distributed.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def shard(idx_list, total_part: int = 1, part: int = 0, rank: Optional[int] = None, ws: Optional[int] = None):
+    """The reference's manual ``total_part/part`` split, then the per-rank split."""
+    idx_list = np.asarray(idx_list)
+    if total_part > 1:
+        idx_list = np.array_split(idx_list, total_part)[part]
+    if rank is None or ws is None:
+        rank, ws, _ = world()
+    if ws > 1:
+        idx_list = np.array_split(idx_list, ws)[rank]
+    return idx_list
+
+
+def barrier() -> None:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        if torch.distributed.get_backend() == "nccl":
+            torch.distributed.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            torch.distributed.barrier()
+
+
+def reduce_counters(counters: Dict[str, float]) -> Dict[str, float]:
+    """Sum scalar counters over ranks ("max_" prefixed keys take the maximum)."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return dict(counters)
+    keys = sorted(counters)
+    dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+    sums = torch.tensor([float(counters[k]) for k in keys if not k.startswith("max_")], dtype=torch.float64, device=dev)
+    maxs = torch.tensor([float(counters[k]) for k in keys if k.startswith("max_")], dtype=torch.float64, device=dev)
+    if sums.numel():
+        torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM)
+    if maxs.numel():
+        torch.distributed.all_reduce(maxs, op=torch.distributed.ReduceOp.MAX)
+    out, si, mi = {}, 0, 0
+    for k in keys:
+        if k.startswith("max_"):
+            out[k] = float(maxs[mi]); mi += 1
+        else:
+            out[k] = float(sums[si]); si += 1
+    return out
+
+
+def finalize() -> None:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+class StageTimer:
+    """Wall-clock accumulator per stage (the reference has only tqdm bars)."""
+
+    def __init__(self):
+        self.t: Dict[str, float] = {}
+        self._t0 = None
+        self._name = None
+
+    def start(self, name):
+        self._name, self._t0 = name, time.perf_counter()
+
+    def stop(self):
+        self.t[self._name] = self.t.get(self._name, 0.0) + time.perf_counter() - self._t0

@@ -1,0 +1,73 @@
+"""``python -m modest_amd.gen_label_files data_root=...`` -- KITTI label CLI.
+
+Drop-in for the reference's ``generate_cluster_mask/gen_label_files.py`` (its
+README calls it ``generate_label_files.py``; that alias exists too): reads
+``bbox_info_save_dst/NNNNNN.pkl``, runs BEV NMS on the device, keeps boxes in
+the camera FOV and writes ``label_file_save_dst/NNNNNN.txt`` in the KITTI text
+format OpenPCDet's ``get_objects_from_label`` parses (class ``Dynamic``).
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import pickle
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import config, dist
+from .utils import kitti_util
+from .utils.pointcloud_utils import is_within_fov, objs2label, objs_nms
+
+
+def eprint(*args, **kwargs):
+    print(*args, file=sys.stderr, **kwargs)
+
+
+def display_args(args):
+    eprint("========== kitti_label gen info ==========")
+    eprint("host: {}".format(os.getenv("HOSTNAME")))
+    eprint(config.to_yaml(args))
+    eprint("==========================================")
+
+
+def gen_label_scan(objs, calib, args):
+    """gen_label_files.py:44-52 for one scan -> (label text, kept objs)."""
+    if args.nms.enable and len(objs) > 0:
+        objs = objs_nms(objs, nms_threshold=args.nms.threshold)
+    if args.fov_only:
+        objs = [obj for obj in objs if is_within_fov(obj, calib, args.image_shape)]
+    return objs2label(objs, calib), objs
+
+
+@config.main(config_name="generate_label_files.yaml")
+def main(args):
+    rank, ws, local = dist.init()
+    if rank == 0:
+        display_args(args)
+    torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))
+    dp = args.data_paths
+    idx_list = np.array([int(x) for x in open(dp.idx_list).readlines()])
+    shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
+    os.makedirs(dp.label_file_save_dst, exist_ok=True)
+    t0, done = time.perf_counter(), 0
+    dist.barrier()
+    for idx in shard:
+        idx = int(idx)
+        objs = pickle.load(open(osp.join(dp.bbox_info_save_dst, f"{idx:06d}.pkl"), "rb"))
+        calib = kitti_util.Calibration(osp.join(args.calib_path, f"{idx:06d}.txt"))
+        text, _ = gen_label_scan(objs, calib, args)
+        with open(osp.join(dp.label_file_save_dst, f"{idx:06d}.txt"), "w") as f:
+            f.write(text)
+        done += 1
+    dist.barrier()
+    tot = dist.reduce_counters(dict(scans=done, max_seconds=time.perf_counter() - t0))
+    if rank == 0:
+        eprint("[gen_label_files] %d scans, %.2f s on %d GPU(s)" % (tot["scans"], tot["max_seconds"], ws))
+    return tot
+
+
+if __name__ == "__main__":
+    main()

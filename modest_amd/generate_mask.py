@@ -1,0 +1,133 @@
+"""``python -m modest_amd.generate_mask data_root=...`` -- mask / cluster CLI.
+
+Drop-in for the reference's ``generate_cluster_mask/generate_mask.py``: same
+config keys, same outputs (``seg_save_dst/NNNNNN.npy`` int64 labels with 0 =
+background, ``bbox_info_save_dst/NNNNNN.pkl`` pickled list of
+``types.SimpleNamespace(t, l, w, h, ry, volume)``, ``configs.yaml`` dumps).
+Per scan: RANSAC ground plane -> plane/range mask -> PP-weighted mutual-kNN
+DBSCAN -> cluster filter -> box fit, each heavy loop in a HIP kernel.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import pickle
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import config, dist, ops
+from .utils import kitti_util
+from .utils.clustering_utils import filter_labels
+from .utils.pointcloud_utils import estimate_plane, get_objs, load_velo_scan, to_device
+
+
+def eprint(*args, **kwargs):
+    print(*args, file=sys.stderr, **kwargs)
+
+
+def display_args(args):
+    eprint("========== clustering info ==========")
+    eprint("host: {}".format(os.getenv("HOSTNAME")))
+    eprint(config.to_yaml(args))
+    eprint("=====================================")
+
+
+def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=None, timer=None):
+    """The body of the reference's per-scan loop (generate_mask.py:52-103).
+
+    ptc (N,4) float32 numpy, pp_score (N,) float32 numpy, calib a Calibration.
+    ``random_state`` feeds both RANSAC calls in order (the reference consumes
+    numpy's global stream in that order); ``planes`` = (plane1, plane2) injects
+    the two ground planes instead (stage-wise parity tests).
+    Returns (labels (N,) int64 with 0 = background, objs list, info dict)."""
+    pe = args.plane_estimate
+    ptc_dev = to_device(ptc)
+    pp_dev = to_device(pp_score)
+    plane = planes[0] if planes is not None else estimate_plane(
+        ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state)
+    _, kept_xyz, kept_idx = ops.plane_range_mask(ptc_dev, plane, pe.offset, pe.range, args.limit_range)
+    labels = np.zeros(ptc.shape[0], dtype=int) - 1
+    if args.clustering.method != "DBSCAN":
+        raise NotImplementedError(args.clustering.method)
+    g = args.graph
+    if (g.neighbor_type, g.affinity_type) != ("radius_mutual_knn", "l1"):
+        raise NotImplementedError(f"graph {g.neighbor_type}/{g.affinity_type} (SURVEY.md §8f-3)")
+    n_kept = int(kept_xyz.shape[0])
+    if n_kept:
+        if n_kept <= g.n_neighbors:
+            raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {g.n_neighbors + 1}, "
+                             f"n_samples_fit = {n_kept}, n_samples = {n_kept}")
+        kept_long = kept_idx.long()
+        lab_kept, _ = ops.cluster_dbscan(kept_xyz, pp_dev[kept_long].contiguous(), g.n_neighbors, g.radius,
+                                         args.clustering.DBSCAN.eps, args.clustering.DBSCAN.min_samples)
+        labels[kept_idx.cpu().numpy()] = lab_kept.cpu().numpy()
+    labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
+                                    plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
+                                    **args.filtering)
+    ptc_in_rect = calib.project_velo_to_rect(ptc[:, :3])
+    n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
+    order = np.argsort(labels_filtered, kind="stable")
+    sl = labels_filtered[order]
+    ids = np.arange(1, n_lab + 1)
+    starts, ends = np.searchsorted(sl, ids, side="left"), np.searchsorted(sl, ids, side="right")
+    members = [order[s:e] for s, e in zip(starts, ends)]
+    cand = get_objs([ptc_in_rect[m] for m in members], ptc_in_rect, fit_method=args.bbox_gen.fit_method)
+    objs = []
+    for m, obj in zip(members, cand):
+        if obj.volume > args.filtering.min_volume and obj.volume < args.filtering.max_volume:
+            objs.append(obj)
+        else:
+            labels_filtered[m] = 0
+    uniq = np.unique(labels_filtered)
+    labels_filtered = np.searchsorted(uniq, labels_filtered).astype(labels_filtered.dtype)
+    return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
+
+
+@config.main(config_name="generate_mask.yaml")
+def main(args):
+    rank, ws, local = dist.init()
+    if rank == 0:
+        display_args(args)
+    torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))
+    dp = args.data_paths
+    idx_list = np.array([int(x) for x in open(dp.idx_list).readlines()])
+    shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
+    os.makedirs(dp.seg_save_dst, exist_ok=True)
+    if rank == 0 and not osp.exists(osp.join(dp.seg_save_dst, "configs.yaml")):
+        config.save(config=args, f=osp.join(dp.seg_save_dst, "configs.yaml"))
+    bbox_dst = dp.get("bbox_info_save_dst", "None")
+    if bbox_dst is not None:
+        os.makedirs(bbox_dst, exist_ok=True)
+        if rank == 0 and not osp.exists(osp.join(bbox_dst, "configs.yaml")):
+            config.save(config=args, f=osp.join(bbox_dst, "configs.yaml"))
+    seed = int(args.get("ransac_seed", 0))
+    t0, done = time.perf_counter(), 0
+    dist.barrier()
+    for idx in shard:
+        idx = int(idx)
+        if osp.exists(osp.join(dp.seg_save_dst, f"{idx:06d}.npy")) and \
+                (bbox_dst is None or osp.exists(osp.join(bbox_dst, f"{idx:06d}.pkl"))):
+            continue
+        ptc = load_velo_scan(osp.join(args.ptc_path, f"{idx:06d}.bin"))
+        pp_score = np.load(osp.join(dp.pp_score_path, f"{idx:06d}.npy"))
+        calib = kitti_util.Calibration(osp.join(args.calib_path, f"{idx:06d}.txt"))
+        labels, objs, _ = generate_mask_scan(ptc, pp_score, calib, args,
+                                             random_state=np.random.RandomState(seed + idx))
+        if bbox_dst is not None:
+            pickle.dump(objs, open(osp.join(bbox_dst, f"{idx:06d}.pkl"), "wb"))
+        np.save(osp.join(dp.seg_save_dst, f"{idx:06d}.npy"), labels)
+        done += 1
+    torch.cuda.synchronize()
+    dist.barrier()
+    tot = dist.reduce_counters(dict(scans=done, max_seconds=time.perf_counter() - t0))
+    if rank == 0:
+        eprint("[generate_mask] %d scans, %.2f s, %.2f scans/s on %d GPU(s)"
+               % (tot["scans"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9), ws))
+    return tot
+
+
+if __name__ == "__main__":
+    main()

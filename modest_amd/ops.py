@@ -91,7 +91,7 @@ def pp_score(live_xyz: torch.Tensor, hist_xyz: torch.Tensor, trav_offsets: Seque
 
 # --------------------------------------------------------------------------- transform
 def transform_points(pts: torch.Tensor, T: np.ndarray, remove_center: bool = False,
-                     ctx: Optional[Context] = None) -> torch.Tensor:
+                     ctx: Optional[Context] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """transform_points (utils/pointcloud_utils.py:11-19) of an (n,3|4) float32 frame,
     optionally preceded by remove_center (pre_compute_pp_score.py:48-52)."""
     lib = load()
@@ -99,7 +99,11 @@ def transform_points(pts: torch.Tensor, T: np.ndarray, remove_center: bool = Fal
     assert pts.ndim == 2 and pts.shape[1] in (3, 4)
     n = pts.shape[0]
     T16 = np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4))
-    out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    else:
+        _dev(out, torch.float32, "out")
+        assert out.shape == (n, 3)
     c = _ctx(ctx, pts)
     if not remove_center:
         check(lib.modest_transform_points(c.handle, pts.data_ptr(), n, pts.shape[1], _np_ptr(T16), 0,

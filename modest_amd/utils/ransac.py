@@ -1,0 +1,137 @@
+"""RANSAC plane regression z ~ (x, y) with the device doing every O(N) loop.
+
+Behavioural mirror of ``sklearn.linear_model.RANSACRegressor()`` with default
+arguments, as the reference calls it (``utils/pointcloud_utils.py:52``):
+LinearRegression base model, ``min_samples = 3``, residual threshold =
+MAD(z), absolute loss, ``max_trials = 100`` with the dynamic stop
+(``stop_probability = 0.99``), accept rule "more inliers, or as many with a
+better R^2", final least-squares refit on the consensus set.
+
+Split of work:
+  host   - the random triplets (``sample_without_replacement`` on the caller's
+           RandomState, exactly the stream sklearn would consume: one draw per
+           executed trial), the 3-point plane of each trial, the sequential
+           accept rule and dynamic trial bound (a few dozen scalar decisions);
+  device - MAD threshold (exact float32 medians), residual / inlier counting /
+           R^2 sums of a whole batch of trials in one launch, the final refit
+           (float64 normal equations).
+
+Numerical contract: inlier decisions are float32 like sklearn's (pred =
+fmaf(y,c1,x*c0)+b); trial planes and the refit are computed in float64 and
+rounded to float32, so the plane agrees with sklearn's float32 LAPACK path to
+~1e-6 relative (tolerance in tests: 1e-4 relative, as BASELINE.json states).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from sklearn.utils import check_random_state
+from sklearn.utils.random import sample_without_replacement
+
+from .. import ops
+
+_EPSILON = np.spacing(1)
+
+
+def dynamic_max_trials(n_inliers, n_samples, min_samples, probability):
+    inlier_ratio = n_inliers / float(n_samples)
+    nom = max(_EPSILON, 1 - probability)
+    denom = max(_EPSILON, 1 - inlier_ratio ** min_samples)
+    if nom == 1:
+        return 0
+    if denom == 1:
+        return float("inf")
+    return abs(float(np.ceil(np.log(nom) / np.log(denom))))
+
+
+def planes_through_triplets(p: np.ndarray) -> np.ndarray:
+    """(B,3,3) float32 points -> (B,3) float32 models [c0, c1, b] of the exact-fit
+    planes z = c0 x + c1 y + b (float64 arithmetic, centred like a least-squares
+    fit; degenerate triplets fall back to the minimum-norm solution)."""
+    p = p.astype(np.float64)
+    mean = p.mean(axis=1, keepdims=True)
+    q = p - mean
+    A, z = q[:, :, :2], q[:, :, 2]
+    ata = np.einsum("bij,bik->bjk", A, A)
+    atz = np.einsum("bij,bi->bj", A, z)
+    det = ata[:, 0, 0] * ata[:, 1, 1] - ata[:, 0, 1] * ata[:, 1, 0]
+    coef = np.zeros((p.shape[0], 2))
+    scale = np.maximum(ata[:, 0, 0] * ata[:, 1, 1], 1e-300)
+    ok = np.abs(det) > 1e-12 * scale
+    coef[ok, 0] = (atz[ok, 0] * ata[ok, 1, 1] - atz[ok, 1] * ata[ok, 0, 1]) / det[ok]
+    coef[ok, 1] = (atz[ok, 1] * ata[ok, 0, 0] - atz[ok, 0] * ata[ok, 0, 1]) / det[ok]
+    for b in np.nonzero(~ok)[0]:
+        coef[b] = np.linalg.lstsq(A[b], z[b], rcond=None)[0]
+    icpt = mean[:, 0, 2] - coef[:, 0] * mean[:, 0, 0] - coef[:, 1] * mean[:, 0, 1]
+    return np.concatenate([coef, icpt[:, None]], axis=1).astype(np.float32)
+
+
+def r2_from_sums(n, sse, sy, syy):
+    """R^2 over the inliers from float64 sums (sklearn r2_score semantics for
+    the degenerate denominators)."""
+    if n < 2:
+        return float("nan")
+    den = syy - sy * sy / n
+    if den <= 0.0:
+        return 1.0 if sse == 0.0 else 0.0
+    return 1.0 - sse / den
+
+
+class RansacResult:
+    __slots__ = ("coef", "intercept", "n_trials", "n_inliers", "threshold", "triplets", "best_model")
+
+
+def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, stop_probability: float = 0.99,
+                 batch: int = 16, ctx=None) -> RansacResult:
+    """cand: (m,3) float32 device tensor of candidate ground points (x, y, z)."""
+    n_samples = int(cand.shape[0])
+    min_samples = 3
+    if n_samples < min_samples:
+        raise ValueError("`min_samples` may not be larger than number of samples: n_samples = %d." % n_samples)
+    rs = check_random_state(random_state)
+    thr = ops.mad_threshold(cand, ctx=ctx)
+
+    n_inliers_best, score_best, best_model = 1, -np.inf, None
+    n_trials, limit = 0, max_trials
+    triplets = []
+    while n_trials < limit:
+        # draw a batch from a COPY of the stream; the real stream is advanced only
+        # by the trials that are actually executed (below)
+        state = rs.get_state()
+        nb = int(min(batch, limit - n_trials))
+        trip = np.stack([sample_without_replacement(n_samples, min_samples, random_state=rs) for _ in range(nb)])
+        pts = cand[torch.as_tensor(trip.reshape(-1), device=cand.device, dtype=torch.long)].cpu().numpy()
+        models = planes_through_triplets(pts.reshape(nb, 3, 3))
+        n_in, sse, sy, syy = ops.ransac_score_trials(cand, models, thr, ctx=ctx)
+        used = 0
+        for k in range(nb):
+            if not (n_trials < limit):
+                break
+            n_trials += 1
+            used += 1
+            triplets.append(trip[k])
+            nk = int(n_in[k])
+            if nk < n_inliers_best:
+                continue
+            score = r2_from_sums(nk, sse[k], sy[k], syy[k])
+            if nk == n_inliers_best and score < score_best:
+                continue
+            n_inliers_best, score_best, best_model = nk, score, models[k].copy()
+            limit = min(limit, dynamic_max_trials(n_inliers_best, n_samples, min_samples, stop_probability))
+        if used < nb:   # rewind, then consume exactly `used` draws
+            rs.set_state(state)
+            for _ in range(used):
+                sample_without_replacement(n_samples, min_samples, random_state=rs)
+    if best_model is None:
+        raise ValueError("RANSAC could not find a valid consensus set. All `max_trials` iterations were "
+                         "skipped because each randomly chosen sub-sample failed the passing criteria.")
+    model64, n_final = ops.ransac_refit(cand, best_model, thr, ctx=ctx)
+    res = RansacResult()
+    res.coef = model64[:2].astype(np.float32)          # LinearRegression on float32 data stores float32
+    res.intercept = np.float32(model64[2])
+    res.n_trials = n_trials
+    res.n_inliers = n_final
+    res.threshold = thr
+    res.triplets = np.array(triplets)
+    res.best_model = best_model
+    return res

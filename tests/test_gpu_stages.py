@@ -1,0 +1,219 @@
+"""GPU parity of every stage after the PP score: HIP path (through the C ABI)
+vs the oracle and the reference-generated fixtures.
+
+Bars: integer / index / mask outputs bit exact; plane coefficients <= 1e-4
+relative (BASELINE.json); box parameters <= 1e-9 relative; BEV IoU <= 2e-6
+absolute (float32 trig, see csrc/trig_f32.h)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ms(golden_dir):
+    return np.load(os.path.join(golden_dir, "mask_stage.npz"))
+
+
+def test_transform_points(gpu, golden_dir):
+    import torch
+    from modest_amd import ops
+    t = np.load(os.path.join(golden_dir, "transform.npz"))
+    pts = torch.from_numpy(t["pts"]).to(gpu)
+    out = ops.transform_points(pts, t["T"]).cpu().numpy()
+    assert np.array_equal(out, t["out"])                      # bit exact vs the reference's BLAS product
+    pts4 = torch.cat([pts, torch.ones((pts.shape[0], 1), device=gpu)], 1).contiguous()
+    assert np.array_equal(ops.transform_points(pts4, t["T"]).cpu().numpy(), t["out"])
+    from oracle import pp_score as opp
+    kept = ops.transform_points(pts4, t["T"], remove_center=True).cpu().numpy()
+    assert np.array_equal(kept, opp.transform_points(t["kept"], t["T"]))
+    # many blocks, order preserved
+    rng = np.random.default_rng(0)
+    big = (rng.standard_normal((300_001, 4)) * [2, 1, 1, 1]).astype(np.float32)
+    ref = opp.transform_points_fma(opp.remove_center(big[:, :3]), t["T"])
+    got = ops.transform_points(torch.from_numpy(big).to(gpu), t["T"], remove_center=True).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert ops.transform_points(pts[:0], t["T"]).shape == (0, 3)
+
+
+def test_plane_candidates_mad_and_scoring(gpu, ms):
+    import torch
+    from modest_amd import ops
+    from oracle import mask as om
+    ptc = ms["ptc"]
+    dev = torch.from_numpy(ptc).to(gpu)
+    rng_ = [[-70, 70], [-20, 20]]
+    cand, idx = ops.plane_candidates(dev, -1.5, rng_)
+    m = om.plane_candidate_mask(ptc, -1.5, rng_)
+    assert np.array_equal(idx.cpu().numpy(), np.nonzero(m)[0])
+    assert np.array_equal(cand.cpu().numpy(), ptc[m][:, :3])
+    z = ptc[m][:, 2]
+    mad = np.median(np.abs(z - np.median(z)))
+    assert ops.mad_threshold(cand) == mad                       # exact float32 medians
+    for n in (1, 2, 3, 10, 11, 4097):
+        sub = cand[:n].contiguous()
+        zz = ptc[m][:n, 2]
+        assert ops.mad_threshold(sub) == np.median(np.abs(zz - np.median(zz))), n
+    # trial scoring vs a float32 numpy statement with the same fma-chain prediction
+    rs = np.random.default_rng(1)
+    models = np.c_[rs.normal(0, 0.01, 40), rs.normal(0, 0.01, 40), rs.normal(-1.7, 0.02, 40)].astype(np.float32)
+    n_in, sse, sy, syy = ops.ransac_score_trials(cand, models, mad)
+    X = ptc[m][:, :2].astype(np.float64)
+    for k in range(40):
+        c0, c1, b = (np.float64(v) for v in models[k])
+        acc = (X[:, 0] * c0).astype(np.float32).astype(np.float64)
+        pred = (X[:, 1] * c1 + acc).astype(np.float32) + models[k, 2]
+        res = np.abs(z - pred)
+        inl = res <= mad
+        assert n_in[k] == inl.sum()
+        assert abs(sse[k] - (res[inl].astype(np.float64) ** 2).sum()) <= 1e-9 * max(1.0, sse[k])
+        assert abs(sy[k] - z[inl].astype(np.float64).sum()) <= 1e-9 * max(1.0, abs(sy[k]))
+
+
+def test_ransac_plane_vs_sklearn(gpu, ms):
+    import torch
+    from modest_amd.utils import pointcloud_utils as pcu
+    from oracle import mask as om
+    ptc = ms["ptc"]
+    for seed, kw in ((int(ms["seed"]), dict(max_hs=-1.5, ptc_range=[[-70, 70], [-20, 20]])),
+                     (int(ms["seed"]) + 7, dict(max_hs=-1.5, ptc_range=((-70, 70), (-50, 50))))):
+        ref = om.estimate_plane(ptc, random_state=np.random.RandomState(seed), **kw)
+        got, info = pcu.estimate_plane(torch.from_numpy(ptc).to(gpu), random_state=np.random.RandomState(seed),
+                                       return_info=True, **kw)
+        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 1e-4, (got, ref)
+        assert got[2] > 0
+    # the triplet stream is the one sklearn consumed for the reference's run
+    got, info = pcu.estimate_plane(torch.from_numpy(ptc).to(gpu), max_hs=-1.5, ptc_range=[[-70, 70], [-20, 20]],
+                                   random_state=np.random.RandomState(int(ms["seed"])), return_info=True)
+    nt = min(len(info.triplets), len(ms["triplets1"]))
+    assert np.array_equal(info.triplets[:nt], ms["triplets1"][:nt])
+    assert abs(info.n_trials - len(ms["triplets1"])) <= 2
+    assert np.max(np.abs(got - ms["plane"]) / np.maximum(np.abs(ms["plane"]), 1e-3)) <= 1e-4
+
+
+def test_plane_range_mask_exact(gpu, ms):
+    import torch
+    from modest_amd import ops
+    dev = torch.from_numpy(ms["ptc"]).to(gpu)
+    mask, kept, idx = ops.plane_range_mask(dev, ms["plane"], 0.05, [[-70, 70], [-20, 20]], [[-70, 70], [-40, 40]])
+    assert np.array_equal(mask.cpu().numpy(), ms["final_mask"])
+    assert np.array_equal(idx.cpu().numpy(), np.nonzero(ms["final_mask"])[0])
+    assert np.array_equal(kept.cpu().numpy(), ms["ptc"][ms["final_mask"]][:, :3])
+    from modest_amd.utils import pointcloud_utils as pcu
+    pm = pcu.above_plane(ms["ptc"][:, :3].copy(), ms["plane"], offset=0.05, only_range=[[-70, 70], [-20, 20]])
+    assert np.array_equal(pm, ms["plane_mask"])
+
+
+def test_cluster_dbscan_exact(gpu, ms):
+    import torch
+    from modest_amd import ops
+    from oracle import mask as om
+    fm = ms["final_mask"]
+    xyz = torch.from_numpy(np.ascontiguousarray(ms["ptc"][fm][:, :3])).to(gpu)
+    pp = torch.from_numpy(np.ascontiguousarray(ms["pp"][fm])).to(gpu)
+    labels, ncl, kth = ops.cluster_dbscan(xyz, pp, 70, 2.0, 0.1, 10, return_kth=True)
+    assert np.array_equal(labels.cpu().numpy().astype(np.int64), ms["dbscan"])
+    assert ncl == ms["dbscan"].max() + 1
+    _, kref = om.dbscan_closed_form(ms["ptc"][fm][:, :3], ms["pp"][fm])
+    assert np.array_equal(kth.cpu().numpy(), kref)
+    # second geometry incl. border points between clusters, small k / min_samples
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.normal([0, 0, 0], 0.4, (300, 3)), rng.normal([3, 0, 0], 0.5, (200, 3)),
+                          rng.uniform(-6, 6, (150, 3))]).astype(np.float32)
+    ppv = np.concatenate([rng.uniform(0, 0.12, 300), rng.uniform(0.5, 0.7, 200), rng.uniform(0, 1, 150)]).astype(np.float32)
+    for k, msmp in ((20, 10), (70, 10), (8, 5)):
+        g = om.precompute_affinity_matrix(pts, ppv, n_neighbors=k, radius=2.0)
+        ref = om.dbscan_labels(g, 0.1, msmp)
+        lab, _ = ops.cluster_dbscan(torch.from_numpy(pts).to(gpu), torch.from_numpy(ppv).to(gpu), k, 2.0, 0.1, msmp)
+        assert np.array_equal(lab.cpu().numpy().astype(np.int64), ref), (k, msmp)
+    e, n0 = ops.cluster_dbscan(xyz[:0], pp[:0])
+    assert e.shape == (0,) and n0 == 0
+
+
+def test_cluster_dbscan_vs_sklearn_full_size(gpu):
+    """Lyft-shape scan: ~15 k kept points, sklearn's two graph calls + DBSCAN vs the implicit-graph kernel."""
+    import torch
+    from modest_amd import ops, synth
+    from oracle import mask as om
+    s = synth.make_scan(21, n_live=30000, n_trav=2, n_frames=1)
+    ptc = s.live_raw
+    keep = (ptc[:, 2] > -1.55) & (np.abs(ptc[:, 1]) < 40) & (np.abs(ptc[:, 0]) < 70)
+    xyz = np.ascontiguousarray(ptc[keep][:, :3])
+    rng = np.random.default_rng(2)
+    ppv = np.clip(0.5 + 0.5 * np.sin(xyz[:, 0] * 0.3) + rng.normal(0, 0.03, len(xyz)), 0, 1).astype(np.float32)
+    g = om.precompute_affinity_matrix(xyz, ppv)
+    ref = om.dbscan_labels(g)
+    lab, ncl = ops.cluster_dbscan(torch.from_numpy(xyz).to(gpu), torch.from_numpy(ppv).to(gpu))
+    assert np.array_equal(lab.cpu().numpy().astype(np.int64), ref)
+    assert ncl == ref.max() + 1 and ncl > 3
+
+
+def test_filter_and_boxes(gpu, ms):
+    from modest_amd.utils import clustering_utils as cu
+    from modest_amd.utils import pointcloud_utils as pcu
+    from oracle import mask as om
+    labels = np.zeros(len(ms["ptc"]), dtype=int) - 1
+    labels[ms["final_mask"]] = ms["dbscan"]
+    rs = np.random.RandomState(int(ms["seed"]))
+    om.estimate_plane(ms["ptc"][:, :3], max_hs=-1.5, ptc_range=[[-70, 70], [-20, 20]], random_state=rs)
+    plane2 = om.estimate_plane(ms["ptc"], max_hs=-1.5, ptc_range=((-70, 70), (-50, 50)), random_state=rs)
+    lf = cu.filter_labels(ms["ptc"], ms["pp"], labels, plane=plane2, **om.DEFAULT_CFG["filtering"])
+    assert np.array_equal(lf, ms["labels_filtered"])
+    rect, off = ms["rect"], ms["cl_offsets"]
+    clusters = [rect[lf == c + 1] for c in range(len(off) - 1)]
+    fits = pcu.closeness_rectangles([c[:, [0, 2]] for c in clusters])
+    for (corners, angle, area), f in zip(fits, ms["fits"]):
+        assert angle == f[0] and area == f[1] and np.array_equal(corners.ravel(), f[2:10])
+    objs = pcu.get_objs(clusters, rect)
+    got = np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs])
+    assert np.array_equal(got, ms["fits"][:, 10:18])
+    # beta table vs the oracle's numpy loop on one cluster (pairwise summation order)
+    import torch
+    from modest_amd import ops
+    ang, cs = pcu.angle_table(0.1)
+    c0 = clusters[0][:, [0, 2]]
+    best, beta = ops.fit_boxes_closeness(torch.from_numpy(np.ascontiguousarray(c0)).to(gpu), [0, len(c0)], cs,
+                                         return_beta=True)
+    ref = []
+    for a in ang:
+        comp = np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
+        pr = c0 @ comp.T
+        dx = np.minimum(pr[:, 0] - pr[:, 0].min(), pr[:, 0].max() - pr[:, 0])
+        dy = np.minimum(pr[:, 1] - pr[:, 1].min(), pr[:, 1].max() - pr[:, 1])
+        ref.append((1 / np.maximum(np.minimum(dx, dy), 1e-2)).sum())
+    assert np.array_equal(beta[0], np.array(ref))
+
+
+def test_bev_iou_and_nms(gpu, golden_dir):
+    import torch
+    from modest_amd import ops
+    from modest_amd.utils import pointcloud_utils as pcu
+    from modest_amd.utils.iou3d_nms import iou3d_nms_utils as iu
+    from oracle import labels as ol
+    g = np.load(os.path.join(golden_dir, "boxes_iou.npz"))
+    b = torch.from_numpy(g["boxes"]).to(gpu)
+    iou = iu.boxes_iou_bev(b, b).cpu().numpy()
+    assert np.max(np.abs(iou - g["iou"])) <= 2e-6
+    ov = ops.boxes_iou_bev(b, b, overlap_only=True).cpu().numpy()
+    assert np.max(np.abs(ov - ol.boxes_iou_bev(g["boxes"], g["boxes"], overlap_only=True))) <= 2e-5
+    assert np.max(np.abs(iu.boxes_bev_iou_cpu(g["boxes"], g["boxes"][:5]) - g["iou"][:, :5])) <= 2e-6
+    objs = [types.SimpleNamespace(t=np.array([x[0], 0.0, x[1]], dtype=np.float64), l=float(x[3]), w=float(x[4]),
+                                  h=float(x[5]), ry=float(-x[6]), score=float(s)) for x, s in zip(g["boxes"], g["scores"])]
+    ident = {id(o): i for i, o in enumerate(objs)}
+    assert [ident[id(o)] for o in pcu.objs_nms(objs, True, 0.1)] == list(g["keep_score"])
+    assert [ident[id(o)] for o in pcu.objs_nms(objs, False, 0.1)] == list(g["keep_diag"])
+    # sorted-box NMS entry points against the oracle (rotated and axis-aligned), > 64 boxes
+    rng = np.random.default_rng(4)
+    big = np.c_[rng.uniform(-20, 20, (300, 2)), np.zeros(300), rng.uniform(1, 5, (300, 2)), np.ones(300),
+                rng.uniform(-3.2, 3.2, 300)].astype(np.float32)
+    scores = torch.from_numpy(rng.uniform(size=300).astype(np.float32)).to(gpu)
+    order = np.argsort(-scores.cpu().numpy(), kind="stable")
+    for rotated, fn in ((True, iu.nms_gpu), (False, iu.nms_normal_gpu)):
+        keep, _ = fn(torch.from_numpy(big).to(gpu), scores, 0.1)
+        ref = order[ol.nms(big[order], 0.1, rotated=rotated)]
+        assert np.array_equal(np.sort(keep.cpu().numpy()), np.sort(ref))
+    iou3d = iu.boxes_iou3d_gpu(b, b).cpu().numpy()
+    assert np.all(np.abs(np.diag(iou3d) - 1) < 1e-4)
