@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's headline metric on synthetic Lyft-shape input.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the whole seed-label hot path over one scan whose inputs
+are already resident in HBM: PP score (live scan vs the stacked 10-traversal x
+36-frame history, ~10.8 M points) -> RANSAC ground plane -> plane/range mask ->
+PP-weighted mutual-kNN DBSCAN -> cluster filter -> closeness box fit -> BEV
+IoU NMS -> KITTI label text.  value = scans/s over all ranks (weak scaling: every
+rank processes K scans of its own).  Besides the contract fields the JSON line
+carries
+  roofline     -- the PP history-stream kernel: algorithmic bytes per launch
+                  (12*M + 16*N) / its mean HIP-event duration,
+                  against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the oracle (the reference's own scipy/sklearn calls, same
+                  threading as the reference: cKDTree single-threaded, sklearn
+                  n_jobs=-1) timed on this host on a bounded sample of the same
+                  scans; rank 0, N=1 only.
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scans", type=int, default=2, help="distinct resident scans per rank, cycled through")
+    ap.add_argument("--n-live", type=int, default=30000)
+    ap.add_argument("--traversals", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=36)
+    ap.add_argument("--cpu-scans", type=int, default=2, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
+    return ap.parse_args()
+
+
+class ResidentScan:
+    def __init__(self, s, dev, calib):
+        self.host = s
+        self.offsets = np.cumsum([0] + [len(h) for h in s.hist]).astype(np.int64)
+        self.live_raw = torch.from_numpy(s.live_raw).to(dev)
+        self.live_xyz = torch.from_numpy(s.live_xyz).to(dev)
+        self.hist = torch.from_numpy(np.concatenate(s.hist)).to(dev)
+        self.calib = calib
+        self.M = int(self.offsets[-1])
+        self.N = int(s.live_xyz.shape[0])
+
+
+def main():
+    a = parse()
+    from modest_amd import _lib, config, dist, ops, synth
+    from modest_amd.gen_label_files import gen_label_scan
+    from modest_amd.generate_mask import generate_mask_scan
+    from modest_amd.utils import kitti_util
+
+    rank, ws, local = dist.init()
+    assert ws == a.gpus or ws == 1, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    ctx = _lib.default_context(local)
+
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+    margs = config.compose("generate_mask", ["data_root=/unused"])
+    largs = config.compose("generate_label_files", ["data_root=/unused"])
+
+    t_gen = time.perf_counter()
+    scans = [ResidentScan(synth.make_scan(1000 * rank + i, n_live=a.n_live, n_trav=a.traversals,
+                                          n_frames=a.frames), dev, calib) for i in range(a.scans)]
+    t_gen = time.perf_counter() - t_gen
+
+    def step(i):
+        sc = scans[i % len(scans)]
+        H = ops.pp_score(sc.live_xyz, sc.hist, sc.offsets, 0.3, ctx=ctx)
+        if a.pp_only:
+            return H, None, None, None
+        pp_host = H.cpu().numpy()
+        labels, objs, _ = generate_mask_scan(sc.host.live_raw, pp_host, sc.calib, margs,
+                                             random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H)
+        text, kept = gen_label_scan(objs, sc.calib, largs)
+        return H, labels, objs, text
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ctx.profile_begin(a.steps + 8)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ctx.profile_collect(a.steps + 8)
+    red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
+    dt_max, total_scans = red["max_seconds"], red["scans"]
+
+    sc0 = scans[0]
+    alg_bytes = 12 * sc0.M + 16 * sc0.N
+    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+    roofline = {"bound": "hbm", "kernel": "pp_stream (history neighbour count)", "achieved": achieved,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                "launches_timed": int(len(kernel_ms))}
+
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and ws == 1 and a.cpu_scans > 0:
+        from oracle import labels as ol
+        from oracle import mask as om
+        from oracle import pp_score as opp
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+            ocalib = ol.Calibration(os.path.join(d, "c.txt"))
+        n_cpu = min(a.cpu_scans, len(scans))
+        tc = time.perf_counter()
+        for i in range(n_cpu):
+            s = scans[i].host
+            Href, cref = opp.pp_score(s.live_xyz, s.hist, 0.3, workers=1)       # reference: single thread
+            if not a.pp_only:
+                ref = om.generate_mask_scan(s.live_raw, Href, ocalib, random_state=np.random.RandomState(i), n_jobs=-1)
+                ol.gen_label_scan(ref["objs"], ocalib)
+            if i == 0:
+                # parity of the measured path against the checker, outside the timed region
+                Hg, cg = ops.pp_score(scans[0].live_xyz, scans[0].hist, scans[0].offsets, 0.3, return_counts=True)
+                parity = {"pp_counts_equal": bool(np.array_equal(cg.cpu().numpy().astype(np.int64), cref)),
+                          "pp_max_abs_err": float(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - Href)))}
+        tc = time.perf_counter() - tc
+        cpu_baseline = {"value": n_cpu / tc, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
+                        "sample": f"{n_cpu} of the benchmarked scans ({'PP stage only' if a.pp_only else 'full pipeline'}); "
+                                  "reference threading: cKDTree build+query 1 thread, sklearn n_jobs=-1 on all "
+                                  f"{os.cpu_count()} host threads; {tc:.1f} s"}
+
+    if rank == 0:
+        value = total_scans / dt_max
+        line = {
+            "metric": "LiDAR scans/sec through PP-score+cluster seed-label pipeline",
+            "value": value, "unit": "scans/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("C2 PP-score only" if a.pp_only else "C3 full pipeline (PP + RANSAC + DBSCAN + box fit + iou3d NMS + labels)")
+                                   + f", Lyft-shape: {sc0.N} live pts vs {a.traversals} traversals x {a.frames} frames = {sc0.M} history pts",
+                       "live_points": sc0.N, "history_points": sc0.M, "traversals": a.traversals,
+                       "frames_per_traversal": a.frames, "radius": 0.3, "scans_per_rank": a.steps,
+                       "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "speedup_vs_cpu": (value / cpu_baseline["value"]) if cpu_baseline else None,
+        }
+        print(json.dumps(line), flush=True)
+    dist.finalize()
+
+
+if __name__ == "__main__":
+    main()

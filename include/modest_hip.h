@@ -42,6 +42,13 @@ const char *modest_last_error(void);
 int modest_device_count(void);
 int modest_ctx_create(int device, modest_ctx **out);
 int modest_ctx_destroy(modest_ctx *ctx);
+/* Measurement hook (no reference counterpart): while enabled, every launch of
+ * the dominant kernel of the path (the PP history-stream kernel) is bracketed
+ * by a HIP event pair on the launch stream; collect returns the elapsed
+ * milliseconds of up to `cap` launches since begin and disables the hook.    */
+int modest_ctx_profile_begin(modest_ctx *ctx, int capacity);
+int modest_ctx_profile_collect(modest_ctx *ctx, float *ms_out_host, int cap,
+                               int *n_out_host);
 
 /* ---- a4  transform_points  (utils/pointcloud_utils.py:11-19) ----------
  * out[i] = (x*T[r][0] (+fma) y*T[r][1] (+fma) z*T[r][2]) + T[r][3], float32,

@@ -27,6 +27,8 @@ SIGNATURES = {
     "modest_device_count": (C.c_int, []),
     "modest_ctx_create": (C.c_int, [C.c_int, C.POINTER(VP)]),
     "modest_ctx_destroy": (C.c_int, [VP]),
+    "modest_ctx_profile_begin": (C.c_int, [VP, C.c_int]),
+    "modest_ctx_profile_collect": (C.c_int, [VP, VP, C.c_int, VP]),
     "modest_transform_points": (C.c_int, [VP, VP, C.c_int64, C.c_int, VP, C.c_int, VP, VP, VP]),
     "modest_pp_count": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP]),
     "modest_pp_entropy": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP]),
@@ -94,6 +96,17 @@ class Context:
     @property
     def handle(self):
         return self._h
+
+    def profile_begin(self, capacity: int = 4096) -> None:
+        check(load().modest_ctx_profile_begin(self._h, int(capacity)), "modest_ctx_profile_begin")
+
+    def profile_collect(self, capacity: int = 4096):
+        import numpy as np
+        ms = np.zeros(capacity, dtype=np.float32)
+        n = C.c_int(0)
+        check(load().modest_ctx_profile_collect(self._h, ms.ctypes.data, capacity, C.byref(n)),
+              "modest_ctx_profile_collect")
+        return ms[: n.value]
 
     def close(self):
         if self._h:

@@ -12,7 +12,15 @@ struct modest_ctx {
     char *pinned;           // grow-only pinned host staging
     size_t pinned_bytes;
     int num_cus;
+    // optional per-launch timing of the dominant (history stream) kernel
+    int profiling;
+    int prof_count;
+    hipEvent_t *prof_ev;   // 2 * prof_cap events
+    int prof_cap;
 };
+
+// Record an event pair around a kernel when profiling is on (no-ops otherwise).
+void modest_prof_mark(modest_ctx *ctx, hipStream_t stream, int end);
 
 void modest_set_error(const char *fmt, ...);
 

@@ -55,6 +55,10 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->pinned = nullptr;
     c->pinned_bytes = 0;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->profiling = 0;
+    c->prof_count = 0;
+    c->prof_ev = nullptr;
+    c->prof_cap = 0;
     *out = c;
     return MODEST_OK;
 }
@@ -63,6 +67,8 @@ extern "C" int modest_ctx_destroy(modest_ctx *ctx) {
     if (!ctx) return MODEST_OK;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
     delete ctx;
     return MODEST_OK;
 }
@@ -93,5 +99,45 @@ int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes) {
     MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     ctx->pinned = static_cast<char *>(p);
     ctx->pinned_bytes = want;
+    return MODEST_OK;
+}
+
+// ---- per-launch timing of the dominant kernel (bench.py's roofline leg) ------
+void modest_prof_mark(modest_ctx *ctx, hipStream_t stream, int end) {
+    if (!ctx->profiling || ctx->prof_count >= ctx->prof_cap) return;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_count + (end ? 1 : 0)], stream);
+    if (end) ++ctx->prof_count;
+}
+
+extern "C" int modest_ctx_profile_begin(modest_ctx *ctx, int capacity) {
+    MODEST_REQUIRE(ctx != nullptr && capacity >= 0 && capacity <= (1 << 20), "bad arguments");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    if (capacity > ctx->prof_cap) {
+        hipEvent_t *ev = new (std::nothrow) hipEvent_t[2 * (size_t)capacity];
+        if (!ev) {
+            modest_set_error("modest_ctx_profile_begin: out of host memory");
+            return MODEST_ERR_CAPACITY;
+        }
+        for (int i = 0; i < 2 * ctx->prof_cap; ++i) ev[i] = ctx->prof_ev[i];
+        for (int i = 2 * ctx->prof_cap; i < 2 * capacity; ++i) MODEST_HIP_CHECK(hipEventCreate(&ev[i]));
+        delete[] ctx->prof_ev;
+        ctx->prof_ev = ev;
+        ctx->prof_cap = capacity;
+    }
+    ctx->prof_count = 0;
+    ctx->profiling = capacity > 0;
+    return MODEST_OK;
+}
+
+extern "C" int modest_ctx_profile_collect(modest_ctx *ctx, float *ms_out, int cap, int *n_out) {
+    MODEST_REQUIRE(ctx != nullptr && n_out != nullptr, "bad arguments");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const int n = ctx->prof_count < cap ? ctx->prof_count : cap;
+    for (int i = 0; i < n; ++i) {
+        MODEST_HIP_CHECK(hipEventSynchronize(ctx->prof_ev[2 * i + 1]));
+        MODEST_HIP_CHECK(hipEventElapsedTime(&ms_out[i], ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    }
+    *n_out = n;
+    ctx->profiling = 0;
     return MODEST_OK;
 }

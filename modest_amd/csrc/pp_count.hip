@@ -289,12 +289,14 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     long long grid = (long long)ctx->num_cus * 3;
     if (grid > nchunks) grid = nchunks;
     const bool aligned = ((reinterpret_cast<uintptr_t>(hist) & 15) == 0) && ((m0 & 3) == 0);
+    modest_prof_mark(ctx, stream, 0);
     if (aligned)
         pp_stream_v1<true><<<(int)grid, 256, 0, stream>>>(hist, m0, m1, tr, g, bitmap, cellStart,
                                                           sorted, counts, n_trav, r2);
     else
         pp_stream_v1<false><<<(int)grid, 256, 0, stream>>>(hist, m0, m1, tr, g, bitmap, cellStart,
                                                            sorted, counts, n_trav, r2);
+    modest_prof_mark(ctx, stream, 1);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }

@@ -35,7 +35,8 @@ def display_args(args):
     eprint("=====================================")
 
 
-def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=None, timer=None):
+def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=None, ptc_dev=None,
+                       pp_dev=None):
     """The body of the reference's per-scan loop (generate_mask.py:52-103).
 
     ptc (N,4) float32 numpy, pp_score (N,) float32 numpy, calib a Calibration.
@@ -44,8 +45,8 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     the two ground planes instead (stage-wise parity tests).
     Returns (labels (N,) int64 with 0 = background, objs list, info dict)."""
     pe = args.plane_estimate
-    ptc_dev = to_device(ptc)
-    pp_dev = to_device(pp_score)
+    ptc_dev = to_device(ptc) if ptc_dev is None else ptc_dev   # (N,4) float32 resident copy
+    pp_dev = to_device(pp_score) if pp_dev is None else pp_dev
     plane = planes[0] if planes is not None else estimate_plane(
         ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state)
     _, kept_xyz, kept_idx = ops.plane_range_mask(ptc_dev, plane, pe.offset, pe.range, args.limit_range)
