@@ -69,6 +69,10 @@ def load() -> C.CDLL:
             raise ModestHipError(
                 f"{LIB_PATH} is missing: build it with `python -m modest_amd.build` "
                 "(there is no CPU fallback for the MODEST hot path)")
+        # Device pointers cross this boundary from PyTorch-ROCm, so both must sit on
+        # ONE HIP runtime instance: import torch first, then libamdhip64.so.7 is
+        # already mapped when our DT_NEEDED entry is resolved.
+        import torch  # noqa: F401
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
