@@ -2,11 +2,30 @@
 // and entropy (pre_compute_pp_score.py:68-75) for gfx950.
 //
 // Inversion of the reference's "KD-tree over 10.8 M history points, query with
-// 30 k live points": the small live scan is indexed (cell-sorted, L2 resident),
-// the history is streamed ONCE with coalesced 16-byte loads and rejected early
-// against an LDS-resident dilated occupancy bitmap of the live scan.
+// 30 k live points": the small live scan is indexed (cell-sorted), the history
+// is streamed ONCE with coalesced 16-byte loads and rejected early against an
+// LDS-resident dilated occupancy bitmap of the live scan.
+//
+// Measured on MI355X (Lyft shape, 10.8 M history points):
+//   stream + bitmap test alone ............  25 us  (5.2 TB/s)
+//   V1: survivors resolved against an L2-resident index, one global atomic per
+//       pair ............................... 2090 us (630 us of divergent loads,
+//                                            1430 us for 10.5 M device atomics)
+// so V2 keeps the stream and moves the pair resolution and the counters to LDS:
+//
+//   route  (K1) stream once; survivors of the bitmap test are binned IN LDS by
+//          32x32-cell tile (9.6 m) and written as ONE contiguous, tile-sorted
+//          run per 4096-point chunk, plus an 8-byte run descriptor per
+//          (tile, traversal, chunk);
+//   tiles  (K2) a persistent grid dequeues balanced (tile, traversal, part)
+//          work items; the tile's live points (+1 cell halo), a local cell
+//          table and the counters live in LDS; a record is resolved with LDS
+//          reads, a float32 pre-test with an exact float64 re-test inside a
+//          1e-6 relative band around r^2, and LDS atomics; non-zero counters
+//          are flushed with one global atomic each.
 #include "pp_common.h"
 #include <cmath>
+#include <cstdlib>
 
 using namespace modest;
 
@@ -16,180 +35,720 @@ constexpr int PP_NX = 640;
 constexpr int PP_NY = 640;
 constexpr int PP_NCELL = PP_NX * PP_NY;       // 409,600 cells (192 m at r=0.3)
 constexpr int PP_BITWORDS = PP_NCELL / 32;    // 12,800 words = 51,200 B of LDS
-constexpr int SCAN_THREADS = 1024;
-constexpr int SCAN_PER = PP_NCELL / SCAN_THREADS;  // 400
-static_assert(PP_NCELL % SCAN_THREADS == 0, "scan tiling");
+constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_NBLK = PP_NCELL / SCAN_BLOCK;   // 400
+static_assert(PP_NCELL % SCAN_BLOCK == 0 && SCAN_NBLK <= 1024, "scan tiling");
+
+constexpr int V2_TS = 32;                       // tile edge in cells
+constexpr int V2_NT = PP_NX / V2_TS;            // 20 tiles per axis
+constexpr int V2_NTILES = V2_NT * V2_NT;        // 400
+constexpr int V2_CH = 4096;                     // history points per route chunk
+constexpr int V2_LMAX = 6144;                   // live points (tile + halo) held in LDS
+constexpr int V2_W = V2_TS + 2;                 // local tile width incl. halo (34)
+static_assert(PP_NX % V2_TS == 0 && PP_NX == PP_NY, "tiling");
 
 // ---- live-scan index build -------------------------------------------------
+// bbox words (zero-initialised): max key(x), max ~key(x), max key(y), max ~key(y)
+__device__ __forceinline__ unsigned pp_fkey(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float pp_fkey_inv(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
 
-__global__ __launch_bounds__(1024) void pp_live_bbox(const float *__restrict__ live, int n,
-                                                     double c, PPGrid *g) {
-    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float x = live[3 * (size_t)i], y = live[3 * (size_t)i + 1];
-        mnx = fminf(mnx, x);
-        mxx = fmaxf(mxx, x);
-        mny = fminf(mny, y);
-        mxy = fmaxf(mxy, y);
+__device__ __forceinline__ PPGrid pp_grid(const unsigned *bb, double c) {
+    const float mxx = pp_fkey_inv(bb[0]), mnx = pp_fkey_inv(~bb[1]);
+    const float mxy = pp_fkey_inv(bb[2]), mny = pp_fkey_inv(~bb[3]);
+    double cx = 0.5 * ((double)mnx + (double)mxx);
+    double cy = 0.5 * ((double)mny + (double)mxy);
+    if (!(cx == cx) || fabs(cx) > 1e30) cx = 0.0;   // NaN / inf guard
+    if (!(cy == cy) || fabs(cy) > 1e30) cy = 0.0;
+    PPGrid g;
+    g.ox = cx - 0.5 * PP_NX * c;
+    g.oy = cy - 0.5 * PP_NY * c;
+    g.inv_c = 1.0 / c;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void pp_live_bbox(const float *__restrict__ live, int n, unsigned *bb) {
+    unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    for (int r = 0; r < 4; ++r) {   // 1024 points per block
+        const int i = blockIdx.x * 1024 + r * 256 + threadIdx.x;
+        if (i < n) {
+            const unsigned kx = pp_fkey(live[3 * (size_t)i]), ky = pp_fkey(live[3 * (size_t)i + 1]);
+            k0 = max(k0, kx);
+            k1 = max(k1, ~kx);
+            k2 = max(k2, ky);
+            k3 = max(k3, ~ky);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
-        mnx = fminf(mnx, __shfl_xor(mnx, o));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o));
-        mny = fminf(mny, __shfl_xor(mny, o));
-        mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+        k0 = max(k0, (unsigned)__shfl_xor((int)k0, o));
+        k1 = max(k1, (unsigned)__shfl_xor((int)k1, o));
+        k2 = max(k2, (unsigned)__shfl_xor((int)k2, o));
+        k3 = max(k3, (unsigned)__shfl_xor((int)k3, o));
     }
-    __shared__ float s[4][16];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) {
-        s[0][w] = mnx;
-        s[1][w] = mxx;
-        s[2][w] = mny;
-        s[3][w] = mxy;
+    __shared__ unsigned red[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w] = k0;
+        red[1][w] = k1;
+        red[2][w] = k2;
+        red[3][w] = k3;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
-            s[0][0] = fminf(s[0][0], s[0][k]);
-            s[1][0] = fmaxf(s[1][0], s[1][k]);
-            s[2][0] = fminf(s[2][0], s[2][k]);
-            s[3][0] = fmaxf(s[3][0], s[3][k]);
-        }
-        double cx = 0.5 * ((double)s[0][0] + (double)s[1][0]);
-        double cy = 0.5 * ((double)s[2][0] + (double)s[3][0]);
-        if (!(cx == cx) || fabs(cx) > 1e30) cx = 0.0;  // NaN / inf guard
-        if (!(cy == cy) || fabs(cy) > 1e30) cy = 0.0;
-        g->ox = cx - 0.5 * PP_NX * c;
-        g->oy = cy - 0.5 * PP_NY * c;
-        g->inv_c = 1.0 / c;
+    if (threadIdx.x < 4) {   // one atomic per word per block (same-address atomics cost ~12 ns each)
+        const unsigned m = max(max(red[threadIdx.x][0], red[threadIdx.x][1]),
+                               max(red[threadIdx.x][2], red[threadIdx.x][3]));
+        atomicMax(&bb[threadIdx.x], m);
     }
 }
 
-__global__ void pp_live_count(const float *__restrict__ live, int n, const PPGrid *g,
-                              unsigned *cellCount, unsigned *bitmap) {
+__global__ void pp_live_count(const float *__restrict__ live, int n, const unsigned *bb, double c,
+                              unsigned *cellCount) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double ox = g->ox, oy = g->oy, inv = g->inv_c;
-    const int cx = pp_cell_coord(live[3 * (size_t)i], ox, inv, PP_NX);
-    const int cy = pp_cell_coord(live[3 * (size_t)i + 1], oy, inv, PP_NY);
+    const PPGrid g = pp_grid(bb, c);
+    const int cx = pp_cell_coord(live[3 * (size_t)i], g.ox, g.inv_c, PP_NX);
+    const int cy = pp_cell_coord(live[3 * (size_t)i + 1], g.oy, g.inv_c, PP_NY);
     atomicAdd(&cellCount[cy * PP_NX + cx], 1u);
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy)
-        for (int xx = max(cx - 1, 0); xx <= min(cx + 1, PP_NX - 1); ++xx) {
-            const int bit = yy * PP_NX + xx;
-            atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+}
+
+// Dilated occupancy bitmap: bit(cell) = any live point in the 3x3 cells around it.
+// One thread per 32-cell word, built from the cell counters (no atomics).
+static_assert(PP_NX % 32 == 0, "bitmap words must not wrap rows");
+__global__ void pp_bitmap(const unsigned *__restrict__ cellCount, unsigned *__restrict__ bitmap) {
+    const int wid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wid >= PP_BITWORDS) return;
+    const int cy = (wid * 32) / PP_NX, cx0 = (wid * 32) % PP_NX;
+    unsigned long long occ = 0;   // bit (k+1): column cx0+k occupied in any of the 3 rows, k = -1..32
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
+        const unsigned *row = cellCount + (size_t)yy * PP_NX;
+        for (int k = -1; k <= 32; ++k) {
+            const int x = cx0 + k;
+            if (x >= 0 && x < PP_NX && row[x]) occ |= 1ULL << (k + 1);
         }
+    }
+    // output bit k (column cx0+k) = occ bits k, k+1, k+2 (columns k-1, k, k+1)
+    const unsigned long long dil = occ | (occ >> 1) | (occ >> 2);
+    bitmap[wid] = (unsigned)(dil & 0xffffffffULL);
 }
 
-// Exclusive scan of the PP_NCELL cell counters (one workgroup; the table is
-// 1.6 MB and L2 resident, this is a few microseconds of a 30 k-point prologue).
-__global__ __launch_bounds__(SCAN_THREADS) void pp_cell_scan(const unsigned *__restrict__ cnt,
-                                                             unsigned *__restrict__ start) {
-    __shared__ unsigned part[SCAN_THREADS];
-    const int tid = threadIdx.x;
-    const unsigned *p = cnt + (size_t)tid * SCAN_PER;
-    unsigned s = 0;
-    for (int k = 0; k < SCAN_PER; ++k) s += p[k];
-    part[tid] = s;
+// Exclusive scan of the cell counters in two coalesced launches.
+__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_blocks(const unsigned *__restrict__ cnt,
+                                                             unsigned *__restrict__ start,
+                                                             unsigned *__restrict__ blockSum) {
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + tid;
+    const unsigned v = cnt[i];
+    unsigned inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    for (int o = 1; o < SCAN_THREADS; o <<= 1) {
-        unsigned v = (tid >= o) ? part[tid - o] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    unsigned run = part[tid] - s;  // exclusive prefix of this thread's segment
-    unsigned *q = start + (size_t)tid * SCAN_PER;
-    for (int k = 0; k < SCAN_PER; ++k) {
-        q[k] = run;
-        run += p[k];
-    }
-    if (tid == SCAN_THREADS - 1) start[PP_NCELL] = run;
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    start[i] = base + inc - v;   // block-local exclusive prefix
+    if (tid == SCAN_BLOCK - 1) blockSum[blockIdx.x] = base + inc;
 }
 
-__global__ void pp_live_scatter(const float *__restrict__ live, int n, const PPGrid *g,
+__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_finish(unsigned *__restrict__ start,
+                                                             const unsigned *__restrict__ blockSum) {
+    __shared__ unsigned red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned v = (tid < (int)blockIdx.x) ? blockSum[tid] : 0u;   // sums of the earlier blocks
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    unsigned off = 0;
+    for (int k = 0; k < 16; ++k) off += red[k];
+    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + tid;
+    start[i] += off;
+    if (blockIdx.x == SCAN_NBLK - 1 && tid == SCAN_BLOCK - 1) start[PP_NCELL] = off + blockSum[SCAN_NBLK - 1];
+}
+
+__global__ void pp_live_scatter(const float *__restrict__ live, int n, const unsigned *bb, double c,
                                 const unsigned *__restrict__ start, unsigned *fill,
                                 float4 *__restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double ox = g->ox, oy = g->oy, inv = g->inv_c;
+    const PPGrid g = pp_grid(bb, c);
     const float x = live[3 * (size_t)i], y = live[3 * (size_t)i + 1], z = live[3 * (size_t)i + 2];
-    const int cell = pp_cell_coord(y, oy, inv, PP_NY) * PP_NX + pp_cell_coord(x, ox, inv, PP_NX);
+    const int cell = pp_cell_coord(y, g.oy, g.inv_c, PP_NY) * PP_NX + pp_cell_coord(x, g.ox, g.inv_c, PP_NX);
     const unsigned slot = start[cell] + atomicAdd(&fill[cell], 1u);
     sorted[slot] = make_float4(x, y, z, __int_as_float(i));
 }
 
-// ---- history stream --------------------------------------------------------
-
+// ---- V1 history stream (kept for A/B: MODEST_PP_VARIANT=1) ---------------------
 __device__ __forceinline__ int pp_find_trav(const TravOffsets &tr, long long p) {
     int t = 0;
     while (t + 1 < tr.n && p >= tr.off[t + 1]) ++t;
     return t;
 }
 
-__device__ __forceinline__ void pp_process_point(float x, float y, float z, long long p,
-                                                 const unsigned *sbits, double ox, double oy,
-                                                 double inv, const TravOffsets &tr,
-                                                 const unsigned *__restrict__ cellStart,
-                                                 const float4 *__restrict__ sorted,
-                                                 int *counts, int T, double r2) {
-    const int cx = pp_cell_coord(x, ox, inv, PP_NX);
-    const int cy = pp_cell_coord(y, oy, inv, PP_NY);
-    const int bit = cy * PP_NX + cx;
-    if (!((sbits[bit >> 5] >> (bit & 31)) & 1u)) return;
-    const int t = pp_find_trav(tr, p);
-    const double hx = x, hy = y, hz = z;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, PP_NX - 1);
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
-        const unsigned s = cellStart[yy * PP_NX + x0];
-        const unsigned e = cellStart[yy * PP_NX + x1 + 1];
-        for (unsigned j = s; j < e; ++j) {
-            const float4 q = sorted[j];
-            if (pp_within(hx, hy, hz, q.x, q.y, q.z, r2))
-                atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + t], 1);
+__global__ __launch_bounds__(256) void pp_stream_v1(const float *__restrict__ hist, long long m0,
+                                                    long long m1, TravOffsets tr, const unsigned *bb,
+                                                    double c, const unsigned *__restrict__ bitmap,
+                                                    const unsigned *__restrict__ cellStart,
+                                                    const float4 *__restrict__ sorted, int *counts,
+                                                    int T, double r2) {
+    __shared__ unsigned sbits[PP_BITWORDS];
+    for (int i = threadIdx.x; i < PP_BITWORDS; i += 256) sbits[i] = bitmap[i];
+    __syncthreads();
+    const PPGrid g = pp_grid(bb, c);
+    for (long long p = m0 + (long long)blockIdx.x * 256 + threadIdx.x; p < m1; p += (long long)gridDim.x * 256) {
+        const float x = hist[3 * p], y = hist[3 * p + 1], z = hist[3 * p + 2];
+        const int cx = pp_cell_coord(x, g.ox, g.inv_c, PP_NX), cy = pp_cell_coord(y, g.oy, g.inv_c, PP_NY);
+        const int bit = cy * PP_NX + cx;
+        if (!((sbits[bit >> 5] >> (bit & 31)) & 1u)) continue;
+        const int t = pp_find_trav(tr, p);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, PP_NX - 1);
+        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
+            const unsigned s = cellStart[yy * PP_NX + x0], e = cellStart[yy * PP_NX + x1 + 1];
+            for (unsigned j = s; j < e; ++j) {
+                const float4 q = sorted[j];
+                if (pp_within(x, y, z, q.x, q.y, q.z, r2))
+                    atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + t], 1);
+            }
         }
     }
 }
 
-// One lane owns 4 consecutive history points = 48 contiguous bytes, read as
-// three 16-byte loads when the base is 16-byte aligned.
-template <bool ALIGNED16>
-__global__ __launch_bounds__(256) void pp_stream_v1(const float *__restrict__ hist, long long m0,
-                                                    long long m1, TravOffsets tr,
-                                                    const PPGrid *g,
-                                                    const unsigned *__restrict__ bitmap,
-                                                    const unsigned *__restrict__ cellStart,
-                                                    const float4 *__restrict__ sorted,
-                                                    int *counts, int T, double r2) {
+// ---- V2 route (K1) ---------------------------------------------------------------
+struct ChunkMap {
+    int cstart[PP_MAX_TRAV + 1];   // first chunk id of each traversal (chunks never straddle)
+};
+
+__global__ __launch_bounds__(1024) void pp2_route(const float *__restrict__ hist, TravOffsets tr,
+                                                  ChunkMap cm, int nchunks, const unsigned *bb, double c,
+                                                  const unsigned *__restrict__ bitmap,
+                                                  float4 *__restrict__ rec, uint2 *__restrict__ desc,
+                                                  unsigned *descCount, unsigned *descRecs, int T,
+                                                  int maxDesc) {
     __shared__ unsigned sbits[PP_BITWORDS];
-    for (int i = threadIdx.x; i < PP_BITWORDS; i += 256) sbits[i] = bitmap[i];
-    __syncthreads();
-    const double ox = g->ox, oy = g->oy, inv = g->inv_c;
-    const long long M = m1 - m0;
-    const long long nchunks = (M + 1023) / 1024;
-    for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const long long p0 = m0 + chunk * 1024 + (long long)threadIdx.x * 4;
-        if (p0 >= m1) continue;
+    __shared__ float4 stage[V2_CH];
+    __shared__ unsigned thist[V2_NTILES];
+    __shared__ unsigned tbase[V2_NTILES + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < PP_BITWORDS; i += 1024) sbits[i] = bitmap[i];
+    const PPGrid g = pp_grid(bb, c);
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        int t = 0;
+        while (t + 1 < tr.n && chunk >= cm.cstart[t + 1]) ++t;
+        const long long p0 = tr.off[t] + (long long)(chunk - cm.cstart[t]) * V2_CH;
+        const long long pend = min(tr.off[t + 1], p0 + V2_CH);
+        if (tid < V2_NTILES) thist[tid] = 0;
+        __syncthreads();   // also orders the bitmap load before its first use
+        const long long q0 = p0 + 4LL * tid;
         float v[12];
-        if (ALIGNED16 && p0 + 4 <= m1) {
-            const float4 *src = reinterpret_cast<const float4 *>(hist + 3 * p0);
-            const float4 a = src[0], b = src[1], c = src[2];
+        const float *src = hist + 3 * q0;
+        if (q0 + 4 <= pend && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            const float4 a = s4[0], b = s4[1], d = s4[2];
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
             v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+            v[8] = d.x; v[9] = d.y; v[10] = d.z; v[11] = d.w;
         } else {
-            const long long left = m1 - p0;
-            for (int k = 0; k < 12; ++k) v[k] = (k / 3 < left) ? hist[3 * p0 + k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = (q0 + k / 3 < pend) ? src[k] : 0.f;
         }
+        int tile[4], rank[4], lcell[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (p0 + k < m1)
-                pp_process_point(v[3 * k], v[3 * k + 1], v[3 * k + 2], p0 + k, sbits, ox, oy, inv,
-                                 tr, cellStart, sorted, counts, T, r2);
+            rank[k] = -1;
+            tile[k] = 0;
+            lcell[k] = 0;
+            if (q0 + k < pend) {
+                const int cx = pp_cell_coord(v[3 * k], g.ox, g.inv_c, PP_NX);
+                const int cy = pp_cell_coord(v[3 * k + 1], g.oy, g.inv_c, PP_NY);
+                const int bit = cy * PP_NX + cx;
+                if ((sbits[bit >> 5] >> (bit & 31)) & 1u) {
+                    tile[k] = (cy / V2_TS) * V2_NT + (cx / V2_TS);
+                    lcell[k] = ((cy % V2_TS) << 8) | (cx % V2_TS);   // cell inside the tile, reused by pp2_tiles
+                    rank[k] = (int)atomicAdd(&thist[tile[k]], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {   // one wavefront scans the 400 tile counters (7 per lane)
+            unsigned loc[7], s = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int i = tid * 7 + j;
+                loc[j] = (i < V2_NTILES) ? thist[i] : 0u;
+                s += loc[j];
+            }
+            unsigned inc = s;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(inc, o);
+                if (tid >= o) inc += u;
+            }
+            unsigned run = inc - s;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int i = tid * 7 + j;
+                if (i < V2_NTILES) tbase[i] = run;
+                run += loc[j];
+            }
+            if (tid == 63) tbase[V2_NTILES] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (rank[k] >= 0)
+                stage[tbase[tile[k]] + rank[k]] = make_float4(v[3 * k], v[3 * k + 1], v[3 * k + 2], __int_as_float(lcell[k]));
+        __syncthreads();
+        const unsigned total = tbase[V2_NTILES];
+        float4 *dst = rec + (size_t)chunk * V2_CH;
+        for (unsigned i = tid; i < total; i += 1024) dst[i] = stage[i];
+        if (tid < V2_NTILES && thist[tid] > 0) {
+            const unsigned list = (unsigned)tid * T + t;
+            const unsigned d = atomicAdd(&descCount[list], 1u);
+            atomicAdd(&descRecs[list], thist[tid]);
+            desc[(size_t)list * maxDesc + d] = make_uint2((unsigned)chunk * V2_CH + tbase[tid], thist[tid]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- V2 work list -------------------------------------------------------------------
+// items[i]   = (list, part | nparts << 16): a (tile, traversal) list, split into parts of
+//              similar estimated cost;
+// entries    = runs of consecutive items of ONE tile with bounded cost: the dequeue unit of
+//              pp2_tiles (entryBegin[e] .. entryBegin[e+1]);
+// cost model = records x (32 + live points of the tile): candidates per record grow with the
+//              local live density, and a record count alone left the dense centre tiles
+//              10x heavier than the rest.
+// ctrl[0] = #items, ctrl[1] = dequeue head, ctrl[2] = #entries.
+__device__ __forceinline__ unsigned long long pp2_block_scan64(unsigned long long v, unsigned long long *sh,
+                                                               int tid) {   // inclusive, 1024 threads
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned long long u = (tid >= o) ? sh[tid - o] : 0ULL;
+        __syncthreads();
+        sh[tid] += u;
+        __syncthreads();
+    }
+    return sh[tid];
+}
+
+__global__ __launch_bounds__(1024) void pp2_worklist(const unsigned *__restrict__ descCount,
+                                                     const unsigned *__restrict__ descRecs,
+                                                     const unsigned *__restrict__ cellStart, int nLists,
+                                                     int T, int nWorkers, uint2 *__restrict__ items,
+                                                     unsigned long long *__restrict__ itemPre,
+                                                     unsigned *__restrict__ entryBegin, unsigned maxItems,
+                                                     unsigned *ctrl) {
+    __shared__ unsigned long long sh[1024];
+    __shared__ unsigned tileL[V2_NTILES];
+    __shared__ unsigned long long s_carry, s_itemT, s_entryT;
+    __shared__ unsigned s_carryK;
+    const int tid = threadIdx.x;
+    if (tid < V2_NTILES) {
+        const int x0 = (tid % V2_NT) * V2_TS - 1, y0 = (tid / V2_NT) * V2_TS - 1;
+        const int gx0 = max(x0, 0), gx1 = min(x0 + V2_W, PP_NX);
+        unsigned L = 0;
+        for (int r = 0; r < V2_W; ++r) {
+            const int gy = y0 + r;
+            if (gy >= 0 && gy < PP_NY) L += cellStart[gy * PP_NX + gx1] - cellStart[gy * PP_NX + gx0];
+        }
+        tileL[tid] = L;
+    }
+    __syncthreads();
+    unsigned long long tot = 0, totR = 0;
+    for (int l = tid; l < nLists; l += 1024) {
+        tot += (unsigned long long)descRecs[l] * (32u + tileL[l / T]);
+        totR += descRecs[l];
+    }
+    const unsigned long long totalRecs = pp2_block_scan64(totR, sh, tid);
+    __syncthreads();
+    const unsigned long long total = pp2_block_scan64(tot, sh, tid);
+    if (tid == 1023) {
+        // an item is at most one LDS chunk of records (the per-chunk cost of pp2_tiles grows with
+        // the tile's live points, so small parts are wasteful); entries balance the estimated cost
+        unsigned long long tI = 4096ULL;
+        const unsigned long long floorT = totalRecs / (unsigned long long)(maxItems - (unsigned)nLists) + 1ULL;
+        if (tI < floorT) tI = floorT;   // never more than maxItems items
+        s_itemT = tI;
+        s_entryT = total / ((unsigned long long)nWorkers * 8ULL) + 1ULL;
+        s_carry = 0;
+        s_carryK = 0;
+    }
+    __syncthreads();
+    const unsigned long long itemT = s_itemT, entryT = s_entryT;
+    for (int base = 0; base < nLists; base += 1024) {
+        const int l = base + tid;
+        unsigned k = 0;
+        unsigned long long wl = 0;
+        if (l < nLists && descCount[l] > 0) {
+            wl = (unsigned long long)descRecs[l] * (32u + tileL[l / T]);
+            const unsigned long long kk = ((unsigned long long)descRecs[l] + itemT - 1) / itemT;
+            k = (unsigned)max(1ULL, min(kk, (unsigned long long)min(descCount[l], 65535u)));
+        }
+        const unsigned long long wItem = k ? wl / k : 0ULL;
+        // two scans: item slots (k) and weights (k * wItem); pack k in the scan of a second array
+        const unsigned long long incW = pp2_block_scan64((unsigned long long)k * wItem, sh, tid);
+        __syncthreads();
+        const unsigned long long incK = pp2_block_scan64((unsigned long long)k, sh, tid);
+        const unsigned start = s_carryK + (unsigned)(incK - k);
+        const unsigned long long wstart = s_carry + incW - (unsigned long long)k * wItem;
+        for (unsigned s = 0; s < k; ++s) {
+            items[start + s] = make_uint2((unsigned)l, s | (k << 16));
+            itemPre[start + s] = wstart + (unsigned long long)s * wItem;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            s_carryK += (unsigned)incK;
+            s_carry += incW;
+        }
+        __syncthreads();
+    }
+    const unsigned nItems = s_carryK;
+    __threadfence_block();
+    __syncthreads();
+    // entries: cut where the tile changes or the cost prefix crosses a multiple of entryT
+    unsigned ecarry = 0;
+    for (unsigned base = 0; base < nItems; base += 1024) {
+        const unsigned i = base + tid;
+        unsigned flag = 0;
+        if (i < nItems) {
+            if (i == 0) flag = 1;
+            else {
+                const int ta = (int)(items[i].x) / T, tb = (int)(items[i - 1].x) / T;
+                flag = (ta != tb) || (itemPre[i] / entryT != itemPre[i - 1] / entryT) || ((i & 63u) == 0u);
+            }
+        }
+        const unsigned inc = (unsigned)pp2_block_scan64(flag, sh, tid);
+        if (flag) entryBegin[ecarry + inc - 1] = i;
+        __syncthreads();
+        ecarry += (unsigned)sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        entryBegin[ecarry] = nItems;
+        ctrl[0] = nItems;
+        ctrl[1] = 0;
+        ctrl[2] = ecarry;
+    }
+}
+
+// ---- V2 tiles (K2) ------------------------------------------------------------------
+// Join of a tile's live points with the history records routed to it.
+//
+// A workgroup dequeues one ENTRY (<= 64 consecutive work items of one tile); item headers
+// and up to 1024 run descriptors at a time are staged in LDS, so an entry costs four
+// dependent global round trips (entry -> items -> descriptors -> records).
+//
+// The join is LIVE-point centric: every thread keeps up to V2_LPT live points of the tile
+// (+1 cell halo) in REGISTERS together with their hit counters; the records of the current
+// (tile, traversal) list are pulled in chunks of V2_RC, counting-sorted by cell INSIDE LDS,
+// and each live point walks the three sorted row segments of its 3x3 cell neighbourhood.
+// Neighbouring lanes own neighbouring live points (the live scan is cell sorted), so they
+// walk nearly the same records: LDS reads are mostly broadcasts, trip counts are coherent
+// across a wavefront, and there are no atomics and no per-pair index arithmetic.  Counters
+// are flushed (one global atomic per non-zero counter) when the list changes.
+constexpr int V2_RPT = 4;                     // records per thread per chunk
+constexpr int V2_RC = 1024 * V2_RPT;          // records sorted in LDS at a time
+constexpr int V2_LPT = V2_LMAX / 1024;        // live points per thread (6)
+constexpr int V2_DC = 1024;                   // run descriptors staged per chunk
+constexpr int V2_EI = 64;                     // max items per entry
+constexpr int V2_NC = V2_W * V2_W;            // local cells incl. halo (1156)
+static_assert(V2_NC <= 2048, "cell scan handles two cells per thread");
+
+// exact float64 predicate, kept out of line so that the hot loop stays small
+__device__ __noinline__ bool pp2_exact(float hx, float hy, float hz, float qx, float qy, float qz, double r2) {
+    return pp_within(hx, hy, hz, qx, qy, qz, r2);
+}
+
+// inclusive block scan (1024 threads) with two barriers; *total receives the block sum
+__device__ __forceinline__ unsigned pp2_scan_u32(unsigned v, unsigned *wsum /* 16 */, int tid, unsigned *total) {
+    const int lane = tid & 63, w = tid >> 6;
+    unsigned inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();   // wsum free
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+        const unsigned s = wsum[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc;
+}
+
+__global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec,
+                                                  const uint2 *__restrict__ desc,
+                                                  const unsigned *__restrict__ descCount,
+                                                  const uint2 *__restrict__ items,
+                                                  const unsigned *__restrict__ entryBegin, unsigned *ctrl,
+                                                  const unsigned *bb, double c,
+                                                  const unsigned *__restrict__ cellStart,
+                                                  const float4 *__restrict__ sorted, int *counts, int T,
+                                                  int maxDesc, double r2, int dbg) {
+    __shared__ float4 srec[V2_RC];              // records of the chunk, sorted by local cell
+    __shared__ unsigned hist[V2_NC + 4], cpre[V2_NC + 4];
+    __shared__ unsigned segStart[V2_W], segLen[V2_W], rowBase[V2_W + 1];
+    __shared__ unsigned dOff[V2_DC], dPre[V2_DC + 1];
+    __shared__ unsigned iList[V2_EI], iDa[V2_EI], iBase[V2_EI + 1];
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned s_item;
+    __shared__ int s_L;
+    const int tid = threadIdx.x;
+    const PPGrid g = pp_grid(bb, c);
+    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    const unsigned nEntries = ctrl[2];
+    // live points owned by this thread (element e = tid + 1024*k of the tile's live list)
+    float qx[V2_LPT], qy[V2_LPT], qz[V2_LPT];
+    int qidx[V2_LPT], qcell[V2_LPT];   // original index; local cell row*V2_W+col, or -1
+    unsigned qcnt[V2_LPT];
+#pragma unroll
+    for (int k = 0; k < V2_LPT; ++k) {
+        qcell[k] = -1;
+        qcnt[k] = 0;
+        qx[k] = qy[k] = qz[k] = 0.f;
+        qidx[k] = 0;
+    }
+    int curTile = -1, L = 0;
+    bool fits = false;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_item = atomicAdd(&ctrl[1], 1u);
+        __syncthreads();
+        const unsigned ent = s_item;
+        if (ent >= nEntries) break;
+        const unsigned ib = entryBegin[ent];
+        const int nI = (int)(entryBegin[ent + 1] - ib);   // <= V2_EI
+        if (tid < 64) {   // item headers -> descriptor ranges, one wavefront
+            unsigned nd = 0, list = 0, da = 0;
+            if (tid < nI) {
+                const uint2 wi = items[ib + tid];
+                list = wi.x;
+                const unsigned part = wi.y & 0xffffu, nparts = wi.y >> 16;
+                const unsigned nd_all = descCount[list];
+                da = (unsigned)(((unsigned long long)nd_all * part) / nparts);
+                nd = (unsigned)(((unsigned long long)nd_all * (part + 1)) / nparts) - da;
+            }
+            unsigned inc = nd;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(inc, o);
+                if (tid >= o) inc += u;
+            }
+            iList[tid] = list;
+            iDa[tid] = da;
+            iBase[tid] = inc - nd;
+            if (tid == 63) iBase[V2_EI] = inc;
+        }
+        __syncthreads();
+        const unsigned ND = iBase[V2_EI];
+        const int tile = (int)iList[0] / T;
+        const int x0 = (tile % V2_NT) * V2_TS - 1, y0 = (tile / V2_NT) * V2_TS - 1;
+        if (tile != curTile) {   // (all counters are zero here: they are flushed at the end of an entry)
+            const int gx0 = max(x0, 0), gx1 = min(x0 + V2_W, PP_NX);
+            if (tid < V2_W) {
+                const int gy = y0 + tid;
+                unsigned s = 0, e = 0;
+                if (gy >= 0 && gy < PP_NY) {
+                    s = cellStart[gy * PP_NX + gx0];
+                    e = cellStart[gy * PP_NX + gx1];
+                }
+                segStart[tid] = s;
+                segLen[tid] = e - s;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned run = 0;
+                for (int r = 0; r < V2_W; ++r) {
+                    rowBase[r] = run;
+                    run += segLen[r];
+                }
+                rowBase[V2_W] = run;
+                s_L = (int)run;
+            }
+            __syncthreads();
+            L = s_L;
+            fits = L <= V2_LMAX;
+#pragma unroll
+            for (int k = 0; k < V2_LPT; ++k) {
+                const int e = tid + 1024 * k;
+                qcell[k] = -1;
+                if (fits && e < L) {
+                    int r = 0;
+                    while (e >= (int)rowBase[r + 1]) ++r;
+                    const float4 q = sorted[segStart[r] + (e - rowBase[r])];
+                    qx[k] = q.x;
+                    qy[k] = q.y;
+                    qz[k] = q.z;
+                    qidx[k] = __float_as_int(q.w);
+                    const int lcx = pp_cell_coord(q.x, g.ox, g.inv_c, PP_NX) - x0;   // 0 .. V2_W-1
+                    qcell[k] = r * V2_W + lcx;
+                }
+            }
+            curTile = tile;
+        }
+        int curList = -1, curT = 0;
+        for (unsigned dc = 0; dc < ND; dc += V2_DC) {
+            const unsigned ndc = min((unsigned)V2_DC, ND - dc);
+            // stage run descriptors dc .. dc+ndc
+            unsigned myCnt = 0;
+            __syncthreads();   // previous chunk's dOff / dPre no longer read
+            if ((unsigned)tid < ndc) {
+                const unsigned gd = dc + tid;
+                int lo = 0, hi = nI - 1;   // last k with iBase[k] <= gd
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (iBase[mid] <= gd) lo = mid; else hi = mid - 1;
+                }
+                const uint2 d = desc[(size_t)iList[lo] * maxDesc + iDa[lo] + (gd - iBase[lo])];
+                dOff[tid] = d.x;
+                myCnt = d.y;
+            }
+            unsigned totalRecs;
+            const unsigned inc = pp2_scan_u32(myCnt, wsum, tid, &totalRecs);
+            dPre[tid] = inc - myCnt;
+            if (tid == 1023) dPre[V2_DC] = totalRecs;
+            __syncthreads();
+            // lists (runs of items with the same list id) that own descriptors of this chunk
+            int k = 0;
+            while (k + 1 < nI && iBase[k + 1] <= dc) ++k;
+            while (k < nI && iBase[k] < dc + ndc) {
+                const int list = (int)iList[k];
+                int k2 = k;
+                while (k2 + 1 < nI && (int)iList[k2 + 1] == list && iBase[k2 + 1] < dc + ndc) ++k2;
+                const unsigned dlo = max(iBase[k], dc) - dc, dhi = min(iBase[k2 + 1], dc + ndc) - dc;
+                k = k2 + 1;
+                if (dhi <= dlo) continue;
+                if (list != curList) {   // flush the counters of the finished list
+                    if (curList >= 0) {
+#pragma unroll
+                        for (int q = 0; q < V2_LPT; ++q)
+                            if (qcnt[q]) {
+                                if (!(dbg & 1)) atomicAdd(&counts[(size_t)qidx[q] * T + curT], (int)qcnt[q]);
+                                qcnt[q] = 0;
+                            }
+                    }
+                    curList = list;
+                    curT = list - tile * T;
+                }
+                const unsigned r0 = dPre[dlo], r1 = dPre[dhi];   // dPre[V2_DC] holds the total
+                for (unsigned cb = r0; cb < r1; cb += V2_RC) {
+                    const unsigned cend = min(cb + (unsigned)V2_RC, r1);
+                    // (a) pull this thread's records
+                    float4 hh[V2_RPT];
+                    bool vv[V2_RPT];
+#pragma unroll
+                    for (int u = 0; u < V2_RPT; ++u) {
+                        const unsigned j = cb + 1024u * u + tid;
+                        vv[u] = j < cend;
+                        hh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (vv[u]) {
+                            int lo = (int)dlo, hi = (int)dhi - 1;   // last d with dPre[d] <= j
+                            while (lo < hi) {
+                                const int mid = (lo + hi + 1) >> 1;
+                                if (dPre[mid] <= j) lo = mid; else hi = mid - 1;
+                            }
+                            hh[u] = rec[dOff[lo] + (j - dPre[lo])];
+                        }
+                    }
+                    if (!fits) {   // tile too dense for the register/LDS join: global index, global atomics
+#pragma unroll
+                        for (int u = 0; u < V2_RPT; ++u)
+                            if (vv[u]) {
+                                const float4 h = hh[u];
+                                const int pk = __float_as_int(h.w);
+                                const int cx = x0 + 1 + (pk & 255), cy = y0 + 1 + (pk >> 8);
+                                const int xa = max(cx - 1, 0), xb = min(cx + 1, PP_NX - 1);
+                                for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
+                                    const unsigned a = cellStart[yy * PP_NX + xa], b = cellStart[yy * PP_NX + xb + 1];
+                                    for (unsigned i = a; i < b; ++i) {
+                                        const float4 q = sorted[i];
+                                        if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2))
+                                            atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + curT], 1);
+                                    }
+                                }
+                            }
+                        continue;
+                    }
+                    // (b) counting sort of the chunk by local cell
+                    __syncthreads();   // previous chunk's join is done with srec / cpre
+                    for (int e = tid; e < V2_NC + 4; e += 1024) hist[e] = 0;
+                    __syncthreads();
+                    unsigned rank[V2_RPT];
+                    int lc[V2_RPT];
+#pragma unroll
+                    for (int u = 0; u < V2_RPT; ++u) {
+                        rank[u] = 0;
+                        lc[u] = 0;
+                        if (vv[u]) {
+                            const int pk = __float_as_int(hh[u].w);
+                            lc[u] = ((pk >> 8) + 1) * V2_W + (pk & 255) + 1;
+                            rank[u] = atomicAdd(&hist[lc[u]], 1u);
+                        }
+                    }
+                    __syncthreads();
+                    {   // exclusive scan of the 1156 cell counters, two cells per thread
+                        const unsigned v0 = (2 * tid < V2_NC) ? hist[2 * tid] : 0u;
+                        const unsigned v1 = (2 * tid + 1 < V2_NC) ? hist[2 * tid + 1] : 0u;
+                        unsigned tot;
+                        const unsigned in2 = pp2_scan_u32(v0 + v1, wsum, tid, &tot);
+                        if (2 * tid < V2_NC + 2) {
+                            cpre[2 * tid] = in2 - v0 - v1;
+                            cpre[2 * tid + 1] = in2 - v1;
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < V2_RPT; ++u)
+                        if (vv[u]) srec[cpre[lc[u]] + rank[u]] = hh[u];
+                    __syncthreads();
+                    // (c) join: every owned live point walks its 3x3 neighbourhood of sorted records
+                    if (!(dbg & 2)) {
+#pragma unroll
+                        for (int q = 0; q < V2_LPT; ++q) {
+                            if (qcell[q] < 0) continue;
+                            const int row = qcell[q] / V2_W, col = qcell[q] - row * V2_W;
+                            const int c0 = max(col - 1, 0), c1 = min(col + 1, V2_W - 1);
+                            unsigned hits = 0;
+                            for (int rr = max(row - 1, 0); rr <= min(row + 1, V2_W - 1); ++rr) {
+                                const unsigned a = cpre[rr * V2_W + c0], b = cpre[rr * V2_W + c1 + 1];
+                                for (unsigned i = a; i < b; ++i) {
+                                    const float4 h = srec[i];
+                                    const float fx = qx[q] - h.x, fy = qy[q] - h.y, fz = qz[q] - h.z;
+                                    const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                                    bool hit = d2 < r2lo;
+                                    if (!hit && d2 <= r2hi) hit = pp2_exact(h.x, h.y, h.z, qx[q], qy[q], qz[q], r2);
+                                    hits += hit ? 1u : 0u;
+                                }
+                            }
+                            qcnt[q] += hits;
+                        }
+                    }
+                }
+            }
+        }
+        // end of the entry: flush (counters return to zero)
+        if (curList >= 0) {
+#pragma unroll
+            for (int q = 0; q < V2_LPT; ++q)
+                if (qcnt[q]) {
+                    if (!(dbg & 1)) atomicAdd(&counts[(size_t)qidx[q] * T + curT], (int)qcnt[q]);
+                    qcnt[q] = 0;
+                }
         }
     }
 }
 
 // ---- entropy ---------------------------------------------------------------
-
 __device__ __forceinline__ double pp_term(int c, double denom) {
     const double P = (double)c / denom;
     return (-P) * log(P + 1e-8);
@@ -252,9 +811,30 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     if (rc) return rc;
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + PP_BITWORDS;
-    size_t need = arena_sz(sizeof(PPGrid)) + arena_sz(zero_words * 4) +
-                  arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz((size_t)n_live * 16);
+
+    // chunk map of the routed path (chunks never straddle traversals)
+    ChunkMap cm;
+    int nchunks = 0, maxDesc = 1;
+    {
+        long long nch = 0;
+        for (int t = 0; t < n_trav; ++t) {
+            cm.cstart[t] = (int)nch;
+            const long long nc = (tr.off[t + 1] - tr.off[t] + V2_CH - 1) / V2_CH;
+            nch += nc;
+            if (nc > maxDesc) maxDesc = (int)nc;
+        }
+        MODEST_REQUIRE(nch < (1LL << 19), "history too large for the routed path");
+        nchunks = (int)nch;
+        cm.cstart[n_trav] = nchunks;
+    }
+    const int nLists = V2_NTILES * n_trav;
+    const size_t maxItems = (size_t)nLists + 65536;
+    // one contiguous zero-initialised block: cellCount | fill | descCount | descRecs | ctrl[2] | bbox[4] | pad
+    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8;   // ctrl[4] bbox[4]
+    size_t need = arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
+                  arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
+                  arena_sz((size_t)nchunks * V2_CH * 16) + arena_sz((size_t)nLists * maxDesc * 8) +
+                  arena_sz(maxItems * 8) + arena_sz(maxItems * 8) + arena_sz((maxItems + 1) * 4);
     rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
     if (rc) return rc;
     if (extra) {
@@ -268,35 +848,55 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     if (m1 == m0) return MODEST_OK;
     MODEST_REQUIRE(live != nullptr && hist != nullptr, "NULL point buffer");
     Arena A(ctx->scratch);
-    PPGrid *g = A.take<PPGrid>(1);
     unsigned *zeroed = A.take<unsigned>(zero_words);
     unsigned *cellCount = zeroed;
-    unsigned *fill = zeroed + (PP_NCELL + 1);
-    unsigned *bitmap = fill + PP_NCELL;
+    unsigned *fill = cellCount + (PP_NCELL + 1);
+    unsigned *descCount = fill + PP_NCELL;
+    unsigned *descRecs = descCount + nLists;
+    unsigned *ctrl = descRecs + nLists;
+    unsigned *bb = ctrl + 4;
     unsigned *cellStart = A.take<unsigned>(PP_NCELL + 1);
+    unsigned *blockSum = A.take<unsigned>(SCAN_NBLK);
+    unsigned *bitmap = A.take<unsigned>(PP_BITWORDS);
     float4 *sorted = A.take<float4>(n_live);
+    float4 *rec = A.take<float4>((size_t)nchunks * V2_CH);
+    uint2 *desc = A.take<uint2>((size_t)nLists * maxDesc);
+    uint2 *items = A.take<uint2>(maxItems);
+    unsigned long long *itemPre = A.take<unsigned long long>(maxItems);
+    unsigned *entryBegin = A.take<unsigned>(maxItems + 1);
 
     MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
-    pp_live_bbox<<<1, 1024, 0, stream>>>(live, n_live, c, g);
     const int nb = (n_live + 255) / 256;
-    pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, g, cellCount, bitmap);
-    pp_cell_scan<<<1, SCAN_THREADS, 0, stream>>>(cellCount, cellStart);
-    pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, g, cellStart, fill, sorted);
+    pp_live_bbox<<<(n_live + 1023) / 1024, 256, 0, stream>>>(live, n_live, bb);
+    pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellCount);
+    pp_bitmap<<<(PP_BITWORDS + 255) / 256, 256, 0, stream>>>(cellCount, bitmap);
+    pp_scan_blocks<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum);
+    pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
+    pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
 
-    const long long nchunks = (m1 - m0 + 1023) / 1024;
-    long long grid = (long long)ctx->num_cus * 3;
-    if (grid > nchunks) grid = nchunks;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(hist) & 15) == 0) && ((m0 & 3) == 0);
-    modest_prof_mark(ctx, stream, 0);
-    if (aligned)
-        pp_stream_v1<true><<<(int)grid, 256, 0, stream>>>(hist, m0, m1, tr, g, bitmap, cellStart,
-                                                          sorted, counts, n_trav, r2);
-    else
-        pp_stream_v1<false><<<(int)grid, 256, 0, stream>>>(hist, m0, m1, tr, g, bitmap, cellStart,
+    const char *var_env = getenv("MODEST_PP_VARIANT");
+    const int var = var_env ? atoi(var_env) : 0;
+    if (var == 1) {   // V1, kept for A/B measurements
+        modest_prof_mark(ctx, stream, 0);
+        pp_stream_v1<<<ctx->num_cus * 3, 256, 0, stream>>>(hist, m0, m1, tr, bb, c, bitmap, cellStart,
                                                            sorted, counts, n_trav, r2);
+        modest_prof_mark(ctx, stream, 1);
+        MODEST_HIP_CHECK(hipGetLastError());
+        return MODEST_OK;
+    }
+    const char *dbg_env = getenv("MODEST_PP_DBG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const int grid1 = ctx->num_cus < nchunks ? ctx->num_cus : nchunks;
+    modest_prof_mark(ctx, stream, 0);
+    pp2_route<<<grid1, 1024, 0, stream>>>(hist, tr, cm, nchunks, bb, c, bitmap, rec, desc, descCount,
+                                          descRecs, n_trav, maxDesc);
     modest_prof_mark(ctx, stream, 1);
+    pp2_worklist<<<1, 1024, 0, stream>>>(descCount, descRecs, cellStart, nLists, n_trav, ctx->num_cus, items,
+                                         itemPre, entryBegin, (unsigned)maxItems, ctrl);
+    pp2_tiles<<<ctx->num_cus, 1024, 0, stream>>>(rec, desc, descCount, items, entryBegin, ctrl, bb, c, cellStart,
+                                                 sorted, counts, n_trav, maxDesc, r2, dbg);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
@@ -331,6 +931,6 @@ extern "C" int modest_pp_score(modest_ctx *ctx, const float *live, int n_live, c
     int rc = pp_count_impl(ctx, live, n_live, hist, trav_offsets, n_trav, radius, counts, stream_,
                            extra, &tail);
     if (rc) return rc;
-    const int32_t *c = counts ? counts : static_cast<const int32_t *>(tail);
-    return modest_pp_entropy(ctx, c, n_live, n_trav, H, stream_);
+    const int32_t *cN = counts ? counts : static_cast<const int32_t *>(tail);
+    return modest_pp_entropy(ctx, cN, n_live, n_trav, H, stream_);
 }
