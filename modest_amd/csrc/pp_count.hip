@@ -117,23 +117,33 @@ __global__ void pp_live_count(const float *__restrict__ live, int n, const unsig
 }
 
 // Dilated occupancy bitmap: bit(cell) = any live point in the 3x3 cells around it.
-// One thread per 32-cell word, built from the cell counters (no atomics).
-static_assert(PP_NX % 32 == 0, "bitmap words must not wrap rows");
-__global__ void pp_bitmap(const unsigned *__restrict__ cellCount, unsigned *__restrict__ bitmap) {
-    const int wid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (wid >= PP_BITWORDS) return;
-    const int cy = (wid * 32) / PP_NX, cx0 = (wid * 32) % PP_NX;
-    unsigned long long occ = 0;   // bit (k+1): column cx0+k occupied in any of the 3 rows, k = -1..32
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
-        const unsigned *row = cellCount + (size_t)yy * PP_NX;
-        for (int k = -1; k <= 32; ++k) {
-            const int x = cx0 + k;
-            if (x >= 0 && x < PP_NX && row[x]) occ |= 1ULL << (k + 1);
+// One block per grid row: coalesced reads of the three neighbouring counter rows,
+// wave ballots for the row's occupancy bits, shifts for the horizontal dilation.
+static_assert(PP_NX % 64 == 0 && PP_NX <= 1024, "one thread per cell of a row, whole wavefronts");
+__global__ __launch_bounds__(PP_NX) void pp_bitmap(const unsigned *__restrict__ cellCount,
+                                                   unsigned *__restrict__ bitmap) {
+    __shared__ unsigned long long sb[PP_NX / 64 + 1];
+    const int cy = blockIdx.x, x = threadIdx.x;
+    unsigned occ = cellCount[(size_t)cy * PP_NX + x];
+    if (cy > 0) occ |= cellCount[(size_t)(cy - 1) * PP_NX + x];
+    if (cy + 1 < PP_NY) occ |= cellCount[(size_t)(cy + 1) * PP_NX + x];
+    const unsigned long long ball = __ballot(occ != 0u);
+    if ((x & 63) == 0) sb[x >> 6] = ball;
+    if (x == 0) sb[PP_NX / 64] = 0ULL;
+    __syncthreads();
+    if (x < PP_NX / 32) {   // output word x covers columns [32x, 32x+32)
+        const int p = 32 * x - 1;   // window bit t = occupancy of column p + t, t = 0..33
+        unsigned long long w;
+        if (p < 0) {
+            w = sb[0] << 1;
+        } else {
+            const int idx = p >> 6, sh = p & 63;
+            w = sb[idx] >> sh;
+            if (sh) w |= sb[idx + 1] << (64 - sh);
         }
+        const unsigned long long dil = w | (w >> 1) | (w >> 2);
+        bitmap[(size_t)cy * (PP_NX / 32) + x] = (unsigned)(dil & 0xffffffffULL);
     }
-    // output bit k (column cx0+k) = occ bits k, k+1, k+2 (columns k-1, k, k+1)
-    const unsigned long long dil = occ | (occ >> 1) | (occ >> 2);
-    bitmap[wid] = (unsigned)(dil & 0xffffffffULL);
 }
 
 // Exclusive scan of the cell counters in two coalesced launches.
@@ -327,15 +337,25 @@ __global__ __launch_bounds__(1024) void pp2_route(const float *__restrict__ hist
 // ctrl[0] = #items, ctrl[1] = dequeue head, ctrl[2] = #entries.
 __device__ __forceinline__ unsigned long long pp2_block_scan64(unsigned long long v, unsigned long long *sh,
                                                                int tid) {   // inclusive, 1024 threads
-    sh[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned long long u = (tid >= o) ? sh[tid - o] : 0ULL;
-        __syncthreads();
-        sh[tid] += u;
-        __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    unsigned long long inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
     }
-    return sh[tid];
+    __syncthreads();   // sh free
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+        const unsigned long long s = sh[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    sh[1023] = tot;    // callers read the block total from sh[1023]
+    __syncthreads();
+    return base + inc;
 }
 
 __global__ __launch_bounds__(1024) void pp2_worklist(const unsigned *__restrict__ descCount,
@@ -350,15 +370,13 @@ __global__ __launch_bounds__(1024) void pp2_worklist(const unsigned *__restrict_
     __shared__ unsigned long long s_carry, s_itemT, s_entryT;
     __shared__ unsigned s_carryK;
     const int tid = threadIdx.x;
-    if (tid < V2_NTILES) {
-        const int x0 = (tid % V2_NT) * V2_TS - 1, y0 = (tid / V2_NT) * V2_TS - 1;
+    if (tid < V2_NTILES) tileL[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < V2_NTILES * V2_W; e += 1024) {   // (tile, row) pairs: independent loads
+        const int tl = e / V2_W, r = e - tl * V2_W;
+        const int x0 = (tl % V2_NT) * V2_TS - 1, gy = (tl / V2_NT) * V2_TS - 1 + r;
         const int gx0 = max(x0, 0), gx1 = min(x0 + V2_W, PP_NX);
-        unsigned L = 0;
-        for (int r = 0; r < V2_W; ++r) {
-            const int gy = y0 + r;
-            if (gy >= 0 && gy < PP_NY) L += cellStart[gy * PP_NX + gx1] - cellStart[gy * PP_NX + gx0];
-        }
-        tileL[tid] = L;
+        if (gy >= 0 && gy < PP_NY) atomicAdd(&tileL[tl], cellStart[gy * PP_NX + gx1] - cellStart[gy * PP_NX + gx0]);
     }
     __syncthreads();
     unsigned long long tot = 0, totR = 0;
@@ -439,31 +457,73 @@ __global__ __launch_bounds__(1024) void pp2_worklist(const unsigned *__restrict_
 }
 
 // ---- V2 tiles (K2) ------------------------------------------------------------------
-// Join of a tile's live points with the history records routed to it.
-//
-// A workgroup dequeues one ENTRY (<= 64 consecutive work items of one tile); item headers
-// and up to 1024 run descriptors at a time are staged in LDS, so an entry costs four
-// dependent global round trips (entry -> items -> descriptors -> records).
-//
-// The join is LIVE-point centric: every thread keeps up to V2_LPT live points of the tile
-// (+1 cell halo) in REGISTERS together with their hit counters; the records of the current
-// (tile, traversal) list are pulled in chunks of V2_RC, counting-sorted by cell INSIDE LDS,
-// and each live point walks the three sorted row segments of its 3x3 cell neighbourhood.
-// Neighbouring lanes own neighbouring live points (the live scan is cell sorted), so they
-// walk nearly the same records: LDS reads are mostly broadcasts, trip counts are coherent
-// across a wavefront, and there are no atomics and no per-pair index arithmetic.  Counters
-// are flushed (one global atomic per non-zero counter) when the list changes.
-constexpr int V2_RPT = 4;                     // records per thread per chunk
-constexpr int V2_RC = 1024 * V2_RPT;          // records sorted in LDS at a time
-constexpr int V2_LPT = V2_LMAX / 1024;        // live points per thread (6)
-constexpr int V2_DC = 1024;                   // run descriptors staged per chunk
-constexpr int V2_EI = 64;                     // max items per entry
-constexpr int V2_NC = V2_W * V2_W;            // local cells incl. halo (1156)
-static_assert(V2_NC <= 2048, "cell scan handles two cells per thread");
+// A workgroup dequeues one ENTRY (<= 64 consecutive work items of one tile).  Per entry
+// there are only four dependent global round trips (entry -> items -> run descriptors ->
+// records): the item headers and up to 1024 run descriptors at a time are staged in LDS,
+// the tile's live points (+halo), its local cell table and the counters stay in LDS, and
+// the counters are flushed when the (tile, traversal) list changes.
+constexpr int V2_U = 4;      // records prefetched per thread
+constexpr int V2_DC = 1024;  // run descriptors staged per chunk
+constexpr int V2_EI = 64;    // max items per entry
+constexpr unsigned V2_HEAVY = 64;   // more candidates than this: the whole wavefront helps
 
 // exact float64 predicate, kept out of line so that the hot loop stays small
 __device__ __noinline__ bool pp2_exact(float hx, float hy, float hz, float qx, float qy, float qz, double r2) {
     return pp_within(hx, hy, hz, qx, qy, qz, r2);
+}
+
+// One record per lane (invalid lanes have n = 0).  Lanes with up to `heavyT` candidates walk
+// their own list four at a time: four independent LDS reads in flight, no branches in the
+// loop body besides the predicated LDS add (the rare candidates inside the 1e-6 band around r^2 are queued
+// in a bit mask and re-tested exactly in float64 afterwards).  Longer lists are shared by
+// the whole wavefront.
+__device__ __forceinline__ void pp2_resolve(const float4 *live, unsigned *cnt, float hx, float hy, float hz,
+                                            unsigned a0, unsigned a1, unsigned a2, unsigned n0, unsigned n1,
+                                            unsigned n, float r2lo, float r2hi, double r2, int lane,
+                                            unsigned heavyT) {
+    const unsigned n01 = n0 + n1;
+    const unsigned b1 = a1 - n0, b2 = a2 - n01;
+    const unsigned own = n > heavyT ? 0u : n;
+    for (unsigned p0 = 0; __any(p0 < own); p0 += 4) {
+        unsigned band = 0;
+#pragma unroll
+        for (unsigned u = 0; u < 4; ++u) {
+            const unsigned p = p0 + u;
+            const bool act = p < own;
+            const unsigned i = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
+            const float4 q = live[i];
+            const float fx = q.x - hx, fy = q.y - hy, fz = q.z - hz;
+            const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+            const bool hit = act && d2 < r2lo;
+            band |= (act && !hit && d2 <= r2hi) ? (1u << u) : 0u;
+            if (hit) atomicAdd(&cnt[i], 1u);
+        }
+        while (band) {   // practically never taken
+            const unsigned u = __ffs((int)band) - 1;
+            band &= band - 1;
+            const unsigned p = p0 + u;
+            const unsigned i = p + (p < n0 ? a0 : (p < n01 ? b1 : b2));
+            const float4 q = live[i];
+            if (pp2_exact(hx, hy, hz, q.x, q.y, q.z, r2)) atomicAdd(&cnt[i], 1u);
+        }
+    }
+    unsigned long long heavy = __ballot(n > heavyT);
+    while (heavy) {
+        const int src = __ffsll((long long)heavy) - 1;
+        heavy &= heavy - 1;
+        const float sx = __shfl(hx, src), sy = __shfl(hy, src), sz = __shfl(hz, src);
+        const unsigned sa0 = __shfl(a0, src), sb1 = __shfl(b1, src), sb2 = __shfl(b2, src);
+        const unsigned sn0 = __shfl(n0, src), sn01 = __shfl(n01, src), sn = __shfl(n, src);
+        for (unsigned p = lane; p < sn; p += 64) {
+            const unsigned i = p + (p < sn0 ? sa0 : (p < sn01 ? sb1 : sb2));
+            const float4 q = live[i];
+            const float fx = q.x - sx, fy = q.y - sy, fz = q.z - sz;
+            const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+            const bool hit = d2 < r2lo;
+            if (hit) atomicAdd(&cnt[i], 1u);
+            if (!hit && d2 <= r2hi && pp2_exact(sx, sy, sz, q.x, q.y, q.z, r2)) atomicAdd(&cnt[i], 1u);
+        }
+    }
 }
 
 // inclusive block scan (1024 threads) with two barriers; *total receives the block sum
@@ -496,29 +556,19 @@ __global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec
                                                   const unsigned *__restrict__ cellStart,
                                                   const float4 *__restrict__ sorted, int *counts, int T,
                                                   int maxDesc, double r2, int dbg) {
-    __shared__ float4 srec[V2_RC];              // records of the chunk, sorted by local cell
-    __shared__ unsigned hist[V2_NC + 4], cpre[V2_NC + 4];
+    __shared__ float4 live[V2_LMAX];
+    __shared__ unsigned cnt[V2_LMAX];
+    __shared__ unsigned short ctab[V2_W * (V2_W + 1)];
     __shared__ unsigned segStart[V2_W], segLen[V2_W], rowBase[V2_W + 1];
     __shared__ unsigned dOff[V2_DC], dPre[V2_DC + 1];
     __shared__ unsigned iList[V2_EI], iDa[V2_EI], iBase[V2_EI + 1];
     __shared__ unsigned wsum[16];
     __shared__ unsigned s_item;
     __shared__ int s_L;
-    const int tid = threadIdx.x;
-    const PPGrid g = pp_grid(bb, c);
+    const int tid = threadIdx.x, lane = tid & 63;
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
     const unsigned nEntries = ctrl[2];
-    // live points owned by this thread (element e = tid + 1024*k of the tile's live list)
-    float qx[V2_LPT], qy[V2_LPT], qz[V2_LPT];
-    int qidx[V2_LPT], qcell[V2_LPT];   // original index; local cell row*V2_W+col, or -1
-    unsigned qcnt[V2_LPT];
-#pragma unroll
-    for (int k = 0; k < V2_LPT; ++k) {
-        qcell[k] = -1;
-        qcnt[k] = 0;
-        qx[k] = qy[k] = qz[k] = 0.f;
-        qidx[k] = 0;
-    }
+    const unsigned heavyT = (dbg >> 8) ? (unsigned)(dbg >> 8) : V2_HEAVY;
     int curTile = -1, L = 0;
     bool fits = false;
     for (;;) {
@@ -553,7 +603,7 @@ __global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec
         const unsigned ND = iBase[V2_EI];
         const int tile = (int)iList[0] / T;
         const int x0 = (tile % V2_NT) * V2_TS - 1, y0 = (tile / V2_NT) * V2_TS - 1;
-        if (tile != curTile) {   // (all counters are zero here: they are flushed at the end of an entry)
+        if (tile != curTile) {
             const int gx0 = max(x0, 0), gx1 = min(x0 + V2_W, PP_NX);
             if (tid < V2_W) {
                 const int gy = y0 + tid;
@@ -578,21 +628,23 @@ __global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec
             __syncthreads();
             L = s_L;
             fits = L <= V2_LMAX;
-#pragma unroll
-            for (int k = 0; k < V2_LPT; ++k) {
-                const int e = tid + 1024 * k;
-                qcell[k] = -1;
-                if (fits && e < L) {
+            if (fits) {
+                for (int e = tid; e < V2_W * (V2_W + 1); e += 1024) {
+                    const int r = e / (V2_W + 1), cc = e - r * (V2_W + 1);
+                    const int gy = y0 + r;
+                    unsigned val = rowBase[r];
+                    if (gy >= 0 && gy < PP_NY) {
+                        const int gx = min(max(x0 + cc, gx0), gx1);
+                        val = cellStart[gy * PP_NX + gx] - segStart[r] + rowBase[r];
+                    }
+                    ctab[e] = (unsigned short)val;
+                }
+                for (int e = tid; e < L; e += 1024) {
                     int r = 0;
                     while (e >= (int)rowBase[r + 1]) ++r;
-                    const float4 q = sorted[segStart[r] + (e - rowBase[r])];
-                    qx[k] = q.x;
-                    qy[k] = q.y;
-                    qz[k] = q.z;
-                    qidx[k] = __float_as_int(q.w);
-                    const int lcx = pp_cell_coord(q.x, g.ox, g.inv_c, PP_NX) - x0;   // 0 .. V2_W-1
-                    qcell[k] = r * V2_W + lcx;
+                    live[e] = sorted[segStart[r] + (e - rowBase[r])];
                 }
+                for (int e = tid; e < L; e += 1024) cnt[e] = 0;
             }
             curTile = tile;
         }
@@ -618,38 +670,37 @@ __global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec
             dPre[tid] = inc - myCnt;
             if (tid == 1023) dPre[V2_DC] = totalRecs;
             __syncthreads();
-            // lists (runs of items with the same list id) that own descriptors of this chunk
+            // items that own descriptors of this chunk
             int k = 0;
             while (k + 1 < nI && iBase[k + 1] <= dc) ++k;
-            while (k < nI && iBase[k] < dc + ndc) {
+            for (; k < nI && iBase[k] < dc + ndc; ++k) {
+                if (iBase[k + 1] == iBase[k]) continue;
                 const int list = (int)iList[k];
-                int k2 = k;
-                while (k2 + 1 < nI && (int)iList[k2 + 1] == list && iBase[k2 + 1] < dc + ndc) ++k2;
-                const unsigned dlo = max(iBase[k], dc) - dc, dhi = min(iBase[k2 + 1], dc + ndc) - dc;
-                k = k2 + 1;
-                if (dhi <= dlo) continue;
-                if (list != curList) {   // flush the counters of the finished list
-                    if (curList >= 0) {
-#pragma unroll
-                        for (int q = 0; q < V2_LPT; ++q)
-                            if (qcnt[q]) {
-                                if (!(dbg & 1)) atomicAdd(&counts[(size_t)qidx[q] * T + curT], (int)qcnt[q]);
-                                qcnt[q] = 0;
+                if (list != curList) {
+                    __syncthreads();   // every record of the previous list is counted
+                    if (fits)
+                        for (int e = tid; e < L; e += 1024) {
+                            const unsigned cN = cnt[e];
+                            if (cN) {
+                                if (!(dbg & 1))
+                                    atomicAdd(&counts[(size_t)__float_as_int(live[e].w) * T + curT], (int)cN);
+                                cnt[e] = 0;
                             }
-                    }
+                        }
+                    __syncthreads();
                     curList = list;
                     curT = list - tile * T;
                 }
-                const unsigned r0 = dPre[dlo], r1 = dPre[dhi];   // dPre[V2_DC] holds the total
-                for (unsigned cb = r0; cb < r1; cb += V2_RC) {
-                    const unsigned cend = min(cb + (unsigned)V2_RC, r1);
-                    // (a) pull this thread's records
-                    float4 hh[V2_RPT];
-                    bool vv[V2_RPT];
+                const unsigned dlo = max(iBase[k], dc) - dc, dhi = min(iBase[k + 1], dc + ndc) - dc;
+                const unsigned r0 = dPre[dlo], r1 = (dhi == (unsigned)V2_DC) ? dPre[V2_DC] : dPre[dhi];
+                // wave-uniform trip count: every lane takes part in the cooperative phase
+                for (unsigned jb = r0 + (unsigned)(tid & ~63); jb < r1; jb += 1024 * V2_U) {
+                    float4 hh[V2_U];
+                    bool vv[V2_U];
 #pragma unroll
-                    for (int u = 0; u < V2_RPT; ++u) {
-                        const unsigned j = cb + 1024u * u + tid;
-                        vv[u] = j < cend;
+                    for (int u = 0; u < V2_U; ++u) {   // issue all record loads before touching any
+                        const unsigned j = jb + 1024u * u + lane;
+                        vv[u] = j < r1;
                         hh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (vv[u]) {
                             int lo = (int)dlo, hi = (int)dhi - 1;   // last d with dPre[d] <= j
@@ -657,94 +708,54 @@ __global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec
                                 const int mid = (lo + hi + 1) >> 1;
                                 if (dPre[mid] <= j) lo = mid; else hi = mid - 1;
                             }
-                            hh[u] = rec[dOff[lo] + (j - dPre[lo])];
+                            hh[u] = (dbg & 4) ? make_float4(1.f, 1.f, 1.f, 0.f) : rec[dOff[lo] + (j - dPre[lo])];
                         }
                     }
-                    if (!fits) {   // tile too dense for the register/LDS join: global index, global atomics
 #pragma unroll
-                        for (int u = 0; u < V2_RPT; ++u)
-                            if (vv[u]) {
-                                const float4 h = hh[u];
-                                const int pk = __float_as_int(h.w);
-                                const int cx = x0 + 1 + (pk & 255), cy = y0 + 1 + (pk >> 8);
-                                const int xa = max(cx - 1, 0), xb = min(cx + 1, PP_NX - 1);
-                                for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
-                                    const unsigned a = cellStart[yy * PP_NX + xa], b = cellStart[yy * PP_NX + xb + 1];
-                                    for (unsigned i = a; i < b; ++i) {
-                                        const float4 q = sorted[i];
-                                        if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2))
-                                            atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + curT], 1);
-                                    }
-                                }
+                    for (int u = 0; u < V2_U; ++u) {
+                        if (jb + 1024u * u >= r1) break;   // wave-uniform
+                        const float4 h = hh[u];
+                        const bool valid = vv[u];
+                        const int pk = __float_as_int(h.w);   // cell inside the tile, packed by pp2_route
+                        if (fits) {
+                            unsigned a0 = 0, a1 = 0, a2 = 0, n0 = 0, n1 = 0, n2 = 0;
+                            if (valid && !(dbg & 2)) {
+                                const int lcx = (pk & 255) + 1, lcy = (pk >> 8) + 1;   // in [1, V2_TS]
+                                const unsigned short *row = ctab + (lcy - 1) * (V2_W + 1) + lcx - 1;
+                                a0 = row[0];
+                                n0 = row[3] - a0;
+                                a1 = row[V2_W + 1];
+                                n1 = row[V2_W + 4] - a1;
+                                a2 = row[2 * (V2_W + 1)];
+                                n2 = row[2 * (V2_W + 1) + 3] - a2;
                             }
-                        continue;
-                    }
-                    // (b) counting sort of the chunk by local cell
-                    __syncthreads();   // previous chunk's join is done with srec / cpre
-                    for (int e = tid; e < V2_NC + 4; e += 1024) hist[e] = 0;
-                    __syncthreads();
-                    unsigned rank[V2_RPT];
-                    int lc[V2_RPT];
-#pragma unroll
-                    for (int u = 0; u < V2_RPT; ++u) {
-                        rank[u] = 0;
-                        lc[u] = 0;
-                        if (vv[u]) {
-                            const int pk = __float_as_int(hh[u].w);
-                            lc[u] = ((pk >> 8) + 1) * V2_W + (pk & 255) + 1;
-                            rank[u] = atomicAdd(&hist[lc[u]], 1u);
-                        }
-                    }
-                    __syncthreads();
-                    {   // exclusive scan of the 1156 cell counters, two cells per thread
-                        const unsigned v0 = (2 * tid < V2_NC) ? hist[2 * tid] : 0u;
-                        const unsigned v1 = (2 * tid + 1 < V2_NC) ? hist[2 * tid + 1] : 0u;
-                        unsigned tot;
-                        const unsigned in2 = pp2_scan_u32(v0 + v1, wsum, tid, &tot);
-                        if (2 * tid < V2_NC + 2) {
-                            cpre[2 * tid] = in2 - v0 - v1;
-                            cpre[2 * tid + 1] = in2 - v1;
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int u = 0; u < V2_RPT; ++u)
-                        if (vv[u]) srec[cpre[lc[u]] + rank[u]] = hh[u];
-                    __syncthreads();
-                    // (c) join: every owned live point walks its 3x3 neighbourhood of sorted records
-                    if (!(dbg & 2)) {
-#pragma unroll
-                        for (int q = 0; q < V2_LPT; ++q) {
-                            if (qcell[q] < 0) continue;
-                            const int row = qcell[q] / V2_W, col = qcell[q] - row * V2_W;
-                            const int c0 = max(col - 1, 0), c1 = min(col + 1, V2_W - 1);
-                            unsigned hits = 0;
-                            for (int rr = max(row - 1, 0); rr <= min(row + 1, V2_W - 1); ++rr) {
-                                const unsigned a = cpre[rr * V2_W + c0], b = cpre[rr * V2_W + c1 + 1];
+                            pp2_resolve(live, cnt, h.x, h.y, h.z, a0, a1, a2, n0, n1, n0 + n1 + n2, r2lo, r2hi,
+                                        r2, lane, heavyT);
+                        } else if (valid) {   // tile too dense for LDS: resolve against the global index
+                            const int cx = x0 + 1 + (pk & 255), cy = y0 + 1 + (pk >> 8);
+                            const int xa = max(cx - 1, 0), xb = min(cx + 1, PP_NX - 1);
+                            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
+                                const unsigned a = cellStart[yy * PP_NX + xa], b = cellStart[yy * PP_NX + xb + 1];
                                 for (unsigned i = a; i < b; ++i) {
-                                    const float4 h = srec[i];
-                                    const float fx = qx[q] - h.x, fy = qy[q] - h.y, fz = qz[q] - h.z;
-                                    const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                    bool hit = d2 < r2lo;
-                                    if (!hit && d2 <= r2hi) hit = pp2_exact(h.x, h.y, h.z, qx[q], qy[q], qz[q], r2);
-                                    hits += hit ? 1u : 0u;
+                                    const float4 q = sorted[i];
+                                    if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2))
+                                        atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + curT], 1);
                                 }
                             }
-                            qcnt[q] += hits;
                         }
                     }
                 }
             }
         }
-        // end of the entry: flush (counters return to zero)
-        if (curList >= 0) {
-#pragma unroll
-            for (int q = 0; q < V2_LPT; ++q)
-                if (qcnt[q]) {
-                    if (!(dbg & 1)) atomicAdd(&counts[(size_t)qidx[q] * T + curT], (int)qcnt[q]);
-                    qcnt[q] = 0;
+        __syncthreads();   // flush the last list of the entry (counters return to zero)
+        if (fits && curList >= 0)
+            for (int e = tid; e < L; e += 1024) {
+                const unsigned cN = cnt[e];
+                if (cN) {
+                    if (!(dbg & 1)) atomicAdd(&counts[(size_t)__float_as_int(live[e].w) * T + curT], (int)cN);
+                    cnt[e] = 0;
                 }
-        }
+            }
     }
 }
 
@@ -871,7 +882,7 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     const int nb = (n_live + 255) / 256;
     pp_live_bbox<<<(n_live + 1023) / 1024, 256, 0, stream>>>(live, n_live, bb);
     pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellCount);
-    pp_bitmap<<<(PP_BITWORDS + 255) / 256, 256, 0, stream>>>(cellCount, bitmap);
+    pp_bitmap<<<PP_NY, PP_NX, 0, stream>>>(cellCount, bitmap);
     pp_scan_blocks<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum);
     pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
     pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
