@@ -11,9 +11,10 @@ PP-weighted mutual-kNN DBSCAN -> cluster filter -> closeness box fit -> BEV
 IoU NMS -> KITTI label text.  value = scans/s over all ranks (weak scaling: every
 rank processes K scans of its own).  Besides the contract fields the JSON line
 carries
-  roofline     -- the PP history-stream kernel: algorithmic bytes per launch
-                  (12*M + 16*N) / its mean HIP-event duration,
-                  against the 8 TB/s HBM3E peak;
+  roofline     -- the PP neighbour count (the operation SURVEY.md §8d prices at
+                  12*M + 16*N algorithmic bytes per scan; here it is a chain of
+                  kernels, so the WHOLE chain is timed with HIP events, not just
+                  its largest kernel) against the 8 TB/s HBM3E peak;
   cpu_baseline -- the oracle (the reference's own scipy/sklearn calls, same
                   threading as the reference: cKDTree single-threaded, sklearn
                   n_jobs=-1) timed on this host on a bounded sample of the same
@@ -122,7 +123,9 @@ def main():
     alg_bytes = 12 * sc0.M + 16 * sc0.N
     k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
-    roofline = {"bound": "hbm", "kernel": "pp_stream (history neighbour count)", "achieved": achieved,
+    roofline = {"bound": "hbm",
+                "kernel": "PP neighbour count of one scan = pp_live_* index build + pp2_route + pp2_worklist + pp2_tiles "
+                          "(all launches of the stage, HIP events on the launch stream)", "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                 "launches_timed": int(len(kernel_ms))}

@@ -42,10 +42,12 @@ const char *modest_last_error(void);
 int modest_device_count(void);
 int modest_ctx_create(int device, modest_ctx **out);
 int modest_ctx_destroy(modest_ctx *ctx);
-/* Measurement hook (no reference counterpart): while enabled, every launch of
- * the dominant kernel of the path (the PP history-stream kernel) is bracketed
- * by a HIP event pair on the launch stream; collect returns the elapsed
- * milliseconds of up to `cap` launches since begin and disables the hook.    */
+/* Measurement hook (no reference counterpart): while enabled, the dominant
+ * operation of the path -- the neighbour-count stage of modest_pp_count /
+ * modest_pp_score (index build + route + work list + tile join kernels of ONE
+ * scan) -- is bracketed by a HIP event pair on the launch stream; collect
+ * returns the elapsed milliseconds of up to `cap` calls since begin and
+ * disables the hook.                                                          */
 int modest_ctx_profile_begin(modest_ctx *ctx, int capacity);
 int modest_ctx_profile_collect(modest_ctx *ctx, float *ms_out_host, int cap,
                                int *n_out_host);

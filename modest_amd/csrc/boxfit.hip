@@ -127,20 +127,30 @@ __global__ __launch_bounds__(128) void closeness_kernel(const double *__restrict
     beta[(size_t)c * n_angles + a] = (n > 0) ? pw_sum(B, n) : 0.0;
 }
 
-__global__ void argmax_kernel(const double *__restrict__ beta, int n_clusters, int n_angles,
-                              int *__restrict__ best) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// first strict maximum over the angles (pointcloud_utils.py:185-187) = largest value, ties to
+// the smallest index; one wavefront per cluster
+__global__ __launch_bounds__(64) void argmax_kernel(const double *__restrict__ beta, int n_clusters,
+                                                    int n_angles, int *__restrict__ best) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n_clusters) return;
     double mx = -INFINITY;
-    int arg = -1;
-    for (int a = 0; a < n_angles; ++a) {
+    int arg = 0x7fffffff;
+    for (int a = lane; a < n_angles; a += 64) {
         const double v = beta[(size_t)c * n_angles + a];
-        if (v > mx) {   // first strict maximum (pointcloud_utils.py:185-187)
+        if (v > mx) {
             mx = v;
             arg = a;
         }
     }
-    best[c] = arg;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(mx, o);
+        const int oa = __shfl_xor(arg, o);
+        if (ov > mx || (ov == mx && oa < arg)) {
+            mx = ov;
+            arg = oa;
+        }
+    }
+    if (lane == 0) best[c] = (arg == 0x7fffffff) ? -1 : arg;
 }
 
 struct Box6 {
@@ -209,7 +219,7 @@ extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
     MODEST_HIP_CHECK(hipMemcpyAsync(d_cs, h_cs, (size_t)n_angles * 16, hipMemcpyHostToDevice, stream));
     dim3 grid((n_angles + 127) / 128, n_clusters);
     closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
-    argmax_kernel<<<(n_clusters + 63) / 64, 64, 0, stream>>>(d_beta, n_clusters, n_angles, d_best);
+    argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, d_best);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(h_best, d_best, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
     if (beta_host)

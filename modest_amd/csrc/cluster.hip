@@ -259,11 +259,15 @@ __global__ __launch_bounds__(64 * WPB) void degree_kernel(const float4 *__restri
 __device__ __forceinline__ int uf_load(int *p, int i) {
     return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// find with path halving: every visited node is re-pointed at its grandparent (a plain
+// racy store is fine: parents only ever move towards the root, i.e. to smaller indices)
 __device__ __forceinline__ int uf_find(int *parent, int x) {
     int p = uf_load(parent, x);
     while (p != x) {
+        const int gp = uf_load(parent, p);
+        if (gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p;
-        p = uf_load(parent, x);
+        p = gp;
     }
     return x;
 }
@@ -286,6 +290,34 @@ __device__ __forceinline__ void uf_unite(int *parent, int a, int b) {
 __global__ void uf_init(int *parent, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) parent[i] = i;
+}
+
+// ECL-CC style initialisation: every core point first hangs under its smallest-index core
+// neighbour (no atomics: one writer per entry, and parent[v] <= v keeps the forest acyclic).
+__global__ __launch_bounds__(64 * WPB) void hook_min_kernel(const float4 *__restrict__ sorted, int n,
+                                                            const CGrid *g,
+                                                            const unsigned *__restrict__ start,
+                                                            const double *__restrict__ kthS,
+                                                            const unsigned char *__restrict__ coreS,
+                                                            const int *__restrict__ sidx, double r2,
+                                                            double eps, int *parent) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    if (!coreS[s]) return;
+    const float4 q = sorted[s];
+    const double kq = kthS[s];
+    const int me = sidx[s];
+    const Rows R = rows_of(q, g, start);
+    int best = me;
+    for (int r = 0; r < R.n; ++r)
+        for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+            if ((int)j == s || !coreS[j]) continue;
+            const int other = sidx[j];
+            if (other < best && edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) best = other;
+        }
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if (lane == 0) parent[me] = best;
 }
 
 __global__ __launch_bounds__(64 * WPB) void union_kernel(const float4 *__restrict__ sorted, int n,
@@ -406,6 +438,7 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
     degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
+    hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
     union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
     compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
     scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);

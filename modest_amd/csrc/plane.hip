@@ -55,48 +55,102 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 // value(i) = MODE==0 ? z_i : |z_i - center|  (float32 arithmetic)
 template <int MODE>
-__device__ float select_kth(const float *__restrict__ cand, int n, int k, float center,
-                            unsigned *hist /* 256 LDS words */) {
+__device__ __forceinline__ float mad_value(const float *__restrict__ cand, int i, float center) {
+    const float v = cand[3 * (size_t)i + 2];
+    return MODE == 1 ? fabsf(v - center) : v;
+}
+
+struct MadShared {
+    unsigned hist[2048];
+    unsigned wsum[16];
+    unsigned sel, knew;
+    unsigned cntLess;
+    unsigned maxLessKey;
+};
+
+// exact k-th smallest (0-based) by radix descent over the order-preserving key: 11 + 11 + 10
+// bits, the bin holding rank k is found with a block scan (two bins per thread)
+template <int MODE>
+__device__ float select_kth(const float *__restrict__ cand, int n, unsigned k, float center, MadShared &S) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned prefix = 0, mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
+    for (int ps = 0; ps < 3; ++ps) {
+        const int shift = shifts[ps];
+        const unsigned nb = 1u << bitsv[ps];
+        for (unsigned b = tid; b < 2048u; b += 1024) S.hist[b] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            float v = cand[3 * (size_t)i + 2];
-            if (MODE == 1) v = fabsf(v - center);
-            const unsigned key = f2key(v);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned key = f2key(mad_value<MODE>(cand, i, center));
+            if ((key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & (nb - 1u)], 1u);
         }
         __syncthreads();
-        // every thread walks the 256 bins identically (uniform result, no extra sync needed)
-        int acc = 0, bin = 0;
-        for (; bin < 256; ++bin) {
-            const int c = (int)hist[bin];
-            if (acc + c > k) break;
-            acc += c;
+        const unsigned v0 = S.hist[2 * tid], v1 = S.hist[2 * tid + 1];
+        unsigned inc = v0 + v1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
         }
-        k -= acc;
-        prefix |= (unsigned)bin << shift;
-        mask |= 255u << shift;
+        if (lane == 63) S.wsum[w] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (int q = 0; q < w; ++q) base += S.wsum[q];
+        const unsigned incl = base + inc, excl = incl - v0 - v1;
+        if (k >= excl && k < excl + v0) {
+            S.sel = 2 * tid;
+            S.knew = k - excl;
+        } else if (k >= excl + v0 && k < incl) {
+            S.sel = 2 * tid + 1;
+            S.knew = k - excl - v0;
+        }
+        __syncthreads();
+        prefix |= S.sel << shift;
+        mask |= (nb - 1u) << shift;
+        k = S.knew;
         __syncthreads();
     }
     return key2f(prefix);
 }
 
+// numpy.median: odd -> middle element; even -> float32 mean of the two middle ones.  The lower
+// middle is the largest value below the upper middle b unless b is duplicated across the middle.
 template <int MODE>
-__device__ float median_np(const float *cand, int n, float center, unsigned *hist) {
-    // numpy.median: odd -> middle element; even -> float32 mean of the two middle ones
-    if (n & 1) return select_kth<MODE>(cand, n, n / 2, center, hist);
-    const float a = select_kth<MODE>(cand, n, n / 2 - 1, center, hist);
-    const float b = select_kth<MODE>(cand, n, n / 2, center, hist);
+__device__ float median_np(const float *cand, int n, float center, MadShared &S) {
+    const float b = select_kth<MODE>(cand, n, (unsigned)(n / 2), center, S);
+    if (n & 1) return b;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        S.cntLess = 0;
+        S.maxLessKey = 0;
+    }
+    __syncthreads();
+    unsigned c = 0, mk = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const float v = mad_value<MODE>(cand, i, center);
+        if (v < b) {
+            ++c;
+            mk = max(mk, f2key(v));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_xor(c, o);
+        mk = max(mk, (unsigned)__shfl_xor((int)mk, o));
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&S.cntLess, c);
+        atomicMax(&S.maxLessKey, mk);
+    }
+    __syncthreads();
+    const float a = (S.cntLess == (unsigned)(n / 2)) ? key2f(S.maxLessKey) : b;
+    __syncthreads();
     return (a + b) / 2.0f;
 }
 
 __global__ __launch_bounds__(1024) void mad_kernel(const float *__restrict__ cand, int n,
                                                    float *out /* [median, mad] */) {
-    __shared__ unsigned hist[256];
-    const float med = median_np<0>(cand, n, 0.f, hist);
-    const float mad = median_np<1>(cand, n, med, hist);
+    __shared__ MadShared S;
+    const float med = median_np<0>(cand, n, 0.f, S);
+    const float mad = median_np<1>(cand, n, med, S);
     if (threadIdx.x == 0) {
         out[0] = med;
         out[1] = mad;
@@ -157,13 +211,15 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
     }
 }
 
-__global__ void score_reduce_kernel(const double *__restrict__ partial, int nblocks, int K,
-                                    double *__restrict__ out /* K*4 */) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per output; lane-strided partial sums then a fixed shuffle tree (deterministic)
+__global__ __launch_bounds__(64) void score_reduce_kernel(const double *__restrict__ partial, int nblocks,
+                                                          int K, double *__restrict__ out /* K*4 */) {
+    const int id = blockIdx.x;
     if (id >= K * 4) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * K * 4 + id];
-    out[id] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * K * 4 + id];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[id] = s;
 }
 
 // ---- refit ---------------------------------------------------------------------
@@ -212,20 +268,18 @@ __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__res
 
 __global__ void refit_reduce_kernel(const double *__restrict__ partial, int nblocks, int pass,
                                     double *__restrict__ acc /* [0..3] sums, [4..6] means, [8..12] moments */) {
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+        for (int q = 0; q < 5; ++q) s[q] += partial[(size_t)b * 5 + q];
+    for (int q = 0; q < 5; ++q) s[q] = wave_sum(s[q]);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (pass == 0) {
-        double s[4] = {0, 0, 0, 0};
-        for (int b = 0; b < nblocks; ++b)
-            for (int q = 0; q < 4; ++q) s[q] += partial[(size_t)b * 5 + q];
         for (int q = 0; q < 4; ++q) acc[q] = s[q];
         const double inv = s[0] > 0 ? 1.0 / s[0] : 0.0;
         acc[4] = s[1] * inv;
         acc[5] = s[2] * inv;
         acc[6] = s[3] * inv;
     } else {
-        double s[5] = {0, 0, 0, 0, 0};
-        for (int b = 0; b < nblocks; ++b)
-            for (int q = 0; q < 5; ++q) s[q] += partial[(size_t)b * 5 + q];
         for (int q = 0; q < 5; ++q) acc[8 + q] = s[q];
     }
 }
@@ -344,7 +398,7 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     for (int i = 0; i < K * 3; ++i) hm[i] = models_host[i];
     MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12, hipMemcpyHostToDevice, stream));
     score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K, thr, dp);
-    score_reduce_kernel<<<(K * 4 + 255) / 256, 256, 0, stream>>>(dp, nb, K, dout);
+    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nb, K, dout);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
