@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads and exports every symbol include/modest_hip.h declares (no
+compute calls without a GPU); host-side logic (config composer, RANSAC control helpers)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "modest_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(modest_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from modest_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.load()
+    names = _header_symbols()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/modest_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names          # the ctypes table mirrors the header one to one
+    assert lib.modest_version() >= 100
+    assert isinstance(lib.modest_device_count(), int)
+
+
+def test_no_cpu_fallback_without_device():
+    from modest_amd import _lib
+    lib = _lib.load()
+    if lib.modest_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.ModestHipError, match="no HIP device"):
+        _lib.Context(0)
+    # argument errors are reported, never exit()
+    h = ctypes.c_void_p()
+    assert lib.modest_ctx_create(0, None) != 0
+    assert b"NULL" in lib.modest_last_error()
+
+
+def test_config_composer_matches_reference_defaults():
+    from modest_amd import config
+    c = config.compose("generate_mask", ["data_root=/d"])
+    assert c.plane_estimate.range == [[-70, 70], [-20, 20]] and c.plane_estimate.max_hs == -1.5
+    assert c.graph.n_neighbors == 70 and c.graph.radius == 2.0 and c.clustering.DBSCAN.eps == 0.1
+    assert dict(**c.filtering)["min_percentile_pp_score"] == 0.7
+    assert c.calib_path == "/d/calib" and c.data_paths.seg_save_dst.endswith("lyft_seg_pp_score_fw70_2m_r0.3/")
+    n = config.compose("pp_score", ["data_root=/d", "data_paths=nusc.yaml", "nusc=True", "total_part=8", "part=3"])
+    assert n.nusc is True and n.total_part == 8 and n.part == 3 and "nuscenes" in n.data_paths.track_path
+    assert n.max_neighbor_dist == 0.3 and n.limit_traversals == -1 and n.ephe_type == "entropy"
+    lab = config.compose("generate_label_files", ["data_root=/d", "image_shape=[900,1600]"])
+    assert lab.image_shape == [900, 1600] and lab.nms.threshold == 0.1 and lab.fov_only is True
+    with pytest.raises(config.MissingMandatoryValue):
+        config.compose("pp_score").data_root
+    with pytest.raises(KeyError):
+        config.compose("pp_score", ["data_root=/d", "no_such_key=1"])
+    assert config.compose("pp_score", ["data_root=/d", "+extra=5"]).extra == 5
+    assert "max_neighbor_dist" in config.to_yaml(n)
+
+
+def test_ransac_control_helpers():
+    from sklearn.linear_model import LinearRegression
+    from sklearn.linear_model._ransac import _dynamic_max_trials
+    from modest_amd.utils import ransac
+    for args in ((5000, 10000, 3, 0.99), (10, 10000, 3, 0.99), (10000, 10000, 3, 0.99), (1, 7, 3, 0.5)):
+        assert ransac.dynamic_max_trials(*args) == _dynamic_max_trials(*args)
+    rng = np.random.default_rng(0)
+    p = (rng.standard_normal((50, 3, 3)) * [10, 10, 0.05] + [0, 0, -1.7]).astype(np.float32)
+    m = ransac.planes_through_triplets(p)
+    for b in range(50):
+        reg = LinearRegression().fit(p[b, :, :2], p[b, :, 2])
+        np.testing.assert_allclose(m[b, :2], reg.coef_, rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(m[b, 2], reg.intercept_, rtol=2e-3, atol=2e-4)
+        assert np.max(np.abs(p[b, :, 0] * m[b, 0] + p[b, :, 1] * m[b, 1] + m[b, 2] - p[b, :, 2])) < 1e-4
+    assert ransac.r2_from_sums(10, 0.0, 5.0, 10.0) == 1.0
+    assert ransac.r2_from_sums(4, 1.0, 4.0, 8.0) == pytest.approx(1.0 - 1.0 / 4.0)
