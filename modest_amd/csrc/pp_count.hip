@@ -116,6 +116,19 @@ __global__ void pp_live_count(const float *__restrict__ live, int n, const unsig
     atomicAdd(&cellCount[cy * PP_NX + cx], 1u);
 }
 
+// live points of every 34x34-cell tile window (tile + 1 cell halo) that pp2_tiles holds in LDS:
+// one wavefront per tile, one lane per window row, from the prefix table
+__global__ __launch_bounds__(64) void pp_tile_live(const unsigned *__restrict__ cellStart,
+                                                   unsigned *__restrict__ tileLive) {
+    const int tl = blockIdx.x, r = threadIdx.x;
+    const int x0 = (tl % (PP_NX / 32)) * 32 - 1, gy = (tl / (PP_NX / 32)) * 32 - 1 + r;
+    const int gx0 = max(x0, 0), gx1 = min(x0 + 34, PP_NX);
+    unsigned v = 0;
+    if (r < 34 && gy >= 0 && gy < PP_NY) v = cellStart[gy * PP_NX + gx1] - cellStart[gy * PP_NX + gx0];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (r == 0) tileLive[tl] = v;
+}
+
 // Dilated occupancy bitmap: bit(cell) = any live point in the 3x3 cells around it.
 // One block per grid row: coalesced reads of the three neighbouring counter rows,
 // wave ballots for the row's occupancy bits, shifts for the horizontal dilation.
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(1024) void pp2_route(const float *__restrict__ hist
                                                   const unsigned *__restrict__ bitmap,
                                                   float4 *__restrict__ rec, uint2 *__restrict__ desc,
                                                   unsigned *descCount, unsigned *descRecs, int T,
-                                                  int maxDesc) {
+                                                  int maxDesc, int dbg) {
     __shared__ unsigned sbits[PP_BITWORDS];
     __shared__ float4 stage[V2_CH];
     __shared__ unsigned thist[V2_NTILES];
@@ -315,8 +328,9 @@ __global__ __launch_bounds__(1024) void pp2_route(const float *__restrict__ hist
         __syncthreads();
         const unsigned total = tbase[V2_NTILES];
         float4 *dst = rec + (size_t)chunk * V2_CH;
-        for (unsigned i = tid; i < total; i += 1024) dst[i] = stage[i];
-        if (tid < V2_NTILES && thist[tid] > 0) {
+        if (!(dbg & 64))
+            for (unsigned i = tid; i < total; i += 1024) dst[i] = stage[i];
+        if (tid < V2_NTILES && thist[tid] > 0 && !(dbg & 128)) {
             const unsigned list = (unsigned)tid * T + t;
             const unsigned d = atomicAdd(&descCount[list], 1u);
             atomicAdd(&descRecs[list], thist[tid]);
@@ -327,17 +341,23 @@ __global__ __launch_bounds__(1024) void pp2_route(const float *__restrict__ hist
 }
 
 // ---- V2 work list -------------------------------------------------------------------
-// items[i]   = (list, part | nparts << 16): a (tile, traversal) list, split into parts of
-//              similar estimated cost;
-// entries    = runs of consecutive items of ONE tile with bounded cost: the dequeue unit of
-//              pp2_tiles (entryBegin[e] .. entryBegin[e+1]);
+// items[i]   = (list, part | nparts << 16): a (tile, traversal) list split into parts of at
+//              most V2_ITEM_RECS records (one LDS chunk of pp2_tiles);
+// entries    = runs of consecutive items of ONE tile with bounded estimated cost: the dequeue
+//              unit of pp2_tiles (entryBegin[e] .. entryBegin[e+1]), at most 64 items each;
 // cost model = records x (32 + live points of the tile): candidates per record grow with the
-//              local live density, and a record count alone left the dense centre tiles
-//              10x heavier than the rest.
+//              local live density (a record count alone left the dense centre tiles 10x
+//              heavier than the rest).
 // ctrl[0] = #items, ctrl[1] = dequeue head, ctrl[2] = #entries.
+// One workgroup; every list is owned by one thread (blocked assignment), so after the single
+// coalesced read of descRecs everything stays in registers / LDS: the kernel is a handful of
+// dependent global round trips instead of one per phase and per 1024 lists.
+constexpr int V2_WL_LPT = 8;                        // lists per thread: up to 8192 lists (20 traversals)
+constexpr unsigned V2_ITEM_RECS = 4096;
+
 __device__ __forceinline__ unsigned long long pp2_block_scan64(unsigned long long v, unsigned long long *sh,
-                                                               int tid) {   // inclusive, 1024 threads
-    const int lane = tid & 63, w = tid >> 6;
+                                                               int tid, unsigned long long *total) {
+    const int lane = tid & 63, w = tid >> 6;   // inclusive, 1024 threads, two barriers
     unsigned long long inc = v;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned long long u = __shfl_up(inc, o);
@@ -352,107 +372,148 @@ __device__ __forceinline__ unsigned long long pp2_block_scan64(unsigned long lon
         if (k < w) base += s;
         tot += s;
     }
-    __syncthreads();
-    sh[1023] = tot;    // callers read the block total from sh[1023]
-    __syncthreads();
+    *total = tot;
     return base + inc;
 }
 
 __global__ __launch_bounds__(1024) void pp2_worklist(const unsigned *__restrict__ descCount,
                                                      const unsigned *__restrict__ descRecs,
-                                                     const unsigned *__restrict__ cellStart, int nLists,
+                                                     const unsigned *__restrict__ tileLive, int nLists,
                                                      int T, int nWorkers, uint2 *__restrict__ items,
-                                                     unsigned long long *__restrict__ itemPre,
                                                      unsigned *__restrict__ entryBegin, unsigned maxItems,
-                                                     unsigned *ctrl) {
-    __shared__ unsigned long long sh[1024];
+                                                     unsigned *ctrl, int entryDiv) {
+    __shared__ unsigned long long sh[16];
     __shared__ unsigned tileL[V2_NTILES];
-    __shared__ unsigned long long s_carry, s_itemT, s_entryT;
-    __shared__ unsigned s_carryK;
+    __shared__ unsigned long long lastPre[1024];   // cost prefix / tile of the last item owned by each thread
+    __shared__ int lastTile[1024];
     const int tid = threadIdx.x;
-    if (tid < V2_NTILES) tileL[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < V2_NTILES * V2_W; e += 1024) {   // (tile, row) pairs: independent loads
-        const int tl = e / V2_W, r = e - tl * V2_W;
-        const int x0 = (tl % V2_NT) * V2_TS - 1, gy = (tl / V2_NT) * V2_TS - 1 + r;
-        const int gx0 = max(x0, 0), gx1 = min(x0 + V2_W, PP_NX);
-        if (gy >= 0 && gy < PP_NY) atomicAdd(&tileL[tl], cellStart[gy * PP_NX + gx1] - cellStart[gy * PP_NX + gx0]);
+    const int per = (nLists + 1023) / 1024;         // <= V2_WL_LPT (checked on the host)
+    const int l0 = min(tid * per, nLists), l1 = min(l0 + per, nLists);
+    unsigned recs[V2_WL_LPT], nd[V2_WL_LPT];
+#pragma unroll
+    for (int q = 0; q < V2_WL_LPT; ++q) {
+        const int l = l0 + q;
+        recs[q] = (q < per && l < l1) ? descRecs[l] : 0u;
+        nd[q] = (q < per && l < l1) ? descCount[l] : 0u;
     }
+    if (tid < V2_NTILES) tileL[tid] = tileLive[tid];   // live points per tile window (pp_live_count)
     __syncthreads();
-    unsigned long long tot = 0, totR = 0;
-    for (int l = tid; l < nLists; l += 1024) {
-        tot += (unsigned long long)descRecs[l] * (32u + tileL[l / T]);
-        totR += descRecs[l];
+    // per-list parts and costs
+    unsigned long long totR = 0, totW = 0;
+#pragma unroll
+    for (int q = 0; q < V2_WL_LPT; ++q) {
+        totR += recs[q];
+        if (recs[q]) totW += (unsigned long long)recs[q] * (32u + tileL[(l0 + q) / T]);
     }
-    const unsigned long long totalRecs = pp2_block_scan64(totR, sh, tid);
-    __syncthreads();
-    const unsigned long long total = pp2_block_scan64(tot, sh, tid);
-    if (tid == 1023) {
-        // an item is at most one LDS chunk of records (the per-chunk cost of pp2_tiles grows with
-        // the tile's live points, so small parts are wasteful); entries balance the estimated cost
-        unsigned long long tI = 4096ULL;
-        const unsigned long long floorT = totalRecs / (unsigned long long)(maxItems - (unsigned)nLists) + 1ULL;
-        if (tI < floorT) tI = floorT;   // never more than maxItems items
-        s_itemT = tI;
-        s_entryT = total / ((unsigned long long)nWorkers * 8ULL) + 1ULL;
-        s_carry = 0;
-        s_carryK = 0;
+    unsigned long long sumR, sumW;
+    pp2_block_scan64(totR, sh, tid, &sumR);
+    pp2_block_scan64(totW, sh, tid, &sumW);
+    unsigned long long itemT = V2_ITEM_RECS;
+    {
+        const unsigned long long floorT =
+            (unsigned long long)((double)sumR / (double)(maxItems - (unsigned)nLists)) + 2ULL;
+        if (itemT < floorT) itemT = floorT;   // never more than maxItems items
     }
-    __syncthreads();
-    const unsigned long long itemT = s_itemT, entryT = s_entryT;
-    for (int base = 0; base < nLists; base += 1024) {
-        const int l = base + tid;
-        unsigned k = 0;
-        unsigned long long wl = 0;
-        if (l < nLists && descCount[l] > 0) {
-            wl = (unsigned long long)descRecs[l] * (32u + tileL[l / T]);
-            const unsigned long long kk = ((unsigned long long)descRecs[l] + itemT - 1) / itemT;
-            k = (unsigned)max(1ULL, min(kk, (unsigned long long)min(descCount[l], 65535u)));
-        }
-        const unsigned long long wItem = k ? wl / k : 0ULL;
-        // two scans: item slots (k) and weights (k * wItem); pack k in the scan of a second array
-        const unsigned long long incW = pp2_block_scan64((unsigned long long)k * wItem, sh, tid);
-        __syncthreads();
-        const unsigned long long incK = pp2_block_scan64((unsigned long long)k, sh, tid);
-        const unsigned start = s_carryK + (unsigned)(incK - k);
-        const unsigned long long wstart = s_carry + incW - (unsigned long long)k * wItem;
+    const unsigned itemT32 = (unsigned)min(itemT, 0x7fffffffULL);
+    const unsigned long long entryT =
+        (unsigned long long)((double)sumW / (double)((unsigned long long)nWorkers * (unsigned long long)entryDiv)) + 1ULL;
+    // parts of list q and cost per part, recomputed where needed (keeps the register file small)
+    // (64-bit integer division is a ~100-instruction software routine on this ISA: item counts use
+    // 32-bit division, the per-part cost estimate uses a float division)
+#define PP2_KK(q) ((recs[q] && nd[q]) ? max(1u, min((recs[q] + itemT32 - 1u) / itemT32, min(nd[q], 65535u))) : 0u)
+#define PP2_WI(q, k) ((k) ? (unsigned long long)(((float)recs[q] * (float)(32u + tileL[(l0 + q) / T])) / (float)(k)) : 0ULL)
+    unsigned long long myK = 0, myW = 0;
+#pragma unroll
+    for (int q = 0; q < V2_WL_LPT; ++q) {
+        const unsigned k = PP2_KK(q);
+        myK += k;
+        myW += (unsigned long long)k * PP2_WI(q, k);
+    }
+    unsigned long long totK, totWW;
+    const unsigned long long incK = pp2_block_scan64(myK, sh, tid, &totK);
+    const unsigned long long incW = pp2_block_scan64(myW, sh, tid, &totWW);
+    // items of this thread's lists; remember the last one for the neighbour's entry test
+    unsigned it = (unsigned)(incK - myK);
+    unsigned long long pre = incW - myW;
+    int lt = -1;
+    unsigned long long lp = 0;
+#pragma unroll
+    for (int q = 0; q < V2_WL_LPT; ++q) {
+        const unsigned k = PP2_KK(q);
+        const unsigned long long wi = PP2_WI(q, k);
         for (unsigned s = 0; s < k; ++s) {
-            items[start + s] = make_uint2((unsigned)l, s | (k << 16));
-            itemPre[start + s] = wstart + (unsigned long long)s * wItem;
+            items[it++] = make_uint2((unsigned)(l0 + q), s | (k << 16));
+            lt = (l0 + q) / T;
+            lp = pre;
+            pre += wi;
         }
-        __syncthreads();
-        if (tid == 1023) {
-            s_carryK += (unsigned)incK;
-            s_carry += incW;
-        }
-        __syncthreads();
     }
-    const unsigned nItems = s_carryK;
-    __threadfence_block();
+    lastTile[tid] = lt;
+    lastPre[tid] = lp;
     __syncthreads();
-    // entries: cut where the tile changes or the cost prefix crosses a multiple of entryT
-    unsigned ecarry = 0;
-    for (unsigned base = 0; base < nItems; base += 1024) {
-        const unsigned i = base + tid;
-        unsigned flag = 0;
-        if (i < nItems) {
-            if (i == 0) flag = 1;
-            else {
-                const int ta = (int)(items[i].x) / T, tb = (int)(items[i - 1].x) / T;
-                flag = (ta != tb) || (itemPre[i] / entryT != itemPre[i - 1] / entryT) || ((i & 63u) == 0u);
+    // predecessor of this thread's first item = last item of the nearest earlier thread that owns one
+    int pt = -1;
+    unsigned long long pp = 0;
+    for (int b = tid - 1; b >= 0; --b)
+        if (lastTile[b] >= 0) {
+            pt = lastTile[b];
+            pp = lastPre[b];
+            break;
+        }
+    // entry starts: tile change, cost prefix crossing a multiple of entryT, or every 64th item
+    const unsigned long long bound0 =
+        ((unsigned long long)((double)pp / (double)entryT) + 1ULL) * entryT;   // one float64 division per thread
+    unsigned nflag = 0;
+    {
+        unsigned i = (unsigned)(incK - myK);
+        unsigned long long p2 = incW - myW;
+        int ct = pt;
+        unsigned long long nextB = bound0;   // first multiple of entryT above the predecessor's prefix
+#pragma unroll
+        for (int q = 0; q < V2_WL_LPT; ++q) {
+            const unsigned k = PP2_KK(q);
+            const unsigned long long wi = PP2_WI(q, k);
+            const int tl = (l0 + q) / T;
+            for (unsigned s = 0; s < k; ++s) {
+                const bool cross = p2 >= nextB;
+                while (p2 >= nextB) nextB += entryT;
+                if (i == 0 || tl != ct || cross || (i & 63u) == 0u) ++nflag;
+                ct = tl;
+                p2 += wi;
+                ++i;
             }
         }
-        const unsigned inc = (unsigned)pp2_block_scan64(flag, sh, tid);
-        if (flag) entryBegin[ecarry + inc - 1] = i;
-        __syncthreads();
-        ecarry += (unsigned)sh[1023];
-        __syncthreads();
+    }
+    unsigned long long totE;
+    const unsigned long long incE = pp2_block_scan64(nflag, sh, tid, &totE);
+    {
+        unsigned e = (unsigned)(incE - nflag);
+        unsigned i = (unsigned)(incK - myK);
+        unsigned long long p2 = incW - myW;
+        int ct = pt;
+        unsigned long long nextB = bound0;
+#pragma unroll
+        for (int q = 0; q < V2_WL_LPT; ++q) {
+            const unsigned k = PP2_KK(q);
+            const unsigned long long wi = PP2_WI(q, k);
+            const int tl = (l0 + q) / T;
+            for (unsigned s = 0; s < k; ++s) {
+                const bool cross = p2 >= nextB;
+                while (p2 >= nextB) nextB += entryT;
+                if (i == 0 || tl != ct || cross || (i & 63u) == 0u) entryBegin[e++] = i;
+                ct = tl;
+                p2 += wi;
+                ++i;
+            }
+        }
+#undef PP2_KK
+#undef PP2_WI
     }
     if (tid == 0) {
-        entryBegin[ecarry] = nItems;
-        ctrl[0] = nItems;
+        entryBegin[totE] = (unsigned)totK;
+        ctrl[0] = (unsigned)totK;
         ctrl[1] = 0;
-        ctrl[2] = ecarry;
+        ctrl[2] = (unsigned)totE;
     }
 }
 
@@ -841,11 +902,11 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     const int nLists = V2_NTILES * n_trav;
     const size_t maxItems = (size_t)nLists + 65536;
     // one contiguous zero-initialised block: cellCount | fill | descCount | descRecs | ctrl[2] | bbox[4] | pad
-    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8;   // ctrl[4] bbox[4]
+    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8 + V2_NTILES;   // ctrl[4] bbox[4] tileLive
     size_t need = arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
                   arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
                   arena_sz((size_t)nchunks * V2_CH * 16) + arena_sz((size_t)nLists * maxDesc * 8) +
-                  arena_sz(maxItems * 8) + arena_sz(maxItems * 8) + arena_sz((maxItems + 1) * 4);
+                  arena_sz(maxItems * 8) + arena_sz((maxItems + 1) * 4);
     rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
     if (rc) return rc;
     if (extra) {
@@ -866,6 +927,7 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     unsigned *descRecs = descCount + nLists;
     unsigned *ctrl = descRecs + nLists;
     unsigned *bb = ctrl + 4;
+    unsigned *tileLive = bb + 4;
     unsigned *cellStart = A.take<unsigned>(PP_NCELL + 1);
     unsigned *blockSum = A.take<unsigned>(SCAN_NBLK);
     unsigned *bitmap = A.take<unsigned>(PP_BITWORDS);
@@ -873,7 +935,6 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     float4 *rec = A.take<float4>((size_t)nchunks * V2_CH);
     uint2 *desc = A.take<uint2>((size_t)nLists * maxDesc);
     uint2 *items = A.take<uint2>(maxItems);
-    unsigned long long *itemPre = A.take<unsigned long long>(maxItems);
     unsigned *entryBegin = A.take<unsigned>(maxItems + 1);
 
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of one scan
@@ -887,10 +948,12 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     pp_scan_blocks<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum);
     pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
     pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
+    pp_tile_live<<<V2_NTILES, 64, 0, stream>>>(cellStart, tileLive);
 
     const char *var_env = getenv("MODEST_PP_VARIANT");
-    const int var = var_env ? atoi(var_env) : 0;
-    if (var == 1) {   // V1, kept for A/B measurements
+    int var = var_env ? atoi(var_env) : 0;
+    if (nLists > 1024 * V2_WL_LPT) var = 1;   // > 40 traversals: beyond the work-list capacity, use the direct path
+    if (var == 1) {   // V1: per-point search in the L2-resident index (also kept for A/B measurements)
         pp_stream_v1<<<ctx->num_cus * 3, 256, 0, stream>>>(hist, m0, m1, tr, bb, c, bitmap, cellStart,
                                                            sorted, counts, n_trav, r2);
         modest_prof_mark(ctx, stream, 1);
@@ -899,11 +962,13 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     }
     const char *dbg_env = getenv("MODEST_PP_DBG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const char *ed_env = getenv("MODEST_PP_ENTRY_DIV");
+    const int entry_div = ed_env ? atoi(ed_env) : 4;
     const int grid1 = ctx->num_cus < nchunks ? ctx->num_cus : nchunks;
     pp2_route<<<grid1, 1024, 0, stream>>>(hist, tr, cm, nchunks, bb, c, bitmap, rec, desc, descCount,
-                                          descRecs, n_trav, maxDesc);
-    pp2_worklist<<<1, 1024, 0, stream>>>(descCount, descRecs, cellStart, nLists, n_trav, ctx->num_cus, items,
-                                         itemPre, entryBegin, (unsigned)maxItems, ctrl);
+                                          descRecs, n_trav, maxDesc, dbg);
+    pp2_worklist<<<1, 1024, 0, stream>>>(descCount, descRecs, tileLive, nLists, n_trav, ctx->num_cus, items,
+                                         entryBegin, (unsigned)maxItems, ctrl, entry_div);
     pp2_tiles<<<ctx->num_cus, 1024, 0, stream>>>(rec, desc, descCount, items, entryBegin, ctrl, bb, c, cellStart,
                                                  sorted, counts, n_trav, maxDesc, r2, dbg);
     modest_prof_mark(ctx, stream, 1);
