@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=36)
     ap.add_argument("--cpu-scans", type=int, default=2, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="scans in flight per GPU: host threads, each with its own HIP stream and modest_ctx")
     return ap.parse_args()
 
 
@@ -80,7 +82,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    ctx = _lib.default_context(local)
+    import threading
+    n_workers = max(1, a.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
+    ctxs = [_lib.Context(local) for _ in range(n_workers)]
 
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
@@ -93,7 +98,7 @@ def main():
                                           n_frames=a.frames), dev, calib) for i in range(a.scans)]
     t_gen = time.perf_counter() - t_gen
 
-    def step(i):
+    def step(i, ctx):
         sc = scans[i % len(scans)]
         H = ops.pp_score(sc.live_xyz, sc.hist, sc.offsets, 0.3, ctx=ctx)
         if a.pp_only:
@@ -104,18 +109,42 @@ def main():
         text, kept = gen_label_scan(objs, sc.calib, largs)
         return H, labels, objs, text
 
-    for i in range(a.warmup):
-        step(i)
+    def run(lo, hi):
+        """steps lo..hi-1, dealt round-robin to the worker threads (one HIP stream + ctx each)"""
+        errs = []
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(streams[w]):
+                    for i in range(lo + w, hi, n_workers):
+                        step(i, ctxs[w])
+                    streams[w].synchronize()
+            except Exception as e:   # surfaced after join
+                errs.append(e)
+
+        if n_workers == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(w,)) for w in range(n_workers)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+
+    run(0, a.warmup)
     torch.cuda.synchronize()
     dist.barrier()
-    ctx.profile_begin(a.steps + 8)
+    for c_ in ctxs:
+        c_.profile_begin(a.steps + 8)
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = step(i)
+    run(a.warmup, a.warmup + a.steps)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = ctx.profile_collect(a.steps + 8)
+    kernel_ms = np.concatenate([c_.profile_collect(a.steps + 8) for c_ in ctxs])
     red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
     dt_max, total_scans = red["max_seconds"], red["scans"]
 
@@ -169,6 +198,7 @@ def main():
                                    + f", Lyft-shape: {sc0.N} live pts vs {a.traversals} traversals x {a.frames} frames = {sc0.M} history pts",
                        "live_points": sc0.N, "history_points": sc0.M, "traversals": a.traversals,
                        "frames_per_traversal": a.frames, "radius": 0.3, "scans_per_rank": a.steps,
+                       "scans_in_flight_per_gpu": n_workers,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "speedup_vs_cpu": (value / cpu_baseline["value"]) if cpu_baseline else None,

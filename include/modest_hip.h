@@ -118,6 +118,18 @@ int modest_ransac_score_trials(modest_ctx *ctx, const float *cand_xyz_dev,
                                float thr, int32_t *n_inliers_host,
                                double *sse_host, double *sy_host,
                                double *syy_host, void *stream);
+/* One round trip for a batch of RANSAC trials: (optional) MAD threshold, the
+ * exact-fit plane through the three candidates `triplets[k]` of every trial
+ * (float64 -> float32; NaN for a degenerate triplet) and the scoring of all K
+ * planes.  *thr_inout [host]: < 0 on entry = compute the MAD threshold on the
+ * device (returned on exit), otherwise the threshold to use.  triplets [host]
+ * (K,3) int32 indices into the candidates; models_out [host] (K,3) float32.
+ * Blocking.                                                                   */
+int modest_ransac_trials(modest_ctx *ctx, const float *cand_xyz_dev, int n_cand,
+                         const int32_t *triplets_host, int K, float *thr_inout_host,
+                         float *models_out_host, int32_t *n_inliers_host,
+                         double *sse_host, double *sy_host, double *syy_host,
+                         void *stream);
 /* Least-squares refit of z ~ x,y over the inliers of `model` (float64
  * normal equations, centred); out_model [host] (3) float64. Blocking.       */
 int modest_ransac_refit(modest_ctx *ctx, const float *cand_xyz_dev, int n_cand,
@@ -153,6 +165,19 @@ int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz_dev,
                           double radius, double eps, int min_samples,
                           int32_t *labels_dev, double *kth_d2_dev,
                           int32_t *n_clusters_host, void *stream);
+
+/* ---- a14 filter_labels / is_valid_cluster statistics ------------------
+ * (utils/clustering_utils.py:94-135).  For each label c in [0, n_clusters):
+ * out[c*6 + {0: member count, 1: min, 2: max signed distance to `plane`
+ * ((p . n + d)/|n|, float64), 3: a, 4: b, 5: gamma}] where a, b are the two
+ * order statistics of the members' PP scores that numpy.percentile(pp,
+ * 100*quantile) interpolates between (method 'linear': virtual index
+ * (n-1)*quantile = floor + gamma).  labels [dev] int32, -1 = noise.
+ * out [host] (n_clusters,6) float64.  Blocking.                              */
+int modest_cluster_stats(modest_ctx *ctx, const float *pts_dev, int n, int stride,
+                         const float *pp_dev, const int32_t *labels_dev,
+                         int n_clusters, const double *plane4_host,
+                         double quantile, double *out_host, void *stream);
 
 /* ---- a16 closeness_rectangle angle search (pointcloud_utils.py:167-187)
  * For each cluster c (points pts_xz[offsets[c]..offsets[c+1]) , float64 (x,z)

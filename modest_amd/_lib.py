@@ -37,11 +37,13 @@ SIGNATURES = {
                                           C.c_float, C.c_float, VP, VP, VP, VP]),
     "modest_mad_threshold": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "modest_ransac_score_trials": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_float, VP, VP, VP, VP, VP]),
+    "modest_ransac_trials": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "modest_ransac_refit": (C.c_int, [VP, VP, C.c_int, VP, C.c_float, VP, VP, VP]),
     "modest_plane_range_mask": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_double, VP, VP, VP, VP, VP,
                                           VP, VP]),
     "modest_cluster_dbscan": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                         VP, VP, VP, VP]),
+    "modest_cluster_stats": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, C.c_double, VP, VP]),
     "modest_fit_boxes_closeness": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP, VP]),
     "modest_lowest_point": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),
     "modest_boxes_overlap_bev": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
@@ -128,7 +130,10 @@ _default_ctx = {}
 
 
 def default_context(device: int = 0) -> Context:
-    ctx = _default_ctx.get(device)
+    """One context (scratch arena) per device AND per host thread: calls on a context are
+    stream ordered, and every host thread drives its own HIP stream."""
+    key = (device, threading.get_ident())
+    ctx = _default_ctx.get(key)
     if ctx is None:
-        ctx = _default_ctx[device] = Context(device)
+        ctx = _default_ctx[key] = Context(device)
     return ctx

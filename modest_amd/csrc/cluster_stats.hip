@@ -1,0 +1,200 @@
+// Per-cluster statistics for filter_labels / is_valid_cluster
+// (generate_cluster_mask/utils/clustering_utils.py:94-135): member count, min / max signed
+// distance to the ground plane, and the two order statistics of the PP score that
+// numpy.percentile(pp, q) interpolates between (method 'linear': virtual index (n-1)*q).
+// The reference evaluates these with one boolean mask + numpy reductions per cluster on the
+// host; here the members of every cluster are gathered by a counting sort and one workgroup
+// per cluster does the reductions and an exact radix select.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int CS_THREADS = 256;
+
+__device__ __forceinline__ unsigned cs_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float cs_unkey(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__global__ void cs_count(const int *__restrict__ labels, int n, int C, unsigned *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int l = labels[i];
+    if (l >= 0 && l < C) atomicAdd(&cnt[l], 1u);
+}
+
+__global__ void cs_scan(const unsigned *__restrict__ cnt, int C, unsigned *__restrict__ start) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned run = 0;
+    for (int c = 0; c < C; ++c) {
+        start[c] = run;
+        run += cnt[c];
+    }
+    start[C] = run;
+}
+
+__global__ void cs_scatter(const int *__restrict__ labels, int n, int C, const unsigned *__restrict__ start,
+                           unsigned *fill, int *__restrict__ members) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int l = labels[i];
+    if (l >= 0 && l < C) members[start[l] + atomicAdd(&fill[l], 1u)] = i;
+}
+
+struct PlaneP {
+    double n0, n1, n2, d, norm, q;
+};
+
+// k-th smallest (0-based) pp among the members: radix descent 11 + 11 + 10 bits
+__device__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n, unsigned k,
+                           unsigned *hist /* 2048 */, unsigned *wsum /* 4 */, unsigned *sel /* 2 */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned prefix = 0, mask = 0;
+    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
+    for (int ps = 0; ps < 3; ++ps) {
+        const int shift = shifts[ps];
+        const unsigned nb = 1u << bitsv[ps];
+        for (unsigned b = tid; b < 2048u; b += CS_THREADS) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += CS_THREADS) {
+            const unsigned key = cs_key(pp[mem[i]]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1u)], 1u);
+        }
+        __syncthreads();
+        // 8 bins per thread
+        unsigned v[8], s = 0;
+        for (int j = 0; j < 8; ++j) {
+            v[j] = hist[8 * tid + j];
+            s += v[j];
+        }
+        unsigned inc = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (int q = 0; q < w; ++q) base += wsum[q];
+        unsigned run = base + inc - s;
+        for (int j = 0; j < 8; ++j) {
+            if (k >= run && k < run + v[j]) {
+                sel[0] = 8 * tid + j;
+                sel[1] = k - run;
+            }
+            run += v[j];
+        }
+        __syncthreads();
+        prefix |= sel[0] << shift;
+        mask |= (nb - 1u) << shift;
+        k = sel[1];
+        __syncthreads();
+    }
+    return cs_unkey(prefix);
+}
+
+// out[c*6 + {0:n, 1:dmin, 2:dmax, 3:a, 4:b, 5:gamma}]  (doubles)
+__global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__ pts, int stride,
+                                                       const float *__restrict__ pp,
+                                                       const int *__restrict__ members,
+                                                       const unsigned *__restrict__ start, PlaneP P,
+                                                       double *__restrict__ out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wsum[4], sel[2];
+    __shared__ double rmin[4], rmax[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int n = (int)(start[c + 1] - start[c]);
+    const int *mem = members + start[c];
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = tid; i < n; i += CS_THREADS) {
+        const float *p = pts + (size_t)mem[i] * stride;
+        // ptc @ plane[:3] + plane[3] then / norm: the float64 rounding of numpy's product
+        double dist = (double)p[0] * P.n0;
+        dist = fma((double)p[1], P.n1, dist);
+        dist = fma((double)p[2], P.n2, dist);
+        dist = (dist + P.d) / P.norm;
+        mn = fmin(mn, dist);
+        mx = fmax(mx, dist);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, o));
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    if ((tid & 63) == 0) {
+        rmin[tid >> 6] = mn;
+        rmax[tid >> 6] = mx;
+    }
+    __syncthreads();
+    double a = 0.0, b = 0.0, gamma = 0.0;
+    if (n > 0) {
+        // numpy 'linear' on float32 data works in float32: virtual index (n-1)*q, neighbours
+        // floor / floor+1; at or beyond the last index both neighbours are the maximum
+        const float qf = (float)P.q;
+        const float vi = (float)(n - 1) * qf;
+        const float fl = floorf(vi);
+        int prev = (int)fl, next = prev + 1;
+        if (vi >= (float)(n - 1)) prev = next = n - 1;
+        if (vi < 0.f) prev = next = 0;
+        next = min(next, n - 1);
+        gamma = (double)(vi - fl);
+        a = (double)cs_select(pp, mem, n, (unsigned)prev, hist, wsum, sel);
+        b = (next == prev) ? a : (double)cs_select(pp, mem, n, (unsigned)next, hist, wsum, sel);
+    }
+    if (tid == 0) {
+        out[6 * c + 0] = (double)n;
+        out[6 * c + 1] = fmin(fmin(rmin[0], rmin[1]), fmin(rmin[2], rmin[3]));
+        out[6 * c + 2] = fmax(fmax(rmax[0], rmax[1]), fmax(rmax[2], rmax[3]));
+        out[6 * c + 3] = a;
+        out[6 * c + 4] = b;
+        out[6 * c + 5] = gamma;
+    }
+}
+
+}  // namespace
+
+extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
+                                    const int32_t *labels, int n_clusters, const double *plane4,
+                                    double quantile, double *out_host, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0 && n_clusters >= 0 && (stride == 3 || stride == 4), "bad sizes");
+    MODEST_REQUIRE(quantile >= 0.0 && quantile <= 1.0, "quantile must be in [0,1]");
+    if (n_clusters == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts && pp && labels && plane4 && out_host, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t b_cnt = arena_sz((size_t)2 * n_clusters * 4), b_start = arena_sz((size_t)(n_clusters + 1) * 4);
+    const size_t b_mem = arena_sz((size_t)n * 4), b_out = arena_sz((size_t)n_clusters * 48);
+    int rc = modest_ctx_reserve(ctx, b_cnt + b_start + b_mem + b_out);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, (size_t)n_clusters * 48);
+    if (rc) return rc;
+    unsigned *cnt = reinterpret_cast<unsigned *>(ctx->scratch);
+    unsigned *fill = cnt + n_clusters;
+    unsigned *start = reinterpret_cast<unsigned *>(ctx->scratch + b_cnt);
+    int *members = reinterpret_cast<int *>(ctx->scratch + b_cnt + b_start);
+    double *d_out = reinterpret_cast<double *>(ctx->scratch + b_cnt + b_start + b_mem);
+    MODEST_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)2 * n_clusters * 4, stream));
+    PlaneP P;
+    P.n0 = plane4[0];
+    P.n1 = plane4[1];
+    P.n2 = plane4[2];
+    P.d = plane4[3];
+    P.norm = sqrt((plane4[0] * plane4[0] + plane4[1] * plane4[1]) + plane4[2] * plane4[2]);
+    P.q = quantile;
+    const int nb = (n + 255) / 256;
+    if (n > 0) cs_count<<<nb, 256, 0, stream>>>(labels, n, n_clusters, cnt);
+    cs_scan<<<1, 64, 0, stream>>>(cnt, n_clusters, start);
+    if (n > 0) cs_scatter<<<nb, 256, 0, stream>>>(labels, n, n_clusters, start, fill, members);
+    cs_stats<<<n_clusters, CS_THREADS, 0, stream>>>(pts, stride, pp, members, start, P, d_out);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, d_out, (size_t)n_clusters * 48, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    const double *h = reinterpret_cast<const double *>(ctx->pinned);
+    for (size_t i = 0; i < (size_t)n_clusters * 6; ++i) out_host[i] = h[i];
+    return MODEST_OK;
+}

@@ -174,9 +174,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // partial[(blk*K + k)*4 + {0:count,1:sse,2:sy,3:syy}]
 __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
                                                               const float *__restrict__ models,
-                                                              int K, float thr,
+                                                              int K, const float *__restrict__ thr_ptr,
                                                               double *__restrict__ partial) {
     __shared__ double red[SCORE_WAVES][4];
+    const float thr = *thr_ptr;
     const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
     const bool valid = i < n;
     float x = 0, y = 0, z = 0;
@@ -209,6 +210,44 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
         }
         __syncthreads();
     }
+}
+
+// exact-fit plane z = c0 x + c1 y + b through the three candidates of every trial: float64,
+// centred 2x2 normal equations, rounded to float32 (what LinearRegression stores for float32
+// data); a degenerate (collinear in xy) triplet yields NaN = a trial without inliers
+__global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__restrict__ trip, int K,
+                           float *__restrict__ models) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double x[3], y[3], z[3];
+    for (int j = 0; j < 3; ++j) {
+        int i = trip[3 * k + j];
+        i = min(max(i, 0), n - 1);
+        x[j] = cand[3 * (size_t)i];
+        y[j] = cand[3 * (size_t)i + 1];
+        z[j] = cand[3 * (size_t)i + 2];
+    }
+    const double mx = (x[0] + x[1] + x[2]) / 3.0, my = (y[0] + y[1] + y[2]) / 3.0, mz = (z[0] + z[1] + z[2]) / 3.0;
+    double sxx = 0, sxy = 0, syy = 0, sxz = 0, syz = 0;
+    for (int j = 0; j < 3; ++j) {
+        const double dx = x[j] - mx, dy = y[j] - my, dz = z[j] - mz;
+        sxx += dx * dx;
+        sxy += dx * dy;
+        syy += dy * dy;
+        sxz += dx * dz;
+        syz += dy * dz;
+    }
+    const double det = sxx * syy - sxy * sxy;
+    float c0 = NAN, c1 = NAN, b = NAN;
+    if (fabs(det) > 1e-12 * fmax(sxx * syy, 1e-300)) {
+        const double a0 = (sxz * syy - syz * sxy) / det, a1 = (syz * sxx - sxz * sxy) / det;
+        c0 = (float)a0;
+        c1 = (float)a1;
+        b = (float)(mz - a0 * mx - a1 * my);
+    }
+    models[3 * k] = c0;
+    models[3 * k + 1] = c1;
+    models[3 * k + 2] = b;
 }
 
 // one wavefront per output; lane-strided partial sums then a fixed shuffle tree (deterministic)
@@ -383,11 +422,11 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
-    const size_t b_models = arena_sz((size_t)K * 12), b_part = arena_sz((size_t)nb * K * 32);
+    const size_t b_models = arena_sz((size_t)K * 12 + 4), b_part = arena_sz((size_t)nb * K * 32);
     const size_t b_out = arena_sz((size_t)K * 32);
     int rc = modest_ctx_reserve(ctx, b_models + b_part + b_out);
     if (rc) return rc;
-    const size_t hoff = ((size_t)K * 12 + 63) & ~size_t(63);
+    const size_t hoff = ((size_t)K * 12 + 4 + 63) & ~size_t(63);
     rc = modest_ctx_reserve_pinned(ctx, hoff + (size_t)K * 32);
     if (rc) return rc;
     float *dm = reinterpret_cast<float *>(ctx->scratch);
@@ -396,8 +435,9 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     float *hm = reinterpret_cast<float *>(ctx->pinned);
     double *hout = reinterpret_cast<double *>(ctx->pinned + hoff);
     for (int i = 0; i < K * 3; ++i) hm[i] = models_host[i];
-    MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12, hipMemcpyHostToDevice, stream));
-    score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K, thr, dp);
+    hm[K * 3] = thr;   // the kernel reads the threshold from device memory
+    MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12 + 4, hipMemcpyHostToDevice, stream));
+    score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K, dm + 3 * K, dp);
     score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nb, K, dout);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
@@ -407,6 +447,64 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
         if (sse) sse[k] = hout[4 * k + 1];
         if (sy) sy[k] = hout[4 * k + 2];
         if (syy) syy[k] = hout[4 * k + 3];
+    }
+    return MODEST_OK;
+}
+
+extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_cand, const int32_t *trip_host,
+                                    int K, float *thr_inout, float *models_out, int32_t *n_inliers,
+                                    double *sse, double *sy, double *syy, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n_cand >= 3 && K >= 1 && K <= 4096, "bad n_cand / K");
+    MODEST_REQUIRE(cand && trip_host && thr_inout && models_out && n_inliers, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
+    // device: [trip K*3 i32 | thr pair 2 f32 | models K*3 f32 | partial | out K*4 f64]
+    const size_t b_trip = arena_sz((size_t)K * 12), b_thr = arena_sz(8), b_models = arena_sz((size_t)K * 12);
+    const size_t b_part = arena_sz((size_t)nb * K * 32), b_out = arena_sz((size_t)K * 32);
+    int rc = modest_ctx_reserve(ctx, b_trip + b_thr + b_models + b_part + b_out);
+    if (rc) return rc;
+    // pinned: [trip | thr(2) | out K*4 f64 | models K*3 f32]
+    const size_t h_trip = ((size_t)K * 12 + 63) & ~size_t(63), h_out = (size_t)K * 32;
+    rc = modest_ctx_reserve_pinned(ctx, h_trip + 64 + h_out + (size_t)K * 12);
+    if (rc) return rc;
+    char *d = ctx->scratch;
+    int *d_trip = reinterpret_cast<int *>(d);
+    float *d_thr = reinterpret_cast<float *>(d + b_trip);
+    float *d_models = reinterpret_cast<float *>(d + b_trip + b_thr);
+    double *d_part = reinterpret_cast<double *>(d + b_trip + b_thr + b_models);
+    double *d_out = reinterpret_cast<double *>(d + b_trip + b_thr + b_models + b_part);
+    int *h_tripp = reinterpret_cast<int *>(ctx->pinned);
+    float *h_thr = reinterpret_cast<float *>(ctx->pinned + h_trip);
+    double *h_outp = reinterpret_cast<double *>(ctx->pinned + h_trip + 64);
+    float *h_models = reinterpret_cast<float *>(ctx->pinned + h_trip + 64 + h_out);
+    for (int i = 0; i < 3 * K; ++i) h_tripp[i] = trip_host[i];
+    MODEST_HIP_CHECK(hipMemcpyAsync(d_trip, h_tripp, (size_t)K * 12, hipMemcpyHostToDevice, stream));
+    if (*thr_inout < 0.f) {   // residual threshold = MAD of the candidates, computed on the device
+        mad_kernel<<<1, 1024, 0, stream>>>(cand, n_cand, d_thr);
+    } else {
+        h_thr[0] = 0.f;
+        h_thr[1] = *thr_inout;
+        MODEST_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr, 8, hipMemcpyHostToDevice, stream));
+    }
+    fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, d_trip, K, d_models);
+    score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K, d_thr + 1, d_part);
+    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nb, K, d_out);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_outp, d_out, h_out, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_models, d_models, (size_t)K * 12, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_thr, d_thr, 8, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    *thr_inout = h_thr[1];
+    for (int k = 0; k < K; ++k) {
+        n_inliers[k] = (int32_t)h_outp[4 * k];
+        if (sse) sse[k] = h_outp[4 * k + 1];
+        if (sy) sy[k] = h_outp[4 * k + 2];
+        if (syy) syy[k] = h_outp[4 * k + 3];
+        models_out[3 * k] = h_models[3 * k];
+        models_out[3 * k + 1] = h_models[3 * k + 1];
+        models_out[3 * k + 2] = h_models[3 * k + 2];
     }
     return MODEST_OK;
 }

@@ -51,6 +51,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
         ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state)
     _, kept_xyz, kept_idx = ops.plane_range_mask(ptc_dev, plane, pe.offset, pe.range, args.limit_range)
     labels = np.zeros(ptc.shape[0], dtype=int) - 1
+    labels_dev = torch.full((ptc.shape[0],), -1, dtype=torch.int32, device=ptc_dev.device)
     if args.clustering.method != "DBSCAN":
         raise NotImplementedError(args.clustering.method)
     g = args.graph
@@ -64,10 +65,11 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
         kept_long = kept_idx.long()
         lab_kept, _ = ops.cluster_dbscan(kept_xyz, pp_dev[kept_long].contiguous(), g.n_neighbors, g.radius,
                                          args.clustering.DBSCAN.eps, args.clustering.DBSCAN.min_samples)
+        labels_dev[kept_long] = lab_kept          # device copy for the cluster statistics (plumbing)
         labels[kept_idx.cpu().numpy()] = lab_kept.cpu().numpy()
     labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
                                     plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
-                                    **args.filtering)
+                                    pp_dev=pp_dev, labels_dev=labels_dev, **args.filtering)
     ptc_in_rect = calib.project_velo_to_rect(ptc[:, :3])
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
     order = np.argsort(labels_filtered, kind="stable")

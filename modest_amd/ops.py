@@ -159,6 +159,25 @@ def ransac_score_trials(cand: torch.Tensor, models: np.ndarray, thr: float, ctx:
     return n_in, sse, sy, syy
 
 
+def ransac_trials(cand: torch.Tensor, triplets: np.ndarray, thr: Optional[float] = None,
+                  ctx: Optional[Context] = None):
+    """MAD threshold (when thr is None) + exact-fit planes of the triplets + their scores, one
+    device round trip.  Returns (thr, models (K,3) f32, n_inliers, sse, sy, syy)."""
+    lib = load()
+    _dev(cand, torch.float32, "cand")
+    trip = np.ascontiguousarray(triplets, dtype=np.int32).reshape(-1, 3)
+    K = trip.shape[0]
+    thr_io = C.c_float(-1.0 if thr is None else float(np.float32(thr)))
+    models = np.zeros((K, 3), dtype=np.float32)
+    n_in = np.zeros(K, dtype=np.int32)
+    sse, sy, syy = (np.zeros(K, dtype=np.float64) for _ in range(3))
+    c = _ctx(ctx, cand)
+    check(lib.modest_ransac_trials(c.handle, cand.data_ptr(), cand.shape[0], _np_ptr(trip), K, C.byref(thr_io),
+                                   _np_ptr(models), _np_ptr(n_in), _np_ptr(sse), _np_ptr(sy), _np_ptr(syy),
+                                   _stream()), "modest_ransac_trials")
+    return np.float32(thr_io.value), models, n_in, sse, sy, syy
+
+
 def ransac_refit(cand: torch.Tensor, model: np.ndarray, thr: float, ctx: Optional[Context] = None):
     lib = load()
     _dev(cand, torch.float32, "cand")
@@ -214,6 +233,24 @@ def cluster_dbscan(xyz: torch.Tensor, pp: torch.Tensor, n_neighbors: int = 70, r
                                     kth.data_ptr() if kth is not None else None, C.byref(ncl), _stream()),
           "modest_cluster_dbscan")
     return (labels, int(ncl.value), kth) if return_kth else (labels, int(ncl.value))
+
+
+def cluster_stats(pts: torch.Tensor, pp: torch.Tensor, labels: torch.Tensor, n_clusters: int,
+                  plane: np.ndarray, quantile: float, ctx: Optional[Context] = None) -> np.ndarray:
+    """Per-cluster (count, min dist, max dist, a, b, gamma) for is_valid_cluster; (C,6) float64 host."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    _dev(pp, torch.float32, "pp")
+    _dev(labels, torch.int32, "labels")
+    out = np.zeros((n_clusters, 6), dtype=np.float64)
+    if n_clusters == 0:
+        return out
+    plane = np.ascontiguousarray(plane, dtype=np.float64).reshape(4)
+    c = _ctx(ctx, pts)
+    check(lib.modest_cluster_stats(c.handle, pts.data_ptr(), pts.shape[0], pts.shape[1], pp.data_ptr(),
+                                   labels.data_ptr(), int(n_clusters), _np_ptr(plane), float(quantile),
+                                   _np_ptr(out), _stream()), "modest_cluster_stats")
+    return out
 
 
 # --------------------------------------------------------------------------- box fitting

@@ -52,23 +52,43 @@ def is_valid_cluster(ptc, pp_score, plane, min_points=10, max_volume=40, min_vol
     return True
 
 
-def filter_labels(ptc, pp_score, labels, random_state=None, plane=None, ptc_dev=None, **kwargs):
-    """(:119-135) drop clusters failing is_valid_cluster, relabel to 0 = background,
-    1..C.  The second ground plane (hard-coded max_hs=-1.5, range ((-70,70),(-50,50)))
-    is estimated on the device; cluster statistics are a few hundred points each."""
+def percentile_from_order_stats(a, b, gamma):
+    """numpy.percentile(float32 data, q, method='linear') given the two neighbouring order
+    statistics a <= b and the fractional part gamma of the virtual index.  numpy (2.x) keeps
+    the data dtype throughout: ``_lerp`` = ``a + (b - a) * t``, replaced by
+    ``b - (b - a) * (1 - t)`` where t >= 0.5, all in float32."""
+    a32, b32 = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    t = np.asarray(gamma, dtype=np.float32)
+    diff = b32 - a32
+    lo = a32 + diff * t
+    hi = b32 - diff * (np.float32(1) - t)
+    return np.where(t >= np.float32(0.5), hi, lo)
+
+
+def filter_labels(ptc, pp_score, labels, random_state=None, plane=None, ptc_dev=None, pp_dev=None,
+                  labels_dev=None, min_points=10, max_volume=40, min_volume=0.5, max_min_height=4,
+                  min_max_height=0, percentile=10, min_percentile_pp_score=0.7):
+    """(:119-135) drop clusters failing is_valid_cluster, relabel to 0 = background, 1..C.
+    The second ground plane (hard-coded max_hs=-1.5, range ((-70,70),(-50,50))) and the
+    per-cluster statistics (count, height extremes, PP-score percentile) are device work;
+    the host keeps the four scalar comparisons per cluster."""
     labels = labels.copy()
+    dev_pts = to_device(ptc) if ptc_dev is None else ptc_dev
     if plane is None:
-        plane = estimate_plane(ptc if ptc_dev is None else ptc_dev, max_hs=-1.5, ptc_range=((-70, 70), (-50, 50)),
-                               random_state=random_state)
-    ptc = np.asarray(ptc)
-    order = np.argsort(labels, kind="stable")          # members of a label in ascending index order
-    sl = labels[order]
+        plane = estimate_plane(dev_pts, max_hs=-1.5, ptc_range=((-70, 70), (-50, 50)), random_state=random_state)
     n_lab = int(labels.max()) + 1 if labels.size else 0
-    starts = np.searchsorted(sl, np.arange(n_lab), side="left")
-    ends = np.searchsorted(sl, np.arange(n_lab), side="right")
-    for i in range(n_lab):
-        members = order[starts[i]:ends[i]]
-        if not is_valid_cluster(ptc[members, :3], pp_score[members], plane, **kwargs):
-            labels[members] = -1
+    if n_lab > 0:
+        dev_pp = to_device(pp_score) if pp_dev is None else pp_dev
+        dev_lab = torch.from_numpy(labels.astype(np.int32)).to(dev_pts.device) if labels_dev is None else labels_dev
+        q32 = np.true_divide(percentile, np.float32(100))     # numpy divides by a float32 hundred for float32 data
+        st = ops.cluster_stats(dev_pts, dev_pp, dev_lab, n_lab, np.asarray(plane, dtype=np.float64), float(q32))
+        n, dmin, dmax = st[:, 0], st[:, 1], st[:, 2]
+        pct = percentile_from_order_stats(st[:, 3], st[:, 4], st[:, 5])
+        valid = (n >= min_points) & ~(dmin > max_min_height) & ~(dmax < min_max_height) & \
+            ~(pct > np.float32(min_percentile_pp_score))
+        member = labels >= 0
+        drop = np.zeros(labels.shape, dtype=bool)
+        drop[member] = ~valid[labels[member]]
+        labels[drop] = -1
     uniq = np.unique(labels)
     return np.searchsorted(uniq, labels).astype(labels.dtype)

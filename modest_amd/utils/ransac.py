@@ -8,12 +8,12 @@ MAD(z), absolute loss, ``max_trials = 100`` with the dynamic stop
 better R^2", final least-squares refit on the consensus set.
 
 Split of work:
-  host   - the random triplets (``sample_without_replacement`` on the caller's
-           RandomState, exactly the stream sklearn would consume: one draw per
-           executed trial), the 3-point plane of each trial, the sequential
+  host   - the random triplets (the caller's RandomState is advanced by exactly the
+           draws sklearn would consume for the executed trials), the sequential
            accept rule and dynamic trial bound (a few dozen scalar decisions);
-  device - MAD threshold (exact float32 medians), residual / inlier counting /
-           R^2 sums of a whole batch of trials in one launch, the final refit
+  device - MAD threshold (exact float32 medians), the 3-point plane of each
+           trial, residual / inlier counting / R^2 sums of a whole batch of
+           trials -- all in ONE round trip per batch -- and the final refit
            (float64 normal equations).
 
 Numerical contract: inlier decisions are float32 like sklearn's (pred =
@@ -81,35 +81,64 @@ class RansacResult:
     __slots__ = ("coef", "intercept", "n_trials", "n_inliers", "threshold", "triplets", "best_model")
 
 
+def draw_triplets(rs, n_population, n_trials):
+    """`n_trials` consecutive ``sample_without_replacement(n_population, 3, random_state=rs)``
+    draws.  For 3/n_population < 0.01 sklearn's 'tracking_selection' is `rs.randint(n)` until
+    three distinct values are found; that stream is consumed here in one vectorised call
+    (tests/test_abi_and_host.py checks triplets AND generator state against sklearn).
+    Returns (triplets (B,3) int64, draws consumed after each trial (B,) or None)."""
+    if 3.0 / n_population >= 0.01:    # small populations use other sklearn methods: call it directly
+        return np.stack([sample_without_replacement(n_population, 3, random_state=rs)
+                         for _ in range(n_trials)]), None
+    state = rs.get_state()
+    draws = rs.randint(n_population, size=3 * n_trials + 16)
+    trip = draws[:3 * n_trials].reshape(n_trials, 3)
+    clean = (trip[:, 0] != trip[:, 1]) & (trip[:, 0] != trip[:, 2]) & (trip[:, 1] != trip[:, 2])
+    if clean.all():
+        used = 3 * np.arange(1, n_trials + 1)
+    else:                             # a duplicate inside a triplet (probability ~3/n): replay scalar-wise
+        rs.set_state(state)
+        draws = rs.randint(n_population, size=4 * n_trials + 64)
+        out, used, pos = [], [], 0
+        for _ in range(n_trials):
+            sel = []
+            while len(sel) < 3:
+                j = int(draws[pos])
+                pos += 1
+                if j not in sel:
+                    sel.append(j)
+            out.append(sel)
+            used.append(pos)
+        trip, used = np.asarray(out), np.asarray(used)
+    rs.set_state(state)               # the caller advances the stream by the trials it executes
+    return trip, used
+
+
 def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, stop_probability: float = 0.99,
-                 batch: int = 16, ctx=None) -> RansacResult:
+                 batch: int = 48, ctx=None) -> RansacResult:
     """cand: (m,3) float32 device tensor of candidate ground points (x, y, z)."""
     n_samples = int(cand.shape[0])
     min_samples = 3
     if n_samples < min_samples:
         raise ValueError("`min_samples` may not be larger than number of samples: n_samples = %d." % n_samples)
     rs = check_random_state(random_state)
-    thr = ops.mad_threshold(cand, ctx=ctx)
+    thr = None                        # MAD(z), computed on the device with the first batch
 
     n_inliers_best, score_best, best_model = 1, -np.inf, None
     n_trials, limit = 0, max_trials
     triplets = []
     while n_trials < limit:
-        # draw a batch from a COPY of the stream; the real stream is advanced only
-        # by the trials that are actually executed (below)
-        state = rs.get_state()
         nb = int(min(batch, limit - n_trials))
-        trip = np.stack([sample_without_replacement(n_samples, min_samples, random_state=rs) for _ in range(nb)])
-        pts = cand[torch.as_tensor(trip.reshape(-1), device=cand.device, dtype=torch.long)].cpu().numpy()
-        models = planes_through_triplets(pts.reshape(nb, 3, 3))
-        n_in, sse, sy, syy = ops.ransac_score_trials(cand, models, thr, ctx=ctx)
+        state = rs.get_state()
+        trip, consumed = draw_triplets(rs, n_samples, nb)
+        # one device round trip: MAD threshold (first batch), exact-fit planes, scores of all nb trials
+        thr, models, n_in, sse, sy, syy = ops.ransac_trials(cand, trip, thr, ctx=ctx)
         used = 0
         for k in range(nb):
             if not (n_trials < limit):
                 break
             n_trials += 1
             used += 1
-            triplets.append(trip[k])
             nk = int(n_in[k])
             if nk < n_inliers_best:
                 continue
@@ -118,7 +147,12 @@ def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, s
                 continue
             n_inliers_best, score_best, best_model = nk, score, models[k].copy()
             limit = min(limit, dynamic_max_trials(n_inliers_best, n_samples, min_samples, stop_probability))
-        if used < nb:   # rewind, then consume exactly `used` draws
+        triplets.append(trip[:used])
+        # advance the caller's stream by exactly the executed trials (what sklearn would have consumed)
+        if consumed is not None:
+            if used:
+                rs.randint(n_samples, size=int(consumed[used - 1]))
+        elif used < nb:
             rs.set_state(state)
             for _ in range(used):
                 sample_without_replacement(n_samples, min_samples, random_state=rs)
@@ -132,6 +166,6 @@ def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, s
     res.n_trials = n_trials
     res.n_inliers = n_final
     res.threshold = thr
-    res.triplets = np.array(triplets)
+    res.triplets = np.concatenate(triplets) if triplets else np.zeros((0, 3), dtype=np.int64)
     res.best_model = best_model
     return res

@@ -78,3 +78,43 @@ def test_ransac_control_helpers():
         assert np.max(np.abs(p[b, :, 0] * m[b, 0] + p[b, :, 1] * m[b, 1] + m[b, 2] - p[b, :, 2])) < 1e-4
     assert ransac.r2_from_sums(10, 0.0, 5.0, 10.0) == 1.0
     assert ransac.r2_from_sums(4, 1.0, 4.0, 8.0) == pytest.approx(1.0 - 1.0 / 4.0)
+
+
+def test_vectorised_triplet_stream_equals_sklearn():
+    from sklearn.utils.random import sample_without_replacement
+    from modest_amd.utils.ransac import draw_triplets
+    for n_pop in (7, 120, 301, 9973, 17001):
+        for seed in (0, 5):
+            a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+            ref = np.stack([sample_without_replacement(n_pop, 3, random_state=a) for _ in range(60)])
+            trip, consumed = draw_triplets(b, n_pop, 60)
+            assert np.array_equal(trip, ref), n_pop
+            # the caller advances its stream by the executed trials only: emulate 37 executed
+            c = np.random.RandomState(seed)
+            for _ in range(37):
+                sample_without_replacement(n_pop, 3, random_state=c)
+            if consumed is not None:
+                b.randint(n_pop, size=int(consumed[36]))
+                assert np.array_equal(b.get_state()[1], c.get_state()[1]) and b.get_state()[2] == c.get_state()[2]
+
+
+def test_percentile_lerp_equals_numpy():
+    from modest_amd.utils.clustering_utils import percentile_from_order_stats
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 5, 10, 11, 37, 100, 1001, 20011):
+        for q in (20, 10, 50, 73.5, 100):
+            x = rng.uniform(0, 1, n).astype(np.float32)
+            if n > 4:
+                x[:3] = x[3]                    # duplicates
+            s = np.sort(x)
+            q32 = np.true_divide(q, np.float32(100))
+            vi = np.float32(n - 1) * q32        # the float32 arithmetic cluster_stats.hip performs
+            fl = np.floor(vi)
+            prev = int(fl)
+            nxt = prev + 1
+            if vi >= n - 1:
+                prev = nxt = n - 1
+            nxt = min(nxt, n - 1)
+            got = percentile_from_order_stats(s[prev], s[nxt], vi - fl)
+            ref = np.percentile(x, q)
+            assert ref.dtype == np.float32 and np.float32(got) == ref, (n, q)

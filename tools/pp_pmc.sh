@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc -o p -- python bench.py --steps 3 --warmup 1 --pp-only --cpu-scans 0 > gpurun_out/pmc.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc -o p -- python bench.py --steps 3 --warmup 1 --pp-only --cpu-scans 0 > gpurun_out/pmc.log 2>&1
 ls gpurun_out/pmc
 python - <<'PY'
 import csv,glob,collections
