@@ -384,6 +384,109 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
     if (lane == 0) labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
 }
 
+// ---- explicit adjacency (the fast path) ----------------------------------------------
+// An edge needs j in kNN_k(i), so a point has at most k (+ exact ties) edges: the degree pass
+// stores them (cell-sorted indices) in a fixed-stride table and every later pass walks the
+// table instead of re-evaluating the float64 predicate.  More than ADJ edges (only possible
+// with dozens of exactly tied k-th distances) raises `overflow` and the host re-runs the
+// recomputing kernels below.
+constexpr int ADJ = 128;
+
+__global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__restrict__ sorted, int n,
+                                                              const CGrid *g,
+                                                              const unsigned *__restrict__ start,
+                                                              const double *__restrict__ kthS, double r2,
+                                                              double eps, int min_samples,
+                                                              unsigned char *__restrict__ coreS,
+                                                              int *__restrict__ deg, int *__restrict__ adj,
+                                                              int *overflow) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    const float4 q = sorted[s];
+    const double kq = kthS[s];
+    const Rows R = rows_of(q, g, start);
+    unsigned total = 0;
+    for (int r = 0; r < R.n; ++r)
+        for (unsigned base = R.s[r]; base < R.e[r]; base += 64) {   // wave-uniform trip count
+            const unsigned j = base + lane;
+            const bool e = j < R.e[r] && (int)j != s && edge_ok(q, kq, sorted[j], kthS[j], r2, eps);
+            const unsigned long long bal = __ballot(e);
+            const unsigned pos = total + __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (e && pos < (unsigned)ADJ) adj[(size_t)s * ADJ + pos] = (int)j;
+            total += __popcll(bal);
+        }
+    if (lane == 0) {
+        deg[s] = (int)min(total, (unsigned)ADJ);
+        coreS[s] = ((int)total + 1 >= min_samples) ? 1 : 0;
+        if (total > (unsigned)ADJ) atomicOr(overflow, 1);
+    }
+}
+
+// one round of min-root hooking: the root of every core point is hung under the smallest root
+// found among its core neighbours (parents only decrease, so the forest stays acyclic)
+__global__ void hook_adj_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+                                const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !coreS[s]) return;
+    const int rme = parent[sidx[s]];
+    int m = rme;
+    const int *row = adj + (size_t)s * ADJ;
+    for (int e = 0; e < deg[s]; ++e) {
+        const int j = row[e];
+        if (coreS[j]) m = min(m, parent[sidx[j]]);
+    }
+    if (m < rme) atomicMin(parent + rme, m);
+}
+
+__global__ void flatten_kernel(int *parent, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = uf_load(parent, i);
+    for (;;) {
+        const int p = uf_load(parent, r);
+        if (p == r) break;
+        r = p;
+    }
+    __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exact clean-up: unite whatever the hooking rounds left apart (pairs that already share a
+// parent are skipped with two plain loads)
+__global__ void union_adj_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+                                 const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !coreS[s]) return;
+    const int me = sidx[s];
+    const int *row = adj + (size_t)s * ADJ;
+    for (int e = 0; e < deg[s]; ++e) {
+        const int j = row[e];
+        if (j <= s || !coreS[j]) continue;
+        const int other = sidx[j];
+        if (uf_load(parent, me) != uf_load(parent, other)) uf_unite(parent, me, other);
+    }
+}
+
+__global__ void label_adj_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+                                 const int *__restrict__ adj, const int *__restrict__ sidx,
+                                 const int *__restrict__ root, const unsigned *__restrict__ rank,
+                                 int *__restrict__ labels) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int me = sidx[s];
+    if (coreS[s]) {
+        labels[me] = (int)rank[root[me]];
+        return;
+    }
+    int best = 0x7fffffff;
+    const int *row = adj + (size_t)s * ADJ;
+    for (int e = 0; e < deg[s]; ++e) {
+        const int j = row[e];
+        if (coreS[j]) best = min(best, root[sidx[j]]);
+    }
+    labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
+}
+
 __global__ void scatter_kth(const double *__restrict__ kthS, const int *__restrict__ sidx, int n,
                             double *__restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,10 +508,11 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
 
-    const size_t zero_words = (size_t)2 * CG_CELLS;
+    const size_t zero_words = (size_t)2 * CG_CELLS + 4;   // cell counters, fill counters, overflow flag
     size_t need = arena_sz(sizeof(CGrid)) + arena_sz(zero_words * 4) + arena_sz((CG_CELLS + 1) * 4) +
                   arena_sz((size_t)n * 16) + arena_sz((size_t)n * 4) + arena_sz((size_t)n * 8) +
-                  arena_sz((size_t)n) + arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4);
+                  arena_sz((size_t)n) + arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4) +
+                  arena_sz((size_t)n * 4) + arena_sz((size_t)n * ADJ * 4);
     int rc = modest_ctx_reserve(ctx, need);
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 64);
@@ -426,6 +530,9 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     int *root = A.take<int>(n);
     unsigned *isroot = A.take<unsigned>(n);
     unsigned *rank = A.take<unsigned>(n + 1);
+    int *deg = A.take<int>(n);
+    int *adj = A.take<int>((size_t)n * ADJ);
+    int *overflow = reinterpret_cast<int *>(zeroed + 2 * CG_CELLS);
 
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
@@ -436,20 +543,37 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     scan_u32<<<1, 1024, 0, stream>>>(cnt, start, CG_CELLS);
     cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, start, fill, sorted, sidx);
     knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
-    degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS);
+    degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS, deg, adj,
+                                                  overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
-    hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
-    union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
+    for (int round = 0; round < 4; ++round) {   // accelerators only: union_adj_kernel makes the result exact
+        hook_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
+        flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
+    }
+    union_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
     compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
     scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
-    label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, r2, eps,
-                                             labels);
-    if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
+    label_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, root, rank, labels);
     MODEST_HIP_CHECK(hipGetLastError());
-    if (n_clusters) {
+    {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
+        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 8, overflow, 4, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-        *n_clusters = (int32_t) * reinterpret_cast<unsigned *>(ctx->pinned);
+        if (*reinterpret_cast<int *>(ctx->pinned + 8)) {
+            degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS);
+            uf_init<<<nb, 256, 0, stream>>>(parent, n);
+            hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
+            union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
+            compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
+            label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, r2, eps,
+                                                     labels);
+            MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
+            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        if (n_clusters) *n_clusters = (int32_t) * reinterpret_cast<unsigned *>(ctx->pinned);
     }
+    if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
+    MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
