@@ -546,7 +546,7 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS, deg, adj,
                                                   overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
-    for (int round = 0; round < 4; ++round) {   // accelerators only: union_adj_kernel makes the result exact
+    for (int round = 0; round < 3; ++round) {   // accelerators only: union_adj_kernel makes the result exact
         hook_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
         flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
     }

@@ -21,11 +21,20 @@ __device__ __forceinline__ float cs_unkey(unsigned k) {
     return __uint_as_float(u);
 }
 
+// label histogram; a few clusters hold most points, so same-address global atomics (~12 ns
+// each) are first folded per wavefront: lanes with equal labels elect one adder
 __global__ void cs_count(const int *__restrict__ labels, int n, int C, unsigned *cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int l = labels[i];
-    if (l >= 0 && l < C) atomicAdd(&cnt[l], 1u);
+    int l = (i < n) ? labels[i] : -1;
+    if (l >= C) l = -1;
+    unsigned long long todo = __ballot(l >= 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int ls = __shfl(l, src);
+        const unsigned long long same = __ballot(l == ls);
+        if ((int)(threadIdx.x & 63) == src) atomicAdd(&cnt[ls], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
 }
 
 __global__ void cs_scan(const unsigned *__restrict__ cnt, int C, unsigned *__restrict__ start) {
