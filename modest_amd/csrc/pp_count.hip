@@ -25,6 +25,7 @@
 //          are flushed with one global atomic each.
 #include "pp_common.h"
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 using namespace modest;
@@ -820,6 +821,8 @@ __global__ __launch_bounds__(1024) void pp2_tiles(const float4 *__restrict__ rec
     }
 }
 
+#include "pp_v3.h"
+
 // ---- entropy ---------------------------------------------------------------
 __device__ __forceinline__ double pp_term(int c, double denom) {
     const double P = (double)c / denom;
@@ -901,12 +904,20 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     }
     const int nLists = V2_NTILES * n_trav;
     const size_t maxItems = (size_t)nLists + 65536;
+    int nwg3 = 2 * ctx->num_cus < V3_MAXWG ? 2 * ctx->num_cus : V3_MAXWG;
+    if (nwg3 > nchunks) nwg3 = nchunks > 0 ? nchunks : 1;
+    const char *sr_env = getenv("MODEST_PP_SLICE");
+    unsigned sliceRecs = sr_env ? (unsigned)atoi(sr_env) : 4096u;
+    sliceRecs = sliceRecs < 256u ? 256u : (sliceRecs > V3_SLICE_MAX ? V3_SLICE_MAX : sliceRecs);
+    const size_t maxSlices = (size_t)V3_NTILES + (size_t)nchunks * V3_CH / sliceRecs + 2;
     // one contiguous zero-initialised block: cellCount | fill | descCount | descRecs | ctrl[2] | bbox[4] | pad
-    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8 + V2_NTILES;   // ctrl[4] bbox[4] tileLive
+    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8 + V2_NTILES + 4 + 2 * V3_NTILES + 4 + 36;   // ctrl[4] bbox[4] tileLive ctrl3[4]
     size_t need = arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
                   arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
                   arena_sz((size_t)nchunks * V2_CH * 16) + arena_sz((size_t)nLists * maxDesc * 8) +
-                  arena_sz(maxItems * 8) + arena_sz((maxItems + 1) * 4);
+                  arena_sz(maxItems * 8) + arena_sz((maxItems + 1) * 4) +
+                  arena_sz((size_t)nchunks * V3_CH * 16) + 2 * arena_sz((size_t)nwg3 * V3_NTILES * 4) +
+                  arena_sz(maxSlices * 16);
     rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
     if (rc) return rc;
     if (extra) {
@@ -928,6 +939,10 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     unsigned *ctrl = descRecs + nLists;
     unsigned *bb = ctrl + 4;
     unsigned *tileLive = bb + 4;
+    unsigned *ctrl3 = tileLive + V2_NTILES;
+    unsigned *tileTotal = ctrl3 + 4;
+    unsigned *tileBase = tileTotal + V3_NTILES;
+    unsigned *dbgStats = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(tileBase + V3_NTILES) + 7) & ~(uintptr_t)7);   // 16 x u64 (debug only)
     unsigned *cellStart = A.take<unsigned>(PP_NCELL + 1);
     unsigned *blockSum = A.take<unsigned>(SCAN_NBLK);
     unsigned *bitmap = A.take<unsigned>(PP_BITWORDS);
@@ -936,6 +951,10 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     uint2 *desc = A.take<uint2>((size_t)nLists * maxDesc);
     uint2 *items = A.take<uint2>(maxItems);
     unsigned *entryBegin = A.take<unsigned>(maxItems + 1);
+    float4 *rec2 = A.take<float4>((size_t)nchunks * V3_CH);
+    unsigned *wgTile = A.take<unsigned>((size_t)nwg3 * V3_NTILES);
+    unsigned *wgOff = A.take<unsigned>((size_t)nwg3 * V3_NTILES);
+    uint4 *slices = A.take<uint4>(maxSlices);
 
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of one scan
     MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
@@ -948,11 +967,11 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     pp_scan_blocks<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum);
     pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
     pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
-    pp_tile_live<<<V2_NTILES, 64, 0, stream>>>(cellStart, tileLive);
 
     const char *var_env = getenv("MODEST_PP_VARIANT");
-    int var = var_env ? atoi(var_env) : 0;
-    if (nLists > 1024 * V2_WL_LPT) var = 1;   // > 40 traversals: beyond the work-list capacity, use the direct path
+    int var = var_env ? atoi(var_env) : 3;
+    if (var == 3 && n_trav > V3_MAXT) var = 2;
+    if (var == 2 && nLists > 1024 * V2_WL_LPT) var = 1;   // > 20 traversals: beyond the work-list capacity, use the direct path
     if (var == 1) {   // V1: per-point search in the L2-resident index (also kept for A/B measurements)
         pp_stream_v1<<<ctx->num_cus * 3, 256, 0, stream>>>(hist, m0, m1, tr, bb, c, bitmap, cellStart,
                                                            sorted, counts, n_trav, r2);
@@ -962,8 +981,52 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     }
     const char *dbg_env = getenv("MODEST_PP_DBG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    if (var == 3) {
+        ChunkMap3 cm3;
+        for (int t = 0; t <= n_trav; ++t) cm3.cstart[t] = cm.cstart[t];
+        const int Th = (n_trav + 1) / 2;
+        const int lcap = V3_JOIN_LDS_DYN / (16 + 4 * Th);
+        static bool attr_done = false;
+        if (!attr_done) {
+            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_scan),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 V3_MAXWG * V3_SCAN_L * 4));
+            attr_done = true;
+        }
+        pp3_stream<false><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, wgTile, wgOff, tileBase,
+                                                     rec);
+        pp3_scan<<<V3_NTILES / V3_SCAN_L, 1024, (size_t)nwg3 * V3_SCAN_L * 4, stream>>>(wgTile, wgOff, nwg3, tileTotal);
+        pp3_plan<<<1, 1024, 0, stream>>>(tileTotal, sliceRecs, tileBase, slices, (unsigned)maxSlices, ctrl3);
+        pp3_stream<true><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, wgTile, wgOff, tileBase,
+                                                    rec);
+        if (dbg & 8)
+            pp3_join<true><<<4 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
+                rec, rec2, slices, ctrl3, cellStart, sorted, counts, n_trav, lcap, r2, dbg,
+                reinterpret_cast<unsigned long long *>(dbgStats));
+        else
+            pp3_join<false><<<4 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
+                rec, rec2, slices, ctrl3, cellStart, sorted, counts, n_trav, lcap, r2, dbg,
+                reinterpret_cast<unsigned long long *>(dbgStats));
+        if (dbg & 8) {
+            unsigned long long hs[16];
+            unsigned hc[4];
+            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+            MODEST_HIP_CHECK(hipMemcpy(hs, dbgStats, sizeof(hs), hipMemcpyDeviceToHost));
+            MODEST_HIP_CHECK(hipMemcpy(hc, ctrl3, sizeof(hc), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) setup %llu hist %llu scatter %llu band-load %llu join %llu flush %llu | max WG total %llu | chunks %llu groups %llu iters %llu flush-atomics %llu\n",
+                    hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[9], hs[10], hs[12]);
+        }
+        modest_prof_mark(ctx, stream, 1);
+        MODEST_HIP_CHECK(hipGetLastError());
+        return MODEST_OK;
+    }
     const char *ed_env = getenv("MODEST_PP_ENTRY_DIV");
     const int entry_div = ed_env ? atoi(ed_env) : 4;
+    pp_tile_live<<<V2_NTILES, 64, 0, stream>>>(cellStart, tileLive);
     const int grid1 = ctx->num_cus < nchunks ? ctx->num_cus : nchunks;
     pp2_route<<<grid1, 1024, 0, stream>>>(hist, tr, cm, nchunks, bb, c, bitmap, rec, desc, descCount,
                                           descRecs, n_trav, maxDesc, dbg);

@@ -1,0 +1,674 @@
+// PP neighbour count, V3: sub-tile scatter + slice sort + cell-uniform join.
+// Included by pp_count.hip (inside its anonymous namespace, after the index-build kernels).
+//
+// What the measurements of V2 said: only 59 M (record, live point) pairs have to be tested for a
+// Lyft-shape scan (6.1 M surviving history records x 9.7 candidates on average), but with records
+// in arrival order every wavefront runs to its slowest lane (2.7x the useful tests) and the
+// per-record set-up (descriptor search, cell table, candidate index arithmetic) costs more
+// instructions than the tests.  V3 therefore SORTS the records so that a wavefront holds
+// records of one cell, which makes the candidate list wave-uniform: live points are read once
+// per wavefront (LDS broadcast), hits are counted with ballots + popcounts instead of one LDS
+// atomic per pair, and there is no per-lane control flow at all.
+//
+//   pp3_stream<0> stream the history (HBM, coalesced 48 B per lane), test the dilated occupancy
+//                 bitmap in LDS, histogram the survivors by 8x8-cell sub-tile (2.4 m, 6400 lists)
+//                 in LDS; one row of 6400 counts per workgroup.  No barrier inside the loop.
+//   pp3_scan      exclusive scan of the count matrix along the workgroup axis (LDS transpose);
+//   pp3_plan      one workgroup: list bases and the slice list.
+//   pp3_stream<1> stream the history again (Infinity Cache: 130 MB < 256 MB), same static
+//                 chunk -> workgroup map: records go straight to their exact position in the
+//                 list-contiguous array (LDS cursor per list, 16-byte stores).  No barrier either.
+//   pp3_join      persistent grid, one slice at a time: counting sort of the slice by cell
+//                 (64 keys; records re-read from L2, written to a second array), then 64-record
+//                 chunks of the sorted slice are dealt to wavefronts; a chunk is processed one
+//                 cell group at a time against the sub-tile's live points (+1 cell halo) in LDS.
+//                 Per-(live point, traversal) counters are 16-bit pairs in LDS, flushed with one
+//                 global atomic per non-zero counter at the end of a band.
+//
+// Why 8x8-cell lists: the cost floor of a slice is one pass over the candidates of every cell it
+// touches, so lists must be small for balance, yet a slice must hold many records PER CELL for
+// the wavefronts to be full: 4096 records over 64 cells are 64 per cell in the dense centre.
+//
+// Sub-tiles whose live points (+halo) do not fit the LDS budget are processed in bands of cell
+// rows; a band that does not fit even as a single row falls back to per-record loops over the
+// global index (correct, slow, never seen on LiDAR-shaped input).
+
+constexpr int V3_TS = 8;                    // list edge in cells
+constexpr int V3_NT = PP_NX / V3_TS;        // 80
+constexpr int V3_NTILES = V3_NT * V3_NT;    // 6400 lists
+constexpr int V3_NC = V3_TS * V3_TS;        // 64 cells per list = sort keys of a slice
+constexpr int V3_W = V3_TS + 2;             // 10: window incl. halo
+constexpr int V3_CH = 4096;                 // history points per chunk (1024 threads x 4)
+constexpr int V3_MAXT = 16;                 // traversals handled by the routed path
+constexpr int V3_MAXWG = 512;               // stream workgroups (eight per lane in pp3_plan)
+constexpr int V3_JT = 512;                  // threads of a join workgroup
+constexpr int V3_JW = V3_JT / 64;
+constexpr unsigned V3_SLICE_MAX = 32768;    // records per slice: 16-bit counters cannot overflow
+constexpr int V3_JOIN_LDS_DYN = 36 * 1024;  // live points + counters of a band
+constexpr unsigned V3_LANE_GROUPS = 4;      // chunks with at least this many cells take the per-lane path
+constexpr unsigned V3_LANE_MAX = 64;        // ... for the lanes with at most this many candidates
+static_assert(PP_NX % V3_TS == 0 && V3_NC == 64, "cell key = 6 bits, one lane per cell in the scan");
+
+struct ChunkMap3 {
+    int cstart[PP_MAX_TRAV + 1];   // first chunk id of each traversal (chunks never straddle)
+};
+
+// Lists are numbered ring by ring from the grid centre outwards (the grid is centred on the live
+// scan, whose dense part is the centre): slices are generated and dequeued in list order, so the
+// expensive ones are started first and the cheap border lists fill the tail.
+// Ring k (0..39) holds the sub-tiles with max(|dx|,|dy|) = k and starts at list 4k^2.
+static_assert(V3_NT % 2 == 0, "ring numbering assumes an even number of sub-tiles per axis");
+__device__ __forceinline__ int pp3_list_of(int tx, int ty) {
+    constexpr int H = V3_NT / 2;
+    const int a = tx < H ? H - 1 - tx : tx - H, b = ty < H ? H - 1 - ty : ty - H;
+    const int k = max(a, b), e = 2 * k + 1;
+    const int u = tx - (H - 1 - k), v = ty - (H - 1 - k);   // in [0, e]
+    int pos;
+    if (v == 0) pos = u;
+    else if (v == e) pos = e + 1 + u;
+    else pos = 2 * (e + 1) + (u == 0 ? 0 : e - 1) + (v - 1);
+    return 4 * k * k + pos;
+}
+__device__ __forceinline__ void pp3_tile_of(int list, int *tx, int *ty) {
+    constexpr int H = V3_NT / 2;
+    int k = (int)(sqrtf((float)list) * 0.5f);
+    while (4 * (k + 1) * (k + 1) <= list) ++k;
+    while (4 * k * k > list) --k;
+    const int e = 2 * k + 1, pos = list - 4 * k * k;
+    int u, v;
+    if (pos <= e) {
+        u = pos;
+        v = 0;
+    } else if (pos < 2 * (e + 1)) {
+        u = pos - (e + 1);
+        v = e;
+    } else {
+        const int q = pos - 2 * (e + 1);
+        u = q < e - 1 ? 0 : e;
+        v = (q < e - 1 ? q : q - (e - 1)) + 1;
+    }
+    *tx = u + (H - 1 - k);
+    *ty = v + (H - 1 - k);
+}
+
+// Cell of a history point, tested against the dilated bitmap: returns the list or -1;
+// *key = (cell row in the sub-tile << 3) | cell column in the sub-tile.
+__device__ __forceinline__ int pp3_classify(float x, float y, const PPGrid &g, const unsigned *sbits, int *key) {
+    const int cx = pp_cell_coord(x, g.ox, g.inv_c, PP_NX);
+    const int cy = pp_cell_coord(y, g.oy, g.inv_c, PP_NY);
+    const int bit = cy * PP_NX + cx;
+    if (!((sbits[bit >> 5] >> (bit & 31)) & 1u)) return -1;
+    *key = ((cy % V3_TS) * V3_TS) | (cx % V3_TS);
+    return pp3_list_of(cx / V3_TS, cy / V3_TS);
+}
+
+// Loads the (up to) four points of this thread's part of a chunk.
+__device__ __forceinline__ void pp3_load4(const float *__restrict__ hist, long long q0, long long pend, float v[12]) {
+    const float *src = hist + 3 * q0;
+    if (q0 + 4 <= pend && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        const float4 a = s4[0], b = s4[1], d = s4[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = d.x; v[9] = d.y; v[10] = d.z; v[11] = d.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = (q0 + k / 3 < pend) ? src[k] : 0.f;
+    }
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ hist, TravOffsets tr, ChunkMap3 cm,
+                                                      int nchunks, const unsigned *bb, double c,
+                                                      const unsigned *__restrict__ bitmap,
+                                                      unsigned *__restrict__ wgTile /* [grid][6400] counts */,
+                                                      const unsigned *__restrict__ wgOff /* [grid][6400] offsets in the list */,
+                                                      const unsigned *__restrict__ tileBase,
+                                                      float4 *__restrict__ rec) {
+    __shared__ unsigned sbits[PP_BITWORDS];
+    __shared__ unsigned cur[V3_NTILES];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < PP_BITWORDS; i += 1024) sbits[i] = bitmap[i];
+    for (int i = tid; i < V3_NTILES; i += 1024)
+        cur[i] = SCATTER ? tileBase[i] + wgOff[(size_t)blockIdx.x * V3_NTILES + i] : 0u;
+    const PPGrid g = pp_grid(bb, c);
+    __syncthreads();
+    // software pipeline: the loads of the next chunk are in flight while this one is classified
+    auto chunk_range = [&](int chunk, int *t_out, long long *q0, long long *pend) {
+        int t = 0;
+        while (t + 1 < tr.n && chunk >= cm.cstart[t + 1]) ++t;
+        const long long p0 = tr.off[t] + (long long)(chunk - cm.cstart[t]) * V3_CH;
+        *pend = min(tr.off[t + 1], p0 + V3_CH);
+        *q0 = p0 + 4LL * tid;
+        *t_out = t;
+    };
+    int chunk = blockIdx.x, t = 0;
+    long long q0 = 0, pend = 0;
+    float v[12];
+    if (chunk < nchunks) {
+        chunk_range(chunk, &t, &q0, &pend);
+        if (q0 < pend) pp3_load4(hist, q0, pend, v);
+    }
+    while (chunk < nchunks) {
+        const int nchunk = chunk + gridDim.x;
+        int nt = 0;
+        long long nq0 = 0, npend = 0;
+        float nv[12];
+        if (nchunk < nchunks) {
+            chunk_range(nchunk, &nt, &nq0, &npend);
+            if (nq0 < npend) pp3_load4(hist, nq0, npend, nv);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (q0 + k < pend) {
+                int key;
+                const int tile = pp3_classify(v[3 * k], v[3 * k + 1], g, sbits, &key);
+                if (tile >= 0) {
+                    if (SCATTER) {
+                        const unsigned pos = atomicAdd(&cur[tile], 1u);
+                        rec[pos] = make_float4(v[3 * k], v[3 * k + 1], v[3 * k + 2], __int_as_float(key | (t << 16)));
+                    } else {
+                        atomicAdd(&cur[tile], 1u);
+                    }
+                }
+            }
+        }
+        chunk = nchunk;
+        t = nt;
+        q0 = nq0;
+        pend = npend;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = nv[k];
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int i = tid; i < V3_NTILES; i += 1024) wgTile[(size_t)blockIdx.x * V3_NTILES + i] = cur[i];
+    }
+}
+
+// ctrl3: [0] = #slices, [1] = dequeue head, [2] = total records
+// pp3_scan: a workgroup owns 64 consecutive lists.  The [workgroup][list] count matrix is read in
+// 256-byte pieces (coalesced), transposed through LDS, scanned along the workgroup axis in place
+// and written back as offsets inside each list; list totals go to tileTotal.
+constexpr int V3_SCAN_L = 64;   // lists per scan workgroup
+static_assert(V3_NTILES % V3_SCAN_L == 0, "scan tiling");
+__global__ __launch_bounds__(1024) void pp3_scan(const unsigned *__restrict__ wgTile, unsigned *__restrict__ wgOff,
+                                                 int nwg, unsigned *__restrict__ tileTotal) {
+    extern __shared__ unsigned m[];             // [nwg][64]
+    __shared__ unsigned segSum[16][V3_SCAN_L];
+    const int tid = threadIdx.x, j = tid & 63, seg = tid >> 6;
+    const int l0 = blockIdx.x * V3_SCAN_L;
+    for (int k = seg; k < nwg; k += 16) m[k * V3_SCAN_L + j] = wgTile[(size_t)k * V3_NTILES + l0 + j];
+    __syncthreads();
+    const int per = (nwg + 15) / 16, k0 = seg * per, k1 = min(k0 + per, nwg);
+    unsigned s = 0;
+    for (int k = k0; k < k1; ++k) s += m[k * V3_SCAN_L + j];
+    segSum[seg][j] = s;
+    __syncthreads();
+    unsigned run = 0, all = 0;
+    for (int q = 0; q < 16; ++q) {
+        const unsigned v = segSum[q][j];
+        if (q < seg) run += v;
+        all += v;
+    }
+    for (int k = k0; k < k1; ++k) {
+        const unsigned v = m[k * V3_SCAN_L + j];
+        m[k * V3_SCAN_L + j] = run;
+        run += v;
+    }
+    if (seg == 0) tileTotal[l0 + j] = all;
+    __syncthreads();
+    for (int k = seg; k < nwg; k += 16) wgOff[(size_t)k * V3_NTILES + l0 + j] = m[k * V3_SCAN_L + j];
+}
+
+// pp3_plan: one workgroup; list bases and the slice list, seven consecutive lists per thread.
+constexpr int V3_PLAN_LPT = 7;
+static_assert(V3_PLAN_LPT * 1024 >= V3_NTILES, "plan covers every list");
+__global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ tileTotal, unsigned sliceRecs,
+                                                 unsigned *__restrict__ tileBase, uint4 *__restrict__ slices,
+                                                 unsigned maxSlices, unsigned *ctrl3) {
+    __shared__ unsigned tot[16], nsl[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned total[V3_PLAN_LPT], ns[V3_PLAN_LPT], sumT = 0, sumS = 0;
+#pragma unroll
+    for (int j = 0; j < V3_PLAN_LPT; ++j) {
+        const int l = tid * V3_PLAN_LPT + j;
+        total[j] = l < V3_NTILES ? tileTotal[l] : 0u;
+        ns[j] = (total[j] + sliceRecs - 1) / sliceRecs;
+        sumT += total[j];
+        sumS += ns[j];
+    }
+    unsigned incA = sumT, incB = sumS;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_up(incA, o), b = __shfl_up(incB, o);
+        if (lane >= o) {
+            incA += a;
+            incB += b;
+        }
+    }
+    if (lane == 63) {
+        tot[w] = incA;
+        nsl[w] = incB;
+    }
+    __syncthreads();
+    unsigned baseA = 0, baseB = 0, allA = 0, allB = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w) {
+            baseA += tot[k];
+            baseB += nsl[k];
+        }
+        allA += tot[k];
+        allB += nsl[k];
+    }
+    if (tid == 0) {
+        ctrl3[0] = min(allB, maxSlices);
+        ctrl3[2] = allA;
+    }
+    unsigned tBase = baseA + incA - sumT, sBase = baseB + incB - sumS;
+#pragma unroll
+    for (int j = 0; j < V3_PLAN_LPT; ++j) {
+        const int l = tid * V3_PLAN_LPT + j;
+        if (l < V3_NTILES) {
+            tileBase[l] = tBase;
+            const unsigned per = ns[j] ? (total[j] + ns[j] - 1) / ns[j] : 0u;   // equal parts
+            for (unsigned k = 0; k < ns[j]; ++k) {
+                if (sBase + k >= maxSlices) break;
+                slices[sBase + k] = make_uint4((unsigned)l, tBase + k * per, tBase + min((k + 1) * per, total[j]), 0u);
+            }
+        }
+        tBase += total[j];
+        sBase += ns[j];
+    }
+}
+
+struct JoinShared {
+    unsigned cursor[V3_NC];                   // cell histogram -> running cursor -> cell END offsets in the slice
+    unsigned cst[V3_W * (V3_W + 1)];          // cellStart of the window cells (one global round trip)
+    unsigned short ctab[V3_W * (V3_W + 1)];   // live points of window row r before column cc
+    unsigned segStart[V3_W], rowBase[V3_W + 1];
+    unsigned bandA[V3_TS], bandB[V3_TS], bandSlow[V3_TS];
+    unsigned nBands, ticket, sliceId;
+    uint4 slice;
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ rec, float4 *__restrict__ rec2,
+                                                     const uint4 *__restrict__ slices, unsigned *ctrl3,
+                                                     const unsigned *__restrict__ cellStart,
+                                                     const float4 *__restrict__ sorted, int *counts, int T,
+                                                     int lcap, double r2, int dbg,
+                                                     unsigned long long *stats) {
+    extern __shared__ __align__(16) unsigned char dynsm[];
+    __shared__ JoinShared S;
+    float4 *live = reinterpret_cast<float4 *>(dynsm);
+    unsigned *cntw = reinterpret_cast<unsigned *>(dynsm + (size_t)lcap * sizeof(float4));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Th = (T + 1) >> 1;   // counter words per live point (two 16-bit counters each)
+    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    const float r2f = (float)r2, bandw = (float)(r2 * 1.5e-6);   // |d2 - r2f| <= bandw covers [r2lo, r2hi]
+    const unsigned nSlices = ctrl3[0];
+    // per-lane constants of the traversal-segmented popcount: lane t < T owns traversal t;
+    // selk = all ones if bit k of t is CLEAR (mask of traversal t = AND_k (B_k ^ selk))
+    const unsigned sel0 = (lane & 1) ? 0u : ~0u, sel1 = (lane & 2) ? 0u : ~0u;
+    const unsigned sel2 = (lane & 4) ? 0u : ~0u, sel3 = (lane & 8) ? 0u : ~0u;
+    const unsigned cshift = (lane & 1) * 16;
+
+    constexpr bool prof = PROF;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, nGroups = 0, nIter = 0, nChunk = 0, nFlush = 0;
+#define PP3_TICK(k)                                     \
+    if (prof && tid == 0) {                              \
+        const unsigned long long now_ = wall_clock64(); \
+        tph[k] += now_ - tlast;                          \
+        tlast = now_;                                    \
+    }
+    if (tid == 0) {   // the first slice; later ones are fetched while the previous slice is processed
+        const unsigned first = atomicAdd(&ctrl3[1], 1u);
+        S.sliceId = first;
+        if (first < nSlices) S.slice = slices[first];
+    }
+    for (;;) {
+        __syncthreads();
+        if (prof && tid == 0) tlast = wall_clock64();
+        const unsigned sid = S.sliceId;
+        if (sid >= nSlices) break;
+        const uint4 sl = S.slice;
+        __syncthreads();   // everyone holds the slice: thread 0 may overwrite the header below
+        unsigned nextId = 0;
+        if (tid == 0) nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the set-up loads
+        int ttx, tty;
+        pp3_tile_of((int)sl.x, &ttx, &tty);
+        const unsigned lo = sl.y, n = sl.z - sl.y;
+        const int x0 = ttx * V3_TS - 1, y0 = tty * V3_TS - 1;
+        const int gx0 = max(x0, 0), gx1 = min(x0 + V3_W, PP_NX);
+
+        // ---- (a) counting sort of the slice by cell ------------------------------
+        if (tid < V3_NC) S.cursor[tid] = 0;
+        if (tid < V3_W * (V3_W + 1)) {
+            const int r = tid / (V3_W + 1), cc = tid - r * (V3_W + 1);
+            const int gy = y0 + r;
+            unsigned val = 0;
+            if (gy >= 0 && gy < PP_NY) val = cellStart[gy * PP_NX + min(max(x0 + cc, gx0), gx1)];
+            S.cst[tid] = val;
+        }
+        __syncthreads();
+        PP3_TICK(0)
+        for (unsigned i0 = tid; i0 < n; i0 += 4 * V3_JT) {   // four independent loads in flight
+            int key[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned i = i0 + u * V3_JT;
+                key[u] = i < n ? (__float_as_int(rec[lo + i].w) & (V3_NC - 1)) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (key[u] >= 0) atomicAdd(&S.cursor[key[u]], 1u);
+        }
+        uint4 nextSl = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0 && nextId < nSlices) nextSl = slices[nextId];
+        if (tid < V3_W * (V3_W + 1)) {   // positions inside a window row
+            const int r = tid / (V3_W + 1);
+            S.ctab[tid] = (unsigned short)min(S.cst[tid] - S.cst[r * (V3_W + 1)], 65535u);
+            if (tid == r * (V3_W + 1)) S.segStart[r] = S.cst[tid];
+        }
+        if (tid == V3_JT - 1) {   // window rows -> prefix, bands of cell rows that fit the LDS budget
+            auto len = [&](int r) { return S.cst[r * (V3_W + 1) + V3_W] - S.cst[r * (V3_W + 1)]; };
+            unsigned run = 0;
+            for (int r = 0; r < V3_W; ++r) {
+                S.rowBase[r] = run;
+                run += len(r);
+            }
+            S.rowBase[V3_W] = run;
+            unsigned nb = 0;
+            int ya = 1;
+            while (ya <= V3_TS) {
+                unsigned sum = len(ya - 1) + len(ya) + len(ya + 1);
+                int yb = ya + 1;
+                const unsigned slow = sum > (unsigned)lcap;
+                if (!slow)
+                    while (yb <= V3_TS && sum + len(yb + 1) <= (unsigned)lcap) {
+                        sum += len(yb + 1);
+                        ++yb;
+                    }
+                S.bandA[nb] = (unsigned)ya;
+                S.bandB[nb] = (unsigned)yb;
+                S.bandSlow[nb] = slow;
+                ++nb;
+                ya = yb;
+            }
+            S.nBands = nb;
+        }
+        __syncthreads();
+        PP3_TICK(1)
+        if (tid < 64) {   // exclusive scan of the 64 cell counts
+            const unsigned c0 = S.cursor[tid];
+            unsigned inc = c0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
+            S.cursor[tid] = inc - c0;
+        }
+        __syncthreads();
+        for (unsigned i0 = tid; i0 < n; i0 += 4 * V3_JT) {
+            float4 h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned i = i0 + u * V3_JT;
+                h[u] = i < n ? rec[lo + i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pk = __float_as_int(h[u].w);
+                if (pk >= 0) {
+                    const unsigned pos = atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u);
+                    rec2[lo + pos] = h[u];
+                }
+            }
+        }
+        // (no __threadfence(): an agent-scope release writes the L2 back on gfx950; the records are
+        //  re-read by this workgroup only, and the barrier orders that at workgroup scope)
+        __syncthreads();   // cursor[k] is now the END of cell k; cell k starts at cursor[k-1]
+        PP3_TICK(2)
+
+        // ---- (b) bands of cell rows ---------------------------------------------
+        const unsigned nBands = (dbg & 4) ? 0u : S.nBands;
+        for (unsigned b = 0; b < nBands; ++b) {
+            const int ya = (int)S.bandA[b], yb = (int)S.bandB[b];
+            const unsigned kA = (unsigned)(ya - 1) * V3_TS, kB = (unsigned)(yb - 1) * V3_TS;
+            const unsigned ra = kA ? S.cursor[kA - 1] : 0u, rb = S.cursor[kB - 1];
+            if (ra == rb) continue;   // uniform: no record in these rows
+            const unsigned lbase = S.rowBase[ya - 1];
+            const unsigned Lb = S.rowBase[yb + 1] - lbase;
+            if (S.bandSlow[b]) {
+                // a single row of cells whose three live rows exceed the LDS budget
+                for (unsigned j = ra + tid; j < rb; j += V3_JT) {
+                    const float4 h = rec2[lo + j];
+                    const int pk = __float_as_int(h.w);
+                    const int tr = pk >> 16;
+                    const int cx = x0 + 1 + (pk & (V3_TS - 1)), cy = y0 + 1 + ((pk & (V3_NC - 1)) / V3_TS);
+                    const int xa = max(cx - 1, 0), xb = min(cx + 1, PP_NX - 1);
+                    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, PP_NY - 1); ++yy) {
+                        const unsigned a = cellStart[yy * PP_NX + xa], e = cellStart[yy * PP_NX + xb + 1];
+                        for (unsigned i = a; i < e; ++i) {
+                            const float4 q = sorted[i];
+                            if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2))
+                                atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + tr], 1);
+                        }
+                    }
+                }
+                continue;
+            }
+            __syncthreads();   // previous band's flush is complete
+            for (unsigned e = tid; e < Lb; e += V3_JT) {
+                int r = ya - 1;
+                while (e + lbase >= S.rowBase[r + 1]) ++r;
+                live[e] = sorted[S.segStart[r] + (e + lbase - S.rowBase[r])];
+            }
+            for (unsigned e = tid; e < Lb * Th; e += V3_JT) cntw[e] = 0;
+            if (tid == 0) S.ticket = 0;
+            __syncthreads();
+            PP3_TICK(3)
+
+            // 64-record chunks of the sorted band range, dealt to wavefronts
+            const unsigned nChunks = (rb - ra + 63) / 64;
+            auto grab = [&]() {
+                unsigned k = 0;
+                if (lane == 0) k = atomicAdd(&S.ticket, 1u);
+                return (unsigned)__builtin_amdgcn_readfirstlane(k);
+            };
+            auto fetch = [&](unsigned k) {
+                const unsigned jj = ra + k * 64 + lane;
+                return (k < nChunks && jj < rb) ? rec2[lo + jj] : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            unsigned ck = grab();
+            float4 h = fetch(ck);
+            while (ck < nChunks) {
+                const unsigned nk = grab();   // next chunk's records are in flight while this one is joined
+                const float4 hn = fetch(nk);
+                if (prof) ++nChunk;
+                const unsigned j = ra + ck * 64 + lane;
+                const bool valid = j < rb;
+                const int pk = valid ? __float_as_int(h.w) : -1;
+                const int key = pk & (V3_NC - 1);
+                const unsigned trv = (unsigned)(pk >> 16) & 15u;
+                // traversal segment masks: lane t keeps the lanes whose record belongs to traversal t
+                unsigned long long seg = __ballot(valid);
+                {
+                    const unsigned long long B0 = __ballot(trv & 1u), B1 = __ballot(trv & 2u);
+                    const unsigned long long B2 = __ballot(trv & 4u), B3 = __ballot(trv & 8u);
+                    const unsigned long long s0 = ((unsigned long long)sel0 << 32) | sel0;
+                    const unsigned long long s1 = ((unsigned long long)sel1 << 32) | sel1;
+                    const unsigned long long s2 = ((unsigned long long)sel2 << 32) | sel2;
+                    const unsigned long long s3 = ((unsigned long long)sel3 << 32) | sel3;
+                    seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3);
+                }
+                const unsigned segLo = (unsigned)seg, segHi = (unsigned)(seg >> 32);
+                unsigned long long todo = __ballot(valid);
+                // Sparse chunks (many cells, few records each) would pay the group set-up once per
+                // cell: there every lane walks its own candidate list instead (four LDS reads in
+                // flight, one LDS atomic per hit); lanes with long lists stay on the group path.
+                {
+                    const int prevKey = __shfl_up(key, 1);
+                    const unsigned nG = __popcll(__ballot(valid && (lane == 0 || key != prevKey)));
+                    if (nG >= V3_LANE_GROUPS && !(dbg & 2)) {
+                        const int lx = (key & (V3_TS - 1)) + 1, ly = key / V3_TS + 1;
+                        const unsigned short *row = S.ctab + (ly - 1) * (V3_W + 1) + lx - 1;
+                        const unsigned c00 = row[0], c10 = row[V3_W + 1], c20 = row[2 * (V3_W + 1)];
+                        const unsigned n0 = row[3] - c00, n1 = row[V3_W + 4] - c10;
+                        const unsigned n2 = row[2 * (V3_W + 1) + 3] - c20;
+                        const unsigned a0 = S.rowBase[ly - 1] - lbase + c00;
+                        const unsigned n01 = n0 + n1, nAll = n01 + n2;
+                        const unsigned b1 = S.rowBase[ly] - lbase + c10 - n0;
+                        const unsigned b2 = S.rowBase[ly + 1] - lbase + c20 - n01;
+                        const bool mine = valid && nAll <= V3_LANE_MAX;
+                        const unsigned own = mine ? nAll : 0u;
+                        const unsigned cword = trv >> 1, cinc = 1u << ((trv & 1u) * 16);
+                        for (unsigned p0 = 0; __any(p0 < own); p0 += 4) {
+                            unsigned bandBits = 0;
+#pragma unroll
+                            for (unsigned u = 0; u < 4; ++u) {
+                                const unsigned p = p0 + u;
+                                const bool act = p < own;
+                                const unsigned i = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
+                                const float4 q = live[i];
+                                const float fx = q.x - h.x, fy = q.y - h.y, fz = q.z - h.z;
+                                const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                                const bool hit = act && d2 < r2lo;
+                                bandBits |= (act && !hit && d2 <= r2hi) ? (1u << u) : 0u;
+                                if (hit) atomicAdd(&cntw[i * Th + cword], cinc);
+                            }
+                            while (bandBits) {   // practically never: exact float64 re-test
+                                const unsigned u = __ffs((int)bandBits) - 1;
+                                bandBits &= bandBits - 1;
+                                const unsigned p = p0 + u;
+                                const unsigned i = p + (p < n0 ? a0 : (p < n01 ? b1 : b2));
+                                const float4 q = live[i];
+                                if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2)) atomicAdd(&cntw[i * Th + cword], cinc);
+                            }
+                        }
+                        todo = __ballot(valid && !mine);
+                    }
+                }
+                while (todo) {   // one cell group at a time (wave-uniform)
+                    const int src = __ffsll((long long)todo) - 1;
+                    const int gkey = __builtin_amdgcn_readlane(key, src);
+                    const unsigned long long grp = __ballot(valid && key == gkey);
+                    todo &= ~grp;
+                    const int lcx = (gkey & (V3_TS - 1)) + 1, lcy = gkey / V3_TS + 1;   // window coordinates
+                    if (prof) ++nGroups;
+                    if (dbg & 2) continue;
+                    // the three candidate runs (cell rows lcy-1 .. lcy+1, columns lcx-1 .. lcx+1): all scalar
+                    const unsigned short *row = S.ctab + (lcy - 1) * (V3_W + 1) + lcx - 1;
+                    const unsigned rb0 = S.rowBase[lcy - 1] - lbase, rb1 = S.rowBase[lcy] - lbase;
+                    const unsigned rb2 = S.rowBase[lcy + 1] - lbase;
+                    const unsigned c00 = row[0], c03 = row[3], c10 = row[V3_W + 1], c13 = row[V3_W + 4];
+                    const unsigned c20 = row[2 * (V3_W + 1)], c23 = row[2 * (V3_W + 1) + 3];
+                    const unsigned a0 = __builtin_amdgcn_readfirstlane(rb0 + c00);
+                    const unsigned n0 = __builtin_amdgcn_readfirstlane(c03 - c00);
+                    const unsigned a1 = __builtin_amdgcn_readfirstlane(rb1 + c10);
+                    const unsigned n1 = __builtin_amdgcn_readfirstlane(c13 - c10);
+                    const unsigned a2 = __builtin_amdgcn_readfirstlane(rb2 + c20);
+                    const unsigned n2 = __builtin_amdgcn_readfirstlane(c23 - c20);
+                    // Row by row, four contiguous candidates per step: one address register, LDS reads
+                    // with immediate offsets, hit masks straight from the compares; reads past the end
+                    // of a run see the next row or the counters (ignored: their masks are forced to 0).
+                    // The rare pairs inside the band around r^2 are found through a running minimum of
+                    // |d2 - r^2| and re-tested in float64 after the group.
+                    float dmin = 3.0e38f;
+                    const unsigned laneWord = (unsigned)lane >> 1;
+#pragma unroll 1
+                    for (int rr = 0; rr < 3; ++rr) {
+                        const unsigned ra_ = rr == 0 ? a0 : (rr == 1 ? a1 : a2);
+                        const unsigned re_ = ra_ + (rr == 0 ? n0 : (rr == 1 ? n1 : n2));
+                        for (unsigned i = ra_; i < re_; i += 4) {
+                            if (prof) ++nIter;
+                            const float4 q0 = live[i], q1 = live[i + 1], q2 = live[i + 2], q3 = live[i + 3];
+                            float fx, fy, fz;
+                            fx = q0.x - h.x, fy = q0.y - h.y, fz = q0.z - h.z;
+                            const float d0 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                            fx = q1.x - h.x, fy = q1.y - h.y, fz = q1.z - h.z;
+                            const float d1 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                            fx = q2.x - h.x, fy = q2.y - h.y, fz = q2.z - h.z;
+                            const float d2_ = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                            fx = q3.x - h.x, fy = q3.y - h.y, fz = q3.z - h.z;
+                            const float d3 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                            const unsigned long long h0 = __ballot(d0 < r2lo) & grp;
+                            const unsigned long long h1 = (i + 1 < re_) ? (__ballot(d1 < r2lo) & grp) : 0ULL;
+                            const unsigned long long h2 = (i + 2 < re_) ? (__ballot(d2_ < r2lo) & grp) : 0ULL;
+                            const unsigned long long h3 = (i + 3 < re_) ? (__ballot(d3 < r2lo) & grp) : 0ULL;
+                            dmin = fminf(dmin, fminf(fminf(fabsf(d0 - r2f), fabsf(d1 - r2f)),
+                                                     fminf(fabsf(d2_ - r2f), fabsf(d3 - r2f))));
+                            if (h0 | h1 | h2 | h3) {
+                                const unsigned c0 = __popc((unsigned)h0 & segLo) + __popc((unsigned)(h0 >> 32) & segHi);
+                                const unsigned c1 = __popc((unsigned)h1 & segLo) + __popc((unsigned)(h1 >> 32) & segHi);
+                                const unsigned c2 = __popc((unsigned)h2 & segLo) + __popc((unsigned)(h2 >> 32) & segHi);
+                                const unsigned c3 = __popc((unsigned)h3 & segLo) + __popc((unsigned)(h3 >> 32) & segHi);
+                                if (lane < T) {   // adding zero is cheaper than testing for it
+                                    unsigned *cw = cntw + i * Th + laneWord;
+                                    atomicAdd(cw, c0 << cshift);
+                                    atomicAdd(cw + Th, c1 << cshift);
+                                    atomicAdd(cw + 2 * Th, c2 << cshift);
+                                    atomicAdd(cw + 3 * Th, c3 << cshift);
+                                }
+                            }
+                        }
+                    }
+                    if (__ballot(dmin <= bandw) & grp) {   // practically never: exact float64 re-test
+                        const unsigned n01 = n0 + n1, nAll = n01 + n2;
+                        const unsigned b1 = a1 - n0, b2 = a2 - n01;
+                        for (unsigned i = 0; i < nAll; ++i) {
+                            const unsigned p = i + (i < n0 ? a0 : (i < n01 ? b1 : b2));
+                            const float4 qq = live[p];
+                            const float fx = qq.x - h.x, fy = qq.y - h.y, fz = qq.z - h.z;
+                            const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                            const bool inBand = (d2 >= r2lo) && (fabsf(d2 - r2f) <= bandw);
+                            const unsigned long long hx =
+                                __ballot(inBand && pp_within(h.x, h.y, h.z, qq.x, qq.y, qq.z, r2)) & grp;
+                            if (hx) {
+                                const unsigned cN = __popc((unsigned)hx & segLo) + __popc((unsigned)(hx >> 32) & segHi);
+                                if (lane < T && cN) atomicAdd(&cntw[p * Th + laneWord], cN << cshift);
+                            }
+                        }
+                    }
+                }
+                ck = nk;
+                h = hn;
+            }
+            __syncthreads();
+            PP3_TICK(4)
+            if (!(dbg & 1))
+                for (unsigned e = tid; e < Lb * Th; e += V3_JT) {
+                    const unsigned cw = cntw[e];
+                    if (cw) {
+                        const unsigned p = e / Th, tp = (e - p * Th) * 2;
+                        const size_t row = (size_t)__float_as_int(live[p].w) * T;
+                        if (cw & 0xffffu) atomicAdd(&counts[row + tp], (int)(cw & 0xffffu));
+                        if (cw >> 16) atomicAdd(&counts[row + tp + 1], (int)(cw >> 16));
+                        if (prof) atomicAdd(&stats[12], (unsigned long long)((cw & 0xffffu) != 0) + ((cw >> 16) != 0));
+                    }
+                }
+        }
+        PP3_TICK(5)
+        if (tid == 0) {
+            S.sliceId = nextId;
+            S.slice = nextSl;
+        }
+    }
+    if (prof) {
+        if (tid == 0) {
+            unsigned long long all = 0;
+            for (int k = 0; k < 6; ++k) {
+                atomicAdd(&stats[k], tph[k]);
+                all += tph[k];
+            }
+            atomicMax(&stats[6], all);
+            atomicAdd(&stats[11], nFlush);
+        }
+        if (lane == 0) {
+            atomicAdd(&stats[8], nChunk);
+            atomicAdd(&stats[9], nGroups);
+            atomicAdd(&stats[10], nIter);
+        }
+    }
+#undef PP3_TICK
+}
