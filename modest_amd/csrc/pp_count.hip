@@ -907,17 +907,16 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     int nwg3 = 2 * ctx->num_cus < V3_MAXWG ? 2 * ctx->num_cus : V3_MAXWG;
     if (nwg3 > nchunks) nwg3 = nchunks > 0 ? nchunks : 1;
     const char *sr_env = getenv("MODEST_PP_SLICE");
-    unsigned sliceRecs = sr_env ? (unsigned)atoi(sr_env) : 4096u;
-    sliceRecs = sliceRecs < 256u ? 256u : (sliceRecs > V3_SLICE_MAX ? V3_SLICE_MAX : sliceRecs);
-    const size_t maxSlices = (size_t)V3_NTILES + (size_t)nchunks * V3_CH / sliceRecs + 2;
+    unsigned sliceCap = sr_env ? (unsigned)atoi(sr_env) : V3_SLICE_MAX;
+    sliceCap = sliceCap < 256u ? 256u : (sliceCap > V3_SLICE_MAX ? V3_SLICE_MAX : sliceCap);
+    const size_t maxSlices = (size_t)V3_NL + (size_t)nchunks * V3_CH / 64 + 2;
     // one contiguous zero-initialised block: cellCount | fill | descCount | descRecs | ctrl[2] | bbox[4] | pad
-    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8 + V2_NTILES + 4 + 2 * V3_NTILES + 4 + 36;   // ctrl[4] bbox[4] tileLive ctrl3[4]
+    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 2 * (size_t)nLists + 8 + V2_NTILES + 4 + 3 * V3_NL + 2 * V3_DWORDS + V3_DMAX + V3_NBLK + 4 + 36;   // ... ctrl3[4] listTotal tileBase listLive dense denseBlock dbg   // ctrl[4] bbox[4] tileLive ctrl3[4]
     size_t need = arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
                   arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
                   arena_sz((size_t)nchunks * V2_CH * 16) + arena_sz((size_t)nLists * maxDesc * 8) +
                   arena_sz(maxItems * 8) + arena_sz((maxItems + 1) * 4) +
-                  arena_sz((size_t)nchunks * V3_CH * 16) + 2 * arena_sz((size_t)nwg3 * V3_NTILES * 4) +
-                  arena_sz(maxSlices * 16);
+                  2 * arena_sz((size_t)nwg3 * V3_NL * 4) + arena_sz(maxSlices * 16);
     rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
     if (rc) return rc;
     if (extra) {
@@ -940,9 +939,13 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     unsigned *bb = ctrl + 4;
     unsigned *tileLive = bb + 4;
     unsigned *ctrl3 = tileLive + V2_NTILES;
-    unsigned *tileTotal = ctrl3 + 4;
-    unsigned *tileBase = tileTotal + V3_NTILES;
-    unsigned *dbgStats = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(tileBase + V3_NTILES) + 7) & ~(uintptr_t)7);   // 16 x u64 (debug only)
+    unsigned *listTotal = ctrl3 + 4;
+    unsigned *tileBase = listTotal + V3_NL;
+    unsigned *listLive = tileBase + V3_NL;
+    unsigned *dense = listLive + V3_NL;
+    unsigned *denseBlock = dense + 2 * V3_DWORDS;
+    unsigned *blockLive = denseBlock + V3_DMAX;
+    unsigned *dbgStats = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(blockLive + V3_NBLK) + 7) & ~(uintptr_t)7);   // 16 x u64 (debug only)
     unsigned *cellStart = A.take<unsigned>(PP_NCELL + 1);
     unsigned *blockSum = A.take<unsigned>(SCAN_NBLK);
     unsigned *bitmap = A.take<unsigned>(PP_BITWORDS);
@@ -951,9 +954,8 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     uint2 *desc = A.take<uint2>((size_t)nLists * maxDesc);
     uint2 *items = A.take<uint2>(maxItems);
     unsigned *entryBegin = A.take<unsigned>(maxItems + 1);
-    float4 *rec2 = A.take<float4>((size_t)nchunks * V3_CH);
-    unsigned *wgTile = A.take<unsigned>((size_t)nwg3 * V3_NTILES);
-    unsigned *wgOff = A.take<unsigned>((size_t)nwg3 * V3_NTILES);
+    unsigned *wgTile = A.take<unsigned>((size_t)nwg3 * V3_NL);
+    unsigned *wgOff = A.take<unsigned>((size_t)nwg3 * V3_NL);
     uint4 *slices = A.take<uint4>(maxSlices);
 
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of one scan
@@ -984,8 +986,6 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     if (var == 3) {
         ChunkMap3 cm3;
         for (int t = 0; t <= n_trav; ++t) cm3.cstart[t] = cm.cstart[t];
-        const int Th = (n_trav + 1) / 2;
-        const int lcap = V3_JOIN_LDS_DYN / (16 + 4 * Th);
         static bool attr_done = false;
         if (!attr_done) {
             MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<false>),
@@ -997,19 +997,22 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
                                                  V3_MAXWG * V3_SCAN_L * 4));
             attr_done = true;
         }
-        pp3_stream<false><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, wgTile, wgOff, tileBase,
-                                                     rec);
-        pp3_scan<<<V3_NTILES / V3_SCAN_L, 1024, (size_t)nwg3 * V3_SCAN_L * 4, stream>>>(wgTile, wgOff, nwg3, tileTotal);
-        pp3_plan<<<1, 1024, 0, stream>>>(tileTotal, sliceRecs, tileBase, slices, (unsigned)maxSlices, ctrl3);
-        pp3_stream<true><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, wgTile, wgOff, tileBase,
-                                                    rec);
+        pp3_block_live<<<(V3_NBLK + 255) / 256, 256, 0, stream>>>(cellStart, blockLive);
+        pp3_blocks<<<1, 1024, 0, stream>>>(blockLive, dense, denseBlock, listLive);
+        pp3_stream<false><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense, wgTile, wgOff,
+                                                     tileBase, rec, dbg);
+        pp3_scan<<<V3_NL / V3_SCAN_L, 1024, (size_t)nwg3 * V3_SCAN_L * 4, stream>>>(wgTile, wgOff, nwg3, listTotal);
+        pp3_plan<<<1, 1024, 0, stream>>>(listTotal, listLive, n_trav, sliceCap, tileBase, slices,
+                                         (unsigned)maxSlices, ctrl3);
+        pp3_stream<true><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense, wgTile, wgOff,
+                                                    tileBase, rec, dbg);
         if (dbg & 8)
-            pp3_join<true><<<4 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
-                rec, rec2, slices, ctrl3, cellStart, sorted, counts, n_trav, lcap, r2, dbg,
+            pp3_join<true><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
+                rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
                 reinterpret_cast<unsigned long long *>(dbgStats));
         else
-            pp3_join<false><<<4 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
-                rec, rec2, slices, ctrl3, cellStart, sorted, counts, n_trav, lcap, r2, dbg,
+            pp3_join<false><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
+                rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
                 reinterpret_cast<unsigned long long *>(dbgStats));
         if (dbg & 8) {
             unsigned long long hs[16];
@@ -1017,8 +1020,8 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hs, dbgStats, sizeof(hs), hipMemcpyDeviceToHost));
             MODEST_HIP_CHECK(hipMemcpy(hc, ctrl3, sizeof(hc), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) setup %llu hist %llu scatter %llu band-load %llu join %llu flush %llu | max WG total %llu | chunks %llu groups %llu iters %llu flush-atomics %llu\n",
-                    hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[9], hs[10], hs[12]);
+            fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu | max WG %llu | chunks %llu groups %llu iters %llu\n",
+                    hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[6], hs[8], hs[9], hs[10]);
         }
         modest_prof_mark(ctx, stream, 1);
         MODEST_HIP_CHECK(hipGetLastError());

@@ -1,4 +1,4 @@
-// PP neighbour count, V3: sub-tile scatter + slice sort + cell-uniform join.
+// PP neighbour count, V3: list scatter + LDS-resident slice sort + cell-uniform join.
 // Included by pp_count.hip (inside its anonymous namespace, after the index-build kernels).
 //
 // What the measurements of V2 said: only 59 M (record, live point) pairs have to be tested for a
@@ -10,54 +10,65 @@
 // per wavefront (LDS broadcast), hits are counted with ballots + popcounts instead of one LDS
 // atomic per pair, and there is no per-lane control flow at all.
 //
+//   pp3_blocks    one workgroup: live points in the 10x10-cell window of every 8x8-cell block;
+//                 the densest blocks are split into their four 4x4-cell quadrants (own lists).
 //   pp3_stream<0> stream the history (HBM, coalesced 48 B per lane), test the dilated occupancy
-//                 bitmap in LDS, histogram the survivors by 8x8-cell sub-tile (2.4 m, 6400 lists)
-//                 in LDS; one row of 6400 counts per workgroup.  No barrier inside the loop.
+//                 bitmap in LDS, histogram the survivors by list (6400 blocks + quadrants of the
+//                 dense ones) in LDS; one row of counts per workgroup.  No barrier in the loop.
 //   pp3_scan      exclusive scan of the count matrix along the workgroup axis (LDS transpose);
-//   pp3_plan      one workgroup: list bases and the slice list.
+//   pp3_plan      one workgroup: list bases and the slice list (dense lists first, then ring by
+//                 ring from the grid centre, so that the expensive slices are dequeued first).
 //   pp3_stream<1> stream the history again (Infinity Cache: 130 MB < 256 MB), same static
 //                 chunk -> workgroup map: records go straight to their exact position in the
 //                 list-contiguous array (LDS cursor per list, 16-byte stores).  No barrier either.
-//   pp3_join      persistent grid, one slice at a time: counting sort of the slice by cell
-//                 (64 keys; records re-read from L2, written to a second array), then 64-record
-//                 chunks of the sorted slice are dealt to wavefronts; a chunk is processed one
-//                 cell group at a time against the sub-tile's live points (+1 cell halo) in LDS.
+//   pp3_join      persistent grid, one slice at a time, everything in LDS: the slice's records
+//                 (<= 4096, loaded once, kept in registers across the histogram) are counting-
+//                 sorted by cell into LDS, the block's live points (+1 cell halo) sit next to them,
+//                 64-record chunks of the sorted slice are dealt to wavefronts; a chunk is joined one
+//                 cell group at a time (chunks spanning many cells: one lane per record instead).
 //                 Per-(live point, traversal) counters are 16-bit pairs in LDS, flushed with one
-//                 global atomic per non-zero counter at the end of a band.
+//                 global atomic per non-zero counter.  Two dependent global round trips per slice.
 //
-// Why 8x8-cell lists: the cost floor of a slice is one pass over the candidates of every cell it
-// touches, so lists must be small for balance, yet a slice must hold many records PER CELL for
-// the wavefronts to be full: 4096 records over 64 cells are 64 per cell in the dense centre.
+// Why small lists: the cost of a slice is (chunks) x (candidates of the cells they touch), so
+// lists must be small for balance, yet a slice must hold >= 64 records PER CELL for the
+// wavefronts to be full: 4096 records over 64 cells, 2048 over the 16 cells of a dense quadrant.
 //
-// Sub-tiles whose live points (+halo) do not fit the LDS budget are processed in bands of cell
+// Blocks whose live points (+halo) do not fit next to the records are processed in bands of cell
 // rows; a band that does not fit even as a single row falls back to per-record loops over the
 // global index (correct, slow, never seen on LiDAR-shaped input).
 
-constexpr int V3_TS = 8;                    // list edge in cells
+constexpr int V3_TS = 8;                    // block edge in cells
 constexpr int V3_NT = PP_NX / V3_TS;        // 80
-constexpr int V3_NTILES = V3_NT * V3_NT;    // 6400 lists
-constexpr int V3_NC = V3_TS * V3_TS;        // 64 cells per list = sort keys of a slice
+constexpr int V3_NBLK = V3_NT * V3_NT;      // 6400 blocks = base lists
+constexpr int V3_DMAX = 192;                // dense blocks that get one list per quadrant
+constexpr int V3_NL = V3_NBLK + 4 * V3_DMAX;   // 7168 lists
+constexpr int V3_NC = V3_TS * V3_TS;        // 64 cells per block = sort keys of a slice
 constexpr int V3_W = V3_TS + 2;             // 10: window incl. halo
 constexpr int V3_CH = 4096;                 // history points per chunk (1024 threads x 4)
 constexpr int V3_MAXT = 16;                 // traversals handled by the routed path
-constexpr int V3_MAXWG = 512;               // stream workgroups (eight per lane in pp3_plan)
-constexpr int V3_JT = 512;                  // threads of a join workgroup
-constexpr int V3_JW = V3_JT / 64;
-constexpr unsigned V3_SLICE_MAX = 32768;    // records per slice: 16-bit counters cannot overflow
-constexpr int V3_JOIN_LDS_DYN = 36 * 1024;  // live points + counters of a band
-constexpr unsigned V3_LANE_GROUPS = 4;      // chunks with at least this many cells take the per-lane path
+constexpr int V3_MAXWG = 512;               // stream workgroups
+constexpr int V3_JT = 1024;                 // threads of a join workgroup
+constexpr int V3_RPT = 4;                   // records per join thread
+constexpr unsigned V3_SLICE_MAX = V3_JT * V3_RPT;   // 4096 records per slice (16-bit counters cannot overflow)
+constexpr unsigned V3_SLICE_MIN = 1024;     // records always guaranteed to fit next to a band
+constexpr int V3_JOIN_LDS_DYN = 76 * 1024;  // records + live points + counters
+constexpr unsigned V3_DENSE_LIVE = 192;     // window live points above which a block is split
+constexpr unsigned V3_LANE_GROUPS = 2;      // chunks spanning at least this many cells take the per-lane path
 constexpr unsigned V3_LANE_MAX = 64;        // ... for the lanes with at most this many candidates
+constexpr int V3_DWORDS = V3_NBLK / 32;     // 200 words of dense-block flags
 static_assert(PP_NX % V3_TS == 0 && V3_NC == 64, "cell key = 6 bits, one lane per cell in the scan");
+static_assert(V3_NL % 64 == 0 && V3_NL == 7 * 1024, "scan / plan tiling");
+static_assert(V3_NBLK % 32 == 0, "dense flag words");
 
 struct ChunkMap3 {
     int cstart[PP_MAX_TRAV + 1];   // first chunk id of each traversal (chunks never straddle)
 };
 
-// Lists are numbered ring by ring from the grid centre outwards (the grid is centred on the live
-// scan, whose dense part is the centre): slices are generated and dequeued in list order, so the
-// expensive ones are started first and the cheap border lists fill the tail.
-// Ring k (0..39) holds the sub-tiles with max(|dx|,|dy|) = k and starts at list 4k^2.
-static_assert(V3_NT % 2 == 0, "ring numbering assumes an even number of sub-tiles per axis");
+// Base lists are numbered ring by ring from the grid centre outwards (the grid is centred on the
+// live scan, whose dense part is the centre): slices are generated and dequeued in list order,
+// so the expensive ones are started first and the cheap border lists fill the tail.
+// Ring k (0..39) holds the blocks with max(|dx|,|dy|) = k and starts at list 4k^2.
+static_assert(V3_NT % 2 == 0, "ring numbering assumes an even number of blocks per axis");
 __device__ __forceinline__ int pp3_list_of(int tx, int ty) {
     constexpr int H = V3_NT / 2;
     const int a = tx < H ? H - 1 - tx : tx - H, b = ty < H ? H - 1 - ty : ty - H;
@@ -91,15 +102,90 @@ __device__ __forceinline__ void pp3_tile_of(int list, int *tx, int *ty) {
     *ty = v + (H - 1 - k);
 }
 
+// ---- blocks ---------------------------------------------------------------------------
+// dense[0 .. 200)   flag words (bit b = block b, row-major, is split into quadrants)
+// dense[200 .. 400) number of dense blocks before each word
+// denseBlock[d]     block of dense index d;   listLive[l] window live points of list l's block
+__global__ __launch_bounds__(256) void pp3_block_live(const unsigned *__restrict__ cellStart,
+                                                      unsigned *__restrict__ blockLive) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= V3_NBLK) return;
+    const int bx = b % V3_NT, by = b / V3_NT;
+    const int gx0 = max(bx * V3_TS - 1, 0), gx1 = min(bx * V3_TS + V3_TS + 1, PP_NX);
+    unsigned lw = 0;
+#pragma unroll
+    for (int r = 0; r < V3_W; ++r) {   // twenty independent loads
+        const int gy = by * V3_TS - 1 + r;
+        const int gyc = min(max(gy, 0), PP_NY - 1);
+        const unsigned v = cellStart[gyc * PP_NX + gx1] - cellStart[gyc * PP_NX + gx0];
+        lw += (gy == gyc) ? v : 0u;
+    }
+    blockLive[b] = lw;
+}
+
+__global__ __launch_bounds__(1024) void pp3_blocks(const unsigned *__restrict__ blockLive, unsigned *__restrict__ dense,
+                                                   unsigned *__restrict__ denseBlock,
+                                                   unsigned *__restrict__ listLive) {
+    __shared__ unsigned bits[V3_DWORDS];
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < V3_DWORDS) bits[tid] = 0;
+    unsigned lw[7], nd = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int b = tid * 7 + j;
+        lw[j] = b < V3_NBLK ? blockLive[b] : 0u;
+        nd += lw[j] > V3_DENSE_LIVE;
+    }
+    unsigned inc = nd;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();   // also orders the zeroing of bits[]
+    unsigned d = inc - nd;
+    for (int k = 0; k < w; ++k) d += wsum[k];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int b = tid * 7 + j;
+        if (b < V3_NBLK) {
+            listLive[pp3_list_of(b % V3_NT, b / V3_NT)] = lw[j];
+            if (lw[j] > V3_DENSE_LIVE) {
+                if (d < (unsigned)V3_DMAX) {
+                    atomicOr(&bits[b >> 5], 1u << (b & 31));
+                    denseBlock[d] = (unsigned)b;
+                    for (int q = 0; q < 4; ++q) listLive[V3_NBLK + 4 * d + q] = lw[j];
+                }
+                ++d;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < V3_DWORDS) {
+        unsigned before = 0;
+        for (int k = 0; k < tid; ++k) before += __popc(bits[k]);
+        dense[tid] = bits[tid];
+        dense[V3_DWORDS + tid] = before;
+    }
+}
+
 // Cell of a history point, tested against the dilated bitmap: returns the list or -1;
-// *key = (cell row in the sub-tile << 3) | cell column in the sub-tile.
-__device__ __forceinline__ int pp3_classify(float x, float y, const PPGrid &g, const unsigned *sbits, int *key) {
+// *key = (cell row in the block << 3) | cell column in the block.
+__device__ __forceinline__ int pp3_classify(float x, float y, const PPGrid &g, const unsigned *sbits,
+                                            const unsigned *sdense, int *key) {
     const int cx = pp_cell_coord(x, g.ox, g.inv_c, PP_NX);
     const int cy = pp_cell_coord(y, g.oy, g.inv_c, PP_NY);
     const int bit = cy * PP_NX + cx;
     if (!((sbits[bit >> 5] >> (bit & 31)) & 1u)) return -1;
     *key = ((cy % V3_TS) * V3_TS) | (cx % V3_TS);
-    return pp3_list_of(cx / V3_TS, cy / V3_TS);
+    const int bx = cx / V3_TS, by = cy / V3_TS, b = by * V3_NT + bx;
+    const unsigned dw = sdense[b >> 5];
+    if ((dw >> (b & 31)) & 1u) {
+        const unsigned d = sdense[V3_DWORDS + (b >> 5)] + __popc(dw & ((1u << (b & 31)) - 1u));
+        return V3_NBLK + 4 * (int)d + (((cy % V3_TS) >> 2) << 1) + ((cx % V3_TS) >> 2);
+    }
+    return pp3_list_of(bx, by);
 }
 
 // Loads the (up to) four points of this thread's part of a chunk.
@@ -121,84 +207,66 @@ template <bool SCATTER>
 __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ hist, TravOffsets tr, ChunkMap3 cm,
                                                       int nchunks, const unsigned *bb, double c,
                                                       const unsigned *__restrict__ bitmap,
-                                                      unsigned *__restrict__ wgTile /* [grid][6400] counts */,
-                                                      const unsigned *__restrict__ wgOff /* [grid][6400] offsets in the list */,
+                                                      const unsigned *__restrict__ dense,
+                                                      unsigned *__restrict__ wgTile /* [grid][NL] counts */,
+                                                      const unsigned *__restrict__ wgOff /* [grid][NL] offsets in the list */,
                                                       const unsigned *__restrict__ tileBase,
-                                                      float4 *__restrict__ rec) {
+                                                      float4 *__restrict__ rec, int dbg) {
     __shared__ unsigned sbits[PP_BITWORDS];
-    __shared__ unsigned cur[V3_NTILES];
+    __shared__ unsigned cur[V3_NL];
+    __shared__ unsigned sdense[2 * V3_DWORDS];
     const int tid = threadIdx.x;
     for (int i = tid; i < PP_BITWORDS; i += 1024) sbits[i] = bitmap[i];
-    for (int i = tid; i < V3_NTILES; i += 1024)
-        cur[i] = SCATTER ? tileBase[i] + wgOff[(size_t)blockIdx.x * V3_NTILES + i] : 0u;
+    for (int i = tid; i < V3_NL; i += 1024) cur[i] = SCATTER ? tileBase[i] + wgOff[(size_t)blockIdx.x * V3_NL + i] : 0u;
+    if (tid < 2 * V3_DWORDS) sdense[tid] = dense[tid];
     const PPGrid g = pp_grid(bb, c);
     __syncthreads();
-    // software pipeline: the loads of the next chunk are in flight while this one is classified
-    auto chunk_range = [&](int chunk, int *t_out, long long *q0, long long *pend) {
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         int t = 0;
         while (t + 1 < tr.n && chunk >= cm.cstart[t + 1]) ++t;
         const long long p0 = tr.off[t] + (long long)(chunk - cm.cstart[t]) * V3_CH;
-        *pend = min(tr.off[t + 1], p0 + V3_CH);
-        *q0 = p0 + 4LL * tid;
-        *t_out = t;
-    };
-    int chunk = blockIdx.x, t = 0;
-    long long q0 = 0, pend = 0;
-    float v[12];
-    if (chunk < nchunks) {
-        chunk_range(chunk, &t, &q0, &pend);
-        if (q0 < pend) pp3_load4(hist, q0, pend, v);
-    }
-    while (chunk < nchunks) {
-        const int nchunk = chunk + gridDim.x;
-        int nt = 0;
-        long long nq0 = 0, npend = 0;
-        float nv[12];
-        if (nchunk < nchunks) {
-            chunk_range(nchunk, &nt, &nq0, &npend);
-            if (nq0 < npend) pp3_load4(hist, nq0, npend, nv);
-        }
+        const long long pend = min(tr.off[t + 1], p0 + V3_CH);
+        const long long q0 = p0 + 4LL * tid;
+        if (q0 >= pend) continue;
+        float v[12];
+        pp3_load4(hist, q0, pend, v);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (q0 + k < pend) {
                 int key;
-                const int tile = pp3_classify(v[3 * k], v[3 * k + 1], g, sbits, &key);
-                if (tile >= 0) {
+                const int list = pp3_classify(v[3 * k], v[3 * k + 1], g, sbits, sdense, &key);
+                if (list >= 0) {
                     if (SCATTER) {
-                        const unsigned pos = atomicAdd(&cur[tile], 1u);
-                        rec[pos] = make_float4(v[3 * k], v[3 * k + 1], v[3 * k + 2], __int_as_float(key | (t << 16)));
+                        const unsigned pos = atomicAdd(&cur[list], 1u);
+                        const float4 rv = make_float4(v[3 * k], v[3 * k + 1], v[3 * k + 2], __int_as_float(key | (t << 16)));
+                        typedef float v4f_t __attribute__((ext_vector_type(4)));
+                        if (dbg & 32) __builtin_nontemporal_store(v4f_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<v4f_t *>(&rec[pos]));
+                        else if (!(dbg & 16)) rec[pos] = rv;
                     } else {
-                        atomicAdd(&cur[tile], 1u);
+                        atomicAdd(&cur[list], 1u);
                     }
                 }
             }
         }
-        chunk = nchunk;
-        t = nt;
-        q0 = nq0;
-        pend = npend;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = nv[k];
     }
     if (!SCATTER) {
         __syncthreads();
-        for (int i = tid; i < V3_NTILES; i += 1024) wgTile[(size_t)blockIdx.x * V3_NTILES + i] = cur[i];
+        for (int i = tid; i < V3_NL; i += 1024) wgTile[(size_t)blockIdx.x * V3_NL + i] = cur[i];
     }
 }
 
 // ctrl3: [0] = #slices, [1] = dequeue head, [2] = total records
 // pp3_scan: a workgroup owns 64 consecutive lists.  The [workgroup][list] count matrix is read in
 // 256-byte pieces (coalesced), transposed through LDS, scanned along the workgroup axis in place
-// and written back as offsets inside each list; list totals go to tileTotal.
+// and written back as offsets inside each list; list totals go to listTotal.
 constexpr int V3_SCAN_L = 64;   // lists per scan workgroup
-static_assert(V3_NTILES % V3_SCAN_L == 0, "scan tiling");
 __global__ __launch_bounds__(1024) void pp3_scan(const unsigned *__restrict__ wgTile, unsigned *__restrict__ wgOff,
-                                                 int nwg, unsigned *__restrict__ tileTotal) {
+                                                 int nwg, unsigned *__restrict__ listTotal) {
     extern __shared__ unsigned m[];             // [nwg][64]
     __shared__ unsigned segSum[16][V3_SCAN_L];
     const int tid = threadIdx.x, j = tid & 63, seg = tid >> 6;
     const int l0 = blockIdx.x * V3_SCAN_L;
-    for (int k = seg; k < nwg; k += 16) m[k * V3_SCAN_L + j] = wgTile[(size_t)k * V3_NTILES + l0 + j];
+    for (int k = seg; k < nwg; k += 16) m[k * V3_SCAN_L + j] = wgTile[(size_t)k * V3_NL + l0 + j];
     __syncthreads();
     const int per = (nwg + 15) / 16, k0 = seg * per, k1 = min(k0 + per, nwg);
     unsigned s = 0;
@@ -216,25 +284,37 @@ __global__ __launch_bounds__(1024) void pp3_scan(const unsigned *__restrict__ wg
         m[k * V3_SCAN_L + j] = run;
         run += v;
     }
-    if (seg == 0) tileTotal[l0 + j] = all;
+    if (seg == 0) listTotal[l0 + j] = all;
     __syncthreads();
-    for (int k = seg; k < nwg; k += 16) wgOff[(size_t)k * V3_NTILES + l0 + j] = m[k * V3_SCAN_L + j];
+    for (int k = seg; k < nwg; k += 16) wgOff[(size_t)k * V3_NL + l0 + j] = m[k * V3_SCAN_L + j];
 }
 
-// pp3_plan: one workgroup; list bases and the slice list, seven consecutive lists per thread.
-constexpr int V3_PLAN_LPT = 7;
-static_assert(V3_PLAN_LPT * 1024 >= V3_NTILES, "plan covers every list");
-__global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ tileTotal, unsigned sliceRecs,
-                                                 unsigned *__restrict__ tileBase, uint4 *__restrict__ slices,
-                                                 unsigned maxSlices, unsigned *ctrl3) {
+// LDS bytes per live point of a band: float4 + T 16-bit counters (rounded up to a 32-bit pair)
+__host__ __device__ __forceinline__ unsigned pp3_live_bytes(int T) { return 16u + 4u * (unsigned)((T + 1) >> 1); }
+
+// pp3_plan: one workgroup; list bases and the slice list, seven lists per thread in PROCESS
+// order (dense quadrant lists first, then the base lists centre-out).  A slice is sized so that
+// its records and the block's live points (+counters) share the LDS of one join workgroup.
+__global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ listTotal,
+                                                 const unsigned *__restrict__ listLive, int T,
+                                                 unsigned sliceCap, unsigned *__restrict__ tileBase,
+                                                 uint4 *__restrict__ slices, unsigned maxSlices,
+                                                 unsigned *ctrl3) {
     __shared__ unsigned tot[16], nsl[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned total[V3_PLAN_LPT], ns[V3_PLAN_LPT], sumT = 0, sumS = 0;
+    const unsigned lb = pp3_live_bytes(T);
+    unsigned total[7], ns[7], sumT = 0, sumS = 0;
+    int list[7];
 #pragma unroll
-    for (int j = 0; j < V3_PLAN_LPT; ++j) {
-        const int l = tid * V3_PLAN_LPT + j;
-        total[j] = l < V3_NTILES ? tileTotal[l] : 0u;
-        ns[j] = (total[j] + sliceRecs - 1) / sliceRecs;
+    for (int j = 0; j < 7; ++j) {
+        const int i = tid * 7 + j;   // process order
+        list[j] = i < 4 * V3_DMAX ? V3_NBLK + i : i - 4 * V3_DMAX;
+        total[j] = listTotal[list[j]];
+        const unsigned liveB = min(listLive[list[j]] * lb, (unsigned)V3_JOIN_LDS_DYN - V3_SLICE_MIN * 16u);
+        const unsigned fit = ((unsigned)V3_JOIN_LDS_DYN - liveB) / 16u;   // >= V3_SLICE_MIN
+        unsigned cap = max(min(min(fit, sliceCap), V3_SLICE_MAX), 64u);
+        if (list[j] >= V3_NBLK) cap = min(cap, 2048u);   // dense quadrants: 16 cells, >= 128 records per cell
+        ns[j] = (total[j] + cap - 1) / cap;
         sumT += total[j];
         sumS += ns[j];
     }
@@ -266,15 +346,12 @@ __global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ ti
     }
     unsigned tBase = baseA + incA - sumT, sBase = baseB + incB - sumS;
 #pragma unroll
-    for (int j = 0; j < V3_PLAN_LPT; ++j) {
-        const int l = tid * V3_PLAN_LPT + j;
-        if (l < V3_NTILES) {
-            tileBase[l] = tBase;
-            const unsigned per = ns[j] ? (total[j] + ns[j] - 1) / ns[j] : 0u;   // equal parts
-            for (unsigned k = 0; k < ns[j]; ++k) {
-                if (sBase + k >= maxSlices) break;
-                slices[sBase + k] = make_uint4((unsigned)l, tBase + k * per, tBase + min((k + 1) * per, total[j]), 0u);
-            }
+    for (int j = 0; j < 7; ++j) {
+        tileBase[list[j]] = tBase;
+        const unsigned per = ns[j] ? (total[j] + ns[j] - 1) / ns[j] : 0u;   // equal parts
+        for (unsigned k = 0; k < ns[j]; ++k) {
+            if (sBase + k >= maxSlices) break;
+            slices[sBase + k] = make_uint4((unsigned)list[j], tBase + k * per, tBase + min((k + 1) * per, total[j]), 0u);
         }
         tBase += total[j];
         sBase += ns[j];
@@ -289,21 +366,22 @@ struct JoinShared {
     unsigned bandA[V3_TS], bandB[V3_TS], bandSlow[V3_TS];
     unsigned nBands, ticket, sliceId;
     uint4 slice;
+    unsigned long long prof[8], tlast;   // PROF builds only
 };
 
 template <bool PROF>
-__global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ rec, float4 *__restrict__ rec2,
+__global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ rec,
                                                      const uint4 *__restrict__ slices, unsigned *ctrl3,
+                                                     const unsigned *__restrict__ denseBlock,
                                                      const unsigned *__restrict__ cellStart,
                                                      const float4 *__restrict__ sorted, int *counts, int T,
-                                                     int lcap, double r2, int dbg,
-                                                     unsigned long long *stats) {
+                                                     double r2, int dbg, unsigned long long *stats) {
     extern __shared__ __align__(16) unsigned char dynsm[];
     __shared__ JoinShared S;
-    float4 *live = reinterpret_cast<float4 *>(dynsm);
-    unsigned *cntw = reinterpret_cast<unsigned *>(dynsm + (size_t)lcap * sizeof(float4));
+    float4 *srec = reinterpret_cast<float4 *>(dynsm);   // the slice, sorted by cell
     const int tid = threadIdx.x, lane = tid & 63;
     const int Th = (T + 1) >> 1;   // counter words per live point (two 16-bit counters each)
+    const unsigned liveBytes = pp3_live_bytes(T);
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
     const float r2f = (float)r2, bandw = (float)(r2 * 1.5e-6);   // |d2 - r2f| <= bandw covers [r2lo, r2hi]
     const unsigned nSlices = ctrl3[0];
@@ -312,14 +390,18 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     const unsigned sel0 = (lane & 1) ? 0u : ~0u, sel1 = (lane & 2) ? 0u : ~0u;
     const unsigned sel2 = (lane & 4) ? 0u : ~0u, sel3 = (lane & 8) ? 0u : ~0u;
     const unsigned cshift = (lane & 1) * 16;
+    const unsigned laneWord = (unsigned)lane >> 1;
 
     constexpr bool prof = PROF;
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, nGroups = 0, nIter = 0, nChunk = 0, nFlush = 0;
+    const unsigned laneGroups = ((dbg >> 8) & 0xff) ? ((dbg >> 8) & 0xff) : V3_LANE_GROUPS;
+    const unsigned laneMax = ((dbg >> 16) & 0xfff) ? ((dbg >> 16) & 0xfff) : V3_LANE_MAX;
+    unsigned nGroups = 0, nIter = 0, nChunk = 0;
+    if (prof && tid < 8) S.prof[tid] = 0;
 #define PP3_TICK(k)                                     \
     if (prof && tid == 0) {                              \
         const unsigned long long now_ = wall_clock64(); \
-        tph[k] += now_ - tlast;                          \
-        tlast = now_;                                    \
+        S.prof[k] += now_ - S.tlast;                     \
+        S.tlast = now_;                                  \
     }
     if (tid == 0) {   // the first slice; later ones are fetched while the previous slice is processed
         const unsigned first = atomicAdd(&ctrl3[1], 1u);
@@ -328,21 +410,37 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     }
     for (;;) {
         __syncthreads();
-        if (prof && tid == 0) tlast = wall_clock64();
+        if (prof && tid == 0) S.tlast = wall_clock64();
         const unsigned sid = S.sliceId;
         if (sid >= nSlices) break;
         const uint4 sl = S.slice;
+        if (tid < V3_NC) S.cursor[tid] = 0;
         __syncthreads();   // everyone holds the slice: thread 0 may overwrite the header below
         unsigned nextId = 0;
-        if (tid == 0) nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the set-up loads
+        if (tid == 0) nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the loads below
         int ttx, tty;
-        pp3_tile_of((int)sl.x, &ttx, &tty);
-        const unsigned lo = sl.y, n = sl.z - sl.y;
+        if (sl.x < (unsigned)V3_NBLK) {
+            pp3_tile_of((int)sl.x, &ttx, &tty);
+        } else {
+            const unsigned b = denseBlock[(sl.x - V3_NBLK) >> 2];
+            ttx = (int)(b % V3_NT);
+            tty = (int)(b / V3_NT);
+        }
+        const unsigned lo = sl.y, n = sl.z - sl.y;   // n <= V3_SLICE_MAX
         const int x0 = ttx * V3_TS - 1, y0 = tty * V3_TS - 1;
         const int gx0 = max(x0, 0), gx1 = min(x0 + V3_W, PP_NX);
+        // live points and counters of a band follow the records
+        const unsigned lcap = ((unsigned)V3_JOIN_LDS_DYN - n * 16u) / liveBytes;
+        float4 *live = srec + n;
+        unsigned *cntw = reinterpret_cast<unsigned *>(live + lcap);
 
-        // ---- (a) counting sort of the slice by cell ------------------------------
-        if (tid < V3_NC) S.cursor[tid] = 0;
+        // ---- (a) one round trip: the window's cell table and the slice's records --------
+        float4 h4[V3_RPT];
+#pragma unroll
+        for (int u = 0; u < V3_RPT; ++u) {
+            const unsigned i = tid + u * V3_JT;
+            h4[u] = i < n ? rec[lo + i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        }
         if (tid < V3_W * (V3_W + 1)) {
             const int r = tid / (V3_W + 1), cc = tid - r * (V3_W + 1);
             const int gy = y0 + r;
@@ -350,27 +448,29 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             if (gy >= 0 && gy < PP_NY) val = cellStart[gy * PP_NX + min(max(x0 + cc, gx0), gx1)];
             S.cst[tid] = val;
         }
-        __syncthreads();
-        PP3_TICK(0)
-        for (unsigned i0 = tid; i0 < n; i0 += 4 * V3_JT) {   // four independent loads in flight
-            int key[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned i = i0 + u * V3_JT;
-                key[u] = i < n ? (__float_as_int(rec[lo + i].w) & (V3_NC - 1)) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (key[u] >= 0) atomicAdd(&S.cursor[key[u]], 1u);
+        for (int u = 0; u < V3_RPT; ++u) {
+            const int pk = __float_as_int(h4[u].w);
+            if (pk >= 0) atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u);
         }
         uint4 nextSl = make_uint4(0u, 0u, 0u, 0u);
         if (tid == 0 && nextId < nSlices) nextSl = slices[nextId];
-        if (tid < V3_W * (V3_W + 1)) {   // positions inside a window row
-            const int r = tid / (V3_W + 1);
-            S.ctab[tid] = (unsigned short)min(S.cst[tid] - S.cst[r * (V3_W + 1)], 65535u);
-            if (tid == r * (V3_W + 1)) S.segStart[r] = S.cst[tid];
-        }
-        if (tid == V3_JT - 1) {   // window rows -> prefix, bands of cell rows that fit the LDS budget
+        __syncthreads();
+        PP3_TICK(0)
+        // ---- (b) cell offsets, window tables, bands -----------------------------------
+        if (tid < 64) {   // exclusive scan of the 64 cell counts
+            const unsigned c0 = S.cursor[tid];
+            unsigned inc = c0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
+            S.cursor[tid] = inc - c0;
+        } else if (tid < 64 + V3_W * (V3_W + 1)) {   // positions inside a window row
+            const int e = tid - 64, r = e / (V3_W + 1);
+            S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * (V3_W + 1)], 65535u);
+            if (e == r * (V3_W + 1)) S.segStart[r] = S.cst[e];
+        } else if (tid == V3_JT - 1) {   // window rows -> prefix, bands of cell rows that fit the LDS budget
             auto len = [&](int r) { return S.cst[r * (V3_W + 1) + V3_W] - S.cst[r * (V3_W + 1)]; };
             unsigned run = 0;
             for (int r = 0; r < V3_W; ++r) {
@@ -383,9 +483,9 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             while (ya <= V3_TS) {
                 unsigned sum = len(ya - 1) + len(ya) + len(ya + 1);
                 int yb = ya + 1;
-                const unsigned slow = sum > (unsigned)lcap;
+                const unsigned slow = sum > lcap;
                 if (!slow)
-                    while (yb <= V3_TS && sum + len(yb + 1) <= (unsigned)lcap) {
+                    while (yb <= V3_TS && sum + len(yb + 1) <= lcap) {
                         sum += len(yb + 1);
                         ++yb;
                     }
@@ -398,51 +498,30 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             S.nBands = nb;
         }
         __syncthreads();
+        // ---- (c) scatter the records into LDS (cell-sorted) -----------------------------
+#pragma unroll
+        for (int u = 0; u < V3_RPT; ++u) {
+            const int pk = __float_as_int(h4[u].w);
+            if (pk >= 0) srec[atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u)] = h4[u];
+        }
+        // cursor[k] becomes the END of cell k; cell k starts at cursor[k-1]
         PP3_TICK(1)
-        if (tid < 64) {   // exclusive scan of the 64 cell counts
-            const unsigned c0 = S.cursor[tid];
-            unsigned inc = c0;
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned u = __shfl_up(inc, o);
-                if (lane >= o) inc += u;
-            }
-            S.cursor[tid] = inc - c0;
-        }
-        __syncthreads();
-        for (unsigned i0 = tid; i0 < n; i0 += 4 * V3_JT) {
-            float4 h[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned i = i0 + u * V3_JT;
-                h[u] = i < n ? rec[lo + i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int pk = __float_as_int(h[u].w);
-                if (pk >= 0) {
-                    const unsigned pos = atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u);
-                    rec2[lo + pos] = h[u];
-                }
-            }
-        }
-        // (no __threadfence(): an agent-scope release writes the L2 back on gfx950; the records are
-        //  re-read by this workgroup only, and the barrier orders that at workgroup scope)
-        __syncthreads();   // cursor[k] is now the END of cell k; cell k starts at cursor[k-1]
-        PP3_TICK(2)
 
-        // ---- (b) bands of cell rows ---------------------------------------------
+        // ---- (d) bands of cell rows -----------------------------------------------------
         const unsigned nBands = (dbg & 4) ? 0u : S.nBands;
         for (unsigned b = 0; b < nBands; ++b) {
             const int ya = (int)S.bandA[b], yb = (int)S.bandB[b];
+            const unsigned lbase = S.rowBase[ya - 1];
+            const unsigned Lb = S.rowBase[yb + 1] - lbase;
+            const bool slow = S.bandSlow[b] != 0;
+            __syncthreads();   // scatter / previous band's flush complete
             const unsigned kA = (unsigned)(ya - 1) * V3_TS, kB = (unsigned)(yb - 1) * V3_TS;
             const unsigned ra = kA ? S.cursor[kA - 1] : 0u, rb = S.cursor[kB - 1];
             if (ra == rb) continue;   // uniform: no record in these rows
-            const unsigned lbase = S.rowBase[ya - 1];
-            const unsigned Lb = S.rowBase[yb + 1] - lbase;
-            if (S.bandSlow[b]) {
+            if (slow) {
                 // a single row of cells whose three live rows exceed the LDS budget
                 for (unsigned j = ra + tid; j < rb; j += V3_JT) {
-                    const float4 h = rec2[lo + j];
+                    const float4 h = srec[j];
                     const int pk = __float_as_int(h.w);
                     const int tr = pk >> 16;
                     const int cx = x0 + 1 + (pk & (V3_TS - 1)), cy = y0 + 1 + ((pk & (V3_NC - 1)) / V3_TS);
@@ -458,7 +537,6 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 }
                 continue;
             }
-            __syncthreads();   // previous band's flush is complete
             for (unsigned e = tid; e < Lb; e += V3_JT) {
                 int r = ya - 1;
                 while (e + lbase >= S.rowBase[r + 1]) ++r;
@@ -467,27 +545,19 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             for (unsigned e = tid; e < Lb * Th; e += V3_JT) cntw[e] = 0;
             if (tid == 0) S.ticket = 0;
             __syncthreads();
-            PP3_TICK(3)
+            PP3_TICK(2)
 
             // 64-record chunks of the sorted band range, dealt to wavefronts
             const unsigned nChunks = (rb - ra + 63) / 64;
-            auto grab = [&]() {
-                unsigned k = 0;
-                if (lane == 0) k = atomicAdd(&S.ticket, 1u);
-                return (unsigned)__builtin_amdgcn_readfirstlane(k);
-            };
-            auto fetch = [&](unsigned k) {
-                const unsigned jj = ra + k * 64 + lane;
-                return (k < nChunks && jj < rb) ? rec2[lo + jj] : make_float4(0.f, 0.f, 0.f, 0.f);
-            };
-            unsigned ck = grab();
-            float4 h = fetch(ck);
-            while (ck < nChunks) {
-                const unsigned nk = grab();   // next chunk's records are in flight while this one is joined
-                const float4 hn = fetch(nk);
+            for (;;) {
+                unsigned ck = 0;
+                if (lane == 0) ck = atomicAdd(&S.ticket, 1u);
+                ck = __builtin_amdgcn_readfirstlane(ck);
+                if (ck >= nChunks) break;
                 if (prof) ++nChunk;
                 const unsigned j = ra + ck * 64 + lane;
                 const bool valid = j < rb;
+                const float4 h = valid ? srec[j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int pk = valid ? __float_as_int(h.w) : -1;
                 const int key = pk & (V3_NC - 1);
                 const unsigned trv = (unsigned)(pk >> 16) & 15u;
@@ -510,7 +580,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 {
                     const int prevKey = __shfl_up(key, 1);
                     const unsigned nG = __popcll(__ballot(valid && (lane == 0 || key != prevKey)));
-                    if (nG >= V3_LANE_GROUPS && !(dbg & 2)) {
+                    if (nG >= laneGroups && !(dbg & 2)) {
                         const int lx = (key & (V3_TS - 1)) + 1, ly = key / V3_TS + 1;
                         const unsigned short *row = S.ctab + (ly - 1) * (V3_W + 1) + lx - 1;
                         const unsigned c00 = row[0], c10 = row[V3_W + 1], c20 = row[2 * (V3_W + 1)];
@@ -520,7 +590,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                         const unsigned n01 = n0 + n1, nAll = n01 + n2;
                         const unsigned b1 = S.rowBase[ly] - lbase + c10 - n0;
                         const unsigned b2 = S.rowBase[ly + 1] - lbase + c20 - n01;
-                        const bool mine = valid && nAll <= V3_LANE_MAX;
+                        const bool mine = valid && nAll <= laneMax;
                         const unsigned own = mine ? nAll : 0u;
                         const unsigned cword = trv >> 1, cinc = 1u << ((trv & 1u) * 16);
                         for (unsigned p0 = 0; __any(p0 < own); p0 += 4) {
@@ -575,7 +645,6 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                     // The rare pairs inside the band around r^2 are found through a running minimum of
                     // |d2 - r^2| and re-tested in float64 after the group.
                     float dmin = 3.0e38f;
-                    const unsigned laneWord = (unsigned)lane >> 1;
 #pragma unroll 1
                     for (int rr = 0; rr < 3; ++rr) {
                         const unsigned ra_ = rr == 0 ? a0 : (rr == 1 ? a1 : a2);
@@ -606,9 +675,9 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                                 if (lane < T) {   // adding zero is cheaper than testing for it
                                     unsigned *cw = cntw + i * Th + laneWord;
                                     atomicAdd(cw, c0 << cshift);
-                                    atomicAdd(cw + Th, c1 << cshift);
-                                    atomicAdd(cw + 2 * Th, c2 << cshift);
-                                    atomicAdd(cw + 3 * Th, c3 << cshift);
+                                    if (i + 1 < re_) atomicAdd(cw + Th, c1 << cshift);
+                                    if (i + 2 < re_) atomicAdd(cw + 2 * Th, c2 << cshift);
+                                    if (i + 3 < re_) atomicAdd(cw + 3 * Th, c3 << cshift);
                                 }
                             }
                         }
@@ -631,11 +700,9 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                         }
                     }
                 }
-                ck = nk;
-                h = hn;
             }
             __syncthreads();
-            PP3_TICK(4)
+            PP3_TICK(3)
             if (!(dbg & 1))
                 for (unsigned e = tid; e < Lb * Th; e += V3_JT) {
                     const unsigned cw = cntw[e];
@@ -644,11 +711,10 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                         const size_t row = (size_t)__float_as_int(live[p].w) * T;
                         if (cw & 0xffffu) atomicAdd(&counts[row + tp], (int)(cw & 0xffffu));
                         if (cw >> 16) atomicAdd(&counts[row + tp + 1], (int)(cw >> 16));
-                        if (prof) atomicAdd(&stats[12], (unsigned long long)((cw & 0xffffu) != 0) + ((cw >> 16) != 0));
                     }
                 }
         }
-        PP3_TICK(5)
+        PP3_TICK(4)
         if (tid == 0) {
             S.sliceId = nextId;
             S.slice = nextSl;
@@ -657,17 +723,16 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     if (prof) {
         if (tid == 0) {
             unsigned long long all = 0;
-            for (int k = 0; k < 6; ++k) {
-                atomicAdd(&stats[k], tph[k]);
-                all += tph[k];
+            for (int k = 0; k < 5; ++k) {
+                atomicAdd(&stats[k], S.prof[k]);
+                all += S.prof[k];
             }
             atomicMax(&stats[6], all);
-            atomicAdd(&stats[11], nFlush);
         }
         if (lane == 0) {
-            atomicAdd(&stats[8], nChunk);
-            atomicAdd(&stats[9], nGroups);
-            atomicAdd(&stats[10], nIter);
+            atomicAdd(&stats[8], (unsigned long long)nChunk);
+            atomicAdd(&stats[9], (unsigned long long)nGroups);
+            atomicAdd(&stats[10], (unsigned long long)nIter);
         }
     }
 #undef PP3_TICK
