@@ -12,17 +12,21 @@ struct TravOffsets {
     int n;
 };
 
-// Uniform 2-D grid over the live scan (x,y), cell edge c = r*(1+2^-10) so that
-// two points within r of each other always land in cells whose coordinates
-// differ by at most 1 (cell coordinates are computed in float64; the map
-// v -> cell is monotone, so clamping to the grid keeps that property).
+// Uniform 2-D grid over the live scan (x,y), cell edge c = r*(1+2^-10) so that two points within
+// r of each other always land in cells whose coordinates differ by at most 1.
+// The coordinate is evaluated in float32: t = fl(fl(v - o) * inv_c).  For a point inside the
+// grid (|v - o| <= 640 c) the subtraction is exact (Sterbenz) or has relative error 2^-24, the
+// product another 2^-24, i.e. at most 7.7e-5 cells in total; two points within r differ by at
+// most r/c = 1 - 9.76e-4 cells, so their computed coordinates differ by less than 1 and the
+// floors by at most 1.  v -> cell is monotone (both operations are), so clamping to the grid keeps
+// the property for points outside it.  All kernels use this one function.
 struct PPGrid {
-    double ox, oy, inv_c;
+    float ox, oy, inv_c;
 };
 
-__device__ __forceinline__ int pp_cell_coord(float v, double o, double inv_c, int n) {
-    double f = floor(((double)v - o) * inv_c);
-    f = fmin(fmax(f, 0.0), (double)(n - 1));
+__device__ __forceinline__ int pp_cell_coord(float v, float o, float inv_c, int n) {
+    float f = floorf((v - o) * inv_c);
+    f = fminf(fmaxf(f, 0.0f), (float)(n - 1));   // NaN -> 0
     return (int)f;
 }
 

@@ -67,13 +67,15 @@ __device__ __forceinline__ PPGrid pp_grid(const unsigned *bb, double c) {
     if (!(cx == cx) || fabs(cx) > 1e30) cx = 0.0;   // NaN / inf guard
     if (!(cy == cy) || fabs(cy) > 1e30) cy = 0.0;
     PPGrid g;
-    g.ox = cx - 0.5 * PP_NX * c;
-    g.oy = cy - 0.5 * PP_NY * c;
-    g.inv_c = 1.0 / c;
+    g.ox = (float)(cx - 0.5 * PP_NX * c);
+    g.oy = (float)(cy - 0.5 * PP_NY * c);
+    g.inv_c = (float)(1.0 / c);
     return g;
 }
 
-__global__ __launch_bounds__(256) void pp_live_bbox(const float *__restrict__ live, int n, unsigned *bb) {
+__global__ __launch_bounds__(256) void pp_live_bbox(const float *__restrict__ live, int n, unsigned *bb,
+                                                    int *__restrict__ counts, size_t nCounts) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nCounts; i += (size_t)gridDim.x * 256) counts[i] = 0;
     unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     for (int r = 0; r < 4; ++r) {   // 1024 points per block
         const int i = blockIdx.x * 1024 + r * 256 + threadIdx.x;
@@ -134,15 +136,18 @@ __global__ __launch_bounds__(64) void pp_tile_live(const unsigned *__restrict__ 
 // One block per grid row: coalesced reads of the three neighbouring counter rows,
 // wave ballots for the row's occupancy bits, shifts for the horizontal dilation.
 static_assert(PP_NX % 64 == 0 && PP_NX <= 1024, "one thread per cell of a row, whole wavefronts");
-__global__ __launch_bounds__(PP_NX) void pp_bitmap(const unsigned *__restrict__ cellCount,
-                                                   unsigned *__restrict__ bitmap) {
+__device__ __forceinline__ void pp_bitmap_row(const unsigned *__restrict__ cellCount, unsigned *__restrict__ bitmap,
+                                              int cy) {
     __shared__ unsigned long long sb[PP_NX / 64 + 1];
-    const int cy = blockIdx.x, x = threadIdx.x;
-    unsigned occ = cellCount[(size_t)cy * PP_NX + x];
-    if (cy > 0) occ |= cellCount[(size_t)(cy - 1) * PP_NX + x];
-    if (cy + 1 < PP_NY) occ |= cellCount[(size_t)(cy + 1) * PP_NX + x];
+    const int x = threadIdx.x;
+    unsigned occ = 0;
+    if (x < PP_NX) {
+        occ = cellCount[(size_t)cy * PP_NX + x];
+        if (cy > 0) occ |= cellCount[(size_t)(cy - 1) * PP_NX + x];
+        if (cy + 1 < PP_NY) occ |= cellCount[(size_t)(cy + 1) * PP_NX + x];
+    }
     const unsigned long long ball = __ballot(occ != 0u);
-    if ((x & 63) == 0) sb[x >> 6] = ball;
+    if ((x & 63) == 0 && x < PP_NX) sb[x >> 6] = ball;
     if (x == 0) sb[PP_NX / 64] = 0ULL;
     __syncthreads();
     if (x < PP_NX / 32) {   // output word x covers columns [32x, 32x+32)
@@ -161,12 +166,11 @@ __global__ __launch_bounds__(PP_NX) void pp_bitmap(const unsigned *__restrict__ 
 }
 
 // Exclusive scan of the cell counters in two coalesced launches.
-__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_blocks(const unsigned *__restrict__ cnt,
-                                                             unsigned *__restrict__ start,
-                                                             unsigned *__restrict__ blockSum) {
+__device__ __forceinline__ void pp_scan_block(const unsigned *__restrict__ cnt, unsigned *__restrict__ start,
+                                              unsigned *__restrict__ blockSum, int blk) {
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + tid;
+    const size_t i = (size_t)blk * SCAN_BLOCK + tid;
     const unsigned v = cnt[i];
     unsigned inc = v;
     for (int o = 1; o < 64; o <<= 1) {
@@ -178,7 +182,17 @@ __global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_blocks(const unsigned *__r
     unsigned base = 0;
     for (int k = 0; k < w; ++k) base += wsum[k];
     start[i] = base + inc - v;   // block-local exclusive prefix
-    if (tid == SCAN_BLOCK - 1) blockSum[blockIdx.x] = base + inc;
+    if (tid == SCAN_BLOCK - 1) blockSum[blk] = base + inc;
+}
+
+// One launch for the two independent consumers of the cell counters: blocks [0, SCAN_NBLK) scan,
+// blocks [SCAN_NBLK, SCAN_NBLK + PP_NY) build one row of the dilated bitmap each.
+__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_bitmap(const unsigned *__restrict__ cnt,
+                                                             unsigned *__restrict__ start,
+                                                             unsigned *__restrict__ blockSum,
+                                                             unsigned *__restrict__ bitmap) {
+    if (blockIdx.x < SCAN_NBLK) pp_scan_block(cnt, start, blockSum, (int)blockIdx.x);
+    else pp_bitmap_row(cnt, bitmap, (int)blockIdx.x - SCAN_NBLK);
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_finish(unsigned *__restrict__ start,
@@ -196,16 +210,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_finish(unsigned *__restric
     if (blockIdx.x == SCAN_NBLK - 1 && tid == SCAN_BLOCK - 1) start[PP_NCELL] = off + blockSum[SCAN_NBLK - 1];
 }
 
-__global__ void pp_live_scatter(const float *__restrict__ live, int n, const unsigned *bb, double c,
-                                const unsigned *__restrict__ start, unsigned *fill,
-                                float4 *__restrict__ sorted) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pp_live_scatter_one(int i, const float *__restrict__ live, int n, const unsigned *bb,
+                                                    double c, const unsigned *__restrict__ start,
+                                                    unsigned *fill, float4 *__restrict__ sorted) {
     if (i >= n) return;
     const PPGrid g = pp_grid(bb, c);
     const float x = live[3 * (size_t)i], y = live[3 * (size_t)i + 1], z = live[3 * (size_t)i + 2];
     const int cell = pp_cell_coord(y, g.oy, g.inv_c, PP_NY) * PP_NX + pp_cell_coord(x, g.ox, g.inv_c, PP_NX);
     const unsigned slot = start[cell] + atomicAdd(&fill[cell], 1u);
     sorted[slot] = make_float4(x, y, z, __int_as_float(i));
+}
+
+__global__ void pp_live_scatter(const float *__restrict__ live, int n, const unsigned *bb, double c,
+                                const unsigned *__restrict__ start, unsigned *fill,
+                                float4 *__restrict__ sorted) {
+    pp_live_scatter_one(blockIdx.x * blockDim.x + threadIdx.x, live, n, bb, c, start, fill, sorted);
 }
 
 // ---- V1 history stream (kept for A/B: MODEST_PP_VARIANT=1) ---------------------
@@ -925,9 +944,11 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     }
     if (n_live == 0) return MODEST_OK;
     MODEST_REQUIRE(counts != nullptr, "counts is NULL");
-    MODEST_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n_live * n_trav * sizeof(int32_t), stream));
     const long long m0 = tr.off[0], m1 = tr.off[n_trav];
-    if (m1 == m0) return MODEST_OK;
+    if (m1 == m0) {   // no history: all counts are zero
+        MODEST_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n_live * n_trav * sizeof(int32_t), stream));
+        return MODEST_OK;
+    }
     MODEST_REQUIRE(live != nullptr && hist != nullptr, "NULL point buffer");
     Arena A(ctx->scratch);
     unsigned *zeroed = A.take<unsigned>(zero_words);
@@ -963,17 +984,19 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
     const int nb = (n_live + 255) / 256;
-    pp_live_bbox<<<(n_live + 1023) / 1024, 256, 0, stream>>>(live, n_live, bb);
+    pp_live_bbox<<<(n_live + 1023) / 1024, 256, 0, stream>>>(live, n_live, bb, counts, (size_t)n_live * n_trav);
     pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellCount);
-    pp_bitmap<<<PP_NY, PP_NX, 0, stream>>>(cellCount, bitmap);
-    pp_scan_blocks<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum);
+    pp_scan_bitmap<<<SCAN_NBLK + PP_NY, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum, bitmap);
     pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
-    pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
-
     const char *var_env = getenv("MODEST_PP_VARIANT");
     int var = var_env ? atoi(var_env) : 3;
     if (var == 3 && n_trav > V3_MAXT) var = 2;
     if (var == 2 && nLists > 1024 * V2_WL_LPT) var = 1;   // > 20 traversals: beyond the work-list capacity, use the direct path
+    if (var == 3)   // the extra blocks count the live points of every 8x8-cell block window
+        pp3_scatter_blocklive<<<nb + (V3_NBLK + 255) / 256, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill,
+                                                                             sorted, nb, blockLive);
+    else
+        pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
     if (var == 1) {   // V1: per-point search in the L2-resident index (also kept for A/B measurements)
         pp_stream_v1<<<ctx->num_cus * 3, 256, 0, stream>>>(hist, m0, m1, tr, bb, c, bitmap, cellStart,
                                                            sorted, counts, n_trav, r2);
@@ -997,7 +1020,6 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
                                                  V3_MAXWG * V3_SCAN_L * 4));
             attr_done = true;
         }
-        pp3_block_live<<<(V3_NBLK + 255) / 256, 256, 0, stream>>>(cellStart, blockLive);
         pp3_blocks<<<1, 1024, 0, stream>>>(blockLive, dense, denseBlock, listLive);
         pp3_stream<false><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense, wgTile, wgOff,
                                                      tileBase, rec, dbg);

@@ -106,9 +106,8 @@ __device__ __forceinline__ void pp3_tile_of(int list, int *tx, int *ty) {
 // dense[0 .. 200)   flag words (bit b = block b, row-major, is split into quadrants)
 // dense[200 .. 400) number of dense blocks before each word
 // denseBlock[d]     block of dense index d;   listLive[l] window live points of list l's block
-__global__ __launch_bounds__(256) void pp3_block_live(const unsigned *__restrict__ cellStart,
-                                                      unsigned *__restrict__ blockLive) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pp3_block_live_one(int b, const unsigned *__restrict__ cellStart,
+                                                   unsigned *__restrict__ blockLive) {
     if (b >= V3_NBLK) return;
     const int bx = b % V3_NT, by = b / V3_NT;
     const int gx0 = max(bx * V3_TS - 1, 0), gx1 = min(bx * V3_TS + V3_TS + 1, PP_NX);
@@ -121,6 +120,18 @@ __global__ __launch_bounds__(256) void pp3_block_live(const unsigned *__restrict
         lw += (gy == gyc) ? v : 0u;
     }
     blockLive[b] = lw;
+}
+
+// last step of the live index build, one launch for two independent jobs: blocks [0, nb) place
+// the live points into their cells, the others count the live points of every block window
+__global__ __launch_bounds__(256) void pp3_scatter_blocklive(const float *__restrict__ live, int n, const unsigned *bb,
+                                                             double c, const unsigned *__restrict__ cellStart,
+                                                             unsigned *fill, float4 *__restrict__ sorted, int nb,
+                                                             unsigned *__restrict__ blockLive) {
+    if ((int)blockIdx.x < nb)
+        pp_live_scatter_one(blockIdx.x * 256 + threadIdx.x, live, n, bb, c, cellStart, fill, sorted);
+    else
+        pp3_block_live_one(((int)blockIdx.x - nb) * 256 + threadIdx.x, cellStart, blockLive);
 }
 
 __global__ __launch_bounds__(1024) void pp3_blocks(const unsigned *__restrict__ blockLive, unsigned *__restrict__ dense,
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
     for (int i = tid; i < V3_NL; i += 1024) cur[i] = SCATTER ? tileBase[i] + wgOff[(size_t)blockIdx.x * V3_NL + i] : 0u;
     if (tid < 2 * V3_DWORDS) sdense[tid] = dense[tid];
     const PPGrid g = pp_grid(bb, c);
+    unsigned dummy = 0;
     __syncthreads();
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         int t = 0;
@@ -242,6 +254,8 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
                         typedef float v4f_t __attribute__((ext_vector_type(4)));
                         if (dbg & 32) __builtin_nontemporal_store(v4f_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<v4f_t *>(&rec[pos]));
                         else if (!(dbg & 16)) rec[pos] = rv;
+                    } else if (dbg & 64) {
+                        dummy += (unsigned)list;
                     } else {
                         atomicAdd(&cur[list], 1u);
                     }
@@ -250,6 +264,7 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
         }
     }
     if (!SCATTER) {
+        if (dummy == 0xdeadbeefu) cur[0] = dummy;
         __syncthreads();
         for (int i = tid; i < V3_NL; i += 1024) wgTile[(size_t)blockIdx.x * V3_NL + i] = cur[i];
     }

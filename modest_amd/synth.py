@@ -86,7 +86,7 @@ def default_l2e() -> np.ndarray:
 
 def sample_frame(world: World, seed: int, n: int, ego_pose: np.ndarray, l2e: np.ndarray,
                  nusc: bool = False, mobiles: np.ndarray | None = None,
-                 max_range: float = 80.0) -> np.ndarray:
+                 max_range: float = 80.0, point_order: str = "shuffled") -> np.ndarray:
     """One LiDAR frame, (n,4) float32 in KITTI-velodyne coordinates
     (x forward, y left, z up; intensity in column 3)."""
     rng = np.random.default_rng(seed)
@@ -152,7 +152,10 @@ def sample_frame(world: World, seed: int, n: int, ego_pose: np.ndarray, l2e: np.
     out = np.empty((n, 4), dtype=np.float32)
     out[:, :3] = ps.astype(np.float32)
     out[:, 3] = rng.uniform(0, 1, n).astype(np.float32)
-    return out[rng.permutation(n)]
+    perm = rng.permutation(n)   # drawn in both modes: the point SET does not depend on the order
+    if point_order == "azimuth":   # spinning-LiDAR firing order: azimuth-major, ranges interleaved
+        return out[np.argsort(np.arctan2(out[:, 1], out[:, 0]), kind="stable")]
+    return out[perm]
 
 
 def make_mobiles(seed: int, ego_x: float, count: int = 16) -> np.ndarray:
@@ -188,7 +191,7 @@ def relative_pose(fixed_l2e, fixed_ego, query_l2e, query_ego, K) -> np.ndarray:
 
 def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: int = 36,
               n_per_frame: int | None = None, nusc: bool = False, frame_gap: float = 2.0,
-              keep_frames: bool = False, world_seed: int = 0) -> ScanInputs:
+              keep_frames: bool = False, world_seed: int = 0, point_order: str = "shuffled") -> ScanInputs:
     """Seeds: live 1000+scan_id, history 2000+scan_id*1000+t*100+f."""
     n_per_frame = n_live if n_per_frame is None else n_per_frame
     world = make_world(world_seed)
@@ -197,7 +200,7 @@ def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: in
     l2e = default_l2e()
     live_pose = _pose_matrix(ego_x, 0.0, 0.01)
     mobiles = make_mobiles(scan_id, ego_x)
-    live_raw = sample_frame(world, 1000 + scan_id, n_live, live_pose, l2e, nusc, mobiles)
+    live_raw = sample_frame(world, 1000 + scan_id, n_live, live_pose, l2e, nusc, mobiles, point_order=point_order)
     first_pose = None
     hist, frames = [], []
     rngp = np.random.default_rng(30_000 + scan_id)
@@ -209,7 +212,8 @@ def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: in
             pose = _pose_matrix(ego_x + frame_gap * f + rngp.uniform(-0.5, 0.5), lat, yaw)
             if first_pose is None:
                 first_pose = pose
-            raw = sample_frame(world, 2000 + scan_id * 1000 + t * 100 + f, n_per_frame, pose, l2e, nusc)
+            raw = sample_frame(world, 2000 + scan_id * 1000 + t * 100 + f, n_per_frame, pose, l2e, nusc,
+                               point_order=point_order)
             rel = relative_pose(l2e, first_pose, l2e, pose, K)
             xyz = raw[:, :3]
             if nusc:

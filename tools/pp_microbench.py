@@ -8,7 +8,8 @@ def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 36
     t0 = time.time()
-    s = synth.make_scan(0, n_live=30000, n_trav=T, n_frames=F)
+    import os
+    s = synth.make_scan(0, n_live=30000, n_trav=T, n_frames=F, point_order=os.environ.get("SYNTH_ORDER", "shuffled"))
     print("gen %.1fs" % (time.time() - t0), flush=True)
     dev = torch.device("cuda:0")
     off = np.cumsum([0] + [len(h) for h in s.hist])
