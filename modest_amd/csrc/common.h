@@ -17,6 +17,7 @@ struct modest_ctx {
     int prof_count;
     hipEvent_t *prof_ev;   // 2 * prof_cap events
     int prof_cap;
+    int pp_attr_done;      // dynamic-LDS limits of the PP kernels raised on this device
 };
 
 // Record an event pair around a kernel when profiling is on (no-ops otherwise).

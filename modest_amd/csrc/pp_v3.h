@@ -45,7 +45,7 @@ constexpr int V3_NL = V3_NBLK + 4 * V3_DMAX;   // 7168 lists
 constexpr int V3_NC = V3_TS * V3_TS;        // 64 cells per block = sort keys of a slice
 constexpr int V3_W = V3_TS + 2;             // 10: window incl. halo
 constexpr int V3_CH = 4096;                 // history points per chunk (1024 threads x 4)
-constexpr int V3_MAXT = 16;                 // traversals handled by the routed path
+constexpr int V3_MAXT = 32;                 // traversals handled by the routed path (5 bits, one lane each)
 constexpr int V3_MAXWG = 512;               // stream workgroups
 constexpr int V3_JT = 1024;                 // threads of a join workgroup
 constexpr int V3_RPT = 4;                   // records per join thread
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     // per-lane constants of the traversal-segmented popcount: lane t < T owns traversal t;
     // selk = all ones if bit k of t is CLEAR (mask of traversal t = AND_k (B_k ^ selk))
     const unsigned sel0 = (lane & 1) ? 0u : ~0u, sel1 = (lane & 2) ? 0u : ~0u;
-    const unsigned sel2 = (lane & 4) ? 0u : ~0u, sel3 = (lane & 8) ? 0u : ~0u;
+    const unsigned sel2 = (lane & 4) ? 0u : ~0u, sel3 = (lane & 8) ? 0u : ~0u, sel4 = (lane & 16) ? 0u : ~0u;
     const unsigned cshift = (lane & 1) * 16;
     const unsigned laneWord = (unsigned)lane >> 1;
 
@@ -575,17 +575,18 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 const float4 h = valid ? srec[j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int pk = valid ? __float_as_int(h.w) : -1;
                 const int key = pk & (V3_NC - 1);
-                const unsigned trv = (unsigned)(pk >> 16) & 15u;
+                const unsigned trv = (unsigned)(pk >> 16) & 31u;
                 // traversal segment masks: lane t keeps the lanes whose record belongs to traversal t
                 unsigned long long seg = __ballot(valid);
                 {
                     const unsigned long long B0 = __ballot(trv & 1u), B1 = __ballot(trv & 2u);
-                    const unsigned long long B2 = __ballot(trv & 4u), B3 = __ballot(trv & 8u);
+                    const unsigned long long B2 = __ballot(trv & 4u), B3 = __ballot(trv & 8u), B4 = __ballot(trv & 16u);
                     const unsigned long long s0 = ((unsigned long long)sel0 << 32) | sel0;
                     const unsigned long long s1 = ((unsigned long long)sel1 << 32) | sel1;
                     const unsigned long long s2 = ((unsigned long long)sel2 << 32) | sel2;
                     const unsigned long long s3 = ((unsigned long long)sel3 << 32) | sel3;
-                    seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3);
+                    const unsigned long long s4 = ((unsigned long long)sel4 << 32) | sel4;
+                    seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3) & (B4 ^ s4);
                 }
                 const unsigned segLo = (unsigned)seg, segHi = (unsigned)(seg >> 32);
                 unsigned long long todo = __ballot(valid);

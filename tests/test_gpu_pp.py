@@ -100,3 +100,47 @@ def test_pp_linearity_full_size(gpu):
     two = ops.pp_count(live, torch.cat([ha, hb]), [0, m, 2 * m], 0.3)
     assert torch.equal(two[:, 0], ca[:, 0]) and torch.equal(two[:, 1], cb[:, 0])
     assert int(cab.sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [17, 32, 40])
+def test_pp_many_traversals(gpu, T):
+    """17 and 32 traversals use the routed path (one lane per traversal in the segmented
+    popcount), 40 the direct path; ragged traversal sizes, some of them empty."""
+    import torch
+    from modest_amd import ops
+    from oracle import pp_score as opp
+    rng = np.random.default_rng(100 + T)
+    live = (rng.standard_normal((3000, 3)) * [6, 6, 0.4]).astype(np.float32)
+    hist = []
+    for t in range(T):
+        m = 0 if t % 7 == 3 else int(rng.integers(500, 6000))
+        hist.append((rng.standard_normal((m, 3)) * [6, 6, 0.4]).astype(np.float32))
+    cref = opp.count_neighbors_bruteforce(live, hist, 0.3)
+    off = np.cumsum([0] + [len(h) for h in hist])
+    H, c = ops.pp_score(torch.from_numpy(live).to(gpu), torch.from_numpy(np.concatenate(hist)).to(gpu), off, 0.3,
+                        return_counts=True)
+    assert np.array_equal(c.cpu().numpy().astype(np.int64), cref)
+    Href = opp.compute_ephe_score(cref)
+    assert np.max(np.abs(H.cpu().numpy().astype(np.float64) - Href)) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spread", [0.25, 1.0, 4.0])
+def test_pp_dense_clusters(gpu, spread):
+    """Live scans far denser than LiDAR data: thousands of live points in a few cells force the
+    row-band split of a block (spread 1.0), the per-record fallback for bands that do not fit
+    the LDS even as a single row (spread 0.25), and dense-block quadrant lists (spread 4.0)."""
+    import torch
+    from modest_amd import ops
+    from oracle import pp_score as opp
+    rng = np.random.default_rng(int(spread * 100))
+    live = np.concatenate([(rng.standard_normal((9000, 3)) * [spread, spread, 0.3]),
+                           (rng.standard_normal((1000, 3)) * [15, 15, 0.3])]).astype(np.float32)
+    hist = [(rng.standard_normal((20000, 3)) * [spread * 1.5, spread * 1.5, 0.3]).astype(np.float32),
+            (rng.standard_normal((15000, 3)) * [10, 10, 0.3]).astype(np.float32),
+            (rng.standard_normal((9000, 3)) * [spread, spread, 0.3] + [0.2, 0.1, 0.0]).astype(np.float32)]
+    cref = opp.count_neighbors(live, hist, 0.3)
+    off = np.cumsum([0] + [len(h) for h in hist])
+    c = ops.pp_count(torch.from_numpy(live).to(gpu), torch.from_numpy(np.concatenate(hist)).to(gpu), off, 0.3)
+    assert np.array_equal(c.cpu().numpy().astype(np.int64), cref)
