@@ -152,12 +152,34 @@ def main():
     alg_bytes = 12 * sc0.M + 16 * sc0.N
     k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+    # the same stage with nothing else on the GPU (the timed region has `--streams` scans in flight,
+    # so its event pairs also see the other scans' kernels): informational, not the reported `achieved`
+    iso_ms = None
+    if rank == 0:
+        ctxs[0].profile_begin(16)
+        with torch.cuda.stream(streams[0]):
+            for i in range(8):
+                ops.pp_score(sc0.live_xyz, sc0.hist, sc0.offsets, 0.3, ctx=ctxs[0])
+            streams[0].synchronize()
+        iso = ctxs[0].profile_collect(16)
+        iso_ms = float(np.mean(iso[2:])) if len(iso) > 2 else None
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_pp_traffic.json")
+    if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
+        tj = json.load(open(tpath))
+        if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
+            traffic, traffic_src = tj["hbm_bytes_per_scan"], "profiles/r01_pp_traffic.json (" + tj["source"] + ")"
     roofline = {"bound": "hbm",
-                "kernel": "PP neighbour count of one scan = pp_live_* index build + pp2_route + pp2_worklist + pp2_tiles "
-                          "(all launches of the stage, HIP events on the launch stream)", "achieved": achieved,
+                "kernel": "PP neighbour count of one scan = live index build (5 launches) + pp3_stream<count> + pp3_scan "
+                          "+ pp3_plan + pp3_stream<scatter> + pp3_join: ALL launches of the stage, HIP events on the "
+                          "launch stream", "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-                "launches_timed": int(len(kernel_ms))}
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                "launches_timed": int(len(kernel_ms)),
+                "isolated": {"kernel_ms": iso_ms,
+                             "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso_ms else None,
+                             "note": "same stage, one scan at a time on an otherwise idle GPU, after the timed region"}}
 
     cpu_baseline = None
     parity = None

@@ -323,7 +323,7 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     // one contiguous zero-initialised block:
     // cellCount | fill | bbox[4] | ctrl3[4] | listTotal | tileBase | listLive | dense | denseBlock | blockLive | dbg
     const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 4 + 4 + 3 * V3_NL + 2 * V3_DWORDS + V3_DMAX +
-                              V3_NBLK + 68;
+                              V3_NBLK + 68 + 2 * (64 + 3 * 1024);
     size_t need = arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
                   arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
                   arena_sz((size_t)nchunks * V3_CH * 16) + 2 * arena_sz((size_t)nwg3 * V3_NL * 4) +
@@ -418,13 +418,35 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
                 rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
                 reinterpret_cast<unsigned long long *>(dbgStats));
         if (dbg & 8) {
-            unsigned long long hs[16];
+            unsigned long long hs[32];
             unsigned hc[4];
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hs, dbgStats, sizeof(hs), hipMemcpyDeviceToHost));
             MODEST_HIP_CHECK(hipMemcpy(hc, ctrl3, sizeof(hc), hipMemcpyDeviceToHost));
             fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu | max WG %llu | chunks %llu groups %llu iters %llu\n",
                     hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[6], hs[8], hs[9], hs[10]);
+            {
+                static unsigned long long tl[64 + 3 * 1024];
+                MODEST_HIP_CHECK(hipMemcpy(tl, dbgStats, sizeof(tl), hipMemcpyDeviceToHost));
+                const int nwg = 2 * ctx->num_cus;
+                unsigned long long t0 = ~0ULL, hist_end[16] = {0}, mx = 0, sl_mx = 0, st_mx = 0;
+                for (int k = 0; k < nwg; ++k) t0 = tl[64 + k] < t0 ? tl[64 + k] : t0;
+                for (int k = 0; k < nwg; ++k) {
+                    const unsigned long long e = tl[64 + 1024 + k] - t0, st = tl[64 + k] - t0;
+                    mx = e > mx ? e : mx;
+                    st_mx = st > st_mx ? st : st_mx;
+                    sl_mx = tl[64 + 2048 + k] > sl_mx ? tl[64 + 2048 + k] : sl_mx;
+                }
+                for (int k = 0; k < nwg; ++k) hist_end[(tl[64 + 1024 + k] - t0) * 15 / (mx ? mx : 1)]++;
+                fprintf(stderr, "[pp3] WG end times: last start %llu, last end %llu ticks; end histogram (16 bins):", st_mx, mx);
+                for (int k = 0; k < 16; ++k) fprintf(stderr, " %llu", hist_end[k]);
+                fprintf(stderr, "; max slices per WG %llu\n", sl_mx);
+                const unsigned worst = (unsigned)(hs[13] & 0xffffffffu);
+                uint4 ws;
+                MODEST_HIP_CHECK(hipMemcpy(&ws, slices + worst, sizeof(ws), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[pp3] slowest slice: id %u list %u records %u, %llu ticks starting at %llu (load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu)\n",
+                        worst, ws.x, ws.z - ws.y, hs[13] >> 32, hs[21], hs[16], hs[17], hs[18], hs[19], hs[20]);
+            }
         }
         modest_prof_mark(ctx, stream, 1);
         MODEST_HIP_CHECK(hipGetLastError());

@@ -381,7 +381,7 @@ struct JoinShared {
     unsigned bandA[V3_TS], bandB[V3_TS], bandSlow[V3_TS];
     unsigned nBands, ticket, sliceId;
     uint4 slice;
-    unsigned long long prof[8], tlast;   // PROF builds only
+    unsigned long long prof[8], prev[8], tlast;   // PROF builds only
 };
 
 template <bool PROF>
@@ -411,13 +411,18 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     const unsigned laneGroups = ((dbg >> 8) & 0xff) ? ((dbg >> 8) & 0xff) : V3_LANE_GROUPS;
     const unsigned laneMax = ((dbg >> 16) & 0xfff) ? ((dbg >> 16) & 0xfff) : V3_LANE_MAX;
     unsigned nGroups = 0, nIter = 0, nChunk = 0;
-    if (prof && tid < 8) S.prof[tid] = 0;
+    if (prof && tid < 8) {
+        S.prof[tid] = 0;
+        S.prev[tid] = 0;
+    }
 #define PP3_TICK(k)                                     \
     if (prof && tid == 0) {                              \
         const unsigned long long now_ = wall_clock64(); \
         S.prof[k] += now_ - S.tlast;                     \
         S.tlast = now_;                                  \
     }
+    if (prof && tid == 0) stats[64 + blockIdx.x] = wall_clock64();
+    unsigned nMine = 0;
     if (tid == 0) {   // the first slice; later ones are fetched while the previous slice is processed
         const unsigned first = atomicAdd(&ctrl3[1], 1u);
         S.sliceId = first;
@@ -425,9 +430,13 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     }
     for (;;) {
         __syncthreads();
-        if (prof && tid == 0) S.tlast = wall_clock64();
+        if (prof && tid == 0) {
+            S.tlast = wall_clock64();
+            S.prof[7] = S.tlast;
+        }
         const unsigned sid = S.sliceId;
         if (sid >= nSlices) break;
+        ++nMine;
         const uint4 sl = S.slice;
         if (tid < V3_NC) S.cursor[tid] = 0;
         __syncthreads();   // everyone holds the slice: thread 0 may overwrite the header below
@@ -731,10 +740,23 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 }
         }
         PP3_TICK(4)
+        if (prof && tid == 0) {
+            const unsigned long long dur = wall_clock64() - S.prof[7];
+            const unsigned long long packed = (dur << 32) | sid;
+            if (atomicMax(&stats[13], packed) < packed) {
+                for (int k = 0; k < 5; ++k) stats[16 + k] = S.prof[k] - S.prev[k];
+                stats[21] = S.prof[7] - stats[64 + blockIdx.x];   // start of the slice, relative to this WG's start
+            }
+            for (int k = 0; k < 5; ++k) S.prev[k] = S.prof[k];
+        }
         if (tid == 0) {
             S.sliceId = nextId;
             S.slice = nextSl;
         }
+    }
+    if (prof && tid == 0) {
+        stats[64 + 1024 + blockIdx.x] = wall_clock64();
+        stats[64 + 2048 + blockIdx.x] = nMine;
     }
     if (prof) {
         if (tid == 0) {
