@@ -179,6 +179,21 @@ int modest_cluster_stats(modest_ctx *ctx, const float *pts_dev, int n, int strid
                          int n_clusters, const double *plane4_host,
                          double quantile, double *out_host, void *stream);
 
+/* ---- §8f-2 combine_labels.py: filter_by_ppscore (combine_labels.py:41-60) -------
+ * For each detector box the reference masks the scan's rect-frame points (offsets from the box
+ * centre rotated into the box frame by `ptc_xz @ rot.T`, strict half-extent tests in x and z,
+ * y in (t_y - h, t_y]) and takes numpy.percentile of the masked PP scores.
+ * rect_xyz [dev] (n,3) float64 (calib.project_velo_to_rect output), pp [dev] (n,) float32.
+ * boxes12 [host] (n_boxes,12) float64, the scalars numpy compares against, evaluated by the
+ * caller in the box fields' own dtypes: cx, cz, rot00, rot01, rot10, rot11, -l/2, l/2, -w/2,
+ * w/2, t_y - h, t_y.
+ * out [host] (n_boxes,4) float64: {0: points inside, 1: a, 2: b, 3: gamma} with a, b the two
+ * order statistics numpy.percentile(pp[mask], 100*quantile) interpolates between ('linear' on
+ * float32 data: virtual index (n-1)*quantile = floor + gamma, all in float32).  Blocking.   */
+int modest_boxes_pp_stats(modest_ctx *ctx, const double *rect_xyz_dev, int n,
+                          const float *pp_dev, const double *boxes12_host, int n_boxes,
+                          double quantile, double *out_host, void *stream);
+
 /* ---- a16 closeness_rectangle angle search (pointcloud_utils.py:167-187)
  * For each cluster c (points pts_xz[offsets[c]..offsets[c+1]) , float64 (x,z)
  * pairs) and each of n_angles (cos,sin) table entries: beta = sum over points

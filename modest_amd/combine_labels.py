@@ -1,0 +1,140 @@
+"""``python -m modest_amd.combine_labels data_root=... det_result_path=... save_path=...``
+
+Drop-in for the reference's ``generate_cluster_mask/combine_labels.py``, the label
+merge of every self-training round: detector boxes (OpenPCDet ``result.pkl``) are kept only if the
+PP-score percentile of the scan points inside them says "mobile" (``filter_by_ppscore``) and their
+score passes ``score_filtering``; the seed boxes of ``bbox_info_save_dst`` are appended with an
+area score below every detection; score-ranked BEV NMS; optional FOV filter; KITTI label text.
+The per-box point mask + percentile (N points x K boxes) and the IoU matrix run on the device.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import pickle
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import config, dist, ops
+from .utils import kitti_util
+from .utils.clustering_utils import percentile_from_order_stats
+from .utils.pointcloud_utils import is_within_fov, load_velo_scan, objs2label, objs_nms, to_device
+
+
+def predicts2objs(preds):
+    """(combine_labels.py:23-34) OpenPCDet prediction dict -> objects; ``dimensions`` = (l, h, w)."""
+    objs = []
+    for i in range(preds["location"].shape[0]):
+        obj = SimpleNamespace()
+        obj.t = preds["location"][i]
+        obj.l = preds["dimensions"][i][0]
+        obj.h = preds["dimensions"][i][1]
+        obj.w = preds["dimensions"][i][2]
+        obj.ry = preds["rotation_y"][i]
+        obj.score = preds["score"][i]
+        objs.append(obj)
+    return objs
+
+
+def add_area_score(objs):
+    """(combine_labels.py:37-39)"""
+    for obj in objs:
+        obj.score = -999 + obj.w * obj.l
+
+
+def _box_scalars(obj):
+    """The twelve float64 scalars of ``modest_boxes_pp_stats``, evaluated with numpy in the box
+    fields' own dtypes exactly as combine_labels.py:42-56 evaluates them (a float32 ``ry`` gives a
+    float32 rotation matrix, ``-l/2`` of a float32 ``l`` is a float32 value, ...)."""
+    ry, l, w = obj.ry, obj.l, obj.w
+    rot = np.array([[np.cos(ry), -np.sin(ry)], [np.sin(ry), np.cos(ry)]])
+    return [obj.t[0], obj.t[2], rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1], -l / 2, l / 2, -w / 2, w / 2,
+            obj.t[1] - obj.h, obj.t[1]]
+
+
+def filter_by_ppscore_batch(ptc_rect_dev, pp_dev, objs, percentile=50, threshold=0.5):
+    """``[filter_by_ppscore(ptc_rect, pp_score, obj, percentile, threshold) for obj in objs]``
+    (combine_labels.py:41-60) in one device call: a box passes iff it contains a point and
+    ``np.percentile(pp_score[mask], percentile) <= threshold``."""
+    if len(objs) == 0:
+        return []
+    boxes12 = np.array([_box_scalars(o) for o in objs], dtype=np.float64)
+    q32 = np.true_divide(percentile, np.float32(100))   # numpy divides by a float32 hundred for float32 data
+    st = ops.boxes_pp_stats(ptc_rect_dev, pp_dev, boxes12, float(q32))
+    pct = percentile_from_order_stats(st[:, 1], st[:, 2], st[:, 3])
+    return [bool(n > 0 and not (p > threshold)) for n, p in zip(st[:, 0], pct)]
+
+
+def combine_scan(ptc, pp_score, calib, det_bbox, gen_obj, args):
+    """combine_labels.py:94-121 for one frame -> (label text, kept objects, per-detection keep flags)."""
+    ptc_in_rect = calib.project_velo_to_rect(ptc[:, :3])
+    dets = predicts2objs(det_bbox)
+    rect_dev = to_device(ptc_in_rect, dtype=torch.float64)
+    pp_dev = to_device(pp_score)   # float32 .npy, as written by pre_compute_pp_score
+    flags = filter_by_ppscore_batch(rect_dev, pp_dev, dets, percentile=args.det_filtering.pp_score_percentile,
+                                    threshold=args.det_filtering.pp_score_threshold)
+    flags = [bool(f & (o.score > args.det_filtering.score_filtering)) for f, o in zip(flags, dets)]
+    det_obj = [o for o, f in zip(dets, flags) if f]
+    add_area_score(gen_obj)
+    objs = det_obj + gen_obj
+    if len(objs) > 0:
+        objs = objs_nms(objs, nms_threshold=args.nms.threshold, use_score_rank=True)
+    if args.fov_only:
+        objs = [obj for obj in objs if is_within_fov(obj, calib, args.image_shape)]
+    return objs2label(objs, calib, with_score=args.with_score), objs, flags
+
+
+def eprint(*args, **kwargs):
+    print(*args, file=sys.stderr, **kwargs)
+
+
+def display_args(args):
+    eprint("========== combine_labels info ==========")
+    eprint("host: {}".format(os.getenv("HOSTNAME")))
+    eprint(config.to_yaml(args))
+    eprint("=========================================")
+
+
+@config.main(config_name="combine_labels.yaml")
+def main(args):
+    rank, ws, local = dist.init()
+    if rank == 0:
+        display_args(args)
+    torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))
+    dp = args.data_paths
+    det_bboxes = pickle.load(open(args.det_result_path, "rb"))
+    by_frame = {int(d["frame_id"]): d for d in det_bboxes}
+    idx_list = np.array([int(d["frame_id"]) for d in det_bboxes])
+    shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
+    os.makedirs(args.save_path, exist_ok=True)
+    if dp.bbox_info_save_dst is None and rank == 0:
+        eprint("Warning: not adding generated bboxes")
+    t0, done = time.perf_counter(), 0
+    dist.barrier()
+    for idx in shard:
+        idx = int(idx)
+        # (the reference zips the sharded index list with the UNsharded detections, combine_labels.py:86,
+        #  and relies on its assert; each frame is paired with its own detections here)
+        det_bbox = by_frame[idx]
+        gen_obj = pickle.load(open(osp.join(dp.bbox_info_save_dst, f"{idx:06d}.pkl"), "rb")) \
+            if dp.bbox_info_save_dst is not None else []
+        calib = kitti_util.Calibration(osp.join(args.calib_path, f"{idx:06d}.txt"))
+        ptc = load_velo_scan(osp.join(args.ptc_path, f"{idx:06d}.bin"))
+        pp_score = np.load(osp.join(dp.pp_score_path, f"{idx:06d}.npy"))
+        text, _, _ = combine_scan(ptc, pp_score, calib, det_bbox, gen_obj, args)
+        with open(osp.join(args.save_path, f"{idx:06d}.txt"), "w") as f:
+            f.write(text)
+        done += 1
+    dist.barrier()
+    tot = dist.reduce_counters(dict(scans=done, max_seconds=time.perf_counter() - t0))
+    if rank == 0:
+        eprint("[combine_labels] %d scans, %.2f s on %d GPU(s)" % (tot["scans"], tot["max_seconds"], ws))
+    return tot
+
+
+if __name__ == "__main__":
+    main()

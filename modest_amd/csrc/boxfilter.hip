@@ -1,0 +1,101 @@
+// PP-score statistics of the points inside detector boxes, for the self-training label merge
+// (reference: generate_cluster_mask/combine_labels.py:41-60 filter_by_ppscore).
+// Per box the reference builds a boolean mask over all N points of the scan (rotate the
+// rect-frame xz offsets into the box frame, strict half-extent tests, y in (t_y - h, t_y]) and
+// takes numpy.percentile of the masked PP scores.  Here one workgroup per box gathers the
+// member indices (wave-aggregated append) and radix-selects the two order statistics the
+// percentile interpolates between.  Boxes may overlap, so the lists are not a partition.
+#include "common.h"
+#include "radix_select.h"
+#include <cmath>
+
+namespace {
+
+// host-evaluated box scalars, exactly the float64 values numpy compares against
+struct BoxP {
+    double cx, cz, r00, r01, r10, r11, xlo, xhi, zlo, zhi, ylo, yhi;
+};
+
+__global__ __launch_bounds__(CS_THREADS) void bf_stats(const double *__restrict__ rect, int n,
+                                                       const float *__restrict__ pp,
+                                                       const BoxP *__restrict__ boxes, float qf,
+                                                       int *__restrict__ members, double *__restrict__ out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wsum[4], sel[2];
+    __shared__ unsigned s_n;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const BoxP B = boxes[b];
+    int *mem = members + (size_t)b * n;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += CS_THREADS) {
+        const int i = i0 + tid;
+        bool in = false;
+        if (i < n) {
+            const double x = rect[3 * (size_t)i] - B.cx, y = rect[3 * (size_t)i + 1];
+            const double z = rect[3 * (size_t)i + 2] - B.cz;
+            // (N,2) @ rot.T through dgemm: acc = x*r; acc = fma(z, r', acc)
+            const double xr = fma(z, B.r01, x * B.r00), zr = fma(z, B.r11, x * B.r10);
+            in = xr > B.xlo && xr < B.xhi && zr > B.zlo && zr < B.zhi && y > B.ylo && y <= B.yhi;
+        }
+        const unsigned long long m = __ballot(in);
+        if (m) {   // wave-aggregated append (order inside a box does not matter)
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, (unsigned)__popcll(m));
+            base = __shfl(base, 0);
+            if (in) mem[base + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
+        }
+    }
+    __syncthreads();
+    const int cnt = (int)s_n;
+    double a = 0.0, c = 0.0, gamma = 0.0;
+    if (cnt > 0) {
+        int prev, next;
+        float g;
+        cs_percentile_ranks(cnt, qf, &prev, &next, &g);
+        gamma = (double)g;
+        a = (double)cs_select(pp, mem, cnt, (unsigned)prev, hist, wsum, sel);
+        c = (next == prev) ? a : (double)cs_select(pp, mem, cnt, (unsigned)next, hist, wsum, sel);
+    }
+    if (tid == 0) {
+        out[4 * b + 0] = (double)cnt;
+        out[4 * b + 1] = a;
+        out[4 * b + 2] = c;
+        out[4 * b + 3] = gamma;
+    }
+}
+
+}  // namespace
+
+extern "C" int modest_boxes_pp_stats(modest_ctx *ctx, const double *rect_xyz, int n, const float *pp,
+                                     const double *boxes12_host, int n_boxes, double quantile,
+                                     double *out_host, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0 && n_boxes >= 0, "bad sizes");
+    MODEST_REQUIRE(quantile >= 0.0 && quantile <= 1.0, "quantile must be in [0,1]");
+    if (n_boxes == 0) return MODEST_OK;
+    MODEST_REQUIRE(boxes12_host && out_host, "NULL buffer");
+    MODEST_REQUIRE(n == 0 || (rect_xyz && pp), "NULL point buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t b_box = arena_sz((size_t)n_boxes * sizeof(BoxP)), b_out = arena_sz((size_t)n_boxes * 32);
+    const size_t b_mem = arena_sz((size_t)n_boxes * (size_t)(n > 0 ? n : 1) * 4);
+    int rc = modest_ctx_reserve(ctx, b_box + b_out + b_mem);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, (size_t)n_boxes * (sizeof(BoxP) + 32));
+    if (rc) return rc;
+    BoxP *d_box = reinterpret_cast<BoxP *>(ctx->scratch);
+    double *d_out = reinterpret_cast<double *>(ctx->scratch + b_box);
+    int *members = reinterpret_cast<int *>(ctx->scratch + b_box + b_out);
+    BoxP *h_box = reinterpret_cast<BoxP *>(ctx->pinned);
+    double *h_out = reinterpret_cast<double *>(ctx->pinned + (size_t)n_boxes * sizeof(BoxP));
+    static_assert(sizeof(BoxP) == 12 * sizeof(double), "BoxP is twelve doubles");
+    for (size_t i = 0; i < (size_t)n_boxes * 12; ++i) reinterpret_cast<double *>(h_box)[i] = boxes12_host[i];
+    MODEST_HIP_CHECK(hipMemcpyAsync(d_box, h_box, (size_t)n_boxes * sizeof(BoxP), hipMemcpyHostToDevice, stream));
+    bf_stats<<<n_boxes, CS_THREADS, 0, stream>>>(rect_xyz, n, pp, d_box, (float)quantile, members, d_out);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_boxes * 32, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < (size_t)n_boxes * 4; ++i) out_host[i] = h_out[i];
+    return MODEST_OK;
+}

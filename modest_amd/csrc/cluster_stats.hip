@@ -6,20 +6,10 @@
 // host; here the members of every cluster are gathered by a counting sort and one workgroup
 // per cluster does the reductions and an exact radix select.
 #include "common.h"
+#include "radix_select.h"
 #include <cmath>
 
 namespace {
-
-constexpr int CS_THREADS = 256;
-
-__device__ __forceinline__ unsigned cs_key(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float cs_unkey(unsigned k) {
-    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
 
 // label histogram; a few clusters hold most points, so same-address global atomics (~12 ns
 // each) are first folded per wavefront: lanes with equal labels elect one adder
@@ -58,54 +48,6 @@ __global__ void cs_scatter(const int *__restrict__ labels, int n, int C, const u
 struct PlaneP {
     double n0, n1, n2, d, norm, q;
 };
-
-// k-th smallest (0-based) pp among the members: radix descent 11 + 11 + 10 bits
-__device__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n, unsigned k,
-                           unsigned *hist /* 2048 */, unsigned *wsum /* 4 */, unsigned *sel /* 2 */) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned prefix = 0, mask = 0;
-    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
-    for (int ps = 0; ps < 3; ++ps) {
-        const int shift = shifts[ps];
-        const unsigned nb = 1u << bitsv[ps];
-        for (unsigned b = tid; b < 2048u; b += CS_THREADS) hist[b] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += CS_THREADS) {
-            const unsigned key = cs_key(pp[mem[i]]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1u)], 1u);
-        }
-        __syncthreads();
-        // 8 bins per thread
-        unsigned v[8], s = 0;
-        for (int j = 0; j < 8; ++j) {
-            v[j] = hist[8 * tid + j];
-            s += v[j];
-        }
-        unsigned inc = s;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u = __shfl_up(inc, o);
-            if (lane >= o) inc += u;
-        }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        unsigned base = 0;
-        for (int q = 0; q < w; ++q) base += wsum[q];
-        unsigned run = base + inc - s;
-        for (int j = 0; j < 8; ++j) {
-            if (k >= run && k < run + v[j]) {
-                sel[0] = 8 * tid + j;
-                sel[1] = k - run;
-            }
-            run += v[j];
-        }
-        __syncthreads();
-        prefix |= sel[0] << shift;
-        mask |= (nb - 1u) << shift;
-        k = sel[1];
-        __syncthreads();
-    }
-    return cs_unkey(prefix);
-}
 
 // out[c*6 + {0:n, 1:dmin, 2:dmax, 3:a, 4:b, 5:gamma}]  (doubles)
 __global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__ pts, int stride,

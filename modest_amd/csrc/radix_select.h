@@ -1,0 +1,83 @@
+// Exact k-th smallest float32 of an indexed subset, one 256-thread workgroup per subset:
+// radix descent over the order-preserving key, 11 + 11 + 10 bits, LDS histograms.
+// Used for the order statistics numpy.percentile interpolates between
+// (clustering_utils.py:107-117 is_valid_cluster; combine_labels.py:41-60 filter_by_ppscore).
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int CS_THREADS = 256;
+
+__device__ __forceinline__ unsigned cs_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float cs_unkey(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// k-th smallest (0-based) pp among the members
+__device__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n, unsigned k,
+                           unsigned *hist /* 2048 */, unsigned *wsum /* 4 */, unsigned *sel /* 2 */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned prefix = 0, mask = 0;
+    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
+    for (int ps = 0; ps < 3; ++ps) {
+        const int shift = shifts[ps];
+        const unsigned nb = 1u << bitsv[ps];
+        for (unsigned b = tid; b < 2048u; b += CS_THREADS) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += CS_THREADS) {
+            const unsigned key = cs_key(pp[mem[i]]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1u)], 1u);
+        }
+        __syncthreads();
+        // 8 bins per thread
+        unsigned v[8], s = 0;
+        for (int j = 0; j < 8; ++j) {
+            v[j] = hist[8 * tid + j];
+            s += v[j];
+        }
+        unsigned inc = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (int q = 0; q < w; ++q) base += wsum[q];
+        unsigned run = base + inc - s;
+        for (int j = 0; j < 8; ++j) {
+            if (k >= run && k < run + v[j]) {
+                sel[0] = 8 * tid + j;
+                sel[1] = k - run;
+            }
+            run += v[j];
+        }
+        __syncthreads();
+        prefix |= sel[0] << shift;
+        mask |= (nb - 1u) << shift;
+        k = sel[1];
+        __syncthreads();
+    }
+    return cs_unkey(prefix);
+}
+
+// numpy.percentile(x, q) ('linear') on float32 data of size n works in float32: virtual index
+// (n-1)*q, neighbours floor / floor+1, both clamped to the last element.  Returns the two
+// neighbour ranks and the interpolation weight.
+__device__ __forceinline__ void cs_percentile_ranks(int n, float qf, int *prev, int *next, float *gamma) {
+    const float vi = (float)(n - 1) * qf;
+    const float fl = floorf(vi);
+    int p = (int)fl, nx = p + 1;
+    if (vi >= (float)(n - 1)) p = nx = n - 1;
+    if (vi < 0.f) p = nx = 0;
+    *prev = p;
+    *next = min(nx, n - 1);
+    *gamma = vi - fl;
+}
+
+}  // namespace

@@ -253,6 +253,25 @@ def cluster_stats(pts: torch.Tensor, pp: torch.Tensor, labels: torch.Tensor, n_c
     return out
 
 
+def boxes_pp_stats(rect_xyz: torch.Tensor, pp: torch.Tensor, boxes12: np.ndarray, quantile: float,
+                   ctx: Optional[Context] = None) -> np.ndarray:
+    """filter_by_ppscore statistics (combine_labels.py:41-60): per box (points inside, a, b, gamma);
+    (K,4) float64 host.  boxes12 = the twelve float64 scalars of include/modest_hip.h."""
+    lib = load()
+    _dev(rect_xyz, torch.float64, "rect_xyz")
+    _dev(pp, torch.float32, "pp")
+    assert rect_xyz.ndim == 2 and rect_xyz.shape[1] == 3 and pp.shape[0] == rect_xyz.shape[0]
+    boxes12 = np.ascontiguousarray(boxes12, dtype=np.float64).reshape(-1, 12)
+    out = np.zeros((boxes12.shape[0], 4), dtype=np.float64)
+    if boxes12.shape[0] == 0:
+        return out
+    c = _ctx(ctx, rect_xyz)
+    check(lib.modest_boxes_pp_stats(c.handle, rect_xyz.data_ptr(), rect_xyz.shape[0], pp.data_ptr(),
+                                    _np_ptr(boxes12), boxes12.shape[0], float(quantile), _np_ptr(out),
+                                    _stream()), "modest_boxes_pp_stats")
+    return out
+
+
 # --------------------------------------------------------------------------- box fitting
 def fit_boxes_closeness(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np.ndarray, d0: float = 1e-2,
                         return_beta: bool = False, ctx: Optional[Context] = None):
