@@ -166,6 +166,24 @@ int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz_dev,
                           int32_t *labels_dev, double *kth_d2_dev,
                           int32_t *n_clusters_host, void *stream);
 
+/* Non-default graph / weight branches of precompute_affinity_matrix (SURVEY §8f-3;
+ * utils/clustering_utils.py:16-56), same DBSCAN semantics as above:
+ *   neighbor_type  RADIUS_MUTUAL_KNN (configs default) | RADIUS (edge <=> d2 <= radius^2)
+ *   affinity_type  L1 |pp_i - pp_j| (default) | EXP exp((pp_i - pp_j)^2) | L2_4D the reference's
+ *                  '3d_l2_distance': float32 norm of the difference of the (n,4) scan rows,
+ *                  i.e. xyz AND intensity (intensity_dev (n) float32 required)
+ * knn / sym_knn / mutual_knn need a k-NN search without a radius bound and return an error.  */
+#define MODEST_GRAPH_RADIUS_MUTUAL_KNN 0
+#define MODEST_GRAPH_RADIUS 1
+#define MODEST_AFFINITY_L1 0
+#define MODEST_AFFINITY_EXP 1
+#define MODEST_AFFINITY_L2_4D 2
+int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz_dev, const float *pp_dev,
+                             const float *intensity_dev, int n, int neighbor_type,
+                             int affinity_type, int k_neighbors, double radius, double eps,
+                             int min_samples, int32_t *labels_dev, double *kth_d2_dev,
+                             int32_t *n_clusters_host, void *stream);
+
 /* ---- a14 filter_labels / is_valid_cluster statistics ------------------
  * (utils/clustering_utils.py:94-135).  For each label c in [0, n_clusters):
  * out[c*6 + {0: member count, 1: min, 2: max signed distance to `plane`

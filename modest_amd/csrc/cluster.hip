@@ -223,21 +223,42 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
     if (lane == 0) kthS[s] = result;
 }
 
-__device__ __forceinline__ bool edge_ok(const float4 &q, double kq, const float4 &c, double kc, double r2,
-                                        double eps) {
+// Graph / weight variants of precompute_affinity_matrix (utils/clustering_utils.py:16-56):
+//   use_knn = 1: radius_mutual_knn (default)   edge <=> d2 <= min(r2_k(i), r2_k(j), radius^2)
+//   use_knn = 0: radius                         edge <=> d2 <= radius^2
+//   affinity 0 'l1'             |pp_i - pp_j|                          (float32, as numpy)
+//            1 'exp'            exp((pp_i - pp_j)^2)                   (float32 square, float32 exp)
+//            2 '3d_l2_distance' norm of the 4-column row difference    (float32: ((dx2+dy2)+dz2)+di2, sqrt)
+//                               -- the reference passes the (n,4) scan rows, so intensity takes part
+struct EdgeP {
+    double r2, eps;
+    int use_knn, affinity;
+    const float *inten;   // intensity in sorted order (affinity 2 only)
+};
+
+__device__ __forceinline__ bool edge_ok(const float4 &q, double kq, const float4 &c, double kc, const EdgeP &ep,
+                                        int s, unsigned j) {
     const double d2 = dist2(q, c);
-    const double lim = fmin(fmin(kq, kc), r2);
+    const double lim = ep.use_knn ? fmin(fmin(kq, kc), ep.r2) : ep.r2;
     if (!(d2 <= lim)) return false;
-    const float w = fabsf(q.w - c.w);
-    return (double)w <= eps;
+    float w;
+    if (ep.affinity == 0) {
+        w = fabsf(q.w - c.w);
+    } else if (ep.affinity == 1) {
+        const float d = q.w - c.w;
+        w = (float)exp((double)(d * d));   // float32 exp evaluated in float64 and rounded once
+    } else {
+        const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z, di = ep.inten[s] - ep.inten[j];
+        w = sqrtf(((dx * dx + dy * dy) + dz * dz) + di * di);
+    }
+    return (double)w <= ep.eps;
 }
 
 // ---- pass B: degrees / core flags ------------------------------------------------
 __global__ __launch_bounds__(64 * WPB) void degree_kernel(const float4 *__restrict__ sorted, int n,
                                                           const CGrid *g,
                                                           const unsigned *__restrict__ start,
-                                                          const double *__restrict__ kthS, double r2,
-                                                          double eps, int min_samples,
+                                                          const double *__restrict__ kthS, EdgeP ep, int min_samples,
                                                           unsigned char *__restrict__ coreS) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(64 * WPB) void degree_kernel(const float4 *__restri
     for (int r = 0; r < R.n; ++r)
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j == s) continue;
-            if (edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) ++cnt;
+            if (edge_ok(q, kq, sorted[j], kthS[j], ep, s, j)) ++cnt;
         }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (lane == 0) coreS[s] = ((int)cnt + 1 >= min_samples) ? 1 : 0;
@@ -299,8 +320,7 @@ __global__ __launch_bounds__(64 * WPB) void hook_min_kernel(const float4 *__rest
                                                             const unsigned *__restrict__ start,
                                                             const double *__restrict__ kthS,
                                                             const unsigned char *__restrict__ coreS,
-                                                            const int *__restrict__ sidx, double r2,
-                                                            double eps, int *parent) {
+                                                            const int *__restrict__ sidx, EdgeP ep, int *parent) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(64 * WPB) void hook_min_kernel(const float4 *__rest
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j == s || !coreS[j]) continue;
             const int other = sidx[j];
-            if (other < best && edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) best = other;
+            if (other < best && edge_ok(q, kq, sorted[j], kthS[j], ep, s, j)) best = other;
         }
     for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
     if (lane == 0) parent[me] = best;
@@ -325,8 +345,7 @@ __global__ __launch_bounds__(64 * WPB) void union_kernel(const float4 *__restric
                                                          const unsigned *__restrict__ start,
                                                          const double *__restrict__ kthS,
                                                          const unsigned char *__restrict__ coreS,
-                                                         const int *__restrict__ sidx, double r2,
-                                                         double eps, int *parent) {
+                                                         const int *__restrict__ sidx, EdgeP ep, int *parent) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(64 * WPB) void union_kernel(const float4 *__restric
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j <= s) continue;          // each unordered pair once
             if (!coreS[j]) continue;
-            if (edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) uf_unite(parent, me, sidx[j]);
+            if (edge_ok(q, kq, sorted[j], kthS[j], ep, s, j)) uf_unite(parent, me, sidx[j]);
         }
 }
 
@@ -361,8 +380,7 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
                                                          const unsigned char *__restrict__ coreS,
                                                          const int *__restrict__ sidx,
                                                          const int *__restrict__ root,
-                                                         const unsigned *__restrict__ rank, double r2,
-                                                         double eps, int *__restrict__ labels) {
+                                                         const unsigned *__restrict__ rank, EdgeP ep, int *__restrict__ labels) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
     for (int r = 0; r < R.n; ++r)
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j == s || !coreS[j]) continue;
-            if (edge_ok(q, kq, sorted[j], kthS[j], r2, eps)) best = min(best, root[sidx[j]]);
+            if (edge_ok(q, kq, sorted[j], kthS[j], ep, s, j)) best = min(best, root[sidx[j]]);
         }
     for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
     if (lane == 0) labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
@@ -395,8 +413,7 @@ constexpr int ADJ = 128;
 __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__restrict__ sorted, int n,
                                                               const CGrid *g,
                                                               const unsigned *__restrict__ start,
-                                                              const double *__restrict__ kthS, double r2,
-                                                              double eps, int min_samples,
+                                                              const double *__restrict__ kthS, EdgeP ep, int min_samples,
                                                               unsigned char *__restrict__ coreS,
                                                               int *__restrict__ deg, int *__restrict__ adj,
                                                               int *overflow) {
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
     for (int r = 0; r < R.n; ++r)
         for (unsigned base = R.s[r]; base < R.e[r]; base += 64) {   // wave-uniform trip count
             const unsigned j = base + lane;
-            const bool e = j < R.e[r] && (int)j != s && edge_ok(q, kq, sorted[j], kthS[j], r2, eps);
+            const bool e = j < R.e[r] && (int)j != s && edge_ok(q, kq, sorted[j], kthS[j], ep, s, j);
             const unsigned long long bal = __ballot(e);
             const unsigned pos = total + __popcll(bal & ((1ULL << lane) - 1ULL));
             if (e && pos < (unsigned)ADJ) adj[(size_t)s * ADJ + pos] = (int)j;
@@ -495,13 +512,28 @@ __global__ void scatter_kth(const double *__restrict__ kthS, const int *__restri
 
 }  // namespace
 
-extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const float *pp, int n,
-                                     int k_neighbors, double radius, double eps, int min_samples,
-                                     int32_t *labels, double *kth_d2, int32_t *n_clusters,
-                                     void *stream_) {
+namespace {
+__global__ void gather_f32(const float *__restrict__ src, const int *__restrict__ sidx, int n,
+                           float *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[sidx[i]];
+}
+}  // namespace
+
+extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const float *pp,
+                                        const float *intensity, int n, int neighbor_type, int affinity_type,
+                                        int k_neighbors, double radius, double eps, int min_samples,
+                                        int32_t *labels, double *kth_d2, int32_t *n_clusters,
+                                        void *stream_) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n >= 0, "n < 0");
     MODEST_REQUIRE(k_neighbors >= 1 && radius > 0.0 && min_samples >= 1, "bad parameters");
+    MODEST_REQUIRE(neighbor_type == MODEST_GRAPH_RADIUS_MUTUAL_KNN || neighbor_type == MODEST_GRAPH_RADIUS,
+                   "neighbor_type: only radius_mutual_knn and radius are built");
+    MODEST_REQUIRE(affinity_type >= MODEST_AFFINITY_L1 && affinity_type <= MODEST_AFFINITY_L2_4D,
+                   "affinity_type must be l1, exp or 3d_l2_distance");
+    MODEST_REQUIRE(affinity_type != MODEST_AFFINITY_L2_4D || intensity != nullptr || n == 0,
+                   "3d_l2_distance needs the intensity column (the reference takes the norm of the (n,4) rows)");
     if (n_clusters) *n_clusters = 0;
     if (n == 0) return MODEST_OK;
     MODEST_REQUIRE(xyz && pp && labels, "NULL buffer");
@@ -512,7 +544,7 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     size_t need = arena_sz(sizeof(CGrid)) + arena_sz(zero_words * 4) + arena_sz((CG_CELLS + 1) * 4) +
                   arena_sz((size_t)n * 16) + arena_sz((size_t)n * 4) + arena_sz((size_t)n * 8) +
                   arena_sz((size_t)n) + arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4) +
-                  arena_sz((size_t)n * 4) + arena_sz((size_t)n * ADJ * 4);
+                  arena_sz((size_t)n * 4) + arena_sz((size_t)n * ADJ * 4) + arena_sz((size_t)n * 4);
     int rc = modest_ctx_reserve(ctx, need);
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 64);
@@ -532,6 +564,7 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     unsigned *rank = A.take<unsigned>(n + 1);
     int *deg = A.take<int>(n);
     int *adj = A.take<int>((size_t)n * ADJ);
+    float *sortedI = A.take<float>(n);
     int *overflow = reinterpret_cast<int *>(zeroed + 2 * CG_CELLS);
 
     const double c = radius * (1.0 + 1.0 / 1024.0);
@@ -542,8 +575,16 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     cg_count<<<nb, 256, 0, stream>>>(xyz, n, g, cnt);
     scan_u32<<<1, 1024, 0, stream>>>(cnt, start, CG_CELLS);
     cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, start, fill, sorted, sidx);
-    knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
-    degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS, deg, adj,
+    EdgeP ep;
+    ep.r2 = r2;
+    ep.eps = eps;
+    ep.use_knn = neighbor_type == MODEST_GRAPH_RADIUS_MUTUAL_KNN;
+    ep.affinity = affinity_type;
+    ep.inten = sortedI;
+    if (affinity_type == MODEST_AFFINITY_L2_4D) gather_f32<<<nb, 256, 0, stream>>>(intensity, sidx, n, sortedI);
+    if (ep.use_knn || kth_d2)
+        knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
+    degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
                                                   overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
     for (int round = 0; round < 3; ++round) {   // accelerators only: union_adj_kernel makes the result exact
@@ -560,13 +601,13 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
         MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         if (*reinterpret_cast<int *>(ctx->pinned + 8)) {
-            degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, r2, eps, min_samples, coreS);
+            degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS);
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
-            hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
-            union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, r2, eps, parent);
+            hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
+            union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
             scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
-            label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, r2, eps,
+            label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, ep,
                                                      labels);
             MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -576,4 +617,12 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
     if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
+}
+
+extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const float *pp, int n,
+                                     int k_neighbors, double radius, double eps, int min_samples,
+                                     int32_t *labels, double *kth_d2, int32_t *n_clusters,
+                                     void *stream_) {
+    return modest_cluster_dbscan_ex(ctx, xyz, pp, nullptr, n, MODEST_GRAPH_RADIUS_MUTUAL_KNN, MODEST_AFFINITY_L1,
+                                    k_neighbors, radius, eps, min_samples, labels, kth_d2, n_clusters, stream_);
 }

@@ -55,16 +55,19 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     if args.clustering.method != "DBSCAN":
         raise NotImplementedError(args.clustering.method)
     g = args.graph
-    if (g.neighbor_type, g.affinity_type) != ("radius_mutual_knn", "l1"):
+    if g.neighbor_type not in ops.GRAPH_TYPES or g.affinity_type not in ops.AFFINITY_TYPES:
         raise NotImplementedError(f"graph {g.neighbor_type}/{g.affinity_type} (SURVEY.md §8f-3)")
     n_kept = int(kept_xyz.shape[0])
     if n_kept:
-        if n_kept <= g.n_neighbors:
+        if g.neighbor_type != "radius" and n_kept <= g.n_neighbors:
             raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {g.n_neighbors + 1}, "
                              f"n_samples_fit = {n_kept}, n_samples = {n_kept}")
         kept_long = kept_idx.long()
+        inten = ptc_dev[kept_long, 3].contiguous() if g.affinity_type == "3d_l2_distance" else None
         lab_kept, _ = ops.cluster_dbscan(kept_xyz, pp_dev[kept_long].contiguous(), g.n_neighbors, g.radius,
-                                         args.clustering.DBSCAN.eps, args.clustering.DBSCAN.min_samples)
+                                         args.clustering.DBSCAN.eps, args.clustering.DBSCAN.min_samples,
+                                         neighbor_type=g.neighbor_type, affinity_type=g.affinity_type,
+                                         intensity=inten)
         labels_dev[kept_long] = lab_kept          # device copy for the cluster statistics (plumbing)
         labels[kept_idx.cpu().numpy()] = lab_kept.cpu().numpy()
     labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,

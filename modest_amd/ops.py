@@ -215,23 +215,42 @@ def plane_range_mask(pts: torch.Tensor, plane: np.ndarray, offset: float, only_r
 
 
 # --------------------------------------------------------------------------- clustering
+GRAPH_TYPES = {"radius_mutual_knn": 0, "radius": 1}
+AFFINITY_TYPES = {"l1": 0, "exp": 1, "3d_l2_distance": 2}
+
+
 def cluster_dbscan(xyz: torch.Tensor, pp: torch.Tensor, n_neighbors: int = 70, radius: float = 2.0,
                    eps: float = 0.1, min_samples: int = 10, return_kth: bool = False,
-                   ctx: Optional[Context] = None):
-    """radius_mutual_knn / l1 affinity graph + DBSCAN(precomputed) labels, (n,) int32 on device."""
+                   ctx: Optional[Context] = None, neighbor_type: str = "radius_mutual_knn",
+                   affinity_type: str = "l1", intensity: Optional[torch.Tensor] = None):
+    """Affinity graph (precompute_affinity_matrix, clustering_utils.py:7-60) + DBSCAN(precomputed)
+    labels, (n,) int32 on device.  neighbor_type radius_mutual_knn | radius; affinity_type l1 | exp |
+    3d_l2_distance (the latter needs the scan's intensity column, see include/modest_hip.h)."""
     lib = load()
     _dev(xyz, torch.float32, "xyz")
     _dev(pp, torch.float32, "pp")
+    if neighbor_type not in GRAPH_TYPES:
+        raise NotImplementedError(f"neighbor_type {neighbor_type!r}: knn / sym_knn / mutual_knn need a k-NN search "
+                                  "without a radius bound (SURVEY.md §8f-3)")
+    if affinity_type not in AFFINITY_TYPES:
+        raise NotImplementedError(affinity_type)
     n = xyz.shape[0]
     assert pp.shape[0] == n
+    if affinity_type == "3d_l2_distance":
+        if intensity is None:
+            raise ValueError("3d_l2_distance needs the intensity column of the scan rows")
+        _dev(intensity, torch.float32, "intensity")
+        assert intensity.shape[0] == n
     labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
     kth = torch.empty((n,), dtype=torch.float64, device=xyz.device) if return_kth else None
     ncl = C.c_int32(0)
     c = _ctx(ctx, xyz)
-    check(lib.modest_cluster_dbscan(c.handle, xyz.data_ptr(), pp.data_ptr(), n, int(n_neighbors), float(radius),
-                                    float(eps), int(min_samples), labels.data_ptr(),
-                                    kth.data_ptr() if kth is not None else None, C.byref(ncl), _stream()),
-          "modest_cluster_dbscan")
+    check(lib.modest_cluster_dbscan_ex(c.handle, xyz.data_ptr(), pp.data_ptr(),
+                                       intensity.data_ptr() if intensity is not None else None, n,
+                                       GRAPH_TYPES[neighbor_type], AFFINITY_TYPES[affinity_type], int(n_neighbors),
+                                       float(radius), float(eps), int(min_samples), labels.data_ptr(),
+                                       kth.data_ptr() if kth is not None else None, C.byref(ncl), _stream()),
+          "modest_cluster_dbscan_ex")
     return (labels, int(ncl.value), kth) if return_kth else (labels, int(ncl.value))
 
 

@@ -14,25 +14,25 @@ import torch
 from .. import ops
 from .pointcloud_utils import distance_to_plane, estimate_plane, to_device
 
-_DEFAULT_GRAPH = ("radius_mutual_knn", "l1")
-
 
 def cluster_points(ptc, pp_score, neighbor_type="radius_mutual_knn", affinity_type="l1", n_neighbors=70,
                    radius=2., eps=0.1, min_samples=10):
     """precompute_affinity_matrix(...) + DBSCAN(metric='precomputed', eps, min_samples).labels_
     in one call -> (n,) int64 numpy labels (-1 = noise)."""
-    if (neighbor_type, affinity_type) != _DEFAULT_GRAPH:
-        raise NotImplementedError(f"graph {neighbor_type}/{affinity_type}: only the configs/generate_mask.yaml "
-                                  "default radius_mutual_knn/l1 is built (SURVEY.md §8f-3)")
-    xyz = to_device(ptc)[:, :3].contiguous()
+    dev = to_device(ptc)
+    xyz = dev[:, :3].contiguous()
     pp = to_device(pp_score)
     assert xyz.shape[0] == pp.shape[0]
     n = xyz.shape[0]
-    if n and n <= n_neighbors:
+    inten = None
+    if affinity_type == "3d_l2_distance":   # the reference takes the norm of the full rows it is given
+        inten = dev[:, 3].contiguous() if dev.shape[1] > 3 else torch.zeros((n,), dtype=torch.float32, device=dev.device)
+    if neighbor_type != "radius" and n and n <= n_neighbors:
         # sklearn raises here as well (kneighbors with n_neighbors > n_samples)
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {n_neighbors + 1}, "
                          f"n_samples_fit = {n}, n_samples = {n}")
-    labels, _ = ops.cluster_dbscan(xyz, pp, n_neighbors, radius, eps, min_samples)
+    labels, _ = ops.cluster_dbscan(xyz, pp, n_neighbors, radius, eps, min_samples, neighbor_type=neighbor_type,
+                                   affinity_type=affinity_type, intensity=inten)
     return labels.cpu().numpy().astype(np.int64)
 
 

@@ -81,19 +81,45 @@ def estimate_plane(origin_ptc, max_hs=-1.5, ptc_range=((-20, 70), (-20, 20)), ra
 
 
 # ----------------------------------------------------------------------------- graph + DBSCAN
-def precompute_affinity_matrix(ptc, pp_score, n_neighbors=70, radius=2.0, n_jobs=-1):
-    """utils/clustering_utils.py:7-60, neighbor_type='radius_mutual_knn',
-    affinity_type='l1' (the defaults of configs/generate_mask.yaml:20-25)."""
+def precompute_affinity_matrix(ptc, pp_score, n_neighbors=70, radius=2.0, n_jobs=-1,
+                               neighbor_type="radius_mutual_knn", affinity_type="l1"):
+    """utils/clustering_utils.py:7-60; defaults = configs/generate_mask.yaml:20-25
+    (neighbor_type='radius_mutual_knn', affinity_type='l1').  All branches of the reference are
+    restated (the product builds radius_mutual_knn and radius with the three affinities)."""
     assert ptc.shape[0] == pp_score.shape[0]
-    graph = neighbors.kneighbors_graph(ptc[:, :3], n_neighbors=n_neighbors, n_jobs=n_jobs)
-    graph = graph.multiply(graph.T)
-    graph = graph.multiply(neighbors.radius_neighbors_graph(ptc[:, :3], radius=radius, n_jobs=n_jobs))
-    graph.eliminate_zeros()
+    if neighbor_type == "knn":                                                      # :16-18
+        graph = neighbors.kneighbors_graph(ptc[:, :3], n_neighbors=n_neighbors, n_jobs=n_jobs)
+    elif neighbor_type == "sym_knn":                                                # :19-23
+        graph = neighbors.kneighbors_graph(ptc[:, :3], n_neighbors=n_neighbors, n_jobs=n_jobs)
+        graph = graph + graph.T
+        graph.eliminate_zeros()
+    elif neighbor_type == "mutual_knn":                                             # :24-28
+        graph = neighbors.kneighbors_graph(ptc[:, :3], n_neighbors=n_neighbors, n_jobs=n_jobs)
+        graph = graph.multiply(graph.T)
+        graph.eliminate_zeros()
+    elif neighbor_type == "radius":                                                 # :29-31
+        graph = neighbors.radius_neighbors_graph(ptc[:, :3], radius=radius, n_jobs=n_jobs)
+    elif neighbor_type == "radius_mutual_knn":                                      # :32-38
+        graph = neighbors.kneighbors_graph(ptc[:, :3], n_neighbors=n_neighbors, n_jobs=n_jobs)
+        graph = graph.multiply(graph.T)
+        graph = graph.multiply(neighbors.radius_neighbors_graph(ptc[:, :3], radius=radius, n_jobs=n_jobs))
+        graph.eliminate_zeros()
+    else:
+        raise NotImplementedError(neighbor_type)
+    graph = scipy.sparse.csr_matrix(graph)
     dist_data = graph.data.copy()
-    # the reference fills row by row (:43-48); the vectorised form below performs the
-    # same float32 subtraction/abs per stored entry and the same cast to float64
+    # the reference fills row by row (:43-56); the vectorised forms below perform the same
+    # float32 operations per stored entry and the same cast to float64
     rows = np.repeat(np.arange(graph.shape[0]), np.diff(graph.indptr))
-    dist_data[:] = np.abs(pp_score[rows] - pp_score[graph.indices])
+    if affinity_type == "l1":
+        dist_data[:] = np.abs(pp_score[rows] - pp_score[graph.indices])
+    elif affinity_type == "exp":
+        dist_data[:] = np.exp((pp_score[rows] - pp_score[graph.indices]) ** 2)
+    elif affinity_type == "3d_l2_distance":
+        # np.linalg.norm(ptc[_r].reshape(1, -1) - ptc[idx], axis=1): ALL columns of the rows passed in
+        dist_data[:] = np.linalg.norm(ptc[rows] - ptc[graph.indices], axis=1)
+    else:
+        raise NotImplementedError(affinity_type)
     return scipy.sparse.csr_matrix((dist_data, graph.indices, graph.indptr), shape=graph.shape)
 
 

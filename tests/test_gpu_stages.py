@@ -217,3 +217,32 @@ def test_bev_iou_and_nms(gpu, golden_dir):
         assert np.array_equal(np.sort(keep.cpu().numpy()), np.sort(ref))
     iou3d = iu.boxes_iou3d_gpu(b, b).cpu().numpy()
     assert np.all(np.abs(np.diag(iou3d) - 1) < 1e-4)
+
+
+@pytest.mark.gpu
+def test_graph_variants_vs_reference_golden(gpu, golden_dir):
+    """radius / radius_mutual_knn graphs with l1, exp and 3d_l2_distance weights:
+    labels bit-exact vs the reference's precompute_affinity_matrix + sklearn DBSCAN."""
+    import os
+    import torch
+    from modest_amd import ops
+    from modest_amd.utils import clustering_utils as cu
+    g = np.load(os.path.join(golden_dir, "graph_variants.npz"))
+    kept, pp = g["kept"], g["pp"]
+    for k, v in enumerate(g["variants"]):
+        nt, at, radius, eps, ms = str(v).split("|")
+        lab = cu.cluster_points(kept, pp, neighbor_type=nt, affinity_type=at, n_neighbors=70, radius=float(radius),
+                                eps=float(eps), min_samples=int(ms))
+        assert np.array_equal(lab, g[f"labels{k}"]), v
+    with pytest.raises(NotImplementedError):
+        cu.cluster_points(kept, pp, neighbor_type="knn")
+    # larger random cloud against the oracle (sklearn): radius graph, l2 weights incl. intensity
+    from oracle import mask as om
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.standard_normal((6000, 3)) * [8, 8, 0.5], rng.uniform(0, 1, (6000, 1))], axis=1).astype(np.float32)
+    ppr = rng.uniform(0, 1, 6000).astype(np.float32)
+    for nt, at, eps in (("radius", "3d_l2_distance", 0.45), ("radius", "l1", 0.02), ("radius_mutual_knn", "exp", 1.0005)):
+        G = om.precompute_affinity_matrix(pts, ppr, n_neighbors=70, radius=1.0, neighbor_type=nt, affinity_type=at)
+        ref = om.dbscan_labels(G, eps=eps, min_samples=6)
+        lab = cu.cluster_points(pts, ppr, neighbor_type=nt, affinity_type=at, n_neighbors=70, radius=1.0, eps=eps, min_samples=6)
+        assert np.array_equal(lab, ref), (nt, at)

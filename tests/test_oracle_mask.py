@@ -115,3 +115,17 @@ def test_iou_oracle(golden_dir):
     keep = ol.nms(g["boxes"][order], 0.1)
     mask = ol.nms_from_iou(g["iou"][np.ix_(order, order)], 0.1, scores=-np.arange(len(order), dtype=float))
     assert list(keep) == list(np.nonzero(mask)[0])
+
+
+def test_graph_variants_match_reference_golden(golden_dir):
+    """Non-default neighbor_type / affinity_type branches: the oracle's restatement
+    of precompute_affinity_matrix + DBSCAN reproduces the labels the reference itself produced."""
+    import os
+    from oracle import mask as om
+    g = np.load(os.path.join(golden_dir, "graph_variants.npz"))
+    for k, v in enumerate(g["variants"]):
+        nt, at, radius, eps, ms = str(v).split("|")
+        G = om.precompute_affinity_matrix(g["kept"], g["pp"], n_neighbors=70, radius=float(radius),
+                                          neighbor_type=nt, affinity_type=at)
+        lab = om.dbscan_labels(G, eps=float(eps), min_samples=int(ms))
+        assert np.array_equal(lab, g[f"labels{k}"]), v
