@@ -5,8 +5,8 @@ import pickle
 import numpy as np
 
 
-def unpack_tree(golden_dir, dst):
-    g = np.load(os.path.join(golden_dir, "e2e_tree.npz"), allow_pickle=False)
+def unpack_tree(golden_dir, dst, name="e2e_tree.npz"):
+    g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
     train = os.path.join(dst, "data", "training")
     meta = os.path.join(dst, "meta")
     for d in ("velodyne", "oxts", "l2e", "calib"):
