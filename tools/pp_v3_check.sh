@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_pp.py -x -q -m gpu 2>&1 | tail -15
 echo "== V3"; timeout 300 python tools/pp_microbench.py 2>&1 | tail -3
-echo "== V2"; MODEST_PP_VARIANT=2 timeout 300 python tools/pp_microbench.py 2>&1 | tail -2
+echo "== V1 (direct path)"; MODEST_PP_VARIANT=1 timeout 300 python tools/pp_microbench.py 2>&1 | tail -2
 rm -rf gpurun_out/prof3
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof3 -o p -- python bench.py --steps 8 --warmup 2 --pp-only --cpu-scans 0 --streams 1 > gpurun_out/prof3.log 2>&1
 python - <<'PY'
