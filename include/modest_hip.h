@@ -172,9 +172,16 @@ int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz_dev,
  *   affinity_type  L1 |pp_i - pp_j| (default) | EXP exp((pp_i - pp_j)^2) | L2_4D the reference's
  *                  '3d_l2_distance': float32 norm of the difference of the (n,4) scan rows,
  *                  i.e. xyz AND intensity (intensity_dev (n) float32 required)
- * knn / sym_knn / mutual_knn need a k-NN search without a radius bound and return an error.  */
+ *   KNN (directed: the rows of kneighbors_graph), SYM_KNN (graph + graph.T), MUTUAL_KNN
+ *   (graph .* graph.T): exact k-th neighbour distances without a radius bound (the grid search
+ *   grows until the k-th distance is certified); `radius` only sizes the grid cells there.
+ *   For KNN sklearn's sequential DBSCAN on the directed graph is reproduced exactly:
+ *   label(v) = rank of the smallest-index core point that reaches v through core points.     */
 #define MODEST_GRAPH_RADIUS_MUTUAL_KNN 0
 #define MODEST_GRAPH_RADIUS 1
+#define MODEST_GRAPH_KNN 2
+#define MODEST_GRAPH_SYM_KNN 3
+#define MODEST_GRAPH_MUTUAL_KNN 4
 #define MODEST_AFFINITY_L1 0
 #define MODEST_AFFINITY_EXP 1
 #define MODEST_AFFINITY_L2_4D 2

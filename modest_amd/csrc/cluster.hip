@@ -236,11 +236,7 @@ struct EdgeP {
     const float *inten;   // intensity in sorted order (affinity 2 only)
 };
 
-__device__ __forceinline__ bool edge_ok(const float4 &q, double kq, const float4 &c, double kc, const EdgeP &ep,
-                                        int s, unsigned j) {
-    const double d2 = dist2(q, c);
-    const double lim = ep.use_knn ? fmin(fmin(kq, kc), ep.r2) : ep.r2;
-    if (!(d2 <= lim)) return false;
+__device__ __forceinline__ bool weight_ok(const float4 &q, const float4 &c, const EdgeP &ep, int s, unsigned j) {
     float w;
     if (ep.affinity == 0) {
         w = fabsf(q.w - c.w);
@@ -252,6 +248,14 @@ __device__ __forceinline__ bool edge_ok(const float4 &q, double kq, const float4
         w = sqrtf(((dx * dx + dy * dy) + dz * dz) + di * di);
     }
     return (double)w <= ep.eps;
+}
+
+__device__ __forceinline__ bool edge_ok(const float4 &q, double kq, const float4 &c, double kc, const EdgeP &ep,
+                                        int s, unsigned j) {
+    const double d2 = dist2(q, c);
+    const double lim = ep.use_knn ? fmin(fmin(kq, kc), ep.r2) : ep.r2;
+    if (!(d2 <= lim)) return false;
+    return weight_ok(q, c, ep, s, j);
 }
 
 // ---- pass B: degrees / core flags ------------------------------------------------
@@ -442,13 +446,13 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
 
 // one round of min-root hooking: the root of every core point is hung under the smallest root
 // found among its core neighbours (parents only decrease, so the forest stays acyclic)
-__global__ void hook_adj_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+__global__ void hook_adj_kernel(int n, int stride, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
                                 const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n || !coreS[s]) return;
     const int rme = parent[sidx[s]];
     int m = rme;
-    const int *row = adj + (size_t)s * ADJ;
+    const int *row = adj + (size_t)s * stride;
     for (int e = 0; e < deg[s]; ++e) {
         const int j = row[e];
         if (coreS[j]) m = min(m, parent[sidx[j]]);
@@ -470,12 +474,12 @@ __global__ void flatten_kernel(int *parent, int n) {
 
 // exact clean-up: unite whatever the hooking rounds left apart (pairs that already share a
 // parent are skipped with two plain loads)
-__global__ void union_adj_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+__global__ void union_adj_kernel(int n, int stride, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
                                  const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n || !coreS[s]) return;
     const int me = sidx[s];
-    const int *row = adj + (size_t)s * ADJ;
+    const int *row = adj + (size_t)s * stride;
     for (int e = 0; e < deg[s]; ++e) {
         const int j = row[e];
         if (j <= s || !coreS[j]) continue;
@@ -484,7 +488,7 @@ __global__ void union_adj_kernel(int n, const unsigned char *__restrict__ coreS,
     }
 }
 
-__global__ void label_adj_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+__global__ void label_adj_kernel(int n, int stride, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
                                  const int *__restrict__ adj, const int *__restrict__ sidx,
                                  const int *__restrict__ root, const unsigned *__restrict__ rank,
                                  int *__restrict__ labels) {
@@ -496,12 +500,200 @@ __global__ void label_adj_kernel(int n, const unsigned char *__restrict__ coreS,
         return;
     }
     int best = 0x7fffffff;
-    const int *row = adj + (size_t)s * ADJ;
+    const int *row = adj + (size_t)s * stride;
     for (int e = 0; e < deg[s]; ++e) {
         const int j = row[e];
         if (coreS[j]) best = min(best, root[sidx[j]]);
     }
     labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
+}
+
+// ---- k-NN graphs without a radius bound (neighbor_type knn / sym_knn / mutual_knn) ------------
+// The grid search grows a square of cells around the query: after all cells with Chebyshev
+// distance <= R have been scanned every unseen point is farther than R*c (its cell differs by at
+// least R+1 in x or y; clamped border cells only hold points that are farther still).
+
+// points in the (2R+1)^2 cells around (cx, cy), summed by the wavefront from the prefix table
+__device__ __forceinline__ unsigned square_count(const unsigned *__restrict__ start, int cx, int cy, int R, int lane) {
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, CG - 1);
+    const int y0 = max(cy - R, 0), y1 = min(cy + R, CG - 1);
+    unsigned c = 0;
+    for (int yy = y0 + lane; yy <= y1; yy += 64) c += start[yy * CG + x1 + 1] - start[yy * CG + x0];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    return c;
+}
+
+// k-th smallest squared distance (self excluded) among the points of the square: wave-level radix
+// select on the float64 bit pattern, 8 byte passes (same scheme as knn_kth_kernel)
+__device__ double square_kth(const float4 *__restrict__ sorted, const unsigned *__restrict__ start, const float4 &q,
+                             int s, int cx, int cy, int R, int k, unsigned *hist, int lane) {
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, CG - 1);
+    const int y0 = max(cy - R, 0), y1 = min(cy + R, CG - 1);
+    unsigned long long prefix = 0, mask = 0;
+    int kk = k - 1;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int b = lane; b < 256; b += 64) hist[b] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int yy = y0; yy <= y1; ++yy) {
+            const unsigned rs = start[yy * CG + x0], re = start[yy * CG + x1 + 1];
+            for (unsigned j = rs + lane; j < re; j += 64) {
+                if ((int)j == s) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(dist2(q, sorted[j]));
+                if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const unsigned mine = c0 + c1 + c2 + c3;
+        unsigned inc = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        const unsigned long long bal = __ballot(inc > (unsigned)kk);
+        const int owner = __ffsll((long long)bal) - 1;
+        const unsigned excl = __shfl(inc - mine, owner);
+        const unsigned o0 = __shfl(c0, owner), o1 = __shfl(c1, owner), o2 = __shfl(c2, owner);
+        int rem = kk - (int)excl, bin = 4 * owner;
+        if (rem >= (int)o0) {
+            rem -= o0;
+            ++bin;
+            if (rem >= (int)o1) {
+                rem -= o1;
+                ++bin;
+                if (rem >= (int)o2) {
+                    rem -= o2;
+                    ++bin;
+                }
+            }
+        }
+        kk = rem;
+        prefix |= (unsigned long long)bin << shift;
+        mask |= 255ULL << shift;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return __longlong_as_double((long long)prefix);
+}
+
+// exact squared distance to the k-th nearest OTHER point (the host guarantees n > k)
+__global__ __launch_bounds__(64 * WPB) void knn_kth_unbounded_kernel(const float4 *__restrict__ sorted, int n,
+                                                                     const CGrid *g,
+                                                                     const unsigned *__restrict__ start, int k,
+                                                                     double c, double *__restrict__ kthS) {
+    __shared__ unsigned hist_all[WPB][256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    const float4 q = sorted[s];
+    const int cx = cg_coord(q.x, g->ox, g->inv_c), cy = cg_coord(q.y, g->oy, g->inv_c);
+    int R = 1;
+    while (R < CG && square_count(start, cx, cy, R, lane) < (unsigned)k + 1u) R = min(2 * R, CG);
+    double kth = square_kth(sorted, start, q, s, cx, cy, R, k, hist_all[w], lane);
+    const double reach = ((double)R - 1e-6) * c;   // everything closer than this has been seen
+    if (R < CG && !(kth <= reach * reach)) {
+        const int R2 = min(CG, (int)ceil(sqrt(kth) / c + 1e-6));
+        kth = square_kth(sorted, start, q, s, cx, cy, R2, k, hist_all[w], lane);
+    }
+    if (lane == 0) kthS[s] = kth;
+}
+
+// out-neighbours of every point inside its own k-NN ball (d2 <= kth_i), weight <= eps;
+// mode 1 (mutual_knn) additionally requires d2 <= kth_j.  adj rows have `stride` slots.
+__global__ __launch_bounds__(64 * WPB) void adj_knn_kernel(const float4 *__restrict__ sorted, int n, const CGrid *g,
+                                                           const unsigned *__restrict__ start,
+                                                           const double *__restrict__ kthS, EdgeP ep, double c,
+                                                           int mutual, int stride, int *__restrict__ deg,
+                                                           int *__restrict__ adj, int *overflow) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= n) return;
+    const float4 q = sorted[s];
+    const double kq = kthS[s];
+    const int cx = cg_coord(q.x, g->ox, g->inv_c), cy = cg_coord(q.y, g->oy, g->inv_c);
+    const int R = min(CG, (int)ceil(sqrt(kq) / c + 1e-6));
+    const int x0 = max(cx - R, 0), x1 = min(cx + R, CG - 1);
+    unsigned total = 0;
+    for (int yy = max(cy - R, 0); yy <= min(cy + R, CG - 1); ++yy) {
+        const unsigned rs = start[yy * CG + x0], re = start[yy * CG + x1 + 1];
+        for (unsigned base = rs; base < re; base += 64) {   // wave-uniform trip count
+            const unsigned j = base + lane;
+            bool e = false;
+            if (j < re && (int)j != s) {
+                const float4 cj = sorted[j];
+                const double d2 = dist2(q, cj);
+                e = d2 <= kq && (!mutual || d2 <= kthS[j]) && weight_ok(q, cj, ep, s, j);
+            }
+            const unsigned long long bal = __ballot(e);
+            const unsigned pos = total + __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (e && pos < (unsigned)stride) adj[(size_t)s * stride + pos] = (int)j;
+            total += __popcll(bal);
+        }
+    }
+    if (lane == 0) {
+        deg[s] = (int)min(total, (unsigned)stride);
+        if (total > (unsigned)stride) atomicOr(overflow, 1);
+    }
+}
+
+// sym_knn: graph + graph.T -- append i to the row of every out-neighbour j that does not hold it yet
+// (i is in j's own k-NN ball iff d2 <= kth_j; the weight test is symmetric)
+__global__ void adj_symmetrize_kernel(const float4 *__restrict__ sorted, int n, const double *__restrict__ kthS,
+                                      int stride, const int *__restrict__ degOut, int *deg, int *adj,
+                                      int *overflow) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float4 q = sorted[s];
+    for (int e = 0; e < degOut[s]; ++e) {
+        const int j = adj[(size_t)s * stride + e];
+        if (dist2(q, sorted[j]) <= kthS[j]) continue;   // already an out-neighbour of j
+        const int pos = atomicAdd(&deg[j], 1);
+        if (pos < stride) adj[(size_t)j * stride + pos] = s;
+        else atomicOr(overflow, 1);
+    }
+}
+
+__global__ void core_from_deg_kernel(int n, const int *__restrict__ deg, int stride, int min_samples,
+                                     unsigned char *__restrict__ coreS, int *deg_clamped) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    coreS[s] = (deg[s] + 1 >= min_samples) ? 1 : 0;
+    deg_clamped[s] = min(deg[s], stride);
+}
+
+// Directed graph (neighbor_type knn).  sklearn's sequential DBSCAN labels a point with the first
+// cluster that reaches it; clusters are seeded in index order and expand along the rows (out-
+// neighbours) of core points only.  That is: label(v) = the smallest ORIGINAL index of a core point
+// that reaches v through core points -- a fixpoint of min-propagation along core out-edges
+// (a core point with a smaller index reaching the minimiser would reach v too).
+__global__ void dir_init_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ sidx,
+                                int *__restrict__ L) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) L[s] = coreS[s] ? sidx[s] : 0x7fffffff;
+}
+__global__ void dir_push_kernel(int n, int stride, const unsigned char *__restrict__ coreS,
+                                const int *__restrict__ deg, const int *__restrict__ adj, int *L, int *changed) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !coreS[s]) return;
+    const int mine = __hip_atomic_load(L + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ch = false;
+    for (int e = 0; e < deg[s]; ++e) {
+        const int j = adj[(size_t)s * stride + e];
+        if (atomicMin(L + j, mine) > mine) ch = true;
+    }
+    if (ch) *changed = 1;
+}
+__global__ void dir_roots_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ sidx,
+                                 const int *__restrict__ L, int *__restrict__ root, unsigned *__restrict__ isroot) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = sidx[s];
+    root[i] = L[s];
+    isroot[i] = (coreS[s] && L[s] == i) ? 1u : 0u;
+}
+__global__ void dir_label_kernel(int n, const int *__restrict__ root, const unsigned *__restrict__ rank,
+                                 int *__restrict__ labels) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) labels[i] = (root[i] == 0x7fffffff) ? -1 : (int)rank[root[i]];
 }
 
 __global__ void scatter_kth(const double *__restrict__ kthS, const int *__restrict__ sidx, int n,
@@ -528,8 +720,10 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n >= 0, "n < 0");
     MODEST_REQUIRE(k_neighbors >= 1 && radius > 0.0 && min_samples >= 1, "bad parameters");
-    MODEST_REQUIRE(neighbor_type == MODEST_GRAPH_RADIUS_MUTUAL_KNN || neighbor_type == MODEST_GRAPH_RADIUS,
-                   "neighbor_type: only radius_mutual_knn and radius are built");
+    MODEST_REQUIRE(neighbor_type >= MODEST_GRAPH_RADIUS_MUTUAL_KNN && neighbor_type <= MODEST_GRAPH_MUTUAL_KNN,
+                   "neighbor_type out of range");
+    const bool unbounded = neighbor_type >= MODEST_GRAPH_KNN;
+    MODEST_REQUIRE(!unbounded || n == 0 || n > k_neighbors, "k-NN graph: n_neighbors must be < n (sklearn raises too)");
     MODEST_REQUIRE(affinity_type >= MODEST_AFFINITY_L1 && affinity_type <= MODEST_AFFINITY_L2_4D,
                    "affinity_type must be l1, exp or 3d_l2_distance");
     MODEST_REQUIRE(affinity_type != MODEST_AFFINITY_L2_4D || intensity != nullptr || n == 0,
@@ -540,11 +734,13 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
 
-    const size_t zero_words = (size_t)2 * CG_CELLS + 4;   // cell counters, fill counters, overflow flag
+    const int ustride = k_neighbors + (neighbor_type == MODEST_GRAPH_SYM_KNN ? 3 * k_neighbors : 0) + 8;   // k-NN graph rows
+    const size_t zero_words = (size_t)2 * CG_CELLS + 4;   // cell counters, fill counters, overflow flag, changed flag
     size_t need = arena_sz(sizeof(CGrid)) + arena_sz(zero_words * 4) + arena_sz((CG_CELLS + 1) * 4) +
                   arena_sz((size_t)n * 16) + arena_sz((size_t)n * 4) + arena_sz((size_t)n * 8) +
                   arena_sz((size_t)n) + arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4) +
-                  arena_sz((size_t)n * 4) + arena_sz((size_t)n * ADJ * 4) + arena_sz((size_t)n * 4);
+                  arena_sz((size_t)n * 4) + arena_sz((size_t)n * (unbounded ? (ustride > ADJ ? ustride : ADJ) : ADJ) * 4) +
+                  arena_sz((size_t)n * 4) * 3;
     int rc = modest_ctx_reserve(ctx, need);
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 64);
@@ -563,8 +759,10 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     unsigned *isroot = A.take<unsigned>(n);
     unsigned *rank = A.take<unsigned>(n + 1);
     int *deg = A.take<int>(n);
-    int *adj = A.take<int>((size_t)n * ADJ);
+    int *adj = A.take<int>((size_t)n * (unbounded ? (ustride > ADJ ? ustride : ADJ) : ADJ));
     float *sortedI = A.take<float>(n);
+    int *degOut = A.take<int>(n);
+    int *Lmin = A.take<int>(n);
     int *overflow = reinterpret_cast<int *>(zeroed + 2 * CG_CELLS);
 
     const double c = radius * (1.0 + 1.0 / 1024.0);
@@ -582,19 +780,66 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     ep.affinity = affinity_type;
     ep.inten = sortedI;
     if (affinity_type == MODEST_AFFINITY_L2_4D) gather_f32<<<nb, 256, 0, stream>>>(intensity, sidx, n, sortedI);
+    if (unbounded) {
+        // ---- knn / sym_knn / mutual_knn: exact k-th neighbour distance without a radius bound ----
+        int *changed = overflow + 1;
+        knn_kth_unbounded_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, c, kthS);
+        adj_knn_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, c,
+                                                   neighbor_type == MODEST_GRAPH_MUTUAL_KNN, ustride, degOut, adj,
+                                                   overflow);
+        MODEST_HIP_CHECK(hipMemcpyAsync(deg, degOut, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+        if (neighbor_type == MODEST_GRAPH_SYM_KNN)
+            adj_symmetrize_kernel<<<nb, 256, 0, stream>>>(sorted, n, kthS, ustride, degOut, deg, adj, overflow);
+        core_from_deg_kernel<<<nb, 256, 0, stream>>>(n, deg, ustride, min_samples, coreS, deg);
+        if (neighbor_type == MODEST_GRAPH_KNN) {
+            dir_init_kernel<<<nb, 256, 0, stream>>>(n, coreS, sidx, Lmin);
+            for (int it = 0; it < 4096; ++it) {   // a propagation step per launch, convergence checked every 8
+                dir_push_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, Lmin, changed);
+                if (it % 8 == 7) {
+                    MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 16, changed, 4, hipMemcpyDeviceToHost, stream));
+                    MODEST_HIP_CHECK(hipMemsetAsync(changed, 0, 4, stream));
+                    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+                    if (!*reinterpret_cast<int *>(ctx->pinned + 16)) break;
+                }
+            }
+            dir_roots_kernel<<<nb, 256, 0, stream>>>(n, coreS, sidx, Lmin, root, isroot);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
+            dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels);
+        } else {
+            uf_init<<<nb, 256, 0, stream>>>(parent, n);
+            for (int round = 0; round < 3; ++round) {
+                hook_adj_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
+                flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
+            }
+            union_adj_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
+            compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
+            label_adj_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, root, rank, labels);
+        }
+        MODEST_HIP_CHECK(hipGetLastError());
+        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 8, overflow, 4, hipMemcpyDeviceToHost, stream));
+        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        MODEST_REQUIRE(!*reinterpret_cast<int *>(ctx->pinned + 8),
+                       "k-NN graph: a row exceeded its capacity (massively tied k-th distances or a hub point)");
+        if (n_clusters) *n_clusters = (int32_t) * reinterpret_cast<unsigned *>(ctx->pinned);
+        if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
+        MODEST_HIP_CHECK(hipGetLastError());
+        return MODEST_OK;
+    }
     if (ep.use_knn || kth_d2)
         knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
     degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
                                                   overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
     for (int round = 0; round < 3; ++round) {   // accelerators only: union_adj_kernel makes the result exact
-        hook_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
+        hook_adj_kernel<<<nb, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
         flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
     }
-    union_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
+    union_adj_kernel<<<nb, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
     compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
     scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
-    label_adj_kernel<<<nb, 256, 0, stream>>>(n, coreS, deg, adj, sidx, root, rank, labels);
+    label_adj_kernel<<<nb, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels);
     MODEST_HIP_CHECK(hipGetLastError());
     {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
         MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 8, overflow, 4, hipMemcpyDeviceToHost, stream));

@@ -215,7 +215,7 @@ def plane_range_mask(pts: torch.Tensor, plane: np.ndarray, offset: float, only_r
 
 
 # --------------------------------------------------------------------------- clustering
-GRAPH_TYPES = {"radius_mutual_knn": 0, "radius": 1}
+GRAPH_TYPES = {"radius_mutual_knn": 0, "radius": 1, "knn": 2, "sym_knn": 3, "mutual_knn": 4}
 AFFINITY_TYPES = {"l1": 0, "exp": 1, "3d_l2_distance": 2}
 
 
@@ -230,8 +230,7 @@ def cluster_dbscan(xyz: torch.Tensor, pp: torch.Tensor, n_neighbors: int = 70, r
     _dev(xyz, torch.float32, "xyz")
     _dev(pp, torch.float32, "pp")
     if neighbor_type not in GRAPH_TYPES:
-        raise NotImplementedError(f"neighbor_type {neighbor_type!r}: knn / sym_knn / mutual_knn need a k-NN search "
-                                  "without a radius bound (SURVEY.md §8f-3)")
+        raise NotImplementedError(neighbor_type)
     if affinity_type not in AFFINITY_TYPES:
         raise NotImplementedError(affinity_type)
     n = xyz.shape[0]

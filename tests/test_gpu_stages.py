@@ -230,19 +230,23 @@ def test_graph_variants_vs_reference_golden(gpu, golden_dir):
     g = np.load(os.path.join(golden_dir, "graph_variants.npz"))
     kept, pp = g["kept"], g["pp"]
     for k, v in enumerate(g["variants"]):
-        nt, at, radius, eps, ms = str(v).split("|")
-        lab = cu.cluster_points(kept, pp, neighbor_type=nt, affinity_type=at, n_neighbors=70, radius=float(radius),
+        nt, at, radius, eps, ms, nn = str(v).split("|")
+        lab = cu.cluster_points(kept, pp, neighbor_type=nt, affinity_type=at, n_neighbors=int(nn), radius=float(radius),
                                 eps=float(eps), min_samples=int(ms))
         assert np.array_equal(lab, g[f"labels{k}"]), v
     with pytest.raises(NotImplementedError):
-        cu.cluster_points(kept, pp, neighbor_type="knn")
+        cu.cluster_points(kept, pp, neighbor_type="no_such_graph")
     # larger random cloud against the oracle (sklearn): radius graph, l2 weights incl. intensity
     from oracle import mask as om
     rng = np.random.default_rng(3)
     pts = np.concatenate([rng.standard_normal((6000, 3)) * [8, 8, 0.5], rng.uniform(0, 1, (6000, 1))], axis=1).astype(np.float32)
     ppr = rng.uniform(0, 1, 6000).astype(np.float32)
-    for nt, at, eps in (("radius", "3d_l2_distance", 0.45), ("radius", "l1", 0.02), ("radius_mutual_knn", "exp", 1.0005)):
-        G = om.precompute_affinity_matrix(pts, ppr, n_neighbors=70, radius=1.0, neighbor_type=nt, affinity_type=at)
+    for nt, at, eps, nn in (("radius", "3d_l2_distance", 0.45, 70), ("radius", "l1", 0.02, 70),
+                            ("radius_mutual_knn", "exp", 1.0005, 70), ("knn", "l1", 0.03, 25), ("knn", "l1", 0.2, 12),
+                            ("sym_knn", "l1", 0.03, 25), ("mutual_knn", "l1", 0.05, 40),
+                            ("knn", "3d_l2_distance", 0.5, 16)):
+        G = om.precompute_affinity_matrix(pts, ppr, n_neighbors=nn, radius=1.0, neighbor_type=nt, affinity_type=at)
         ref = om.dbscan_labels(G, eps=eps, min_samples=6)
-        lab = cu.cluster_points(pts, ppr, neighbor_type=nt, affinity_type=at, n_neighbors=70, radius=1.0, eps=eps, min_samples=6)
-        assert np.array_equal(lab, ref), (nt, at)
+        lab = cu.cluster_points(pts, ppr, neighbor_type=nt, affinity_type=at, n_neighbors=nn, radius=1.0, eps=eps,
+                                min_samples=6)
+        assert np.array_equal(lab, ref), (nt, at, eps, nn, int((lab != ref).sum()), int(ref.max()))

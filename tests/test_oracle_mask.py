@@ -124,8 +124,8 @@ def test_graph_variants_match_reference_golden(golden_dir):
     from oracle import mask as om
     g = np.load(os.path.join(golden_dir, "graph_variants.npz"))
     for k, v in enumerate(g["variants"]):
-        nt, at, radius, eps, ms = str(v).split("|")
-        G = om.precompute_affinity_matrix(g["kept"], g["pp"], n_neighbors=70, radius=float(radius),
+        nt, at, radius, eps, ms, nn = str(v).split("|")
+        G = om.precompute_affinity_matrix(g["kept"], g["pp"], n_neighbors=int(nn), radius=float(radius),
                                           neighbor_type=nt, affinity_type=at)
         lab = om.dbscan_labels(G, eps=float(eps), min_samples=int(ms))
         assert np.array_equal(lab, g[f"labels{k}"]), v
