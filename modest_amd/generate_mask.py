@@ -20,7 +20,7 @@ import torch
 
 from . import config, dist, ops
 from .utils import kitti_util
-from .utils.clustering_utils import filter_labels
+from .utils.clustering_utils import compact_labels, filter_labels, members_by_label
 from .utils.pointcloud_utils import estimate_plane, get_objs, load_velo_scan, to_device
 
 
@@ -75,11 +75,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
                                     pp_dev=pp_dev, labels_dev=labels_dev, **args.filtering)
     ptc_in_rect = calib.project_velo_to_rect(ptc[:, :3])
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
-    order = np.argsort(labels_filtered, kind="stable")
-    sl = labels_filtered[order]
-    ids = np.arange(1, n_lab + 1)
-    starts, ends = np.searchsorted(sl, ids, side="left"), np.searchsorted(sl, ids, side="right")
-    members = [order[s:e] for s, e in zip(starts, ends)]
+    members = members_by_label(labels_filtered, n_lab)
     cand = get_objs([ptc_in_rect[m] for m in members], ptc_in_rect, fit_method=args.bbox_gen.fit_method)
     objs = []
     for m, obj in zip(members, cand):
@@ -87,8 +83,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
             objs.append(obj)
         else:
             labels_filtered[m] = 0
-    uniq = np.unique(labels_filtered)
-    labels_filtered = np.searchsorted(uniq, labels_filtered).astype(labels_filtered.dtype)
+    labels_filtered = compact_labels(labels_filtered)
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
 
 

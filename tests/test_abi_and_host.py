@@ -118,3 +118,23 @@ def test_percentile_lerp_equals_numpy():
             got = percentile_from_order_stats(s[prev], s[nxt], vi - fl)
             ref = np.percentile(x, q)
             assert ref.dtype == np.float32 and np.float32(got) == ref, (n, q)
+
+
+def test_label_helpers_equal_numpy_formulation():
+    """compact_labels == searchsorted(unique(l), l); members_by_label == flatnonzero per label."""
+    from modest_amd.utils.clustering_utils import compact_labels, members_by_label
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n = int(rng.integers(1, 5000))
+        lab = rng.integers(-1, 40, n) * (rng.uniform(size=n) < 0.3) - (rng.uniform(size=n) < 0.2)
+        lab = np.maximum(lab, -1).astype(np.int64)
+        ref = np.searchsorted(np.unique(lab), lab).astype(lab.dtype)
+        got = compact_labels(lab)
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)
+        c = compact_labels(np.maximum(lab, 0))       # 0 = background, 1..C
+        n_lab = int(c.max())
+        mem = members_by_label(c, n_lab)
+        assert len(mem) == n_lab
+        for i, m in enumerate(mem, start=1):
+            assert np.array_equal(m, np.flatnonzero(c == i))
+    assert compact_labels(np.zeros(0, dtype=np.int64)).shape == (0,)

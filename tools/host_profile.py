@@ -28,4 +28,4 @@ for i in range(3): step(i)
 pr = cProfile.Profile(); pr.enable()
 for i in range(20): step(i)
 torch.cuda.synchronize(); pr.disable()
-st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45); print(st.getvalue()[:9000])
+st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(40); print(st.getvalue()[:9000])
