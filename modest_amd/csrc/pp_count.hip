@@ -315,6 +315,10 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
         cm3.cstart[n_trav] = nchunks;
     }
     int nwg3 = 2 * ctx->num_cus < V3_MAXWG ? 2 * ctx->num_cus : V3_MAXWG;
+    {
+        const char *nw_env = getenv("MODEST_PP_NWG");
+        if (nw_env && atoi(nw_env) > 0 && atoi(nw_env) <= V3_MAXWG) nwg3 = atoi(nw_env);
+    }
     if (nwg3 > nchunks) nwg3 = nchunks > 0 ? nchunks : 1;
     const char *sr_env = getenv("MODEST_PP_SLICE");
     unsigned sliceCap = sr_env ? (unsigned)atoi(sr_env) : V3_SLICE_MAX;
@@ -402,13 +406,14 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
             ctx->pp_attr_done = 1;
         }
         pp3_blocks<<<1, 1024, 0, stream>>>(blockLive, dense, denseBlock, listLive);
+        const int pair = (nwg3 % 2 == 0 && nwg3 >= 4 && !getenv("MODEST_PP_NOPAIR")) ? 1 : 0;
         pp3_stream<false><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense, wgTile, wgOff,
-                                                     tileBase, rec, dbg);
+                                                     tileBase, rec, dbg, pair);
         pp3_scan<<<V3_NL / V3_SCAN_L, 1024, (size_t)nwg3 * V3_SCAN_L * 4, stream>>>(wgTile, wgOff, nwg3, listTotal);
         pp3_plan<<<1, 1024, 0, stream>>>(listTotal, listLive, n_trav, sliceCap, tileBase, slices,
                                          (unsigned)maxSlices, ctrl3);
-        pp3_stream<true><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense, wgTile, wgOff,
-                                                    tileBase, rec, dbg);
+        pp3_stream<true><<<pair ? nwg3 / 2 : nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense,
+                                                                      wgTile, wgOff, tileBase, rec, dbg, pair);
         if (dbg & 8)
             pp3_join<true><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
                 rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
