@@ -231,6 +231,22 @@ int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz_dev,
                                double *beta_host /* optional (C,n_angles) */,
                                void *stream);
 
+/* fit_method = 'variance_to_edge' (utils/pointcloud_utils.py:218-275): the same
+ * angle table, criterion -var(Dx[Dx<Dy]) - var(Dy[Dy<Dx]) with numpy's var (pairwise sums of the
+ * subsets in index order); returns the first strict maximum per cluster and the criteria.   */
+int modest_fit_boxes_variance(modest_ctx *ctx, const double *pts_xz_dev,
+                              const int32_t *offsets_host, int n_clusters,
+                              const double *cossin_host, int n_angles,
+                              int32_t *best_angle_host, double *crit_host, void *stream);
+
+/* fit_method = 'PCA' (utils/pointcloud_utils.py:189-206): per cluster the two principal axes of
+ * the centred (x,z) points with sklearn's sign convention (svd_flip, u_based_decision=False) and
+ * the extent of the points along them.  out8 [host] (n_clusters,8) float64:
+ * components row-major (4), min0, max0, min1, max1.  Agrees with sklearn to ~1e-13 relative
+ * (LAPACK's SVD and the closed form differ in the last bits).                                */
+int modest_fit_boxes_pca(modest_ctx *ctx, const double *pts_xz_dev, const int32_t *offsets_host,
+                         int n_clusters, double *out8_host, void *stream);
+
 /* ---- a17 get_lowest_point_rect (pointcloud_utils.py:278-290) ----------
  * For each box b = (cx, cz, l, w, cos(ry), sin(ry)) float64 [host] the max
  * rect-y over all scan points strictly inside the rotated footprint

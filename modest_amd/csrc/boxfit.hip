@@ -153,6 +153,226 @@ __global__ __launch_bounds__(64) void argmax_kernel(const double *__restrict__ b
     if (lane == 0) best[c] = (arg == 0x7fffffff) ? -1 : arg;
 }
 
+// ---- fit_method = 'variance_to_edge' (utils/pointcloud_utils.py:218-275) ---------------
+// Same 901-angle search, criterion  -var(Dx[Dx<Dy]) - var(Dy[Dy<Dx])  with numpy's var:
+// mean = pairwise_sum(x)/n, var = pairwise_sum((x-mean)*(x-mean))/n.  The subsets are never
+// materialised: a forward iterator yields their elements in index order, which is the order
+// in which numpy's pairwise summation consumes them.
+struct VarIt {
+    const double *pts;
+    double c, s, ns, minx, maxx, miny, maxy, shift;
+    int i, sel, sq;
+};
+
+__device__ __forceinline__ double var_next(VarIt &it) {
+    for (;;) {
+        const double x = it.pts[2 * (size_t)it.i], z = it.pts[2 * (size_t)it.i + 1];
+        ++it.i;
+        const double p0 = fma(z, it.s, x * it.c);
+        const double p1 = fma(z, it.c, x * it.ns);
+        const double dx = fmin(p0 - it.minx, it.maxx - p0);
+        const double dy = fmin(p1 - it.miny, it.maxy - p1);
+        const bool take = it.sel == 0 ? (dx < dy) : (dy < dx);
+        if (!take) continue;
+        const double v = it.sel == 0 ? dx : dy;
+        if (!it.sq) return v;
+        const double t = v - it.shift;
+        return t * t;
+    }
+}
+
+__device__ double pw_leaf_it(VarIt &it, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += var_next(it);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = var_next(it);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += var_next(it);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += var_next(it);
+    return res;
+}
+
+__device__ double pw_sum_it(VarIt &it, int n) {
+    int f_n[32], f_stage[32];
+    double f_left[32];
+    int sp = 0;
+    f_n[0] = n;
+    f_stage[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        const int len = f_n[sp];
+        if (len <= 128) {
+            ret = pw_leaf_it(it, len);
+            --sp;
+            continue;
+        }
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if (f_stage[sp] == 0) {
+            f_stage[sp] = 1;
+            ++sp;
+            f_n[sp] = n2;
+            f_stage[sp] = 0;
+        } else if (f_stage[sp] == 1) {
+            f_left[sp] = ret;
+            f_stage[sp] = 2;
+            ++sp;
+            f_n[sp] = len - n2;
+            f_stage[sp] = 0;
+        } else {
+            ret = f_left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+__global__ __launch_bounds__(128) void variance_kernel(const double *__restrict__ pts,
+                                                       const int *__restrict__ offsets,
+                                                       const double *__restrict__ cossin, int n_angles,
+                                                       double *__restrict__ crit) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (a >= n_angles) return;
+    const int b = offsets[c], n = offsets[c + 1] - b;
+    VarIt it;
+    it.pts = pts + 2 * (size_t)b;
+    it.c = cossin[2 * a];
+    it.s = cossin[2 * a + 1];
+    it.ns = -it.s;
+    double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        const double x = it.pts[2 * (size_t)i], z = it.pts[2 * (size_t)i + 1];
+        const double p0 = fma(z, it.s, x * it.c), p1 = fma(z, it.c, x * it.ns);
+        mnx = fmin(mnx, p0);
+        mxx = fmax(mxx, p0);
+        mny = fmin(mny, p1);
+        mxy = fmax(mxy, p1);
+    }
+    it.minx = mnx;
+    it.maxx = mxx;
+    it.miny = mny;
+    it.maxy = mxy;
+    int cnt[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const double x = it.pts[2 * (size_t)i], z = it.pts[2 * (size_t)i + 1];
+        const double p0 = fma(z, it.s, x * it.c), p1 = fma(z, it.c, x * it.ns);
+        const double dx = fmin(p0 - mnx, mxx - p0), dy = fmin(p1 - mny, mxy - p1);
+        cnt[0] += dx < dy;
+        cnt[1] += dy < dx;
+    }
+    double var = 0.0;
+    for (int sel = 0; sel < 2; ++sel) {
+        const int m = cnt[sel];
+        if (m == 0) continue;
+        it.sel = sel;
+        it.i = 0;
+        it.sq = 0;
+        it.shift = 0.0;
+        const double mean = pw_sum_it(it, m) / (double)m;
+        it.i = 0;
+        it.sq = 1;
+        it.shift = mean;
+        var += -(pw_sum_it(it, m) / (double)m);
+    }
+    crit[(size_t)c * n_angles + a] = (n > 0) ? var : -INFINITY;
+}
+
+// ---- fit_method = 'PCA' (utils/pointcloud_utils.py:189-206) ------------------------------
+// sklearn PCA(n_components=2).components_ of the (n,2) cluster: principal axes of the centred
+// points (closed form for the 2x2 scatter matrix), signs fixed as svd_flip(u_based_decision=False)
+// does (largest |entry| of every axis positive); then the extent of the raw points along them.
+// out[c*8 + {0..3: components row-major, 4: min0, 5: max0, 6: min1, 7: max1}]
+__global__ __launch_bounds__(64) void pca_kernel(const double *__restrict__ pts, const int *__restrict__ offsets,
+                                                 double *__restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int b = offsets[c], n = offsets[c + 1] - b;
+    const double *p = pts + 2 * (size_t)b;
+    double sx = 0.0, sz = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        sx += p[2 * (size_t)i];
+        sz += p[2 * (size_t)i + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o);
+        sz += __shfl_xor(sz, o);
+    }
+    const double mx = n ? sx / n : 0.0, mz = n ? sz / n : 0.0;
+    double a = 0.0, bb = 0.0, d = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double x = p[2 * (size_t)i] - mx, z = p[2 * (size_t)i + 1] - mz;
+        a += x * x;
+        bb += x * z;
+        d += z * z;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        bb += __shfl_xor(bb, o);
+        d += __shfl_xor(d, o);
+    }
+    // leading eigenvector of [[a, bb], [bb, d]]
+    double v0, v1;
+    if (bb == 0.0) {
+        v0 = a >= d ? 1.0 : 0.0;
+        v1 = a >= d ? 0.0 : 1.0;
+    } else {
+        const double h = 0.5 * (a - d), r = sqrt(h * h + bb * bb);
+        if (h >= 0.0) {   // lambda1 - d = h + r (no cancellation)
+            v0 = h + r;
+            v1 = bb;
+        } else {          // lambda1 - a = r - h
+            v0 = bb;
+            v1 = r - h;
+        }
+        const double nrm = sqrt(v0 * v0 + v1 * v1);
+        v0 /= nrm;
+        v1 /= nrm;
+    }
+    double w0 = -v1, w1 = v0;
+    if ((fabs(v0) >= fabs(v1) ? v0 : v1) < 0.0) {
+        v0 = -v0;
+        v1 = -v1;
+    }
+    if ((fabs(w0) >= fabs(w1) ? w0 : w1) < 0.0) {
+        w0 = -w0;
+        w1 = -w1;
+    }
+    double mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        const double x = p[2 * (size_t)i], z = p[2 * (size_t)i + 1];
+        const double q0 = fma(z, v1, x * v0), q1 = fma(z, w1, x * w0);   // cluster @ components.T
+        mn0 = fmin(mn0, q0);
+        mx0 = fmax(mx0, q0);
+        mn1 = fmin(mn1, q1);
+        mx1 = fmax(mx1, q1);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn0 = fmin(mn0, __shfl_xor(mn0, o));
+        mx0 = fmax(mx0, __shfl_xor(mx0, o));
+        mn1 = fmin(mn1, __shfl_xor(mn1, o));
+        mx1 = fmax(mx1, __shfl_xor(mx1, o));
+    }
+    if (lane == 0) {
+        double *o8 = out + 8 * (size_t)c;
+        o8[0] = v0;
+        o8[1] = v1;
+        o8[2] = w0;
+        o8[3] = w1;
+        o8[4] = mn0;
+        o8[5] = mx0;
+        o8[6] = mn1;
+        o8[7] = mx1;
+    }
+}
+
 struct Box6 {
     double cx, cz, l, w, c, s;
 };
@@ -182,11 +402,9 @@ __global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__
 
 }  // namespace
 
-extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
-                                          const int32_t *offsets_host, int n_clusters,
-                                          const double *cossin_host, int n_angles, double d0,
-                                          int32_t *best_angle_host, double *beta_host,
-                                          void *stream_) {
+static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz, const int32_t *offsets_host,
+                            int n_clusters, const double *cossin_host, int n_angles, double d0,
+                            int32_t *best_angle_host, double *beta_host, void *stream_) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n_clusters >= 0 && n_angles >= 1 && n_angles <= 65536, "bad sizes");
     if (n_clusters == 0) return MODEST_OK;
@@ -218,7 +436,8 @@ extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
     MODEST_HIP_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(n_clusters + 1) * 4, hipMemcpyHostToDevice, stream));
     MODEST_HIP_CHECK(hipMemcpyAsync(d_cs, h_cs, (size_t)n_angles * 16, hipMemcpyHostToDevice, stream));
     dim3 grid((n_angles + 127) / 128, n_clusters);
-    closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
+    if (variance) variance_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d_beta);
+    else closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
     argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, d_best);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(h_best, d_best, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
@@ -229,6 +448,54 @@ extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
     for (int i = 0; i < n_clusters; ++i) best_angle_host[i] = h_best[i];
     if (beta_host)
         for (size_t i = 0; i < (size_t)n_clusters * n_angles; ++i) beta_host[i] = h_beta[i];
+    return MODEST_OK;
+}
+
+extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
+                                          const int32_t *offsets_host, int n_clusters,
+                                          const double *cossin_host, int n_angles, double d0,
+                                          int32_t *best_angle_host, double *beta_host,
+                                          void *stream_) {
+    return fit_boxes_angles(ctx, 0, pts_xz, offsets_host, n_clusters, cossin_host, n_angles, d0, best_angle_host,
+                            beta_host, stream_);
+}
+
+extern "C" int modest_fit_boxes_variance(modest_ctx *ctx, const double *pts_xz,
+                                         const int32_t *offsets_host, int n_clusters,
+                                         const double *cossin_host, int n_angles,
+                                         int32_t *best_angle_host, double *crit_host, void *stream_) {
+    return fit_boxes_angles(ctx, 1, pts_xz, offsets_host, n_clusters, cossin_host, n_angles, 0.0, best_angle_host,
+                            crit_host, stream_);
+}
+
+extern "C" int modest_fit_boxes_pca(modest_ctx *ctx, const double *pts_xz, const int32_t *offsets_host,
+                                    int n_clusters, double *out8_host, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n_clusters >= 0, "bad sizes");
+    if (n_clusters == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts_xz && offsets_host && out8_host, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t b_off = arena_sz((size_t)(n_clusters + 1) * 4), b_out = arena_sz((size_t)n_clusters * 64);
+    int rc = modest_ctx_reserve(ctx, b_off + b_out);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, b_off + b_out);
+    if (rc) return rc;
+    int *d_off = reinterpret_cast<int *>(ctx->scratch);
+    double *d_out = reinterpret_cast<double *>(ctx->scratch + b_off);
+    int *h_off = reinterpret_cast<int *>(ctx->pinned);
+    double *h_out = reinterpret_cast<double *>(ctx->pinned + b_off);
+    for (int i = 0; i <= n_clusters; ++i) {
+        MODEST_REQUIRE(offsets_host[i] >= 0 && (i == 0 || offsets_host[i] >= offsets_host[i - 1]),
+                       "offsets must be non-decreasing");
+        h_off[i] = offsets_host[i];
+    }
+    MODEST_HIP_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(n_clusters + 1) * 4, hipMemcpyHostToDevice, stream));
+    pca_kernel<<<n_clusters, 64, 0, stream>>>(pts_xz, d_off, d_out);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_clusters * 64, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < (size_t)n_clusters * 8; ++i) out8_host[i] = h_out[i];
     return MODEST_OK;
 }
 

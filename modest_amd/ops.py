@@ -308,6 +308,35 @@ def fit_boxes_closeness(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np
     return (best, beta) if return_beta else best
 
 
+def fit_boxes_variance(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np.ndarray, return_crit: bool = False,
+                       ctx: Optional[Context] = None):
+    """Index of the first strict maximum of the variance_to_edge criterion per cluster."""
+    lib = load()
+    _dev(pts_xz, torch.float64, "pts_xz")
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+    cs = np.ascontiguousarray(cossin, dtype=np.float64).reshape(-1, 2)
+    ncl, na = off.shape[0] - 1, cs.shape[0]
+    best = np.full(ncl, -1, dtype=np.int32)
+    crit = np.zeros((ncl, na), dtype=np.float64) if return_crit else None
+    c = _ctx(ctx, pts_xz)
+    check(lib.modest_fit_boxes_variance(c.handle, pts_xz.data_ptr(), _np_ptr(off), ncl, _np_ptr(cs), na,
+                                        _np_ptr(best), _np_ptr(crit) if return_crit else None, _stream()),
+          "modest_fit_boxes_variance")
+    return (best, crit) if return_crit else best
+
+
+def fit_boxes_pca(pts_xz: torch.Tensor, offsets: Sequence[int], ctx: Optional[Context] = None) -> np.ndarray:
+    """(K,8): PCA components (row-major 2x2) and the extent of every cluster along them."""
+    lib = load()
+    _dev(pts_xz, torch.float64, "pts_xz")
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+    out = np.zeros((off.shape[0] - 1, 8), dtype=np.float64)
+    c = _ctx(ctx, pts_xz)
+    check(lib.modest_fit_boxes_pca(c.handle, pts_xz.data_ptr(), _np_ptr(off), off.shape[0] - 1, _np_ptr(out),
+                                   _stream()), "modest_fit_boxes_pca")
+    return out
+
+
 def lowest_point(pts_rect: torch.Tensor, boxes6: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
     lib = load()
     _dev(pts_rect, torch.float64, "pts_rect")

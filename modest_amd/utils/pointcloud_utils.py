@@ -147,6 +147,34 @@ def closeness_rectangles(clusters_xz: Sequence[np.ndarray], delta=0.1, d0=1e-2):
     return [rectangle_at_angle(c, ang[b]) for c, b in zip(clusters_xz, best)]
 
 
+def variance_rectangles(clusters_xz: Sequence[np.ndarray], delta=0.1):
+    """Batched variance_rectangle (:218-275): same angle table, criterion
+    -var(Dx[Dx<Dy]) - var(Dy[Dy<Dx]) on the device, the rectangle at the chosen angle on the host."""
+    if len(clusters_xz) == 0:
+        return []
+    ang, cs = _angles(delta)
+    off = np.cumsum([0] + [len(c) for c in clusters_xz]).astype(np.int32)
+    pts = to_device(np.concatenate(clusters_xz).astype(np.float64), dtype=torch.float64)
+    best = ops.fit_boxes_variance(pts, off, cs)
+    return [rectangle_at_angle(c, ang[b]) for c, b in zip(clusters_xz, best)]
+
+
+def pca_rectangles(clusters_xz: Sequence[np.ndarray]):
+    """Batched PCA_rectangle (:189-206): principal axes and extents on the device."""
+    if len(clusters_xz) == 0:
+        return []
+    off = np.cumsum([0] + [len(c) for c in clusters_xz]).astype(np.int32)
+    pts = to_device(np.concatenate(clusters_xz).astype(np.float64), dtype=torch.float64)
+    out = []
+    for r in ops.fit_boxes_pca(pts, off):
+        components = r[:4].reshape(2, 2)
+        min_x, max_x, min_y, max_y = r[4], r[5], r[6], r[7]
+        area = (max_x - min_x) * (max_y - min_y)
+        rval = np.array([[max_x, min_y], [min_x, min_y], [min_x, max_y], [max_x, max_y]]) @ components
+        out.append((rval, np.arctan2(components[0, 1], components[0, 0]), area))
+    return out
+
+
 def closeness_rectangle(cluster_ptc, delta=0.1, d0=1e-2):
     """(:167-216) single-cluster form."""
     return closeness_rectangles([np.asarray(cluster_ptc, dtype=np.float64)], delta, d0)[0]
@@ -172,12 +200,15 @@ def get_lowest_point_rect(ptc, xz_center, l, w, ry):
 def get_objs(clusters_rect: List[np.ndarray], full_ptc, fit_method="closeness_to_edge"):
     """Batched get_obj (:292-317) for a scan: boxes of all clusters.
     clusters_rect: list of (n_c,3) float64 rect-frame points; full_ptc (N,3) float64."""
-    if fit_method != "closeness_to_edge":
-        raise NotImplementedError(f"fit_method={fit_method!r}: only the default closeness_to_edge is built "
-                                  "(SURVEY.md §8f-3)")
+    fitters = {"closeness_to_edge": closeness_rectangles, "variance_to_edge": variance_rectangles,
+               "PCA": pca_rectangles}
+    if fit_method not in fitters:
+        # min_zx_area_fit walks the hull edges in scipy/Qhull's vertex order and skips the closing
+        # edge (pointcloud_utils.py:104-107): not reproducible without Qhull's starting vertex
+        raise NotImplementedError(f"fit_method={fit_method!r} (SURVEY.md §8f-3)")
     if len(clusters_rect) == 0:
         return []
-    fits = closeness_rectangles([c[:, [0, 2]] for c in clusters_rect])
+    fits = fitters[fit_method]([c[:, [0, 2]] for c in clusters_rect])
     ls, ws, cs, rys = [], [], [], []
     for corners, ry, _ in fits:
         ry = ry * -1

@@ -242,6 +242,73 @@ def rectangle_at_angle(cluster_ptc, choose_angle):
     return rval, angle, area
 
 
+def variance_rectangle(cluster_ptc, delta=0.1, return_index=False):
+    """utils/pointcloud_utils.py:218-275 (fit_method='variance_to_edge')."""
+    max_var, choose_angle, best_idx = -float("inf"), None, -1
+    for k, deg in enumerate(np.arange(0, 90 + delta, delta)):
+        angle = deg / 180. * np.pi
+        comp = np.array([[np.cos(angle), np.sin(angle)], [-np.sin(angle), np.cos(angle)]])
+        proj = cluster_ptc @ comp.T
+        min_x, max_x = proj[:, 0].min(), proj[:, 0].max()
+        min_y, max_y = proj[:, 1].min(), proj[:, 1].max()
+        Dx = np.vstack((proj[:, 0] - min_x, max_x - proj[:, 0])).min(axis=0)
+        Dy = np.vstack((proj[:, 1] - min_y, max_y - proj[:, 1])).min(axis=0)
+        Ex, Ey = Dx[Dx < Dy], Dy[Dy < Dx]
+        var = 0
+        if (Dx < Dy).sum() > 0:
+            var += -np.var(Ex)
+        if (Dy < Dx).sum() > 0:
+            var += -np.var(Ey)
+        if var > max_var:
+            max_var, choose_angle, best_idx = var, angle, k
+    out = rectangle_at_angle(cluster_ptc, choose_angle)   # :253-275 is the same tail as :188-216
+    return out + (best_idx,) if return_index else out
+
+
+def PCA_rectangle(cluster_ptc):
+    """utils/pointcloud_utils.py:189-206 (fit_method='PCA')."""
+    import sklearn.decomposition
+    components = sklearn.decomposition.PCA(n_components=2).fit(cluster_ptc).components_
+    on_component_ptc = cluster_ptc @ components.T
+    min_x, max_x = on_component_ptc[:, 0].min(), on_component_ptc[:, 0].max()
+    min_y, max_y = on_component_ptc[:, 1].min(), on_component_ptc[:, 1].max()
+    area = (max_x - min_x) * (max_y - min_y)
+    rval = np.array([[max_x, min_y], [min_x, min_y], [min_x, max_y], [max_x, max_y]])
+    rval = rval @ components
+    angle = np.arctan2(components[0, 1], components[0, 0])
+    return rval, angle, area
+
+
+def minimum_bounding_rectangle(points):
+    """utils/pointcloud_utils.py:88-147 (fit_method='min_zx_area_fit'): rotating calipers over the
+    edges hull[1:] - hull[:-1] of scipy's (Qhull's) vertex order -- the closing edge is not tried."""
+    from scipy.spatial import ConvexHull
+    pi2 = np.pi / 2.
+    hull_points = points[ConvexHull(points).vertices]
+    edges = hull_points[1:] - hull_points[:-1]
+    angles = np.arctan2(edges[:, 1], edges[:, 0])
+    angles = np.abs(np.mod(angles, pi2))
+    angles = np.unique(angles)
+    rotations = np.vstack([np.cos(angles), np.cos(angles - pi2), np.cos(angles + pi2), np.cos(angles)]).T
+    rotations = rotations.reshape((-1, 2, 2))
+    rot_points = np.dot(rotations, hull_points.T)
+    min_x, max_x = np.nanmin(rot_points[:, 0], axis=1), np.nanmax(rot_points[:, 0], axis=1)
+    min_y, max_y = np.nanmin(rot_points[:, 1], axis=1), np.nanmax(rot_points[:, 1], axis=1)
+    areas = (max_x - min_x) * (max_y - min_y)
+    best_idx = np.argmin(areas)
+    x1, x2, y1, y2 = max_x[best_idx], min_x[best_idx], max_y[best_idx], min_y[best_idx]
+    r = rotations[best_idx]
+    rval = np.zeros((4, 2))
+    rval[0] = np.dot([x1, y2], r)
+    rval[1] = np.dot([x2, y2], r)
+    rval[2] = np.dot([x2, y1], r)
+    rval[3] = np.dot([x1, y1], r)
+    return rval, angles[best_idx], areas[best_idx]
+
+
+FIT_METHODS = {"closeness_to_edge": None, "variance_to_edge": None, "PCA": None, "min_zx_area_fit": None}
+
+
 def get_lowest_point_rect(ptc, xz_center, l, w, ry):
     """utils/pointcloud_utils.py:278-290."""
     ptc_xz = ptc[:, [0, 2]] - xz_center
@@ -251,9 +318,11 @@ def get_lowest_point_rect(ptc, xz_center, l, w, ry):
     return ptc[mask, 1].max()
 
 
-def get_obj(ptc, full_ptc):
-    """utils/pointcloud_utils.py:292-317, fit_method='closeness_to_edge'."""
-    corners, ry, area = closeness_rectangle(ptc[:, [0, 2]])
+def get_obj(ptc, full_ptc, fit_method="closeness_to_edge"):
+    """utils/pointcloud_utils.py:292-317 (configs/generate_mask.yaml uses 'closeness_to_edge')."""
+    fit = {"closeness_to_edge": closeness_rectangle, "variance_to_edge": variance_rectangle,
+           "PCA": PCA_rectangle, "min_zx_area_fit": minimum_bounding_rectangle}[fit_method]
+    corners, ry, area = fit(ptc[:, [0, 2]])
     ry *= -1
     l = np.linalg.norm(corners[0] - corners[1])
     w = np.linalg.norm(corners[0] - corners[-1])

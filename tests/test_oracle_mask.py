@@ -129,3 +129,23 @@ def test_graph_variants_match_reference_golden(golden_dir):
                                           neighbor_type=nt, affinity_type=at)
         lab = om.dbscan_labels(G, eps=float(eps), min_samples=int(ms))
         assert np.array_equal(lab, g[f"labels{k}"]), v
+
+
+def test_fit_variants_match_reference_golden(golden_dir):
+    """variance_to_edge / PCA / min_zx_area_fit: the oracle's restatements reproduce
+    the rectangles and objects the reference's own functions produced."""
+    import os
+    from oracle import mask as om
+    g = np.load(os.path.join(golden_dir, "mask_stage.npz"))
+    f = np.load(os.path.join(golden_dir, "fit_variants.npz"))
+    off, pts, rect, seg = g["cl_offsets"], g["cl_pts"], g["rect"], g["labels_filtered"]
+    for name, fn in (("variance", om.variance_rectangle), ("pca", om.PCA_rectangle), ("minarea", om.minimum_bounding_rectangle)):
+        for k in range(len(off) - 1):
+            corners, angle, area = fn(pts[off[k]:off[k + 1]])
+            got = np.concatenate([np.asarray(corners).reshape(-1), [angle, area]])
+            assert np.array_equal(got, f[name][k]), (name, k)
+    ids = [i for i in np.unique(seg) if i > 0]
+    for method in ("variance_to_edge", "PCA", "min_zx_area_fit"):
+        got = np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in
+                        (om.get_obj(rect[seg == i], rect, fit_method=method) for i in ids)])
+        assert np.array_equal(got, f["objs_" + method]), method
