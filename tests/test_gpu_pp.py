@@ -144,3 +144,34 @@ def test_pp_dense_clusters(gpu, spread):
     off = np.cumsum([0] + [len(h) for h in hist])
     c = ops.pp_count(torch.from_numpy(live).to(gpu), torch.from_numpy(np.concatenate(hist)).to(gpu), off, 0.3)
     assert np.array_equal(c.cpu().numpy().astype(np.int64), cref)
+
+
+@pytest.mark.gpu
+def test_pp_permutation_invariance_full_size(gpu):
+    """Size-independent properties at BASELINE config-2 scale (30 k live points, 10 x 1.08 M
+    history points): counts do not depend on the order of the history points inside a traversal
+    (the scatter pass fills lists in arrival order), they follow a permutation of the live points,
+    and swapping two traversals swaps the two count columns."""
+    import torch
+    from modest_amd import ops, synth
+    s = synth.make_scan(5, n_live=30000, n_trav=10, n_frames=36)
+    off = np.cumsum([0] + [len(h) for h in s.hist])
+    live = torch.from_numpy(s.live_xyz).to(gpu)
+    hist = torch.from_numpy(np.concatenate(s.hist)).to(gpu)
+    base = ops.pp_count(live, hist, off, 0.3)
+    assert int(base.sum()) > 0
+    g = torch.Generator(device="cpu").manual_seed(1)
+    # (1) shuffle the history inside every traversal
+    parts = []
+    for t in range(10):
+        seg = hist[off[t]:off[t + 1]]
+        parts.append(seg[torch.randperm(seg.shape[0], generator=g).to(gpu)])
+    assert torch.equal(ops.pp_count(live, torch.cat(parts), off, 0.3), base)
+    # (2) permute the live points
+    perm = torch.randperm(live.shape[0], generator=g).to(gpu)
+    assert torch.equal(ops.pp_count(live[perm].contiguous(), hist, off, 0.3), base[perm])
+    # (3) swap traversals 2 and 7
+    order = [0, 1, 7, 3, 4, 5, 6, 2, 8, 9]
+    hs = torch.cat([hist[off[t]:off[t + 1]] for t in order])
+    offs = np.cumsum([0] + [int(off[t + 1] - off[t]) for t in order])
+    assert torch.equal(ops.pp_count(live, hs, offs, 0.3), base[:, order])
