@@ -175,3 +175,19 @@ def test_pp_permutation_invariance_full_size(gpu):
     hs = torch.cat([hist[off[t]:off[t + 1]] for t in order])
     offs = np.cumsum([0] + [int(off[t + 1] - off[t]) for t in order])
     assert torch.equal(ops.pp_count(live, hs, offs, 0.3), base[:, order])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius", [0.05, 0.5, 1.25])
+def test_pp_other_radii(gpu, radius):
+    """max_neighbor_dist other than the config default (the grid cell follows the radius)."""
+    import torch
+    from modest_amd import ops
+    from oracle import pp_score as opp
+    rng = np.random.default_rng(int(radius * 100))
+    live = (rng.standard_normal((4000, 3)) * [10, 10, 0.5]).astype(np.float32)
+    hist = [(rng.standard_normal((m, 3)) * [10, 10, 0.5]).astype(np.float32) for m in (30000, 1, 12345)]
+    cref = opp.count_neighbors(live, hist, radius)
+    off = np.cumsum([0] + [len(h) for h in hist])
+    c = ops.pp_count(torch.from_numpy(live).to(gpu), torch.from_numpy(np.concatenate(hist)).to(gpu), off, radius)
+    assert np.array_equal(c.cpu().numpy().astype(np.int64), cref)
