@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
+Every rank feeds its GPU from `--procs` helper processes x `--streams` threads (the host side of
+a scan is Python + ~100 HIP calls and saturates one process long before the GPU; --procs 1 keeps
+everything in the rank process).  Timing is the rank's: barrier, clock, all helpers run their
+share of the K steps and synchronise, barrier, clock; max over ranks.
+
 A "step" is one pass of the whole seed-label hot path over one scan whose inputs
 are already resident in HBM: PP score (live scan vs the stacked 10-traversal x
 36-frame history, ~10.8 M points) -> RANSAC ground plane -> plane/range mask ->
@@ -43,16 +48,21 @@ HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s sp
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--steps", type=int, default=160)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--scans", type=int, default=2, help="distinct resident scans per rank, cycled through")
+    ap.add_argument("--scans", type=int, default=2, help="distinct resident scans per host process, cycled through")
     ap.add_argument("--n-live", type=int, default=30000)
     ap.add_argument("--traversals", type=int, default=10)
     ap.add_argument("--frames", type=int, default=36)
     ap.add_argument("--cpu-scans", type=int, default=2, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="scans in flight per GPU: host threads, each with its own HIP stream and modest_ctx")
+    ap.add_argument("--procs", type=int, default=4,
+                    help="host processes per GPU (per rank).  The host side of a scan is Python + ~100 HIP calls; one "
+                         "process saturates at ~350 scans/s on its interpreter lock and HIP runtime locks while the "
+                         "GPU is half idle, so every rank feeds its GPU from several helper processes (what the "
+                         "reference's own total_part/part split does by hand).  1 = everything in the rank process.")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="scans in flight per host process: threads, each with its own HIP stream and modest_ctx")
     return ap.parse_args()
 
 
@@ -68,69 +78,71 @@ class ResidentScan:
         self.N = int(s.live_xyz.shape[0])
 
 
-def main():
-    a = parse()
-    from modest_amd import _lib, config, dist, ops, synth
-    from modest_amd.gen_label_files import gen_label_scan
-    from modest_amd.generate_mask import generate_mask_scan
-    from modest_amd.utils import kitti_util
+class Runner:
+    """The pipeline of one host process: resident synthetic scans, `n_threads` worker threads with
+    one HIP stream + modest_ctx each."""
 
-    rank, ws, local = dist.init()
-    assert ws == a.gpus or ws == 1, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
-    _lib.load()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    import threading
-    n_workers = max(1, a.streams)
-    if n_workers > 1:
-        # the worker threads hand the GIL over at their blocking library calls; CPython's default
-        # forced-switch interval (5 ms) is longer than a whole step, 0.5 ms measured best (+20 %)
-        sys.setswitchinterval(float(os.environ.get("MODEST_SWITCH_INTERVAL", "0.0005")))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_workers)]
-    ctxs = [_lib.Context(local) for _ in range(n_workers)]
+    def __init__(self, a, rank, local, slot):
+        import threading
+        from modest_amd import _lib, config, ops, synth
+        from modest_amd.gen_label_files import gen_label_scan
+        from modest_amd.generate_mask import generate_mask_scan
+        from modest_amd.utils import kitti_util
+        self.a, self.ops, self.threading = a, ops, threading
+        self._gen_label_scan, self._generate_mask_scan = gen_label_scan, generate_mask_scan
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        self.dev = torch.device("cuda", local)
+        torch.cuda.set_device(self.dev)
+        self.n_threads = max(1, a.streams)
+        if self.n_threads > 1:
+            # the worker threads hand the GIL over at their blocking library calls; CPython's default
+            # forced-switch interval (5 ms) is longer than a whole step, 0.5 ms measured best (+20 %)
+            sys.setswitchinterval(float(os.environ.get("MODEST_SWITCH_INTERVAL", "0.0005")))
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_threads)]
+        self.ctxs = [_lib.Context(local) for _ in range(self.n_threads)]
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+            calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+        self.margs = config.compose("generate_mask", ["data_root=/unused"])
+        self.largs = config.compose("generate_label_files", ["data_root=/unused"])
+        self.scans = [ResidentScan(synth.make_scan(1000 * rank + 16 * slot + i, n_live=a.n_live, n_trav=a.traversals,
+                                                   n_frames=a.frames), self.dev, calib) for i in range(a.scans)]
+        # every thread (stream + scratch arena + kernel attributes) runs before any clock starts
+        self.n_warm = max(a.warmup, 2 * self.n_threads)
+        self.run(0, self.n_warm)
+        torch.cuda.synchronize()
 
-    with tempfile.TemporaryDirectory() as d:
-        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
-        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
-    margs = config.compose("generate_mask", ["data_root=/unused"])
-    largs = config.compose("generate_label_files", ["data_root=/unused"])
-
-    t_gen = time.perf_counter()
-    scans = [ResidentScan(synth.make_scan(1000 * rank + i, n_live=a.n_live, n_trav=a.traversals,
-                                          n_frames=a.frames), dev, calib) for i in range(a.scans)]
-    t_gen = time.perf_counter() - t_gen
-
-    def step(i, ctx):
-        sc = scans[i % len(scans)]
-        H = ops.pp_score(sc.live_xyz, sc.hist, sc.offsets, 0.3, ctx=ctx)
+    def step(self, i, ctx):
+        a, sc = self.a, self.scans[i % len(self.scans)]
+        H = self.ops.pp_score(sc.live_xyz, sc.hist, sc.offsets, 0.3, ctx=ctx)
         if a.pp_only:
             return H, None, None, None
         pp_host = H.cpu().numpy()
-        labels, objs, _ = generate_mask_scan(sc.host.live_raw, pp_host, sc.calib, margs,
-                                             random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H)
-        text, kept = gen_label_scan(objs, sc.calib, largs)
+        labels, objs, _ = self._generate_mask_scan(sc.host.live_raw, pp_host, sc.calib, self.margs,
+                                                   random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H)
+        text, kept = self._gen_label_scan(objs, sc.calib, self.largs)
         return H, labels, objs, text
 
-    def run(lo, hi):
-        """steps lo..hi-1, dealt round-robin to the worker threads (one HIP stream + ctx each)"""
+    def run(self, lo, hi):
+        """steps lo..hi-1, dealt round-robin to the worker threads"""
         errs = []
 
         def worker(w):
             try:
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(streams[w]):
-                    for i in range(lo + w, hi, n_workers):
-                        step(i, ctxs[w])
-                    streams[w].synchronize()
+                torch.cuda.set_device(self.dev)
+                with torch.cuda.stream(self.streams[w]):
+                    for i in range(lo + w, hi, self.n_threads):
+                        self.step(i, self.ctxs[w])
+                    self.streams[w].synchronize()
             except Exception as e:   # surfaced after join
                 errs.append(e)
 
-        if n_workers == 1:
+        if self.n_threads == 1:
             worker(0)
         else:
-            th = [threading.Thread(target=worker, args=(w,)) for w in range(n_workers)]
+            th = [self.threading.Thread(target=worker, args=(w,)) for w in range(self.n_threads)]
             for t in th:
                 t.start()
             for t in th:
@@ -138,38 +150,136 @@ def main():
         if errs:
             raise errs[0]
 
-    # every worker thread (stream + scratch arena + kernel attributes) must have run before the clock
-    # starts: W warm-up steps are dealt round-robin, so at least two rounds are made
-    n_warm = max(a.warmup, 2 * n_workers)
-    run(0, n_warm)
-    torch.cuda.synchronize()
+    def timed(self, n_steps):
+        """n_steps steps -> (seconds, HIP-event times of every PP stage launched)"""
+        for c_ in self.ctxs:
+            c_.profile_begin(n_steps + 8)
+        t0 = time.perf_counter()
+        self.run(self.n_warm, self.n_warm + n_steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, np.concatenate([c_.profile_collect(n_steps + 8) for c_ in self.ctxs])
+
+    def isolated_pp_ms(self):
+        sc0 = self.scans[0]
+        self.ctxs[0].profile_begin(16)
+        with torch.cuda.stream(self.streams[0]):
+            for i in range(8):
+                self.ops.pp_score(sc0.live_xyz, sc0.hist, sc0.offsets, 0.3, ctx=self.ctxs[0])
+            self.streams[0].synchronize()
+        iso = self.ctxs[0].profile_collect(16)
+        return float(np.mean(iso[2:])) if len(iso) > 2 else None
+
+
+def _helper_main(conn, a, rank, local, slot):
+    """entry point of a helper process (multiprocessing 'spawn'): pipe protocol
+    child -> ('ready', None) ; parent -> ('go', n_steps) ; child -> ('done', (seconds, kernel_ms)) ;
+    parent -> ('iso', None) -> child ('iso', ms) ; parent -> ('exit', None)"""
+    try:
+        r = Runner(a, rank, local, slot)
+        conn.send(("ready", r.scans[0].M))
+        while True:
+            cmd, arg = conn.recv()
+            if cmd == "go":
+                dt, kms = r.timed(int(arg))
+                conn.send(("done", (dt, kms.tolist())))
+            elif cmd == "iso":
+                conn.send(("iso", r.isolated_pp_ms()))
+            else:
+                break
+    except BaseException as e:   # reported, the parent falls back to the in-process path
+        try:
+            conn.send(("error", repr(e)))
+        except Exception:
+            pass
+
+
+def _split(n, parts):
+    return [n // parts + (1 if k < n % parts else 0) for k in range(parts)]
+
+
+def main():
+    a = parse()
+    from modest_amd import dist, ops, synth
+
+    rank, ws, local = dist.init()
+    assert ws == a.gpus or ws == 1, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(torch.device("cuda", local))
+
+    helpers, note, M = [], None, None
+    n_procs = max(1, a.procs)
+    if n_procs > 1:
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        try:
+            for slot in range(n_procs):
+                pc, cc = ctx.Pipe()
+                p = ctx.Process(target=_helper_main, args=(cc, a, rank, local, slot), daemon=True)
+                p.start()
+                helpers.append((p, pc))
+            for p, pc in helpers:
+                if not pc.poll(900):
+                    raise RuntimeError("helper process did not come up")
+                tag, msg = pc.recv()
+                if tag != "ready":
+                    raise RuntimeError(f"helper process failed: {msg}")
+                M = int(msg)
+        except Exception as e:   # e.g. no semaphores / fork limits on this host: stay inside the rank process
+            note = f"helper processes unavailable ({e}); ran in the rank process"
+            for p, pc in helpers:
+                try:
+                    pc.send(("exit", None))
+                except Exception:
+                    pass
+                p.join(5)
+                if p.is_alive():
+                    p.terminate()
+            helpers, n_procs = [], 1
+    runner = Runner(a, rank, local, 0) if not helpers else None
+
     dist.barrier()
-    for c_ in ctxs:
-        c_.profile_begin(a.steps + 8)
     t0 = time.perf_counter()
-    run(n_warm, n_warm + a.steps)
+    if helpers:
+        shares = _split(a.steps, n_procs)
+        for (p, pc), n in zip(helpers, shares):
+            pc.send(("go", n))
+        kms = []
+        for p, pc in helpers:
+            tag, msg = pc.recv()
+            if tag != "done":
+                raise RuntimeError(f"helper process failed: {msg}")
+            kms.append(np.asarray(msg[1], dtype=np.float32))
+        kernel_ms = np.concatenate(kms)
+    else:
+        _, kernel_ms = runner.timed(a.steps)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = np.concatenate([c_.profile_collect(a.steps + 8) for c_ in ctxs])
     red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
     dt_max, total_scans = red["max_seconds"], red["scans"]
 
-    sc0 = scans[0]
-    alg_bytes = 12 * sc0.M + 16 * sc0.N
-    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
-    # the same stage with nothing else on the GPU (the timed region has `--streams` scans in flight,
-    # so its event pairs also see the other scans' kernels): informational, not the reported `achieved`
+    # the same stage with nothing else on the GPU (the timed region has several scans in flight, so its
+    # event pairs also see the other scans' kernels): informational, not the reported `achieved`
     iso_ms = None
     if rank == 0:
-        ctxs[0].profile_begin(16)
-        with torch.cuda.stream(streams[0]):
-            for i in range(8):
-                ops.pp_score(sc0.live_xyz, sc0.hist, sc0.offsets, 0.3, ctx=ctxs[0])
-            streams[0].synchronize()
-        iso = ctxs[0].profile_collect(16)
-        iso_ms = float(np.mean(iso[2:])) if len(iso) > 2 else None
+        if helpers:
+            helpers[0][1].send(("iso", None))
+            iso_ms = helpers[0][1].recv()[1]
+        else:
+            iso_ms = runner.isolated_pp_ms()
+    for p, pc in helpers:
+        pc.send(("exit", None))
+    for p, pc in helpers:
+        p.join(30)
+    n_threads = max(1, a.streams)
+
+    if runner is not None:
+        M = runner.scans[0].M
+    alg_bytes = 12 * M + 16 * a.n_live
+    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_pp_traffic.json")
     if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
@@ -197,17 +307,23 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
             ocalib = ol.Calibration(os.path.join(d, "c.txt"))
-        n_cpu = min(a.cpu_scans, len(scans))
+        # the sample = the scans helper 0 (or the rank process) benchmarked: same generator, same seeds
+        import torch as _t
+        host_scans = [synth.make_scan(1000 * rank + i, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames)
+                      for i in range(min(a.cpu_scans, a.scans))]
+        n_cpu = len(host_scans)
         tc = time.perf_counter()
         for i in range(n_cpu):
-            s = scans[i].host
+            s = host_scans[i]
             Href, cref = opp.pp_score(s.live_xyz, s.hist, 0.3, workers=1)       # reference: single thread
             if not a.pp_only:
                 ref = om.generate_mask_scan(s.live_raw, Href, ocalib, random_state=np.random.RandomState(i), n_jobs=-1)
                 ol.gen_label_scan(ref["objs"], ocalib)
             if i == 0:
                 # parity of the measured path against the checker, outside the timed region
-                Hg, cg = ops.pp_score(scans[0].live_xyz, scans[0].hist, scans[0].offsets, 0.3, return_counts=True)
+                dv = _t.device("cuda", local)
+                Hg, cg = ops.pp_score(_t.from_numpy(s.live_xyz).to(dv), _t.from_numpy(np.concatenate(s.hist)).to(dv),
+                                      np.cumsum([0] + [len(h) for h in s.hist]), 0.3, return_counts=True)
                 parity = {"pp_counts_equal": bool(np.array_equal(cg.cpu().numpy().astype(np.int64), cref)),
                           "pp_max_abs_err": float(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - Href)))}
         tc = time.perf_counter() - tc
@@ -224,10 +340,11 @@ def main():
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C2 PP-score only" if a.pp_only else "C3 full pipeline (PP + RANSAC + DBSCAN + box fit + iou3d NMS + labels)")
-                                   + f", Lyft-shape: {sc0.N} live pts vs {a.traversals} traversals x {a.frames} frames = {sc0.M} history pts",
-                       "live_points": sc0.N, "history_points": sc0.M, "traversals": a.traversals,
+                                   + f", Lyft-shape: {a.n_live} live pts vs {a.traversals} traversals x {a.frames} frames = {M} history pts",
+                       "live_points": a.n_live, "history_points": M, "traversals": a.traversals,
                        "frames_per_traversal": a.frames, "radius": 0.3, "scans_per_rank": a.steps,
-                       "scans_in_flight_per_gpu": n_workers,
+                       "host_processes_per_gpu": n_procs, "threads_per_process": n_threads,
+                       "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "speedup_vs_cpu": (value / cpu_baseline["value"]) if cpu_baseline else None,
