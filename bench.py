@@ -237,6 +237,7 @@ def main():
                 if p.is_alive():
                     p.terminate()
             helpers, n_procs = [], 1
+            a.streams = max(a.streams, 4)   # threads instead
     runner = Runner(a, rank, local, 0) if not helpers else None
 
     dist.barrier()
