@@ -14,7 +14,10 @@
 // The (cos, sin) table comes from the host so that device libm differences
 // cannot move the chosen angle.
 #include "common.h"
+#include <algorithm>
 #include <cmath>
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -125,6 +128,94 @@ __global__ __launch_bounds__(128) void closeness_kernel(const double *__restrict
     B.miny = mny;
     B.maxy = mxy;
     beta[(size_t)c * n_angles + a] = (n > 0) ? pw_sum(B, n) : 0.0;
+}
+
+// The same sum, spread over the lanes of a block.  numpy's pairwise sum is a fixed binary tree
+// over the index range whose leaves hold 65..128 elements (or everything when n <= 128); the host
+// lists the leaves of every cluster and the post-order "program" (0 = next leaf, 1 = add) that
+// combines them, so the leaves can be summed side by side and combined in numpy's order.
+// A block serves one cluster and 256/P angles; P lanes share an angle: they split the min/max
+// pass by points and the sum pass by leaves, then lane 0 runs the program on an LDS stack.
+// (One lane per (cluster, angle), above, walks the whole cluster serially -- a 2000-point
+// cluster made that kernel take 76 us while most of the chip idled.)
+constexpr int CT_STACK = 40;
+template <int P>
+__global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__restrict__ pts,
+                                                             const int *__restrict__ offsets,
+                                                             const double *__restrict__ cossin, int n_angles,
+                                                             double d0, const int *__restrict__ leafBase,
+                                                             const int2 *__restrict__ leaves,
+                                                             const int *__restrict__ progBase,
+                                                             const unsigned char *__restrict__ prog,
+                                                             int maxLeaves, double *__restrict__ beta) {
+    constexpr int AB = 256 / P;
+    extern __shared__ double ct_lsum[];          // [AB][maxLeaves]
+    __shared__ double stk[AB][CT_STACK];
+    const int c = blockIdx.y, al = threadIdx.x / P, sub = threadIdx.x % P;
+    const int a = blockIdx.x * AB + al;
+    const int aa = min(a, n_angles - 1);
+    const int b = offsets[c], n = offsets[c + 1] - b;
+    const int lb = leafBase[c], nl = leafBase[c + 1] - lb;
+    BetaCtx B;
+    B.pts = pts + 2 * (size_t)b;
+    B.c = cossin[2 * aa];
+    B.s = cossin[2 * aa + 1];
+    B.ns = -B.s;
+    B.d0 = d0;
+    double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    for (int i = sub; i < n; i += P) {
+        const double x = B.pts[2 * (size_t)i], z = B.pts[2 * (size_t)i + 1];
+        const double p0 = fma(z, B.s, x * B.c);
+        const double p1 = fma(z, B.c, x * B.ns);
+        mnx = fmin(mnx, p0);
+        mxx = fmax(mxx, p0);
+        mny = fmin(mny, p1);
+        mxy = fmax(mxy, p1);
+    }
+#pragma unroll
+    for (int o = P / 2; o > 0; o >>= 1) {
+        mnx = fmin(mnx, __shfl_xor(mnx, o));
+        mxx = fmax(mxx, __shfl_xor(mxx, o));
+        mny = fmin(mny, __shfl_xor(mny, o));
+        mxy = fmax(mxy, __shfl_xor(mxy, o));
+    }
+    B.minx = mnx;
+    B.maxx = mxx;
+    B.miny = mny;
+    B.maxy = mxy;
+    double *ls = ct_lsum + (size_t)al * maxLeaves;
+    for (int l = sub; l < nl; l += P) {
+        const int2 lf = leaves[lb + l];
+        ls[l] = pw_leaf(B, lf.x, lf.y);
+    }
+    __syncthreads();
+    if (sub != 0 || a >= n_angles) return;
+    double *st = stk[al];
+    int sp = 0, li = 0;
+    for (int t = progBase[c]; t < progBase[c + 1]; ++t) {
+        if (prog[t] == 0) {
+            st[sp++] = ls[li++];
+        } else {
+            const double r = st[--sp], l = st[--sp];
+            st[sp++] = l + r;
+        }
+    }
+    beta[(size_t)c * n_angles + a] = (n > 0) ? st[0] : 0.0;
+}
+
+// leaves and combine program of numpy's pairwise sum over n elements (host side)
+static void pw_tree_host(int off, int n, std::vector<int> &leaf, std::vector<unsigned char> &prog) {
+    if (n <= 128) {
+        leaf.push_back(off);
+        leaf.push_back(n);
+        prog.push_back(0);
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    pw_tree_host(off, n2, leaf, prog);
+    pw_tree_host(off + n2, n - n2, leaf, prog);
+    prog.push_back(1);
 }
 
 // first strict maximum over the angles (pointcloud_utils.py:185-187) = largest value, ties to
@@ -377,26 +468,33 @@ struct Box6 {
     double cx, cz, l, w, c, s;
 };
 
-__global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__ pts, int n,
-                                                      const Box6 *__restrict__ boxes,
-                                                      double *__restrict__ out) {
-    const Box6 b = boxes[blockIdx.x];
-    const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
-    double best = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double dx = pts[3 * (size_t)i] - b.cx, dz = pts[3 * (size_t)i + 2] - b.cz;
+// order-preserving 64-bit key of a double; 0 is below every real value ("no point inside")
+__device__ __forceinline__ unsigned long long d2key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+
+// every thread keeps one point and walks the boxes (the loads happen once); a wavefront that
+// has a point inside a box posts its maximum with one atomic
+__global__ __launch_bounds__(256) void lowest_kernel(const double *__restrict__ pts, int n,
+                                                     const Box6 *__restrict__ boxes, int n_boxes,
+                                                     unsigned long long *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const double px = valid ? pts[3 * (size_t)i] : 0.0, py = valid ? pts[3 * (size_t)i + 1] : 0.0;
+    const double pz = valid ? pts[3 * (size_t)i + 2] : 0.0;
+    for (int k = 0; k < n_boxes; ++k) {
+        const Box6 b = boxes[k];
+        const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
+        const double dx = px - b.cx, dz = pz - b.cz;
         // [dx dz] @ [[c,-s],[s,c]]^T
         const double q0 = fma(dz, ns, dx * b.c);
         const double q1 = fma(dz, b.c, dx * b.s);
-        if (q0 > -hl && q0 < hl && q1 > -hw && q1 < hw) best = fmax(best, pts[3 * (size_t)i + 1]);
-    }
-    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
-    __shared__ double red[16];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; ++k) best = fmax(best, red[k]);
-        out[blockIdx.x] = best;
+        const bool in = valid && q0 > -hl && q0 < hl && q1 > -hw && q1 < hw;
+        if (__ballot(in) == 0) continue;
+        double best = in ? py : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(out + k, d2key(best));
     }
 }
 
@@ -412,32 +510,72 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
     MODEST_REQUIRE(n_clusters <= 65535, "too many clusters");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t b_off = arena_sz((size_t)(n_clusters + 1) * 4), b_cs = arena_sz((size_t)n_angles * 16);
-    const size_t b_beta = arena_sz((size_t)n_clusters * n_angles * 8), b_best = arena_sz((size_t)n_clusters * 4);
-    int rc = modest_ctx_reserve(ctx, b_off + b_cs + b_beta + b_best);
-    if (rc) return rc;
-    const size_t h_need = b_off + b_cs + b_best + (beta_host ? b_beta : 0);
-    rc = modest_ctx_reserve_pinned(ctx, h_need);
-    if (rc) return rc;
-    int *d_off = reinterpret_cast<int *>(ctx->scratch);
-    double *d_cs = reinterpret_cast<double *>(ctx->scratch + b_off);
-    double *d_beta = reinterpret_cast<double *>(ctx->scratch + b_off + b_cs);
-    int *d_best = reinterpret_cast<int *>(ctx->scratch + b_off + b_cs + b_beta);
-    int *h_off = reinterpret_cast<int *>(ctx->pinned);
-    double *h_cs = reinterpret_cast<double *>(ctx->pinned + b_off);
-    int *h_best = reinterpret_cast<int *>(ctx->pinned + b_off + b_cs);
-    double *h_beta = reinterpret_cast<double *>(ctx->pinned + b_off + b_cs + b_best);
-    for (int i = 0; i <= n_clusters; ++i) {
+    for (int i = 0; i <= n_clusters; ++i)
         MODEST_REQUIRE(offsets_host[i] >= 0 && (i == 0 || offsets_host[i] >= offsets_host[i - 1]),
                        "offsets must be non-decreasing");
-        h_off[i] = offsets_host[i];
+    // closeness: leaf list + combine program of every cluster's pairwise-sum tree
+    std::vector<int> leaf, leafBase, progBase;
+    std::vector<unsigned char> prog;
+    int maxLeaves = 1, maxN = 0;
+    if (!variance) {
+        leafBase.push_back(0);
+        progBase.push_back(0);
+        for (int c = 0; c < n_clusters; ++c) {
+            const int n = offsets_host[c + 1] - offsets_host[c];
+            if (n > 0) pw_tree_host(0, n, leaf, prog);
+            leafBase.push_back((int)(leaf.size() / 2));
+            progBase.push_back((int)prog.size());
+            maxLeaves = std::max(maxLeaves, leafBase[c + 1] - leafBase[c]);
+            maxN = std::max(maxN, n);
+        }
     }
-    for (int i = 0; i < 2 * n_angles; ++i) h_cs[i] = cossin_host[i];
-    MODEST_HIP_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)(n_clusters + 1) * 4, hipMemcpyHostToDevice, stream));
-    MODEST_HIP_CHECK(hipMemcpyAsync(d_cs, h_cs, (size_t)n_angles * 16, hipMemcpyHostToDevice, stream));
+    // upload block: [offsets | cos,sin | leafBase | progBase | leaves | prog], one copy
+    const size_t u_off = 0, u_cs = arena_sz((size_t)(n_clusters + 1) * 4);
+    const size_t u_lb = u_cs + arena_sz((size_t)n_angles * 16);
+    const size_t u_pb = u_lb + arena_sz(leafBase.size() * 4);
+    const size_t u_lf = u_pb + arena_sz(progBase.size() * 4);
+    const size_t u_pg = u_lf + arena_sz(leaf.size() * 4);
+    const size_t b_up = u_pg + arena_sz(prog.size());
+    const size_t b_beta = arena_sz((size_t)n_clusters * n_angles * 8), b_best = arena_sz((size_t)n_clusters * 4);
+    int rc = modest_ctx_reserve(ctx, b_up + b_beta + b_best);
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, b_up + b_best + (beta_host ? b_beta : 0));
+    if (rc) return rc;
+    char *d = ctx->scratch, *h = ctx->pinned;
+    int *d_off = reinterpret_cast<int *>(d + u_off);
+    double *d_cs = reinterpret_cast<double *>(d + u_cs);
+    double *d_beta = reinterpret_cast<double *>(d + b_up);
+    int *d_best = reinterpret_cast<int *>(d + b_up + b_beta);
+    int *h_best = reinterpret_cast<int *>(h + b_up);
+    double *h_beta = reinterpret_cast<double *>(h + b_up + b_best);
+    memcpy(h + u_off, offsets_host, (size_t)(n_clusters + 1) * 4);
+    memcpy(h + u_cs, cossin_host, (size_t)n_angles * 16);
+    if (!variance) {
+        memcpy(h + u_lb, leafBase.data(), leafBase.size() * 4);
+        memcpy(h + u_pb, progBase.data(), progBase.size() * 4);
+        if (!leaf.empty()) memcpy(h + u_lf, leaf.data(), leaf.size() * 4);
+        if (!prog.empty()) memcpy(h + u_pg, prog.data(), prog.size());
+    }
+    MODEST_HIP_CHECK(hipMemcpyAsync(d, h, b_up, hipMemcpyHostToDevice, stream));
     dim3 grid((n_angles + 127) / 128, n_clusters);
-    if (variance) variance_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d_beta);
-    else closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
+    const int P = maxN > 4096 ? 64 : 16, AB = 256 / P;
+    const size_t lds = (size_t)AB * maxLeaves * 8;
+    if (variance) {
+        variance_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d_beta);
+    } else if (lds <= 48 * 1024) {
+        const dim3 g2((n_angles + AB - 1) / AB, n_clusters);
+        const int *d_lb = reinterpret_cast<const int *>(d + u_lb), *d_pb = reinterpret_cast<const int *>(d + u_pb);
+        const int2 *d_lf = reinterpret_cast<const int2 *>(d + u_lf);
+        const unsigned char *d_pg = reinterpret_cast<const unsigned char *>(d + u_pg);
+        if (P == 64)
+            closeness_tree_kernel<64><<<g2, 256, lds, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_lb, d_lf, d_pb,
+                                                                d_pg, maxLeaves, d_beta);
+        else
+            closeness_tree_kernel<16><<<g2, 256, lds, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_lb, d_lf, d_pb,
+                                                                d_pg, maxLeaves, d_beta);
+    } else {   // a cluster of > 90 k points: one lane per (cluster, angle)
+        closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
+    }
     argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, d_best);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(h_best, d_best, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
@@ -515,15 +653,22 @@ extern "C" int modest_lowest_point(modest_ctx *ctx, const double *pts_rect, int 
     rc = modest_ctx_reserve_pinned(ctx, b_box + b_out);
     if (rc) return rc;
     Box6 *d_box = reinterpret_cast<Box6 *>(ctx->scratch);
-    double *d_out = reinterpret_cast<double *>(ctx->scratch + b_box);
+    unsigned long long *d_out = reinterpret_cast<unsigned long long *>(ctx->scratch + b_box);
     double *h_box = reinterpret_cast<double *>(ctx->pinned);
-    double *h_out = reinterpret_cast<double *>(ctx->pinned + b_box);
+    unsigned long long *h_out = reinterpret_cast<unsigned long long *>(ctx->pinned + b_box);
     for (int i = 0; i < 6 * n_boxes; ++i) h_box[i] = boxes6_host[i];
     MODEST_HIP_CHECK(hipMemcpyAsync(d_box, h_box, (size_t)n_boxes * sizeof(Box6), hipMemcpyHostToDevice, stream));
-    lowest_kernel<<<n_boxes, 1024, 0, stream>>>(pts_rect, n, d_box, d_out);
+    MODEST_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)n_boxes * 8, stream));
+    if (n > 0) lowest_kernel<<<(n + 255) / 256, 256, 0, stream>>>(pts_rect, n, d_box, n_boxes, d_out);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_boxes * 8, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-    for (int i = 0; i < n_boxes; ++i) bottom_host[i] = h_out[i];
+    for (int i = 0; i < n_boxes; ++i) {   // undo d2key; key 0 = no point inside = -inf
+        const unsigned long long k = h_out[i];
+        const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+        double v;
+        memcpy(&v, &u, 8);
+        bottom_host[i] = k ? v : -INFINITY;
+    }
     return MODEST_OK;
 }

@@ -89,30 +89,57 @@ __global__ void cg_count(const float *__restrict__ xyz, int n, const CGrid *g, u
     atomicAdd(&cnt[cy * CG + cx], 1u);
 }
 
-// exclusive scan of `n` counters into out[0..n] by one 1024-thread workgroup
+// exclusive scan of `n` counters into out[0..n] by one 1024-thread workgroup: every wavefront
+// owns a contiguous segment and walks it 64 counters at a time (coalesced, four rounds of loads
+// in flight), first for the segment totals, then for the prefixes with a running carry
 __global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in,
-                                                 unsigned *__restrict__ out, int n) {
-    __shared__ unsigned part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = min(tid * per, n), e = min(b + per, n);
+                                                 unsigned *__restrict__ out, int n,
+                                                 unsigned *__restrict__ total_copy = nullptr) {
+    __shared__ unsigned wtot[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = (((n + 15) / 16) + 63) & ~63;           // per-wavefront segment, multiple of 64
+    const int b = min(w * seg, n), e = min(b + seg, n);
     unsigned s = 0;
-    for (int k = b; k < e; ++k) s += in[k];
-    part[tid] = s;
+    for (int k0 = b; k0 < e; k0 += 256) {
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 64 + lane;
+            v[u] = k < e ? in[k] : 0u;
+        }
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) wtot[w] = s;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = (tid >= o) ? part[tid - o] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    unsigned carry = 0, total = 0;
+    for (int q = 0; q < 16; ++q) {
+        if (q < w) carry += wtot[q];
+        total += wtot[q];
     }
-    unsigned run = part[tid] - s;
-    for (int k = b; k < e; ++k) {
-        const unsigned c = in[k];
-        out[k] = run;
-        run += c;
+    for (int k0 = b; k0 < e; k0 += 256) {
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 64 + lane;
+            v[u] = k < e ? in[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned inc = v[u];
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const int k = k0 + u * 64 + lane;
+            if (k < e) out[k] = carry + inc - v[u];
+            carry += __shfl(inc, 63);
+        }
     }
-    if (tid == 1023) out[n] = part[1023];
+    if (threadIdx.x == 0) {
+        out[n] = total;
+        if (total_copy) *total_copy = total;   // next to the overflow flag: one copy back fetches both
+    }
 }
 
 __global__ void cg_scatter(const float *__restrict__ xyz, const float *__restrict__ pp, int n,
@@ -413,6 +440,7 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
 // with dozens of exactly tied k-th distances) raises `overflow` and the host re-runs the
 // recomputing kernels below.
 constexpr int ADJ = 128;
+constexpr int AG = 16;    // lanes that share one adjacency row in the passes below
 
 __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__restrict__ sorted, int n,
                                                               const CGrid *g,
@@ -448,16 +476,25 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
 // found among its core neighbours (parents only decrease, so the forest stays acyclic)
 __global__ void hook_adj_kernel(int n, int stride, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
                                 const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n || !coreS[s]) return;
-    const int rme = parent[sidx[s]];
-    int m = rme;
-    const int *row = adj + (size_t)s * stride;
-    for (int e = 0; e < deg[s]; ++e) {
-        const int j = row[e];
-        if (coreS[j]) m = min(m, parent[sidx[j]]);
+    // AG lanes per point: the row is read coalesced and the coreS -> sidx -> parent chains of the
+    // edges run side by side (one thread per point made this 40+ dependent loads deep, and a scan
+    // has too few points to hide that with occupancy)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
+    const bool on = s < n && coreS[s];
+    int rme = 0, m = 0x7fffffff;
+    if (on) {
+        rme = parent[sidx[s]];
+        m = rme;
+        const int *row = adj + (size_t)s * stride;
+        const int d = deg[s];
+        for (int e = sub; e < d; e += AG) {
+            const int j = row[e];
+            if (coreS[j]) m = min(m, parent[sidx[j]]);
+        }
     }
-    if (m < rme) atomicMin(parent + rme, m);
+    for (int o = AG / 2; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+    if (on && sub == 0 && m < rme) atomicMin(parent + rme, m);
 }
 
 __global__ void flatten_kernel(int *parent, int n) {
@@ -476,11 +513,13 @@ __global__ void flatten_kernel(int *parent, int n) {
 // parent are skipped with two plain loads)
 __global__ void union_adj_kernel(int n, int stride, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
                                  const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
     if (s >= n || !coreS[s]) return;
     const int me = sidx[s];
     const int *row = adj + (size_t)s * stride;
-    for (int e = 0; e < deg[s]; ++e) {
+    const int d = deg[s];
+    for (int e = sub; e < d; e += AG) {
         const int j = row[e];
         if (j <= s || !coreS[j]) continue;
         const int other = sidx[j];
@@ -492,20 +531,23 @@ __global__ void label_adj_kernel(int n, int stride, const unsigned char *__restr
                                  const int *__restrict__ adj, const int *__restrict__ sidx,
                                  const int *__restrict__ root, const unsigned *__restrict__ rank,
                                  int *__restrict__ labels) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const int me = sidx[s];
-    if (coreS[s]) {
-        labels[me] = (int)rank[root[me]];
-        return;
-    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
+    const bool on = s < n;
+    const bool core = on && coreS[s];
     int best = 0x7fffffff;
-    const int *row = adj + (size_t)s * stride;
-    for (int e = 0; e < deg[s]; ++e) {
-        const int j = row[e];
-        if (coreS[j]) best = min(best, root[sidx[j]]);
+    if (on && !core) {
+        const int *row = adj + (size_t)s * stride;
+        const int d = deg[s];
+        for (int e = sub; e < d; e += AG) {
+            const int j = row[e];
+            if (coreS[j]) best = min(best, root[sidx[j]]);
+        }
     }
-    labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
+    for (int o = AG / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if (!on || sub) return;
+    const int me = sidx[s];
+    labels[me] = core ? (int)rank[root[me]] : (best == 0x7fffffff) ? -1 : (int)rank[best];
 }
 
 // ---- k-NN graphs without a radius bound (neighbor_type knn / sym_knn / mutual_knn) ------------
@@ -672,11 +714,13 @@ __global__ void dir_init_kernel(int n, const unsigned char *__restrict__ coreS, 
 }
 __global__ void dir_push_kernel(int n, int stride, const unsigned char *__restrict__ coreS,
                                 const int *__restrict__ deg, const int *__restrict__ adj, int *L, int *changed) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
     if (s >= n || !coreS[s]) return;
     const int mine = __hip_atomic_load(L + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ch = false;
-    for (int e = 0; e < deg[s]; ++e) {
+    const int d = deg[s];
+    for (int e = sub; e < d; e += AG) {
         const int j = adj[(size_t)s * stride + e];
         if (atomicMin(L + j, mine) > mine) ch = true;
     }
@@ -764,10 +808,12 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     int *degOut = A.take<int>(n);
     int *Lmin = A.take<int>(n);
     int *overflow = reinterpret_cast<int *>(zeroed + 2 * CG_CELLS);
+    unsigned *n_roots = zeroed + 2 * CG_CELLS + 2;   // [overflow, changed, n_roots]
 
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
     const int nb = (n + 255) / 256, nw = (n + WPB - 1) / WPB;
+    const int nbA = (int)(((long long)n * AG + 255) / 256);
     MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
     cg_bbox<<<1, 1024, 0, stream>>>(xyz, n, c, g);
     cg_count<<<nb, 256, 0, stream>>>(xyz, n, g, cnt);
@@ -794,7 +840,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
         if (neighbor_type == MODEST_GRAPH_KNN) {
             dir_init_kernel<<<nb, 256, 0, stream>>>(n, coreS, sidx, Lmin);
             for (int it = 0; it < 4096; ++it) {   // a propagation step per launch, convergence checked every 8
-                dir_push_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, Lmin, changed);
+                dir_push_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, Lmin, changed);
                 if (it % 8 == 7) {
                     MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 16, changed, 4, hipMemcpyDeviceToHost, stream));
                     MODEST_HIP_CHECK(hipMemsetAsync(changed, 0, 4, stream));
@@ -803,26 +849,25 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
                 }
             }
             dir_roots_kernel<<<nb, 256, 0, stream>>>(n, coreS, sidx, Lmin, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
             dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels);
         } else {
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
             for (int round = 0; round < 3; ++round) {
-                hook_adj_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
+                hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
                 flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
             }
-            union_adj_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
+            union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
-            label_adj_kernel<<<nb, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, root, rank, labels);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
+            label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, root, rank, labels);
         }
         MODEST_HIP_CHECK(hipGetLastError());
-        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 8, overflow, 4, hipMemcpyDeviceToHost, stream));
-        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
+        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, overflow, 12, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-        MODEST_REQUIRE(!*reinterpret_cast<int *>(ctx->pinned + 8),
+        MODEST_REQUIRE(!reinterpret_cast<int *>(ctx->pinned)[0],
                        "k-NN graph: a row exceeded its capacity (massively tied k-th distances or a hub point)");
-        if (n_clusters) *n_clusters = (int32_t) * reinterpret_cast<unsigned *>(ctx->pinned);
+        if (n_clusters) *n_clusters = (int32_t) reinterpret_cast<unsigned *>(ctx->pinned)[2];
         if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
         MODEST_HIP_CHECK(hipGetLastError());
         return MODEST_OK;
@@ -833,31 +878,30 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
                                                   overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
     for (int round = 0; round < 3; ++round) {   // accelerators only: union_adj_kernel makes the result exact
-        hook_adj_kernel<<<nb, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
+        hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
         flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
     }
-    union_adj_kernel<<<nb, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
+    union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
     compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-    scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
-    label_adj_kernel<<<nb, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels);
+    scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
+    label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels);
     MODEST_HIP_CHECK(hipGetLastError());
     {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
-        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned + 8, overflow, 4, hipMemcpyDeviceToHost, stream));
-        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
+        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, overflow, 12, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-        if (*reinterpret_cast<int *>(ctx->pinned + 8)) {
+        if (reinterpret_cast<int *>(ctx->pinned)[0]) {
             degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS);
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
             hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
             label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, ep,
                                                      labels);
-            MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, rank + n, 4, hipMemcpyDeviceToHost, stream));
+            MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, overflow, 12, hipMemcpyDeviceToHost, stream));
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         }
-        if (n_clusters) *n_clusters = (int32_t) * reinterpret_cast<unsigned *>(ctx->pinned);
+        if (n_clusters) *n_clusters = (int32_t) reinterpret_cast<unsigned *>(ctx->pinned)[2];
     }
     if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
     MODEST_HIP_CHECK(hipGetLastError());

@@ -45,6 +45,65 @@ __global__ void cs_scatter(const int *__restrict__ labels, int n, int C, const u
     if (l >= 0 && l < C) members[start[l] + atomicAdd(&fill[l], 1u)] = i;
 }
 
+// cs_count + cs_scan + cs_scatter in one workgroup for the usual case (a scan has tens of clusters
+// and 30 k labels): LDS histogram, block scan, LDS cursors -- no same-line global atomics at all
+// (they made the three-kernel path take 130 us).
+constexpr int CS_GROUP_MAXC = 8192;
+constexpr int CS_LDS_KEYS = 8192;
+__global__ __launch_bounds__(1024) void cs_group(const int *__restrict__ labels, int n, int C,
+                                                 unsigned *__restrict__ start, int *__restrict__ members) {
+    __shared__ unsigned hist[CS_GROUP_MAXC];
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int c = tid; c < C; c += 1024) hist[c] = 0;
+    __syncthreads();
+    // eight labels per thread and round, loaded before the atomics (one load latency per round)
+    for (int base = 0; base < n; base += 8 * 1024) {
+        int l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 1024 + tid;
+            l[u] = i < n ? labels[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (l[u] >= 0 && l[u] < C) atomicAdd(&hist[l[u]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of hist[0..C): `per` consecutive bins per thread
+    const int per = (C + 1023) / 1024, b0 = min(tid * per, C), b1 = min(b0 + per, C);
+    unsigned s = 0;
+    for (int c = b0; c < b1; ++c) s += hist[c];
+    unsigned inc = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned run = inc - s;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+    for (int c = b0; c < b1; ++c) {
+        const unsigned v = hist[c];
+        start[c] = run;
+        hist[c] = run;   // becomes the cursor
+        run += v;
+    }
+    if (tid == 1023) start[C] = run;
+    __syncthreads();
+    for (int base = 0; base < n; base += 8 * 1024) {
+        int l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 1024 + tid;
+            l[u] = i < n ? labels[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (l[u] >= 0 && l[u] < C) members[atomicAdd(&hist[l[u]], 1u)] = base + u * 1024 + tid;
+    }
+}
+
 struct PlaneP {
     double n0, n1, n2, d, norm, q;
 };
@@ -58,12 +117,18 @@ __global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__
     __shared__ unsigned hist[2048];
     __shared__ unsigned wsum[4], sel[2];
     __shared__ double rmin[4], rmax[4];
+    // PP keys of the members, gathered once (each of the up to seven select passes otherwise
+    // repeats the members -> pp chain of dependent loads)
+    __shared__ unsigned keys[CS_LDS_KEYS];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int n = (int)(start[c + 1] - start[c]);
     const int *mem = members + start[c];
+    const bool cached = n <= CS_LDS_KEYS;
     double mn = INFINITY, mx = -INFINITY;
     for (int i = tid; i < n; i += CS_THREADS) {
-        const float *p = pts + (size_t)mem[i] * stride;
+        const int m = mem[i];
+        if (cached) keys[i] = cs_key(pp[m]);
+        const float *p = pts + (size_t)m * stride;
         // ptc @ plane[:3] + plane[3] then / norm: the float64 rounding of numpy's product
         double dist = (double)p[0] * P.n0;
         dist = fma((double)p[1], P.n1, dist);
@@ -93,8 +158,14 @@ __global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__
         if (vi < 0.f) prev = next = 0;
         next = min(next, n - 1);
         gamma = (double)(vi - fl);
-        a = (double)cs_select(pp, mem, n, (unsigned)prev, hist, wsum, sel);
-        b = (next == prev) ? a : (double)cs_select(pp, mem, n, (unsigned)next, hist, wsum, sel);
+        if (cached) {
+            const auto key_at = [&](int i) { return keys[i]; };
+            a = (double)cs_select_keys(key_at, n, (unsigned)prev, hist, wsum, sel);
+            b = (next == prev) ? a : (double)cs_select_keys(key_at, n, (unsigned)next, hist, wsum, sel);
+        } else {
+            a = (double)cs_select(pp, mem, n, (unsigned)prev, hist, wsum, sel);
+            b = (next == prev) ? a : (double)cs_select(pp, mem, n, (unsigned)next, hist, wsum, sel);
+        }
     }
     if (tid == 0) {
         out[6 * c + 0] = (double)n;
@@ -129,7 +200,6 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
     unsigned *start = reinterpret_cast<unsigned *>(ctx->scratch + b_cnt);
     int *members = reinterpret_cast<int *>(ctx->scratch + b_cnt + b_start);
     double *d_out = reinterpret_cast<double *>(ctx->scratch + b_cnt + b_start + b_mem);
-    MODEST_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)2 * n_clusters * 4, stream));
     PlaneP P;
     P.n0 = plane4[0];
     P.n1 = plane4[1];
@@ -137,10 +207,15 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
     P.d = plane4[3];
     P.norm = sqrt((plane4[0] * plane4[0] + plane4[1] * plane4[1]) + plane4[2] * plane4[2]);
     P.q = quantile;
-    const int nb = (n + 255) / 256;
-    if (n > 0) cs_count<<<nb, 256, 0, stream>>>(labels, n, n_clusters, cnt);
-    cs_scan<<<1, 64, 0, stream>>>(cnt, n_clusters, start);
-    if (n > 0) cs_scatter<<<nb, 256, 0, stream>>>(labels, n, n_clusters, start, fill, members);
+    if (n_clusters <= CS_GROUP_MAXC) {
+        cs_group<<<1, 1024, 0, stream>>>(labels, n, n_clusters, start, members);
+    } else {
+        const int nb = (n + 255) / 256;
+        MODEST_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)2 * n_clusters * 4, stream));
+        if (n > 0) cs_count<<<nb, 256, 0, stream>>>(labels, n, n_clusters, cnt);
+        cs_scan<<<1, 64, 0, stream>>>(cnt, n_clusters, start);
+        if (n > 0) cs_scatter<<<nb, 256, 0, stream>>>(labels, n, n_clusters, start, fill, members);
+    }
     cs_stats<<<n_clusters, CS_THREADS, 0, stream>>>(pts, stride, pp, members, start, P, d_out);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, d_out, (size_t)n_clusters * 48, hipMemcpyDeviceToHost, stream));

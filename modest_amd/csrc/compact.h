@@ -1,11 +1,13 @@
 // Order-preserving stream compaction helper (numpy boolean-mask semantics).
 //
 // Each 1024-thread block takes a LOGICAL index from a ticket counter when it
-// starts and chains a running total through one 64-bit word
-// (state[0] = (#blocks published << 40) | total, state[1] = ticket), so a block
-// only ever waits on blocks that are already running: no assumption about
-// dispatch order, residency or XCD placement.  state[] (16 bytes) must be
-// zeroed on the stream before the launch.
+// starts (state[1]) and publishes its own keep-count at once in state[2 + blk]
+// (bit 40 = published).  Its first wavefront then sums the counts of all
+// logically earlier blocks, 64 at a time: a block only ever waits on blocks that
+// are already running (no assumption about dispatch order, residency or XCD
+// placement), and nobody waits on a chain -- the 30 blocks of a scan used to hand
+// a running total from one to the next, 0.6 us per hop.
+// state[] (compact_state_bytes(nblocks)) must be zeroed on the stream before the launch.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -15,6 +17,8 @@ struct CompactSlot {
     unsigned blk;             // logical block index (use instead of blockIdx.x)
     unsigned long long dst;   // output position of this thread's element (valid iff keep)
 };
+
+__host__ __device__ inline size_t compact_state_bytes(size_t nblocks) { return 16 + 8 * nblocks; }
 
 __device__ __forceinline__ unsigned compact_ticket(unsigned long long *state) {
     __shared__ unsigned ticket_s;
@@ -41,17 +45,28 @@ __device__ __forceinline__ unsigned long long compact_offset(bool keep, unsigned
         if (k < w) woff += wave_cnt[k];
         total += wave_cnt[k];
     }
-    if (threadIdx.x == 0) {
-        unsigned long long s;
-        for (;;) {
-            s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((s >> 40) == (unsigned long long)blk) break;
-            __builtin_amdgcn_s_sleep(2);
+    if (w == 0) {
+        constexpr unsigned long long FLAG = 1ULL << 40;
+        if (lane == 0)
+            __hip_atomic_store(state + 2 + blk, FLAG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long sum = 0;
+        for (unsigned j0 = 0; j0 < blk; j0 += 64) {
+            const unsigned j = j0 + lane;
+            if (j < blk) {
+                unsigned long long s;
+                for (;;) {
+                    s = __hip_atomic_load(state + 2 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (s & FLAG) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                sum += s & (FLAG - 1ULL);
+            }
         }
-        base_s = s & ((1ULL << 40) - 1ULL);
-        const unsigned long long ns = ((unsigned long long)(blk + 1) << 40) | (base_s + total);
-        __hip_atomic_store(state, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blk == nblocks - 1 && total_out) *total_out = (int)(base_s + total);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) {
+            base_s = sum;
+            if (blk == nblocks - 1 && total_out) *total_out = (int)(sum + total);
+        }
     }
     __syncthreads();
     return base_s + woff + before;

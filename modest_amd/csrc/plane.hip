@@ -53,12 +53,24 @@ __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float(u);
 }
 
-// value(i) = MODE==0 ? z_i : |z_i - center|  (float32 arithmetic)
-template <int MODE>
-__device__ __forceinline__ float mad_value(const float *__restrict__ cand, int i, float center) {
-    const float v = cand[3 * (size_t)i + 2];
-    return MODE == 1 ? fabsf(v - center) : v;
-}
+// The z column of the candidates as the select passes see it: element r*1024 + tid of thread tid.
+// ZRegs holds a thread's (up to MAD_R) elements in registers -- the eight passes of the two
+// medians then never touch memory; one workgroup re-reading 12-byte-strided global memory paid a
+// full load latency per element and pass.  ZGlobal is the fallback for > 32768 candidates.
+constexpr int MAD_R = 32;
+struct ZRegs {
+    float z[MAD_R];
+    __device__ __forceinline__ void load(const float *__restrict__ cand, int n) {
+#pragma unroll
+        for (int r = 0; r < MAD_R; ++r) {
+            const int i = r * 1024 + (int)threadIdx.x;
+            z[r] = i < n ? cand[3 * (size_t)i + 2] : 0.f;
+        }
+    }
+};
+struct ZGlobal {
+    const float *cand;
+};
 
 struct MadShared {
     unsigned hist[2048];
@@ -68,55 +80,111 @@ struct MadShared {
     unsigned maxLessKey;
 };
 
-// exact k-th smallest (0-based) by radix descent over the order-preserving key: 11 + 11 + 10
-// bits, the bin holding rank k is found with a block scan (two bins per thread)
-template <int MODE>
-__device__ float select_kth(const float *__restrict__ cand, int n, unsigned k, float center, MadShared &S) {
+// hist[bin] += 1 for the lanes with act set; must be reached by the whole wavefront.
+// The values crowd into a few bins and same-address LDS atomics serialise, so the two most
+// common bins of the wavefront are added once per wavefront; the rest go one by one.
+__device__ __forceinline__ void lds_hist_add(unsigned *hist, unsigned bin, bool act) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(act);
+    for (int r = 0; r < 2 && todo; ++r) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)bin, lead);
+        const unsigned long long same = __ballot(act && bin == lb);
+        if (lane == lead) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+        if (bin == lb) act = false;
+        todo &= ~same;
+    }
+    if (act) atomicAdd(&hist[bin], 1u);
+}
+
+// block scan of hist[0..2048) (two bins per thread): the bin holding rank k -> S.sel, the rank
+// inside it -> S.knew.  Ends with a barrier.
+__device__ __forceinline__ void pick_bin(MadShared &S, unsigned k) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned prefix = 0, mask = 0;
-    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
-    for (int ps = 0; ps < 3; ++ps) {
-        const int shift = shifts[ps];
-        const unsigned nb = 1u << bitsv[ps];
+    const unsigned v0 = S.hist[2 * tid], v1 = S.hist[2 * tid + 1];
+    unsigned inc = v0 + v1;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) S.wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int q = 0; q < w; ++q) base += S.wsum[q];
+    const unsigned incl = base + inc, excl = incl - v0 - v1;
+    if (k >= excl && k < excl + v0) {
+        S.sel = 2 * tid;
+        S.knew = k - excl;
+    } else if (k >= excl + v0 && k < incl) {
+        S.sel = 2 * tid + 1;
+        S.knew = k - excl - v0;
+    }
+    __syncthreads();
+}
+
+// calls f(value, valid) for every element slot of this thread, wave-uniform trip count;
+// value = MODE==0 ? z_i : |z_i - center|  (float32 arithmetic)
+template <int MODE, class F>
+__device__ __forceinline__ void for_values(const ZRegs &Z, int n, float center, F f) {
+#pragma unroll
+    for (int r = 0; r < MAD_R; ++r) {
+        if (r * 1024 >= n) break;
+        const float v = Z.z[r];
+        f(MODE == 1 ? fabsf(v - center) : v, r * 1024 + (int)threadIdx.x < n);
+    }
+}
+template <int MODE, class F>
+__device__ __forceinline__ void for_values(const ZGlobal &Z, int n, float center, F f) {
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const float v = i < n ? Z.cand[3 * (size_t)i + 2] : 0.f;
+        f(MODE == 1 ? fabsf(v - center) : v, i < n);
+    }
+}
+
+// radix descent over the low `rb` bits of sub-keys u (all < 2^rb): each(f) must call
+// f(u, valid) for every element slot of the thread with a wave-uniform trip count
+template <class Each>
+__device__ __forceinline__ unsigned descend(Each each, int rb, unsigned k, MadShared &S) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0;   // the digits chosen so far = u >> rb
+    while (rb > 0) {
+        const int db = min(11, rb), shift = rb - db;
         for (unsigned b = tid; b < 2048u; b += 1024) S.hist[b] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned key = f2key(mad_value<MODE>(cand, i, center));
-            if ((key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & (nb - 1u)], 1u);
-        }
+        const int rbc = rb;
+        each([&](unsigned u, bool valid) {
+            // rbc == 32 only on the first round, when prefix is 0 and everything matches
+            const bool match = valid && (rbc >= 32 || (u >> rbc) == prefix);
+            lds_hist_add(S.hist, (u >> shift) & ((1u << db) - 1u), match);
+        });
         __syncthreads();
-        const unsigned v0 = S.hist[2 * tid], v1 = S.hist[2 * tid + 1];
-        unsigned inc = v0 + v1;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u = __shfl_up(inc, o);
-            if (lane >= o) inc += u;
-        }
-        if (lane == 63) S.wsum[w] = inc;
-        __syncthreads();
-        unsigned base = 0;
-        for (int q = 0; q < w; ++q) base += S.wsum[q];
-        const unsigned incl = base + inc, excl = incl - v0 - v1;
-        if (k >= excl && k < excl + v0) {
-            S.sel = 2 * tid;
-            S.knew = k - excl;
-        } else if (k >= excl + v0 && k < incl) {
-            S.sel = 2 * tid + 1;
-            S.knew = k - excl - v0;
-        }
-        __syncthreads();
-        prefix |= S.sel << shift;
-        mask |= (nb - 1u) << shift;
+        pick_bin(S, k);
+        prefix = (prefix << db) | S.sel;
         k = S.knew;
+        rb = shift;
         __syncthreads();
     }
-    return key2f(prefix);
+    return prefix;
+}
+
+// exact k-th smallest (0-based): 11 + 11 + 10 bit radix descent over the order-preserving key.
+// (Measured alternatives on 15 k ground candidates, one workgroup = one CU, which is what bounds
+// this kernel -- about 85 issue cycles per 64 elements and pass: range-relative bins with the
+// survivors compacted into LDS 37 us, this descent 34 us, a bitwise rank search 135 us.)
+template <int MODE, class ZS>
+__device__ float select_kth(const ZS &Z, int n, unsigned k, float center, MadShared &S) {
+    __syncthreads();   // the previous select may still be reading S
+    return key2f(descend([&](auto f) {
+        for_values<MODE>(Z, n, center, [&](float v, bool valid) { f(f2key(v), valid); });
+    }, 32, k, S));
 }
 
 // numpy.median: odd -> middle element; even -> float32 mean of the two middle ones.  The lower
 // middle is the largest value below the upper middle b unless b is duplicated across the middle.
-template <int MODE>
-__device__ float median_np(const float *cand, int n, float center, MadShared &S) {
-    const float b = select_kth<MODE>(cand, n, (unsigned)(n / 2), center, S);
+template <int MODE, class ZS>
+__device__ float median_np(const ZS &Z, int n, float center, MadShared &S) {
+    const float b = select_kth<MODE>(Z, n, (unsigned)(n / 2), center, S);
     if (n & 1) return b;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -125,13 +193,12 @@ __device__ float median_np(const float *cand, int n, float center, MadShared &S)
     }
     __syncthreads();
     unsigned c = 0, mk = 0;
-    for (int i = tid; i < n; i += 1024) {
-        const float v = mad_value<MODE>(cand, i, center);
-        if (v < b) {
+    for_values<MODE>(Z, n, center, [&](float v, bool valid) {
+        if (valid && v < b) {
             ++c;
             mk = max(mk, f2key(v));
         }
-    }
+    });
     for (int o = 32; o > 0; o >>= 1) {
         c += __shfl_xor(c, o);
         mk = max(mk, (unsigned)__shfl_xor((int)mk, o));
@@ -146,16 +213,29 @@ __device__ float median_np(const float *cand, int n, float center, MadShared &S)
     return (a + b) / 2.0f;
 }
 
-__global__ __launch_bounds__(1024) void mad_kernel(const float *__restrict__ cand, int n,
-                                                   float *out /* [median, mad] */) {
-    __shared__ MadShared S;
-    const float med = median_np<0>(cand, n, 0.f, S);
-    const float mad = median_np<1>(cand, n, med, S);
+template <class ZS>
+__device__ __forceinline__ void mad_body(const ZS &Z, int n, float *out, MadShared &S) {
+    const float med = median_np<0>(Z, n, 0.f, S);
+    const float mad = median_np<1>(Z, n, med, S);
     if (threadIdx.x == 0) {
         out[0] = med;
         out[1] = mad;
     }
 }
+
+__global__ __launch_bounds__(1024) void mad_kernel(const float *__restrict__ cand, int n,
+                                                   float *out /* [median, mad] */) {
+    __shared__ MadShared S;
+    if (n <= MAD_R * 1024) {
+        ZRegs Z;
+        Z.load(cand, n);
+        mad_body(Z, n, out, S);
+    } else {
+        ZGlobal Z{cand};
+        mad_body(Z, n, out, S);
+    }
+}
+
 
 // ---- trial scoring -------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
@@ -171,44 +251,55 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// partial[(blk*K + k)*4 + {0:count,1:sse,2:sy,3:syy}]
+// One block scores SCORE_PTS candidates against SCORE_KG trials: every thread keeps its
+// SCORE_PPT points in registers, sums its own inliers first and the wavefront reduces once per
+// trial; wavefronts write their own partial rows (no block barrier anywhere).
+// partial[((blk*SCORE_WAVES + w)*K + k)*4 + {0:count,1:sse,2:sy,3:syy}]
+constexpr int SCORE_PPT = 4;
+constexpr int SCORE_PTS = SCORE_THREADS * SCORE_PPT;
+constexpr int SCORE_KG = 8;
 __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
                                                               const float *__restrict__ models,
                                                               int K, const float *__restrict__ thr_ptr,
                                                               double *__restrict__ partial) {
-    __shared__ double red[SCORE_WAVES][4];
     const float thr = *thr_ptr;
-    const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
-    const bool valid = i < n;
-    float x = 0, y = 0, z = 0;
-    if (valid) {
-        x = cand[3 * (size_t)i];
-        y = cand[3 * (size_t)i + 1];
-        z = cand[3 * (size_t)i + 2];
-    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int k = 0; k < K; ++k) {
+    float x[SCORE_PPT], y[SCORE_PPT], z[SCORE_PPT];
+    bool valid[SCORE_PPT];
+#pragma unroll
+    for (int p = 0; p < SCORE_PPT; ++p) {
+        // consecutive lanes take consecutive points, as the summation order has always been
+        const int i = blockIdx.x * SCORE_PTS + (w * SCORE_PPT + p) * 64 + lane;
+        valid[p] = i < n;
+        x[p] = valid[p] ? cand[3 * (size_t)i] : 0.f;
+        y[p] = valid[p] ? cand[3 * (size_t)i + 1] : 0.f;
+        z[p] = valid[p] ? cand[3 * (size_t)i + 2] : 0.f;
+    }
+    const int k0 = blockIdx.y * SCORE_KG, k1 = min(k0 + SCORE_KG, K);
+    double *row = partial + ((size_t)(blockIdx.x * SCORE_WAVES + w) * K) * 4;
+    for (int k = k0; k < k1; ++k) {
         const float c0 = models[3 * k], c1 = models[3 * k + 1], b = models[3 * k + 2];
-        const float res = fabsf(z - plane_pred(x, y, c0, c1, b));
-        const bool in = valid && (res <= thr);
-        const double r = in ? (double)res : 0.0, zz = in ? (double)z : 0.0;
-        const double cnt = wave_sum(in ? 1.0 : 0.0);
-        const double sse = wave_sum(r * r);
-        const double sy = wave_sum(zz);
-        const double syy = wave_sum(zz * zz);
+        unsigned cnt = 0;
+        double sse = 0.0, sy = 0.0, syy = 0.0;
+#pragma unroll
+        for (int p = 0; p < SCORE_PPT; ++p) {
+            const float res = fabsf(z[p] - plane_pred(x[p], y[p], c0, c1, b));
+            const bool in = valid[p] && (res <= thr);
+            const double r = in ? (double)res : 0.0, zz = in ? (double)z[p] : 0.0;
+            cnt += (unsigned)__popcll(__ballot(in));
+            sse += r * r;
+            sy += zz;
+            syy += zz * zz;
+        }
+        sse = wave_sum(sse);
+        sy = wave_sum(sy);
+        syy = wave_sum(syy);
         if (lane == 0) {
-            red[w][0] = cnt;
-            red[w][1] = sse;
-            red[w][2] = sy;
-            red[w][3] = syy;
+            row[4 * k + 0] = (double)cnt;
+            row[4 * k + 1] = sse;
+            row[4 * k + 2] = sy;
+            row[4 * k + 3] = syy;
         }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            double s = 0.0;
-            for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][threadIdx.x];
-            partial[((size_t)blockIdx.x * K + k) * 4 + threadIdx.x] = s;
-        }
-        __syncthreads();
     }
 }
 
@@ -379,14 +470,17 @@ extern "C" int modest_plane_candidates(modest_ctx *ctx, const float *pts, int n,
     MODEST_REQUIRE(n_cand != nullptr, "n_cand is NULL");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    MODEST_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(int32_t), stream));
-    if (n == 0) return MODEST_OK;
+    if (n == 0) {   // otherwise the last block of the kernel writes the total
+        MODEST_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(int32_t), stream));
+        return MODEST_OK;
+    }
     MODEST_REQUIRE(pts && cand, "NULL buffer");
-    int rc = modest_ctx_reserve(ctx, 256);
+    const int nblk = (n + 1023) / 1024;
+    int rc = modest_ctx_reserve(ctx, compact_state_bytes(nblk));
     if (rc) return rc;
     unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
-    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, 16, stream));
-    candidates_kernel<<<(n + 1023) / 1024, 1024, 0, stream>>>(pts, n, stride, max_hs, xlo, xhi, ylo, yhi,
+    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, compact_state_bytes(nblk), stream));
+    candidates_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, max_hs, xlo, xhi, ylo, yhi,
                                                              cand, cand_idx, state, n_cand);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
@@ -421,8 +515,8 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     MODEST_REQUIRE(cand && models_host && n_inliers, "NULL buffer");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
-    const size_t b_models = arena_sz((size_t)K * 12 + 4), b_part = arena_sz((size_t)nb * K * 32);
+    const int nb = (n_cand + SCORE_PTS - 1) / SCORE_PTS, nrows = nb * SCORE_WAVES;
+    const size_t b_models = arena_sz((size_t)K * 12 + 4), b_part = arena_sz((size_t)nrows * K * 32);
     const size_t b_out = arena_sz((size_t)K * 32);
     int rc = modest_ctx_reserve(ctx, b_models + b_part + b_out);
     if (rc) return rc;
@@ -437,8 +531,9 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     for (int i = 0; i < K * 3; ++i) hm[i] = models_host[i];
     hm[K * 3] = thr;   // the kernel reads the threshold from device memory
     MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12 + 4, hipMemcpyHostToDevice, stream));
-    score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K, dm + 3 * K, dp);
-    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nb, K, dout);
+    score_kernel<<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K,
+                                                                                       dm + 3 * K, dp);
+    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nrows, K, dout);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -459,42 +554,44 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     MODEST_REQUIRE(cand && trip_host && thr_inout && models_out && n_inliers, "NULL buffer");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
-    // device: [trip K*3 i32 | thr pair 2 f32 | models K*3 f32 | partial | out K*4 f64]
-    const size_t b_trip = arena_sz((size_t)K * 12), b_thr = arena_sz(8), b_models = arena_sz((size_t)K * 12);
-    const size_t b_part = arena_sz((size_t)nb * K * 32), b_out = arena_sz((size_t)K * 32);
-    int rc = modest_ctx_reserve(ctx, b_trip + b_thr + b_models + b_part + b_out);
+    const int nb = (n_cand + SCORE_PTS - 1) / SCORE_PTS, nrows = nb * SCORE_WAVES;
+    // device: [out K*4 f64 | models K*3 f32 | thr pair 2 f32] (one block, one copy back) | trip | partial
+    const size_t n_out = (size_t)K * 32, n_models = (size_t)K * 12;
+    const size_t b_res = arena_sz(n_out + n_models + 8), b_trip = arena_sz((size_t)K * 12);
+    const size_t b_part = arena_sz((size_t)nrows * K * 32);
+    int rc = modest_ctx_reserve(ctx, b_res + b_trip + b_part);
     if (rc) return rc;
-    // pinned: [trip | thr(2) | out K*4 f64 | models K*3 f32]
-    const size_t h_trip = ((size_t)K * 12 + 63) & ~size_t(63), h_out = (size_t)K * 32;
-    rc = modest_ctx_reserve_pinned(ctx, h_trip + 64 + h_out + (size_t)K * 12);
+    // pinned: [trip | thr in (2) | results]
+    const size_t h_trip = ((size_t)K * 12 + 63) & ~size_t(63);
+    rc = modest_ctx_reserve_pinned(ctx, h_trip + 64 + n_out + n_models + 8);
     if (rc) return rc;
     char *d = ctx->scratch;
-    int *d_trip = reinterpret_cast<int *>(d);
-    float *d_thr = reinterpret_cast<float *>(d + b_trip);
-    float *d_models = reinterpret_cast<float *>(d + b_trip + b_thr);
-    double *d_part = reinterpret_cast<double *>(d + b_trip + b_thr + b_models);
-    double *d_out = reinterpret_cast<double *>(d + b_trip + b_thr + b_models + b_part);
+    double *d_out = reinterpret_cast<double *>(d);
+    float *d_models = reinterpret_cast<float *>(d + n_out);
+    float *d_thr = reinterpret_cast<float *>(d + n_out + n_models);
+    int *d_trip = reinterpret_cast<int *>(d + b_res);
+    double *d_part = reinterpret_cast<double *>(d + b_res + b_trip);
     int *h_tripp = reinterpret_cast<int *>(ctx->pinned);
-    float *h_thr = reinterpret_cast<float *>(ctx->pinned + h_trip);
-    double *h_outp = reinterpret_cast<double *>(ctx->pinned + h_trip + 64);
-    float *h_models = reinterpret_cast<float *>(ctx->pinned + h_trip + 64 + h_out);
+    float *h_thr_in = reinterpret_cast<float *>(ctx->pinned + h_trip);
+    char *h_res = ctx->pinned + h_trip + 64;
+    const double *h_outp = reinterpret_cast<const double *>(h_res);
+    const float *h_models = reinterpret_cast<const float *>(h_res + n_out);
+    const float *h_thr = reinterpret_cast<const float *>(h_res + n_out + n_models);
     for (int i = 0; i < 3 * K; ++i) h_tripp[i] = trip_host[i];
     MODEST_HIP_CHECK(hipMemcpyAsync(d_trip, h_tripp, (size_t)K * 12, hipMemcpyHostToDevice, stream));
     if (*thr_inout < 0.f) {   // residual threshold = MAD of the candidates, computed on the device
         mad_kernel<<<1, 1024, 0, stream>>>(cand, n_cand, d_thr);
     } else {
-        h_thr[0] = 0.f;
-        h_thr[1] = *thr_inout;
-        MODEST_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr, 8, hipMemcpyHostToDevice, stream));
+        h_thr_in[0] = 0.f;
+        h_thr_in[1] = *thr_inout;
+        MODEST_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr_in, 8, hipMemcpyHostToDevice, stream));
     }
     fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, d_trip, K, d_models);
-    score_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K, d_thr + 1, d_part);
-    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nb, K, d_out);
+    score_kernel<<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K,
+                                                                                       d_thr + 1, d_part);
+    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, d_out);
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(h_outp, d_out, h_out, hipMemcpyDeviceToHost, stream));
-    MODEST_HIP_CHECK(hipMemcpyAsync(h_models, d_models, (size_t)K * 12, hipMemcpyDeviceToHost, stream));
-    MODEST_HIP_CHECK(hipMemcpyAsync(h_thr, d_thr, 8, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipMemcpyAsync(h_res, d, n_out + n_models + 8, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     *thr_inout = h_thr[1];
     for (int k = 0; k < K; ++k) {
@@ -560,8 +657,10 @@ extern "C" int modest_plane_range_mask(modest_ctx *ctx, const float *pts, int n,
     MODEST_REQUIRE(plane4 && limit_range4 && n_kept, "NULL argument");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    MODEST_HIP_CHECK(hipMemsetAsync(n_kept, 0, sizeof(int32_t), stream));
-    if (n == 0) return MODEST_OK;
+    if (n == 0) {   // otherwise the last block of the kernel writes the total
+        MODEST_HIP_CHECK(hipMemsetAsync(n_kept, 0, sizeof(int32_t), stream));
+        return MODEST_OK;
+    }
     MODEST_REQUIRE(pts && mask, "NULL buffer");
     MaskParams P;
     P.n0 = plane4[0];
@@ -584,11 +683,12 @@ extern "C" int modest_plane_range_mask(modest_ctx *ctx, const float *pts, int n,
     P.lx1 = (float)limit_range4[1];
     P.ly0 = (float)limit_range4[2];
     P.ly1 = (float)limit_range4[3];
-    int rc = modest_ctx_reserve(ctx, 256);
+    const int nblk = (n + 1023) / 1024;
+    int rc = modest_ctx_reserve(ctx, compact_state_bytes(nblk));
     if (rc) return rc;
     unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
-    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, 16, stream));
-    mask_kernel<<<(n + 1023) / 1024, 1024, 0, stream>>>(pts, n, stride, P, mask, kept, kept_idx, state,
+    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, compact_state_bytes(nblk), stream));
+    mask_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, P, mask, kept, kept_idx, state,
                                                        n_kept);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;

@@ -18,9 +18,10 @@ __device__ __forceinline__ float cs_unkey(unsigned k) {
     return __uint_as_float(u);
 }
 
-// k-th smallest (0-based) pp among the members
-__device__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n, unsigned k,
-                           unsigned *hist /* 2048 */, unsigned *wsum /* 4 */, unsigned *sel /* 2 */) {
+// k-th smallest (0-based) of the n values whose order-preserving keys key_at(i) yields
+template <class KeyAt>
+__device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k, unsigned *hist /* 2048 */,
+                                                unsigned *wsum /* 4 */, unsigned *sel /* 2 */) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned prefix = 0, mask = 0;
     const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
@@ -30,7 +31,7 @@ __device__ float cs_select(const float *__restrict__ pp, const int *__restrict__
         for (unsigned b = tid; b < 2048u; b += CS_THREADS) hist[b] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += CS_THREADS) {
-            const unsigned key = cs_key(pp[mem[i]]);
+            const unsigned key = key_at(i);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1u)], 1u);
         }
         __syncthreads();
@@ -64,6 +65,12 @@ __device__ float cs_select(const float *__restrict__ pp, const int *__restrict__
         __syncthreads();
     }
     return cs_unkey(prefix);
+}
+
+// k-th smallest (0-based) pp among the members
+__device__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n, unsigned k,
+                           unsigned *hist, unsigned *wsum, unsigned *sel) {
+    return cs_select_keys([=](int i) { return cs_key(pp[mem[i]]); }, n, k, hist, wsum, sel);
 }
 
 // numpy.percentile(x, q) ('linear') on float32 data of size n works in float32: virtual index

@@ -69,7 +69,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
                                          neighbor_type=g.neighbor_type, affinity_type=g.affinity_type,
                                          intensity=inten)
         labels_dev[kept_long] = lab_kept          # device copy for the cluster statistics (plumbing)
-        labels[kept_idx.cpu().numpy()] = lab_kept.cpu().numpy()
+        labels = labels_dev.cpu().numpy().astype(int)
     labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
                                     plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
                                     pp_dev=pp_dev, labels_dev=labels_dev, **args.filtering)

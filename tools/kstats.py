@@ -1,0 +1,12 @@
+"""Per-scan GPU time by kernel from a rocprofv3 --kernel-trace --stats CSV (scan count = pp3_join launches)."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+ns = int([r for r in rows if 'pp3_join' in r['Name']][0]['Calls'])
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:top]:
+    print(f"{r['Name'][:58]:58s} calls/scan {int(r['Calls']) / ns:5.1f}  avg {float(r['AverageNs']) / 1e3:7.1f} us"
+          f"  per-scan {float(r['TotalDurationNs']) / ns / 1e3:7.1f} us")
+print(f"total {tot / ns / 1e3:.1f} us/scan over {ns} scans, {sum(int(r['Calls']) for r in rows) / ns:.1f} launches/scan")

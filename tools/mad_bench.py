@@ -1,0 +1,15 @@
+"""GPU box: time the MAD-threshold kernel alone on a realistic candidate set (run under rocprofv3)."""
+import numpy as np
+import torch
+
+from modest_amd import ops, synth
+from modest_amd.utils.pointcloud_utils import to_device
+
+scan = synth.make_scan(3)
+pts = to_device(np.ascontiguousarray(scan.live_raw, dtype=np.float32))
+cand, _ = ops.plane_candidates(pts, -1.5, ((-20, 70), (-20, 20)))
+print("candidates", cand.shape[0])
+vals = [float(ops.mad_threshold(cand)) for _ in range(200)]
+z = cand[:, 2].cpu().numpy()
+ref = np.median(np.abs(z - np.median(z)))
+print("mad", vals[0], "numpy", float(ref), "equal", vals[0] == float(ref), "stable", len(set(vals)) == 1)
