@@ -474,27 +474,30 @@ __device__ __forceinline__ unsigned long long d2key(double v) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
 }
 
-// every thread keeps one point and walks the boxes (the loads happen once); a wavefront that
-// has a point inside a box posts its maximum with one atomic
-__global__ __launch_bounds__(256) void lowest_kernel(const double *__restrict__ pts, int n,
-                                                     const Box6 *__restrict__ boxes, int n_boxes,
-                                                     unsigned long long *__restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < n;
-    const double px = valid ? pts[3 * (size_t)i] : 0.0, py = valid ? pts[3 * (size_t)i + 1] : 0.0;
-    const double pz = valid ? pts[3 * (size_t)i + 2] : 0.0;
-    for (int k = 0; k < n_boxes; ++k) {
-        const Box6 b = boxes[k];
-        const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
-        const double dx = px - b.cx, dz = pz - b.cz;
+// grid (LOW_SPLIT point slices, boxes): a block scans its slice of the points for one box, reduces
+// in registers / LDS and posts one atomic.  (One atomic per wavefront with a point inside made
+// the 64-bit atomics on a handful of addresses the whole cost of the kernel.)
+constexpr int LOW_SPLIT = 8;
+__global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__ pts, int n,
+                                                      const Box6 *__restrict__ boxes, int n_boxes,
+                                                      unsigned long long *__restrict__ out) {
+    const Box6 b = boxes[blockIdx.y];
+    const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
+    double best = -INFINITY;
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += LOW_SPLIT * 1024) {
+        const double dx = pts[3 * (size_t)i] - b.cx, dz = pts[3 * (size_t)i + 2] - b.cz;
         // [dx dz] @ [[c,-s],[s,c]]^T
         const double q0 = fma(dz, ns, dx * b.c);
         const double q1 = fma(dz, b.c, dx * b.s);
-        const bool in = valid && q0 > -hl && q0 < hl && q1 > -hw && q1 < hw;
-        if (__ballot(in) == 0) continue;
-        double best = in ? py : -INFINITY;
-        for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(out + k, d2key(best));
+        if (q0 > -hl && q0 < hl && q1 > -hw && q1 < hw) best = fmax(best, pts[3 * (size_t)i + 1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+    __shared__ double red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) best = fmax(best, red[k]);
+        if (best > -INFINITY) atomicMax(out + blockIdx.y, d2key(best));
     }
 }
 
@@ -659,7 +662,8 @@ extern "C" int modest_lowest_point(modest_ctx *ctx, const double *pts_rect, int 
     for (int i = 0; i < 6 * n_boxes; ++i) h_box[i] = boxes6_host[i];
     MODEST_HIP_CHECK(hipMemcpyAsync(d_box, h_box, (size_t)n_boxes * sizeof(Box6), hipMemcpyHostToDevice, stream));
     MODEST_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)n_boxes * 8, stream));
-    if (n > 0) lowest_kernel<<<(n + 255) / 256, 256, 0, stream>>>(pts_rect, n, d_box, n_boxes, d_out);
+    if (n > 0)
+        lowest_kernel<<<dim3(LOW_SPLIT, n_boxes), 1024, 0, stream>>>(pts_rect, n, d_box, n_boxes, d_out);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_boxes * 8, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));

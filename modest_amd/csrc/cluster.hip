@@ -161,30 +161,37 @@ __device__ __forceinline__ double dist2(const float4 &a, const float4 &b) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-// Sweep helper: the three cell rows around (cx,cy) as contiguous [s,e) ranges.
+// Sweep helper: the three cell rows around (cx,cy) as contiguous [s,e) ranges; rows outside the
+// grid are empty.  Fixed size and constant indices only: a row count with indexed stores put the
+// struct into scratch memory, and that alone cost every sweep kernel 25 us.
 struct Rows {
+    static constexpr int n = 3;
     unsigned s[3], e[3];
-    int n;
 };
 __device__ __forceinline__ Rows rows_of(const float4 &q, const CGrid *g, const unsigned *__restrict__ start) {
     const int cx = cg_coord(q.x, g->ox, g->inv_c), cy = cg_coord(q.y, g->oy, g->inv_c);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, CG - 1);
     Rows r;
-    r.n = 0;
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, CG - 1); ++yy) {
-        r.s[r.n] = start[yy * CG + x0];
-        r.e[r.n] = start[yy * CG + x1 + 1];
-        ++r.n;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int yy = cy - 1 + d;
+        const bool ok = yy >= 0 && yy < CG;
+        r.s[d] = ok ? start[yy * CG + x0] : 0u;
+        r.e[d] = ok ? start[yy * CG + x1 + 1] : 0u;
     }
     return r;
 }
 
-// ---- pass A: k-th neighbour squared distance (wave-level radix select on the
-// float64 bit pattern; distances are recomputed in each of the 8 byte passes) --
+// ---- pass A: k-th neighbour squared distance ------------------------------------------
+// Wave-level radix select.  (float)d2 is a monotone map of the float64 distances, so the k-th
+// smallest float32 key belongs to the k-th smallest distance: four byte passes over the float32
+// keys find it (instead of eight over the float64 bit pattern; the distances are recomputed in
+// every pass), and the exact float64 value is then taken from the candidates that share the key
+// -- one more pass when the key is unique, a min/count loop over the ties otherwise.
 __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restrict__ sorted, int n,
                                                            const CGrid *g,
                                                            const unsigned *__restrict__ start, int k,
-                                                           double r2, double *__restrict__ kthS) {
+                                                           double r2, double *__restrict__ kthS, int dbg) {
     __shared__ unsigned hist_all[WPB][256];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
@@ -192,20 +199,24 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
     unsigned *hist = hist_all[w];
     const float4 q = sorted[s];
     const Rows R = rows_of(q, g, start);
-    unsigned long long prefix = 0, mask = 0;
+    if (dbg == 1) {
+        if (lane == 0) kthS[s] = (double)((R.e[0] - R.s[0]) + (R.e[1] - R.s[1]) + (R.e[2] - R.s[2]));
+        return;
+    }
+    unsigned prefix = 0, mask = 0, cntF = 0;
     int kk = k - 1;
-    double result = D_INF;
-    bool done = false;
-    for (int shift = 56; shift >= 0 && !done; shift -= 8) {
+    bool enough = true;
+    for (int shift = 24; shift >= 0; shift -= 8) {
         for (int b = lane; b < 256; b += 64) hist[b] = 0;
         __builtin_amdgcn_wave_barrier();
-        for (int r = 0; r < R.n; ++r)
+    #pragma unroll
+    for (int r = 0; r < R.n; ++r)
             for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
                 if ((int)j == s) continue;
                 const double d2 = dist2(q, sorted[j]);
                 if (d2 <= r2) {
-                    const unsigned long long key = (unsigned long long)__double_as_longlong(d2);
-                    if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+                    const unsigned key = __float_as_uint((float)d2);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
                 }
             }
         __builtin_amdgcn_wave_barrier();
@@ -219,33 +230,69 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
             if (lane >= o) inc += v;
         }
         const unsigned total = __shfl(inc, 63);
-        if (shift == 56 && total < (unsigned)k) {
-            done = true;   // fewer than k neighbours inside the radius
+        if ((shift == 24 && total < (unsigned)k) || dbg == 2) {
+            enough = false;   // fewer than k neighbours inside the radius
             break;
         }
         const unsigned long long bal = __ballot(inc > (unsigned)kk);
         const int owner = __ffsll((long long)bal) - 1;
         const unsigned excl = __shfl(inc - mine, owner);
-        const unsigned o0 = __shfl(c0, owner), o1 = __shfl(c1, owner), o2 = __shfl(c2, owner);
+        const unsigned o0 = __shfl(c0, owner), o1 = __shfl(c1, owner), o2 = __shfl(c2, owner),
+                       o3 = __shfl(c3, owner);
         int rem = kk - (int)excl;
         int bin = 4 * owner;
+        cntF = o0;
         if (rem >= (int)o0) {
             rem -= o0;
             ++bin;
+            cntF = o1;
             if (rem >= (int)o1) {
                 rem -= o1;
                 ++bin;
+                cntF = o2;
                 if (rem >= (int)o2) {
                     rem -= o2;
                     ++bin;
+                    cntF = o3;
                 }
             }
         }
         kk = rem;
-        prefix |= (unsigned long long)bin << shift;
-        mask |= 255ULL << shift;
-        if (shift == 0) result = __longlong_as_double((long long)prefix);
+        prefix |= (unsigned)bin << shift;
+        mask |= 255u << shift;
         __builtin_amdgcn_wave_barrier();
+    }
+    double result = D_INF;
+    if (enough && dbg != 3) {
+        // kk = rank (0-based) among the cntF in-radius candidates whose float32 key is `prefix`
+        double lo = -1.0;
+        for (;;) {
+            double m = D_INF;
+        #pragma unroll
+    for (int r = 0; r < R.n; ++r)
+                for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+                    if ((int)j == s) continue;
+                    const double d2 = dist2(q, sorted[j]);
+                    if (d2 <= r2 && d2 > lo && __float_as_uint((float)d2) == prefix) m = fmin(m, d2);
+                }
+            for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
+            if (cntF == 1) {
+                result = m;
+                break;
+            }
+            unsigned c = 0;
+        #pragma unroll
+    for (int r = 0; r < R.n; ++r)
+                for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64)
+                    if ((int)j != s && dist2(q, sorted[j]) == m) ++c;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (kk < (int)c || c == 0) {
+                result = m;
+                break;
+            }
+            kk -= (int)c;
+            lo = m;
+        }
     }
     if (lane == 0) kthS[s] = result;
 }
@@ -298,6 +345,7 @@ __global__ __launch_bounds__(64 * WPB) void degree_kernel(const float4 *__restri
     const double kq = kthS[s];
     const Rows R = rows_of(q, g, start);
     unsigned cnt = 0;
+#pragma unroll
     for (int r = 0; r < R.n; ++r)
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j == s) continue;
@@ -361,6 +409,7 @@ __global__ __launch_bounds__(64 * WPB) void hook_min_kernel(const float4 *__rest
     const int me = sidx[s];
     const Rows R = rows_of(q, g, start);
     int best = me;
+#pragma unroll
     for (int r = 0; r < R.n; ++r)
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j == s || !coreS[j]) continue;
@@ -385,6 +434,7 @@ __global__ __launch_bounds__(64 * WPB) void union_kernel(const float4 *__restric
     const double kq = kthS[s];
     const int me = sidx[s];
     const Rows R = rows_of(q, g, start);
+#pragma unroll
     for (int r = 0; r < R.n; ++r)
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j <= s) continue;          // each unordered pair once
@@ -424,6 +474,7 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
     const double kq = kthS[s];
     const Rows R = rows_of(q, g, start);
     int best = 0x7fffffff;
+#pragma unroll
     for (int r = 0; r < R.n; ++r)
         for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
             if ((int)j == s || !coreS[j]) continue;
@@ -456,6 +507,7 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
     const double kq = kthS[s];
     const Rows R = rows_of(q, g, start);
     unsigned total = 0;
+#pragma unroll
     for (int r = 0; r < R.n; ++r)
         for (unsigned base = R.s[r]; base < R.e[r]; base += 64) {   // wave-uniform trip count
             const unsigned j = base + lane;
@@ -756,6 +808,15 @@ __global__ void gather_f32(const float *__restrict__ src, const int *__restrict_
 }
 }  // namespace
 
+static int knn_dbg() {
+    static const int v = getenv("MODEST_KNN_DBG") ? atoi(getenv("MODEST_KNN_DBG")) : 0;
+    return v;
+}
+static int hook_rounds() {
+    static const int v = getenv("MODEST_HOOK_ROUNDS") ? atoi(getenv("MODEST_HOOK_ROUNDS")) : 3;
+    return v;
+}
+
 extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const float *pp,
                                         const float *intensity, int n, int neighbor_type, int affinity_type,
                                         int k_neighbors, double radius, double eps, int min_samples,
@@ -853,7 +914,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
             dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels);
         } else {
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
-            for (int round = 0; round < 3; ++round) {
+            for (int round = 0; round < hook_rounds(); ++round) {
                 hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
                 flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
             }
@@ -873,11 +934,11 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
         return MODEST_OK;
     }
     if (ep.use_knn || kth_d2)
-        knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
+        knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS, knn_dbg());
     degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
                                                   overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
-    for (int round = 0; round < 3; ++round) {   // accelerators only: union_adj_kernel makes the result exact
+    for (int round = 0; round < hook_rounds(); ++round) {   // accelerators only: union_adj_kernel makes the result exact
         hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
         flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
     }

@@ -385,8 +385,8 @@ struct JoinShared {
     unsigned short ctab[V3_W * (V3_W + 1)];   // live points of window row r before column cc
     unsigned segStart[V3_W], rowBase[V3_W + 1];
     unsigned bandA[V3_TS], bandB[V3_TS], bandSlow[V3_TS];
-    unsigned nBands, ticket, sliceId;
-    uint4 slice;
+    unsigned nBands, ticket, sliceId, nextId;
+    uint4 slice, nextSlice;
     unsigned long long prof[8], prev[8], tlast;   // PROF builds only
 };
 
@@ -408,10 +408,8 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     const unsigned nSlices = ctrl3[0];
     // per-lane constants of the traversal-segmented popcount: lane t < T owns traversal t;
     // selk = all ones if bit k of t is CLEAR (mask of traversal t = AND_k (B_k ^ selk))
-    const unsigned sel0 = (lane & 1) ? 0u : ~0u, sel1 = (lane & 2) ? 0u : ~0u;
-    const unsigned sel2 = (lane & 4) ? 0u : ~0u, sel3 = (lane & 8) ? 0u : ~0u, sel4 = (lane & 16) ? 0u : ~0u;
-    const unsigned cshift = (lane & 1) * 16;
-    const unsigned laneWord = (unsigned)lane >> 1;
+    // (recomputed for every chunk from an opaque copy of the lane id: hoisted out of the slice loop
+    // they are seven registers the allocator spills)
 
     constexpr bool prof = PROF;
     const unsigned laneGroups = ((dbg >> 8) & 0xff) ? ((dbg >> 8) & 0xff) : V3_LANE_GROUPS;
@@ -446,8 +444,9 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         const uint4 sl = S.slice;
         if (tid < V3_NC) S.cursor[tid] = 0;
         __syncthreads();   // everyone holds the slice: thread 0 may overwrite the header below
-        unsigned nextId = 0;
-        if (tid == 0) nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the loads below
+        // the next slice header goes through LDS, not registers: values that live across the whole
+        // slice get spilled, and a kernel that touches scratch memory at all pays for it at dispatch
+        if (tid == 0) S.nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the loads below
         int ttx, tty;
         if (sl.x < (unsigned)V3_NBLK) {
             pp3_tile_of((int)sl.x, &ttx, &tty);
@@ -483,8 +482,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             const int pk = __float_as_int(h4[u].w);
             if (pk >= 0) atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u);
         }
-        uint4 nextSl = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0 && nextId < nSlices) nextSl = slices[nextId];
+        if (tid == 0 && S.nextId < nSlices) S.nextSlice = slices[S.nextId];
         __syncthreads();
         PP3_TICK(0)
         // ---- (b) cell offsets, window tables, bands -----------------------------------
@@ -591,6 +589,12 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 const int pk = valid ? __float_as_int(h.w) : -1;
                 const int key = pk & (V3_NC - 1);
                 const unsigned trv = (unsigned)(pk >> 16) & 31u;
+                int lq = lane;
+                asm volatile("" : "+v"(lq));
+                const unsigned sel0 = (lq & 1) ? 0u : ~0u, sel1 = (lq & 2) ? 0u : ~0u;
+                const unsigned sel2 = (lq & 4) ? 0u : ~0u, sel3 = (lq & 8) ? 0u : ~0u, sel4 = (lq & 16) ? 0u : ~0u;
+                const unsigned cshift = (lq & 1) * 16;
+                const unsigned laneWord = (unsigned)lq >> 1;
                 // traversal segment masks: lane t keeps the lanes whose record belongs to traversal t
                 unsigned long long seg = __ballot(valid);
                 {
@@ -756,8 +760,8 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             for (int k = 0; k < 5; ++k) S.prev[k] = S.prof[k];
         }
         if (tid == 0) {
-            S.sliceId = nextId;
-            S.slice = nextSl;
+            S.sliceId = S.nextId;
+            S.slice = S.nextSlice;
         }
     }
     if (prof && tid == 0) {
