@@ -9,6 +9,7 @@ the repository snapshot to the GPU box.
 from __future__ import annotations
 
 import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -57,25 +58,46 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     hdrs = sorted(CSRC.glob("*.h")) + sorted((ROOT / "include").glob("*.h"))
     stamp = LIBDIR / "build.stamp"
     digest = _digest(srcs + hdrs)
-    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == digest:
+    if (not force and LIB.exists() and (LIBDIR / "kernel_resources.json").exists() and stamp.exists()
+            and stamp.read_text() == digest):
         return LIB
     OBJDIR.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
 
+    resources = {}
+
     def compile_one(src: Path) -> Path:
         obj = OBJDIR / (src.stem + ".o")
-        cmd = [hipcc, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        # the resource remarks (registers, scratch, LDS per kernel) are kept next to the library:
+        # a kernel that uses scratch memory pays ~25 us at dispatch, tests/ assert there is none
+        cmd = [hipcc, *CXXFLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[modest_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        rest = []
+        cur = None
+        for line in r.stderr.splitlines():
+            if "[-Rpass-analysis=kernel-resource-usage]" not in line:
+                if not rest or rest[-1] != "skip":
+                    rest.append(line)
+                continue
+            body = line.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+            key, _, val = body.partition(":")
+            if key == "Function Name":
+                cur = resources.setdefault(val.strip(), {"file": src.name})
+            elif cur is not None and val.strip().lstrip("-").isdigit():
+                cur[key.strip()] = int(val.strip())
+        # drop the source-context lines clang prints under every remark
+        diag = [l for l in rest if l.strip() and not l.lstrip().startswith(("|", "^")) and not l.lstrip()[:1].isdigit()]
+        if verbose and diag:
+            print("\n".join(diag), file=sys.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
+    (LIBDIR / "kernel_resources.json").write_text(json.dumps(resources, indent=1, sort_keys=True))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     if verbose:
         print("[modest_amd.build]", " ".join(cmd), flush=True)

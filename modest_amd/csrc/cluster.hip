@@ -191,7 +191,7 @@ __device__ __forceinline__ Rows rows_of(const float4 &q, const CGrid *g, const u
 __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restrict__ sorted, int n,
                                                            const CGrid *g,
                                                            const unsigned *__restrict__ start, int k,
-                                                           double r2, double *__restrict__ kthS, int dbg) {
+                                                           double r2, double *__restrict__ kthS) {
     __shared__ unsigned hist_all[WPB][256];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
@@ -199,10 +199,6 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
     unsigned *hist = hist_all[w];
     const float4 q = sorted[s];
     const Rows R = rows_of(q, g, start);
-    if (dbg == 1) {
-        if (lane == 0) kthS[s] = (double)((R.e[0] - R.s[0]) + (R.e[1] - R.s[1]) + (R.e[2] - R.s[2]));
-        return;
-    }
     unsigned prefix = 0, mask = 0, cntF = 0;
     int kk = k - 1;
     bool enough = true;
@@ -230,7 +226,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
             if (lane >= o) inc += v;
         }
         const unsigned total = __shfl(inc, 63);
-        if ((shift == 24 && total < (unsigned)k) || dbg == 2) {
+        if (shift == 24 && total < (unsigned)k) {
             enough = false;   // fewer than k neighbours inside the radius
             break;
         }
@@ -263,7 +259,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
         __builtin_amdgcn_wave_barrier();
     }
     double result = D_INF;
-    if (enough && dbg != 3) {
+    if (enough) {
         // kk = rank (0-based) among the cntF in-radius candidates whose float32 key is `prefix`
         double lo = -1.0;
         for (;;) {
@@ -808,14 +804,9 @@ __global__ void gather_f32(const float *__restrict__ src, const int *__restrict_
 }
 }  // namespace
 
-static int knn_dbg() {
-    static const int v = getenv("MODEST_KNN_DBG") ? atoi(getenv("MODEST_KNN_DBG")) : 0;
-    return v;
-}
-static int hook_rounds() {
-    static const int v = getenv("MODEST_HOOK_ROUNDS") ? atoi(getenv("MODEST_HOOK_ROUNDS")) : 3;
-    return v;
-}
+// Rounds of min-root hooking before the exact union pass.  Measured on a 9 k-point scan
+// (hook + flatten 14 us per round): union_adj takes 305 / 220 / 59 / 19 us after 0 / 1 / 2 / 3 rounds.
+constexpr int HOOK_ROUNDS = 3;
 
 extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const float *pp,
                                         const float *intensity, int n, int neighbor_type, int affinity_type,
@@ -914,7 +905,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
             dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels);
         } else {
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
-            for (int round = 0; round < hook_rounds(); ++round) {
+            for (int round = 0; round < HOOK_ROUNDS; ++round) {
                 hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
                 flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
             }
@@ -934,11 +925,11 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
         return MODEST_OK;
     }
     if (ep.use_knn || kth_d2)
-        knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS, knn_dbg());
+        knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
     degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
                                                   overflow);
     uf_init<<<nb, 256, 0, stream>>>(parent, n);
-    for (int round = 0; round < hook_rounds(); ++round) {   // accelerators only: union_adj_kernel makes the result exact
+    for (int round = 0; round < HOOK_ROUNDS; ++round) {   // accelerators only: union_adj_kernel makes the result exact
         hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
         flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
     }

@@ -8,8 +8,8 @@
 // at most 24 vertices, fan area); this file is compiled with
 // -ffp-contract=off so no multiply-add is fused.  K (boxes per scan) is tens,
 // so the design goal here is exactness and one launch, not bandwidth:
-// one lane per (a,b) pair, 64-lane wavefront rows, no LDS needed for the IoU
-// matrix; the NMS mask kernel stages its 64 column boxes in LDS.
+// one lane per (a,b) pair, 64-lane wavefront blocks, the clipped polygon of each
+// pair in an LDS column; the NMS mask kernel also stages its 64 column boxes in LDS.
 #include "common.h"
 #include "trig_f32.h"
 #include <vector>
@@ -73,7 +73,16 @@ __device__ __forceinline__ void rot_center(const Pt &ctr, float c, float s, Pt &
     p.y = ny;
 }
 
-__device__ float box_overlap(const float *a, const float *b) {
+// The clipped polygon (at most 24 vertices) and its polar angles live in LDS, one column per lane
+// ([vertex][lane], conflict-free): as indexed per-thread arrays they went to scratch memory, which a
+// kernel pays for at dispatch even before the first access.
+constexpr int POLY_MAX = 24;
+struct PolyLds {
+    float x[POLY_MAX][NMS_TPB], y[POLY_MAX][NMS_TPB], ang[POLY_MAX][NMS_TPB];
+};
+
+__device__ float box_overlap(const float *a, const float *b, PolyLds &L) {
+    const int ln = threadIdx.x & (NMS_TPB - 1);
     const float a_ang = a[6], b_ang = b[6];
     const float a_dxh = a[3] / 2, b_dxh = b[3] / 2, a_dyh = a[4] / 2, b_dyh = b[4] / 2;
     const float ax1 = a[0] - a_dxh, ay1 = a[1] - a_dyh, ax2 = a[0] + a_dxh, ay2 = a[1] + a_dyh;
@@ -91,7 +100,6 @@ __device__ float box_overlap(const float *a, const float *b) {
     A[4] = A[0];
     B[4] = B[0];
 
-    Pt poly[24];
     Pt center{0.f, 0.f};
     int cnt = 0;
     for (int i = 0; i < 4; ++i)
@@ -100,7 +108,9 @@ __device__ float box_overlap(const float *a, const float *b) {
             if (seg_intersection(A[i + 1], A[i], B[j + 1], B[j], x)) {
                 center.x = center.x + x.x;
                 center.y = center.y + x.y;
-                poly[cnt++] = x;
+                L.x[cnt][ln] = x.x;
+                L.y[cnt][ln] = x.y;
+                ++cnt;
             }
         }
     // the containment tests rotate by the opposite angle: cos(-h), sin(-h)
@@ -110,43 +120,50 @@ __device__ float box_overlap(const float *a, const float *b) {
         if (in_box2d(a, a_ncos, a_nsin, B[k])) {
             center.x = center.x + B[k].x;
             center.y = center.y + B[k].y;
-            poly[cnt++] = B[k];
+            L.x[cnt][ln] = B[k].x;
+            L.y[cnt][ln] = B[k].y;
+            ++cnt;
         }
         if (in_box2d(b, b_ncos, b_nsin, A[k])) {
             center.x = center.x + A[k].x;
             center.y = center.y + A[k].y;
-            poly[cnt++] = A[k];
+            L.x[cnt][ln] = A[k].x;
+            L.y[cnt][ln] = A[k].y;
+            ++cnt;
         }
     }
     center.x /= cnt;
     center.y /= cnt;
 
     // bubble sort by polar angle around the centroid, descending swaps as in the reference
-    float ang[24];
-    for (int i = 0; i < cnt; ++i) ang[i] = modest::atan2_f32(poly[i].y - center.y, poly[i].x - center.x);
+    for (int i = 0; i < cnt; ++i) L.ang[i][ln] = modest::atan2_f32(L.y[i][ln] - center.y, L.x[i][ln] - center.x);
     for (int j = 0; j < cnt - 1; ++j)
-        for (int i = 0; i < cnt - j - 1; ++i)
-            if (ang[i] > ang[i + 1]) {
-                const Pt t = poly[i];
-                poly[i] = poly[i + 1];
-                poly[i + 1] = t;
-                const float ta = ang[i];
-                ang[i] = ang[i + 1];
-                ang[i + 1] = ta;
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            const float a0 = L.ang[i][ln], a1 = L.ang[i + 1][ln];
+            if (a0 > a1) {
+                const float tx = L.x[i][ln], ty = L.y[i][ln];
+                L.x[i][ln] = L.x[i + 1][ln];
+                L.y[i][ln] = L.y[i + 1][ln];
+                L.x[i + 1][ln] = tx;
+                L.y[i + 1][ln] = ty;
+                L.ang[i][ln] = a1;
+                L.ang[i + 1][ln] = a0;
             }
+        }
     float area = 0.f;
+    const float x0 = cnt > 0 ? L.x[0][ln] : 0.f, y0 = cnt > 0 ? L.y[0][ln] : 0.f;
     for (int k = 0; k < cnt - 1; ++k) {
-        const Pt u{poly[k].x - poly[0].x, poly[k].y - poly[0].y};
-        const Pt v{poly[k + 1].x - poly[0].x, poly[k + 1].y - poly[0].y};
+        const Pt u{L.x[k][ln] - x0, L.y[k][ln] - y0};
+        const Pt v{L.x[k + 1][ln] - x0, L.y[k + 1][ln] - y0};
         area += cross2(u, v);
     }
     return fabsf(area) / 2.0f;
 }
 
-__device__ __forceinline__ float iou_bev(const float *a, const float *b) {
+__device__ __forceinline__ float iou_bev(const float *a, const float *b, PolyLds &L) {
     const float sa = a[3] * a[4];
     const float sb = b[3] * b[4];
-    const float so = box_overlap(a, b);
+    const float so = box_overlap(a, b, L);
     return so / fmaxf(sa + sb - so, IOU_EPS);
 }
 
@@ -161,9 +178,10 @@ __device__ __forceinline__ float iou_normal(const float *a, const float *b) {
 }
 
 template <bool IOU>
-__global__ __launch_bounds__(256) void pair_kernel(const float *__restrict__ A, int na,
-                                                   const float *__restrict__ B, int nb,
-                                                   float *__restrict__ out) {
+__global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__ A, int na,
+                                                       const float *__restrict__ B, int nb,
+                                                       float *__restrict__ out) {
+    __shared__ PolyLds L;
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (long long)na * nb) return;
     const int ia = (int)(id / nb), ib = (int)(id % nb);
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(256) void pair_kernel(const float *__restrict__ A, 
         a[k] = A[(size_t)ia * 7 + k];
         b[k] = B[(size_t)ib * 7 + k];
     }
-    out[id] = IOU ? iou_bev(a, b) : box_overlap(a, b);
+    out[id] = IOU ? iou_bev(a, b, L) : box_overlap(a, b, L);
 }
 
 // 64x64 tile suppression words (src/iou3d_nms_kernel.cu:267-311, :328-372).
@@ -185,6 +203,7 @@ __global__ __launch_bounds__(NMS_TPB) void nms_mask_kernel(int n, float thresh,
     const int row_size = min(n - row_start * NMS_TPB, NMS_TPB);
     const int col_size = min(n - col_start * NMS_TPB, NMS_TPB);
     __shared__ float sb[NMS_TPB * 7];
+    __shared__ PolyLds L;
     if ((int)threadIdx.x < col_size)
         for (int k = 0; k < 7; ++k)
             sb[threadIdx.x * 7 + k] = boxes[(size_t)(NMS_TPB * col_start + threadIdx.x) * 7 + k];
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(NMS_TPB) void nms_mask_kernel(int n, float thresh,
         unsigned long long t = 0;
         int start = (row_start == col_start) ? threadIdx.x + 1 : 0;
         for (int i = start; i < col_size; ++i) {
-            const float v = ROTATED ? iou_bev(c, sb + i * 7) : iou_normal(c, sb + i * 7);
+            const float v = ROTATED ? iou_bev(c, sb + i * 7, L) : iou_normal(c, sb + i * 7);
             if (v > thresh) t |= 1ULL << i;
         }
         const int col_blocks = (n + NMS_TPB - 1) / NMS_TPB;
@@ -209,11 +228,11 @@ int pair_launch(bool iou, const float *a, int na, const float *b, int nb, float 
     if (na == 0 || nb == 0) return MODEST_OK;
     MODEST_REQUIRE(a && b && out, "NULL buffer");
     const long long total = (long long)na * nb;
-    const int blocks = (int)((total + 255) / 256);
+    const int blocks = (int)((total + NMS_TPB - 1) / NMS_TPB);
     if (iou)
-        pair_kernel<true><<<blocks, 256, 0, as_stream(stream)>>>(a, na, b, nb, out);
+        pair_kernel<true><<<blocks, NMS_TPB, 0, as_stream(stream)>>>(a, na, b, nb, out);
     else
-        pair_kernel<false><<<blocks, 256, 0, as_stream(stream)>>>(a, na, b, nb, out);
+        pair_kernel<false><<<blocks, NMS_TPB, 0, as_stream(stream)>>>(a, na, b, nb, out);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }

@@ -29,6 +29,22 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.modest_device_count(), int)
 
 
+def test_hot_kernels_use_no_scratch_memory():
+    """A gfx950 kernel that touches scratch memory (spills, indexed per-thread arrays) pays ~25 us
+    at dispatch; the build records hipcc's per-kernel resource remarks, every kernel on the
+    default path must report ScratchSize 0."""
+    import json
+    from modest_amd import build
+    build.build(verbose=False)
+    res = json.load(open(os.path.join(os.path.dirname(build.LIB), "kernel_resources.json")))
+    assert len(res) > 40
+    # not on the default path: one-lane-per-angle fits (variance_to_edge, clusters > 90 k points), profiling build
+    allowed = ("variance_kernel", "closeness_kernel", "pp3_joinILb1")
+    bad = {k: v["ScratchSize [bytes/lane]"] for k, v in res.items()
+           if v.get("ScratchSize [bytes/lane]", 0) > 0 and not any(a in k for a in allowed)}
+    assert not bad, bad
+
+
 def test_no_cpu_fallback_without_device():
     from modest_amd import _lib
     lib = _lib.load()
