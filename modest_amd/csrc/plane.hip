@@ -43,7 +43,12 @@ __global__ __launch_bounds__(1024) void candidates_kernel(const float *__restric
     }
 }
 
-// ---- exact k-th smallest of float32 values (radix select, one workgroup) -----
+// ---- MAD(z): median and median absolute deviation, one workgroup ---------------------
+// One workgroup = one CU, and this kernel is bound by that CU's instruction issue (64 lanes x
+// 1 instruction per cycle for 16 wavefronts), so everything is about instructions per element
+// and pass: the order-preserving keys are computed once per median and kept in registers, a
+// select is three 11/11/10-bit histogram rounds of three barriers each, the scan zeroes the
+// histogram for the next round as it reads it.
 __device__ __forceinline__ unsigned f2key(float f) {
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -53,35 +58,43 @@ __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float(u);
 }
 
-// The z column of the candidates as the select passes see it: element r*1024 + tid of thread tid.
-// ZRegs holds a thread's (up to MAD_R) elements in registers -- the eight passes of the two
-// medians then never touch memory; one workgroup re-reading 12-byte-strided global memory paid a
-// full load latency per element and pass.  ZGlobal is the fallback for > 32768 candidates.
-constexpr int MAD_R = 32;
-struct ZRegs {
-    float z[MAD_R];
-    __device__ __forceinline__ void load(const float *__restrict__ cand, int n) {
-#pragma unroll
-        for (int r = 0; r < MAD_R; ++r) {
-            const int i = r * 1024 + (int)threadIdx.x;
-            z[r] = i < n ? cand[3 * (size_t)i + 2] : 0.f;
-        }
-    }
+constexpr int MAD_R = 32;   // element r*1024 + tid of thread tid, up to 32768 candidates in registers
+struct KeysReg {
+    unsigned k[MAD_R];
 };
-struct ZGlobal {
+struct KeysGlobal {   // fallback for more candidates: keys recomputed from memory in every pass
     const float *cand;
+    float center;
+    int mode;
 };
 
+// calls f(key, valid) for every element slot of this thread, wave-uniform trip count
+template <class F>
+__device__ __forceinline__ void for_keys(const KeysReg &K, int n, F f) {
+#pragma unroll
+    for (int r = 0; r < MAD_R; ++r) {
+        if (r * 1024 >= n) break;
+        f(K.k[r], r * 1024 + (int)threadIdx.x < n);
+    }
+}
+template <class F>
+__device__ __forceinline__ void for_keys(const KeysGlobal &K, int n, F f) {
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const float v = i < n ? K.cand[3 * (size_t)i + 2] : 0.f;
+        f(f2key(K.mode ? fabsf(v - K.center) : v), i < n);
+    }
+}
+
 struct MadShared {
-    unsigned hist[2048];
+    unsigned hist[2048];   // zero between rounds
     unsigned wsum[16];
-    unsigned sel, knew;
-    unsigned cntLess;
-    unsigned maxLessKey;
+    unsigned sel[3], knew[3], cnt[3];
+    unsigned cntLess, maxLessKey;
 };
 
 // hist[bin] += 1 for the lanes with act set; must be reached by the whole wavefront.
-// The values crowd into a few bins and same-address LDS atomics serialise, so the two most
+// Ground heights crowd into a few bins and same-address LDS atomics serialise, so the two most
 // common bins of the wavefront are added once per wavefront; the rest go one by one.
 __device__ __forceinline__ void lds_hist_add(unsigned *hist, unsigned bin, bool act) {
     const int lane = threadIdx.x & 63;
@@ -97,145 +110,127 @@ __device__ __forceinline__ void lds_hist_add(unsigned *hist, unsigned bin, bool 
     if (act) atomicAdd(&hist[bin], 1u);
 }
 
-// block scan of hist[0..2048) (two bins per thread): the bin holding rank k -> S.sel, the rank
-// inside it -> S.knew.  Ends with a barrier.
-__device__ __forceinline__ void pick_bin(MadShared &S, unsigned k) {
+// exact k-th smallest key (0-based).  S.hist is zero on entry and on exit.
+template <class KS>
+__device__ __forceinline__ unsigned select_kth(const KS &K, int n, unsigned k, MadShared &S) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned v0 = S.hist[2 * tid], v1 = S.hist[2 * tid + 1];
-    unsigned inc = v0 + v1;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-    }
-    if (lane == 63) S.wsum[w] = inc;
-    __syncthreads();
-    unsigned base = 0;
-    for (int q = 0; q < w; ++q) base += S.wsum[q];
-    const unsigned incl = base + inc, excl = incl - v0 - v1;
-    if (k >= excl && k < excl + v0) {
-        S.sel = 2 * tid;
-        S.knew = k - excl;
-    } else if (k >= excl + v0 && k < incl) {
-        S.sel = 2 * tid + 1;
-        S.knew = k - excl - v0;
-    }
-    __syncthreads();
-}
-
-// calls f(value, valid) for every element slot of this thread, wave-uniform trip count;
-// value = MODE==0 ? z_i : |z_i - center|  (float32 arithmetic)
-template <int MODE, class F>
-__device__ __forceinline__ void for_values(const ZRegs &Z, int n, float center, F f) {
+    unsigned prefix = 0, mask = 0, remaining = (unsigned)n;
+    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
 #pragma unroll
-    for (int r = 0; r < MAD_R; ++r) {
-        if (r * 1024 >= n) break;
-        const float v = Z.z[r];
-        f(MODE == 1 ? fabsf(v - center) : v, r * 1024 + (int)threadIdx.x < n);
-    }
-}
-template <int MODE, class F>
-__device__ __forceinline__ void for_values(const ZGlobal &Z, int n, float center, F f) {
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const float v = i < n ? Z.cand[3 * (size_t)i + 2] : 0.f;
-        f(MODE == 1 ? fabsf(v - center) : v, i < n);
-    }
-}
-
-// radix descent over the low `rb` bits of sub-keys u (all < 2^rb): each(f) must call
-// f(u, valid) for every element slot of the thread with a wave-uniform trip count
-template <class Each>
-__device__ __forceinline__ unsigned descend(Each each, int rb, unsigned k, MadShared &S) {
-    const int tid = threadIdx.x;
-    unsigned prefix = 0;   // the digits chosen so far = u >> rb
-    while (rb > 0) {
-        const int db = min(11, rb), shift = rb - db;
-        for (unsigned b = tid; b < 2048u; b += 1024) S.hist[b] = 0;
+    for (int ps = 0; ps < 3; ++ps) {
+        const int shift = shifts[ps];
+        const unsigned bm = (1u << bitsv[ps]) - 1u;
+        // the aggregated add costs ~25 instructions per slot whether or not anything matches; once
+        // few elements are left, collisions cannot serialise for long and a plain atomic is cheaper
+        if (remaining > 4096u)
+            for_keys(K, n, [&](unsigned key, bool valid) {
+                lds_hist_add(S.hist, (key >> shift) & bm, valid && (key & mask) == prefix);
+            });
+        else
+            for_keys(K, n, [&](unsigned key, bool valid) {
+                if (valid && (key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & bm], 1u);
+            });
         __syncthreads();
-        const int rbc = rb;
-        each([&](unsigned u, bool valid) {
-            // rbc == 32 only on the first round, when prefix is 0 and everything matches
-            const bool match = valid && (rbc >= 32 || (u >> rbc) == prefix);
-            lds_hist_add(S.hist, (u >> shift) & ((1u << db) - 1u), match);
-        });
+        // block scan, two bins per thread; the bins are cleared for the next round on the way
+        const unsigned v0 = S.hist[2 * tid], v1 = S.hist[2 * tid + 1];
+        S.hist[2 * tid] = 0;
+        S.hist[2 * tid + 1] = 0;
+        unsigned inc = v0 + v1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) S.wsum[w] = inc;
         __syncthreads();
-        pick_bin(S, k);
-        prefix = (prefix << db) | S.sel;
-        k = S.knew;
-        rb = shift;
+        unsigned base = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) base += q < w ? S.wsum[q] : 0u;
+        const unsigned incl = base + inc, excl = incl - v0 - v1;
+        if (k >= excl && k < excl + v0) {
+            S.sel[ps] = 2 * tid;
+            S.knew[ps] = k - excl;
+            S.cnt[ps] = v0;
+        } else if (k >= excl + v0 && k < incl) {
+            S.sel[ps] = 2 * tid + 1;
+            S.knew[ps] = k - excl - v0;
+            S.cnt[ps] = v1;
+        }
         __syncthreads();
+        prefix |= S.sel[ps] << shift;
+        mask |= bm << shift;
+        k = S.knew[ps];
+        remaining = S.cnt[ps];
     }
     return prefix;
 }
 
-// exact k-th smallest (0-based): 11 + 11 + 10 bit radix descent over the order-preserving key.
-// (Measured alternatives on 15 k ground candidates, one workgroup = one CU, which is what bounds
-// this kernel -- about 85 issue cycles per 64 elements and pass: range-relative bins with the
-// survivors compacted into LDS 37 us, this descent 34 us, a bitwise rank search 135 us.)
-template <int MODE, class ZS>
-__device__ float select_kth(const ZS &Z, int n, unsigned k, float center, MadShared &S) {
-    __syncthreads();   // the previous select may still be reading S
-    return key2f(descend([&](auto f) {
-        for_values<MODE>(Z, n, center, [&](float v, bool valid) { f(f2key(v), valid); });
-    }, 32, k, S));
-}
-
 // numpy.median: odd -> middle element; even -> float32 mean of the two middle ones.  The lower
 // middle is the largest value below the upper middle b unless b is duplicated across the middle.
-template <int MODE, class ZS>
-__device__ float median_np(const ZS &Z, int n, float center, MadShared &S) {
-    const float b = select_kth<MODE>(Z, n, (unsigned)(n / 2), center, S);
+template <class KS>
+__device__ __forceinline__ float median_np(const KS &K, int n, MadShared &S) {
+    const unsigned bkey = select_kth(K, n, (unsigned)(n / 2), S);
+    const float b = key2f(bkey);
     if (n & 1) return b;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        S.cntLess = 0;
-        S.maxLessKey = 0;
-    }
-    __syncthreads();
     unsigned c = 0, mk = 0;
-    for_values<MODE>(Z, n, center, [&](float v, bool valid) {
-        if (valid && v < b) {
+    for_keys(K, n, [&](unsigned key, bool valid) {
+        if (valid && key < bkey) {
             ++c;
-            mk = max(mk, f2key(v));
+            mk = max(mk, key);
         }
     });
     for (int o = 32; o > 0; o >>= 1) {
         c += __shfl_xor(c, o);
         mk = max(mk, (unsigned)__shfl_xor((int)mk, o));
     }
-    if ((tid & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) {
         atomicAdd(&S.cntLess, c);
         atomicMax(&S.maxLessKey, mk);
     }
     __syncthreads();
     const float a = (S.cntLess == (unsigned)(n / 2)) ? key2f(S.maxLessKey) : b;
     __syncthreads();
-    return (a + b) / 2.0f;
-}
-
-template <class ZS>
-__device__ __forceinline__ void mad_body(const ZS &Z, int n, float *out, MadShared &S) {
-    const float med = median_np<0>(Z, n, 0.f, S);
-    const float mad = median_np<1>(Z, n, med, S);
-    if (threadIdx.x == 0) {
-        out[0] = med;
-        out[1] = mad;
+    if (threadIdx.x == 0) {   // for the next median (its select has barriers before these are used)
+        S.cntLess = 0;
+        S.maxLessKey = 0;
     }
+    return (a + b) / 2.0f;
 }
 
 __global__ __launch_bounds__(1024) void mad_kernel(const float *__restrict__ cand, int n,
                                                    float *out /* [median, mad] */) {
     __shared__ MadShared S;
+    const int tid = threadIdx.x;
+    S.hist[2 * tid] = 0;
+    S.hist[2 * tid + 1] = 0;
+    if (tid == 0) {
+        S.cntLess = 0;
+        S.maxLessKey = 0;
+    }
+    float med, mad;
     if (n <= MAD_R * 1024) {
-        ZRegs Z;
-        Z.load(cand, n);
-        mad_body(Z, n, out, S);
+        float z[MAD_R];
+        KeysReg K;
+#pragma unroll
+        for (int r = 0; r < MAD_R; ++r) {
+            const int i = r * 1024 + tid;
+            z[r] = i < n ? cand[3 * (size_t)i + 2] : 0.f;
+            K.k[r] = f2key(z[r]);
+        }
+        __syncthreads();
+        med = median_np(K, n, S);
+#pragma unroll
+        for (int r = 0; r < MAD_R; ++r) K.k[r] = f2key(fabsf(z[r] - med));   // float32, as numpy
+        mad = median_np(K, n, S);
     } else {
-        ZGlobal Z{cand};
-        mad_body(Z, n, out, S);
+        __syncthreads();
+        med = median_np(KeysGlobal{cand, 0.f, 0}, n, S);
+        mad = median_np(KeysGlobal{cand, med, 1}, n, S);
+    }
+    if (tid == 0) {
+        out[0] = med;
+        out[1] = mad;
     }
 }
-
 
 // ---- trial scoring -------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
