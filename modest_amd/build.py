@@ -90,7 +90,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             elif cur is not None and val.strip().lstrip("-").isdigit():
                 cur[key.strip()] = int(val.strip())
         # drop the source-context lines clang prints under every remark
-        diag = [l for l in rest if l.strip() and not l.lstrip().startswith(("|", "^")) and not l.lstrip()[:1].isdigit()]
+        diag = [l for l in rest if l.strip() and not l.lstrip().startswith(("|", "^", "In file included"))
+                and not l.lstrip()[:1].isdigit()]
         if verbose and diag:
             print("\n".join(diag), file=sys.stderr)
         return obj

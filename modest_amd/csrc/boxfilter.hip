@@ -54,8 +54,8 @@ __global__ __launch_bounds__(CS_THREADS) void bf_stats(const double *__restrict_
         float g;
         cs_percentile_ranks(cnt, qf, &prev, &next, &g);
         gamma = (double)g;
-        a = (double)cs_select(pp, mem, cnt, (unsigned)prev, hist, wsum, sel);
-        c = (next == prev) ? a : (double)cs_select(pp, mem, cnt, (unsigned)next, hist, wsum, sel);
+        a = (double)cs_select<CS_THREADS>(pp, mem, cnt, (unsigned)prev, hist, wsum, sel);
+        c = (next == prev) ? a : (double)cs_select<CS_THREADS>(pp, mem, cnt, (unsigned)next, hist, wsum, sel);
     }
     if (tid == 0) {
         out[4 * b + 0] = (double)cnt;

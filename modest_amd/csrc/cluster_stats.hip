@@ -109,14 +109,15 @@ struct PlaneP {
 };
 
 // out[c*6 + {0:n, 1:dmin, 2:dmax, 3:a, 4:b, 5:gamma}]  (doubles)
-__global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__ pts, int stride,
+constexpr int CSS_THREADS = 1024;   // the largest cluster sets the kernel time: more lanes, fewer gather rounds
+__global__ __launch_bounds__(CSS_THREADS) void cs_stats(const float *__restrict__ pts, int stride,
                                                        const float *__restrict__ pp,
                                                        const int *__restrict__ members,
                                                        const unsigned *__restrict__ start, PlaneP P,
                                                        double *__restrict__ out) {
     __shared__ unsigned hist[2048];
-    __shared__ unsigned wsum[4], sel[2];
-    __shared__ double rmin[4], rmax[4];
+    __shared__ unsigned wsum[CSS_THREADS / 64], sel[2];
+    __shared__ double rmin[CSS_THREADS / 64], rmax[CSS_THREADS / 64];
     // PP keys of the members, gathered once (each of the up to seven select passes otherwise
     // repeats the members -> pp chain of dependent loads)
     __shared__ unsigned keys[CS_LDS_KEYS];
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__
     const int *mem = members + start[c];
     const bool cached = n <= CS_LDS_KEYS;
     double mn = INFINITY, mx = -INFINITY;
-    for (int i = tid; i < n; i += CS_THREADS) {
+    for (int i = tid; i < n; i += CSS_THREADS) {
         const int m = mem[i];
         if (cached) keys[i] = cs_key(pp[m]);
         const float *p = pts + (size_t)m * stride;
@@ -160,17 +161,22 @@ __global__ __launch_bounds__(CS_THREADS) void cs_stats(const float *__restrict__
         gamma = (double)(vi - fl);
         if (cached) {
             const auto key_at = [&](int i) { return keys[i]; };
-            a = (double)cs_select_keys(key_at, n, (unsigned)prev, hist, wsum, sel);
-            b = (next == prev) ? a : (double)cs_select_keys(key_at, n, (unsigned)next, hist, wsum, sel);
+            a = (double)cs_select_keys<CSS_THREADS>(key_at, n, (unsigned)prev, hist, wsum, sel);
+            b = (next == prev) ? a : (double)cs_select_keys<CSS_THREADS>(key_at, n, (unsigned)next, hist, wsum, sel);
         } else {
-            a = (double)cs_select(pp, mem, n, (unsigned)prev, hist, wsum, sel);
-            b = (next == prev) ? a : (double)cs_select(pp, mem, n, (unsigned)next, hist, wsum, sel);
+            a = (double)cs_select<CSS_THREADS>(pp, mem, n, (unsigned)prev, hist, wsum, sel);
+            b = (next == prev) ? a : (double)cs_select<CSS_THREADS>(pp, mem, n, (unsigned)next, hist, wsum, sel);
         }
     }
     if (tid == 0) {
         out[6 * c + 0] = (double)n;
-        out[6 * c + 1] = fmin(fmin(rmin[0], rmin[1]), fmin(rmin[2], rmin[3]));
-        out[6 * c + 2] = fmax(fmax(rmax[0], rmax[1]), fmax(rmax[2], rmax[3]));
+        double mn_ = rmin[0], mx_ = rmax[0];
+        for (int q = 1; q < CSS_THREADS / 64; ++q) {
+            mn_ = fmin(mn_, rmin[q]);
+            mx_ = fmax(mx_, rmax[q]);
+        }
+        out[6 * c + 1] = mn_;
+        out[6 * c + 2] = mx_;
         out[6 * c + 3] = a;
         out[6 * c + 4] = b;
         out[6 * c + 5] = gamma;
@@ -216,7 +222,7 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
         cs_scan<<<1, 64, 0, stream>>>(cnt, n_clusters, start);
         if (n > 0) cs_scatter<<<nb, 256, 0, stream>>>(labels, n, n_clusters, start, fill, members);
     }
-    cs_stats<<<n_clusters, CS_THREADS, 0, stream>>>(pts, stride, pp, members, start, P, d_out);
+    cs_stats<<<n_clusters, CSS_THREADS, 0, stream>>>(pts, stride, pp, members, start, P, d_out);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, d_out, (size_t)n_clusters * 48, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));

@@ -18,7 +18,14 @@ struct modest_ctx {
     hipEvent_t *prof_ev;   // 2 * prof_cap events
     int prof_cap;
     int pp_attr_done;      // dynamic-LDS limits of the PP kernels raised on this device
+    // zeroed state words of the order-preserving compaction kernels (compact.h); the kernels leave
+    // them zeroed, so no memset per launch
+    unsigned long long *cstate;
+    size_t cstate_blocks;
 };
+
+// persistent compaction state for `nblocks` blocks (allocated and zeroed on first use / growth)
+int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream, unsigned long long **out);
 
 // Record an event pair around a kernel when profiling is on (no-ops otherwise).
 void modest_prof_mark(modest_ctx *ctx, hipStream_t stream, int end);

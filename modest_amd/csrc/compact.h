@@ -7,7 +7,9 @@
 // are already running (no assumption about dispatch order, residency or XCD
 // placement), and nobody waits on a chain -- the 30 blocks of a scan used to hand
 // a running total from one to the next, 0.6 us per hop.
-// state[] (compact_state_bytes(nblocks)) must be zeroed on the stream before the launch.
+// state[] (compact_state_bytes(nblocks)) must be zero before the launch; the block that finishes
+// its look-back last (state[0] counts them) zeroes it again, so a buffer that is only ever used by
+// these kernels (modest_ctx_compact_state) needs no memset per launch.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,6 +37,7 @@ __device__ __forceinline__ unsigned long long compact_offset(bool keep, unsigned
                                                              int *total_out) {
     __shared__ unsigned wave_cnt[16];
     __shared__ unsigned long long base_s;
+    __shared__ unsigned last_s;
     const unsigned long long bal = __ballot(keep);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned before = __popcll(bal & ((1ULL << lane) - 1ULL));
@@ -66,9 +69,15 @@ __device__ __forceinline__ unsigned long long compact_offset(bool keep, unsigned
         if (lane == 0) {
             base_s = sum;
             if (blk == nblocks - 1 && total_out) *total_out = (int)(sum + total);
+            // every block that has counted itself here is done reading state[]
+            last_s = atomicAdd(state, 1ULL) == (unsigned long long)(nblocks - 1) ? 1u : 0u;
         }
     }
     __syncthreads();
+    if (last_s) {
+        for (unsigned j = threadIdx.x; j < nblocks + 2; j += blockDim.x)
+            __hip_atomic_store(state + j, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return base_s + woff + before;
 }
 

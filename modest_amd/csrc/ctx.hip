@@ -59,6 +59,9 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->prof_count = 0;
     c->prof_ev = nullptr;
     c->prof_cap = 0;
+    c->pp_attr_done = 0;
+    c->cstate = nullptr;
+    c->cstate_blocks = 0;
     *out = c;
     return MODEST_OK;
 }
@@ -67,9 +70,27 @@ extern "C" int modest_ctx_destroy(modest_ctx *ctx) {
     if (!ctx) return MODEST_OK;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->cstate) (void)hipFree(ctx->cstate);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     delete[] ctx->prof_ev;
     delete ctx;
+    return MODEST_OK;
+}
+
+int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream, unsigned long long **out) {
+    if (nblocks > ctx->cstate_blocks) {
+        MODEST_HIP_CHECK(hipDeviceSynchronize());
+        if (ctx->cstate) MODEST_HIP_CHECK(hipFree(ctx->cstate));
+        ctx->cstate = nullptr;
+        ctx->cstate_blocks = 0;
+        const size_t want = nblocks < 4096 ? 4096 : nblocks + nblocks / 4;
+        void *p = nullptr;
+        MODEST_HIP_CHECK(hipMalloc(&p, 16 + 8 * want));
+        MODEST_HIP_CHECK(hipMemsetAsync(p, 0, 16 + 8 * want, stream));
+        ctx->cstate = static_cast<unsigned long long *>(p);
+        ctx->cstate_blocks = want;
+    }
+    *out = ctx->cstate;
     return MODEST_OK;
 }
 

@@ -471,10 +471,9 @@ extern "C" int modest_plane_candidates(modest_ctx *ctx, const float *pts, int n,
     }
     MODEST_REQUIRE(pts && cand, "NULL buffer");
     const int nblk = (n + 1023) / 1024;
-    int rc = modest_ctx_reserve(ctx, compact_state_bytes(nblk));
+    unsigned long long *state = nullptr;
+    int rc = modest_ctx_compact_state(ctx, (size_t)nblk, stream, &state);
     if (rc) return rc;
-    unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
-    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, compact_state_bytes(nblk), stream));
     candidates_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, max_hs, xlo, xhi, ylo, yhi,
                                                              cand, cand_idx, state, n_cand);
     MODEST_HIP_CHECK(hipGetLastError());
@@ -679,10 +678,9 @@ extern "C" int modest_plane_range_mask(modest_ctx *ctx, const float *pts, int n,
     P.ly0 = (float)limit_range4[2];
     P.ly1 = (float)limit_range4[3];
     const int nblk = (n + 1023) / 1024;
-    int rc = modest_ctx_reserve(ctx, compact_state_bytes(nblk));
+    unsigned long long *state = nullptr;
+    int rc = modest_ctx_compact_state(ctx, (size_t)nblk, stream, &state);
     if (rc) return rc;
-    unsigned long long *state = reinterpret_cast<unsigned long long *>(ctx->scratch);
-    MODEST_HIP_CHECK(hipMemsetAsync(state, 0, compact_state_bytes(nblk), stream));
     mask_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, P, mask, kept, kept_idx, state,
                                                        n_kept);
     MODEST_HIP_CHECK(hipGetLastError());

@@ -1,4 +1,4 @@
-// Exact k-th smallest float32 of an indexed subset, one 256-thread workgroup per subset:
+// Exact k-th smallest float32 of an indexed subset, one workgroup per subset:
 // radix descent over the order-preserving key, 11 + 11 + 10 bits, LDS histograms.
 // Used for the order statistics numpy.percentile interpolates between
 // (clustering_utils.py:107-117 is_valid_cluster; combine_labels.py:41-60 filter_by_ppscore).
@@ -19,26 +19,28 @@ __device__ __forceinline__ float cs_unkey(unsigned k) {
 }
 
 // k-th smallest (0-based) of the n values whose order-preserving keys key_at(i) yields
-template <class KeyAt>
+// (workgroup of NT threads)
+template <int NT, class KeyAt>
 __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k, unsigned *hist /* 2048 */,
-                                                unsigned *wsum /* 4 */, unsigned *sel /* 2 */) {
+                                                unsigned *wsum /* NT/64 */, unsigned *sel /* 2 */) {
+    constexpr int BPT = 2048 / NT;   // bins per thread in the scan
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned prefix = 0, mask = 0;
     const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
     for (int ps = 0; ps < 3; ++ps) {
         const int shift = shifts[ps];
         const unsigned nb = 1u << bitsv[ps];
-        for (unsigned b = tid; b < 2048u; b += CS_THREADS) hist[b] = 0;
+        for (unsigned b = tid; b < 2048u; b += NT) hist[b] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += CS_THREADS) {
+        for (int i = tid; i < n; i += NT) {
             const unsigned key = key_at(i);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1u)], 1u);
         }
         __syncthreads();
-        // 8 bins per thread
-        unsigned v[8], s = 0;
-        for (int j = 0; j < 8; ++j) {
-            v[j] = hist[8 * tid + j];
+        unsigned v[BPT], s = 0;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+            v[j] = hist[BPT * tid + j];
             s += v[j];
         }
         unsigned inc = s;
@@ -51,9 +53,10 @@ __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k,
         unsigned base = 0;
         for (int q = 0; q < w; ++q) base += wsum[q];
         unsigned run = base + inc - s;
-        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
             if (k >= run && k < run + v[j]) {
-                sel[0] = 8 * tid + j;
+                sel[0] = BPT * tid + j;
                 sel[1] = k - run;
             }
             run += v[j];
@@ -68,9 +71,10 @@ __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k,
 }
 
 // k-th smallest (0-based) pp among the members
-__device__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n, unsigned k,
-                           unsigned *hist, unsigned *wsum, unsigned *sel) {
-    return cs_select_keys([=](int i) { return cs_key(pp[mem[i]]); }, n, k, hist, wsum, sel);
+template <int NT>
+__device__ __forceinline__ float cs_select(const float *__restrict__ pp, const int *__restrict__ mem, int n,
+                                           unsigned k, unsigned *hist, unsigned *wsum, unsigned *sel) {
+    return cs_select_keys<NT>([=](int i) { return cs_key(pp[mem[i]]); }, n, k, hist, wsum, sel);
 }
 
 // numpy.percentile(x, q) ('linear') on float32 data of size n works in float32: virtual index
