@@ -422,13 +422,13 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
             pp3_join<false><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
                 rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
                 reinterpret_cast<unsigned long long *>(dbgStats));
-        if (dbg & 8) {
+        if (dbg & (8 | 128)) {
             unsigned long long hs[32];
             unsigned hc[4];
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hs, dbgStats, sizeof(hs), hipMemcpyDeviceToHost));
             MODEST_HIP_CHECK(hipMemcpy(hc, ctrl3, sizeof(hc), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu | max WG %llu | chunks %llu groups %llu iters %llu\n",
+            if (dbg & 8) fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu | max WG %llu | chunks %llu groups %llu iters %llu\n",
                     hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[6], hs[8], hs[9], hs[10]);
             {
                 static unsigned long long tl[64 + 3 * 1024];
@@ -447,9 +447,9 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
                 for (int k = 0; k < 16; ++k) fprintf(stderr, " %llu", hist_end[k]);
                 fprintf(stderr, "; max slices per WG %llu\n", sl_mx);
                 const unsigned worst = (unsigned)(hs[13] & 0xffffffffu);
-                uint4 ws;
-                MODEST_HIP_CHECK(hipMemcpy(&ws, slices + worst, sizeof(ws), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[pp3] slowest slice: id %u list %u records %u, %llu ticks starting at %llu (load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu)\n",
+                uint4 ws = make_uint4(0, 0, 0, 0);
+                if (dbg & 8) MODEST_HIP_CHECK(hipMemcpy(&ws, slices + worst, sizeof(ws), hipMemcpyDeviceToHost));
+                if (dbg & 8) fprintf(stderr, "[pp3] slowest slice: id %u list %u records %u, %llu ticks starting at %llu (load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu)\n",
                         worst, ws.x, ws.z - ws.y, hs[13] >> 32, hs[21], hs[16], hs[17], hs[18], hs[19], hs[20]);
             }
         }
