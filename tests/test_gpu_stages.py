@@ -107,6 +107,57 @@ def test_plane_range_mask_exact(gpu, ms):
     assert np.array_equal(pm, ms["plane_mask"])
 
 
+def test_compaction_many_blocks_and_reuse(gpu):
+    """Order-preserving compaction across hundreds of blocks (the look-back sums predecessors 64 at
+    a time) and back-to-back launches on one context (the state words reset themselves): candidate
+    selection and the plane/range mask against numpy boolean indexing, ragged sizes included."""
+    import torch
+    from modest_amd import ops
+    rng = np.random.RandomState(5)
+    plane = np.array([0.01, -0.02, 1.0, 1.6])
+    for n in (700_001, 1, 1023, 1025, 131_072, 70_000):
+        pts = np.empty((n, 4), dtype=np.float32)
+        pts[:, 0] = rng.uniform(-80, 80, n)
+        pts[:, 1] = rng.uniform(-50, 50, n)
+        pts[:, 2] = rng.uniform(-3, 1, n)
+        pts[:, 3] = rng.rand(n)
+        dev = torch.from_numpy(pts).to(gpu)
+        for _ in range(2):
+            cand, idx = ops.plane_candidates(dev, -1.5, ((-20, 70), (-20, 20)))
+            m = (pts[:, 2] < -1.5) & (pts[:, 0] > -20) & (pts[:, 0] < 70) & (pts[:, 1] > -20) & (pts[:, 1] < 20)
+            assert np.array_equal(idx.cpu().numpy(), np.nonzero(m)[0])
+            assert np.array_equal(cand.cpu().numpy(), pts[m][:, :3])
+            mask, kept, kidx = ops.plane_range_mask(dev, plane, 0.05, [[-70, 70], [-20, 20]], [[-70, 70], [-40, 40]])
+            mk = mask.cpu().numpy()
+            assert np.array_equal(kidx.cpu().numpy(), np.nonzero(mk)[0])
+            assert np.array_equal(kept.cpu().numpy(), pts[mk][:, :3])
+            d = (pts[:, :3].astype(np.float64) @ plane[:3] + plane[3]) / np.sqrt((plane[:3] ** 2).sum())
+            below = (d < 0.05) & (pts[:, 0] < 70) & (pts[:, 0] > -70) & (pts[:, 1] < 20) & (pts[:, 1] > -20)
+            rng_ok = (pts[:, 0] <= 70) & (pts[:, 0] > -70) & (pts[:, 1] <= 40) & (pts[:, 1] > -40)
+            ref = ~below & rng_ok
+            # the float64 dot product may differ from numpy's in the last bit: only points off the threshold
+            sure = np.abs(d - 0.05) > 1e-9
+            assert np.array_equal(mk[sure], ref[sure])
+
+
+def test_mad_threshold_exact(gpu):
+    """MAD(z) = numpy.median(|z - median(z)|) in float32, bit for bit: odd / even counts, heavy
+    duplicates, a single value, more candidates than the register-resident path holds."""
+    import torch
+    from modest_amd import ops
+    rng = np.random.RandomState(11)
+    cases = [rng.normal(-1.7, 0.05, 14935), rng.normal(-1.7, 0.05, 14936), np.full(5000, -1.625),
+             np.round(rng.normal(-1.7, 0.05, 20001), 2), rng.uniform(-3, 3, 3), rng.normal(0, 1, 40_001),
+             rng.normal(0, 1e-3, 32_768), np.array([0.5])]
+    for z in cases:
+        z = z.astype(np.float32)
+        cand = np.zeros((z.size, 3), dtype=np.float32)
+        cand[:, 2] = z
+        got = np.float32(ops.mad_threshold(torch.from_numpy(cand).to(gpu)))
+        ref = np.median(np.abs(z - np.median(z)))
+        assert got == ref, (z.size, got, ref)
+
+
 def test_cluster_dbscan_exact(gpu, ms):
     import torch
     from modest_amd import ops
