@@ -59,11 +59,11 @@ __device__ double pw_leaf(const BetaCtx &B, int off, int n) {
 }
 
 // explicit-stack form of: n<=128 ? leaf : sum(a,n2) + sum(a+n2,n-n2), n2 = n/2 - (n/2)%8
-__device__ double pw_sum(const BetaCtx &B, int n) {
+__device__ double pw_tree(const BetaCtx &B, int off0, int n) {
     int f_off[32], f_n[32], f_stage[32];
     double f_left[32];
     int sp = 0;
-    f_off[0] = 0;
+    f_off[0] = off0;
     f_n[0] = n;
     f_stage[0] = 0;
     double ret = 0.0;
@@ -95,6 +95,16 @@ __device__ double pw_sum(const BetaCtx &B, int n) {
         }
     }
     return ret;
+}
+
+// numpy.add.reduce walks a contiguous array in buffers of NP_BUFSIZE elements: each buffer is summed
+// pairwise and added to the running total, ((p(c0) + p(c1)) + p(c2)) + ... (measured against
+// numpy 2.2: the plain tree over the whole array differs in the last bits from n ~ 20 k on)
+constexpr int NP_BUFSIZE = 8192;
+__device__ double pw_sum(const BetaCtx &B, int n) {
+    double total = 0.0;
+    for (int off = 0; off < n; off += NP_BUFSIZE) total += pw_tree(B, off, min(NP_BUFSIZE, n - off));
+    return total;
 }
 
 __global__ __launch_bounds__(128) void closeness_kernel(const double *__restrict__ pts,
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(128) void closeness_kernel(const double *__restrict
 }
 
 // The same sum, spread over the lanes of a block.  numpy's pairwise sum is a fixed binary tree
-// over the index range whose leaves hold 65..128 elements (or everything when n <= 128); the host
+// over the index range (of every 8192-element reduction buffer) whose leaves hold 65..128 elements (or everything when n <= 128); the host
 // lists the leaves of every cluster and the post-order "program" (0 = next leaf, 1 = add) that
 // combines them, so the leaves can be summed side by side and combined in numpy's order.
 // A block serves one cluster and 256/P angles; P lanes share an angle: they split the min/max
@@ -291,7 +301,7 @@ __device__ double pw_leaf_it(VarIt &it, int n) {
     return res;
 }
 
-__device__ double pw_sum_it(VarIt &it, int n) {
+__device__ double pw_tree_it(VarIt &it, int n) {
     int f_n[32], f_stage[32];
     double f_left[32];
     int sp = 0;
@@ -324,6 +334,12 @@ __device__ double pw_sum_it(VarIt &it, int n) {
         }
     }
     return ret;
+}
+
+__device__ double pw_sum_it(VarIt &it, int n) {   // buffers of NP_BUFSIZE, as numpy reduces them
+    double total = 0.0;
+    for (int off = 0; off < n; off += NP_BUFSIZE) total += pw_tree_it(it, min(NP_BUFSIZE, n - off));
+    return total;
 }
 
 __global__ __launch_bounds__(128) void variance_kernel(const double *__restrict__ pts,
@@ -525,7 +541,10 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
         progBase.push_back(0);
         for (int c = 0; c < n_clusters; ++c) {
             const int n = offsets_host[c + 1] - offsets_host[c];
-            if (n > 0) pw_tree_host(0, n, leaf, prog);
+            for (int off = 0; off < n; off += NP_BUFSIZE) {   // numpy's reduction buffers, added left to right
+                pw_tree_host(off, std::min(NP_BUFSIZE, n - off), leaf, prog);
+                if (off > 0) prog.push_back(1);
+            }
             leafBase.push_back((int)(leaf.size() / 2));
             progBase.push_back((int)prog.size());
             maxLeaves = std::max(maxLeaves, leafBase[c + 1] - leafBase[c]);

@@ -238,6 +238,64 @@ def test_filter_and_boxes(gpu, ms):
     assert np.array_equal(beta[0], np.array(ref))
 
 
+def test_closeness_criterion_tree_sizes(gpu):
+    """The closeness criterion of every (cluster, angle) equals numpy's pairwise sum bit for bit at
+    the sizes where numpy's summation tree changes shape (8-accumulator leaves, 128-element leaves,
+    halves split at multiples of 8), with 16 and with 64 lanes per angle, and on the one-lane-per-
+    angle kernel that clusters too large for the LDS leaf table fall back to."""
+    import torch
+    from modest_amd import ops
+    from modest_amd.utils import pointcloud_utils as pcu
+    rng = np.random.RandomState(3)
+    ang, cs = pcu.angle_table(0.1)
+    sub = np.arange(0, len(ang), 60)          # 16 of the 901 angles keep the numpy reference loop short
+    cs_sub = np.ascontiguousarray(cs[sub])
+
+    def reference(c):
+        out = []
+        for a in ang[sub]:
+            comp = np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
+            pr = c @ comp.T
+            dx = np.minimum(pr[:, 0] - pr[:, 0].min(), pr[:, 0].max() - pr[:, 0])
+            dy = np.minimum(pr[:, 1] - pr[:, 1].min(), pr[:, 1].max() - pr[:, 1])
+            out.append((1 / np.maximum(np.minimum(dx, dy), 1e-2)).sum())
+        return np.array(out)
+
+    def check(sizes):
+        cl = [rng.normal(0, 1, (n, 2)) * [2.0, 0.8] + rng.uniform(-30, 30, 2) for n in sizes]
+        off = np.cumsum([0] + list(sizes))
+        pts = torch.from_numpy(np.ascontiguousarray(np.concatenate(cl))).to(gpu)
+        best, beta = ops.fit_boxes_closeness(pts, off, cs_sub, return_beta=True)
+        for k, c in enumerate(cl):
+            ref = reference(c)
+            assert np.array_equal(beta[k], ref), (sizes[k], np.abs(beta[k] - ref).max())
+            assert best[k] == int(np.argmax(ref))
+
+    check([1, 2, 7, 8, 9, 15, 16, 17, 127, 128, 129, 130, 136, 255, 256, 257, 263, 264, 1000, 4096])   # 16 lanes
+    check([5000, 3, 20_011, 129, 8192, 8193])   # 64 lanes; beyond 8192 elements numpy reduces buffer by buffer
+    check([100_003, 40])                         # fallback
+
+    # variance_to_edge criterion: np.var of data-dependent subsets, the same summation rules
+    sizes = [1, 9, 300, 20_011]
+    cl = [rng.normal(0, 1, (n, 2)) * [2.0, 0.8] + rng.uniform(-30, 30, 2) for n in sizes]
+    pts = torch.from_numpy(np.ascontiguousarray(np.concatenate(cl))).to(gpu)
+    best, crit = ops.fit_boxes_variance(pts, np.cumsum([0] + sizes), cs_sub, return_crit=True)
+    for k, c in enumerate(cl):
+        ref = []
+        for a in ang[sub]:
+            comp = np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]])
+            pr = c @ comp.T
+            dx = np.vstack((pr[:, 0] - pr[:, 0].min(), pr[:, 0].max() - pr[:, 0])).min(axis=0)
+            dy = np.vstack((pr[:, 1] - pr[:, 1].min(), pr[:, 1].max() - pr[:, 1])).min(axis=0)
+            v = 0
+            if (dx < dy).sum() > 0:
+                v += -np.var(dx[dx < dy])
+            if (dy < dx).sum() > 0:
+                v += -np.var(dy[dy < dx])
+            ref.append(v)
+        assert np.array_equal(crit[k], np.array(ref, dtype=np.float64)), (sizes[k], np.abs(crit[k] - ref).max())
+
+
 def test_bev_iou_and_nms(gpu, golden_dir):
     import torch
     from modest_amd import ops
