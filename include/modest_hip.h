@@ -97,7 +97,10 @@ int modest_pp_score(modest_ctx *ctx, const float *live_xyz_dev, int n_live,
 /* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
  * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).
  * Candidate selection: z<max_hs, xlo<x<xhi, ylo<y<yhi (strict), compacted in
- * input order into cand_xyz [dev] (capacity n), *n_cand_dev [dev].          */
+ * input order into cand_xyz [dev] (capacity n), *n_cand_dev [dev].
+ * n_cand_dev may be any device-accessible word: device memory, or pinned host
+ * memory (hipHostMalloc) -- then the count is on the host after a stream
+ * synchronise, without a copy.  Same for n_kept_dev below.                   */
 int modest_plane_candidates(modest_ctx *ctx, const float *pts_dev, int n,
                             int stride, float max_hs, float xlo, float xhi,
                             float ylo, float yhi, float *cand_xyz_dev,

@@ -108,6 +108,14 @@ class Context:
     def handle(self):
         return self._h
 
+    def host_counter(self):
+        """A pinned (device-visible) int32 word of this context: the compaction kernels write their
+        totals straight into it, the caller reads it after a stream sync -- no copy kernel."""
+        import torch
+        if getattr(self, "_counter", None) is None:
+            self._counter = torch.zeros((16,), dtype=torch.int32).pin_memory()
+        return self._counter
+
     def profile_begin(self, capacity: int = 4096) -> None:
         check(load().modest_ctx_profile_begin(self._h, int(capacity)), "modest_ctx_profile_begin")
 

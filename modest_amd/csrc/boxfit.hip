@@ -598,9 +598,9 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
     } else {   // a cluster of > 90 k points: one lane per (cluster, angle)
         closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
     }
-    argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, d_best);
+    (void)d_best;
+    argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, h_best);   // pinned host memory
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(h_best, d_best, (size_t)n_clusters * 4, hipMemcpyDeviceToHost, stream));
     if (beta_host)
         MODEST_HIP_CHECK(hipMemcpyAsync(h_beta, d_beta, (size_t)n_clusters * n_angles * 8,
                                         hipMemcpyDeviceToHost, stream));

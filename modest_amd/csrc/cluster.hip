@@ -94,7 +94,8 @@ __global__ void cg_count(const float *__restrict__ xyz, int n, const CGrid *g, u
 // in flight), first for the segment totals, then for the prefixes with a running carry
 __global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in,
                                                  unsigned *__restrict__ out, int n,
-                                                 unsigned *__restrict__ total_copy = nullptr) {
+                                                 unsigned *__restrict__ total_copy = nullptr,
+                                                 const int *__restrict__ flag_src = nullptr) {
     __shared__ unsigned wtot[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg = (((n + 15) / 16) + 63) & ~63;           // per-wavefront segment, multiple of 64
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in
     }
     if (threadIdx.x == 0) {
         out[n] = total;
-        if (total_copy) *total_copy = total;   // next to the overflow flag: one copy back fetches both
+        // pinned host memory: [overflow flag, total] are there when the stream has been synchronised
+        if (total_copy) {
+            total_copy[0] = flag_src ? (unsigned)*flag_src : 0u;
+            total_copy[1] = total;
+        }
     }
 }
 
@@ -860,7 +865,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     int *degOut = A.take<int>(n);
     int *Lmin = A.take<int>(n);
     int *overflow = reinterpret_cast<int *>(zeroed + 2 * CG_CELLS);
-    unsigned *n_roots = zeroed + 2 * CG_CELLS + 2;   // [overflow, changed, n_roots]
+    unsigned *h_res = reinterpret_cast<unsigned *>(ctx->pinned);   // [overflow, number of clusters], written by the last scan
 
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
@@ -901,7 +906,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
                 }
             }
             dir_roots_kernel<<<nb, 256, 0, stream>>>(n, coreS, sidx, Lmin, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
             dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels);
         } else {
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
@@ -911,15 +916,14 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
             }
             union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
             label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, root, rank, labels);
         }
         MODEST_HIP_CHECK(hipGetLastError());
-        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, overflow, 12, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-        MODEST_REQUIRE(!reinterpret_cast<int *>(ctx->pinned)[0],
+        MODEST_REQUIRE(!h_res[0],
                        "k-NN graph: a row exceeded its capacity (massively tied k-th distances or a hub point)");
-        if (n_clusters) *n_clusters = (int32_t) reinterpret_cast<unsigned *>(ctx->pinned)[2];
+        if (n_clusters) *n_clusters = (int32_t)h_res[1];
         if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
         MODEST_HIP_CHECK(hipGetLastError());
         return MODEST_OK;
@@ -935,25 +939,23 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     }
     union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
     compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-    scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
+    scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
     label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels);
     MODEST_HIP_CHECK(hipGetLastError());
     {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
-        MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, overflow, 12, hipMemcpyDeviceToHost, stream));
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-        if (reinterpret_cast<int *>(ctx->pinned)[0]) {
+        if (h_res[0]) {
             degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS);
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
             hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, n_roots);
+            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
             label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, ep,
                                                      labels);
-            MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, overflow, 12, hipMemcpyDeviceToHost, stream));
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         }
-        if (n_clusters) *n_clusters = (int32_t) reinterpret_cast<unsigned *>(ctx->pinned)[2];
+        if (n_clusters) *n_clusters = (int32_t)h_res[1];
     }
     if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
     MODEST_HIP_CHECK(hipGetLastError());

@@ -222,9 +222,11 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
         cs_scan<<<1, 64, 0, stream>>>(cnt, n_clusters, start);
         if (n > 0) cs_scatter<<<nb, 256, 0, stream>>>(labels, n, n_clusters, start, fill, members);
     }
-    cs_stats<<<n_clusters, CSS_THREADS, 0, stream>>>(pts, stride, pp, members, start, P, d_out);
+    // six doubles per cluster, written by thread 0 of each workgroup straight into pinned host memory
+    (void)d_out;
+    cs_stats<<<n_clusters, CSS_THREADS, 0, stream>>>(pts, stride, pp, members, start, P,
+                                                     reinterpret_cast<double *>(ctx->pinned));
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, d_out, (size_t)n_clusters * 48, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     const double *h = reinterpret_cast<const double *>(ctx->pinned);
     for (size_t i = 0; i < (size_t)n_clusters * 6; ++i) out_host[i] = h[i];

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
 // centred 2x2 normal equations, rounded to float32 (what LinearRegression stores for float32
 // data); a degenerate (collinear in xy) triplet yields NaN = a trial without inliers
 __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__restrict__ trip, int K,
-                           float *__restrict__ models) {
+                           float *__restrict__ models, float *__restrict__ models_host) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     double x[3], y[3], z[3];
@@ -334,17 +334,25 @@ __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__r
     models[3 * k] = c0;
     models[3 * k + 1] = c1;
     models[3 * k + 2] = b;
+    if (models_host) {   // pinned host memory: the caller reads it after the stream sync, no copy kernel
+        models_host[3 * k] = c0;
+        models_host[3 * k + 1] = c1;
+        models_host[3 * k + 2] = b;
+    }
 }
 
 // one wavefront per output; lane-strided partial sums then a fixed shuffle tree (deterministic)
 __global__ __launch_bounds__(64) void score_reduce_kernel(const double *__restrict__ partial, int nblocks,
-                                                          int K, double *__restrict__ out /* K*4 */) {
+                                                          int K, double *__restrict__ out /* K*4 */,
+                                                          const float *__restrict__ thr_src = nullptr,
+                                                          float *__restrict__ thr_dst = nullptr) {
     const int id = blockIdx.x;
     if (id >= K * 4) return;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * K * 4 + id];
     s = wave_sum(s);
-    if (threadIdx.x == 0) out[id] = s;
+    if (threadIdx.x == 0) out[id] = s;   // `out` may be pinned host memory
+    if (thr_dst && id == 0 && threadIdx.x < 2) thr_dst[threadIdx.x] = thr_src[threadIdx.x];
 }
 
 // ---- refit ---------------------------------------------------------------------
@@ -392,7 +400,8 @@ __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__res
 }
 
 __global__ void refit_reduce_kernel(const double *__restrict__ partial, int nblocks, int pass,
-                                    double *__restrict__ acc /* [0..3] sums, [4..6] means, [8..12] moments */) {
+                                    double *__restrict__ acc /* [0..3] sums, [4..6] means, [8..12] moments */,
+                                    double *__restrict__ acc_host = nullptr /* pinned mirror, written by pass 1 */) {
     double s[5] = {0, 0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblocks; b += 64)
         for (int q = 0; q < 5; ++q) s[q] += partial[(size_t)b * 5 + q];
@@ -406,6 +415,10 @@ __global__ void refit_reduce_kernel(const double *__restrict__ partial, int nblo
         acc[6] = s[3] * inv;
     } else {
         for (int q = 0; q < 5; ++q) acc[8 + q] = s[q];
+        if (acc_host) {
+            for (int q = 0; q < 7; ++q) acc_host[q] = acc[q];
+            for (int q = 0; q < 5; ++q) acc_host[8 + q] = s[q];
+        }
     }
 }
 
@@ -549,30 +562,28 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const int nb = (n_cand + SCORE_PTS - 1) / SCORE_PTS, nrows = nb * SCORE_WAVES;
-    // device: [out K*4 f64 | models K*3 f32 | thr pair 2 f32] (one block, one copy back) | trip | partial
+    // device: [models K*3 f32 | thr pair 2 f32 | partial]; pinned host: [trip | thr in | results].
+    // The kernels read the triplets from and write the results (sums, models, threshold) to the pinned
+    // block directly: one stream sync, no copy kernels in either direction.
     const size_t n_out = (size_t)K * 32, n_models = (size_t)K * 12;
-    const size_t b_res = arena_sz(n_out + n_models + 8), b_trip = arena_sz((size_t)K * 12);
+    const size_t b_models = arena_sz(n_models), b_thr = arena_sz(8);
     const size_t b_part = arena_sz((size_t)nrows * K * 32);
-    int rc = modest_ctx_reserve(ctx, b_res + b_trip + b_part);
+    int rc = modest_ctx_reserve(ctx, b_models + b_thr + b_part);
     if (rc) return rc;
-    // pinned: [trip | thr in (2) | results]
     const size_t h_trip = ((size_t)K * 12 + 63) & ~size_t(63);
     rc = modest_ctx_reserve_pinned(ctx, h_trip + 64 + n_out + n_models + 8);
     if (rc) return rc;
     char *d = ctx->scratch;
-    double *d_out = reinterpret_cast<double *>(d);
-    float *d_models = reinterpret_cast<float *>(d + n_out);
-    float *d_thr = reinterpret_cast<float *>(d + n_out + n_models);
-    int *d_trip = reinterpret_cast<int *>(d + b_res);
-    double *d_part = reinterpret_cast<double *>(d + b_res + b_trip);
+    float *d_models = reinterpret_cast<float *>(d);
+    float *d_thr = reinterpret_cast<float *>(d + b_models);
+    double *d_part = reinterpret_cast<double *>(d + b_models + b_thr);
     int *h_tripp = reinterpret_cast<int *>(ctx->pinned);
     float *h_thr_in = reinterpret_cast<float *>(ctx->pinned + h_trip);
     char *h_res = ctx->pinned + h_trip + 64;
-    const double *h_outp = reinterpret_cast<const double *>(h_res);
-    const float *h_models = reinterpret_cast<const float *>(h_res + n_out);
-    const float *h_thr = reinterpret_cast<const float *>(h_res + n_out + n_models);
+    double *h_outp = reinterpret_cast<double *>(h_res);
+    float *h_models = reinterpret_cast<float *>(h_res + n_out);
+    float *h_thr = reinterpret_cast<float *>(h_res + n_out + n_models);
     for (int i = 0; i < 3 * K; ++i) h_tripp[i] = trip_host[i];
-    MODEST_HIP_CHECK(hipMemcpyAsync(d_trip, h_tripp, (size_t)K * 12, hipMemcpyHostToDevice, stream));
     if (*thr_inout < 0.f) {   // residual threshold = MAD of the candidates, computed on the device
         mad_kernel<<<1, 1024, 0, stream>>>(cand, n_cand, d_thr);
     } else {
@@ -580,12 +591,11 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
         h_thr_in[1] = *thr_inout;
         MODEST_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr_in, 8, hipMemcpyHostToDevice, stream));
     }
-    fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, d_trip, K, d_models);
+    fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, h_tripp, K, d_models, h_models);
     score_kernel<<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K,
                                                                                        d_thr + 1, d_part);
-    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, d_out);
+    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, h_outp, d_thr, h_thr);
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(h_res, d, n_out + n_models + 8, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     *thr_inout = h_thr[1];
     for (int k = 0; k < K; ++k) {
@@ -620,10 +630,9 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     refit_kernel<0><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, nullptr, dp);
     refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 0, acc);
     refit_kernel<1><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, acc + 4, dp);
-    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 1, acc);
-    MODEST_HIP_CHECK(hipGetLastError());
     double *h = reinterpret_cast<double *>(ctx->pinned);
-    MODEST_HIP_CHECK(hipMemcpyAsync(h, acc, 16 * 8, hipMemcpyDeviceToHost, stream));
+    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 1, acc, h);   // results straight into pinned host memory
+    MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     const double cnt = h[0], mx = h[4], my = h[5], mz = h[6];
     const double sxx = h[8], sxy = h[9], syy = h[10], sxz = h[11], syz = h[12];

@@ -124,13 +124,14 @@ def plane_candidates(pts: torch.Tensor, max_hs: float, ptc_range, ctx: Optional[
     n = pts.shape[0]
     cand = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
     idx = torch.empty((n,), dtype=torch.int32, device=pts.device)
-    cnt = torch.empty((1,), dtype=torch.int32, device=pts.device)   # always written by the call
     c = _ctx(ctx, pts)
+    cnt = c.host_counter()   # pinned host word, always written by the call (n == 0: a memset)
     (xlo, xhi), (ylo, yhi) = ptc_range
     check(lib.modest_plane_candidates(c.handle, pts.data_ptr(), n, pts.shape[1], float(max_hs), float(xlo),
                                       float(xhi), float(ylo), float(yhi), cand.data_ptr(), idx.data_ptr(),
                                       cnt.data_ptr(), _stream()), "modest_plane_candidates")
-    m = int(cnt.item())
+    torch.cuda.current_stream().synchronize()
+    m = int(cnt[0])
     return cand[:m], idx[:m]
 
 
@@ -204,13 +205,14 @@ def plane_range_mask(pts: torch.Tensor, plane: np.ndarray, offset: float, only_r
     mask = torch.empty((n,), dtype=torch.uint8, device=pts.device)
     kept = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
     idx = torch.empty((n,), dtype=torch.int32, device=pts.device)
-    cnt = torch.empty((1,), dtype=torch.int32, device=pts.device)   # always written by the call
     c = _ctx(ctx, pts)
+    cnt = c.host_counter()   # pinned host word, always written by the call
     check(lib.modest_plane_range_mask(c.handle, pts.data_ptr(), n, pts.shape[1], _np_ptr(plane), float(offset),
                                       None if onl is None else _np_ptr(onl), _np_ptr(lim), mask.data_ptr(),
                                       kept.data_ptr(), idx.data_ptr(), cnt.data_ptr(), _stream()),
           "modest_plane_range_mask")
-    m = int(cnt.item())
+    torch.cuda.current_stream().synchronize()
+    m = int(cnt[0])
     return mask.bool(), kept[:m], idx[:m]
 
 
