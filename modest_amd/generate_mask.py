@@ -62,7 +62,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
         if g.neighbor_type != "radius" and n_kept <= g.n_neighbors:
             raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {g.n_neighbors + 1}, "
                              f"n_samples_fit = {n_kept}, n_samples = {n_kept}")
-        kept_long = kept_idx.long()
+        kept_long = kept_idx              # int32 indices: torch indexes with them as they are
         inten = ptc_dev[kept_long, 3].contiguous() if g.affinity_type == "3d_l2_distance" else None
         lab_kept, _ = ops.cluster_dbscan(kept_xyz, pp_dev[kept_long].contiguous(), g.n_neighbors, g.radius,
                                          args.clustering.DBSCAN.eps, args.clustering.DBSCAN.min_samples,

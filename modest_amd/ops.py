@@ -213,7 +213,7 @@ def plane_range_mask(pts: torch.Tensor, plane: np.ndarray, offset: float, only_r
           "modest_plane_range_mask")
     torch.cuda.current_stream().synchronize()
     m = int(cnt[0])
-    return mask.bool(), kept[:m], idx[:m]
+    return mask.view(torch.bool), kept[:m], idx[:m]   # 0/1 bytes reinterpreted, no kernel
 
 
 # --------------------------------------------------------------------------- clustering
