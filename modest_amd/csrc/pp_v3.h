@@ -379,51 +379,13 @@ __global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ li
     }
 }
 
-// cursor[key] += 1 for the lanes with act set (whole wavefront must call).  Static structure seen
-// by every history frame piles thousands of records into one 0.3 m cell, and same-address LDS
-// atomics serialise across the workgroup: the two most common keys of a wavefront are added once.
-__device__ __forceinline__ void pp3_cursor_count(unsigned *cursor, unsigned key, bool act) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(act);
-    for (int r = 0; r < 2 && todo; ++r) {
-        const int lead = __ffsll((long long)todo) - 1;
-        const unsigned lk = (unsigned)__builtin_amdgcn_readlane((int)key, lead);
-        const unsigned long long same = __ballot(act && key == lk);
-        if (lane == lead) atomicAdd(&cursor[lk], (unsigned)__popcll(same));
-        if (key == lk) act = false;
-        todo &= ~same;
-    }
-    if (act) atomicAdd(&cursor[key], 1u);
-}
-// the same with the slot returned: one atomic per (wavefront, key) for the two most common keys
-__device__ __forceinline__ unsigned pp3_cursor_take(unsigned *cursor, unsigned key, bool act) {
-    const int lane = threadIdx.x & 63;
-    unsigned pos = 0;
-    unsigned long long todo = __ballot(act);
-    for (int r = 0; r < 2 && todo; ++r) {
-        const int lead = __ffsll((long long)todo) - 1;
-        const unsigned lk = (unsigned)__builtin_amdgcn_readlane((int)key, lead);
-        const unsigned long long same = __ballot(act && key == lk);
-        unsigned base = 0;
-        if (lane == lead) base = atomicAdd(&cursor[lk], (unsigned)__popcll(same));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, lead);
-        if (act && key == lk) {
-            pos = base + (unsigned)__popcll(same & ((1ULL << lane) - 1ULL));
-            act = false;
-        }
-        todo &= ~same;
-    }
-    if (act) pos = atomicAdd(&cursor[key], 1u);
-    return pos;
-}
-
 struct JoinShared {
     unsigned cursor[V3_NC];                   // cell histogram -> running cursor -> cell END offsets in the slice
     unsigned cst[V3_W * (V3_W + 1)];          // cellStart of the window cells (one global round trip)
     unsigned short ctab[V3_W * (V3_W + 1)];   // live points of window row r before column cc
     unsigned segStart[V3_W], rowBase[V3_W + 1];
     unsigned bandA[V3_TS], bandB[V3_TS], bandSlow[V3_TS];
-    unsigned nBands, ticket, sliceId, nextId, maxCell;
+    unsigned nBands, ticket, sliceId, nextId;
     uint4 slice, nextSlice;
     unsigned long long prof[8], prev[8], tlast;   // PROF builds only
 };
@@ -482,11 +444,9 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         const uint4 sl = S.slice;
         if (tid < V3_NC) S.cursor[tid] = 0;
         __syncthreads();   // everyone holds the slice: thread 0 may overwrite the header below
-        // The next slice header is fetched now but parked in LDS (phase b), not kept in registers:
-        // values that live across the whole slice get spilled, and a kernel that touches scratch
-        // memory at all pays for it at dispatch.
-        unsigned nextId = 0;
-        if (tid == 0) nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the loads below
+        // the next slice header goes through LDS, not registers: values that live across the whole
+        // slice get spilled, and a kernel that touches scratch memory at all pays for it at dispatch
+        if (tid == 0) S.nextId = atomicAdd(&ctrl3[1], 1u);   // in flight during the loads below
         int ttx, tty;
         if (sl.x < (unsigned)V3_NBLK) {
             pp3_tile_of((int)sl.x, &ttx, &tty);
@@ -520,27 +480,20 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
 #pragma unroll
         for (int u = 0; u < V3_RPT; ++u) {
             const int pk = __float_as_int(h4[u].w);
-            pp3_cursor_count(S.cursor, (unsigned)pk & (V3_NC - 1), pk >= 0);
+            if (pk >= 0) atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u);
         }
-        uint4 nextSl = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0 && nextId < nSlices) nextSl = slices[nextId];   // lands during the barrier
+        if (tid == 0 && S.nextId < nSlices) S.nextSlice = slices[S.nextId];
         __syncthreads();
         PP3_TICK(0)
-        if (tid == 0) {
-            S.nextId = nextId;
-            S.nextSlice = nextSl;
-        }
         // ---- (b) cell offsets, window tables, bands -----------------------------------
         if (tid < 64) {   // exclusive scan of the 64 cell counts
             const unsigned c0 = S.cursor[tid];
-            unsigned inc = c0, mx = c0;
+            unsigned inc = c0;
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned u = __shfl_up(inc, o);
                 if (lane >= o) inc += u;
-                mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
             }
             S.cursor[tid] = inc - c0;
-            if (tid == 0) S.maxCell = mx;
         } else if (tid < 64 + V3_W * (V3_W + 1)) {   // positions inside a window row
             const int e = tid - 64, r = e / (V3_W + 1);
             S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * (V3_W + 1)], 65535u);
@@ -574,19 +527,10 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         }
         __syncthreads();
         // ---- (c) scatter the records into LDS (cell-sorted) -----------------------------
-        if (S.maxCell > 256u) {   // a crowded cell: one cursor atomic per (wavefront, cell)
 #pragma unroll
-            for (int u = 0; u < V3_RPT; ++u) {
-                const int pk = __float_as_int(h4[u].w);
-                const unsigned at = pp3_cursor_take(S.cursor, (unsigned)pk & (V3_NC - 1), pk >= 0);
-                if (pk >= 0) srec[at] = h4[u];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < V3_RPT; ++u) {
-                const int pk = __float_as_int(h4[u].w);
-                if (pk >= 0) srec[atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u)] = h4[u];
-            }
+        for (int u = 0; u < V3_RPT; ++u) {
+            const int pk = __float_as_int(h4[u].w);
+            if (pk >= 0) srec[atomicAdd(&S.cursor[pk & (V3_NC - 1)], 1u)] = h4[u];
         }
         // cursor[k] becomes the END of cell k; cell k starts at cursor[k-1]
         PP3_TICK(1)
