@@ -64,3 +64,68 @@ def test_cli_end_to_end_nuscenes_config(gpu, golden_dir, tmp_path):
     np.testing.assert_allclose(got, g["objs"], rtol=1e-9, atol=1e-12)
     gen_label_files.main(config.compose("generate_label_files", ov + ["image_shape=[900,1600]"]))
     assert open(f"{out}/labels/{origin:06d}.txt").read() == str(g["label_txt"])
+
+
+def test_full_pipeline_is_deterministic_and_thread_safe(gpu):
+    """The whole seed-label pipeline of one synthetic scan (BASELINE config-3 shape, smaller sizes):
+    identical PP scores, labels, boxes and label text when repeated on one context and when run from
+    four threads at once (one HIP stream + modest_ctx each, as bench.py's in-process mode does) --
+    atomics-based kernels (compaction look-back, union-find, cursor scatter) must not leak their
+    scheduling into the results."""
+    import os
+    import tempfile
+    import threading
+
+    import torch
+    from modest_amd import _lib, config, ops, synth
+    from modest_amd.gen_label_files import gen_label_scan
+    from modest_amd.generate_mask import generate_mask_scan
+    from modest_amd.utils import kitti_util
+
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+    margs = config.compose("generate_mask", ["data_root=/unused"])
+    largs = config.compose("generate_label_files", ["data_root=/unused"])
+    sc = synth.make_scan(77, n_live=20_000, n_trav=6, n_frames=12)
+    live_raw = torch.from_numpy(sc.live_raw).to(gpu)
+    live_xyz = torch.from_numpy(sc.live_xyz).to(gpu)
+    hist = torch.from_numpy(np.concatenate(sc.hist)).to(gpu)
+    offsets = np.cumsum([0] + [len(h) for h in sc.hist]).astype(np.int64)
+
+    def run(ctx):
+        H = ops.pp_score(live_xyz, hist, offsets, 0.3, ctx=ctx)
+        pp_host = H.cpu().numpy()
+        labels, objs, _ = generate_mask_scan(sc.live_raw, pp_host, calib, margs, random_state=np.random.RandomState(5),
+                                             ptc_dev=live_raw, pp_dev=H)
+        text, kept = gen_label_scan(objs, calib, largs)
+        boxes = np.array([[*o.t, o.l, o.w, o.h, o.ry] for o in objs], dtype=np.float64).reshape(-1, 7)
+        return pp_host, labels, boxes, text
+
+    ctx0 = _lib.Context(torch.cuda.current_device())
+    ref = run(ctx0)
+    assert ref[1].max() >= 3 and len(ref[2]) >= 3, "the scan must produce a few clusters and boxes"
+    for _ in range(2):
+        got = run(ctx0)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert np.array_equal(got[2], ref[2]) and got[3] == ref[3]
+
+    results, errs = [None] * 4, []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(gpu)
+            with torch.cuda.stream(torch.cuda.Stream(device=gpu)):
+                ctx = _lib.Context(torch.cuda.current_device())
+                results[k] = [run(ctx) for _ in range(3)]
+        except BaseException as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for per_thread in results:
+        for got in per_thread:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+            assert np.array_equal(got[2], ref[2]) and got[3] == ref[3]
