@@ -175,6 +175,37 @@ def pca_rectangles(clusters_xz: Sequence[np.ndarray]):
     return out
 
 
+def min_area_rectangles(clusters_xz: Sequence[np.ndarray]):
+    """minimum_bounding_rectangle (:88-147, fit_method='min_zx_area_fit') per cluster.
+
+    The reference tries the directions of the hull edges ``hull[1:] - hull[:-1]`` in the vertex order
+    scipy's ConvexHull (Qhull) reports and never the closing edge, so its answer depends on the
+    vertex Qhull happens to start from.  The hull therefore comes from the same library call on the
+    host (tens of vertices; the only O(n) step of this branch), the caliper arithmetic follows the
+    reference line by line in numpy; the lowest-point search of get_obj stays on the device."""
+    from scipy.spatial import ConvexHull
+    half_pi = np.pi / 2.
+    out = []
+    for pts in clusters_xz:
+        hull = pts[ConvexHull(pts).vertices]
+        step = hull[1:] - hull[:-1]
+        ang = np.unique(np.abs(np.mod(np.arctan2(step[:, 1], step[:, 0]), half_pi)))
+        rot = np.vstack([np.cos(ang), np.cos(ang - half_pi), np.cos(ang + half_pi), np.cos(ang)]).T.reshape((-1, 2, 2))
+        turned = np.dot(rot, hull.T)
+        lo_x, hi_x = np.nanmin(turned[:, 0], axis=1), np.nanmax(turned[:, 0], axis=1)
+        lo_y, hi_y = np.nanmin(turned[:, 1], axis=1), np.nanmax(turned[:, 1], axis=1)
+        area = (hi_x - lo_x) * (hi_y - lo_y)
+        k = np.argmin(area)
+        r = rot[k]
+        corners = np.zeros((4, 2))
+        corners[0] = np.dot([hi_x[k], lo_y[k]], r)
+        corners[1] = np.dot([lo_x[k], lo_y[k]], r)
+        corners[2] = np.dot([lo_x[k], hi_y[k]], r)
+        corners[3] = np.dot([hi_x[k], hi_y[k]], r)
+        out.append((corners, ang[k], area[k]))
+    return out
+
+
 def closeness_rectangle(cluster_ptc, delta=0.1, d0=1e-2):
     """(:167-216) single-cluster form."""
     return closeness_rectangles([np.asarray(cluster_ptc, dtype=np.float64)], delta, d0)[0]
@@ -201,11 +232,9 @@ def get_objs(clusters_rect: List[np.ndarray], full_ptc, fit_method="closeness_to
     """Batched get_obj (:292-317) for a scan: boxes of all clusters.
     clusters_rect: list of (n_c,3) float64 rect-frame points; full_ptc (N,3) float64."""
     fitters = {"closeness_to_edge": closeness_rectangles, "variance_to_edge": variance_rectangles,
-               "PCA": pca_rectangles}
+               "PCA": pca_rectangles, "min_zx_area_fit": min_area_rectangles}
     if fit_method not in fitters:
-        # min_zx_area_fit walks the hull edges in scipy/Qhull's vertex order and skips the closing
-        # edge (pointcloud_utils.py:104-107): not reproducible without Qhull's starting vertex
-        raise NotImplementedError(f"fit_method={fit_method!r} (SURVEY.md §8f-3)")
+        raise NotImplementedError(fit_method)
     if len(clusters_rect) == 0:
         return []
     fits = fitters[fit_method]([c[:, [0, 2]] for c in clusters_rect])

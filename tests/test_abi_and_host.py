@@ -154,3 +154,18 @@ def test_label_helpers_equal_numpy_formulation():
         for i, m in enumerate(mem, start=1):
             assert np.array_equal(m, np.flatnonzero(c == i))
     assert compact_labels(np.zeros(0, dtype=np.int64)).shape == (0,)
+
+
+def test_min_area_rectangles_equal_reference_golden(golden_dir):
+    """fit_method='min_zx_area_fit': the host caliper search over Qhull's hull order reproduces the
+    reference's rectangles (fixtures generated by tools/make_golden_fits.py from the reference)."""
+    import os
+    from modest_amd.utils import pointcloud_utils as pu
+    g = np.load(os.path.join(golden_dir, "mask_stage.npz"))
+    f = np.load(os.path.join(golden_dir, "fit_variants.npz"))
+    off, pts = g["cl_offsets"], g["cl_pts"]
+    clusters = [pts[off[k]:off[k + 1]] for k in range(len(off) - 1)]
+    got = pu.min_area_rectangles(clusters)
+    assert len(got) == len(f["minarea"])
+    for k, (corners, angle, area) in enumerate(got):
+        assert np.array_equal(np.concatenate([corners.reshape(-1), [angle, area]]), f["minarea"][k]), k

@@ -395,8 +395,14 @@ def test_fit_variants_vs_reference_golden(gpu, golden_dir):
         b_in = om.get_lowest_point_rect(rect, c, x.l - 1e-7, x.w - 1e-7, x.ry)
         b_out = om.get_lowest_point_rect(rect, c, x.l + 1e-7, x.w + 1e-7, x.ry)
         assert b_in <= x.t[1] <= b_out and b_in <= r[1] <= b_out
+    # min_zx_area_fit: hull from the same Qhull call as the reference, everything else ours
+    got = pu.min_area_rectangles(clusters)
+    for k, (corners, angle, area) in enumerate(got):
+        assert np.array_equal(np.concatenate([corners.reshape(-1), [angle, area]]), f["minarea"][k]), k
+    o = pu.get_objs(members, rect, fit_method="min_zx_area_fit")
+    assert np.array_equal(np.array([[*x.t, x.l, x.w, x.h, x.ry, x.volume] for x in o]), f["objs_min_zx_area_fit"])
     with pytest.raises(NotImplementedError):
-        pu.get_objs(members, rect, fit_method="min_zx_area_fit")
+        pu.get_objs(members, rect, fit_method="no_such_fit")
     # variance criterion values against the oracle on random clusters of awkward sizes (pairwise-sum edges)
     from modest_amd import ops
     from oracle import mask as om
