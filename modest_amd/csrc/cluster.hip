@@ -500,10 +500,12 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
                                                               const double *__restrict__ kthS, EdgeP ep, int min_samples,
                                                               unsigned char *__restrict__ coreS,
                                                               int *__restrict__ deg, int *__restrict__ adj,
-                                                              int *overflow) {
+                                                              int *overflow, const int *__restrict__ sidx,
+                                                              int *__restrict__ parent) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;
+    if (lane == 0) parent[sidx[s]] = sidx[s];   // uf_init, one launch less (sidx is a permutation)
     const float4 q = sorted[s];
     const double kq = kthS[s];
     const Rows R = rows_of(q, g, start);
@@ -931,8 +933,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     if (ep.use_knn || kth_d2)
         knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
     degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
-                                                  overflow);
-    uf_init<<<nb, 256, 0, stream>>>(parent, n);
+                                                  overflow, sidx, parent);
     for (int round = 0; round < HOOK_ROUNDS; ++round) {   // accelerators only: union_adj_kernel makes the result exact
         hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
         flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);

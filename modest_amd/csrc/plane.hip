@@ -246,6 +246,45 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// exact-fit plane through three candidates (see fit_kernel)
+__device__ __forceinline__ void fit_triplet(const float *__restrict__ cand, int n, int i0, int i1, int i2, float *c0,
+                                            float *c1, float *b) {
+    const int idx[3] = {i0, i1, i2};
+    double x[3], y[3], z[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = min(max(idx[j], 0), n - 1);
+        x[j] = cand[3 * (size_t)i];
+        y[j] = cand[3 * (size_t)i + 1];
+        z[j] = cand[3 * (size_t)i + 2];
+    }
+    const double mx = (x[0] + x[1] + x[2]) / 3.0, my = (y[0] + y[1] + y[2]) / 3.0, mz = (z[0] + z[1] + z[2]) / 3.0;
+    double sxx = 0, sxy = 0, syy = 0, sxz = 0, syz = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double dx = x[j] - mx, dy = y[j] - my, dz = z[j] - mz;
+        sxx += dx * dx;
+        sxy += dx * dy;
+        syy += dy * dy;
+        sxz += dx * dz;
+        syz += dy * dz;
+    }
+    const double det = sxx * syy - sxy * sxy;
+    *c0 = *c1 = *b = NAN;
+    if (fabs(det) > 1e-12 * fmax(sxx * syy, 1e-300)) {
+        const double a0 = (sxz * syy - syz * sxy) / det, a1 = (syz * sxx - sxz * sxy) / det;
+        *c0 = (float)a0;
+        *c1 = (float)a1;
+        *b = (float)(mz - a0 * mx - a1 * my);
+    }
+}
+
+// The triplets of a batch travel as a kernel argument (no upload, no separate fit launch).
+constexpr int TRIP_MAX = 64;
+struct TripArg {
+    int t[3 * TRIP_MAX];
+};
+
 // One block scores SCORE_PTS candidates against SCORE_KG trials: every thread keeps its
 // SCORE_PPT points in registers, sums its own inliers first and the wavefront reduces once per
 // trial; wavefronts write their own partial rows (no block barrier anywhere).
@@ -253,10 +292,29 @@ __device__ __forceinline__ double wave_sum(double v) {
 constexpr int SCORE_PPT = 4;
 constexpr int SCORE_PTS = SCORE_THREADS * SCORE_PPT;
 constexpr int SCORE_KG = 8;
+template <bool FUSED>
 __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
                                                               const float *__restrict__ models,
                                                               int K, const float *__restrict__ thr_ptr,
-                                                              double *__restrict__ partial) {
+                                                              double *__restrict__ partial, TripArg trip,
+                                                              float *__restrict__ models_host) {
+    __shared__ float sm[SCORE_KG][3];
+    if (FUSED) {   // the block fits its own SCORE_KG planes; the first block column reports them
+        const int k = blockIdx.y * SCORE_KG + (int)threadIdx.x;
+        if (threadIdx.x < SCORE_KG && k < K) {
+            float c0, c1, b;
+            fit_triplet(cand, n, trip.t[3 * k], trip.t[3 * k + 1], trip.t[3 * k + 2], &c0, &c1, &b);
+            sm[threadIdx.x][0] = c0;
+            sm[threadIdx.x][1] = c1;
+            sm[threadIdx.x][2] = b;
+            if (blockIdx.x == 0) {
+                models_host[3 * k] = c0;
+                models_host[3 * k + 1] = c1;
+                models_host[3 * k + 2] = b;
+            }
+        }
+        __syncthreads();
+    }
     const float thr = *thr_ptr;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float x[SCORE_PPT], y[SCORE_PPT], z[SCORE_PPT];
@@ -273,7 +331,8 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
     const int k0 = blockIdx.y * SCORE_KG, k1 = min(k0 + SCORE_KG, K);
     double *row = partial + ((size_t)(blockIdx.x * SCORE_WAVES + w) * K) * 4;
     for (int k = k0; k < k1; ++k) {
-        const float c0 = models[3 * k], c1 = models[3 * k + 1], b = models[3 * k + 2];
+        const float c0 = FUSED ? sm[k - k0][0] : models[3 * k], c1 = FUSED ? sm[k - k0][1] : models[3 * k + 1];
+        const float b = FUSED ? sm[k - k0][2] : models[3 * k + 2];
         unsigned cnt = 0;
         double sse = 0.0, sy = 0.0, syy = 0.0;
 #pragma unroll
@@ -305,32 +364,8 @@ __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__r
                            float *__restrict__ models, float *__restrict__ models_host) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    double x[3], y[3], z[3];
-    for (int j = 0; j < 3; ++j) {
-        int i = trip[3 * k + j];
-        i = min(max(i, 0), n - 1);
-        x[j] = cand[3 * (size_t)i];
-        y[j] = cand[3 * (size_t)i + 1];
-        z[j] = cand[3 * (size_t)i + 2];
-    }
-    const double mx = (x[0] + x[1] + x[2]) / 3.0, my = (y[0] + y[1] + y[2]) / 3.0, mz = (z[0] + z[1] + z[2]) / 3.0;
-    double sxx = 0, sxy = 0, syy = 0, sxz = 0, syz = 0;
-    for (int j = 0; j < 3; ++j) {
-        const double dx = x[j] - mx, dy = y[j] - my, dz = z[j] - mz;
-        sxx += dx * dx;
-        sxy += dx * dy;
-        syy += dy * dy;
-        sxz += dx * dz;
-        syz += dy * dz;
-    }
-    const double det = sxx * syy - sxy * sxy;
-    float c0 = NAN, c1 = NAN, b = NAN;
-    if (fabs(det) > 1e-12 * fmax(sxx * syy, 1e-300)) {
-        const double a0 = (sxz * syy - syz * sxy) / det, a1 = (syz * sxx - sxz * sxy) / det;
-        c0 = (float)a0;
-        c1 = (float)a1;
-        b = (float)(mz - a0 * mx - a1 * my);
-    }
+    float c0, c1, b;
+    fit_triplet(cand, n, trip[3 * k], trip[3 * k + 1], trip[3 * k + 2], &c0, &c1, &b);
     models[3 * k] = c0;
     models[3 * k + 1] = c1;
     models[3 * k + 2] = b;
@@ -358,13 +393,39 @@ __global__ __launch_bounds__(64) void score_reduce_kernel(const double *__restri
 // ---- refit ---------------------------------------------------------------------
 // pass 0: count, sum x, sum y, sum z over inliers; pass 1: centred 2nd moments
 // Sxx, Sxy, Syy, Sxz, Syz given the means.
+// PASS 1 first reduces pass 0's per-block partials itself (the lane-strided sums and shuffle tree
+// of refit_reduce_kernel, so the means are bit-identical in every block) -- one launch less.
 template <int PASS>
 __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n,
                                                               float c0, float c1, float b, float thr,
-                                                              const double *__restrict__ means,
+                                                              const double *__restrict__ partial0, int nblocks0,
+                                                              double *__restrict__ acc,
                                                               double *__restrict__ partial) {
     constexpr int NV = PASS == 0 ? 4 : 5;
     __shared__ double red[SCORE_WAVES][5];
+    __shared__ double means[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (PASS == 1) {
+        if (w == 0) {
+            double s[4] = {0, 0, 0, 0};
+            for (int bb = lane; bb < nblocks0; bb += 64)
+                for (int q = 0; q < 4; ++q) s[q] += partial0[(size_t)bb * 5 + q];
+            for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
+            if (lane == 0) {
+                const double inv = s[0] > 0 ? 1.0 / s[0] : 0.0;
+                means[0] = s[1] * inv;
+                means[1] = s[2] * inv;
+                means[2] = s[3] * inv;
+                if (blockIdx.x == 0) {   // [0..3] sums, [4..6] means for the final reduction's mirror
+                    for (int q = 0; q < 4; ++q) acc[q] = s[q];
+                    acc[4] = means[0];
+                    acc[5] = means[1];
+                    acc[6] = means[2];
+                }
+            }
+        }
+        __syncthreads();
+    }
     const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
     double v[5] = {0, 0, 0, 0, 0};
     if (i < n) {
@@ -385,7 +446,6 @@ __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__res
             }
         }
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         const double s = wave_sum(v[q]);
@@ -538,8 +598,8 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     for (int i = 0; i < K * 3; ++i) hm[i] = models_host[i];
     hm[K * 3] = thr;   // the kernel reads the threshold from device memory
     MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12 + 4, hipMemcpyHostToDevice, stream));
-    score_kernel<<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(cand, n_cand, dm, K,
-                                                                                       dm + 3 * K, dp);
+    score_kernel<false><<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(
+        cand, n_cand, dm, K, dm + 3 * K, dp, TripArg{}, nullptr);
     score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nrows, K, dout);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
@@ -591,9 +651,17 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
         h_thr_in[1] = *thr_inout;
         MODEST_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr_in, 8, hipMemcpyHostToDevice, stream));
     }
-    fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, h_tripp, K, d_models, h_models);
-    score_kernel<<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K,
-                                                                                       d_thr + 1, d_part);
+    const dim3 sgrid(nb, (K + SCORE_KG - 1) / SCORE_KG);
+    if (K <= TRIP_MAX) {
+        TripArg ta;
+        for (int i = 0; i < 3 * K; ++i) ta.t[i] = trip_host[i];
+        score_kernel<true><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, nullptr, K, d_thr + 1, d_part, ta,
+                                                               h_models);
+    } else {
+        fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, h_tripp, K, d_models, h_models);
+        score_kernel<false><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K, d_thr + 1, d_part,
+                                                                TripArg{}, nullptr);
+    }
     score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, h_outp, d_thr, h_thr);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -619,7 +687,7 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
-    const size_t b_part = arena_sz((size_t)nb * 40), b_acc = arena_sz(16 * 8);
+    const size_t b_part = arena_sz((size_t)nb * 80), b_acc = arena_sz(16 * 8);
     int rc = modest_ctx_reserve(ctx, b_part + b_acc);
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 16 * 8);
@@ -627,11 +695,11 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     double *dp = reinterpret_cast<double *>(ctx->scratch);
     double *acc = reinterpret_cast<double *>(ctx->scratch + b_part);
     const float c0 = model_host[0], c1 = model_host[1], b = model_host[2];
-    refit_kernel<0><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, nullptr, dp);
-    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 0, acc);
-    refit_kernel<1><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, acc + 4, dp);
+    double *dp1 = dp + (size_t)nb * 5;   // pass 1 reads pass 0's partials while it writes its own
+    refit_kernel<0><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, nullptr, 0, nullptr, dp);
+    refit_kernel<1><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, nb, acc, dp1);
     double *h = reinterpret_cast<double *>(ctx->pinned);
-    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp, nb, 1, acc, h);   // results straight into pinned host memory
+    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp1, nb, 1, acc, h);   // results straight into pinned host memory
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     const double cnt = h[0], mx = h[4], my = h[5], mz = h[6];
