@@ -73,6 +73,30 @@ def test_plane_candidates_mad_and_scoring(gpu, ms):
         assert abs(sy[k] - z[inl].astype(np.float64).sum()) <= 1e-9 * max(1.0, abs(sy[k]))
 
 
+def test_ransac_trials_batch_paths_agree(gpu, ms):
+    """One round trip per batch of trials: batches of up to 64 triplets travel as a kernel argument and
+    are fitted inside the scoring kernel, larger ones through the separate fit kernel; both must give
+    the same planes and sums as the explicit-model scoring entry point, trial by trial."""
+    import torch
+    from modest_amd import ops
+    dev = torch.from_numpy(ms["ptc"]).to(gpu)
+    cand, _ = ops.plane_candidates(dev, -1.5, [[-70, 70], [-20, 20]])
+    n = cand.shape[0]
+    trip = np.random.RandomState(2).randint(0, n, size=(150, 3))
+    trip[7] = [5, 5, 9]                                # degenerate triplet -> NaN model, no inliers
+    thr, models_big, n_big, sse_big, sy_big, syy_big = ops.ransac_trials(cand, trip)          # K = 150
+    assert thr == ops.mad_threshold(cand)
+    for lo, hi in ((0, 48), (48, 112), (112, 150), (7, 8)):                                     # K <= 64
+        t2, m2, n2, sse2, sy2, syy2 = ops.ransac_trials(cand, trip[lo:hi], thr)
+        assert t2 == thr and np.array_equal(m2, models_big[lo:hi], equal_nan=True)
+        assert np.array_equal(n2, n_big[lo:hi]) and np.array_equal(sse2, sse_big[lo:hi])
+        assert np.array_equal(sy2, sy_big[lo:hi]) and np.array_equal(syy2, syy_big[lo:hi])
+    ok = ~np.isnan(models_big[:, 0])
+    assert not ok[7] and n_big[7] == 0 and ok.sum() >= 140
+    n3, sse3, sy3, syy3 = ops.ransac_score_trials(cand, models_big[ok], thr)
+    assert np.array_equal(n3, n_big[ok]) and np.array_equal(sse3, sse_big[ok]) and np.array_equal(syy3, syy_big[ok])
+
+
 def test_ransac_plane_vs_sklearn(gpu, ms):
     import torch
     from modest_amd.utils import pointcloud_utils as pcu
