@@ -58,6 +58,26 @@ __device__ double pw_leaf(const BetaCtx &B, int off, int n) {
     return res;
 }
 
+// the same leaf on eight adjacent lanes (j = lane & 7): lane j owns numpy's accumulator r[j], the
+// three shuffle-adds rebuild ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) (every level adds the same two
+// values on both sides, so all eight lanes end up with numpy's bits), lane 0's tail loop follows.
+// Must be called by all eight lanes; the result is valid on every one of them.
+__device__ __forceinline__ double pw_leaf8(const BetaCtx &B, int off, int n, int j) {
+    if (n < 8) {   // wave-divergence free: every lane of the group takes the same branch
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += beta_at(B, off + i);
+        return res;
+    }
+    const int body = n - (n % 8);
+    double r = beta_at(B, off + j);
+    for (int i = 8 + j; i < body; i += 8) r += beta_at(B, off + i);
+    r += __shfl_xor(r, 1);
+    r += __shfl_xor(r, 2);
+    r += __shfl_xor(r, 4);
+    for (int i = body; i < n; ++i) r += beta_at(B, off + i);
+    return r;
+}
+
 // explicit-stack form of: n<=128 ? leaf : sum(a,n2) + sum(a+n2,n-n2), n2 = n/2 - (n/2)%8
 __device__ double pw_tree(const BetaCtx &B, int off0, int n) {
     int f_off[32], f_n[32], f_stage[32];
@@ -194,9 +214,13 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
     B.miny = mny;
     B.maxy = mxy;
     double *ls = ct_lsum + (size_t)al * maxLeaves;
-    for (int l = sub; l < nl; l += P) {
-        const int2 lf = leaves[lb + l];
-        ls[l] = pw_leaf(B, lf.x, lf.y);
+    // eight lanes per leaf (one per numpy accumulator): a scan's clusters have a handful of leaves,
+    // one lane per leaf left most lanes idle behind a 128-element serial chain of divisions
+    for (int l0 = 0; l0 < nl; l0 += P / 8) {   // block-uniform trip count (pw_leaf8 shuffles)
+        const int l = l0 + sub / 8;
+        const int2 lf = l < nl ? leaves[lb + l] : make_int2(0, 0);
+        const double v = pw_leaf8(B, lf.x, lf.y, sub & 7);
+        if (l < nl && (sub & 7) == 0) ls[l] = v;
     }
     __syncthreads();
     if (sub != 0 || a >= n_angles) return;
