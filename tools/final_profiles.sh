@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/final; rm -rf $F; mkdir -p $F
 line() { grep '^{"metric"' | tail -1; }
+python bench.py --cpu-scans 0 > /dev/null 2>&1   # warm the box (clocks, page cache)
 python bench.py 2>/dev/null | line > $F/bench_full.json
 python bench.py --cpu-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_full_1proc.json
 python bench.py --pp-only --cpu-scans 0 2>/dev/null | line > $F/bench_pp_only.json
