@@ -16,7 +16,7 @@
 //       one LDS atomic per pair .............  ~400 us
 //   V3 (pp_v3.h): records sorted by cell, wave-uniform candidate lists, ballot +
 //       popcount instead of atomics ......... ~330 us
-// V1 stays as the path for more than 32 traversals and for A/B runs (MODEST_PP_VARIANT=1).
+// V1 stays as the path for more than 64 traversals and for A/B runs (MODEST_PP_VARIANT=1).
 #include "pp_common.h"
 #include <cmath>
 #include <cstdio>
@@ -379,7 +379,7 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
     const char *var_env = getenv("MODEST_PP_VARIANT");
     int var = var_env ? atoi(var_env) : 3;
-    if (var != 1 || n_trav > V3_MAXT) var = n_trav > V3_MAXT ? 1 : 3;   // more than 32 traversals: the direct path
+    if (var != 1 || n_trav > V3_MAXT) var = n_trav > V3_MAXT ? 1 : 3;   // more than 64 traversals: the direct path
     if (var == 3)   // the extra blocks count the live points of every 8x8-cell block window
         pp3_scatter_blocklive<<<nb + (V3_NBLK + 255) / 256, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill,
                                                                              sorted, nb, blockLive);

@@ -45,7 +45,7 @@ constexpr int V3_NL = V3_NBLK + 4 * V3_DMAX;   // 7168 lists
 constexpr int V3_NC = V3_TS * V3_TS;        // 64 cells per block = sort keys of a slice
 constexpr int V3_W = V3_TS + 2;             // 10: window incl. halo
 constexpr int V3_CH = 4096;                 // history points per chunk (1024 threads x 4)
-constexpr int V3_MAXT = 32;                 // traversals handled by the routed path (5 bits, one lane each)
+constexpr int V3_MAXT = 64;                 // traversals handled by the routed path (6 bits, one lane each)
 constexpr int V3_MAXWG = 512;               // stream workgroups
 constexpr int V3_JT = 1024;                 // threads of a join workgroup
 constexpr int V3_RPT = 4;                   // records per join thread
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 const float4 h = valid ? srec[j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int pk = valid ? __float_as_int(h.w) : -1;
                 const int key = pk & (V3_NC - 1);
-                const unsigned trv = (unsigned)(pk >> 16) & 31u;
+                const unsigned trv = (unsigned)(pk >> 16) & 63u;
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
                 const unsigned sel0 = (lq & 1) ? 0u : ~0u, sel1 = (lq & 2) ? 0u : ~0u;
@@ -606,6 +606,10 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                     const unsigned long long s3 = ((unsigned long long)sel3 << 32) | sel3;
                     const unsigned long long s4 = ((unsigned long long)sel4 << 32) | sel4;
                     seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3) & (B4 ^ s4);
+                    if (T > 32) {   // sixth traversal bit only when there are that many (wave-uniform)
+                        const unsigned sel5 = (lq & 32) ? 0u : ~0u;
+                        seg &= __ballot(trv & 32u) ^ (((unsigned long long)sel5 << 32) | sel5);
+                    }
                 }
                 const unsigned segLo = (unsigned)seg, segHi = (unsigned)(seg >> 32);
                 unsigned long long todo = __ballot(valid);

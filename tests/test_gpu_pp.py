@@ -103,10 +103,10 @@ def test_pp_linearity_full_size(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T", [17, 32, 40])
+@pytest.mark.parametrize("T", [17, 32, 33, 40, 64, 65])
 def test_pp_many_traversals(gpu, T):
-    """17 and 32 traversals use the routed path (one lane per traversal in the segmented
-    popcount), 40 the direct path; ragged traversal sizes, some of them empty."""
+    """Up to 64 traversals use the routed path (one lane per traversal in the segmented popcount,
+    a sixth traversal bit beyond 32), 65 the direct path; ragged traversal sizes, some of them empty."""
     import torch
     from modest_amd import ops
     from oracle import pp_score as opp
