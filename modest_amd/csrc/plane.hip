@@ -79,10 +79,18 @@ __device__ __forceinline__ void for_keys(const KeysReg &K, int n, F f) {
 }
 template <class F>
 __device__ __forceinline__ void for_keys(const KeysGlobal &K, int n, F f) {
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const float v = i < n ? K.cand[3 * (size_t)i + 2] : 0.f;
-        f(f2key(K.mode ? fabsf(v - K.center) : v), i < n);
+    for (int base = 0; base < n; base += 8 * 1024) {   // eight strided loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 1024 + (int)threadIdx.x;
+            v[u] = i < n ? K.cand[3 * (size_t)i + 2] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (base + u * 1024 >= n) break;   // wave-uniform
+            f(f2key(K.mode ? fabsf(v[u] - K.center) : v[u]), base + u * 1024 + (int)threadIdx.x < n);
+        }
     }
 }
 

@@ -9,7 +9,8 @@ scan = synth.make_scan(3)
 pts = to_device(np.ascontiguousarray(scan.live_raw, dtype=np.float32))
 cand, _ = ops.plane_candidates(pts, -1.5, ((-20, 70), (-20, 20)))
 print("candidates", cand.shape[0])
-vals = [float(ops.mad_threshold(cand)) for _ in range(200)]
-z = cand[:, 2].cpu().numpy()
-ref = np.median(np.abs(z - np.median(z)))
-print("mad", vals[0], "numpy", float(ref), "equal", vals[0] == float(ref), "stable", len(set(vals)) == 1)
+for c in (cand, torch.cat([cand] * 5)[: 70000].contiguous()):      # register-resident path / > 32768 candidates
+    vals = [float(ops.mad_threshold(c)) for _ in range(100)]
+    z = c[:, 2].cpu().numpy()
+    ref = np.median(np.abs(z - np.median(z)))
+    print("n", c.shape[0], "mad", vals[0], "numpy", float(ref), "equal", vals[0] == float(ref), "stable", len(set(vals)) == 1)
