@@ -129,3 +129,52 @@ def test_full_pipeline_is_deterministic_and_thread_safe(gpu):
         for got in per_thread:
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
             assert np.array_equal(got[2], ref[2]) and got[3] == ref[3]
+
+
+@pytest.mark.parametrize("case", ["dense", "sparse", "no_objects", "low_pp"])
+def test_scan_pipeline_equals_oracle_on_synthetic_scans(gpu, case):
+    """generate_mask_scan + gen_label_scan of whole synthetic scans against the oracle's restatement
+    of the reference loop (same RandomState for the two RANSAC fits): final labels equal, boxes within
+    1e-9, label text identical -- on a scan with many objects, a sparse one, one whose points are all
+    ground (no cluster survives) and one whose PP scores are high everywhere (every cluster is
+    filtered as persistent)."""
+    import os
+    import tempfile
+    import torch
+    from modest_amd import config, ops, synth
+    from modest_amd.gen_label_files import gen_label_scan
+    from modest_amd.generate_mask import generate_mask_scan
+    from modest_amd.utils import kitti_util
+    from oracle import labels as ol
+    from oracle import mask as om
+
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+    margs = config.compose("generate_mask", ["data_root=/unused"])
+    largs = config.compose("generate_label_files", ["data_root=/unused"])
+    n_live = {"dense": 24_000, "sparse": 3_000, "no_objects": 12_000, "low_pp": 12_000}[case]
+    sc = synth.make_scan(31 + len(case), n_live=n_live, n_trav=4, n_frames=8)
+    raw = sc.live_raw.copy()
+    if case == "no_objects":
+        raw = raw[raw[:, 2] < -1.45]                   # ground returns only
+    live_xyz = np.ascontiguousarray(raw[:, :3])
+    hist = np.concatenate(sc.hist)
+    offsets = np.cumsum([0] + [len(h) for h in sc.hist]).astype(np.int64)
+    H = ops.pp_score(torch.from_numpy(live_xyz).to(gpu), torch.from_numpy(hist).to(gpu), offsets, 0.3)
+    if case == "low_pp":
+        H = torch.full_like(H, 0.95)                   # persistent everywhere: min_percentile_pp_score filters all
+    pp = H.cpu().numpy()
+    labels, objs, _ = generate_mask_scan(raw, pp, calib, margs, random_state=np.random.RandomState(9),
+                                         ptc_dev=torch.from_numpy(raw).to(gpu), pp_dev=H)
+    text, _ = gen_label_scan(objs, calib, largs)
+    ref = om.generate_mask_scan(raw, pp, calib, random_state=np.random.RandomState(9), n_jobs=1)
+    ref_text, _ = ol.gen_label_scan(ref["objs"], calib)
+    assert np.array_equal(labels, ref["labels"])
+    assert len(objs) == len(ref["objs"])
+    if case in ("no_objects", "low_pp"):
+        assert len(objs) == 0 and labels.max() == 0
+    for o, r in zip(objs, ref["objs"]):
+        np.testing.assert_allclose([*o.t, o.l, o.w, o.h, o.ry, o.volume], [*r.t, r.l, r.w, r.h, r.ry, r.volume],
+                                   rtol=1e-9, atol=1e-9)
+    assert text == ref_text
