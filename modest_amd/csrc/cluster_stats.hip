@@ -161,8 +161,35 @@ __global__ __launch_bounds__(CSS_THREADS) void cs_stats(const float *__restrict_
         gamma = (double)(vi - fl);
         if (cached) {
             const auto key_at = [&](int i) { return keys[i]; };
-            a = (double)cs_select_keys<CSS_THREADS>(key_at, n, (unsigned)prev, hist, wsum, sel);
-            b = (next == prev) ? a : (double)cs_select_keys<CSS_THREADS>(key_at, n, (unsigned)next, hist, wsum, sel);
+            const float af = cs_select_keys<CSS_THREADS>(key_at, n, (unsigned)prev, hist, wsum, sel);
+            a = (double)af;
+            b = a;
+            if (next != prev) {
+                // the neighbour rank prev + 1 without a second descent: it is the same value when more
+                // than `next` keys are <= a, the smallest key above a otherwise (one pass over LDS)
+                const unsigned akey = cs_key(af);
+                if (tid == 0) {
+                    sel[0] = 0;
+                    sel[1] = 0xffffffffu;
+                }
+                __syncthreads();
+                unsigned cle = 0, mgt = 0xffffffffu;
+                for (int i = tid; i < n; i += CSS_THREADS) {
+                    const unsigned k = keys[i];
+                    cle += k <= akey ? 1u : 0u;
+                    mgt = k > akey ? min(mgt, k) : mgt;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    cle += __shfl_xor(cle, o);
+                    mgt = min(mgt, (unsigned)__shfl_xor((int)mgt, o));
+                }
+                if ((tid & 63) == 0) {
+                    atomicAdd(&sel[0], cle);
+                    atomicMin(&sel[1], mgt);
+                }
+                __syncthreads();
+                b = sel[0] > (unsigned)next ? a : (double)cs_unkey(sel[1]);
+            }
         } else {
             a = (double)cs_select<CSS_THREADS>(pp, mem, n, (unsigned)prev, hist, wsum, sel);
             b = (next == prev) ? a : (double)cs_select<CSS_THREADS>(pp, mem, n, (unsigned)next, hist, wsum, sel);
