@@ -19,7 +19,8 @@ __device__ __forceinline__ float cs_unkey(unsigned k) {
 }
 
 // k-th smallest (0-based) of the n values whose order-preserving keys key_at(i) yields
-// (workgroup of NT threads)
+// (workgroup of NT threads).  Three 11/11/10-bit histogram rounds of three barriers each: the scan
+// clears the bins it reads, so the next round (and the next call) finds the histogram zeroed.
 template <int NT, class KeyAt>
 __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k, unsigned *hist /* 2048 */,
                                                 unsigned *wsum /* NT/64 */, unsigned *sel /* 2 */) {
@@ -27,11 +28,11 @@ __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned prefix = 0, mask = 0;
     const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
+    for (unsigned b = tid; b < 2048u; b += NT) hist[b] = 0;
+    __syncthreads();
     for (int ps = 0; ps < 3; ++ps) {
         const int shift = shifts[ps];
         const unsigned nb = 1u << bitsv[ps];
-        for (unsigned b = tid; b < 2048u; b += NT) hist[b] = 0;
-        __syncthreads();
         for (int i = tid; i < n; i += NT) {
             const unsigned key = key_at(i);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1u)], 1u);
@@ -41,6 +42,7 @@ __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k,
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
             v[j] = hist[BPT * tid + j];
+            hist[BPT * tid + j] = 0;
             s += v[j];
         }
         unsigned inc = s;
@@ -65,8 +67,9 @@ __device__ __forceinline__ float cs_select_keys(KeyAt key_at, int n, unsigned k,
         prefix |= sel[0] << shift;
         mask |= (nb - 1u) << shift;
         k = sel[1];
-        __syncthreads();
+        // sel is rewritten only after the next round's two barriers
     }
+    __syncthreads();   // callers reuse sel / hist right away
     return cs_unkey(prefix);
 }
 
