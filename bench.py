@@ -288,7 +288,7 @@ def main():
         if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
             traffic, traffic_src = tj["hbm_bytes_per_scan"], "profiles/r01_pp_traffic.json (" + tj["source"] + ")"
     roofline = {"bound": "hbm",
-                "kernel": "PP neighbour count of one scan = live index build (5 launches) + pp3_stream<count> + pp3_scan "
+                "kernel": "PP neighbour count of one scan = zero-fill + live index build (6 launches) + pp3_stream<count> + pp3_scan "
                           "+ pp3_plan + pp3_stream<scatter> + pp3_join: ALL launches of the stage, HIP events on the "
                           "launch stream", "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
