@@ -40,7 +40,11 @@ __device__ __forceinline__ int cg_coord(float v, double o, double inv_c) {
     return (int)f;
 }
 
-__global__ __launch_bounds__(1024) void cg_bbox(const float *__restrict__ xyz, int n, double c, CGrid *g) {
+__global__ __launch_bounds__(1024) void cg_bbox(const float *__restrict__ xyz, int n, double c, CGrid *g,
+                                                unsigned *__restrict__ zeroed, int zero_words) {
+    // the cell / fill counters and flags of this call are cleared here (one memset launch less);
+    // the next kernel on the stream is their first user
+    for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zeroed[i] = 0u;
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1];
@@ -873,8 +877,7 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     const double r2 = radius * radius;
     const int nb = (n + 255) / 256, nw = (n + WPB - 1) / WPB;
     const int nbA = (int)(((long long)n * AG + 255) / 256);
-    MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
-    cg_bbox<<<1, 1024, 0, stream>>>(xyz, n, c, g);
+    cg_bbox<<<1, 1024, 0, stream>>>(xyz, n, c, g, zeroed, (int)zero_words);
     cg_count<<<nb, 256, 0, stream>>>(xyz, n, g, cnt);
     scan_u32<<<1, 1024, 0, stream>>>(cnt, start, CG_CELLS);
     cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, start, fill, sorted, sidx);
