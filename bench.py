@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=36)
     ap.add_argument("--cpu-scans", type=int, default=2, help="scans of the CPU baseline sample (0 = skip)")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
-    ap.add_argument("--procs", type=int, default=6,
+    ap.add_argument("--procs", type=int, default=7,
                     help="host processes per GPU (per rank).  The host side of a scan is Python + ~100 HIP calls; one "
                          "process saturates at ~350 scans/s on its interpreter lock and HIP runtime locks while the "
                          "GPU is half idle, so every rank feeds its GPU from several helper processes (what the "

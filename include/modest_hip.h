@@ -111,6 +111,13 @@ int modest_plane_candidates(modest_ctx *ctx, const float *pts_dev, int n,
  * is even).  Blocking; result written to *mad_host.                         */
 int modest_mad_threshold(modest_ctx *ctx, const float *cand_xyz_dev,
                          int n_cand, float *mad_host, void *stream);
+/* The same for up to four candidate sets in ONE launch (one workgroup each): a scan's two plane fits
+ * (generate_mask.py:55-56 and clustering_utils.py:126) take their thresholds from one call.
+ * cand_xyz_dev / n_cand: host arrays of `count` device pointers / sizes (each >= 1); mad_host[count].
+ * Blocking.                                                                 */
+int modest_mad_threshold_batch(modest_ctx *ctx, const float *const *cand_xyz_dev,
+                               const int32_t *n_cand, int count, float *mad_host,
+                               void *stream);
 /* Score K trial models z = c0*x + c1*y + b (float32, pred = fma chain
  * fmaf(y,c1,x*c0)+b) against all candidates in ONE launch:
  *   n_inliers[k] = #{ |z - pred| <= thr },  sse[k], sy[k], syy[k] over the

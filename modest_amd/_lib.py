@@ -36,6 +36,7 @@ SIGNATURES = {
     "modest_plane_candidates": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, VP, VP, VP, VP]),
     "modest_mad_threshold": (C.c_int, [VP, VP, C.c_int, VP, VP]),
+    "modest_mad_threshold_batch": (C.c_int, [VP, VP, VP, C.c_int, VP, VP]),
     "modest_ransac_score_trials": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_float, VP, VP, VP, VP, VP]),
     "modest_ransac_trials": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "modest_ransac_refit": (C.c_int, [VP, VP, C.c_int, VP, C.c_float, VP, VP, VP]),

@@ -204,9 +204,20 @@ __device__ __forceinline__ float median_np(const KS &K, int n, MadShared &S) {
     return (a + b) / 2.0f;
 }
 
-__global__ __launch_bounds__(1024) void mad_kernel(const float *__restrict__ cand, int n,
-                                                   float *out /* [median, mad] */) {
+// up to MAD_SETS candidate sets per launch, one workgroup (= one CU) each: the two ground-plane fits
+// of a scan get their thresholds from one launch, side by side
+constexpr int MAD_SETS = 4;
+struct MadArgs {
+    const float *cand[MAD_SETS];
+    int n[MAD_SETS];
+    float *out[MAD_SETS];   // [median, mad] each; device or pinned host memory
+};
+
+__global__ __launch_bounds__(1024) void mad_kernel(MadArgs A) {
     __shared__ MadShared S;
+    const float *__restrict__ cand = A.cand[blockIdx.x];
+    const int n = A.n[blockIdx.x];
+    float *out = A.out[blockIdx.x];
     const int tid = threadIdx.x;
     S.hist[2 * tid] = 0;
     S.hist[2 * tid + 1] = 0;
@@ -304,6 +315,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
                                                               const float *__restrict__ models,
                                                               int K, const float *__restrict__ thr_ptr,
+                                                              float thr_val /* used when thr_ptr is NULL */,
                                                               double *__restrict__ partial, TripArg trip,
                                                               float *__restrict__ models_host) {
     __shared__ float sm[SCORE_KG][3];
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
         }
         __syncthreads();
     }
-    const float thr = *thr_ptr;
+    const float thr = thr_ptr ? *thr_ptr : thr_val;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float x[SCORE_PPT], y[SCORE_PPT], z[SCORE_PPT];
     bool valid[SCORE_PPT];
@@ -572,12 +584,36 @@ extern "C" int modest_mad_threshold(modest_ctx *ctx, const float *cand, int n_ca
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 64);
     if (rc) return rc;
-    float *d = reinterpret_cast<float *>(ctx->scratch);
-    mad_kernel<<<1, 1024, 0, stream>>>(cand, n_cand, d);
+    MadArgs A{};
+    A.cand[0] = cand;
+    A.n[0] = n_cand;
+    A.out[0] = reinterpret_cast<float *>(ctx->pinned);   // pinned host memory, read after the sync
+    mad_kernel<<<1, 1024, 0, stream>>>(A);
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(ctx->pinned, d, 8, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     *mad_host = reinterpret_cast<float *>(ctx->pinned)[1];
+    return MODEST_OK;
+}
+
+extern "C" int modest_mad_threshold_batch(modest_ctx *ctx, const float *const *cand, const int32_t *n_cand,
+                                          int count, float *mad_host, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && cand != nullptr && n_cand != nullptr && mad_host != nullptr, "NULL argument");
+    MODEST_REQUIRE(count >= 1 && count <= MAD_SETS, "1..4 candidate sets per call");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = modest_ctx_reserve_pinned(ctx, 64);
+    if (rc) return rc;
+    MadArgs A{};
+    for (int i = 0; i < count; ++i) {
+        MODEST_REQUIRE(n_cand[i] >= 1 && cand[i] != nullptr, "every set needs at least one candidate");
+        A.cand[i] = cand[i];
+        A.n[i] = n_cand[i];
+        A.out[i] = reinterpret_cast<float *>(ctx->pinned) + 2 * i;
+    }
+    mad_kernel<<<count, 1024, 0, stream>>>(A);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < count; ++i) mad_host[i] = reinterpret_cast<float *>(ctx->pinned)[2 * i + 1];
     return MODEST_OK;
 }
 
@@ -607,7 +643,7 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     hm[K * 3] = thr;   // the kernel reads the threshold from device memory
     MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12 + 4, hipMemcpyHostToDevice, stream));
     score_kernel<false><<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(
-        cand, n_cand, dm, K, dm + 3 * K, dp, TripArg{}, nullptr);
+        cand, n_cand, dm, K, nullptr, thr, dp, TripArg{}, nullptr);
     score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nrows, K, dout);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
@@ -652,28 +688,34 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     float *h_models = reinterpret_cast<float *>(h_res + n_out);
     float *h_thr = reinterpret_cast<float *>(h_res + n_out + n_models);
     for (int i = 0; i < 3 * K; ++i) h_tripp[i] = trip_host[i];
-    if (*thr_inout < 0.f) {   // residual threshold = MAD of the candidates, computed on the device
-        mad_kernel<<<1, 1024, 0, stream>>>(cand, n_cand, d_thr);
-    } else {
-        h_thr_in[0] = 0.f;
-        h_thr_in[1] = *thr_inout;
-        MODEST_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr_in, 8, hipMemcpyHostToDevice, stream));
+    const bool thr_known = !(*thr_inout < 0.f);
+    const float thr_val = *thr_inout;
+    if (!thr_known) {   // residual threshold = MAD of the candidates, computed on the device
+        MadArgs A{};
+        A.cand[0] = cand;
+        A.n[0] = n_cand;
+        A.out[0] = d_thr;
+        mad_kernel<<<1, 1024, 0, stream>>>(A);
     }
+    (void)h_thr_in;
     const dim3 sgrid(nb, (K + SCORE_KG - 1) / SCORE_KG);
     if (K <= TRIP_MAX) {
         TripArg ta;
         for (int i = 0; i < 3 * K; ++i) ta.t[i] = trip_host[i];
-        score_kernel<true><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, nullptr, K, d_thr + 1, d_part, ta,
+        score_kernel<true><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, nullptr, K,
+                                                               thr_known ? nullptr : d_thr + 1, thr_val, d_part, ta,
                                                                h_models);
     } else {
         fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, h_tripp, K, d_models, h_models);
-        score_kernel<false><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K, d_thr + 1, d_part,
+        score_kernel<false><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K,
+                                                                thr_known ? nullptr : d_thr + 1, thr_val, d_part,
                                                                 TripArg{}, nullptr);
     }
-    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, h_outp, d_thr, h_thr);
+    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, h_outp, thr_known ? nullptr : d_thr,
+                                                  thr_known ? nullptr : h_thr);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-    *thr_inout = h_thr[1];
+    *thr_inout = thr_known ? thr_val : h_thr[1];
     for (int k = 0; k < K; ++k) {
         n_inliers[k] = (int32_t)h_outp[4 * k];
         if (sse) sse[k] = h_outp[4 * k + 1];

@@ -20,8 +20,8 @@ import torch
 
 from . import config, dist, ops
 from .utils import kitti_util
-from .utils.clustering_utils import compact_labels, filter_labels, members_by_label
-from .utils.pointcloud_utils import estimate_plane, get_objs, load_velo_scan, to_device
+from .utils.clustering_utils import FILTER_PLANE_SPEC, compact_labels, filter_labels, members_by_label
+from .utils.pointcloud_utils import estimate_plane, get_objs, load_velo_scan, prepare_planes, to_device
 
 
 def eprint(*args, **kwargs):
@@ -47,8 +47,11 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     pe = args.plane_estimate
     ptc_dev = to_device(ptc) if ptc_dev is None else ptc_dev   # (N,4) float32 resident copy
     pp_dev = to_device(pp_score) if pp_dev is None else pp_dev
+    # both ground fits of the scan (here and in filter_labels) need their candidates and MAD
+    # thresholds before any random draw: selected and computed together, one launch for the two MADs
+    prep = prepare_planes(ptc_dev, [(pe.max_hs, pe.range), FILTER_PLANE_SPEC]) if planes is None else (None, None)
     plane = planes[0] if planes is not None else estimate_plane(
-        ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state)
+        ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state, prepared=prep[0])
     _, kept_xyz, kept_idx = ops.plane_range_mask(ptc_dev, plane, pe.offset, pe.range, args.limit_range)
     labels = np.zeros(ptc.shape[0], dtype=int) - 1
     labels_dev = torch.full((ptc.shape[0],), -1, dtype=torch.int32, device=ptc_dev.device)
@@ -72,7 +75,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
         labels = labels_dev.cpu().numpy().astype(int)
     labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
                                     plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
-                                    pp_dev=pp_dev, labels_dev=labels_dev, **args.filtering)
+                                    pp_dev=pp_dev, labels_dev=labels_dev, plane_prepared=prep[1], **args.filtering)
     ptc_in_rect = calib.project_velo_to_rect(ptc[:, :3])
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
     members = members_by_label(labels_filtered, n_lab)

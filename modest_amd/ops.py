@@ -145,6 +145,21 @@ def mad_threshold(cand: torch.Tensor, ctx: Optional[Context] = None) -> np.float
     return np.float32(out.value)
 
 
+def mad_threshold_batch(cands: Sequence[torch.Tensor], ctx: Optional[Context] = None) -> np.ndarray:
+    """MAD thresholds of up to four candidate sets from one launch (one workgroup per set)."""
+    lib = load()
+    for t in cands:
+        _dev(t, torch.float32, "cand")
+    k = len(cands)
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in cands])
+    ns = np.ascontiguousarray([t.shape[0] for t in cands], dtype=np.int32)
+    out = np.zeros(k, dtype=np.float32)
+    c = _ctx(ctx, cands[0])
+    check(lib.modest_mad_threshold_batch(c.handle, ptrs, _np_ptr(ns), k, _np_ptr(out), _stream()),
+          "modest_mad_threshold_batch")
+    return out
+
+
 def ransac_score_trials(cand: torch.Tensor, models: np.ndarray, thr: float, ctx: Optional[Context] = None):
     """Inlier counts (+ SSE / sum z / sum z^2 over the inliers, float64) of K trial planes."""
     lib = load()

@@ -91,8 +91,11 @@ def members_by_label(labels, n_lab):
     return [order[s:e] for s, e in zip(starts, ends)]
 
 
+FILTER_PLANE_SPEC = (-1.5, ((-70, 70), (-50, 50)))   # the reference's hard-coded second ground fit (:126)
+
+
 def filter_labels(ptc, pp_score, labels, random_state=None, plane=None, ptc_dev=None, pp_dev=None,
-                  labels_dev=None, min_points=10, max_volume=40, min_volume=0.5, max_min_height=4,
+                  labels_dev=None, plane_prepared=None, min_points=10, max_volume=40, min_volume=0.5, max_min_height=4,
                   min_max_height=0, percentile=10, min_percentile_pp_score=0.7):
     """(:119-135) drop clusters failing is_valid_cluster, relabel to 0 = background, 1..C.
     The second ground plane (hard-coded max_hs=-1.5, range ((-70,70),(-50,50))) and the
@@ -101,7 +104,8 @@ def filter_labels(ptc, pp_score, labels, random_state=None, plane=None, ptc_dev=
     labels = labels.copy()
     dev_pts = to_device(ptc) if ptc_dev is None else ptc_dev
     if plane is None:
-        plane = estimate_plane(dev_pts, max_hs=-1.5, ptc_range=((-70, 70), (-50, 50)), random_state=random_state)
+        plane = estimate_plane(dev_pts, max_hs=FILTER_PLANE_SPEC[0], ptc_range=FILTER_PLANE_SPEC[1],
+                               random_state=random_state, prepared=plane_prepared)
     n_lab = int(labels.max()) + 1 if labels.size else 0
     if n_lab > 0:
         dev_pp = to_device(pp_score) if pp_dev is None else pp_dev

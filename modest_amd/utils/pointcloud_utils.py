@@ -66,7 +66,7 @@ def plane_from_linear_model(coef, intercept):
 
 
 def estimate_plane(origin_ptc, max_hs=-1.5, it=1, ptc_range=((-20, 70), (-20, 20)), random_state=None,
-                   return_info: bool = False):
+                   return_info: bool = False, prepared=None):
     """(:44-65) RANSAC ground plane of the points with z < max_hs inside ptc_range
     (strict bounds) -> (4,) float64 [n, d] with n.z > 0.
 
@@ -74,13 +74,28 @@ def estimate_plane(origin_ptc, max_hs=-1.5, it=1, ptc_range=((-20, 70), (-20, 20
     numpy's global stream (sklearn's default), which makes its result depend on
     processing order; pass ``np.random.mtrand._rand`` to reproduce that.  The
     loop body's trailing above_plane (:63-64) is dead work for it=1 and skipped.
+    ``prepared`` = (candidates, MAD threshold) from ``prepare_planes`` for the same arguments.
     """
     assert it == 1, "the reference only ever runs one iteration"
-    pts = to_device(origin_ptc)
-    cand, _ = ops.plane_candidates(pts, max_hs, ptc_range)
-    res = ransac_plane(cand, random_state=random_state)
+    if prepared is not None:
+        cand, thr = prepared
+    else:
+        cand, _ = ops.plane_candidates(to_device(origin_ptc), max_hs, ptc_range)
+        thr = None
+    res = ransac_plane(cand, random_state=random_state, thr=thr)
     plane = plane_from_linear_model(res.coef, res.intercept)
     return (plane, res) if return_info else plane
+
+
+def prepare_planes(pts_dev, specs):
+    """The RNG-independent part of several estimate_plane calls on one scan, batched: candidate
+    selection per (max_hs, ptc_range) and all MAD thresholds from ONE launch (a workgroup each).
+    Returns a list of (candidates, threshold) for ``estimate_plane(..., prepared=...)``; a set with
+    fewer than one candidate gets threshold None (the fit itself then raises, where the reference does)."""
+    cands = [ops.plane_candidates(pts_dev, max_hs, rng)[0] for max_hs, rng in specs]
+    live = [c for c in cands if c.shape[0] >= 1]
+    thr = iter(ops.mad_threshold_batch(live)) if live else iter(())
+    return [(c, next(thr) if c.shape[0] >= 1 else None) for c in cands]
 
 
 def distance_to_plane(ptc, plane, directional=False):

@@ -115,14 +115,15 @@ def draw_triplets(rs, n_population, n_trials):
 
 
 def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, stop_probability: float = 0.99,
-                 batch: int = 48, ctx=None) -> RansacResult:
-    """cand: (m,3) float32 device tensor of candidate ground points (x, y, z)."""
+                 batch: int = 48, ctx=None, thr=None) -> RansacResult:
+    """cand: (m,3) float32 device tensor of candidate ground points (x, y, z).
+    ``thr``: the residual threshold MAD(z) when the caller already has it (ops.mad_threshold_batch)."""
     n_samples = int(cand.shape[0])
     min_samples = 3
     if n_samples < min_samples:
         raise ValueError("`min_samples` may not be larger than number of samples: n_samples = %d." % n_samples)
     rs = check_random_state(random_state)
-    thr = None                        # MAD(z), computed on the device with the first batch
+    # thr None: MAD(z) is computed on the device with the first batch
 
     n_inliers_best, score_best, best_model = 1, -np.inf, None
     n_trials, limit = 0, max_trials
