@@ -48,7 +48,7 @@ HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s sp
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=160)
+    ap.add_argument("--steps", type=int, default=560)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--scans", type=int, default=2, help="distinct resident scans per host process, cycled through")
     ap.add_argument("--n-live", type=int, default=30000)
