@@ -286,11 +286,12 @@ int modest_nms_normal(modest_ctx *ctx, const float *boxes_dev, int n,
                       float thresh, int64_t *keep_host, int *num_keep_host,
                       void *stream);
 /* boxes_iou_bev_cpu (src/iou3d_cpu.cpp:232-252): host pointers in and out.
- * Runs the same kernel through a staging copy (there is no CPU arithmetic
- * path in this library).                                                    */
+ * Runs the same kernel on the boxes staged in the context's pinned block (the
+ * kernel reads them and writes the matrix there directly; there is no CPU
+ * arithmetic path in this library).  Blocking.                              */
 int modest_boxes_iou_bev_host(modest_ctx *ctx, const float *boxes_a_host,
                               int n_a, const float *boxes_b_host, int n_b,
-                              float *out_host);
+                              float *out_host, void *stream);
 
 #ifdef __cplusplus
 }

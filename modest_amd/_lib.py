@@ -56,7 +56,7 @@ SIGNATURES = {
     "modest_boxes_iou_bev": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
     "modest_nms_bev": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP]),
     "modest_nms_normal": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP]),
-    "modest_boxes_iou_bev_host": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP]),
+    "modest_boxes_iou_bev_host": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),
 }
 
 _lib = None

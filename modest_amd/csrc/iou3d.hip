@@ -301,23 +301,26 @@ extern "C" int modest_nms_normal(modest_ctx *ctx, const float *boxes, int n, flo
 }
 
 extern "C" int modest_boxes_iou_bev_host(modest_ctx *ctx, const float *a_host, int na,
-                                         const float *b_host, int nb, float *out_host) {
+                                         const float *b_host, int nb, float *out_host, void *stream_) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(na >= 0 && nb >= 0, "negative box count");
     if (na == 0 || nb == 0) return MODEST_OK;
     MODEST_REQUIRE(a_host && b_host && out_host, "NULL buffer");
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    // The boxes are staged in the context's pinned block and the kernel reads them and writes the
+    // matrix there directly (a few hundred bytes each way): one launch, one stream sync, no copies.
     const size_t ba = arena_sz((size_t)na * 28), bb = arena_sz((size_t)nb * 28);
     const size_t bo = arena_sz((size_t)na * nb * 4);
-    int rc = modest_ctx_reserve(ctx, ba + bb + bo);
+    int rc = modest_ctx_reserve_pinned(ctx, ba + bb + bo);
     if (rc) return rc;
-    float *da = reinterpret_cast<float *>(ctx->scratch);
-    float *db = reinterpret_cast<float *>(ctx->scratch + ba);
-    float *dout = reinterpret_cast<float *>(ctx->scratch + ba + bb);
-    MODEST_HIP_CHECK(hipMemcpy(da, a_host, (size_t)na * 28, hipMemcpyHostToDevice));
-    MODEST_HIP_CHECK(hipMemcpy(db, b_host, (size_t)nb * 28, hipMemcpyHostToDevice));
-    rc = pair_launch(true, da, na, db, nb, dout, nullptr);
+    float *pa = reinterpret_cast<float *>(ctx->pinned);
+    float *pb = reinterpret_cast<float *>(ctx->pinned + ba);
+    float *pout = reinterpret_cast<float *>(ctx->pinned + ba + bb);
+    memcpy(pa, a_host, (size_t)na * 28);
+    memcpy(pb, b_host, (size_t)nb * 28);
+    rc = pair_launch(true, pa, na, pb, nb, pout, stream_);
     if (rc) return rc;
-    MODEST_HIP_CHECK(hipMemcpy(out_host, dout, (size_t)na * nb * 4, hipMemcpyDeviceToHost));
+    MODEST_HIP_CHECK(hipStreamSynchronize(as_stream(stream_)));
+    memcpy(out_host, pout, (size_t)na * nb * 4);
     return MODEST_OK;
 }

@@ -378,6 +378,19 @@ def boxes_iou_bev(a: torch.Tensor, b: torch.Tensor, overlap_only: bool = False) 
     return out
 
 
+def boxes_iou_bev_host(a: np.ndarray, b: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
+    """Rotated BEV IoU of host box arrays (n,7) float32 -> (na, nb) float32 host matrix: boxes and matrix
+    go through the context's pinned block, no device tensors and no copies."""
+    lib = load()
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 7)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 7)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    c = ctx if ctx is not None else default_context(torch.cuda.current_device())
+    check(lib.modest_boxes_iou_bev_host(c.handle, _np_ptr(a), a.shape[0], _np_ptr(b), b.shape[0], _np_ptr(out),
+                                        _stream()), "modest_boxes_iou_bev_host")
+    return out
+
+
 def nms(boxes: torch.Tensor, thresh: float, rotated: bool = True, ctx: Optional[Context] = None) -> np.ndarray:
     """Greedy NMS over boxes already sorted by score; returns kept indices (int64, host)."""
     lib = load()

@@ -77,5 +77,5 @@ def boxes_iou_bev_cpu(boxes_a_tensor, boxes_b_tensor, ans_iou_tensor):
     ctx = _lib.default_context(0)
     _lib.check(lib.modest_boxes_iou_bev_host(ctx.handle, boxes_a_tensor.data_ptr(), boxes_a_tensor.size(0),
                                              boxes_b_tensor.data_ptr(), boxes_b_tensor.size(0),
-                                             ans_iou_tensor.data_ptr()), "modest_boxes_iou_bev_host")
+                                             ans_iou_tensor.data_ptr(), None), "modest_boxes_iou_bev_host")
     return 1

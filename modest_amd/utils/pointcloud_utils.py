@@ -280,8 +280,9 @@ def get_obj(ptc, full_ptc, fit_method="closeness_to_edge"):
 def objs_nms(objs, use_score_rank=False, nms_threshold=0.1):
     """(:320-344) BEV NMS of boxes in the rect frame; keeps the original order."""
     boxes = np.array([[obj.t[0], obj.t[2], 0, obj.l, obj.w, obj.h, -obj.ry] for obj in objs])
-    boxes = torch.from_numpy(boxes).float().to(_device())
-    overlaps_bev = iou3d_nms_utils.boxes_iou_bev(boxes.contiguous(), boxes.contiguous()).cpu().numpy()
+    # float32 boxes as the reference's .float() makes them; the IoU kernel reads them from and writes
+    # the matrix to pinned host memory (same kernel as iou3d_nms_utils.boxes_iou_bev)
+    overlaps_bev = ops.boxes_iou_bev_host(boxes.astype(np.float32), boxes.astype(np.float32))
     mask = np.ones(overlaps_bev.shape[0], dtype=bool)
     if use_score_rank:
         order = np.argsort([obj.score for obj in objs])[::-1]
