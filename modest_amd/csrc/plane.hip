@@ -666,7 +666,7 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const int nb = (n_cand + SCORE_PTS - 1) / SCORE_PTS, nrows = nb * SCORE_WAVES;
-    // device: [models K*3 f32 | thr pair 2 f32 | partial]; pinned host: [trip | thr in | results].
+    // device: [models K*3 f32 | thr pair 2 f32 | partial]; pinned host: [trip | results].
     // The kernels read the triplets from and write the results (sums, models, threshold) to the pinned
     // block directly: one stream sync, no copy kernels in either direction.
     const size_t n_out = (size_t)K * 32, n_models = (size_t)K * 12;
@@ -675,15 +675,14 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     int rc = modest_ctx_reserve(ctx, b_models + b_thr + b_part);
     if (rc) return rc;
     const size_t h_trip = ((size_t)K * 12 + 63) & ~size_t(63);
-    rc = modest_ctx_reserve_pinned(ctx, h_trip + 64 + n_out + n_models + 8);
+    rc = modest_ctx_reserve_pinned(ctx, h_trip + n_out + n_models + 8);
     if (rc) return rc;
     char *d = ctx->scratch;
     float *d_models = reinterpret_cast<float *>(d);
     float *d_thr = reinterpret_cast<float *>(d + b_models);
     double *d_part = reinterpret_cast<double *>(d + b_models + b_thr);
     int *h_tripp = reinterpret_cast<int *>(ctx->pinned);
-    float *h_thr_in = reinterpret_cast<float *>(ctx->pinned + h_trip);
-    char *h_res = ctx->pinned + h_trip + 64;
+    char *h_res = ctx->pinned + h_trip;
     double *h_outp = reinterpret_cast<double *>(h_res);
     float *h_models = reinterpret_cast<float *>(h_res + n_out);
     float *h_thr = reinterpret_cast<float *>(h_res + n_out + n_models);
@@ -697,7 +696,6 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
         A.out[0] = d_thr;
         mad_kernel<<<1, 1024, 0, stream>>>(A);
     }
-    (void)h_thr_in;
     const dim3 sgrid(nb, (K + SCORE_KG - 1) / SCORE_KG);
     if (K <= TRIP_MAX) {
         TripArg ta;
