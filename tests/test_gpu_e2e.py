@@ -178,3 +178,33 @@ def test_scan_pipeline_equals_oracle_on_synthetic_scans(gpu, case):
         np.testing.assert_allclose([*o.t, o.l, o.w, o.h, o.ry, o.volume], [*r.t, r.l, r.w, r.h, r.ry, r.volume],
                                    rtol=1e-9, atol=1e-9)
     assert text == ref_text
+
+
+def test_bench_contract_json_line(gpu):
+    """`python bench.py` prints exactly one JSON line with the driver's contract fields, the roofline
+    object of the PP stage and the cpu_baseline object (small sizes, two helper processes)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "2", "--procs", "2", "--scans", "1",
+           "--cpu-scans", "1", "--n-live", "8000", "--traversals", "3", "--frames", "6"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "scans/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and d["value"] > 0
+    assert abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000.0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["launches_timed"] == 12 and rf["isolated"]["kernel_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert d["parity"]["pp_counts_equal"] is True
