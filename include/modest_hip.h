@@ -44,8 +44,8 @@ int modest_ctx_create(int device, modest_ctx **out);
 int modest_ctx_destroy(modest_ctx *ctx);
 /* Measurement hook (no reference counterpart): while enabled, the dominant
  * operation of the path -- the neighbour-count stage of modest_pp_count /
- * modest_pp_score (index build + route + work list + tile join kernels of ONE
- * scan) -- is bracketed by a HIP event pair on the launch stream; collect
+ * modest_pp_score / modest_pp_score_frames (every kernel of ONE scan between the
+ * live index build and the last join) -- is bracketed by a HIP event pair on the launch stream; collect
  * returns the elapsed milliseconds of up to `cap` calls since begin and
  * disables the hook.                                                          */
 int modest_ctx_profile_begin(modest_ctx *ctx, int capacity);
@@ -93,6 +93,58 @@ int modest_pp_score(modest_ctx *ctx, const float *live_xyz_dev, int n_live,
                     const float *hist_xyz_dev, const int64_t *trav_offsets_host,
                     int n_trav, double radius, int32_t *counts_dev,
                     float *H_dev, void *stream);
+
+/* ---- a1+a3+a4+a5+a6+a7 over a FRAME STORE (history assembly on the device) ------
+ * The reference re-reads, transforms and stacks every history frame for every scan
+ * (pre_compute_pp_score.py:132-150: load_velo_scan + remove_center + transform_points +
+ * np.concatenate) and builds one cKDTree per traversal (:188-190).  Here a raw frame enters the
+ * frame store ONCE: modest_frame_sort orders its points by the 8x8-cell tile of a world lattice
+ * (cell edge c = r*(1+2^-10), the lattice is shared by all frames of a data set) and writes the
+ * prefix table tile -> first point.  A scan then names its frames by descriptor
+ * (modest_pp_frame: store buffers + traversal id + the float32 relative pose of
+ * get_relative_pose, :27-28) and modest_pp_score_frames gathers, per live tile, the run of that
+ * tile from every frame's table, applies the pose (transform_points' float32 rounding) and counts
+ * neighbours: history bytes cross HBM once and no stacked copy exists.
+ *
+ * W [host] 2x4 float64, rows x and y of (1/c) * (raw frame -> world lattice metres).
+ * TX0, TY0: global tile coordinates of the table's first tile; the table covers
+ * MODEST_FRAME_NTF x MODEST_FRAME_NTF tiles (callers centre it on the sensor origin).
+ * Outputs [dev]: xyz (n,3) f32 tile-sorted raw points, perm (n) u32 sorted -> original index,
+ * tab (NTF*NTF+1) u32 prefix offsets (row-major tiles); tab[NTF*NTF] = points inside the table,
+ * the rest of xyz are outliers.  n_inside_host[k] receives that count (a scan whose frames have
+ * outliers must use the stacked path, modest_pp_score).  Blocking.                             */
+#define MODEST_FRAME_NTF 128
+typedef struct {
+    const float *raw_dev;   /* (n, stride) f32, stride 3 or 4 (velodyne .bin: load_velo_scan) */
+    int32_t n, stride;
+    int32_t TX0, TY0;
+    double W[8];
+    float *xyz_dev;
+    uint32_t *perm_dev;
+    uint32_t *tab_dev;
+} modest_frame_sort_job;
+int modest_frame_table_tiles(void);   /* MODEST_FRAME_NTF of the built library */
+int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *jobs_host, int n_jobs,
+                      int32_t *n_inside_host, void *stream);
+
+#define MODEST_FRAME_REMOVE_CENTER 1   /* remove_center, pre_compute_pp_score.py:48-52 */
+typedef struct {
+    const float *xyz_dev;      /* store buffers of the frame */
+    const uint32_t *tab_dev;
+    int32_t n, TX0, TY0;
+    int32_t trav;              /* traversal index in [0, n_trav) (ignored for the live scan) */
+    int32_t flags;             /* MODEST_FRAME_REMOVE_CENTER */
+    float rel[12];             /* rows 0..2 of get_relative_pose(...).astype(float32) */
+} modest_pp_frame;
+/* counts[i*T+t] / H[i] are indexed by the ORIGINAL point order of the live frame (perm).
+ * A [host] 2x4 float64: rows x, y of (1/c) * (common frame -> world lattice metres); it must agree
+ * with W * rel^-1 of every frame to better than r/1024 (callers check 1e-4 m).
+ * counts_dev may be NULL (scratch) when only H is wanted; H_dev may be NULL.  n_trav <= 64.
+ * Not blocking.                                                                              */
+int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *live_host,
+                           const uint32_t *live_perm_dev, const modest_pp_frame *frames_host,
+                           int n_frames, int n_trav, const double *A8_host, double radius,
+                           int32_t *counts_dev, float *H_dev, void *stream);
 
 /* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
  * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include "modest_hip.h"
 
+constexpr int MODEST_STAGE_SLOTS = 8;
+
 struct modest_ctx {
     int device;
     char *scratch;          // grow-only device arena
@@ -22,7 +24,20 @@ struct modest_ctx {
     // them zeroed, so no memset per launch
     unsigned long long *cstate;
     size_t cstate_blocks;
+    // ring of pinned staging slots for small per-call tables that are copied to the device
+    // asynchronously (frame descriptors of modest_pp_score_frames): a slot is reused only after the
+    // event recorded behind its copy has completed
+    char *stage[MODEST_STAGE_SLOTS];
+    size_t stage_bytes[MODEST_STAGE_SLOTS];
+    hipEvent_t stage_ev[MODEST_STAGE_SLOTS];
+    int stage_used[MODEST_STAGE_SLOTS];
+    int stage_next;
 };
+
+// next staging slot with at least `bytes` (waits for the slot's previous copy); commit records the
+// event behind the copy that was just enqueued from it
+int modest_ctx_stage_slot(modest_ctx *ctx, size_t bytes, void **out);
+int modest_ctx_stage_commit(modest_ctx *ctx, hipStream_t stream);
 
 // persistent compaction state for `nblocks` blocks (allocated and zeroed on first use / growth)
 int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream, unsigned long long **out);

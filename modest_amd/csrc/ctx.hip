@@ -62,6 +62,13 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->pp_attr_done = 0;
     c->cstate = nullptr;
     c->cstate_blocks = 0;
+    for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
+        c->stage[i] = nullptr;
+        c->stage_bytes[i] = 0;
+        c->stage_ev[i] = nullptr;
+        c->stage_used[i] = 0;
+    }
+    c->stage_next = 0;
     *out = c;
     return MODEST_OK;
 }
@@ -71,6 +78,10 @@ extern "C" int modest_ctx_destroy(modest_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->cstate) (void)hipFree(ctx->cstate);
+    for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
+        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+    }
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     delete[] ctx->prof_ev;
     delete ctx;
@@ -120,6 +131,35 @@ int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes) {
     MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     ctx->pinned = static_cast<char *>(p);
     ctx->pinned_bytes = want;
+    return MODEST_OK;
+}
+
+int modest_ctx_stage_slot(modest_ctx *ctx, size_t bytes, void **out) {
+    const int k = ctx->stage_next;
+    if (ctx->stage_used[k]) {   // the copy that last read this slot must be over
+        MODEST_HIP_CHECK(hipEventSynchronize(ctx->stage_ev[k]));
+        ctx->stage_used[k] = 0;
+    }
+    if (bytes > ctx->stage_bytes[k]) {
+        if (ctx->stage[k]) MODEST_HIP_CHECK(hipHostFree(ctx->stage[k]));
+        ctx->stage[k] = nullptr;
+        ctx->stage_bytes[k] = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        void *p = nullptr;
+        MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        ctx->stage[k] = static_cast<char *>(p);
+        ctx->stage_bytes[k] = want;
+    }
+    if (!ctx->stage_ev[k]) MODEST_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    *out = ctx->stage[k];
+    return MODEST_OK;
+}
+
+int modest_ctx_stage_commit(modest_ctx *ctx, hipStream_t stream) {
+    const int k = ctx->stage_next;
+    MODEST_HIP_CHECK(hipEventRecord(ctx->stage_ev[k], stream));
+    ctx->stage_used[k] = 1;
+    ctx->stage_next = (k + 1) % MODEST_STAGE_SLOTS;
     return MODEST_OK;
 }
 

@@ -17,8 +17,10 @@
 //   V3 (pp_v3.h): records sorted by cell, wave-uniform candidate lists, ballot +
 //       popcount instead of atomics ......... ~330 us
 // V1 stays as the path for more than 64 traversals and for A/B runs (MODEST_PP_VARIANT=1).
-#include "pp_common.h"
+#include "pp_frames.h"
 #include <cmath>
+#include <cstring>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 
@@ -287,33 +289,31 @@ int check_offsets(const int64_t *off, int n_trav, TravOffsets &tr) {
 
 }  // namespace
 
-// `extra_bytes` of arena are reserved behind this call's own carve and
-// returned in *extra (used by modest_pp_score for its private counts).
-static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const float *hist,
-                         const int64_t *trav_offsets, int n_trav, double radius,
-                         int32_t *counts, void *stream_, size_t extra_bytes, void **extra) {
+// Where the history comes from: a stacked (M,3) array with traversal offsets, or the frames of the
+// frame store through a descriptor table (chunkTab: one entry per 4096-point chunk of a frame).
+struct HistSrc {
+    const float *hist = nullptr;
+    TravOffsets tr;
+    ChunkMap3 cm;
+    const FrameDev *frames = nullptr;
+    const uint2 *chunkTab = nullptr;
+    int nchunks = 0;
+    bool useFrames = false;
+    long long totalPts = 0;
+};
+
+// `extra_bytes` of arena are reserved behind this call's own carve; `prepare` is called with that
+// block after the reservation and before the first launch (it may fill in `live` / `src` / `counts`
+// with buffers inside the block and enqueue work that produces them).
+static int pp_count_run(modest_ctx *ctx, const float *live, int n_live, HistSrc &src, int n_trav, double radius,
+                        int32_t *counts, hipStream_t stream, size_t extra_bytes,
+                        const std::function<int(char *extra, const float **live, int32_t **counts)> &prepare) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n_live >= 0, "n_live < 0");
     MODEST_REQUIRE(radius > 0.0 && radius < 1e6, "radius must be positive and finite");
-    TravOffsets tr;
-    int rc = check_offsets(trav_offsets, n_trav, tr);
-    if (rc) return rc;
-    hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-
-    // chunk map of the routed path (chunks never straddle traversals)
-    ChunkMap3 cm3;
-    int nchunks = 0;
-    {
-        long long nch = 0;
-        for (int t = 0; t < n_trav; ++t) {
-            cm3.cstart[t] = (int)nch;
-            nch += (tr.off[t + 1] - tr.off[t] + V3_CH - 1) / V3_CH;
-        }
-        MODEST_REQUIRE(nch < (1LL << 19), "history too large for the routed path");
-        nchunks = (int)nch;
-        cm3.cstart[n_trav] = nchunks;
-    }
+    const int nchunks = src.nchunks;
+    MODEST_REQUIRE(nchunks < (1 << 19), "history too large for the routed path");
     int nwg3 = 2 * ctx->num_cus < V3_MAXWG ? 2 * ctx->num_cus : V3_MAXWG;
     {
         const char *nw_env = getenv("MODEST_PP_NWG");
@@ -332,20 +332,19 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
                   arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
                   arena_sz((size_t)nchunks * V3_CH * 16) + 2 * arena_sz((size_t)nwg3 * V3_NL * 4) +
                   arena_sz(maxSlices * 16);
-    rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
+    int rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
     if (rc) return rc;
-    if (extra) {
-        *extra = ctx->scratch + need;
-        if (!counts) counts = static_cast<int32_t *>(*extra);
+    if (prepare) {
+        rc = prepare(ctx->scratch + need, &live, &counts);
+        if (rc) return rc;
     }
     if (n_live == 0) return MODEST_OK;
     MODEST_REQUIRE(counts != nullptr, "counts is NULL");
-    const long long m0 = tr.off[0], m1 = tr.off[n_trav];
-    if (m1 == m0) {   // no history: all counts are zero
+    if (src.totalPts == 0) {   // no history: all counts are zero
         MODEST_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)n_live * n_trav * sizeof(int32_t), stream));
         return MODEST_OK;
     }
-    MODEST_REQUIRE(live != nullptr && hist != nullptr, "NULL point buffer");
+    MODEST_REQUIRE(live != nullptr && (src.useFrames ? src.frames != nullptr : src.hist != nullptr), "NULL point buffer");
     Arena A(ctx->scratch);
     unsigned *zeroed = A.take<unsigned>(zero_words);
     unsigned *cellCount = zeroed;
@@ -358,7 +357,7 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     unsigned *dense = listLive + V3_NL;
     unsigned *denseBlock = dense + 2 * V3_DWORDS;
     unsigned *blockLive = denseBlock + V3_DMAX;
-    unsigned *dbgStats = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(blockLive + V3_NBLK) + 7) & ~(uintptr_t)7);   // 16 x u64 (debug only)
+    unsigned *dbgStats = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(blockLive + V3_NBLK) + 7) & ~(uintptr_t)7);   // 16 x u64 (PROF builds)
     unsigned *cellStart = A.take<unsigned>(PP_NCELL + 1);
     unsigned *blockSum = A.take<unsigned>(SCAN_NBLK);
     unsigned *bitmap = A.take<unsigned>(PP_BITWORDS);
@@ -380,84 +379,175 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
     const char *var_env = getenv("MODEST_PP_VARIANT");
     int var = var_env ? atoi(var_env) : 3;
     if (var != 1 || n_trav > V3_MAXT) var = n_trav > V3_MAXT ? 1 : 3;   // more than 64 traversals: the direct path
+    MODEST_REQUIRE(var == 3 || !src.useFrames, "the frame path needs n_trav <= 64");
     if (var == 3)   // the extra blocks count the live points of every 8x8-cell block window
         pp3_scatter_blocklive<<<nb + (V3_NBLK + 255) / 256, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill,
                                                                              sorted, nb, blockLive);
     else
         pp_live_scatter<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellStart, fill, sorted);
     if (var == 1) {   // V1: per-point search in the L2-resident index (also kept for A/B measurements)
-        pp_stream_v1<<<ctx->num_cus * 3, 256, 0, stream>>>(hist, m0, m1, tr, bb, c, bitmap, cellStart,
-                                                           sorted, counts, n_trav, r2);
+        pp_stream_v1<<<ctx->num_cus * 3, 256, 0, stream>>>(src.hist, src.tr.off[0], src.tr.off[n_trav], src.tr, bb, c,
+                                                           bitmap, cellStart, sorted, counts, n_trav, r2);
         modest_prof_mark(ctx, stream, 1);
         MODEST_HIP_CHECK(hipGetLastError());
         return MODEST_OK;
     }
     const char *dbg_env = getenv("MODEST_PP_DBG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
-    if (var == 3) {
-        if (!ctx->pp_attr_done) {
-            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
-            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
-            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_scan),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 V3_MAXWG * V3_SCAN_L * 4));
-            ctx->pp_attr_done = 1;
-        }
-        pp3_blocks<<<1, 1024, 0, stream>>>(blockLive, dense, denseBlock, listLive);
-        const int pair = (nwg3 % 2 == 0 && nwg3 >= 4 && !getenv("MODEST_PP_NOPAIR")) ? 1 : 0;
-        pp3_stream<false><<<nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense, wgTile, wgOff,
-                                                     tileBase, rec, dbg, pair);
-        pp3_scan<<<V3_NL / V3_SCAN_L, 1024, (size_t)nwg3 * V3_SCAN_L * 4, stream>>>(wgTile, wgOff, nwg3, listTotal);
-        pp3_plan<<<1, 1024, 0, stream>>>(listTotal, listLive, n_trav, sliceCap, tileBase, slices,
-                                         (unsigned)maxSlices, ctrl3);
-        pp3_stream<true><<<pair ? nwg3 / 2 : nwg3, 1024, 0, stream>>>(hist, tr, cm3, nchunks, bb, c, bitmap, dense,
-                                                                      wgTile, wgOff, tileBase, rec, dbg, pair);
-        if (dbg & 8)
-            pp3_join<true><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
-                rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
-                reinterpret_cast<unsigned long long *>(dbgStats));
-        else
-            pp3_join<false><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
-                rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
-                reinterpret_cast<unsigned long long *>(dbgStats));
-        if (dbg & (8 | 128)) {
-            unsigned long long hs[32];
-            unsigned hc[4];
-            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-            MODEST_HIP_CHECK(hipMemcpy(hs, dbgStats, sizeof(hs), hipMemcpyDeviceToHost));
-            MODEST_HIP_CHECK(hipMemcpy(hc, ctrl3, sizeof(hc), hipMemcpyDeviceToHost));
-            if (dbg & 8) fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu | max WG %llu | chunks %llu groups %llu iters %llu\n",
-                    hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[6], hs[8], hs[9], hs[10]);
-            {
-                static unsigned long long tl[64 + 3 * 1024];
-                MODEST_HIP_CHECK(hipMemcpy(tl, dbgStats, sizeof(tl), hipMemcpyDeviceToHost));
-                const int nwg = 2 * ctx->num_cus;
-                unsigned long long t0 = ~0ULL, hist_end[16] = {0}, mx = 0, sl_mx = 0, st_mx = 0;
-                for (int k = 0; k < nwg; ++k) t0 = tl[64 + k] < t0 ? tl[64 + k] : t0;
-                for (int k = 0; k < nwg; ++k) {
-                    const unsigned long long e = tl[64 + 1024 + k] - t0, st = tl[64 + k] - t0;
-                    mx = e > mx ? e : mx;
-                    st_mx = st > st_mx ? st : st_mx;
-                    sl_mx = tl[64 + 2048 + k] > sl_mx ? tl[64 + 2048 + k] : sl_mx;
-                }
-                for (int k = 0; k < nwg; ++k) hist_end[(tl[64 + 1024 + k] - t0) * 15 / (mx ? mx : 1)]++;
-                fprintf(stderr, "[pp3] WG end times: last start %llu, last end %llu ticks; end histogram (16 bins):", st_mx, mx);
-                for (int k = 0; k < 16; ++k) fprintf(stderr, " %llu", hist_end[k]);
-                fprintf(stderr, "; max slices per WG %llu\n", sl_mx);
-                const unsigned worst = (unsigned)(hs[13] & 0xffffffffu);
-                uint4 ws = make_uint4(0, 0, 0, 0);
-                if (dbg & 8) MODEST_HIP_CHECK(hipMemcpy(&ws, slices + worst, sizeof(ws), hipMemcpyDeviceToHost));
-                if (dbg & 8) fprintf(stderr, "[pp3] slowest slice: id %u list %u records %u, %llu ticks starting at %llu (load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu)\n",
-                        worst, ws.x, ws.z - ws.y, hs[13] >> 32, hs[21], hs[16], hs[17], hs[18], hs[19], hs[20]);
-            }
-        }
-        modest_prof_mark(ctx, stream, 1);
-        MODEST_HIP_CHECK(hipGetLastError());
-        return MODEST_OK;
+    if (!ctx->pp_attr_done) {
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_scan),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             V3_MAXWG * V3_SCAN_L * 4));
+        ctx->pp_attr_done = 1;
     }
-    return MODEST_OK;   // not reached
+    pp3_blocks<<<1, 1024, 0, stream>>>(blockLive, dense, denseBlock, listLive);
+    const int pair = (nwg3 % 2 == 0 && nwg3 >= 4 && !getenv("MODEST_PP_NOPAIR")) ? 1 : 0;
+    if (src.useFrames)
+        pp3_stream<false, true><<<nwg3, 1024, 0, stream>>>(nullptr, src.tr, src.cm, src.frames, src.chunkTab, nchunks, bb,
+                                                           c, bitmap, dense, wgTile, wgOff, tileBase, rec, pair);
+    else
+        pp3_stream<false, false><<<nwg3, 1024, 0, stream>>>(src.hist, src.tr, src.cm, nullptr, nullptr, nchunks, bb, c,
+                                                            bitmap, dense, wgTile, wgOff, tileBase, rec, pair);
+    pp3_scan<<<V3_NL / V3_SCAN_L, 1024, (size_t)nwg3 * V3_SCAN_L * 4, stream>>>(wgTile, wgOff, nwg3, listTotal);
+    pp3_plan<<<1, 1024, 0, stream>>>(listTotal, listLive, n_trav, sliceCap, tileBase, slices, (unsigned)maxSlices, ctrl3);
+    const int sgrid = pair ? nwg3 / 2 : nwg3;
+    if (src.useFrames)
+        pp3_stream<true, true><<<sgrid, 1024, 0, stream>>>(nullptr, src.tr, src.cm, src.frames, src.chunkTab, nchunks, bb,
+                                                           c, bitmap, dense, wgTile, wgOff, tileBase, rec, pair);
+    else
+        pp3_stream<true, false><<<sgrid, 1024, 0, stream>>>(src.hist, src.tr, src.cm, nullptr, nullptr, nchunks, bb, c,
+                                                            bitmap, dense, wgTile, wgOff, tileBase, rec, pair);
+    if (dbg & 8)
+        pp3_join<true><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
+            rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, dbg,
+            reinterpret_cast<unsigned long long *>(dbgStats));
+    else
+        pp3_join<false><<<2 * ctx->num_cus, V3_JT, V3_JOIN_LDS_DYN, stream>>>(
+            rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, n_trav, r2, 0,
+            reinterpret_cast<unsigned long long *>(dbgStats));
+    if (dbg & 8) {
+        unsigned long long hs[32];
+        unsigned hc[4];
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        MODEST_HIP_CHECK(hipMemcpy(hs, dbgStats, sizeof(hs), hipMemcpyDeviceToHost));
+        MODEST_HIP_CHECK(hipMemcpy(hc, ctrl3, sizeof(hc), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pp3] slices %u records %u | wg-time (10ns ticks, summed over WGs) load+hist %llu tables+scatter %llu band-load %llu join %llu flush %llu | max WG %llu | chunks %llu groups %llu iters %llu\n",
+                hc[0], hc[2], hs[0], hs[1], hs[2], hs[3], hs[4], hs[6], hs[8], hs[9], hs[10]);
+    }
+    modest_prof_mark(ctx, stream, 1);
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
+
+// stacked history: `extra_bytes` behind the carve are returned in *extra (modest_pp_score's counts)
+static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const float *hist,
+                         const int64_t *trav_offsets, int n_trav, double radius,
+                         int32_t *counts, void *stream_, size_t extra_bytes, void **extra) {
+    HistSrc src;
+    int rc = check_offsets(trav_offsets, n_trav, src.tr);
+    if (rc) return rc;
+    long long nch = 0;
+    for (int t = 0; t < n_trav; ++t) {   // chunks never straddle traversals
+        src.cm.cstart[t] = (int)nch;
+        nch += (src.tr.off[t + 1] - src.tr.off[t] + V3_CH - 1) / V3_CH;
+    }
+    MODEST_REQUIRE(nch < (1LL << 19), "history too large for the routed path");
+    src.cm.cstart[n_trav] = (int)nch;
+    src.nchunks = (int)nch;
+    src.hist = hist;
+    src.totalPts = src.tr.off[n_trav] - src.tr.off[0];
+    return pp_count_run(ctx, live, n_live, src, n_trav, radius, counts, as_stream(stream_), extra_bytes,
+                        [&](char *tail, const float **, int32_t **cnt) {
+                            if (extra) {
+                                *extra = tail;
+                                if (!*cnt) *cnt = reinterpret_cast<int32_t *>(tail);
+                            }
+                            return MODEST_OK;
+                        });
+}
+
+// ---- frame path of the V3 kernels ------------------------------------------------------------
+namespace {
+// live scan of the frame store (tile-sorted + perm) -> common frame, ORIGINAL point order
+__global__ void pp3_live_transform(const float *__restrict__ xyz, const unsigned *__restrict__ perm, int n,
+                                   FrameDev d, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[3];
+    rel_apply(d.rel, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], o);
+    const size_t j = perm[i];
+    out[3 * j] = o[0];
+    out[3 * j + 1] = o[1];
+    out[3 * j + 2] = o[2];
+}
+}  // namespace
+
+int modest_pp3_frames(modest_ctx *ctx, const modest_pp_frame *live, const uint32_t *live_perm_dev,
+                      const modest_pp_frame *frames, int n_frames, int n_trav, double radius,
+                      int32_t *counts_dev, float *H_dev, hipStream_t stream) {
+    const int N = live->n, T = n_trav;
+    HistSrc src;
+    src.useFrames = true;
+    src.tr.n = n_trav;
+    for (int t = 0; t <= n_trav && t <= PP_MAX_TRAV; ++t) src.tr.off[t] = 0;
+    long long nch = 0, pts = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        nch += (frames[f].n + V3_CH - 1) / V3_CH;
+        pts += frames[f].n;
+    }
+    MODEST_REQUIRE(nch < (1LL << 19) && pts < (1LL << 31), "history too large for the routed path");
+    src.nchunks = (int)nch;
+    src.totalPts = pts;
+    const size_t descB = arena_sz((size_t)(n_frames > 0 ? n_frames : 1) * sizeof(FrameDev));
+    const size_t tabB = arena_sz((size_t)(nch > 0 ? nch : 1) * sizeof(uint2));
+    const size_t liveB = arena_sz((size_t)N * 12 + 16);
+    const size_t cntB = counts_dev ? 0 : arena_sz((size_t)N * T * 4);
+    int32_t *cnt_used = counts_dev;
+    int rc = pp_count_run(
+        ctx, nullptr, N, src, n_trav, radius, counts_dev, stream, descB + tabB + liveB + cntB,
+        [&](char *tail, const float **livep, int32_t **cnt) -> int {
+            FrameDev *dframes = reinterpret_cast<FrameDev *>(tail);
+            uint2 *dtab = reinterpret_cast<uint2 *>(tail + descB);
+            float *dlive = reinterpret_cast<float *>(tail + descB + tabB);
+            if (!*cnt) *cnt = reinterpret_cast<int32_t *>(tail + descB + tabB + liveB);
+            cnt_used = *cnt;
+            // descriptors and the chunk table travel through one pinned staging slot
+            char *hslot = nullptr;
+            int r = modest_ctx_stage_slot(ctx, descB + tabB, reinterpret_cast<void **>(&hslot));
+            if (r) return r;
+            FrameDev *hd = reinterpret_cast<FrameDev *>(hslot);
+            uint2 *ht = reinterpret_cast<uint2 *>(hslot + descB);
+            size_t k = 0;
+            for (int f = 0; f < n_frames; ++f) {
+                FrameDev &d = hd[f];
+                d.xyz = frames[f].xyz_dev;
+                d.tab = frames[f].tab_dev;
+                d.n = frames[f].n;
+                d.TX0 = frames[f].TX0;
+                d.TY0 = frames[f].TY0;
+                d.trav_flags = frames[f].trav | (frames[f].flags << 16);
+                for (int q = 0; q < 12; ++q) d.rel[q] = frames[f].rel[q];
+                for (int p0 = 0; p0 < frames[f].n; p0 += V3_CH) ht[k++] = make_uint2((unsigned)f, (unsigned)p0);
+            }
+            MODEST_HIP_CHECK(hipMemcpyAsync(dframes, hslot, descB + tabB, hipMemcpyHostToDevice, stream));
+            r = modest_ctx_stage_commit(ctx, stream);
+            if (r) return r;
+            FrameDev ld;
+            memset(&ld, 0, sizeof(ld));
+            for (int q = 0; q < 12; ++q) ld.rel[q] = live->rel[q];
+            if (N > 0) pp3_live_transform<<<(N + 255) / 256, 256, 0, stream>>>(live->xyz_dev, live_perm_dev, N, ld, dlive);
+            *livep = dlive;
+            src.frames = dframes;
+            src.chunkTab = dtab;
+            return MODEST_OK;
+        });
+    if (rc) return rc;
+    if (H_dev && N > 0) return modest_pp_entropy(ctx, cnt_used, N, T, H_dev, stream);
+    return MODEST_OK;
 }
 
 extern "C" int modest_pp_count(modest_ctx *ctx, const float *live, int n_live, const float *hist,

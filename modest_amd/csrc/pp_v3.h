@@ -214,15 +214,21 @@ __device__ __forceinline__ void pp3_load4(const float *__restrict__ hist, long l
     }
 }
 
-template <bool SCATTER>
+// FRAMES: the history is not a stacked array but the frames of the frame store, named by a
+// descriptor table; chunkTab[chunk] = (frame, first point).  The frame's relative pose is applied on
+// the fly (transform_points' float32 rounding, pp_frames.h; the pose is wave-uniform: scalar loads),
+// remove_center drops points before the transform (pre_compute_pp_score.py:141-142).
+template <bool SCATTER, bool FRAMES>
 __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ hist, TravOffsets tr, ChunkMap3 cm,
-                                                      int nchunks, const unsigned *bb, double c,
+                                                      const FrameDev *__restrict__ frames,
+                                                      const uint2 *__restrict__ chunkTab, int nchunks,
+                                                      const unsigned *bb, double c,
                                                       const unsigned *__restrict__ bitmap,
                                                       const unsigned *__restrict__ dense,
                                                       unsigned *__restrict__ wgTile /* [grid][NL] counts */,
                                                       const unsigned *__restrict__ wgOff /* [grid][NL] offsets in the list */,
                                                       const unsigned *__restrict__ tileBase,
-                                                      float4 *__restrict__ rec, int dbg, int pair) {
+                                                      float4 *__restrict__ rec, int pair) {
     __shared__ unsigned sbits[PP_BITWORDS];
     __shared__ unsigned cur[V3_NL];
     __shared__ unsigned sdense[2 * V3_DWORDS];
@@ -237,31 +243,51 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
     for (int i = tid; i < V3_NL; i += 1024) cur[i] = SCATTER ? tileBase[i] + wgOff[row * V3_NL + i] : 0u;
     if (tid < 2 * V3_DWORDS) sdense[tid] = dense[tid];
     const PPGrid g = pp_grid(bb, c);
-    unsigned dummy = 0;
     __syncthreads();
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         int t = 0;
-        while (t + 1 < tr.n && chunk >= cm.cstart[t + 1]) ++t;
-        const long long p0 = tr.off[t] + (long long)(chunk - cm.cstart[t]) * V3_CH;
-        const long long pend = min(tr.off[t + 1], p0 + V3_CH);
+        long long p0, pend;
+        const float *src = hist;
+        const FrameDev *fd = nullptr;
+        bool center = false;
+        if (FRAMES) {
+            const uint2 ct = chunkTab[chunk];
+            fd = frames + ct.x;
+            src = fd->xyz;
+            p0 = ct.y;
+            pend = min((long long)fd->n, p0 + V3_CH);
+            t = fd->trav_flags & 0xffff;
+            center = ((fd->trav_flags >> 16) & F_FLAG_CENTER) != 0;
+        } else {
+            while (t + 1 < tr.n && chunk >= cm.cstart[t + 1]) ++t;
+            p0 = tr.off[t] + (long long)(chunk - cm.cstart[t]) * V3_CH;
+            pend = min(tr.off[t + 1], p0 + V3_CH);
+        }
         const long long q0 = p0 + 4LL * tid;
         if (q0 >= pend) continue;
         float v[12];
-        pp3_load4(hist, q0, pend, v);
+        pp3_load4(src, q0, pend, v);
+        bool dropped[4] = {false, false, false, false};
+        if (FRAMES) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dropped[k] = center && in_center_box(v[3 * k], v[3 * k + 1]);
+                float o[3];
+                rel_apply(fd->rel, v[3 * k], v[3 * k + 1], v[3 * k + 2], o);
+                v[3 * k] = o[0];
+                v[3 * k + 1] = o[1];
+                v[3 * k + 2] = o[2];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (q0 + k < pend) {
+            if (q0 + k < pend && !dropped[k]) {
                 int key;
                 const int list = pp3_classify(v[3 * k], v[3 * k + 1], g, sbits, sdense, &key);
                 if (list >= 0) {
                     if (SCATTER) {
                         const unsigned pos = atomicAdd(&cur[list], 1u);
-                        const float4 rv = make_float4(v[3 * k], v[3 * k + 1], v[3 * k + 2], __int_as_float(key | (t << 16)));
-                        typedef float v4f_t __attribute__((ext_vector_type(4)));
-                        if (dbg & 32) __builtin_nontemporal_store(v4f_t{rv.x, rv.y, rv.z, rv.w}, reinterpret_cast<v4f_t *>(&rec[pos]));
-                        else if (!(dbg & 16)) rec[pos] = rv;
-                    } else if (dbg & 64) {
-                        dummy += (unsigned)list;
+                        rec[pos] = make_float4(v[3 * k], v[3 * k + 1], v[3 * k + 2], __int_as_float(key | (t << 16)));
                     } else {
                         atomicAdd(&cur[list], 1u);
                     }
@@ -270,7 +296,6 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
         }
     }
     if (!SCATTER) {
-        if (dummy == 0xdeadbeefu) cur[0] = dummy;
         __syncthreads();
         for (int i = tid; i < V3_NL; i += 1024) wgTile[row * V3_NL + i] = cur[i];
     }
@@ -412,8 +437,9 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
     // they are seven registers the allocator spills)
 
     constexpr bool prof = PROF;
-    const unsigned laneGroups = ((dbg >> 8) & 0xff) ? ((dbg >> 8) & 0xff) : V3_LANE_GROUPS;
-    const unsigned laneMax = ((dbg >> 16) & 0xfff) ? ((dbg >> 16) & 0xfff) : V3_LANE_MAX;
+    // ablation knobs (MODEST_PP_DBG) exist in the PROF instantiation only
+    const unsigned laneGroups = (PROF && ((dbg >> 8) & 0xff)) ? ((dbg >> 8) & 0xff) : V3_LANE_GROUPS;
+    const unsigned laneMax = (PROF && ((dbg >> 16) & 0xfff)) ? ((dbg >> 16) & 0xfff) : V3_LANE_MAX;
     unsigned nGroups = 0, nIter = 0, nChunk = 0;
     if (prof && tid < 8) {
         S.prof[tid] = 0;
@@ -425,7 +451,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         S.prof[k] += now_ - S.tlast;                     \
         S.tlast = now_;                                  \
     }
-    if ((prof || (dbg & 128)) && tid == 0) stats[64 + blockIdx.x] = wall_clock64();
+    if (prof && tid == 0) stats[64 + blockIdx.x] = wall_clock64();
     unsigned nMine = 0;
     if (tid == 0) {   // the first slice; later ones are fetched while the previous slice is processed
         const unsigned first = atomicAdd(&ctrl3[1], 1u);
@@ -536,7 +562,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         PP3_TICK(1)
 
         // ---- (d) bands of cell rows -----------------------------------------------------
-        const unsigned nBands = (dbg & 4) ? 0u : S.nBands;
+        const unsigned nBands = (PROF && (dbg & 4)) ? 0u : S.nBands;
         for (unsigned b = 0; b < nBands; ++b) {
             const int ya = (int)S.bandA[b], yb = (int)S.bandB[b];
             const unsigned lbase = S.rowBase[ya - 1];
@@ -619,7 +645,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                 {
                     const int prevKey = __shfl_up(key, 1);
                     const unsigned nG = __popcll(__ballot(valid && (lane == 0 || key != prevKey)));
-                    if (nG >= laneGroups && !(dbg & 2)) {
+                    if (nG >= laneGroups && !(PROF && (dbg & 2))) {
                         const int lx = (key & (V3_TS - 1)) + 1, ly = key / V3_TS + 1;
                         const unsigned short *row = S.ctab + (ly - 1) * (V3_W + 1) + lx - 1;
                         const unsigned c00 = row[0], c10 = row[V3_W + 1], c20 = row[2 * (V3_W + 1)];
@@ -665,7 +691,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
                     todo &= ~grp;
                     const int lcx = (gkey & (V3_TS - 1)) + 1, lcy = gkey / V3_TS + 1;   // window coordinates
                     if (prof) ++nGroups;
-                    if (dbg & 2) continue;
+                    if (PROF && (dbg & 2)) continue;
                     // the three candidate runs (cell rows lcy-1 .. lcy+1, columns lcx-1 .. lcx+1): all scalar
                     const unsigned short *row = S.ctab + (lcy - 1) * (V3_W + 1) + lcx - 1;
                     const unsigned rb0 = S.rowBase[lcy - 1] - lbase, rb1 = S.rowBase[lcy] - lbase;
@@ -742,7 +768,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             }
             __syncthreads();
             PP3_TICK(3)
-            if (!(dbg & 1))
+            if (!(PROF && (dbg & 1)))
                 for (unsigned e = tid; e < Lb * Th; e += V3_JT) {
                     const unsigned cw = cntw[e];
                     if (cw) {
@@ -768,7 +794,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             S.slice = S.nextSlice;
         }
     }
-    if ((prof || (dbg & 128)) && tid == 0) {   // dbg 128: per-workgroup start / end / slice count only
+    if (prof && tid == 0) {   // per-workgroup start / end / slice count
         stats[64 + 1024 + blockIdx.x] = wall_clock64();
         stats[64 + 2048 + blockIdx.x] = nMine;
     }

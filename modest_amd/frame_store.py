@@ -1,0 +1,200 @@
+"""Frame store: raw LiDAR frames resident in HBM in the layout the PP kernels gather from.
+
+The reference re-reads, transforms and stacks every history frame for every scan
+(``pre_compute_pp_score.py:132-150``).  Here a frame is uploaded ONCE, sorted by the 8x8-cell tile
+of a world lattice (``modest_frame_sort``; cell edge ``c = r (1 + 2^-10)``, the lattice is fixed by
+the store's anchor and shared by every frame), and kept with its tile prefix table.  A scan names
+frames by key; ``pp_score`` hands descriptors (store buffers + traversal + the reference's float32
+relative pose) to ``modest_pp_score_frames`` -- no stacked history is ever built.
+
+World lattice: ``lattice = (world_xy - anchor_xy) / c`` with ``world = W @ [p, 1]`` for the frame's
+raw->world matrix ``W = E @ L @ K`` (ego pose, lidar-to-ego, KITTI2NU; the factors of
+``get_relative_pose``, ``pre_compute_pp_score.py:27-28``).  The PP kernels recompute a point's cell
+from its float32 common-frame coordinates through ``A = (fixed frame -> world)``; the two must agree
+to better than ``r/1024`` (checked per scan at 1e-4 m; otherwise, or when a frame has points outside
+its table, the scan takes the stacked path ``ops.pp_score``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Hashable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check, load
+
+
+class SortJob(C.Structure):
+    _fields_ = [("raw_dev", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32), ("TX0", C.c_int32),
+                ("TY0", C.c_int32), ("W", C.c_double * 8), ("xyz_dev", C.c_void_p), ("perm_dev", C.c_void_p),
+                ("tab_dev", C.c_void_p)]
+
+
+class PPFrame(C.Structure):
+    _fields_ = [("xyz_dev", C.c_void_p), ("tab_dev", C.c_void_p), ("n", C.c_int32), ("TX0", C.c_int32),
+                ("TY0", C.c_int32), ("trav", C.c_int32), ("flags", C.c_int32), ("rel", C.c_float * 12)]
+
+
+REMOVE_CENTER = 1
+
+
+@dataclass
+class StoredFrame:
+    xyz: torch.Tensor        # (n,3) f32 tile-sorted raw points
+    perm: torch.Tensor       # (n,) int32 (u32 bits): sorted -> original index
+    tab: torch.Tensor        # (NTF*NTF+1,) int32 prefix offsets
+    n: int
+    TX0: int
+    TY0: int
+    n_inside: int            # points inside the table (== n unless the frame has outliers)
+    W: np.ndarray            # (4,4) f64 raw frame -> world metres
+
+    @property
+    def nbytes(self) -> int:
+        return self.xyz.numel() * 4 + self.perm.numel() * 4 + self.tab.numel() * 4
+
+    def original_order(self) -> torch.Tensor:
+        """(n,3) raw points in file order (for the stacked fallback path)."""
+        out = torch.empty_like(self.xyz)
+        out[self.perm.long()] = self.xyz
+        return out
+
+
+class FrameStore:
+    """LRU store of tile-sorted frames on one device, for one ``max_neighbor_dist``."""
+
+    def __init__(self, device, radius: float, capacity_bytes: float = 64 * 2 ** 30, ctx=None):
+        self.device = torch.device(device)
+        self.radius = float(radius)
+        self.cell = self.radius * (1.0 + 1.0 / 1024.0)
+        self.cap = int(capacity_bytes)
+        self.bytes = 0
+        self.frames: "OrderedDict[Hashable, StoredFrame]" = OrderedDict()
+        self.anchor: Optional[np.ndarray] = None
+        self.ntf = int(load().modest_frame_table_tiles())
+        self.hits = self.misses = 0
+        self.ctx = ctx
+
+    # ------------------------------------------------------------------ lattice
+    def lattice_rows(self, M44: np.ndarray) -> np.ndarray:
+        """Rows x, y of (1/c) * (M - anchor) for a 4x4 map into world metres: 8 float64."""
+        M = np.asarray(M44, dtype=np.float64)
+        rows = M[:2, :].copy()
+        rows[:, 3] -= self.anchor[:2]
+        return np.ascontiguousarray(rows / self.cell).reshape(8)
+
+    def _table_origin(self, W44: np.ndarray) -> Tuple[int, int]:
+        o = (np.asarray(W44, dtype=np.float64)[:2, 3] - self.anchor[:2]) / self.cell
+        return (int(np.floor(o[0] / 8.0)) - self.ntf // 2, int(np.floor(o[1] / 8.0)) - self.ntf // 2)
+
+    # ------------------------------------------------------------------ insertion
+    def insert_many(self, items: Sequence[Tuple[Hashable, torch.Tensor, np.ndarray]]) -> None:
+        """items: (key, raw (n,3|4) f32 device tensor, W (4,4) f64 raw->world).  One launch."""
+        items = [it for it in items if it[0] not in self.frames]
+        if not items:
+            return
+        lib = load()
+        if self.anchor is None:
+            self.anchor = np.floor(np.asarray(items[0][2], dtype=np.float64)[:3, 3])
+        jobs = (SortJob * len(items))()
+        made = []
+        for k, (key, raw, W) in enumerate(items):
+            assert raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous() and raw.ndim == 2
+            n = int(raw.shape[0])
+            xyz = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            perm = torch.empty((n,), dtype=torch.int32, device=self.device)
+            tab = torch.empty((self.ntf * self.ntf + 1,), dtype=torch.int32, device=self.device)
+            TX0, TY0 = self._table_origin(W)
+            j = jobs[k]
+            j.raw_dev, j.n, j.stride, j.TX0, j.TY0 = raw.data_ptr(), n, int(raw.shape[1]), TX0, TY0
+            j.W[:] = list(self.lattice_rows(W))
+            j.xyz_dev, j.perm_dev, j.tab_dev = xyz.data_ptr(), perm.data_ptr(), tab.data_ptr()
+            made.append((key, xyz, perm, tab, n, TX0, TY0, np.asarray(W, dtype=np.float64).copy()))
+        inside = (C.c_int32 * len(items))()
+        c = self.ctx if self.ctx is not None else _lib.default_context(self.device.index or 0)
+        check(lib.modest_frame_sort(c.handle, jobs, len(items), inside, torch.cuda.current_stream().cuda_stream),
+              "modest_frame_sort")
+        for k, (key, xyz, perm, tab, n, TX0, TY0, W) in enumerate(made):
+            sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, int(inside[k]), W)
+            self.frames[key] = sf
+            self.bytes += sf.nbytes
+        while self.bytes > self.cap and len(self.frames) > len(items):
+            _, old = self.frames.popitem(last=False)
+            self.bytes -= old.nbytes
+
+    def insert(self, key, raw: torch.Tensor, W: np.ndarray) -> StoredFrame:
+        self.insert_many([(key, raw, W)])
+        return self.frames[key]
+
+    def get(self, key) -> Optional[StoredFrame]:
+        f = self.frames.get(key)
+        if f is not None:
+            self.frames.move_to_end(key)
+            self.hits += 1
+        else:
+            self.misses += 1
+        return f
+
+    # ------------------------------------------------------------------ the PP stage of one scan
+    def consistent(self, frames: Sequence[StoredFrame], rels: np.ndarray, A44: np.ndarray,
+                   tol: float = 1e-4, reach: float = 160.0) -> bool:
+        """|A @ rel_f @ p - W_f @ p| < tol for every raw point p within `reach` of the sensor."""
+        A = np.asarray(A44, dtype=np.float64)
+        Ws = np.stack([f.W for f in frames])
+        D = A[None] @ rels.astype(np.float64) - Ws
+        dev = np.abs(D[:, :2, :3]).sum(axis=2) * reach + np.abs(D[:, :2, 3])
+        return bool(np.all(np.isfinite(dev)) and dev.max() < tol)
+
+    def pp_score(self, live_key, live_rel: np.ndarray, hist: Sequence[Tuple[Hashable, int]], rels: np.ndarray,
+                 A44: np.ndarray, n_trav: int, remove_center: bool = False, return_counts: bool = False,
+                 out: Optional[torch.Tensor] = None, ctx=None, force_stacked: bool = False):
+        """PP score of one scan.  hist: (frame key, traversal index) per history frame; rels: (F,4,4)
+        float32 relative poses (get_relative_pose); live_rel (4,4) float32; A44 (4,4) float64 common
+        frame -> world.  Returns H (N,) float32 in the live frame's file order (and counts (N,T))."""
+        lib = load()
+        live = self.frames[live_key]
+        frames = [self.frames[k] for k, _ in hist]
+        rels = np.ascontiguousarray(np.asarray(rels, dtype=np.float32).reshape(len(frames), 4, 4))
+        live_rel = np.ascontiguousarray(np.asarray(live_rel, dtype=np.float32).reshape(4, 4))
+        N, T = live.n, int(n_trav)
+        ok = (not force_stacked and T <= 64 and live.n_inside == live.n
+              and all(f.n_inside == f.n for f in frames)
+              and self.consistent(frames + [live], np.concatenate([rels, live_rel[None]]), A44))
+        if not ok:
+            return self._pp_score_stacked(live, live_rel, frames, [t for _, t in hist], rels, T, remove_center,
+                                          return_counts, out, ctx)
+        arr = (PPFrame * max(len(frames), 1))()
+        for k, (f, (_, t)) in enumerate(zip(frames, hist)):
+            d = arr[k]
+            d.xyz_dev, d.tab_dev, d.n, d.TX0, d.TY0 = f.xyz.data_ptr(), f.tab.data_ptr(), f.n, f.TX0, f.TY0
+            d.trav, d.flags = int(t), (REMOVE_CENTER if remove_center else 0)
+            d.rel[:] = rels[k, :3, :].reshape(12).tolist()
+        lv = PPFrame()
+        lv.xyz_dev, lv.tab_dev, lv.n, lv.TX0, lv.TY0 = live.xyz.data_ptr(), live.tab.data_ptr(), live.n, live.TX0, live.TY0
+        lv.trav, lv.flags = 0, 0
+        lv.rel[:] = live_rel[:3, :].reshape(12).tolist()
+        A8 = (C.c_double * 8)(*self.lattice_rows(A44))
+        H = out if out is not None else torch.empty((N,), dtype=torch.float32, device=self.device)
+        counts = torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None
+        c = ctx if ctx is not None else (self.ctx if self.ctx is not None else _lib.default_context(self.device.index or 0))
+        check(lib.modest_pp_score_frames(c.handle, C.byref(lv), live.perm.data_ptr(), arr, len(frames), T, A8,
+                                         self.radius, counts.data_ptr() if counts is not None else None,
+                                         H.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "modest_pp_score_frames")
+        return (H, counts) if return_counts else H
+
+    def _pp_score_stacked(self, live, live_rel, frames, travs, rels, T, remove_center, return_counts, out, ctx):
+        """Stacked path (V3 kernels) for scans the frame path does not take: frames with outliers,
+        more than 64 traversals, a lattice that disagrees with the relative poses."""
+        parts = [[] for _ in range(T)]
+        for f, t, rel in zip(frames, travs, rels):
+            parts[t].append(ops.transform_points(f.xyz, rel, remove_center=remove_center, ctx=ctx))
+        flat = [p for tp in parts for p in tp]
+        hist = torch.cat(flat) if flat else torch.empty((0, 3), dtype=torch.float32, device=self.device)
+        offsets = np.cumsum([0] + [sum(int(p.shape[0]) for p in tp) for tp in parts]).astype(np.int64)
+        lv = ops.transform_points(live.original_order(), live_rel, ctx=ctx)
+        return ops.pp_score(lv, hist, offsets, self.radius, ctx=ctx, return_counts=return_counts, out=out)

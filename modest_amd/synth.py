@@ -176,7 +176,10 @@ class ScanInputs:
     live_raw: np.ndarray              # (N,4) f32 KITTI-velodyne frame of the live scan
     live_xyz: np.ndarray              # (N,3) f32 transformed into the first-history-frame system
     hist: List[np.ndarray]            # T arrays (M_t,3) f32 transformed
-    frames: List[List[Tuple[np.ndarray, np.ndarray]]] = field(default_factory=list)  # raw frame + 4x4 f32
+    frames: List[List[Tuple[np.ndarray, np.ndarray, np.ndarray]]] = field(default_factory=list)  # raw frame, 4x4 f32 relative pose, 4x4 f64 raw->world
+    live_rel: np.ndarray = None       # (4,4) f32 relative pose of the live scan
+    live_W: np.ndarray = None         # (4,4) f64 live raw frame -> world
+    world_from_ref: np.ndarray = None  # (4,4) f64 common (first history frame) system -> world
 
 
 def _transform_f32(pts_xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
@@ -221,12 +224,13 @@ def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: in
                 xyz = xyz[~m]
             q.append(_transform_f32(xyz, rel))
             if keep_frames:
-                fr.append((raw, rel))
+                fr.append((raw, rel, pose @ l2e @ K))
         hist.append(np.concatenate(q).astype(np.float32))
         frames.append(fr)
     rel_live = relative_pose(l2e, first_pose, l2e, live_pose, K)
     live_xyz = _transform_f32(live_raw[:, :3], rel_live)
-    return ScanInputs(live_raw=live_raw, live_xyz=np.ascontiguousarray(live_xyz), hist=hist, frames=frames)
+    return ScanInputs(live_raw=live_raw, live_xyz=np.ascontiguousarray(live_xyz), hist=hist, frames=frames,
+                      live_rel=rel_live, live_W=live_pose @ l2e @ K, world_from_ref=first_pose @ l2e @ K)
 
 
 CALIB_TXT = (
