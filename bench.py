@@ -2,28 +2,31 @@
 """bench.py -- BASELINE.json's headline metric on synthetic Lyft-shape input.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Every rank feeds its GPU from `--procs` helper processes x `--streams` threads (the host side of
-a scan is Python + ~100 HIP calls and saturates one process long before the GPU; --procs 1 keeps
-everything in the rank process).  Timing is the rank's: barrier, clock, all helpers run their
-share of the K steps and synchronise, barrier, clock; max over ranks.
+With --gpus N > 1 and no launcher in the environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank
+per GPU, RCCL); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE as usual and REFUSES to run
+when WORLD_SIZE != --gpus.  Every rank feeds its GPU from `--procs` helper processes x `--streams`
+threads (the host side of a scan is Python + ~60 HIP calls and saturates one process long before the
+GPU; --procs 1 keeps everything in the rank process).  Timing is the rank's: barrier, clock, all
+helpers run their share of the K steps and synchronise, barrier, clock; max over ranks.
 
-A "step" is one pass of the whole seed-label hot path over one scan whose inputs
-are already resident in HBM: PP score (live scan vs the stacked 10-traversal x
-36-frame history, ~10.8 M points) -> RANSAC ground plane -> plane/range mask ->
-PP-weighted mutual-kNN DBSCAN -> cluster filter -> closeness box fit -> BEV
-IoU NMS -> KITTI label text.  value = scans/s over all ranks (weak scaling: every
-rank processes K scans of its own).  Besides the contract fields the JSON line
-carries
-  roofline     -- the PP neighbour count (the operation SURVEY.md §8d prices at
-                  12*M + 16*N algorithmic bytes per scan; here it is a chain of
-                  kernels, so the WHOLE chain is timed with HIP events, not just
-                  its largest kernel) against the 8 TB/s HBM3E peak;
-  cpu_baseline -- the oracle (the reference's own scipy/sklearn calls, same
-                  threading as the reference: cKDTree single-threaded, sklearn
-                  n_jobs=-1) timed on this host on a bounded sample of the same
-                  scans; rank 0, N=1 only.
+A "step" is one pass of the whole seed-label hot path over one scan whose inputs are already
+resident in HBM -- the live frame and the 10 x 36 history frames sit in the frame store
+(modest_amd/frame_store.py) exactly as the CLI keeps them; there is no pre-stacked, pre-transformed
+history: PP score (descriptor table -> pose fused into the neighbour count, ~10.8 M history points)
+-> RANSAC ground plane -> plane/range mask -> PP-weighted mutual-kNN DBSCAN -> cluster filter ->
+closeness box fit -> BEV IoU NMS -> KITTI label text.  value = scans/s over all ranks (weak scaling:
+every rank processes K scans of its own).  Besides the contract fields the JSON line carries
+  roofline     -- the PP neighbour count (the operation SURVEY.md 8d prices at 12*M + 16*N
+                  algorithmic bytes per scan; here it is a chain of kernels, so the WHOLE chain is
+                  timed with HIP events, not just its largest kernel) against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the oracle (the reference's own scipy/sklearn calls, same threading as the
+                  reference: cKDTree single-threaded, sklearn n_jobs=-1) timed on this host on a
+                  bounded sample of the same scans, plus `best_effort` (SURVEY 8d baseline B:
+                  query_ball_point(workers=-1), one process per scan); rank 0, N=1 only;
+  cli          -- the three product CLIs (pre_compute_pp_score, generate_mask, gen_label_files) on a
+                  synthetic KITTI tree with shared history frames, file I/O included; rank 0, N=1.
 Nothing here reads /root/reference.
 """
 from __future__ import annotations
@@ -31,6 +34,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -43,39 +48,94 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+MIN_STEPS_PER_HELPER = 8   # a helper with 2-3 scans measures its start skew, not its throughput
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=560)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--scans", type=int, default=2, help="distinct resident scans per host process, cycled through")
+    ap.add_argument("--scans", type=int, default=3, help="distinct resident scans per host process, cycled through")
     ap.add_argument("--n-live", type=int, default=30000)
     ap.add_argument("--traversals", type=int, default=10)
     ap.add_argument("--frames", type=int, default=36)
     ap.add_argument("--cpu-scans", type=int, default=2, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-best-effort", type=int, default=16,
+                    help="scans of the best-effort CPU baseline (one process per scan, workers=-1; 0 = skip)")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
+    ap.add_argument("--stacked", action="store_true",
+                    help="A/B: feed the PP stage a pre-stacked, pre-transformed history (round-1 bench input)")
     ap.add_argument("--procs", type=int, default=7,
-                    help="host processes per GPU (per rank).  The host side of a scan is Python + ~100 HIP calls; one "
+                    help="host processes per GPU (per rank).  The host side of a scan is Python + ~60 HIP calls; one "
                          "process saturates at ~350 scans/s on its interpreter lock and HIP runtime locks while the "
                          "GPU is half idle, so every rank feeds its GPU from several helper processes (what the "
                          "reference's own total_part/part split does by hand).  1 = everything in the rank process.")
     ap.add_argument("--streams", type=int, default=1,
                     help="scans in flight per host process: threads, each with its own HIP stream and modest_ctx")
-    return ap.parse_args()
+    ap.add_argument("--cli-scans", type=int, default=48,
+                    help="live scans of the CLI measurement (0 = skip): the three product CLIs on a synthetic KITTI "
+                         "tree, 10 history traversals x 36 frames per scan, frames shared between consecutive scans")
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(gpus: int, argv) -> list:
+    """The command `python bench.py --gpus N` re-executes itself as when no launcher set WORLD_SIZE."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+
+
+def maybe_relaunch(a, argv) -> None:
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} HIP device(s) visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(launch_command(a.gpus, argv), env=env))
+
+
+# --------------------------------------------------------------------------- resident inputs
 class ResidentScan:
-    def __init__(self, s, dev, calib):
-        self.host = s
-        self.offsets = np.cumsum([0] + [len(h) for h in s.hist]).astype(np.int64)
-        self.live_raw = torch.from_numpy(s.live_raw).to(dev)
-        self.live_xyz = torch.from_numpy(s.live_xyz).to(dev)
-        self.hist = torch.from_numpy(np.concatenate(s.hist)).to(dev)
+    """One scan as the CLI holds it: frames in the frame store + descriptor table (or, --stacked,
+    the round-1 input: transformed live scan + stacked transformed history)."""
+
+    def __init__(self, s, dev, calib, store, key, stacked):
         self.calib = calib
-        self.M = int(self.offsets[-1])
+        self.live_host = s.live_raw
+        self.live_raw = torch.from_numpy(s.live_raw).to(dev)
+        self.M = int(sum(len(h) for h in s.hist))
         self.N = int(s.live_xyz.shape[0])
+        self.T = len(s.hist)
+        if stacked:
+            self.offsets = np.cumsum([0] + [len(h) for h in s.hist]).astype(np.int64)
+            self.live_xyz = torch.from_numpy(s.live_xyz).to(dev)
+            self.hist = torch.from_numpy(np.concatenate(s.hist)).to(dev)
+            return
+        items, self.hist_keys, rels = [], [], []
+        for t, fr in enumerate(s.frames):
+            for f, (raw, rel, W) in enumerate(fr):
+                k = (key, t, f)
+                items.append((k, torch.from_numpy(raw).to(dev), W))
+                self.hist_keys.append((k, t))
+                rels.append(rel)
+        self.live_key = (key, "live")
+        items.append((self.live_key, self.live_raw, s.live_W))
+        store.insert_many(items)
+        self.rels = np.stack(rels)
+        self.live_rel, self.A44 = s.live_rel, s.world_from_ref
+        self.desc = store.describe(self.live_key, self.live_rel, [k for k, _ in self.hist_keys],
+                                   [t for _, t in self.hist_keys], self.rels)
 
 
 class Runner:
@@ -85,6 +145,7 @@ class Runner:
     def __init__(self, a, rank, local, slot):
         import threading
         from modest_amd import _lib, config, ops, synth
+        from modest_amd.frame_store import FrameStore
         from modest_amd.gen_label_files import gen_label_scan
         from modest_amd.generate_mask import generate_mask_scan
         from modest_amd.utils import kitti_util
@@ -107,20 +168,31 @@ class Runner:
             calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
         self.margs = config.compose("generate_mask", ["data_root=/unused"])
         self.largs = config.compose("generate_label_files", ["data_root=/unused"])
-        self.scans = [ResidentScan(synth.make_scan(1000 * rank + 16 * slot + i, n_live=a.n_live, n_trav=a.traversals,
-                                                   n_frames=a.frames), self.dev, calib) for i in range(a.scans)]
+        self.store = None if a.stacked else FrameStore(self.dev, 0.3, ctx=self.ctxs[0])
+        self.scans = []
+        for i in range(a.scans):
+            sid = scan_seed(rank, slot, i)
+            s = synth.make_scan(sid, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames, keep_frames=not a.stacked)
+            self.scans.append(ResidentScan(s, self.dev, calib, self.store, sid, a.stacked))
+            del s
         # every thread (stream + scratch arena + kernel attributes) runs before any clock starts
         self.n_warm = max(a.warmup, 2 * self.n_threads)
         self.run(0, self.n_warm)
         torch.cuda.synchronize()
 
+    def pp(self, sc, ctx, return_counts=False):
+        if self.a.stacked:
+            return self.ops.pp_score(sc.live_xyz, sc.hist, sc.offsets, 0.3, ctx=ctx, return_counts=return_counts)
+        return self.store.pp_score(sc.live_key, sc.live_rel, sc.hist_keys, sc.rels, sc.A44, sc.T, ctx=ctx,
+                                   desc=sc.desc, return_counts=return_counts)
+
     def step(self, i, ctx):
         a, sc = self.a, self.scans[i % len(self.scans)]
-        H = self.ops.pp_score(sc.live_xyz, sc.hist, sc.offsets, 0.3, ctx=ctx)
+        H = self.pp(sc, ctx)
         if a.pp_only:
             return H, None, None, None
         pp_host = H.cpu().numpy()
-        labels, objs, _ = self._generate_mask_scan(sc.host.live_raw, pp_host, sc.calib, self.margs,
+        labels, objs, _ = self._generate_mask_scan(sc.live_host, pp_host, sc.calib, self.margs,
                                                    random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H)
         text, kept = self._gen_label_scan(objs, sc.calib, self.largs)
         return H, labels, objs, text
@@ -161,19 +233,25 @@ class Runner:
         return dt, np.concatenate([c_.profile_collect(n_steps + 8) for c_ in self.ctxs])
 
     def isolated_pp_ms(self):
-        sc0 = self.scans[0]
-        self.ctxs[0].profile_begin(16)
+        """The PP stage alone on the GPU, cycling through ALL resident scans (>= 3 x 130 MB of
+        distinct history: the 256 MiB Infinity Cache cannot hold the working set)."""
+        reps = max(4 * len(self.scans), 12)
+        self.ctxs[0].profile_begin(reps + 4)
         with torch.cuda.stream(self.streams[0]):
-            for i in range(8):
-                self.ops.pp_score(sc0.live_xyz, sc0.hist, sc0.offsets, 0.3, ctx=self.ctxs[0])
+            for i in range(reps):
+                self.pp(self.scans[i % len(self.scans)], self.ctxs[0])
             self.streams[0].synchronize()
-        iso = self.ctxs[0].profile_collect(16)
-        return float(np.mean(iso[2:])) if len(iso) > 2 else None
+        iso = self.ctxs[0].profile_collect(reps + 4)
+        return float(np.mean(iso[len(self.scans):])) if len(iso) > len(self.scans) else None
+
+
+def scan_seed(rank, slot, i):
+    return 1000 * rank + 16 * slot + i
 
 
 def _helper_main(conn, a, rank, local, slot):
     """entry point of a helper process (multiprocessing 'spawn'): pipe protocol
-    child -> ('ready', None) ; parent -> ('go', n_steps) ; child -> ('done', (seconds, kernel_ms)) ;
+    child -> ('ready', M) ; parent -> ('go', n_steps) ; child -> ('done', (seconds, kernel_ms)) ;
     parent -> ('iso', None) -> child ('iso', ms) ; parent -> ('exit', None)"""
     try:
         r = Runner(a, rank, local, slot)
@@ -198,18 +276,104 @@ def _split(n, parts):
     return [n // parts + (1 if k < n % parts else 0) for k in range(parts)]
 
 
+def helper_count(procs: int, steps: int) -> int:
+    """Helpers actually used: every one gets at least MIN_STEPS_PER_HELPER steps."""
+    return max(1, min(procs, steps // MIN_STEPS_PER_HELPER))
+
+
+# --------------------------------------------------------------------------- CPU baselines
+def _cpu_one_scan(args):
+    """best-effort CPU worker: one process per scan, multi-threaded neighbour queries"""
+    sid, n_live, trav, frames, pp_only = args
+    from modest_amd import synth
+    from oracle import labels as ol
+    from oracle import mask as om
+    from oracle import pp_score as opp
+    s = synth.make_scan(sid, n_live=n_live, n_trav=trav, n_frames=frames)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        ocalib = ol.Calibration(os.path.join(d, "c.txt"))
+    t0 = time.perf_counter()
+    H, _ = opp.pp_score(s.live_xyz, s.hist, 0.3, workers=-1)
+    if not pp_only:
+        ref = om.generate_mask_scan(s.live_raw, H, ocalib, random_state=np.random.RandomState(0), n_jobs=-1)
+        ol.gen_label_scan(ref["objs"], ocalib)
+    return t0, time.perf_counter()
+
+
+def cpu_best_effort(a):
+    """SURVEY 8d baseline (B): query_ball_point(workers=-1), sklearn n_jobs=-1, one process per scan,
+    all scans at once.  Throughput = scans / (last end - first start of the processing phases)."""
+    import multiprocessing as mp
+    n = a.cpu_best_effort
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(processes=n) as pool:
+        spans = pool.map(_cpu_one_scan, [(5000 + i, a.n_live, a.traversals, a.frames, a.pp_only) for i in range(n)])
+    t_lo, t_hi = min(s[0] for s in spans), max(s[1] for s in spans)
+    return n / (t_hi - t_lo), t_hi - t_lo
+
+
+# --------------------------------------------------------------------------- CLI measurement
+def cli_bench(a, local):
+    """The three product CLIs on a synthetic KITTI tree shaped like a Lyft shard: one live sequence
+    and 10 history sequences, 36 history frames per traversal per scan, consecutive live scans share
+    35 of them.  Everything is included: .bin reads, upload + tile sort of new frames, batched pose
+    solves, kernels, .npy/.pkl/.txt writes."""
+    from modest_amd import gen_label_files, generate_mask, pre_compute_pp_score, synth
+    n_scan, F, T = int(a.cli_scans), int(a.frames), int(a.traversals)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    out = {}
+    with tempfile.TemporaryDirectory(dir=base) as root:
+        t0 = time.perf_counter()
+        paths = synth.write_kitti_tree(os.path.join(root, "kitti"), os.path.join(root, "meta"), n_seq=T + 1,
+                                       n_frames=n_scan + F, n_pts=a.n_live, origins=tuple(range(n_scan)),
+                                       hist_frames=F, max_range=80.0)
+        out["tree_seconds"] = time.perf_counter() - t0
+        common = [f"data_root={root}/kitti/training", f"data_paths.track_path={paths['track_path']}",
+                  f"data_paths.idx_info={paths['idx_info']}", f"data_paths.idx_list={paths['idx_list']}",
+                  f"data_paths.pp_score_path={root}/pp", f"device={local}"]
+        t0 = time.perf_counter()
+        pre_compute_pp_score.main(argv=common)
+        torch.cuda.synchronize()
+        out["pp_scans_per_s"] = n_scan / (time.perf_counter() - t0)
+        margs = [common[0], f"data_paths.idx_list={paths['idx_list']}", f"data_paths.pp_score_path={root}/pp",
+                 f"data_paths.seg_save_dst={root}/seg", f"data_paths.bbox_info_save_dst={root}/bbox"]
+        t0 = time.perf_counter()
+        generate_mask.main(argv=margs)
+        torch.cuda.synchronize()
+        out["mask_scans_per_s"] = n_scan / (time.perf_counter() - t0)
+        largs = [common[0], f"data_paths.idx_list={paths['idx_list']}", f"data_paths.bbox_info_save_dst={root}/bbox",
+                 f"data_paths.label_file_save_dst={root}/labels"]
+        t0 = time.perf_counter()
+        gen_label_files.main(argv=largs)
+        out["label_scans_per_s"] = n_scan / (time.perf_counter() - t0)
+        out["pipeline_scans_per_s"] = 1.0 / (1.0 / out["pp_scans_per_s"] + 1.0 / out["mask_scans_per_s"]
+                                             + 1.0 / out["label_scans_per_s"])
+        out["label_files"] = len([f for f in os.listdir(f"{root}/labels") if f.endswith(".txt")])
+    out["scans"] = n_scan
+    out["note"] = (f"{n_scan} live scans x {T} traversals x {F} frames of {a.n_live} points; one process, one GPU; "
+                   "tree on " + (base or "the default tmp dir") + "; every stage timed cold (its first scan uploads and "
+                   "sorts all 361 frames, later scans 11 new ones)")
+    return out
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    maybe_relaunch(a, argv)
     from modest_amd import dist, ops, synth
 
     rank, ws, local = dist.init()
-    assert ws == a.gpus or ws == 1, f"--gpus {a.gpus} but WORLD_SIZE={ws}"
+    if ws != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={ws} rank(s); "
+                         f"run `python bench.py --gpus {a.gpus}` (it launches its own ranks) or make them agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(torch.device("cuda", local))
+    rccl_ws = torch.distributed.get_world_size() if (ws > 1 and torch.distributed.is_initialized()) else 1
 
     helpers, note, M = [], None, None
-    n_procs = max(1, a.procs)
+    n_procs = helper_count(a.procs, a.steps)
     if n_procs > 1:
         import multiprocessing as mp
         ctx = mp.get_context("spawn")
@@ -282,25 +446,31 @@ def main():
     k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_pp_traffic.json")
-    if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
-        tj = json.load(open(tpath))
-        if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
-            traffic, traffic_src = tj["hbm_bytes_per_scan"], "profiles/r01_pp_traffic.json (" + tj["source"] + ")"
+    for tname in ("r02_pp_traffic.json", "r01_pp_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
+            tj = json.load(open(tpath))
+            if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
+                traffic, traffic_src = tj["hbm_bytes_per_scan"], f"profiles/{tname} (" + tj["source"] + ")"
+                break
     roofline = {"bound": "hbm",
-                "kernel": "PP neighbour count of one scan = zero-fill + live index build (6 launches) + pp3_stream<count> + pp3_scan "
-                          "+ pp3_plan + pp3_stream<scatter> + pp3_join: ALL launches of the stage, HIP events on the "
-                          "launch stream", "achieved": achieved,
+                "kernel": "PP neighbour count of one scan = zero-fill + live transform + live index build (6 launches) + "
+                          "pp3_stream<count> + pp3_scan + pp3_plan + pp3_stream<scatter> + pp3_join: ALL launches of the "
+                          "stage, HIP events on the launch stream; the history is read from the frame store through the "
+                          "descriptor table (pose fused), not from a stacked copy",
+                "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                 "launches_timed": int(len(kernel_ms)),
                 "isolated": {"kernel_ms": iso_ms,
                              "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso_ms else None,
-                             "note": "same stage, one scan at a time on an otherwise idle GPU, after the timed region"}}
+                             "note": f"same stage, one scan at a time on an otherwise idle GPU, cycling {a.scans} distinct "
+                                     "scans, after the timed region"}}
 
     cpu_baseline = None
     parity = None
+    cli = None
     if rank == 0 and ws == 1 and a.cpu_scans > 0:
         from oracle import labels as ol
         from oracle import mask as om
@@ -309,29 +479,55 @@ def main():
             open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
             ocalib = ol.Calibration(os.path.join(d, "c.txt"))
         # the sample = the scans helper 0 (or the rank process) benchmarked: same generator, same seeds
-        import torch as _t
-        host_scans = [synth.make_scan(1000 * rank + i, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames)
+        host_scans = [synth.make_scan(scan_seed(rank, 0, i), n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames,
+                                      keep_frames=(i == 0 and not a.stacked))
                       for i in range(min(a.cpu_scans, a.scans))]
         n_cpu = len(host_scans)
+        refs = []
         tc = time.perf_counter()
         for i in range(n_cpu):
             s = host_scans[i]
             Href, cref = opp.pp_score(s.live_xyz, s.hist, 0.3, workers=1)       # reference: single thread
+            ref = None
             if not a.pp_only:
                 ref = om.generate_mask_scan(s.live_raw, Href, ocalib, random_state=np.random.RandomState(i), n_jobs=-1)
-                ol.gen_label_scan(ref["objs"], ocalib)
-            if i == 0:
-                # parity of the measured path against the checker, outside the timed region
-                dv = _t.device("cuda", local)
-                Hg, cg = ops.pp_score(_t.from_numpy(s.live_xyz).to(dv), _t.from_numpy(np.concatenate(s.hist)).to(dv),
-                                      np.cumsum([0] + [len(h) for h in s.hist]), 0.3, return_counts=True)
-                parity = {"pp_counts_equal": bool(np.array_equal(cg.cpu().numpy().astype(np.int64), cref)),
-                          "pp_max_abs_err": float(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - Href)))}
+                ref["text"] = ol.gen_label_scan(ref["objs"], ocalib)
+            refs.append((Href, cref, ref))
         tc = time.perf_counter() - tc
+        # parity of the measured path against the checker on the first sampled scan, outside every timed region
+        pa = argparse.Namespace(**vars(a))
+        pa.scans, pa.warmup, pa.streams = 1, 0, 1
+        pr = Runner(pa, rank, local, 0)
+        Hg, cg = pr.pp(pr.scans[0], pr.ctxs[0], return_counts=True)
+        Href, cref, ref = refs[0]
+        parity = {"pp_counts_equal": bool(np.array_equal(cg.cpu().numpy().astype(np.int64), cref)),
+                  "pp_max_abs_err": float(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - Href)))}
+        if ref is not None:
+            _, labels, objs, text = pr.step(0, pr.ctxs[0])
+            parity["labels_equal"] = bool(np.array_equal(labels, ref["labels"]))
+            parity["n_objs"] = [len(objs), len(ref["objs"])]
+            parity["label_text_equal"] = bool(text == ref["text"][0])
+        del pr
         cpu_baseline = {"value": n_cpu / tc, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
                         "sample": f"{n_cpu} of the benchmarked scans ({'PP stage only' if a.pp_only else 'full pipeline'}); "
                                   "reference threading: cKDTree build+query 1 thread, sklearn n_jobs=-1 on all "
-                                  f"{os.cpu_count()} host threads; {tc:.1f} s"}
+                                  f"{os.cpu_count()} host threads; {tc:.1f} s.  The oracle fills the affinity weights with "
+                                  "one vectorised numpy expression where the reference loops over CSR rows in Python "
+                                  "(oracle/mask.py:113-121): it is faster than the reference there, i.e. conservative"}
+        if a.cpu_best_effort > 0:
+            try:
+                v, secs = cpu_best_effort(a)
+                cpu_baseline["best_effort"] = {
+                    "value": v, "unit": "scans/s", "cores": os.cpu_count(),
+                    "sample": f"{a.cpu_best_effort} scans of the same generator, one process per scan in parallel, "
+                              f"query_ball_point(workers=-1), sklearn n_jobs=-1; {secs:.1f} s"}
+            except Exception as e:
+                cpu_baseline["best_effort"] = {"error": repr(e)}
+    if rank == 0 and ws == 1 and a.cli_scans > 0 and not a.pp_only and not a.stacked:
+        try:
+            cli = cli_bench(a, local)
+        except Exception as e:
+            cli = {"error": repr(e)}
 
     if rank == 0:
         value = total_scans / dt_max
@@ -344,10 +540,13 @@ def main():
                                    + f", Lyft-shape: {a.n_live} live pts vs {a.traversals} traversals x {a.frames} frames = {M} history pts",
                        "live_points": a.n_live, "history_points": M, "traversals": a.traversals,
                        "frames_per_traversal": a.frames, "radius": 0.3, "scans_per_rank": a.steps,
+                       "history_input": "pre-stacked transformed array" if a.stacked else
+                                        "frame store + descriptor table (no stacked history)",
                        "host_processes_per_gpu": n_procs, "threads_per_process": n_threads,
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
+                       "rccl_world_size": rccl_ws,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli,
             "speedup_vs_cpu": (value / cpu_baseline["value"]) if cpu_baseline else None,
         }
         print(json.dumps(line), flush=True)

@@ -1017,7 +1017,7 @@ __global__ void pp5_entropy_kernel(const int *__restrict__ counts, int n, int T,
 
 // launch geometry.  Fused kernel: two 512-thread workgroups per CU, gather rounds of 1536 points, up
 // to 3072 surviving records sorted and joined at a time.  Split kernels: gather = 256-thread
-// workgroups with no record buffer in LDS; join = two 1024-thread workgroups per CU, 4096 records.
+// workgroups with no record buffer in LDS; join = two 512-thread workgroups per CU, 3072 records.
 constexpr int J_JT = 512, J_RPT = 3, J_CAP = 3072, J_FMAX = 384, J_FCH = 128;
 using JCfg = JoinCfg<J_JT, J_RPT, J_CAP, J_FMAX, J_FCH>;
 constexpr unsigned J_LDS = 78 * 1024;
@@ -1025,7 +1025,7 @@ static_assert(JCfg::OFF_LIVE + 4096 < J_LDS, "room for the live window");
 constexpr int G_JT = 256, G_RPT = 4;
 using GCfg = JoinCfg<G_JT, G_RPT, 0, J_FMAX, J_FCH>;
 constexpr unsigned G_LDS = (unsigned)GCfg::OFF_LIVE + 64;
-constexpr int K_JT = 1024, K_CAP = 4096;
+constexpr int K_JT = 512, K_CAP = 3072;
 using KCfg = JoinCfg<K_JT, 1, K_CAP, 4, 4>;
 constexpr unsigned K_LDS = 78 * 1024;
 static_assert(KCfg::OFF_LIVE + 4096 < K_LDS, "room for the live window");

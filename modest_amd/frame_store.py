@@ -1,4 +1,4 @@
-"""Frame store: raw LiDAR frames resident in HBM in the layout the PP kernels gather from.
+"""Frame store: raw LiDAR frames resident in HBM in the layout the PP kernels read.
 
 The reference re-reads, transforms and stacks every history frame for every scan
 (``pre_compute_pp_score.py:132-150``).  Here a frame is uploaded ONCE, sorted by the 8x8-cell tile
@@ -9,17 +9,18 @@ relative pose) to ``modest_pp_score_frames`` -- no stacked history is ever built
 
 World lattice: ``lattice = (world_xy - anchor_xy) / c`` with ``world = W @ [p, 1]`` for the frame's
 raw->world matrix ``W = E @ L @ K`` (ego pose, lidar-to-ego, KITTI2NU; the factors of
-``get_relative_pose``, ``pre_compute_pp_score.py:27-28``).  The PP kernels recompute a point's cell
-from its float32 common-frame coordinates through ``A = (fixed frame -> world)``; the two must agree
-to better than ``r/1024`` (checked per scan at 1e-4 m; otherwise, or when a frame has points outside
-its table, the scan takes the stacked path ``ops.pp_score``).
+``get_relative_pose``, ``pre_compute_pp_score.py:27-28``).  The gather-join path recomputes a
+point's cell from its float32 common-frame coordinates through ``A = (fixed frame -> world)``; the
+two must agree to better than ``r/1024`` (checked per scan at 1e-4 m; otherwise, or when a frame has
+points outside its table, the scan takes the stacked path ``ops.pp_score``).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Dict, Hashable, List, Optional, Sequence, Tuple
+from typing import Hashable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -34,10 +35,10 @@ class SortJob(C.Structure):
                 ("tab_dev", C.c_void_p)]
 
 
-class PPFrame(C.Structure):
-    _fields_ = [("xyz_dev", C.c_void_p), ("tab_dev", C.c_void_p), ("n", C.c_int32), ("TX0", C.c_int32),
-                ("TY0", C.c_int32), ("trav", C.c_int32), ("flags", C.c_int32), ("rel", C.c_float * 12)]
-
+# modest_pp_frame (include/modest_hip.h) as a numpy record: descriptor tables are filled vectorised
+PP_FRAME = np.dtype([("xyz_dev", "u8"), ("tab_dev", "u8"), ("n", "i4"), ("TX0", "i4"), ("TY0", "i4"),
+                     ("trav", "i4"), ("flags", "i4"), ("rel", "f4", (12,))], align=True)
+assert PP_FRAME.itemsize == 88
 
 REMOVE_CENTER = 1
 
@@ -52,6 +53,7 @@ class StoredFrame:
     TY0: int
     n_inside: int            # points inside the table (== n unless the frame has outliers)
     W: np.ndarray            # (4,4) f64 raw frame -> world metres
+    slot: int = -1
 
     @property
     def nbytes(self) -> int:
@@ -78,6 +80,11 @@ class FrameStore:
         self.ntf = int(load().modest_frame_table_tiles())
         self.hits = self.misses = 0
         self.ctx = ctx
+        # slot tables: the static part of every frame's descriptor, gathered per scan by fancy indexing
+        self._rec = np.zeros(1024, dtype=PP_FRAME)
+        self._W = np.zeros((1024, 4, 4))
+        self._clean = np.zeros(1024, dtype=bool)   # no point outside the table
+        self._free: List[int] = list(range(1023, -1, -1))
 
     # ------------------------------------------------------------------ lattice
     def lattice_rows(self, M44: np.ndarray) -> np.ndarray:
@@ -91,18 +98,35 @@ class FrameStore:
         o = (np.asarray(W44, dtype=np.float64)[:2, 3] - self.anchor[:2]) / self.cell
         return (int(np.floor(o[0] / 8.0)) - self.ntf // 2, int(np.floor(o[1] / 8.0)) - self.ntf // 2)
 
+    def _ctx(self, ctx=None):
+        return ctx if ctx is not None else (self.ctx if self.ctx is not None
+                                            else _lib.default_context(self.device.index or 0))
+
+    def _take_slot(self) -> int:
+        if not self._free:
+            old = self._rec.shape[0]
+            self._rec = np.concatenate([self._rec, np.zeros(old, dtype=PP_FRAME)])
+            self._W = np.concatenate([self._W, np.zeros((old, 4, 4))])
+            self._clean = np.concatenate([self._clean, np.zeros(old, dtype=bool)])
+            self._free = list(range(2 * old - 1, old - 1, -1))
+        return self._free.pop()
+
     # ------------------------------------------------------------------ insertion
-    def insert_many(self, items: Sequence[Tuple[Hashable, torch.Tensor, np.ndarray]]) -> None:
+    def insert_many(self, items: Sequence[Tuple[Hashable, torch.Tensor, np.ndarray]], ctx=None) -> None:
         """items: (key, raw (n,3|4) f32 device tensor, W (4,4) f64 raw->world).  One launch."""
-        items = [it for it in items if it[0] not in self.frames]
-        if not items:
+        seen, todo = set(), []
+        for it in items:
+            if it[0] not in self.frames and it[0] not in seen:
+                seen.add(it[0])
+                todo.append(it)
+        if not todo:
             return
         lib = load()
         if self.anchor is None:
-            self.anchor = np.floor(np.asarray(items[0][2], dtype=np.float64)[:3, 3])
-        jobs = (SortJob * len(items))()
+            self.anchor = np.floor(np.asarray(todo[0][2], dtype=np.float64)[:3, 3])
+        jobs = (SortJob * len(todo))()
         made = []
-        for k, (key, raw, W) in enumerate(items):
+        for k, (key, raw, W) in enumerate(todo):
             assert raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous() and raw.ndim == 2
             n = int(raw.shape[0])
             xyz = torch.empty((n, 3), dtype=torch.float32, device=self.device)
@@ -114,17 +138,21 @@ class FrameStore:
             j.W[:] = list(self.lattice_rows(W))
             j.xyz_dev, j.perm_dev, j.tab_dev = xyz.data_ptr(), perm.data_ptr(), tab.data_ptr()
             made.append((key, xyz, perm, tab, n, TX0, TY0, np.asarray(W, dtype=np.float64).copy()))
-        inside = (C.c_int32 * len(items))()
-        c = self.ctx if self.ctx is not None else _lib.default_context(self.device.index or 0)
-        check(lib.modest_frame_sort(c.handle, jobs, len(items), inside, torch.cuda.current_stream().cuda_stream),
-              "modest_frame_sort")
+        inside = (C.c_int32 * len(todo))()
+        check(lib.modest_frame_sort(self._ctx(ctx).handle, jobs, len(todo), inside,
+                                    torch.cuda.current_stream().cuda_stream), "modest_frame_sort")
         for k, (key, xyz, perm, tab, n, TX0, TY0, W) in enumerate(made):
-            sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, int(inside[k]), W)
+            sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, int(inside[k]), W, self._take_slot())
+            r = self._rec[sf.slot]
+            r["xyz_dev"], r["tab_dev"], r["n"], r["TX0"], r["TY0"] = xyz.data_ptr(), tab.data_ptr(), n, TX0, TY0
+            self._W[sf.slot] = W
+            self._clean[sf.slot] = sf.n_inside == n
             self.frames[key] = sf
             self.bytes += sf.nbytes
-        while self.bytes > self.cap and len(self.frames) > len(items):
+        while self.bytes > self.cap and len(self.frames) > len(todo):
             _, old = self.frames.popitem(last=False)
             self.bytes -= old.nbytes
+            self._free.append(old.slot)
 
     def insert(self, key, raw: torch.Tensor, W: np.ndarray) -> StoredFrame:
         self.insert_many([(key, raw, W)])
@@ -139,57 +167,71 @@ class FrameStore:
             self.misses += 1
         return f
 
+    def __contains__(self, key) -> bool:
+        return key in self.frames
+
     # ------------------------------------------------------------------ the PP stage of one scan
-    def consistent(self, frames: Sequence[StoredFrame], rels: np.ndarray, A44: np.ndarray,
-                   tol: float = 1e-4, reach: float = 160.0) -> bool:
+    def consistent(self, slots: np.ndarray, rels: np.ndarray, A44: np.ndarray, tol: float = 1e-4,
+                   reach: float = 160.0) -> bool:
         """|A @ rel_f @ p - W_f @ p| < tol for every raw point p within `reach` of the sensor."""
         A = np.asarray(A44, dtype=np.float64)
-        Ws = np.stack([f.W for f in frames])
-        D = A[None] @ rels.astype(np.float64) - Ws
+        D = A[None] @ rels.astype(np.float64) - self._W[slots]
         dev = np.abs(D[:, :2, :3]).sum(axis=2) * reach + np.abs(D[:, :2, 3])
         return bool(np.all(np.isfinite(dev)) and dev.max() < tol)
 
+    def describe(self, live_key, live_rel: np.ndarray, hist_keys: Sequence[Hashable], travs: Sequence[int],
+                 rels: np.ndarray, remove_center: bool = False):
+        """Descriptor table of a scan: (live record (1,), history records (F,), slots (F+1,))."""
+        slots = np.fromiter((self.frames[k].slot for k in hist_keys), dtype=np.int64, count=len(hist_keys))
+        arr = self._rec[slots] if len(slots) else np.zeros(1, dtype=PP_FRAME)
+        if len(slots):
+            arr["trav"] = np.asarray(travs, dtype=np.int32)
+            arr["flags"] = REMOVE_CENTER if remove_center else 0
+            arr["rel"] = np.asarray(rels, dtype=np.float32).reshape(len(slots), 4, 4)[:, :3, :].reshape(len(slots), 12)
+        lslot = self.frames[live_key].slot
+        lv = self._rec[[lslot]]
+        lv["rel"] = np.asarray(live_rel, dtype=np.float32).reshape(4, 4)[:3, :].reshape(1, 12)
+        return lv, arr, np.concatenate([slots, [lslot]])
+
     def pp_score(self, live_key, live_rel: np.ndarray, hist: Sequence[Tuple[Hashable, int]], rels: np.ndarray,
                  A44: np.ndarray, n_trav: int, remove_center: bool = False, return_counts: bool = False,
-                 out: Optional[torch.Tensor] = None, ctx=None, force_stacked: bool = False):
+                 out: Optional[torch.Tensor] = None, ctx=None, force_stacked: bool = False, desc=None):
         """PP score of one scan.  hist: (frame key, traversal index) per history frame; rels: (F,4,4)
         float32 relative poses (get_relative_pose); live_rel (4,4) float32; A44 (4,4) float64 common
-        frame -> world.  Returns H (N,) float32 in the live frame's file order (and counts (N,T))."""
+        frame -> world.  Returns H (N,) float32 in the live frame's file order (and counts (N,T)).
+        `desc` = a table from describe() reused across calls (the frames must still be resident)."""
         lib = load()
         live = self.frames[live_key]
-        frames = [self.frames[k] for k, _ in hist]
-        rels = np.ascontiguousarray(np.asarray(rels, dtype=np.float32).reshape(len(frames), 4, 4))
+        F = len(hist)
+        rels = np.ascontiguousarray(np.asarray(rels, dtype=np.float32).reshape(F, 4, 4))
         live_rel = np.ascontiguousarray(np.asarray(live_rel, dtype=np.float32).reshape(4, 4))
         N, T = live.n, int(n_trav)
-        ok = (not force_stacked and T <= 64 and live.n_inside == live.n
-              and all(f.n_inside == f.n for f in frames)
-              and self.consistent(frames + [live], np.concatenate([rels, live_rel[None]]), A44))
+        if desc is None:
+            desc = self.describe(live_key, live_rel, [k for k, _ in hist], [t for _, t in hist], rels, remove_center)
+        lv, arr, slots = desc
+        # the streaming path reads frames as plain point lists; only the gather-join relies on the
+        # tile tables (no outliers) and on the lattice agreeing with the relative poses
+        gather = os.environ.get("MODEST_PP_FRAMES_PATH", "").startswith("gather")
+        ok = (not force_stacked and T <= 64
+              and (not gather or (bool(self._clean[slots].all())
+                                  and self.consistent(slots, np.concatenate([rels, live_rel[None]]), A44))))
         if not ok:
+            frames = [self.frames[k] for k, _ in hist]
             return self._pp_score_stacked(live, live_rel, frames, [t for _, t in hist], rels, T, remove_center,
                                           return_counts, out, ctx)
-        arr = (PPFrame * max(len(frames), 1))()
-        for k, (f, (_, t)) in enumerate(zip(frames, hist)):
-            d = arr[k]
-            d.xyz_dev, d.tab_dev, d.n, d.TX0, d.TY0 = f.xyz.data_ptr(), f.tab.data_ptr(), f.n, f.TX0, f.TY0
-            d.trav, d.flags = int(t), (REMOVE_CENTER if remove_center else 0)
-            d.rel[:] = rels[k, :3, :].reshape(12).tolist()
-        lv = PPFrame()
-        lv.xyz_dev, lv.tab_dev, lv.n, lv.TX0, lv.TY0 = live.xyz.data_ptr(), live.tab.data_ptr(), live.n, live.TX0, live.TY0
-        lv.trav, lv.flags = 0, 0
-        lv.rel[:] = live_rel[:3, :].reshape(12).tolist()
-        A8 = (C.c_double * 8)(*self.lattice_rows(A44))
+        A8 = np.ascontiguousarray(self.lattice_rows(A44))
         H = out if out is not None else torch.empty((N,), dtype=torch.float32, device=self.device)
         counts = torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None
-        c = ctx if ctx is not None else (self.ctx if self.ctx is not None else _lib.default_context(self.device.index or 0))
-        check(lib.modest_pp_score_frames(c.handle, C.byref(lv), live.perm.data_ptr(), arr, len(frames), T, A8,
-                                         self.radius, counts.data_ptr() if counts is not None else None,
+        check(lib.modest_pp_score_frames(self._ctx(ctx).handle, lv.ctypes.data, live.perm.data_ptr(), arr.ctypes.data,
+                                         F, T, A8.ctypes.data, self.radius,
+                                         counts.data_ptr() if counts is not None else None,
                                          H.data_ptr(), torch.cuda.current_stream().cuda_stream),
               "modest_pp_score_frames")
         return (H, counts) if return_counts else H
 
     def _pp_score_stacked(self, live, live_rel, frames, travs, rels, T, remove_center, return_counts, out, ctx):
-        """Stacked path (V3 kernels) for scans the frame path does not take: frames with outliers,
-        more than 64 traversals, a lattice that disagrees with the relative poses."""
+        """Stacked path (V3 kernels on a transformed copy) for scans the frame path does not take:
+        frames with outliers, more than 64 traversals, a lattice that disagrees with the poses."""
         parts = [[] for _ in range(T)]
         for f, t, rel in zip(frames, travs, rels):
             parts[t].append(ops.transform_points(f.xyz, rel, remove_center=remove_center, ctx=ctx))

@@ -2,12 +2,14 @@
 
 Drop-in for the reference's ``generate_cluster_mask/pre_compute_pp_score.py``
 (same config keys, same ``pp_score_path/NNNNNN.npy`` float32 outputs).  What
-changes is where the work happens: raw ``.bin`` frames are uploaded once and
-kept resident in HBM (LRU), each frame is transformed into the common
-coordinate system by a HIP kernel straight into the stacked-history buffer
-(``transform_points`` + ``remove_center`` fused, reference :132-150), and the
-KD-tree build + ball query of the reference (:188-193) is replaced by the
-streamed neighbour-count kernel.
+changes is where the work happens: raw ``.bin`` frames are uploaded once into
+the frame store (``frame_store.py``: tile-sorted, resident in HBM, LRU), a scan
+names its history frames through a descriptor table carrying the reference's
+float32 relative poses (one batched ``np.linalg.solve`` per scan), and the
+neighbour-count kernels read the frames through that table with
+``transform_points`` + ``remove_center`` fused (reference :132-150) -- no
+stacked history is built; the KD-tree build + ball query of the reference
+(:188-193) is replaced by the streamed neighbour count.
 """
 from __future__ import annotations
 
@@ -16,13 +18,13 @@ import os.path as osp
 import pickle
 import sys
 import time
-from collections import OrderedDict
 
 import numpy as np
 import torch
 from scipy.spatial.transform import Rotation as R
 
 from . import config, dist, ops
+from .frame_store import FrameStore
 from .utils.pointcloud_utils import load_velo_scan
 
 
@@ -69,57 +71,49 @@ def load_poses(track_list, oxts_path, l2e_path):
     return poses, l2es
 
 
-class FrameCache:
-    """Raw (n,4) float32 frames resident in HBM, least-recently-used eviction.
-    A Lyft training split is ~12.7 k frames x ~0.5 MB: it fits in one MI355X."""
+class FrameLoader:
+    """Feeds the frame store (modest_amd/frame_store.py): a `.bin` frame is read, uploaded and
+    tile-sorted once, then serves every scan that names it (a Lyft frame is history of ~70 scans).
+    A Lyft training split is ~12.7 k frames x ~0.55 MB: it fits in one MI355X many times over."""
 
-    def __init__(self, velodyne_dir, device, capacity_bytes):
-        self.dir, self.device, self.cap = velodyne_dir, device, int(capacity_bytes)
-        self.bytes = 0
-        self.frames: "OrderedDict[int, torch.Tensor]" = OrderedDict()
-        self.hits = self.misses = 0
+    def __init__(self, velodyne_dir, store: FrameStore, world):
+        self.dir, self.store, self.world = velodyne_dir, store, world
 
-    def get(self, file_idx: int) -> torch.Tensor:
-        t = self.frames.get(file_idx)
-        if t is not None:
-            self.frames.move_to_end(file_idx)
-            self.hits += 1
-            return t
-        self.misses += 1
-        raw = load_velo_scan(osp.join(self.dir, f"{file_idx:06d}.bin"))
-        t = torch.from_numpy(raw).to(self.device)
-        self.frames[file_idx] = t
-        self.bytes += t.numel() * 4
-        while self.bytes > self.cap and len(self.frames) > 1:
-            _, old = self.frames.popitem(last=False)
-            self.bytes -= old.numel() * 4
-        return t
+    def ensure(self, file_ids):
+        """Upload + sort (one launch) every frame of `file_ids` that is not resident."""
+        missing = [i for i in dict.fromkeys(file_ids) if i not in self.store]
+        if missing:
+            items = []
+            for i in missing:
+                raw = load_velo_scan(osp.join(self.dir, f"{i:06d}.bin"))
+                items.append((i, torch.from_numpy(raw).to(self.store.device), self.world[i]))
+            self.store.insert_many(items)
+        for i in file_ids:
+            self.store.get(i)   # LRU touch + hit statistics
 
 
-def assemble_history(cache, track_list, poses, l2es, traversals, first_pose, first_l2e, K, nusc):
-    """(:132-150) stack the transformed frames of every traversal.
-    Returns (hist (M,3) f32 device, offsets (T+1) int64, per-traversal seq ids)."""
-    parts, offsets, total = [], [0], 0
-    if not nusc:
-        sizes = [[cache.get(track_list[s][f]).shape[0] for f in idx] for s, idx in traversals]
-        M = int(sum(sum(x) for x in sizes))
-        hist = torch.empty((M, 3), dtype=torch.float32, device=cache.device)
-        for (seq_id, indices), sz in zip(traversals, sizes):
-            for frame, n in zip(indices, sz):
-                rel = get_relative_pose(first_l2e, first_pose, l2es[seq_id][frame], poses[seq_id][frame], K)
-                ops.transform_points(cache.get(track_list[seq_id][frame]), rel, out=hist[total:total + n])
-                total += n
-            offsets.append(total)
-        return hist, np.asarray(offsets, dtype=np.int64)
-    for seq_id, indices in traversals:          # nuScenes: remove_center makes sizes data dependent
-        for frame in indices:
-            rel = get_relative_pose(first_l2e, first_pose, l2es[seq_id][frame], poses[seq_id][frame], K)
-            p = ops.transform_points(cache.get(track_list[seq_id][frame]), rel, remove_center=True)
-            parts.append(p)
-            total += p.shape[0]
-        offsets.append(total)
-    hist = torch.cat(parts) if parts else torch.empty((0, 3), dtype=torch.float32, device=cache.device)
-    return hist, np.asarray(offsets, dtype=np.int64)
+def frame_world_matrices(track_list, poses, l2es, K):
+    """W_f = E_f @ L_f @ K for every frame -- the right-hand factor of get_relative_pose (:27-28),
+    the same three-matrix product in the same order -- computed once: it does not depend on the scan."""
+    world = {}
+    for seq, ps, ls in zip(track_list, poses, l2es):
+        for idx, E, L in zip(seq, ps, ls):
+            world[idx] = E @ L @ K
+    return world
+
+
+def relative_poses(fixed_l2e, fixed_ego, world_stack, K):
+    """get_relative_pose (:27-28) for a stack of frames: the three nested solves run once over the
+    (F,4,4) stack of E_q @ L_q @ K products (LAPACK gesv per matrix: bit-identical to F calls)."""
+    return np.linalg.solve(K, np.linalg.solve(fixed_l2e, np.linalg.solve(fixed_ego, world_stack))).astype(np.float32)
+
+
+def save_npy_atomic(path, arr):
+    """np.save through a temporary file + os.replace: a killed rank never leaves a truncated .npy
+    that the skip-if-exists test would count as done."""
+    tmp = f"{path}.tmp{os.getpid()}.npy"
+    np.save(tmp, arr)
+    os.replace(tmp, path)
 
 
 def display_args(args):
@@ -149,56 +143,81 @@ def main(args):
     for d in (dp.load_save_precomputed_trans_mat, dp.load_precomputed_lidars):
         if d is not None:
             os.makedirs(d, exist_ok=True)
-    cache = FrameCache(osp.join(args.data_root, "velodyne"), device, float(args.get("frame_cache_gb", 64)) * 2 ** 30)
     K = _KITTI2NU_nusc if args.nusc else _KITTI2NU_lyft
     if args.ephe_type != "entropy":
         raise NotImplementedError(args.ephe_type)
+    radius = float(args.max_neighbor_dist)
+    store = FrameStore(device, radius, float(args.get("frame_cache_gb", 64)) * 2 ** 30)
+    world = frame_world_matrices(track_list, poses, l2es, K)
+    loader = FrameLoader(osp.join(args.data_root, "velodyne"), store, world)
     t0, done, pts = time.perf_counter(), 0, 0
     dist.barrier()
     for origin_idx in shard:
         origin_idx = int(origin_idx)
         out_path = osp.join(dp.pp_score_path, f"{origin_idx:06d}.npy")
-        # the reference tests the name without ".npy" (:123-124) and so never skips
+        # the reference tests the name without ".npy" (:123-124) and so never skips; here finished
+        # scans are skipped unless overwrite=True (required after changing max_neighbor_dist,
+        # limit_traversals or add_random_noise: the outputs carry no config hash)
         if osp.exists(out_path) and not args.get("overwrite", False):
             continue
         traversals = valid_idx[origin_idx][2]
         assert len(traversals) > 1, origin_idx
         first_seq, first_indices = traversals[0]
         first_pose, first_l2e = poses[first_seq][first_indices[0]], l2es[first_seq][first_indices[0]]
-        hist, offsets = assemble_history(cache, track_list, poses, l2es, traversals, first_pose, first_l2e, K,
-                                         bool(args.nusc))
-        if dp.load_precomputed_lidars is not None:
-            host = hist.cpu().numpy()
-            combined = {s: host[offsets[i]:offsets[i + 1]] for i, (s, _) in enumerate(traversals)}
-            pickle.dump(combined, open(osp.join(dp.load_precomputed_lidars, f"{origin_idx:06d}.pkl"), "wb"))
         origin_seq, origin_frame = valid_idx[origin_idx][0], valid_idx[origin_idx][1]
-        trans_mat = get_relative_pose(first_l2e, first_pose, l2es[origin_seq][origin_frame],
-                                      poses[origin_seq][origin_frame], K)
+        live_id = track_list[origin_seq][origin_frame]
+        # history frames of the scan (:132-150): file ids and traversal index
+        hist_ids, travs = [], []
+        for t, (seq_id, indices) in enumerate(traversals):
+            for frame in indices:
+                hist_ids.append(track_list[seq_id][frame])
+                travs.append(t)
+        loader.ensure(hist_ids + [live_id])
+        rels = relative_poses(first_l2e, first_pose, np.stack([world[i] for i in hist_ids + [live_id]]), K)
+        trans_mat = rels[-1]
         if dp.load_save_precomputed_trans_mat is not None:
             np.save(osp.join(dp.load_save_precomputed_trans_mat, f"{origin_idx:06d}.npy"), trans_mat)
+        if dp.load_precomputed_lidars is not None:   # (:152-155) dump of the stacked, transformed history
+            combined = {}
+            for t, (sq, _) in enumerate(traversals):
+                parts = [ops.transform_points(store.frames[hist_ids[k]].original_order(), rels[k],
+                                              remove_center=bool(args.nusc)).cpu().numpy()
+                         for k, tt in enumerate(travs) if tt == t]
+                combined[sq] = np.concatenate(parts) if parts else np.zeros((0, 3), np.float32)
+            pickle.dump(combined, open(osp.join(dp.load_precomputed_lidars, f"{origin_idx:06d}.pkl"), "wb"))
         if args.skip_ephe:
             continue
-        live = ops.transform_points(cache.get(track_list[origin_seq][origin_frame]), trans_mat)
-        if args.add_random_noise > 0:            # (:175-179) host draw, same numpy expressions
+        n_trav = len(traversals)
+        if args.limit_traversals > 1:   # (:181-186)
+            n_trav = min(n_trav, int(args.limit_traversals))
+        keep = [k for k, t in enumerate(travs) if t < n_trav]
+        hist = [(hist_ids[k], travs[k]) for k in keep]
+        if args.add_random_noise > 0:            # (:175-179) host draw, same numpy expressions; stacked path
             noise = np.random.randn(3)
             noise /= np.linalg.norm(noise)
             noise *= (args.add_random_noise * np.random.uniform())
-            live_np = live.cpu().numpy()
+            live_np = ops.transform_points(store.frames[live_id].original_order(), trans_mat).cpu().numpy()
             live_np += noise.reshape(-1, 3)
-            live = torch.from_numpy(live_np).to(device)
-        if args.limit_traversals > 1:
-            offsets = offsets[: int(args.limit_traversals) + 1]
-        H = ops.pp_score(live, hist, offsets, float(args.max_neighbor_dist))
-        np.save(osp.join(dp.pp_score_path, f"{origin_idx:06d}"), H.cpu().numpy())
+            parts = [[] for _ in range(n_trav)]
+            for k in keep:
+                parts[travs[k]].append(ops.transform_points(store.frames[hist_ids[k]].xyz, rels[k],
+                                                            remove_center=bool(args.nusc)))
+            offsets = np.cumsum([0] + [sum(int(q.shape[0]) for q in tp) for tp in parts]).astype(np.int64)
+            H = ops.pp_score(torch.from_numpy(live_np).to(device), torch.cat([q for tp in parts for q in tp]),
+                             offsets, radius)
+        else:
+            A44 = first_pose.astype(np.float64) @ np.asarray(first_l2e, dtype=np.float64) @ K
+            H = store.pp_score(live_id, trans_mat, hist, rels[keep], A44, n_trav, remove_center=bool(args.nusc))
+        save_npy_atomic(out_path, H.cpu().numpy())
         done += 1
-        pts += int(offsets[-1])
+        pts += int(sum(store.frames[i].n for i, _ in hist))
     torch.cuda.synchronize()
     dist.barrier()
     tot = dist.reduce_counters(dict(scans=done, hist_points=pts, max_seconds=time.perf_counter() - t0))
     if rank == 0:
-        eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame cache %d hits / %d misses"
+        eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame store %d hits / %d misses"
                % (tot["scans"], tot["hist_points"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9),
-                  ws, cache.hits, cache.misses))
+                  ws, store.hits, store.misses))
     return tot
 
 

@@ -246,7 +246,7 @@ CALIB_TXT = (
 
 def write_kitti_tree(root: str, meta: str, n_seq: int = 3, n_frames: int = 12, n_pts: int = 8000,
                      nusc: bool = False, world_seed: int = 0, origins: Tuple[int, ...] = (2,),
-                     hist_frames: int = 8) -> Dict[str, str]:
+                     hist_frames: int = 8, max_range: float = 60.0) -> Dict[str, str]:
     """Tiny KITTI-format tree + MODEST meta data (track list, valid idx info,
     idx list) for CLI tests: sequence 0 holds the live scans (with mobile
     objects), sequences 1.. are the historical traversals.
@@ -267,7 +267,7 @@ def write_kitti_tree(root: str, meta: str, n_seq: int = 3, n_frames: int = 12, n
             yaw = 0.01 * s
             pose = _pose_matrix(ex, lat, yaw)
             mob = make_mobiles(s * 100 + f, ex, 8) if (s == 0 and f in origins) else None
-            raw = sample_frame(world, 50_000 + 1000 * s + f, n_pts, pose, l2e, nusc, mob, max_range=60.0)
+            raw = sample_frame(world, 50_000 + 1000 * s + f, n_pts, pose, l2e, nusc, mob, max_range=max_range)
             raw.tofile(os.path.join(train, "velodyne", f"{idx:06d}.bin"))
             with open(os.path.join(train, "oxts", f"{idx:06d}.txt"), "w") as fh:
                 fh.write(f"{ex!r} {lat!r} 0.0 0.0 0.0 {yaw!r}")

@@ -187,8 +187,9 @@ def test_bench_contract_json_line(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "2", "--procs", "2", "--scans", "1",
-           "--cpu-scans", "1", "--n-live", "8000", "--traversals", "3", "--frames", "6"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--procs", "2", "--scans", "2",
+           "--cpu-scans", "1", "--cpu-best-effort", "2", "--cli-scans", "3", "--n-live", "8000", "--traversals", "3",
+           "--frames", "6"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -197,14 +198,19 @@ def test_bench_contract_json_line(gpu):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["unit"] == "scans/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and d["value"] > 0
     assert abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000.0
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["launches_timed"] == 12 and rf["isolated"]["kernel_ms"] > 0
+    assert rf["launches_timed"] == 16 and rf["isolated"]["kernel_ms"] > 0
+    assert d["config"]["host_processes_per_gpu"] == 2 and d["config"]["rccl_world_size"] == 1
+    assert d["config"]["history_input"].startswith("frame store")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
-    assert d["parity"]["pp_counts_equal"] is True
+    assert cb["best_effort"]["value"] > 0
+    assert d["parity"]["pp_counts_equal"] is True and d["parity"]["labels_equal"] is True
+    assert d["parity"]["label_text_equal"] is True
+    assert d["cli"]["label_files"] == 3 and d["cli"]["pp_scans_per_s"] > 0 and d["cli"]["mask_scans_per_s"] > 0
