@@ -73,7 +73,7 @@ def parse(argv=None):
                          "reference's own total_part/part split does by hand).  1 = everything in the rank process.")
     ap.add_argument("--streams", type=int, default=1,
                     help="scans in flight per host process: threads, each with its own HIP stream and modest_ctx")
-    ap.add_argument("--cli-scans", type=int, default=48,
+    ap.add_argument("--cli-scans", type=int, default=192,
                     help="live scans of the CLI measurement (0 = skip): the three product CLIs on a synthetic KITTI "
                          "tree, 10 history traversals x 36 frames per scan, frames shared between consecutive scans")
     return ap.parse_args(argv)
@@ -318,9 +318,10 @@ def cli_bench(a, local):
     """The three product CLIs on a synthetic KITTI tree shaped like a Lyft shard: one live sequence
     and 10 history sequences, 36 history frames per traversal per scan, consecutive live scans share
     35 of them.  Everything is included: .bin reads, upload + tile sort of new frames, batched pose
-    solves, kernels, .npy/.pkl/.txt writes."""
+    solves, kernels, .npy/.pkl/.txt writes.  Every CLI runs twice: one process, and `workers=N`
+    (N child processes on the GPU; their own loop clocks, i.e. without interpreter start-up)."""
     from modest_amd import gen_label_files, generate_mask, pre_compute_pp_score, synth
-    n_scan, F, T = int(a.cli_scans), int(a.frames), int(a.traversals)
+    n_scan, F, T, W = int(a.cli_scans), int(a.frames), int(a.traversals), max(2, int(a.procs))
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     out = {}
     with tempfile.TemporaryDirectory(dir=base) as root:
@@ -329,31 +330,41 @@ def cli_bench(a, local):
                                        n_frames=n_scan + F, n_pts=a.n_live, origins=tuple(range(n_scan)),
                                        hist_frames=F, max_range=80.0)
         out["tree_seconds"] = time.perf_counter() - t0
-        common = [f"data_root={root}/kitti/training", f"data_paths.track_path={paths['track_path']}",
-                  f"data_paths.idx_info={paths['idx_info']}", f"data_paths.idx_list={paths['idx_list']}",
-                  f"data_paths.pp_score_path={root}/pp", f"device={local}"]
-        t0 = time.perf_counter()
-        pre_compute_pp_score.main(argv=common)
-        torch.cuda.synchronize()
-        out["pp_scans_per_s"] = n_scan / (time.perf_counter() - t0)
-        margs = [common[0], f"data_paths.idx_list={paths['idx_list']}", f"data_paths.pp_score_path={root}/pp",
-                 f"data_paths.seg_save_dst={root}/seg", f"data_paths.bbox_info_save_dst={root}/bbox"]
-        t0 = time.perf_counter()
-        generate_mask.main(argv=margs)
-        torch.cuda.synchronize()
-        out["mask_scans_per_s"] = n_scan / (time.perf_counter() - t0)
-        largs = [common[0], f"data_paths.idx_list={paths['idx_list']}", f"data_paths.bbox_info_save_dst={root}/bbox",
-                 f"data_paths.label_file_save_dst={root}/labels"]
-        t0 = time.perf_counter()
-        gen_label_files.main(argv=largs)
-        out["label_scans_per_s"] = n_scan / (time.perf_counter() - t0)
+        data = f"data_root={root}/kitti/training"
+        idx = f"data_paths.idx_list={paths['idx_list']}"
+
+        def pp(tag, workers):
+            tot = pre_compute_pp_score.main(argv=[data, f"data_paths.track_path={paths['track_path']}",
+                                                  f"data_paths.idx_info={paths['idx_info']}", idx,
+                                                  f"data_paths.pp_score_path={root}/pp{tag}", f"device={local}",
+                                                  f"workers={workers}"])
+            return tot["scans"] / tot.get("max_worker_seconds", tot["max_seconds"])
+
+        def mask(tag, workers):
+            tot = generate_mask.main(argv=[data, idx, f"data_paths.pp_score_path={root}/pp1",
+                                           f"data_paths.seg_save_dst={root}/seg{tag}",
+                                           f"data_paths.bbox_info_save_dst={root}/bbox{tag}", f"device={local}",
+                                           f"workers={workers}"])
+            return tot["scans"] / tot.get("max_worker_seconds", tot["max_seconds"])
+
+        out["pp_scans_per_s"] = pp("1", 1)
+        out["mask_scans_per_s"] = mask("1", 1)
+        tot = gen_label_files.main(argv=[data, idx, f"data_paths.bbox_info_save_dst={root}/bbox1",
+                                         f"data_paths.label_file_save_dst={root}/labels", f"device={local}"])
+        out["label_scans_per_s"] = tot["scans"] / tot["max_seconds"]
         out["pipeline_scans_per_s"] = 1.0 / (1.0 / out["pp_scans_per_s"] + 1.0 / out["mask_scans_per_s"]
                                              + 1.0 / out["label_scans_per_s"])
         out["label_files"] = len([f for f in os.listdir(f"{root}/labels") if f.endswith(".txt")])
+        out["workers"] = W
+        out["pp_scans_per_s_workers"] = pp("W", W)
+        out["mask_scans_per_s_workers"] = mask("W", W)
+        same = all(open(f"{root}/seg1/{f}", "rb").read() == open(f"{root}/segW/{f}", "rb").read()
+                   for f in os.listdir(f"{root}/seg1") if f.endswith(".npy"))
+        out["workers_outputs_identical"] = bool(same)
     out["scans"] = n_scan
-    out["note"] = (f"{n_scan} live scans x {T} traversals x {F} frames of {a.n_live} points; one process, one GPU; "
-                   "tree on " + (base or "the default tmp dir") + "; every stage timed cold (its first scan uploads and "
-                   "sorts all 361 frames, later scans 11 new ones)")
+    out["note"] = (f"{n_scan} live scans x {T} traversals x {F} frames of {a.n_live} points, one GPU, tree on "
+                   + (base or "the default tmp dir") + "; cold: the first scan of a process uploads and sorts all 361 "
+                   "frames, later scans 11 new ones; *_workers: max over the workers' own loop clocks")
     return out
 
 

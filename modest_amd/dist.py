@@ -40,15 +40,73 @@ def init(backend: Optional[str] = None) -> tuple:
 
 
 def shard(idx_list, total_part: int = 1, part: int = 0, rank: Optional[int] = None, ws: Optional[int] = None):
-    """The reference's manual ``total_part/part`` split, then the per-rank split."""
+    """The reference's manual ``total_part/part`` split, then the per-rank split, then -- inside a
+    worker process of a rank (``workers=N``, see run_workers) -- the per-worker split.  All three
+    are contiguous ``np.array_split`` pieces: consecutive scans share history frames."""
     idx_list = np.asarray(idx_list)
     if total_part > 1:
         idx_list = np.array_split(idx_list, total_part)[part]
     if rank is None or ws is None:
         rank, ws, _ = world()
+        if "MODEST_PARENT_WS" in os.environ:   # worker process: the rank split of its parent
+            rank, ws = int(os.environ["MODEST_PARENT_RANK"]), int(os.environ["MODEST_PARENT_WS"])
     if ws > 1:
         idx_list = np.array_split(idx_list, ws)[rank]
+    w = os.environ.get("MODEST_WORKER")
+    if w:
+        wp, wt = (int(x) for x in w.split("/"))
+        idx_list = np.array_split(idx_list, wt)[wp]
     return idx_list
+
+
+def run_workers(module: str, cfg, rank: int, ws: int, local: int) -> Optional[Dict[str, float]]:
+    """``workers=N`` of the CLIs: the host side of a scan (Python + ~60 HIP calls + blocking round
+    trips) saturates one process long before the GPU, which is why the reference is run as several
+    ``total_part/part`` jobs by hand (generate_mask.py:33-37).  Here a rank does that itself: N
+    child processes on the rank's GPU, each taking a contiguous piece of the rank's shard and
+    writing its own output files.  Returns the summed counters of the children (None when this
+    process should do the work itself: workers <= 1, or it IS a worker)."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    from . import config as _config
+    n = int(cfg.get("workers", 1) or 1)
+    if n <= 1 or os.environ.get("MODEST_WORKER"):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        cpath = os.path.join(d, "cfg.yaml")
+        c2 = _config.ConfigNode(cfg.to_container(resolve=True))
+        c2["workers"] = 1
+        c2["device"] = local if ws > 1 else int(cfg.get("device", 0))
+        _config.save(c2, cpath, resolve=False)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(MODEST_PARENT_RANK=str(rank), MODEST_PARENT_WS=str(ws))
+        procs = []
+        for w in range(n):
+            e = dict(env, MODEST_WORKER=f"{w}/{n}", MODEST_WORKER_RESULT=os.path.join(d, f"w{w}.json"))
+            procs.append(subprocess.Popen([sys.executable, "-m", "modest_amd.dist", module, cpath], env=e))
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise RuntimeError(f"{module}: worker processes failed with exit codes {rcs}")
+        tot: Dict[str, float] = {}
+        for w in range(n):
+            for k, v in json.load(open(os.path.join(d, f"w{w}.json"))).items():
+                tot[k] = max(tot.get(k, 0.0), v) if k.startswith("max_") else tot.get(k, 0.0) + v
+    return tot
+
+
+def _worker_entry() -> None:
+    """``python -m modest_amd.dist <module> <config.yaml>``: one worker of run_workers."""
+    import importlib
+    import json
+    import sys
+    import yaml
+    module, cpath = sys.argv[1], sys.argv[2]
+    cfg = yaml.safe_load(open(cpath))
+    tot = importlib.import_module(module).main(cfg)
+    with open(os.environ["MODEST_WORKER_RESULT"], "w") as f:
+        json.dump({k: float(v) for k, v in (tot or {}).items()}, f)
 
 
 def barrier() -> None:
@@ -98,3 +156,7 @@ class StageTimer:
 
     def stop(self):
         self.t[self._name] = self.t.get(self._name, 0.0) + time.perf_counter() - self._t0
+
+
+if __name__ == "__main__":
+    _worker_entry()

@@ -42,6 +42,22 @@ def gen_label_scan(objs, calib, args):
     return objs2label(objs, calib), objs
 
 
+def _pooled(args, rank, ws, local):
+    """workers=N: N child processes on this rank's GPU (dist.run_workers), same barrier + counter
+    all-reduce around them as around the in-process loop."""
+    dist.barrier()
+    t0 = time.perf_counter()
+    tot = dist.run_workers("modest_amd.gen_label_files", args, rank, ws, local)
+    dist.barrier()
+    tot["max_worker_seconds"] = tot.get("max_seconds", 0.0)   # the workers' own loop clocks (no start-up)
+    tot["max_seconds"] = time.perf_counter() - t0
+    tot = dist.reduce_counters(tot)
+    if rank == 0:
+        eprint("[gen_label_files] %d scans, %.2f s, %.2f scans/s on %d GPU(s) x %d worker processes"
+               % (tot["scans"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9), ws, int(args.workers)))
+    return tot
+
+
 @config.main(config_name="generate_label_files.yaml")
 def main(args):
     rank, ws, local = dist.init()
@@ -52,6 +68,8 @@ def main(args):
     idx_list = np.array([int(x) for x in open(dp.idx_list).readlines()])
     shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
     os.makedirs(dp.label_file_save_dst, exist_ok=True)
+    if int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER"):
+        return _pooled(args, rank, ws, local)
     t0, done = time.perf_counter(), 0
     dist.barrier()
     for idx in shard:

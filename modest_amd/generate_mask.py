@@ -90,6 +90,22 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
 
 
+def _pooled(args, rank, ws, local):
+    """workers=N: N child processes on this rank's GPU (dist.run_workers), same barrier + counter
+    all-reduce around them as around the in-process loop."""
+    dist.barrier()
+    t0 = time.perf_counter()
+    tot = dist.run_workers("modest_amd.generate_mask", args, rank, ws, local)
+    dist.barrier()
+    tot["max_worker_seconds"] = tot.get("max_seconds", 0.0)   # the workers' own loop clocks (no start-up)
+    tot["max_seconds"] = time.perf_counter() - t0
+    tot = dist.reduce_counters(tot)
+    if rank == 0:
+        eprint("[generate_mask] %d scans, %.2f s, %.2f scans/s on %d GPU(s) x %d worker processes"
+               % (tot["scans"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9), ws, int(args.workers)))
+    return tot
+
+
 @config.main(config_name="generate_mask.yaml")
 def main(args):
     rank, ws, local = dist.init()
@@ -97,6 +113,7 @@ def main(args):
         display_args(args)
     torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))
     dp = args.data_paths
+    pooled = int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER")
     idx_list = np.array([int(x) for x in open(dp.idx_list).readlines()])
     shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
     os.makedirs(dp.seg_save_dst, exist_ok=True)
@@ -107,6 +124,8 @@ def main(args):
         os.makedirs(bbox_dst, exist_ok=True)
         if rank == 0 and not osp.exists(osp.join(bbox_dst, "configs.yaml")):
             config.save(config=args, f=osp.join(bbox_dst, "configs.yaml"))
+    if pooled:
+        return _pooled(args, rank, ws, local)
     seed = int(args.get("ransac_seed", 0))
     t0, done = time.perf_counter(), 0
     dist.barrier()

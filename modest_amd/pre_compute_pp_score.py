@@ -123,6 +123,22 @@ def display_args(args):
     eprint("=======================================")
 
 
+def _pooled(args, rank, ws, local):
+    """workers=N: N child processes on this rank's GPU (dist.run_workers), same barrier + counter
+    all-reduce around them as around the in-process loop."""
+    dist.barrier()
+    t0 = time.perf_counter()
+    tot = dist.run_workers("modest_amd.pre_compute_pp_score", args, rank, ws, local)
+    dist.barrier()
+    tot["max_worker_seconds"] = tot.get("max_seconds", 0.0)   # the workers' own loop clocks (no start-up)
+    tot["max_seconds"] = time.perf_counter() - t0
+    tot = dist.reduce_counters(tot)
+    if rank == 0:
+        eprint("[pp_score] %d scans, %.2f s, %.2f scans/s on %d GPU(s) x %d worker processes"
+               % (tot["scans"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9), ws, int(args.workers)))
+    return tot
+
+
 @config.main(config_name="pp_score.yaml")
 def main(args):
     rank, ws, local = dist.init()
@@ -131,6 +147,9 @@ def main(args):
     device = torch.device("cuda", local if ws > 1 else int(args.get("device", 0)))
     torch.cuda.set_device(device)
     dp = args.data_paths
+    if int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER"):
+        os.makedirs(dp.pp_score_path, exist_ok=True)
+        return _pooled(args, rank, ws, local)
     track_list = pickle.load(open(dp.track_path, "rb"))
     valid_idx = pickle.load(open(dp.idx_info, "rb"))
     os.makedirs(dp.pp_score_path, exist_ok=True)

@@ -36,3 +36,22 @@ def test_two_ranks_gloo(tmp_path):
         assert outs[k]["shard2"] == [int(x) for x in np.array_split(np.array_split(idx, 3)[1], 2)[k]]
         assert outs[k]["tot"]["scans"] == 37 and outs[k]["tot"]["hist_points"] == 3000
         assert outs[k]["tot"]["max_seconds"] == 1.5
+
+
+def test_worker_split_env(monkeypatch):
+    """workers=N: a worker process takes a contiguous piece of its parent rank's shard; the pieces of
+    all workers of all ranks partition the list in order."""
+    from modest_amd import dist
+    idx = np.arange(200, 263)
+    pieces = []
+    for r in range(2):
+        for w in range(3):
+            monkeypatch.setenv("MODEST_PARENT_RANK", str(r))
+            monkeypatch.setenv("MODEST_PARENT_WS", "2")
+            monkeypatch.setenv("MODEST_WORKER", f"{w}/3")
+            pieces.append(dist.shard(idx, 1, 0))
+    assert np.array_equal(np.concatenate(pieces), idx)
+    monkeypatch.delenv("MODEST_WORKER")
+    monkeypatch.delenv("MODEST_PARENT_RANK")
+    monkeypatch.delenv("MODEST_PARENT_WS")
+    assert np.array_equal(dist.shard(idx, 1, 0), idx)
