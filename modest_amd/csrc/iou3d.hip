@@ -12,7 +12,7 @@
 // pair in an LDS column; the NMS mask kernel also stages its 64 column boxes in LDS.
 #include "common.h"
 #include "trig_f32.h"
-#include <vector>
+#include <cmath>
 #include <cstring>
 
 namespace {
@@ -81,17 +81,16 @@ struct PolyLds {
     float x[POLY_MAX][NMS_TPB], y[POLY_MAX][NMS_TPB], ang[POLY_MAX][NMS_TPB];
 };
 
-__device__ float box_overlap(const float *a, const float *b, PolyLds &L) {
+// ta / tb = (cos h, sin h, cos(-h), sin(-h)) of the two headings
+__device__ float box_overlap(const float *a, const float *b, const float4 ta, const float4 tb, PolyLds &L) {
     const int ln = threadIdx.x & (NMS_TPB - 1);
-    const float a_ang = a[6], b_ang = b[6];
     const float a_dxh = a[3] / 2, b_dxh = b[3] / 2, a_dyh = a[4] / 2, b_dyh = b[4] / 2;
     const float ax1 = a[0] - a_dxh, ay1 = a[1] - a_dyh, ax2 = a[0] + a_dxh, ay2 = a[1] + a_dyh;
     const float bx1 = b[0] - b_dxh, by1 = b[1] - b_dyh, bx2 = b[0] + b_dxh, by2 = b[1] + b_dyh;
     const Pt ca{a[0], a[1]}, cb{b[0], b[1]};
     Pt A[5] = {{ax1, ay1}, {ax2, ay1}, {ax2, ay2}, {ax1, ay2}, {0, 0}};
     Pt B[5] = {{bx1, by1}, {bx2, by1}, {bx2, by2}, {bx1, by2}, {0, 0}};
-    const float a_cos = modest::cos_f32(a_ang), a_sin = modest::sin_f32(a_ang);
-    const float b_cos = modest::cos_f32(b_ang), b_sin = modest::sin_f32(b_ang);
+    const float a_cos = ta.x, a_sin = ta.y, b_cos = tb.x, b_sin = tb.y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         rot_center(ca, a_cos, a_sin, A[k]);
@@ -114,8 +113,7 @@ __device__ float box_overlap(const float *a, const float *b, PolyLds &L) {
             }
         }
     // the containment tests rotate by the opposite angle: cos(-h), sin(-h)
-    const float a_ncos = modest::cos_f32(-a_ang), a_nsin = modest::sin_f32(-a_ang);
-    const float b_ncos = modest::cos_f32(-b_ang), b_nsin = modest::sin_f32(-b_ang);
+    const float a_ncos = ta.z, a_nsin = ta.w, b_ncos = tb.z, b_nsin = tb.w;
     for (int k = 0; k < 4; ++k) {
         if (in_box2d(a, a_ncos, a_nsin, B[k])) {
             center.x = center.x + B[k].x;
@@ -160,10 +158,15 @@ __device__ float box_overlap(const float *a, const float *b, PolyLds &L) {
     return fabsf(area) / 2.0f;
 }
 
-__device__ __forceinline__ float iou_bev(const float *a, const float *b, PolyLds &L) {
+// trig of a heading evaluated on the device: float64 evaluation rounded once (trig_f32.h)
+__device__ __forceinline__ float4 device_trig(float h) {
+    return make_float4(modest::cos_f32(h), modest::sin_f32(h), modest::cos_f32(-h), modest::sin_f32(-h));
+}
+
+__device__ __forceinline__ float iou_bev(const float *a, const float *b, const float4 ta, const float4 tb, PolyLds &L) {
     const float sa = a[3] * a[4];
     const float sb = b[3] * b[4];
-    const float so = box_overlap(a, b, L);
+    const float so = box_overlap(a, b, ta, tb, L);
     return so / fmaxf(sa + sb - so, IOU_EPS);
 }
 
@@ -177,7 +180,10 @@ __device__ __forceinline__ float iou_normal(const float *a, const float *b) {
     return inter / fmaxf(sa + sb - inter, IOU_EPS);
 }
 
-template <bool IOU>
+// HOSTTRIG: rows of 11 floats, the box followed by cos h, sin h, cos(-h), sin(-h) evaluated by the
+// HOST's libm (modest_boxes_iou_bev_host: objs_nms orders boxes by float noise of their self-IoU,
+// SURVEY H6, so the label path uses the very cosf / sinf the reference's CPU path calls).
+template <bool IOU, bool HOSTTRIG>
 __global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__ A, int na,
                                                        const float *__restrict__ B, int nb,
                                                        float *__restrict__ out) {
@@ -185,42 +191,182 @@ __global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (long long)na * nb) return;
     const int ia = (int)(id / nb), ib = (int)(id % nb);
+    constexpr int STRIDE = HOSTTRIG ? 11 : 7;
     float a[7], b[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        a[k] = A[(size_t)ia * 7 + k];
-        b[k] = B[(size_t)ib * 7 + k];
+        a[k] = A[(size_t)ia * STRIDE + k];
+        b[k] = B[(size_t)ib * STRIDE + k];
     }
-    out[id] = IOU ? iou_bev(a, b, L) : box_overlap(a, b, L);
+    float4 ta, tb;
+    if (HOSTTRIG) {
+        const float *pa = A + (size_t)ia * STRIDE + 7, *pb = B + (size_t)ib * STRIDE + 7;
+        ta = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        tb = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    } else {
+        ta = device_trig(a[6]);
+        tb = device_trig(b[6]);
+    }
+    out[id] = IOU ? iou_bev(a, b, ta, tb, L) : box_overlap(a, b, ta, tb, L);
 }
 
-// 64x64 tile suppression words (src/iou3d_nms_kernel.cu:267-311, :328-372).
+// ---- NMS over score-sorted boxes (semantics: src/iou3d_nms.cpp:90-136, nms_gpu / nms_normal_gpu) ----
+// Built for detector scale (thousands of boxes) on this chip, not the reference's structure:
+//   nms_trig      heading -> (cos, sin, cos(-h), sin(-h)) once per box (the pair tests reuse them);
+//   nms_tiles     UPPER-TRIANGULAR grid of 64 x 64 tiles (linear tile id -> (row block, column block
+//                 >= row block): no launched-then-exited blocks), one wavefront per tile, the 64 column
+//                 boxes and their trig in LDS; bit j of word (i, cb) = box i suppresses box 64 cb + j;
+//   nms_reduce    ONE wavefront walks the sorted order on the device, 64 boxes at a time: the 64
+//                 diagonal words of the block sit in the lanes and the in-block chain is resolved with
+//                 cross-lane reads (no memory in the loop); the words of the surviving rows are then
+//                 OR-ed into the running `removed` words of all later blocks, one lane per column block,
+//                 all row loads in flight together.  The keep list and its length are written straight
+//                 into pinned host memory: nothing of size n^2/64 ever crosses PCIe, the host does no
+//                 reduction.
+__global__ void nms_trig(const float *__restrict__ boxes, int n, float4 *__restrict__ trig) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) trig[i] = device_trig(boxes[(size_t)i * 7 + 6]);
+}
+
 template <bool ROTATED>
-__global__ __launch_bounds__(NMS_TPB) void nms_mask_kernel(int n, float thresh,
-                                                           const float *__restrict__ boxes,
-                                                           unsigned long long *__restrict__ mask) {
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
-    const int row_size = min(n - row_start * NMS_TPB, NMS_TPB);
-    const int col_size = min(n - col_start * NMS_TPB, NMS_TPB);
+__global__ __launch_bounds__(NMS_TPB) void nms_tiles(int n, int cb, float thresh, const float *__restrict__ boxes,
+                                                     const float4 *__restrict__ trig,
+                                                     unsigned long long *__restrict__ mask) {
+    // linear id over the upper triangle, row by row: row r holds cb - r tiles
+    const long long t = blockIdx.x;
+    int r = (int)(((2.0 * cb + 1.0) - sqrt((2.0 * cb + 1.0) * (2.0 * cb + 1.0) - 8.0 * (double)t)) * 0.5);
+    auto first = [&](int rr) { return (long long)rr * cb - (long long)rr * (rr - 1) / 2; };
+    while (r > 0 && first(r) > t) --r;
+    while (first(r + 1) <= t) ++r;
+    const int c = r + (int)(t - first(r));
     __shared__ float sb[NMS_TPB * 7];
+    __shared__ float4 st[NMS_TPB];
     __shared__ PolyLds L;
-    if ((int)threadIdx.x < col_size)
-        for (int k = 0; k < 7; ++k)
-            sb[threadIdx.x * 7 + k] = boxes[(size_t)(NMS_TPB * col_start + threadIdx.x) * 7 + k];
-    __syncthreads();
-    if ((int)threadIdx.x < row_size) {
-        const int cur = NMS_TPB * row_start + threadIdx.x;
-        float c[7];
-        for (int k = 0; k < 7; ++k) c[k] = boxes[(size_t)cur * 7 + k];
-        unsigned long long t = 0;
-        int start = (row_start == col_start) ? threadIdx.x + 1 : 0;
-        for (int i = start; i < col_size; ++i) {
-            const float v = ROTATED ? iou_bev(c, sb + i * 7, L) : iou_normal(c, sb + i * 7);
-            if (v > thresh) t |= 1ULL << i;
-        }
-        const int col_blocks = (n + NMS_TPB - 1) / NMS_TPB;
-        mask[(size_t)cur * col_blocks + col_start] = t;
+    const int lane = threadIdx.x;
+    const int col_size = min(n - c * NMS_TPB, NMS_TPB);
+    if (lane < col_size) {
+        for (int k = 0; k < 7; ++k) sb[lane * 7 + k] = boxes[(size_t)(NMS_TPB * c + lane) * 7 + k];
+        if (ROTATED) st[lane] = trig[NMS_TPB * c + lane];
     }
+    __syncthreads();
+    const int cur = NMS_TPB * r + lane;
+    if (cur >= n) return;
+    float bx[7];
+    for (int k = 0; k < 7; ++k) bx[k] = boxes[(size_t)cur * 7 + k];
+    const float4 tc = ROTATED ? trig[cur] : make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long w = 0;
+    for (int i = (r == c) ? lane + 1 : 0; i < col_size; ++i) {
+        const float v = ROTATED ? iou_bev(bx, sb + i * 7, tc, st[i], L) : iou_normal(bx, sb + i * 7);
+        if (v > thresh) w |= 1ULL << i;
+    }
+    mask[(size_t)cur * cb + c] = w;
+}
+
+__global__ __launch_bounds__(NMS_TPB) void nms_reduce(int n, int cb, const unsigned long long *__restrict__ mask,
+                                                      long long *__restrict__ keep, int *__restrict__ num_keep) {
+    extern __shared__ unsigned long long removed[];   // cb running suppression words
+    const int lane = threadIdx.x;
+    for (int c = lane; c < cb; c += NMS_TPB) removed[c] = 0ULL;
+    __syncthreads();
+    int kept = 0;
+    for (int b = 0; b < cb; ++b) {
+        const int row = b * NMS_TPB + lane;
+        // suppression inside the block: lane i holds the diagonal word of row i (bits j > i only)
+        const unsigned long long diag = row < n ? mask[(size_t)row * cb + b] : 0ULL;
+        unsigned long long dead = removed[b];   // written by this wavefront in earlier iterations
+        const int rows = min(n - b * NMS_TPB, NMS_TPB);
+        if (rows < NMS_TPB) dead |= ~0ULL << rows;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        for (int i = 0; i < rows; ++i) {
+            if (!((dead >> i) & 1ULL)) {
+                const unsigned lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
+                dead |= ((unsigned long long)hi << 32) | lo;
+            }
+        }
+        const unsigned long long alive = ~dead & (rows < NMS_TPB ? ((1ULL << rows) - 1ULL) : ~0ULL);
+        // keep list (ascending) and the suppression of all later blocks by the surviving rows
+        if ((alive >> lane) & 1ULL) keep[kept + __popcll(alive & ((1ULL << lane) - 1ULL))] = row;
+        kept += __popcll(alive);
+        for (int c0 = b + 1; c0 < cb; c0 += NMS_TPB) {
+            const int c = c0 + lane;
+            unsigned long long acc = 0;
+            if (c < cb) {
+                unsigned long long m = alive;
+                while (m) {   // the loads of all surviving rows are independent: one latency, not 64
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    acc |= mask[(size_t)(b * NMS_TPB + i) * cb + c];
+                }
+                removed[c] |= acc;
+            }
+        }
+        __syncthreads();   // `removed` is re-read by other lanes in the next iteration
+    }
+    if (lane == 0) *num_keep = kept;
+}
+
+// The same reduction for up to 4096 boxes (cb <= 64), four wavefronts: the words of block b+1's 64
+// rows are fetched into registers by all 256 threads while wavefront 0 resolves block b from the
+// slab that already sits in LDS, then parked in the other half of the LDS double buffer -- the
+// global latency of a block is hidden behind the previous block's chain.
+constexpr int NMS_RT = 256;
+__global__ __launch_bounds__(NMS_RT) void nms_reduce_lds(int n, int cb, const unsigned long long *__restrict__ mask,
+                                                         long long *__restrict__ keep, int *__restrict__ num_keep) {
+    __shared__ unsigned long long slab[2][NMS_TPB * NMS_TPB];   // [row in block][column block]
+    __shared__ unsigned long long removed[NMS_TPB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int PER = NMS_TPB * NMS_TPB / NMS_RT;   // 16 words per thread
+    if (tid < NMS_TPB) removed[tid] = 0ULL;
+    unsigned long long pre[PER];
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + k * NMS_RT, r = e / NMS_TPB, c = e % NMS_TPB;
+            const int row = b * NMS_TPB + r;
+            pre[k] = (b < cb && row < n && c >= b && c < cb) ? mask[(size_t)row * cb + c] : 0ULL;
+        }
+    };
+    auto park = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) slab[b & 1][tid + k * NMS_RT] = pre[k];
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    int kept = 0;
+    for (int b = 0; b < cb; ++b) {
+        fetch(b + 1);   // in flight during the chain below
+        if (tid < NMS_TPB) {
+            const unsigned long long *S = slab[b & 1];
+            const int row = b * NMS_TPB + lane;
+            const unsigned long long diag = S[lane * NMS_TPB + b];
+            unsigned long long dead = removed[b];
+            const int rows = min(n - b * NMS_TPB, NMS_TPB);
+            if (rows < NMS_TPB) dead |= ~0ULL << rows;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            for (int i = 0; i < rows; ++i) {
+                if (!((dead >> i) & 1ULL)) {
+                    const unsigned lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
+                    dead |= ((unsigned long long)hi << 32) | lo;
+                }
+            }
+            const unsigned long long alive = ~dead & (rows < NMS_TPB ? ((1ULL << rows) - 1ULL) : ~0ULL);
+            if ((alive >> lane) & 1ULL) keep[kept + __popcll(alive & ((1ULL << lane) - 1ULL))] = row;
+            kept += __popcll(alive);
+            if (lane > b && lane < cb) {   // lane = later column block
+                unsigned long long acc = 0, m = alive;
+                while (m) {
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    acc |= S[i * NMS_TPB + lane];
+                }
+                removed[lane] |= acc;
+            }
+        }
+        park(b + 1);
+        __syncthreads();
+    }
+    if (tid == 0) *num_keep = kept;
 }
 
 int pair_launch(bool iou, const float *a, int na, const float *b, int nb, float *out, void *stream) {
@@ -230,9 +376,9 @@ int pair_launch(bool iou, const float *a, int na, const float *b, int nb, float 
     const long long total = (long long)na * nb;
     const int blocks = (int)((total + NMS_TPB - 1) / NMS_TPB);
     if (iou)
-        pair_kernel<true><<<blocks, NMS_TPB, 0, as_stream(stream)>>>(a, na, b, nb, out);
+        pair_kernel<true, false><<<blocks, NMS_TPB, 0, as_stream(stream)>>>(a, na, b, nb, out);
     else
-        pair_kernel<false><<<blocks, NMS_TPB, 0, as_stream(stream)>>>(a, na, b, nb, out);
+        pair_kernel<false, false><<<blocks, NMS_TPB, 0, as_stream(stream)>>>(a, na, b, nb, out);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
@@ -249,31 +395,30 @@ int nms_impl(bool rotated, modest_ctx *ctx, const float *boxes, int n, float thr
     hipStream_t stream = as_stream(stream_);
     const int cb = (n + NMS_TPB - 1) / NMS_TPB;
     const size_t words = (size_t)n * cb;
-    int rc = modest_ctx_reserve(ctx, arena_sz(words * 8));
+    MODEST_REQUIRE(cb <= 6144, "at most 393216 boxes (the running suppression words live in LDS)");
+    const size_t trigB = arena_sz((size_t)n * 16), maskB = arena_sz(words * 8);
+    int rc = modest_ctx_reserve(ctx, trigB + maskB);
     if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, words * 8);
+    rc = modest_ctx_reserve_pinned(ctx, (size_t)n * 8 + 64);
     if (rc) return rc;
-    unsigned long long *dmask = reinterpret_cast<unsigned long long *>(ctx->scratch);
-    unsigned long long *hmask = reinterpret_cast<unsigned long long *>(ctx->pinned);
-    dim3 grid(cb, cb);
-    if (rotated)
-        nms_mask_kernel<true><<<grid, NMS_TPB, 0, stream>>>(n, thresh, boxes, dmask);
-    else
-        nms_mask_kernel<false><<<grid, NMS_TPB, 0, stream>>>(n, thresh, boxes, dmask);
-    MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(hmask, dmask, words * 8, hipMemcpyDeviceToHost, stream));
-    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-    // sequential reduction over the sorted boxes (src/iou3d_nms.cpp:116-133)
-    std::vector<unsigned long long> remv(cb, 0ULL);
-    int kept = 0;
-    for (int i = 0; i < n; ++i) {
-        const int nblock = i / NMS_TPB, inblock = i % NMS_TPB;
-        if (!(remv[nblock] & (1ULL << inblock))) {
-            keep[kept++] = i;
-            const unsigned long long *p = hmask + (size_t)i * cb;
-            for (int j = nblock; j < cb; ++j) remv[j] |= p[j];
-        }
+    float4 *trig = reinterpret_cast<float4 *>(ctx->scratch);
+    unsigned long long *dmask = reinterpret_cast<unsigned long long *>(ctx->scratch + trigB);
+    int *hcount = reinterpret_cast<int *>(ctx->pinned);
+    long long *hkeep = reinterpret_cast<long long *>(ctx->pinned + 64);
+    const long long tiles = (long long)cb * (cb + 1) / 2;
+    MODEST_REQUIRE(tiles < (1LL << 31), "too many boxes");
+    if (rotated) {
+        nms_trig<<<(n + 255) / 256, 256, 0, stream>>>(boxes, n, trig);
+        nms_tiles<true><<<(unsigned)tiles, NMS_TPB, 0, stream>>>(n, cb, thresh, boxes, trig, dmask);
+    } else {
+        nms_tiles<false><<<(unsigned)tiles, NMS_TPB, 0, stream>>>(n, cb, thresh, boxes, trig, dmask);
     }
+    if (cb <= NMS_TPB) nms_reduce_lds<<<1, NMS_RT, 0, stream>>>(n, cb, dmask, hkeep, hcount);
+    else nms_reduce<<<1, NMS_TPB, (size_t)cb * 8, stream>>>(n, cb, dmask, hkeep, hcount);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    const int kept = *hcount;
+    for (int i = 0; i < kept; ++i) keep[i] = hkeep[i];
     *num_keep = kept;
     return MODEST_OK;
 }
@@ -307,19 +452,36 @@ extern "C" int modest_boxes_iou_bev_host(modest_ctx *ctx, const float *a_host, i
     if (na == 0 || nb == 0) return MODEST_OK;
     MODEST_REQUIRE(a_host && b_host && out_host, "NULL buffer");
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    // The boxes are staged in the context's pinned block and the kernel reads them and writes the
+    // The boxes are staged in the context's pinned block -- each followed by cos / sin of its heading
+    // evaluated HERE, by the host's libm: objs_nms ranks boxes by the float noise of their self-IoU
+    // (pointcloud_utils.py:335-336), so the label path must use the cosf / sinf the reference's CPU
+    // path (iou3d_cpu.cpp:128-133) calls, not the device's -- and the kernel reads them and writes the
     // matrix there directly (a few hundred bytes each way): one launch, one stream sync, no copies.
-    const size_t ba = arena_sz((size_t)na * 28), bb = arena_sz((size_t)nb * 28);
+    const size_t ba = arena_sz((size_t)na * 44), bb = arena_sz((size_t)nb * 44);
     const size_t bo = arena_sz((size_t)na * nb * 4);
     int rc = modest_ctx_reserve_pinned(ctx, ba + bb + bo);
     if (rc) return rc;
     float *pa = reinterpret_cast<float *>(ctx->pinned);
     float *pb = reinterpret_cast<float *>(ctx->pinned + ba);
     float *pout = reinterpret_cast<float *>(ctx->pinned + ba + bb);
-    memcpy(pa, a_host, (size_t)na * 28);
-    memcpy(pb, b_host, (size_t)nb * 28);
-    rc = pair_launch(true, pa, na, pb, nb, pout, stream_);
-    if (rc) return rc;
+    auto stage = [](float *dst, const float *src, int n) {
+        for (int i = 0; i < n; ++i) {
+            float *d = dst + (size_t)i * 11;
+            memcpy(d, src + (size_t)i * 7, 28);
+            const float h = d[6];
+            d[7] = cosf(h);
+            d[8] = sinf(h);
+            d[9] = cosf(-h);
+            d[10] = sinf(-h);
+        }
+    };
+    stage(pa, a_host, na);
+    stage(pb, b_host, nb);
+    {
+        const long long total = (long long)na * nb;
+        pair_kernel<true, true><<<(int)((total + NMS_TPB - 1) / NMS_TPB), NMS_TPB, 0, as_stream(stream_)>>>(pa, na, pb, nb, pout);
+        MODEST_HIP_CHECK(hipGetLastError());
+    }
     MODEST_HIP_CHECK(hipStreamSynchronize(as_stream(stream_)));
     memcpy(out_host, pout, (size_t)na * nb * 4);
     return MODEST_OK;
