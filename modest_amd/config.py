@@ -206,8 +206,16 @@ def compose(config_name: str, overrides: Optional[List[str]] = None, config_dir:
         else:
             merged[k] = v
     for ov in rest:
-        if ov.startswith("~"):
-            _set_dotted(merged, ov[1:], None, must_exist=False)
+        if ov.startswith("~"):            # Hydra: delete the key
+            node, parts = merged, ov[1:].split("=")[0].split(".")
+            for part in parts[:-1]:
+                node = node.get(part) if isinstance(node, dict) else None
+                if node is None:
+                    break
+            if isinstance(node, dict) and parts[-1] in node:
+                del node[parts[-1]]
+            else:
+                raise KeyError(f"Could not delete '{ov[1:]}': no such key in the config")
             continue
         if "=" not in ov:
             raise ValueError(f"cannot parse override '{ov}' (expected key=value)")

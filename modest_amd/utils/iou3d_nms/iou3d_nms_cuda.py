@@ -5,7 +5,7 @@ libmodest_hip.so.  The reference prints and ``exit(-1)``s on bad input
 (``src/iou3d_nms.cpp:14-26``); here a ``RuntimeError`` is raised instead.
 
 To make the MODEST / OpenPCDet sources pick this module up unchanged, put
-``modest_amd/utils/iou3d_nms`` on ``sys.path`` (or ``import modest_amd.compat``),
+``modest_amd/utils/iou3d_nms`` on ``sys.path``,
 see INTEGRATION.md.
 """
 import ctypes as _C

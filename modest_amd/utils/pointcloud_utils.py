@@ -243,7 +243,7 @@ def get_lowest_point_rect(ptc, xz_center, l, w, ry):
     return get_lowest_points_rect(to_device(ptc, torch.float64), [xz_center], [l], [w], [ry])[0]
 
 
-def get_objs(clusters_rect: List[np.ndarray], full_ptc, fit_method="closeness_to_edge"):
+def get_objs(clusters_rect: List[np.ndarray], full_ptc, fit_method="min_zx_area_fit"):
     """Batched get_obj (:292-317) for a scan: boxes of all clusters.
     clusters_rect: list of (n_c,3) float64 rect-frame points; full_ptc (N,3) float64."""
     fitters = {"closeness_to_edge": closeness_rectangles, "variance_to_edge": variance_rectangles,
@@ -272,7 +272,7 @@ def get_objs(clusters_rect: List[np.ndarray], full_ptc, fit_method="closeness_to
     return objs
 
 
-def get_obj(ptc, full_ptc, fit_method="closeness_to_edge"):
+def get_obj(ptc, full_ptc, fit_method="min_zx_area_fit"):
     """(:292-317) single-cluster form."""
     return get_objs([np.asarray(ptc, dtype=np.float64)], full_ptc, fit_method)[0]
 

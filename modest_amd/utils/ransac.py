@@ -29,6 +29,7 @@ from sklearn.utils import check_random_state
 from sklearn.utils.random import sample_without_replacement
 
 from .. import ops
+from .._lib import ModestHipError
 
 _EPSILON = np.spacing(1)
 
@@ -160,7 +161,19 @@ def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, s
     if best_model is None:
         raise ValueError("RANSAC could not find a valid consensus set. All `max_trials` iterations were "
                          "skipped because each randomly chosen sub-sample failed the passing criteria.")
-    model64, n_final = ops.ransac_refit(cand, best_model, thr, ctx=ctx)
+    try:
+        model64, n_final = ops.ransac_refit(cand, best_model, thr, ctx=ctx)
+    except ModestHipError:
+        # degenerate consensus set (fewer than 3 points, or a singular normal matrix): the device refit
+        # reports it instead of dividing by zero.  sklearn's LinearRegression returns the minimum-norm
+        # least-squares fit there; do the same on the host (scalar work, once in a blue moon).
+        pts = cand.cpu().numpy().astype(np.float32)
+        pred = (pts[:, 1] * best_model[1] + pts[:, 0] * best_model[0]) + best_model[2]
+        inl = np.abs(pts[:, 2] - pred) <= np.float32(thr)
+        X, z = pts[inl, :2].astype(np.float64), pts[inl, 2].astype(np.float64)
+        xm, zm = X.mean(axis=0), z.mean()
+        coef = np.linalg.lstsq(X - xm, z - zm, rcond=None)[0]
+        model64, n_final = np.array([coef[0], coef[1], zm - xm @ coef]), int(inl.sum())
     res = RansacResult()
     res.coef = model64[:2].astype(np.float32)          # LinearRegression on float32 data stores float32
     res.intercept = np.float32(model64[2])

@@ -6,7 +6,7 @@
  * reference's order, glibc cosf/sinf/atan2f.  Build with -ffp-contract=off
  * (oracle/Makefile).  Validated against the reference's own iou3d_cpu.cpp
  * compiled where it lies (oracle/build_ref.py -> oracle/_ref/iou3d_ref.so) and
- * against tests/golden/boxes_iou.npz in tests/test_oracle_iou.py.
+ * against tests/golden/boxes_iou.npz in tests/test_oracle_mask.py (test_iou_oracle_*).
  */
 #include <math.h>
 #include <stdint.h>

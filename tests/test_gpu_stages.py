@@ -242,7 +242,7 @@ def test_filter_and_boxes(gpu, ms):
     fits = pcu.closeness_rectangles([c[:, [0, 2]] for c in clusters])
     for (corners, angle, area), f in zip(fits, ms["fits"]):
         assert angle == f[0] and area == f[1] and np.array_equal(corners.ravel(), f[2:10])
-    objs = pcu.get_objs(clusters, rect)
+    objs = pcu.get_objs(clusters, rect, fit_method="closeness_to_edge")
     got = np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs])
     assert np.array_equal(got, ms["fits"][:, 10:18])
     # beta table vs the oracle's numpy loop on one cluster (pairwise summation order)

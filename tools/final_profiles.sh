@@ -3,23 +3,23 @@
 cd $GRAFT_REPO_ROOT
 F=gpurun_out/final; rm -rf $F; mkdir -p $F
 line() { grep '^{"metric"' | tail -1; }
-python bench.py --cpu-scans 0 > /dev/null 2>&1   # warm the box (clocks, page cache)
+python bench.py --cpu-scans 0 --cli-scans 0 > /dev/null 2>&1   # warm the box (clocks, page cache)
 python bench.py 2>/dev/null | line > $F/bench_full.json
-python bench.py --cpu-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_full_1proc.json
-python bench.py --pp-only --cpu-scans 0 2>/dev/null | line > $F/bench_pp_only.json
-python bench.py --pp-only --cpu-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_pp_only_1stream.json
+python bench.py --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_full_1proc.json
+python bench.py --pp-only --cpu-scans 0 --cli-scans 0 2>/dev/null | line > $F/bench_pp_only.json
+python bench.py --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_pp_only_1stream.json
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # the default command: rank process + helper processes, one output set per process, merged
 rm -rf gpurun_out/prof_default
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_default -o bench_%pid% -- python bench.py --cpu-scans 0 > gpurun_out/prof_default.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_default -o bench_%pid% -- python bench.py --cpu-scans 0 --cli-scans 0 > gpurun_out/prof_default.log 2>&1
 python tools/merge_kstats.py $F/bench_full_kernel_stats.csv $(ls gpurun_out/prof_default/*kernel_stats.csv)
 rm -f gpurun_out/prof_default/*kernel_trace.csv
 # one scan at a time: clean per-kernel durations
 rm -rf gpurun_out/prof_single
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_single -o bench -- python bench.py --cpu-scans 0 --procs 1 --streams 1 --steps 64 > gpurun_out/prof_single.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_single -o bench -- python bench.py --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 --steps 64 > gpurun_out/prof_single.log 2>&1
 cp gpurun_out/prof_single/bench_kernel_stats.csv $F/bench_full_1proc_kernel_stats.csv
 rm -rf gpurun_out/prof_pp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pp -o bench -- python bench.py --pp-only --cpu-scans 0 --procs 1 --streams 1 --steps 16 --warmup 2 > gpurun_out/prof_pp.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pp -o bench -- python bench.py --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 --steps 16 --warmup 2 > gpurun_out/prof_pp.log 2>&1
 cp gpurun_out/prof_pp/bench_kernel_stats.csv $F/pp_only_kernel_stats.csv
 rm -f gpurun_out/prof_single/*kernel_trace.csv gpurun_out/prof_pp/*kernel_trace.csv
 bash tools/pp_pmc.sh > $F/pp_pmc.log 2>&1

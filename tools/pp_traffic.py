@@ -1,7 +1,7 @@
 """HBM bytes per scan of the PP stage from the PMC passes of tools/pp_pmc.sh (gpurun_out/pp_pmc.json):
 FETCH_SIZE / WRITE_SIZE are reported in KiB per launch; both are calibrated on pp3_stream<count>,
 whose traffic is known (it reads the 12-byte history points once and writes its count matrix).
-Writes gpurun_out/pp_traffic.json (copied to profiles/r01_pp_traffic.json, which bench.py reads)."""
+Writes gpurun_out/pp_traffic.json (copied to profiles/r02_pp_traffic.json, which bench.py reads)."""
 import json
 
 M, N_WG, N_LIST = 10_800_000, 512, 7168
@@ -9,7 +9,7 @@ d = json.load(open("gpurun_out/pp_pmc.json"))
 per_scan = {k: (2 if "fillBuffer" in k else 1) for k in d}      # launches per scan
 fetch = sum(v.get("FETCH_SIZE", 0.0) * 1024 * per_scan[k] for k, v in d.items())
 write = sum(v.get("WRITE_SIZE", 0.0) * 1024 * per_scan[k] for k, v in d.items())
-cnt = [v for k, v in d.items() if "pp3_stream<false>" in k][0]
+cnt = [v for k, v in d.items() if "pp3_stream<false" in k][0]
 f_fac = (12.0 * M + 28 * 1024) / (cnt["FETCH_SIZE"] * 1024)
 w_fac = (N_WG * N_LIST * 4.0) / (cnt["WRITE_SIZE"] * 1024)
 out = {
@@ -18,7 +18,7 @@ out = {
     "fetch_raw_bytes_per_scan": fetch,
     "write_raw_bytes_per_scan": write,
     "fetch_calibration": {
-        "kernel": "pp3_stream<false> reads 12 B x 10.8 M points + 28 KB of tables with 16-byte coalesced loads",
+        "kernel": "pp3_stream<count> reads 12 B x 10.8 M points (frame store, through the descriptor table) + 28 KB of tables with 16-byte coalesced loads",
         "factor": f_fac,
         "note": "MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read on gfx950 -> doubled",
     },
