@@ -63,6 +63,7 @@ struct SortJob {
     float *xyz;
     unsigned *perm;
     unsigned *tab;
+    int *n_inside;   // one word per job, contiguous: read back with a single copy
 };
 
 __device__ __forceinline__ int frame_bin(const Map24 &W, float x, float y, float z, int TX0, int TY0) {
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(1024) void frame_sort_kernel(const SortJob *__restr
         if (b <= F_NTILE) {
             hist[b] = run;
             J.tab[b] = run;   // tab[F_NTILE] = points inside the table = start of the outliers
+            if (b == F_NTILE) *J.n_inside = (int)run;
         }
         run += loc[k];
     }
@@ -1043,7 +1045,7 @@ extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *j
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     static_assert(sizeof(SortJob) % 8 == 0, "job layout");
-    int rc = modest_ctx_reserve(ctx, arena_sz((size_t)n_jobs * sizeof(SortJob)));
+    int rc = modest_ctx_reserve(ctx, arena_sz((size_t)n_jobs * sizeof(SortJob)) + arena_sz((size_t)n_jobs * 4));
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, (size_t)n_jobs * (sizeof(SortJob) + 4));
     if (rc) return rc;
@@ -1064,6 +1066,7 @@ extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *j
         hj[k].xyz = j.xyz_dev;
         hj[k].perm = j.perm_dev;
         hj[k].tab = j.tab_dev;
+        hj[k].n_inside = reinterpret_cast<int *>(ctx->scratch + arena_sz((size_t)n_jobs * sizeof(SortJob))) + k;
     }
     SortJob *dj = reinterpret_cast<SortJob *>(ctx->scratch);
     MODEST_HIP_CHECK(hipMemcpyAsync(dj, hj, (size_t)n_jobs * sizeof(SortJob), hipMemcpyHostToDevice, stream));
@@ -1076,8 +1079,8 @@ extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *j
     }
     frame_sort_kernel<<<n_jobs, 1024, lds, stream>>>(dj);
     MODEST_HIP_CHECK(hipGetLastError());
-    for (int k = 0; k < n_jobs; ++k)
-        MODEST_HIP_CHECK(hipMemcpyAsync(&hin[k], jobs[k].tab_dev + F_NTILE, 4, hipMemcpyDeviceToHost, stream));
+    MODEST_HIP_CHECK(hipMemcpyAsync(hin, ctx->scratch + arena_sz((size_t)n_jobs * sizeof(SortJob)), (size_t)n_jobs * 4,
+                                    hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     if (n_inside_host)
         for (int k = 0; k < n_jobs; ++k) n_inside_host[k] = hin[k];
