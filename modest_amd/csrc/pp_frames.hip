@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void pp5_live_index(const float *__restrict__ 
                                                       Mat34f rel, Map24 A, float4 *__restrict__ sorted,
                                                       uint2 *__restrict__ cellPk,
                                                       unsigned long long *__restrict__ tileOcc,
+                                                      uint4 *__restrict__ tileEdge /* 2 per tile, non-empty tiles */,
                                                       int *__restrict__ counts, size_t nCounts,
                                                       unsigned *__restrict__ ctrl) {
     __shared__ unsigned hist[F_NC];
@@ -203,6 +204,22 @@ __global__ __launch_bounds__(256) void pp5_live_index(const float *__restrict__ 
             hist[tid] = inc - c0;
             const unsigned long long occ = __ballot(c0 != 0u);
             if (tid == 0) tileOcc[tile] = occ;
+            // live points on the tile's border: what the 10x10-cell windows of the neighbours see
+            // (top row, bottom row, left column, right column; corners 00, 70, 07, 77)
+            const int kx = tid & 7, ky = tid >> 3;
+            unsigned e0 = ky == 0 ? c0 : 0u, e1 = ky == 7 ? c0 : 0u, e2 = kx == 0 ? c0 : 0u, e3 = kx == 7 ? c0 : 0u;
+            for (int o = 32; o > 0; o >>= 1) {
+                e0 += __shfl_xor(e0, o);
+                e1 += __shfl_xor(e1, o);
+                e2 += __shfl_xor(e2, o);
+                e3 += __shfl_xor(e3, o);
+            }
+            const unsigned k00 = __builtin_amdgcn_readlane(c0, 0), k70 = __builtin_amdgcn_readlane(c0, 7);
+            const unsigned k07 = __builtin_amdgcn_readlane(c0, 56), k77 = __builtin_amdgcn_readlane(c0, 63);
+            if (tid == 0) {
+                tileEdge[2 * (size_t)tile] = make_uint4(e0, e1, e2, e3);
+                tileEdge[2 * (size_t)tile + 1] = make_uint4(k00, k70, k07, k77);
+            }
         }
         __syncthreads();
         for (unsigned base = a; base < b; base += 256) {
@@ -232,11 +249,13 @@ __global__ __launch_bounds__(256) void pp5_live_index(const float *__restrict__ 
 //   ctrl[8 + s] heavy items of shard s, ctrl[8 + PL_SHARDS + s] light items; shard = tile % PL_SHARDS;
 //   shard s owns items[s * shardCap ...).
 constexpr int PL_T = 256;
+constexpr int W_CAP = 128;   // live points a single wavefront keeps in its LDS slice (wave path)
 constexpr int PL_ITEMS_PER_TILE = 128;   // >= 33 point cuts + (frames / fmax) frame cuts
 constexpr unsigned PL_SHARD_CAP = (unsigned)(F_NTILE / PL_SHARDS) * PL_ITEMS_PER_TILE;
 __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ frames, int nFrames,
                                                  const unsigned *__restrict__ ltab, int LTX0, int LTY0,
-                                                 const unsigned long long *__restrict__ tileOcc, unsigned pmax,
+                                                 const unsigned long long *__restrict__ tileOcc,
+                                                 const uint4 *__restrict__ tileEdge, unsigned pmax, unsigned wmax,
                                                  unsigned heavy, int fmax, uint2 *__restrict__ runs,
                                                  uint4 *__restrict__ itemsH, uint4 *__restrict__ itemsL,
                                                  unsigned *__restrict__ tileTotal, unsigned *__restrict__ ctrl) {
@@ -265,6 +284,28 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
         if (yy < 0 || yy >= F_NTF) continue;
         const int xa = max(tx - 1, 0), xb = min(tx + 1, F_NTF - 1);
         wt += ltab[yy * F_NTF + xb + 1] - ltab[yy * F_NTF + xa];
+    }
+    // exact number of live points in the 10x10-cell window (own tile + the neighbours' border cells)
+    unsigned wlive = ltab[t + 1] - ltab[t];
+    {
+        auto edge = [&](int x, int y, int which) -> unsigned {
+            if (x < 0 || x >= F_NTF || y < 0 || y >= F_NTF) return 0u;
+            const int tt = y * F_NTF + x;
+            if (!tileOcc[tt]) return 0u;
+            const uint4 a = tileEdge[2 * (size_t)tt], b = tileEdge[2 * (size_t)tt + 1];
+            switch (which) {
+                case 0: return a.x;   // top row (ky = 0)
+                case 1: return a.y;   // bottom row (ky = 7)
+                case 2: return a.z;   // left column
+                case 3: return a.w;   // right column
+                case 4: return b.x;   // cell (0,0)
+                case 5: return b.y;   // cell (7,0)
+                case 6: return b.z;   // cell (0,7)
+                default: return b.w;  // cell (7,7)
+            }
+        };
+        wlive += edge(tx, ty - 1, 1) + edge(tx, ty + 1, 0) + edge(tx - 1, ty, 3) + edge(tx + 1, ty, 2) +
+                 edge(tx - 1, ty - 1, 7) + edge(tx + 1, ty - 1, 6) + edge(tx - 1, ty + 1, 5) + edge(tx + 1, ty + 1, 4);
     }
     const int gtx = LTX0 + tx, gty = LTY0 + ty;
     const int per = (nFrames + PL_T - 1) / PL_T;
@@ -310,10 +351,20 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
     if (total == 0) return;   // uniform
     // cuts: a new item starts at frame f when the points before it cross a multiple of `step`, or
     // at every multiple of fmax frames
+    // wmax == 0: every tile is a workgroup item, tiles with many points first.  wmax > 0 (wave path):
+    // class H = tiles whose window holds more than W_CAP live points (workgroup kernel), class L = the
+    // rest, cut into items of about wmax points for single wavefronts.
     unsigned step = pmax;
-    if (wt > heavy) step = max(pmax / min((wt + heavy - 1) / heavy, 8u), 256u);
+    bool hv;
+    if (wmax == 0) {
+        if (wt > heavy) step = max(pmax / min((wt + heavy - 1) / heavy, 8u), 256u);
+        hv = total >= 2 * pmax;
+    } else {
+        hv = wlive > (unsigned)W_CAP;
+        if (hv) step = max(pmax / min((wlive + heavy - 1) / heavy, 8u), 256u);
+        else step = wmax;
+    }
     step = max(step, (total + 31) / 32);
-    const bool hv = total >= 2 * pmax;
     unsigned nc = 0;
     for (int f = max(fa, 1); f < fb; ++f) nc += (pre[f] / step != pre[f - 1] / step) || (f % fmax == 0);
     unsigned cinc = nc;
@@ -426,7 +477,7 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
                                                const unsigned *__restrict__ ltab, int LTX0, int LTY0,
                                                const uint2 *__restrict__ cellPk, const float4 *__restrict__ sorted,
                                                Map24 A, int *counts, int T, double r2, unsigned ldsBytes,
-                                               unsigned long long *stats) {
+                                               unsigned long long *stats, int nShards) {
     using C = JoinCfg<JT, RPT, CAP, FMAX, FCH>;
     extern __shared__ __align__(16) unsigned char dynsm[];
     __shared__ JoinS5 S;
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
     const float r2f = (float)r2, bandw = (float)(r2 * 1.5e-6);
     __shared__ unsigned shardEnd[2 * PL_SHARDS];   // inclusive prefix of the shard counters, heavy shards first
     if (tid < 64) {
-        const unsigned c0 = tid < 2 * PL_SHARDS ? min(ctrl[8 + tid], PL_SHARD_CAP) : 0u;
+        const unsigned c0 = tid < nShards ? min(ctrl[8 + tid], PL_SHARD_CAP) : 0u;   // nShards = PL_SHARDS: class H only
         unsigned inc = c0;
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned u = __shfl_up(inc, o);
@@ -457,7 +508,7 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
     }
     if (PROF && tid < 8) S.prof[tid] = 0;
     __syncthreads();
-    const unsigned nItems = shardEnd[2 * PL_SHARDS - 1];
+    const unsigned nItems = shardEnd[nShards - 1];
 #define PP5_TICK(k)                                     \
     if (PROF && tid == 0) {                              \
         const unsigned long long now_ = wall_clock64(); \
@@ -465,7 +516,7 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
         S.tlast = now_;                                  \
     }
     auto fetch_item = [&](unsigned id) -> uint4 {
-        int lo = 0, hi = 2 * PL_SHARDS - 1;   // first shard whose end exceeds id
+        int lo = 0, hi = nShards - 1;   // first shard whose end exceeds id
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (shardEnd[mid] > id) hi = mid;
@@ -985,6 +1036,254 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
 #undef PP5_TICK
 }
 
+// ---- wave-autonomous join (MODEST_PP_FRAMES_PATH=wave) ------------------------------------------
+// The workgroup-sized items of pp5_join are latency bound: chains of
+// dependent round trips fenced by workgroup barriers, 16 wavefronts per CU.  Here ONE wavefront owns
+// an item (a light tile x a frame range of about a thousand points) end to end: its live window
+// (<= W_CAP points) and counters sit in a private LDS slice, there is no workgroup barrier, every
+// wavefront of the chip works on its own item and their round trips overlap.
+//   lanes = frames for the run look-up (64 at a time; run, pointer and pose stay in registers),
+//   lanes = points for the gather (the owning frame's data comes through cross-lane reads),
+//   lanes = records for the pair tests (every lane walks its own candidate list in the LDS slice).
+constexpr int W_WAVES = 4;   // wavefronts per workgroup (they never synchronise with each other)
+__host__ __device__ __forceinline__ unsigned pp6_slice_bytes(int T) {
+    // live points + counters + cell counts (u16 [100]) + row tables (u16 [10][11], u32 [11]), 16-B multiple
+    return ((unsigned)W_CAP * pp5_live_bytes(T) + 200u + 220u + 44u + 15u) & ~15u;
+}
+
+__global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev *__restrict__ frames, int nFrames,
+                                                                const uint2 *__restrict__ runs,
+                                                                const uint4 *__restrict__ itemsL, unsigned *ctrl,
+                                                                const unsigned *__restrict__ ltab, int LTX0, int LTY0,
+                                                                const uint2 *__restrict__ cellPk,
+                                                                const float4 *__restrict__ sorted, Map24 A, int *counts,
+                                                                int T, double r2, unsigned sliceBytes) {
+    extern __shared__ __align__(16) unsigned char dynsm[];
+    __shared__ unsigned shardEnd[W_WAVES][PL_SHARDS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned char *slice = dynsm + (size_t)w * sliceBytes;
+    const int Th = (T + 1) >> 1;
+    float4 *live = reinterpret_cast<float4 *>(slice);
+    unsigned *cntw = reinterpret_cast<unsigned *>(slice + (size_t)W_CAP * 16);
+    unsigned short *ccnt = reinterpret_cast<unsigned short *>(slice + (size_t)W_CAP * pp5_live_bytes(T));
+    unsigned short *ctab = ccnt + 100;
+    unsigned *rowBase = reinterpret_cast<unsigned *>(ctab + 110);
+    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    {   // inclusive prefix of the light shards' item counts (per wavefront copy: no workgroup barrier)
+        const unsigned c0 = lane < PL_SHARDS ? min(ctrl[8 + PL_SHARDS + lane], PL_SHARD_CAP) : 0u;
+        unsigned inc = c0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane < PL_SHARDS) shardEnd[w][lane] = inc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned nItems = shardEnd[w][PL_SHARDS - 1];
+    for (;;) {
+        unsigned id = 0;
+        if (lane == 0) id = atomicAdd(&ctrl[5], 1u);
+        id = __builtin_amdgcn_readfirstlane(id);
+        if (id >= nItems) break;
+        int sh = 0;
+        while (shardEnd[w][sh] <= id) ++sh;
+        const uint4 it = itemsL[(size_t)sh * PL_SHARD_CAP + (id - (sh ? shardEnd[w][sh - 1] : 0u))];
+        const int ttx = (int)(it.x % F_NTF), tty = (int)(it.x / F_NTF);
+        const int gtx = LTX0 + ttx, gty = LTY0 + tty;
+        const int x0 = ttx * F_TS - 1, y0 = tty * F_TS - 1;
+        // ---- window: cell counts and starts (lane = window cell, two rounds), tables, live points
+        unsigned gst0 = 0, gst1 = 0;
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int e = lane + 64 * rnd;
+            unsigned c = 0, g = 0;
+            if (e < F_W * F_W) {
+                const int r = e / F_W, cc = e - r * F_W;
+                const int wx = x0 + cc, wy = y0 + r;
+                if (wx >= 0 && wy >= 0 && wx < F_NTF * F_TS && wy < F_NTF * F_TS) {
+                    const int tile = (wy >> 3) * F_NTF + (wx >> 3);
+                    const unsigned ta = ltab[tile], tb = ltab[tile + 1];
+                    if (tb > ta) {
+                        const uint2 pk = cellPk[(size_t)tile * F_NC + (wy & 7) * F_TS + (wx & 7)];
+                        c = pk.y;
+                        g = ta + pk.x;
+                    }
+                }
+                ccnt[e] = (unsigned short)c;
+            }
+            if (rnd == 0) gst0 = g;
+            else gst1 = g;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < F_W) {   // one lane per window row: positions inside the row
+            unsigned run = 0;
+            for (int cc = 0; cc < F_W; ++cc) {
+                ctab[lane * (F_W + 1) + cc] = (unsigned short)run;
+                run += ccnt[lane * F_W + cc];
+            }
+            ctab[lane * (F_W + 1) + F_W] = (unsigned short)run;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            unsigned run = 0;
+            for (int r = 0; r < F_W; ++r) {
+                rowBase[r] = run;
+                run += ctab[r * (F_W + 1) + F_W];
+            }
+            rowBase[F_W] = run;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned Lw = rowBase[F_W];   // <= W_CAP by the plan's exact window count
+        unsigned long long occ;
+        {
+            const int kx = lane & 7, ky = lane >> 3;
+            unsigned sOr = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) sOr |= ccnt[(ky + dy) * F_W + kx + dx];
+            occ = __ballot(sOr != 0u);
+        }
+        if (!occ || Lw > (unsigned)W_CAP) continue;   // (the second cannot happen)
+        // live points -> LDS, one lane per point; the global starts of the window cells travel through
+        // the (still unused) counter area
+        if (lane < F_W * F_W) cntw[lane] = gst0;
+        if (lane + 64 < F_W * F_W) cntw[lane + 64] = gst1;
+        __builtin_amdgcn_wave_barrier();
+        float4 lv[(W_CAP + 63) / 64];
+#pragma unroll
+        for (int k = 0; k < (W_CAP + 63) / 64; ++k) {
+            const unsigned e = lane + 64 * k;
+            lv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Lw) {
+                int r = 0;
+                while (e >= rowBase[r + 1]) ++r;
+                const unsigned pos = e - rowBase[r];
+                const unsigned short *rw = ctab + r * (F_W + 1);
+                int cc = 0;
+                while (pos >= rw[cc + 1]) ++cc;
+                lv[k] = sorted[cntw[r * F_W + cc] + (pos - rw[cc])];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < (W_CAP + 63) / 64; ++k)
+            if (lane + 64u * k < Lw) live[lane + 64 * k] = lv[k];
+        for (unsigned e = lane; e < Lw * Th; e += 64) cntw[e] = 0;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- frames, 64 at a time
+        const int f0 = (int)it.y, f1 = (int)it.z;
+        unsigned sinceFlush = 0;
+        auto flush = [&](bool clear) {
+            for (unsigned e = lane; e < Lw * Th; e += 64) {
+                const unsigned cw = cntw[e];
+                if (cw) {
+                    const unsigned p = e / Th, tp = (e - p * Th) * 2;
+                    const size_t rowi = (size_t)__float_as_int(live[p].w) * T;
+                    if (cw & 0xffffu) atomicAdd(&counts[rowi + tp], (int)(cw & 0xffffu));
+                    if (cw >> 16) atomicAdd(&counts[rowi + tp + 1], (int)(cw >> 16));
+                    if (clear) cntw[e] = 0;
+                }
+            }
+        };
+        for (int c0 = f0; c0 < f1; c0 += 64) {
+            const int f = c0 + lane;
+            unsigned rstart = 0, rlen = 0, plo = 0, phi = 0;
+            int tf = 0;
+            float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0, m2 = m0;
+            if (f < f1) {
+                const uint2 rn = runs[(size_t)it.x * nFrames + f];
+                rstart = rn.x;
+                rlen = rn.y;
+                const float4 *q = reinterpret_cast<const float4 *>(frames + f);
+                const float4 h0 = q[0];
+                plo = __float_as_uint(h0.x);
+                phi = __float_as_uint(h0.y);
+                tf = __float_as_int(q[1].w);
+                m0 = q[2];
+                m1 = q[3];
+                m2 = q[4];
+            }
+            unsigned inc = rlen;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
+            const unsigned pre = inc - rlen;   // exclusive
+            const unsigned Pc = __builtin_amdgcn_readlane(inc, 63);
+            for (unsigned b0 = 0; b0 < Pc; b0 += 64) {
+                if (sinceFlush > 60000u) {   // 16-bit counters
+                    __builtin_amdgcn_wave_barrier();
+                    flush(true);
+                    __builtin_amdgcn_wave_barrier();
+                    sinceFlush = 0;
+                }
+                sinceFlush += 64;
+                const unsigned i = b0 + lane;
+                const bool valid = i < Pc;
+                int lo = 0;   // largest lane whose prefix <= i
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int cand = lo + step;
+                    const unsigned p = __shfl(pre, cand & 63);
+                    if (cand < 64 && p <= i) lo = cand;
+                }
+                const unsigned sPre = __shfl(pre, lo), sStart = __shfl(rstart, lo);
+                const unsigned sLo = __shfl(plo, lo), sHi = __shfl(phi, lo);
+                const int sTf = __shfl(tf, lo);
+                float rel[12];
+                rel[0] = __shfl(m0.x, lo); rel[1] = __shfl(m0.y, lo); rel[2] = __shfl(m0.z, lo); rel[3] = __shfl(m0.w, lo);
+                rel[4] = __shfl(m1.x, lo); rel[5] = __shfl(m1.y, lo); rel[6] = __shfl(m1.z, lo); rel[7] = __shfl(m1.w, lo);
+                rel[8] = __shfl(m2.x, lo); rel[9] = __shfl(m2.y, lo); rel[10] = __shfl(m2.z, lo); rel[11] = __shfl(m2.w, lo);
+                bool keep = false;
+                float hx = 0.f, hy = 0.f, hz = 0.f;
+                int key = 0;
+                if (valid) {
+                    const float *src = reinterpret_cast<const float *>(((unsigned long long)sHi << 32) | sLo) +
+                                       3 * (size_t)(sStart + (i - sPre));
+                    const float x = src[0], y = src[1], z = src[2];
+                    const bool drop = ((sTf >> 16) & F_FLAG_CENTER) && in_center_box(x, y);
+                    float o[3];
+                    rel_apply(rel, x, y, z, o);
+                    key = cell_in_tile(A, o[0], o[1], o[2], gtx, gty);
+                    keep = !drop && ((occ >> key) & 1ULL);
+                    hx = o[0];
+                    hy = o[1];
+                    hz = o[2];
+                }
+                if (!__any(keep)) continue;
+                // ---- pair tests: every lane walks the candidates of its record
+                const int lx = (key & (F_TS - 1)) + 1, ly = key / F_TS + 1;
+                const unsigned short *row = ctab + (ly - 1) * (F_W + 1) + lx - 1;
+                const unsigned c00 = row[0], c10 = row[F_W + 1], c20 = row[2 * (F_W + 1)];
+                const unsigned n0 = row[3] - c00, n1 = row[F_W + 4] - c10, n2 = row[2 * (F_W + 1) + 3] - c20;
+                const unsigned a0 = rowBase[ly - 1] + c00, n01 = n0 + n1, nAll = n01 + n2;
+                const unsigned b1 = rowBase[ly] + c10 - n0, b2 = rowBase[ly + 1] + c20 - n01;
+                const unsigned own = keep ? nAll : 0u;
+                const unsigned trv = (unsigned)sTf & 0xffffu;
+                const unsigned cword = trv >> 1, cinc = 1u << ((trv & 1u) * 16);
+                for (unsigned p0 = 0; __any(p0 < own); p0 += 2) {
+#pragma unroll
+                    for (unsigned u = 0; u < 2; ++u) {
+                        const unsigned p = p0 + u;
+                        const bool act = p < own;
+                        const unsigned ci = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
+                        const float4 q = live[ci];
+                        const float fx = q.x - hx, fy = q.y - hy, fz = q.z - hz;
+                        const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                        bool hit = act && d2 < r2lo;
+                        if (act && !hit && d2 <= r2hi) hit = pp_within(hx, hy, hz, q.x, q.y, q.z, r2);   // exact re-test
+                        if (hit) atomicAdd(&cntw[ci * Th + cword], cinc);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        flush(false);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // entropy of a count matrix (same arithmetic as pp_count.hip's kernel; duplicated so that the two
 // translation units stay independent)
 __device__ __forceinline__ double pp5_term(int c, double denom) {
@@ -1115,14 +1414,15 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
 
     const size_t shardItems = (size_t)PL_SHARDS * PL_SHARD_CAP;
     const bool fused = strcmp(path, "gather-fused") == 0;
+    const bool wave = strcmp(path, "gather-wave") == 0;   // dense tiles: fused workgroup kernel, the rest: one wavefront per item
     size_t totalPts = 0;
-    if (!fused)
+    if (!fused && !wave)
         for (int f = 0; f < n_frames; ++f) totalPts += (size_t)frames[f].n;
     MODEST_REQUIRE(totalPts < (1ULL << 31), "history must hold fewer than 2^31 points");
     MODEST_REQUIRE(n_frames < (1 << 15), "too many frames");
     const size_t descBytes = arena_sz((size_t)(n_frames > 0 ? n_frames : 1) * sizeof(FrameDev));
     size_t need = descBytes + arena_sz((size_t)N * 16) + arena_sz((size_t)F_NTILE * F_NC * 8) +
-                  arena_sz((size_t)F_NTILE * 8) + arena_sz(1024) + 2 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
+                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz(1024) + 2 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
                   arena_sz((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1) * 8) + 2 * arena_sz((size_t)F_NTILE * 4) +
                   arena_sz(shardItems * 2 * 4) + arena_sz((size_t)(totalPts + 1) * 16) +
                   arena_sz((size_t)N * T * 4);
@@ -1133,6 +1433,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     float4 *sorted = Ar.take<float4>(N);
     uint2 *cellPk = Ar.take<uint2>((size_t)F_NTILE * F_NC);
     unsigned long long *tileOcc = Ar.take<unsigned long long>(F_NTILE);
+    uint4 *tileEdge = Ar.take<uint4>((size_t)F_NTILE * 2);
     unsigned *ctrl = Ar.take<unsigned>(256);
     uint4 *itemsH = Ar.take<uint4>(shardItems);
     uint4 *itemsL = Ar.take<uint4>(shardItems);
@@ -1173,15 +1474,18 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
 
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of one scan
     pp5_live_index<<<F_NTILE / LI_TILES, 256, 0, stream>>>(live->xyz_dev, live_perm_dev, live->tab_dev, live->TX0,
-                                                           live->TY0, rel, A, sorted, cellPk, tileOcc, counts,
+                                                           live->TY0, rel, A, sorted, cellPk, tileOcc, tileEdge, counts,
                                                            (size_t)N * T, ctrl);
     if (n_frames > 0) {
         const char *hv = getenv("MODEST_PP5_HEAVY");
         const unsigned heavy = hv ? (unsigned)atoi(hv) : 256u;
         const char *pm = getenv("MODEST_PP5_PMAX");
         const unsigned pmax = pm ? (unsigned)atoi(pm) : 6144u;
+        const char *wm = getenv("MODEST_PP6_WMAX");
+        const unsigned wmax = wm ? (unsigned)atoi(wm) : 1536u;
         pp5_plan<<<F_NTILE, PL_T, (size_t)(n_frames + 1) * 4, stream>>>(dframes, n_frames, live->tab_dev, live->TX0,
-                                                                        live->TY0, tileOcc, pmax, heavy, J_FMAX, runs,
+                                                                        live->TY0, tileOcc, tileEdge, pmax,
+                                                                        wave ? wmax : 0u, heavy, J_FMAX, runs,
                                                                         itemsH, itemsL, tileTotal, ctrl);
         const char *pe = getenv("MODEST_PP5_PROF");
         const bool prof = pe && atoi(pe);
@@ -1204,18 +1508,33 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
         if (prof) MODEST_HIP_CHECK(hipMemsetAsync(stats, 0, 64 * 8, stream));
 #define PP5_ARGS dframes, n_frames, runs, itemsH, itemsL, ctrl, tileBase, rec, itemSurv, live->tab_dev, live->TX0, \
                  live->TY0, cellPk, sorted, A, counts, T, r2
-        if (fused) {
+        if (fused || wave) {
             const int grid = 2 * ctx->num_cus;
-            if (prof) pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, true><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats);
-            else pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, false><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats);
+            const int nsh = wave ? PL_SHARDS : 2 * PL_SHARDS;   // wave path: the workgroup kernel takes class H only
+            if (prof) pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, true><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
+            else pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, false><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
+            if (wave) {
+                const unsigned slice = pp6_slice_bytes(T);
+                static bool wattr = false;
+                if (!wattr) {
+                    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
+                    wattr = true;
+                }
+                const char *wg = getenv("MODEST_PP6_WGS");
+                const int wgs = (wg ? atoi(wg) : 6) * ctx->num_cus;
+                pp6_wave_join<<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
+                    dframes, n_frames, runs, itemsL, ctrl, live->tab_dev, live->TX0, live->TY0, cellPk, sorted, A, counts, T,
+                    r2, slice);
+            }
         } else {
             pp5_tile_scan<<<1, 1024, 0, stream>>>(tileTotal, tileBase);
             const int ggrid = 8 * ctx->num_cus;
-            pp5_join<1, G_JT, G_RPT, 0, J_FMAX, J_FCH, false><<<ggrid, G_JT, G_LDS, stream>>>(PP5_ARGS, G_LDS, stats);
+            pp5_join<1, G_JT, G_RPT, 0, J_FMAX, J_FCH, false><<<ggrid, G_JT, G_LDS, stream>>>(PP5_ARGS, G_LDS, stats, 2 * PL_SHARDS);
             MODEST_HIP_CHECK(hipMemsetAsync(ctrl + 1, 0, 4, stream));   // dequeue head of the second pass
             const int grid = 2 * ctx->num_cus;
-            if (prof) pp5_join<2, K_JT, 1, K_CAP, 4, 4, true><<<grid, K_JT, K_LDS, stream>>>(PP5_ARGS, K_LDS, stats);
-            else pp5_join<2, K_JT, 1, K_CAP, 4, 4, false><<<grid, K_JT, K_LDS, stream>>>(PP5_ARGS, K_LDS, stats);
+            if (prof) pp5_join<2, K_JT, 1, K_CAP, 4, 4, true><<<grid, K_JT, K_LDS, stream>>>(PP5_ARGS, K_LDS, stats, 2 * PL_SHARDS);
+            else pp5_join<2, K_JT, 1, K_CAP, 4, 4, false><<<grid, K_JT, K_LDS, stream>>>(PP5_ARGS, K_LDS, stats, 2 * PL_SHARDS);
         }
 #undef PP5_ARGS
         if (prof) {
