@@ -48,7 +48,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-MIN_STEPS_PER_HELPER = 8   # a helper with 2-3 scans measures its start skew, not its throughput
+# A helper with 2-3 scans measures start skew, not throughput: a run with few steps uses fewer helpers
+# (the driver's 20-step run: 5 helpers x 4 steps) and reports the steady state of the full pool in
+# `steady_state`, measured after the contract region with its own barrier / synchronise bracket.
+MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "4"))
+STEADY_STEPS_PER_HELPER = 24
 
 
 def parse(argv=None):
@@ -249,17 +253,24 @@ def scan_seed(rank, slot, i):
     return 1000 * rank + 16 * slot + i
 
 
-def _helper_main(conn, a, rank, local, slot):
+def _helper_main(conn, a, rank, local, slot, flag):
     """entry point of a helper process (multiprocessing 'spawn'): pipe protocol
-    child -> ('ready', M) ; parent -> ('go', n_steps) ; child -> ('done', (seconds, kernel_ms)) ;
-    parent -> ('iso', None) -> child ('iso', ms) ; parent -> ('exit', None)"""
+    child -> ('ready', M) ; parent -> ('arm', (n_steps, generation)) ; child -> ('armed', None), then spins
+    on the shared start flag (all helpers leave the spin within microseconds of each other: a pipe
+    message per helper staggers them by ~0.1 ms each, which a 20-step run cannot afford) ;
+    child -> ('done', (seconds, kernel_ms)) ; parent -> ('iso', None) -> child ('iso', ms) ;
+    parent -> ('exit', None)"""
     try:
         r = Runner(a, rank, local, slot)
         conn.send(("ready", r.scans[0].M))
         while True:
             cmd, arg = conn.recv()
-            if cmd == "go":
-                dt, kms = r.timed(int(arg))
+            if cmd == "arm":
+                n, gen = arg
+                conn.send(("armed", None))
+                while flag.value != gen:
+                    pass
+                dt, kms = r.timed(int(n))
                 conn.send(("done", (dt, kms.tolist())))
             elif cmd == "iso":
                 conn.send(("iso", r.isolated_pp_ms()))
@@ -385,13 +396,16 @@ def main():
 
     helpers, note, M = [], None, None
     n_procs = helper_count(a.procs, a.steps)
-    if n_procs > 1:
+    n_pool = max(1, a.procs)
+    flag = None
+    if n_pool > 1:
         import multiprocessing as mp
         ctx = mp.get_context("spawn")
+        flag = ctx.Value("i", 0, lock=False)
         try:
-            for slot in range(n_procs):
+            for slot in range(n_pool):
                 pc, cc = ctx.Pipe()
-                p = ctx.Process(target=_helper_main, args=(cc, a, rank, local, slot), daemon=True)
+                p = ctx.Process(target=_helper_main, args=(cc, a, rank, local, slot, flag), daemon=True)
                 p.start()
                 helpers.append((p, pc))
             for p, pc in helpers:
@@ -411,30 +425,54 @@ def main():
                 p.join(5)
                 if p.is_alive():
                     p.terminate()
-            helpers, n_procs = [], 1
+            helpers, n_procs, n_pool = [], 1, 1
             a.streams = max(a.streams, 4)   # threads instead
     runner = Runner(a, rank, local, 0) if not helpers else None
+    generation = [0]
 
-    dist.barrier()
-    t0 = time.perf_counter()
-    if helpers:
-        shares = _split(a.steps, n_procs)
-        for (p, pc), n in zip(helpers, shares):
-            pc.send(("go", n))
-        kms = []
-        for p, pc in helpers:
+    def timed_region(active, shares):
+        """barrier + synchronise, the helpers run their shares, synchronise + barrier; rank wall clock"""
+        for (p, pc), n in zip(active, shares):
+            pc.send(("arm", (n, generation[0] + 1)))
+        for p, pc in active:
             tag, msg = pc.recv()
+            if tag != "armed":
+                raise RuntimeError(f"helper process failed: {msg}")
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        generation[0] += 1
+        flag.value = generation[0]          # every armed helper starts now
+        kms = []
+        for p, pc in active:
+            tag, msg = pc.recv()            # a helper synchronises its streams before it answers
             if tag != "done":
                 raise RuntimeError(f"helper process failed: {msg}")
             kms.append(np.asarray(msg[1], dtype=np.float32))
-        kernel_ms = np.concatenate(kms)
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter() - t0, np.concatenate(kms)
+
+    if helpers:
+        dt, kernel_ms = timed_region(helpers[:n_procs], _split(a.steps, n_procs))
     else:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
         _, kernel_ms = runner.timed(a.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
     red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
     dt_max, total_scans = red["max_seconds"], red["scans"]
+    steady = None
+    if helpers and n_procs < n_pool:   # few steps: also report the whole pool's steady state
+        n_ss = STEADY_STEPS_PER_HELPER * n_pool
+        dt_ss, _ = timed_region(helpers, _split(n_ss, n_pool))
+        red_ss = dist.reduce_counters(dict(max_seconds=dt_ss, scans=n_ss))
+        steady = {"value": red_ss["scans"] / red_ss["max_seconds"], "unit": "scans/s", "steps": n_ss,
+                  "host_processes_per_gpu": n_pool,
+                  "note": "same bracket (barrier + synchronise on both sides) as the contract region, run after it"}
 
     # the same stage with nothing else on the GPU (the timed region has several scans in flight, so its
     # event pairs also see the other scans' kernels): informational, not the reported `achieved`
@@ -557,7 +595,7 @@ def main():
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
                        "rccl_world_size": rccl_ws,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli, "steady_state": steady,
             "speedup_vs_cpu": (value / cpu_baseline["value"]) if cpu_baseline else None,
         }
         print(json.dumps(line), flush=True)

@@ -207,6 +207,7 @@ def test_bench_contract_json_line(gpu):
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["launches_timed"] == 16 and rf["isolated"]["kernel_ms"] > 0
     assert d["config"]["host_processes_per_gpu"] == 2 and d["config"]["rccl_world_size"] == 1
+    assert "steady_state" in d and d["steady_state"] is None   # 8 steps per helper: the pool was used whole
     assert d["config"]["history_input"].startswith("frame store")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
