@@ -70,3 +70,67 @@ def test_frame_sort_layout(gpu):
     ts = tile[perm]
     assert np.all(np.diff(ts) >= 0)
     assert np.array_equal(np.searchsorted(ts, np.arange(st.ntf * st.ntf + 1)), tab)
+
+
+def _rigid(rng, yaw_range=3.1, shift=20.0):
+    from scipy.spatial.transform import Rotation as R
+    t = np.eye(4)
+    t[:3, :3] = R.from_euler("xyz", [rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.uniform(-yaw_range, yaw_range)]).as_matrix()
+    t[:3, 3] = [rng.uniform(-shift, shift), rng.uniform(-shift, shift), rng.uniform(-0.3, 0.3)]
+    return t
+
+
+@pytest.mark.parametrize("T,radius", [(1, 0.3), (7, 0.5), (33, 0.3), (64, 0.3), (65, 0.3)])
+def test_frames_edge_cases(gpu, frames_path, T, radius):
+    """Ragged inputs through the frame API on every device path: empty frames, a frame far outside
+    the live window, a frame with points beyond its own table (outliers: the gather paths must fall
+    back), duplicated points, arbitrary rigid poses with roll/pitch, 1..65 traversals (65 takes the
+    stacked path), another radius.  Counts are compared with the brute-force oracle on the
+    reference-transformed points."""
+    import torch
+    from modest_amd.frame_store import FrameStore
+    from oracle import pp_score as opp
+    rng = np.random.default_rng(1000 * T + int(radius * 10))
+    world0 = _rigid(rng, shift=500.0)                      # the common (first history) frame in the world
+
+    def transform(p, M):
+        hom = np.hstack((p.astype(np.float32), np.ones((p.shape[0], 1), dtype=np.float32)))
+        return np.dot(hom, M.astype(np.float32).T)[:, :3]
+
+    live_W = world0 @ _rigid(rng, shift=5.0)
+    live_raw = np.concatenate([rng.standard_normal((1500, 3)) * [8, 8, 0.4], rng.standard_normal((300, 3)) * [0.5, 0.5, 0.2]]
+                              ).astype(np.float32)
+    live_rel = np.linalg.solve(world0, live_W).astype(np.float32)
+    st = FrameStore(gpu, radius)
+    items, hist, rels, stacks = [("live", torch.from_numpy(live_raw).to(gpu), live_W)], [], [], [[] for _ in range(T)]
+    n_fr = 0
+    for t in range(T):
+        for f in range(int(rng.integers(0, 4)) if T > 8 else 3):
+            W = world0 @ _rigid(rng, shift=15.0)
+            kind = (t + f) % 5
+            n = 0 if kind == 0 else int(rng.integers(50, 2500))
+            raw = (rng.standard_normal((n, 3)) * [10, 10, 0.4]).astype(np.float32)
+            if kind == 1 and n:
+                raw[: n // 4] = raw[0]                      # duplicates
+            if kind == 2:
+                W = world0 @ _rigid(rng, shift=15.0)
+                W[:3, 3] += [4000.0, -3000.0, 0.0]          # nowhere near the live scan
+            if kind == 3 and n:
+                raw[:5] += np.float32(900.0)                # outside the frame's own table
+            rel = np.linalg.solve(world0, W).astype(np.float32)
+            key = (t, f)
+            items.append((key, torch.from_numpy(raw).to(gpu), W))
+            hist.append((key, t))
+            rels.append(rel)
+            stacks[t].append(transform(raw, rel))
+            n_fr += 1
+    st.insert_many(items)
+    rels = np.stack(rels) if rels else np.zeros((0, 4, 4), np.float32)
+    H, c = st.pp_score("live", live_rel, hist, rels, world0, T, return_counts=True)
+    live_xyz = transform(live_raw, live_rel)
+    ref_hist = [np.concatenate(s) if s else np.zeros((0, 3), np.float32) for s in stacks]
+    cref = opp.count_neighbors_bruteforce(live_xyz, ref_hist, radius)
+    assert np.array_equal(c.cpu().numpy().astype(np.int64), cref), (T, radius, n_fr)
+    if T > 1:
+        Href = opp.compute_ephe_score(cref)
+        assert np.max(np.abs(H.cpu().numpy().astype(np.float64) - Href)) <= 1e-6
