@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 using namespace modest;
 
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
                                                  const uint4 *__restrict__ tileEdge, unsigned pmax, unsigned wmax,
                                                  unsigned heavy, int fmax, uint2 *__restrict__ runs,
                                                  uint4 *__restrict__ itemsH, uint4 *__restrict__ itemsL,
+                                                 unsigned *__restrict__ itemPts /* [2][shards][cap] points per item */,
                                                  unsigned *__restrict__ tileTotal, unsigned *__restrict__ ctrl) {
     extern __shared__ unsigned pre[];   // nFrames + 1 prefix of the run lengths
     __shared__ unsigned wsum[PL_T / 64];
@@ -399,7 +401,10 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
     uint4 *dst = (hv ? itemsH : itemsL) + (size_t)(t % PL_SHARDS) * PL_SHARD_CAP + slotBase;
     for (unsigned k = tid; k < n; k += PL_T) {
         const unsigned f0 = cuts[k], f1 = (k + 1 == n) ? (unsigned)nFrames : cuts[k + 1];
-        if (slotBase + k < PL_SHARD_CAP) dst[k] = make_uint4((unsigned)t, f0, f1, pre[f0]);
+        if (slotBase + k < PL_SHARD_CAP) {
+            dst[k] = make_uint4((unsigned)t, f0, f1, pre[f0]);
+            itemPts[((size_t)(hv ? 0 : 1) * PL_SHARDS + t % PL_SHARDS) * PL_SHARD_CAP + slotBase + k] = pre[f1] - pre[f0];
+        }
     }
 }
 
@@ -1422,7 +1427,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     MODEST_REQUIRE(n_frames < (1 << 15), "too many frames");
     const size_t descBytes = arena_sz((size_t)(n_frames > 0 ? n_frames : 1) * sizeof(FrameDev));
     size_t need = descBytes + arena_sz((size_t)N * 16) + arena_sz((size_t)F_NTILE * F_NC * 8) +
-                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz(1024) + 2 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
+                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz(1024) + 3 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
                   arena_sz((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1) * 8) + 2 * arena_sz((size_t)F_NTILE * 4) +
                   arena_sz(shardItems * 2 * 4) + arena_sz((size_t)(totalPts + 1) * 16) +
                   arena_sz((size_t)N * T * 4);
@@ -1437,6 +1442,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     unsigned *ctrl = Ar.take<unsigned>(256);
     uint4 *itemsH = Ar.take<uint4>(shardItems);
     uint4 *itemsL = Ar.take<uint4>(shardItems);
+    unsigned *itemPts = Ar.take<unsigned>(shardItems * 2);
     uint2 *runs = Ar.take<uint2>((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1));
     unsigned *tileTotal = Ar.take<unsigned>(F_NTILE);
     unsigned *tileBase = Ar.take<unsigned>(F_NTILE);
@@ -1486,7 +1492,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
         pp5_plan<<<F_NTILE, PL_T, (size_t)(n_frames + 1) * 4, stream>>>(dframes, n_frames, live->tab_dev, live->TX0,
                                                                         live->TY0, tileOcc, tileEdge, pmax,
                                                                         wave ? wmax : 0u, heavy, J_FMAX, runs,
-                                                                        itemsH, itemsL, tileTotal, ctrl);
+                                                                        itemsH, itemsL, itemPts, tileTotal, ctrl);
         const char *pe = getenv("MODEST_PP5_PROF");
         const bool prof = pe && atoi(pe);
         static bool attr = false;
@@ -1550,6 +1556,25 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
                     hc[0] += sh[k];
                     hc[1] += sh[PL_SHARDS + k];
                 }
+            }
+            {   // points per class
+                unsigned sh[2 * PL_SHARDS];
+                MODEST_HIP_CHECK(hipMemcpy(sh, ctrl + 8, sizeof(sh), hipMemcpyDeviceToHost));
+                unsigned long long pts[2] = {0, 0}, mx[2] = {0, 0};
+                std::vector<unsigned> buf(PL_SHARD_CAP);
+                for (int c = 0; c < 2; ++c)
+                    for (int k = 0; k < PL_SHARDS; ++k) {
+                        const unsigned n = sh[c * PL_SHARDS + k] < PL_SHARD_CAP ? sh[c * PL_SHARDS + k] : PL_SHARD_CAP;
+                        if (!n) continue;
+                        MODEST_HIP_CHECK(hipMemcpy(buf.data(), itemPts + ((size_t)c * PL_SHARDS + k) * PL_SHARD_CAP, n * 4,
+                                                   hipMemcpyDeviceToHost));
+                        for (unsigned q = 0; q < n; ++q) {
+                            pts[c] += buf[q];
+                            if (buf[q] > mx[c]) mx[c] = buf[q];
+                        }
+                    }
+                fprintf(stderr, "[pp5] points class H %llu (max item %llu), class L %llu (max item %llu)\n", pts[0], mx[0],
+                        pts[1], mx[1]);
             }
             fprintf(stderr,
                     "[pp5] items %u heavy + %u | wg-time (10 ns ticks, summed) lookups %llu tables %llu gather %llu sort %llu "
