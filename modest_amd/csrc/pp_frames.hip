@@ -250,13 +250,18 @@ __global__ __launch_bounds__(256) void pp5_live_index(const float *__restrict__ 
 //   ctrl[8 + s] heavy items of shard s, ctrl[8 + PL_SHARDS + s] light items; shard = tile % PL_SHARDS;
 //   shard s owns items[s * shardCap ...).
 constexpr int PL_T = 256;
+constexpr int PL_MAX_RECTS = 192;     // cell rectangles of a dense tile (wave path)
+constexpr int PL_DENSE_ITEMS = 256;   // rectangles x frame cuts of a dense tile
 constexpr int W_CAP = 128;   // live points a single wavefront keeps in its LDS slice (wave path)
+// wave item rectangle (item.w): all cells of the tile, all window rows
+__host__ __device__ __forceinline__ unsigned pp6_full_rect() { return 0u | (7u << 3) | (0u << 6) | (7u << 9) | (0u << 12) | (9u << 16); }
 constexpr int PL_ITEMS_PER_TILE = 128;   // >= 33 point cuts + (frames / fmax) frame cuts
 constexpr unsigned PL_SHARD_CAP = (unsigned)(F_NTILE / PL_SHARDS) * PL_ITEMS_PER_TILE;
 __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ frames, int nFrames,
                                                  const unsigned *__restrict__ ltab, int LTX0, int LTY0,
                                                  const unsigned long long *__restrict__ tileOcc,
-                                                 const uint4 *__restrict__ tileEdge, unsigned pmax, unsigned wmax,
+                                                 const uint4 *__restrict__ tileEdge, const uint2 *__restrict__ cellPk,
+                                                 unsigned pmax, unsigned wmax,
                                                  unsigned heavy, int fmax, uint2 *__restrict__ runs,
                                                  uint4 *__restrict__ itemsH, uint4 *__restrict__ itemsL,
                                                  unsigned *__restrict__ itemPts /* [2][shards][cap] points per item */,
@@ -353,18 +358,91 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
     if (total == 0) return;   // uniform
     // cuts: a new item starts at frame f when the points before it cross a multiple of `step`, or
     // at every multiple of fmax frames
-    // wmax == 0: every tile is a workgroup item, tiles with many points first.  wmax > 0 (wave path):
-    // class H = tiles whose window holds more than W_CAP live points (workgroup kernel), class L = the
-    // rest, cut into items of about wmax points for single wavefronts.
+    // wmax == 0 (workgroup kernels): every tile is an item class by point count, heavy tiles first.
+    // wmax > 0 (wave path): every item goes to class L for single wavefronts.  A tile whose window
+    // holds more than W_CAP live points is subdivided: its 8x8 cells are halved recursively until the
+    // live points around a rectangle of cells (the rectangle grown by one cell) fit a wavefront's LDS
+    // slice; a single cell that still does not fit is split by window row (and, beyond that, the
+    // kernel walks its live points in slices).  Every rectangle re-gathers the tile's points and keeps
+    // the records of its own cells, so rectangles x frame cuts is capped at PL_DENSE_ITEMS.
+    __shared__ unsigned rects[PL_MAX_RECTS];
+    __shared__ unsigned nRects;
+    __shared__ unsigned short wc[F_W * F_W];
+    __shared__ unsigned W2[(F_W + 1) * (F_W + 1)];
+    __shared__ unsigned stack[64];
+    const bool dense = wmax != 0 && wlive > (unsigned)W_CAP;
+    if (tid == 0) {
+        rects[0] = pp6_full_rect();
+        nRects = 1;
+    }
+    if (dense) {   // uniform
+        if (tid < F_W * F_W) {
+            const int r = tid / F_W, cc = tid - r * F_W;
+            const int wx = tx * F_TS - 1 + cc, wy = ty * F_TS - 1 + r;
+            unsigned c = 0;
+            if (wx >= 0 && wy >= 0 && wx < F_NTF * F_TS && wy < F_NTF * F_TS) {
+                const int tile = (wy >> 3) * F_NTF + (wx >> 3);
+                if (ltab[tile + 1] > ltab[tile]) c = cellPk[(size_t)tile * F_NC + (wy & 7) * F_TS + (wx & 7)].y;
+            }
+            wc[tid] = (unsigned short)min(c, 65535u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < (F_W + 1) * (F_W + 1); ++i) W2[i] = 0;
+            for (int r = 0; r < F_W; ++r)
+                for (int cc = 0; cc < F_W; ++cc)
+                    W2[(r + 1) * (F_W + 1) + cc + 1] = wc[r * F_W + cc] + W2[r * (F_W + 1) + cc + 1] +
+                                                       W2[(r + 1) * (F_W + 1) + cc] - W2[r * (F_W + 1) + cc];
+            auto live_of = [&](unsigned rc) -> unsigned {   // live points the item of rectangle rc holds
+                const int cx0 = rc & 7, cx1 = (rc >> 3) & 7, cy0 = (rc >> 6) & 7, cy1 = (rc >> 9) & 7;
+                const int ry0 = (rc >> 12) & 15, ry1 = (rc >> 16) & 15;
+                const int r0 = max(cy0, ry0), r1 = min(cy1 + 2, ry1), c0 = cx0, c1 = cx1 + 2;
+                if (r1 < r0) return 0u;
+                return W2[(r1 + 1) * (F_W + 1) + c1 + 1] - W2[r0 * (F_W + 1) + c1 + 1] - W2[(r1 + 1) * (F_W + 1) + c0] +
+                       W2[r0 * (F_W + 1) + c0];
+            };
+            unsigned sp = 0, n = 0;   // (the stack lives in LDS: an indexed per-thread array would be scratch memory)
+            stack[sp++] = pp6_full_rect();
+            while (sp) {
+                const unsigned rc = stack[--sp];
+                const unsigned lv = live_of(rc);
+                if (lv == 0) continue;   // no live point around these cells: their records match nothing
+                const int cx0 = rc & 7, cx1 = (rc >> 3) & 7, cy0 = (rc >> 6) & 7, cy1 = (rc >> 9) & 7;
+                const bool rowSplit = ((rc >> 12) & 15) != 0 || ((rc >> 16) & 15) != 9;
+                if (lv <= (unsigned)W_CAP || rowSplit || n + 4 > (unsigned)PL_MAX_RECTS || sp + 3 > 64) {
+                    if (n < (unsigned)PL_MAX_RECTS) rects[n++] = rc;
+                    continue;
+                }
+                if (cx1 > cx0 || cy1 > cy0) {   // halve the longer side
+                    if (cx1 - cx0 >= cy1 - cy0) {
+                        const int m = (cx0 + cx1) >> 1;
+                        stack[sp++] = (rc & ~0x3fu) | cx0 | (m << 3);
+                        stack[sp++] = (rc & ~0x3fu) | (m + 1) | (cx1 << 3);
+                    } else {
+                        const int m = (cy0 + cy1) >> 1;
+                        stack[sp++] = (rc & ~0xfc0u) | (cy0 << 6) | (m << 9);
+                        stack[sp++] = (rc & ~0xfc0u) | ((m + 1) << 6) | (cy1 << 9);
+                    }
+                } else {   // one cell: one item per window row of its 3x3 neighbourhood
+                    for (int dr = 0; dr < 3; ++dr)
+                        stack[sp++] = (rc & 0xfffu) | ((unsigned)(cy0 + dr) << 12) | ((unsigned)(cy0 + dr) << 16);
+                }
+            }
+            nRects = n;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const unsigned nR = nRects;
+    if (nR == 0) return;   // uniform
     unsigned step = pmax;
     bool hv;
     if (wmax == 0) {
         if (wt > heavy) step = max(pmax / min((wt + heavy - 1) / heavy, 8u), 256u);
         hv = total >= 2 * pmax;
     } else {
-        hv = wlive > (unsigned)W_CAP;
-        if (hv) step = max(pmax / min((wlive + heavy - 1) / heavy, 8u), 256u);
-        else step = wmax;
+        hv = false;
+        step = dense ? max(wmax, (total * nR + PL_DENSE_ITEMS - 1) / PL_DENSE_ITEMS) : wmax;
     }
     step = max(step, (total + 31) / 32);
     unsigned nc = 0;
@@ -394,16 +472,17 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
         cuts[n] = (unsigned)nFrames;
         if (pre[nFrames] == pre[cuts[n - 1]]) --n;   // nothing after the last cut
         nCuts = n;
-        slotBase = n ? atomicAdd(&ctrl[8 + (hv ? 0 : PL_SHARDS) + t % PL_SHARDS], n) : 0u;
+        slotBase = n ? atomicAdd(&ctrl[8 + (hv ? 0 : PL_SHARDS) + t % PL_SHARDS], n * nR) : 0u;
     }
     __syncthreads();
     n = nCuts;
     uint4 *dst = (hv ? itemsH : itemsL) + (size_t)(t % PL_SHARDS) * PL_SHARD_CAP + slotBase;
-    for (unsigned k = tid; k < n; k += PL_T) {
+    for (unsigned idx = tid; idx < n * nR; idx += PL_T) {
+        const unsigned k = idx / nR, rr = idx - k * nR;   // the rectangles of one frame cut are neighbours
         const unsigned f0 = cuts[k], f1 = (k + 1 == n) ? (unsigned)nFrames : cuts[k + 1];
-        if (slotBase + k < PL_SHARD_CAP) {
-            dst[k] = make_uint4((unsigned)t, f0, f1, pre[f0]);
-            itemPts[((size_t)(hv ? 0 : 1) * PL_SHARDS + t % PL_SHARDS) * PL_SHARD_CAP + slotBase + k] = pre[f1] - pre[f0];
+        if (slotBase + idx < PL_SHARD_CAP) {
+            dst[idx] = make_uint4((unsigned)t, f0, f1, wmax ? rects[rr] : pre[f0]);
+            itemPts[((size_t)(hv ? 0 : 1) * PL_SHARDS + t % PL_SHARDS) * PL_SHARD_CAP + slotBase + idx] = pre[f1] - pre[f0];
         }
     }
 }
@@ -1041,28 +1120,36 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
 #undef PP5_TICK
 }
 
-// ---- wave-autonomous join (MODEST_PP_FRAMES_PATH=wave) ------------------------------------------
+// ---- wave-autonomous join (MODEST_PP_FRAMES_PATH=gather-wave) ----------------------------------
 // The workgroup-sized items of pp5_join are latency bound: chains of
 // dependent round trips fenced by workgroup barriers, 16 wavefronts per CU.  Here ONE wavefront owns
-// an item (a light tile x a frame range of about a thousand points) end to end: its live window
-// (<= W_CAP points) and counters sit in a private LDS slice, there is no workgroup barrier, every
-// wavefront of the chip works on its own item and their round trips overlap.
+// an item end to end: a tile (or a rectangle of its cells) x a frame range of about a thousand points
+// x a range of window rows whose live points (<= W_CAP) and counters sit in a private LDS slice.
+// There is no workgroup barrier; every wavefront of the chip works on its own item and their round
+// trips overlap.
 //   lanes = frames for the run look-up (64 at a time; run, pointer and pose stay in registers),
-//   lanes = points for the gather (the owning frame's data comes through cross-lane reads),
+//   lanes = points for the gather (the owning frame's data comes through cross-lane reads; the
+//           loads of batch b+1 are issued before batch b is transformed and joined),
 //   lanes = records for the pair tests (every lane walks its own candidate list in the LDS slice).
+// item.w = cx0 | cx1 << 3 | cy0 << 6 | cy1 << 9 | ry0 << 12 | ry1 << 16: the cells whose records the
+// item joins and the window rows (0..9) whose live points it holds.
 constexpr int W_WAVES = 4;   // wavefronts per workgroup (they never synchronise with each other)
+constexpr int W_DEPTH = 4;   // batches of 64 points whose loads are in flight together
 __host__ __device__ __forceinline__ unsigned pp6_slice_bytes(int T) {
     // live points + counters + cell counts (u16 [100]) + row tables (u16 [10][11], u32 [11]), 16-B multiple
-    return ((unsigned)W_CAP * pp5_live_bytes(T) + 200u + 220u + 44u + 15u) & ~15u;
+    // ... + the queue of surviving records (128 x 16 B)
+    return (((unsigned)W_CAP * pp5_live_bytes(T) + 200u + 220u + 44u + 15u) & ~15u) + 128u * 16u;
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev *__restrict__ frames, int nFrames,
                                                                 const uint2 *__restrict__ runs,
                                                                 const uint4 *__restrict__ itemsL, unsigned *ctrl,
                                                                 const unsigned *__restrict__ ltab, int LTX0, int LTY0,
                                                                 const uint2 *__restrict__ cellPk,
                                                                 const float4 *__restrict__ sorted, Map24 A, int *counts,
-                                                                int T, double r2, unsigned sliceBytes) {
+                                                                int T, double r2, unsigned sliceBytes,
+                                                                unsigned long long *stats) {
     extern __shared__ __align__(16) unsigned char dynsm[];
     __shared__ unsigned shardEnd[W_WAVES][PL_SHARDS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1073,7 +1160,15 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
     unsigned short *ccnt = reinterpret_cast<unsigned short *>(slice + (size_t)W_CAP * pp5_live_bytes(T));
     unsigned short *ctab = ccnt + 100;
     unsigned *rowBase = reinterpret_cast<unsigned *>(ctab + 110);
+    float4 *queue = reinterpret_cast<float4 *>(slice + ((W_CAP * pp5_live_bytes(T) + 464u + 15u) & ~15u));   // 128 records
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    unsigned long long tprof[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define PP6_TICK(k)                                      \
+    if (PROF) {                                          \
+        const unsigned long long now_ = wall_clock64();  \
+        tprof[k] += now_ - tlast;                        \
+        tlast = now_;                                    \
+    }
     {   // inclusive prefix of the light shards' item counts (per wavefront copy: no workgroup barrier)
         const unsigned c0 = lane < PL_SHARDS ? min(ctrl[8 + PL_SHARDS + lane], PL_SHARD_CAP) : 0u;
         unsigned inc = c0;
@@ -1085,6 +1180,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
     }
     __builtin_amdgcn_wave_barrier();
     const unsigned nItems = shardEnd[w][PL_SHARDS - 1];
+    if (PROF) tlast = wall_clock64();
     for (;;) {
         unsigned id = 0;
         if (lane == 0) id = atomicAdd(&ctrl[5], 1u);
@@ -1096,7 +1192,11 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
         const int ttx = (int)(it.x % F_NTF), tty = (int)(it.x / F_NTF);
         const int gtx = LTX0 + ttx, gty = LTY0 + tty;
         const int x0 = ttx * F_TS - 1, y0 = tty * F_TS - 1;
-        // ---- window: cell counts and starts (lane = window cell, two rounds), tables, live points
+        const int cx0 = (int)(it.w & 7u), cx1 = (int)((it.w >> 3) & 7u), cy0 = (int)((it.w >> 6) & 7u);
+        const int cy1 = (int)((it.w >> 9) & 7u), ry0 = (int)((it.w >> 12) & 15u), ry1 = (int)((it.w >> 16) & 15u);
+        // live sub-window: window rows max(cy0, ry0) .. min(cy1 + 2, ry1), window columns cx0 .. cx1 + 2
+        const int wr0 = max(cy0, ry0), wr1 = min(cy1 + 2, ry1);
+        // ---- window: cell counts and starts (lane = window cell, two rounds)
         unsigned gst0 = 0, gst1 = 0;
         for (int rnd = 0; rnd < 2; ++rnd) {
             const int e = lane + 64 * rnd;
@@ -1104,7 +1204,8 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
             if (e < F_W * F_W) {
                 const int r = e / F_W, cc = e - r * F_W;
                 const int wx = x0 + cc, wy = y0 + r;
-                if (wx >= 0 && wy >= 0 && wx < F_NTF * F_TS && wy < F_NTF * F_TS) {
+                if (r >= wr0 && r <= wr1 && cc >= cx0 && cc <= cx1 + 2 && wx >= 0 && wy >= 0 && wx < F_NTF * F_TS &&
+                    wy < F_NTF * F_TS) {
                     const int tile = (wy >> 3) * F_NTF + (wx >> 3);
                     const unsigned ta = ltab[tile], tb = ltab[tile + 1];
                     if (tb > ta) {
@@ -1119,25 +1220,21 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
             else gst1 = g;
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < F_W) {   // one lane per window row: positions inside the row
+        // row tables, all lanes: ctab[r][cc] = live points of row r before column cc; rowBase[r]
+        for (int e = lane; e < F_W * (F_W + 1); e += 64) {
+            const int r = e / (F_W + 1), cc = e - r * (F_W + 1);
             unsigned run = 0;
-            for (int cc = 0; cc < F_W; ++cc) {
-                ctab[lane * (F_W + 1) + cc] = (unsigned short)run;
-                run += ccnt[lane * F_W + cc];
-            }
-            ctab[lane * (F_W + 1) + F_W] = (unsigned short)run;
+            for (int k = 0; k < cc; ++k) run += ccnt[r * F_W + k];
+            ctab[e] = (unsigned short)run;
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
+        if (lane <= F_W) {
             unsigned run = 0;
-            for (int r = 0; r < F_W; ++r) {
-                rowBase[r] = run;
-                run += ctab[r * (F_W + 1) + F_W];
-            }
-            rowBase[F_W] = run;
+            for (int r = 0; r < lane; ++r) run += ctab[r * (F_W + 1) + F_W];
+            rowBase[lane] = run;
         }
         __builtin_amdgcn_wave_barrier();
-        const unsigned Lw = rowBase[F_W];   // <= W_CAP by the plan's exact window count
+        const unsigned Lw = rowBase[F_W];   // <= W_CAP by the plan
         unsigned long long occ;
         {
             const int kx = lane & 7, ky = lane >> 3;
@@ -1146,20 +1243,28 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) sOr |= ccnt[(ky + dy) * F_W + kx + dx];
-            occ = __ballot(sOr != 0u);
+            occ = __ballot(sOr != 0u && kx >= cx0 && kx <= cx1 && ky >= cy0 && ky <= cy1);
         }
-        if (!occ || Lw > (unsigned)W_CAP) continue;   // (the second cannot happen)
+        if (!occ) {
+            PP6_TICK(0)
+            continue;
+        }
+        // The plan sizes items so that Lw <= W_CAP; a sub-window that cannot be split further (one
+        // window row of a single cell's neighbourhood) is walked in slices of W_CAP live points.
+        for (unsigned lb0 = 0; lb0 < Lw; lb0 += W_CAP) {
+        const unsigned Ls = min((unsigned)W_CAP, Lw - lb0);
         // live points -> LDS, one lane per point; the global starts of the window cells travel through
         // the (still unused) counter area
+        __builtin_amdgcn_wave_barrier();
         if (lane < F_W * F_W) cntw[lane] = gst0;
         if (lane + 64 < F_W * F_W) cntw[lane + 64] = gst1;
         __builtin_amdgcn_wave_barrier();
         float4 lv[(W_CAP + 63) / 64];
 #pragma unroll
         for (int k = 0; k < (W_CAP + 63) / 64; ++k) {
-            const unsigned e = lane + 64 * k;
+            const unsigned e = lb0 + lane + 64 * k;
             lv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < Lw) {
+            if (e < lb0 + Ls) {
                 int r = 0;
                 while (e >= rowBase[r + 1]) ++r;
                 const unsigned pos = e - rowBase[r];
@@ -1172,15 +1277,16 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < (W_CAP + 63) / 64; ++k)
-            if (lane + 64u * k < Lw) live[lane + 64 * k] = lv[k];
-        for (unsigned e = lane; e < Lw * Th; e += 64) cntw[e] = 0;
+            if (lane + 64u * k < Ls) live[lane + 64 * k] = lv[k];
+        for (unsigned e = lane; e < Ls * Th; e += 64) cntw[e] = 0;
         __builtin_amdgcn_wave_barrier();
+        PP6_TICK(0)
 
         // ---- frames, 64 at a time
         const int f0 = (int)it.y, f1 = (int)it.z;
         unsigned sinceFlush = 0;
         auto flush = [&](bool clear) {
-            for (unsigned e = lane; e < Lw * Th; e += 64) {
+            for (unsigned e = lane; e < Ls * Th; e += 64) {
                 const unsigned cw = cntw[e];
                 if (cw) {
                     const unsigned p = e / Th, tp = (e - p * Th) * 2;
@@ -1188,6 +1294,43 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
                     if (cw & 0xffffu) atomicAdd(&counts[rowi + tp], (int)(cw & 0xffffu));
                     if (cw >> 16) atomicAdd(&counts[rowi + tp + 1], (int)(cw >> 16));
                     if (clear) cntw[e] = 0;
+                }
+            }
+        };
+        unsigned qn = 0;   // queued records (uniform)
+        // pair tests of the first m queued records: every lane walks the candidates of its record (the
+        // live points of the 3x3 cells around it).  Measured against a wave-uniform all-pairs loop over the
+        // whole sub-window (one broadcast read per candidate, segmented popcounts instead of atomics): the
+        // per-lane walk wins, 349 vs 517 ms of summed wave time -- a light tile's window holds ~10x more
+        // live points than a record has candidates.
+        auto pairs = [&](unsigned m) {
+            const bool has = (unsigned)lane < m;
+            const float4 rq = has ? queue[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int pk = has ? __float_as_int(rq.w) : 0;
+            const int key = pk & (F_NC - 1);
+            const unsigned trv = (unsigned)pk >> 16;
+            const float hx = rq.x, hy = rq.y, hz = rq.z;
+            const int lx = (key & (F_TS - 1)) + 1, ly = key / F_TS + 1;
+            const unsigned short *row = ctab + (ly - 1) * (F_W + 1) + lx - 1;
+            const unsigned c00 = row[0], c10 = row[F_W + 1], c20 = row[2 * (F_W + 1)];
+            const unsigned n0 = row[3] - c00, n1 = row[F_W + 4] - c10, n2 = row[2 * (F_W + 1) + 3] - c20;
+            const unsigned a0 = rowBase[ly - 1] + c00, n01 = n0 + n1, nAll = n01 + n2;
+            const unsigned b1 = rowBase[ly] + c10 - n0, b2 = rowBase[ly + 1] + c20 - n01;
+            const unsigned own = has ? nAll : 0u;
+            const unsigned cword = trv >> 1, cinc = 1u << ((trv & 1u) * 16);
+            for (unsigned p0 = 0; __any(p0 < own); p0 += 2) {
+#pragma unroll
+                for (unsigned u = 0; u < 2; ++u) {
+                    const unsigned p = p0 + u;
+                    const unsigned ca = p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) - lb0;   // index inside the slice
+                    const bool act = p < own && ca < Ls;
+                    const unsigned ci = act ? ca : 0u;
+                    const float4 q = live[ci];
+                    const float fx = q.x - hx, fy = q.y - hy, fz = q.z - hz;
+                    const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                    bool hit = act && d2 < r2lo;
+                    if (act && !hit && d2 <= r2hi) hit = pp_within(hx, hy, hz, q.x, q.y, q.z, r2);   // exact re-test
+                    if (hit) atomicAdd(&cntw[ci * Th + cword], cinc);
                 }
             }
         };
@@ -1216,17 +1359,12 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
             }
             const unsigned pre = inc - rlen;   // exclusive
             const unsigned Pc = __builtin_amdgcn_readlane(inc, 63);
-            for (unsigned b0 = 0; b0 < Pc; b0 += 64) {
-                if (sinceFlush > 60000u) {   // 16-bit counters
-                    __builtin_amdgcn_wave_barrier();
-                    flush(true);
-                    __builtin_amdgcn_wave_barrier();
-                    sinceFlush = 0;
-                }
-                sinceFlush += 64;
+            PP6_TICK(1)
+            // software pipeline: the raw point of batch b + 1 is in flight while batch b is processed
+            auto issue = [&](unsigned b0, int &lo, bool &valid, float &x, float &y, float &z) {
                 const unsigned i = b0 + lane;
-                const bool valid = i < Pc;
-                int lo = 0;   // largest lane whose prefix <= i
+                valid = i < Pc;
+                lo = 0;   // largest lane whose prefix <= i
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1) {
                     const int cand = lo + step;
@@ -1235,58 +1373,102 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
                 }
                 const unsigned sPre = __shfl(pre, lo), sStart = __shfl(rstart, lo);
                 const unsigned sLo = __shfl(plo, lo), sHi = __shfl(phi, lo);
-                const int sTf = __shfl(tf, lo);
-                float rel[12];
-                rel[0] = __shfl(m0.x, lo); rel[1] = __shfl(m0.y, lo); rel[2] = __shfl(m0.z, lo); rel[3] = __shfl(m0.w, lo);
-                rel[4] = __shfl(m1.x, lo); rel[5] = __shfl(m1.y, lo); rel[6] = __shfl(m1.z, lo); rel[7] = __shfl(m1.w, lo);
-                rel[8] = __shfl(m2.x, lo); rel[9] = __shfl(m2.y, lo); rel[10] = __shfl(m2.z, lo); rel[11] = __shfl(m2.w, lo);
-                bool keep = false;
-                float hx = 0.f, hy = 0.f, hz = 0.f;
-                int key = 0;
+                x = y = z = 0.f;
                 if (valid) {
                     const float *src = reinterpret_cast<const float *>(((unsigned long long)sHi << 32) | sLo) +
                                        3 * (size_t)(sStart + (i - sPre));
-                    const float x = src[0], y = src[1], z = src[2];
-                    const bool drop = ((sTf >> 16) & F_FLAG_CENTER) && in_center_box(x, y);
-                    float o[3];
-                    rel_apply(rel, x, y, z, o);
-                    key = cell_in_tile(A, o[0], o[1], o[2], gtx, gty);
-                    keep = !drop && ((occ >> key) & 1ULL);
-                    hx = o[0];
-                    hy = o[1];
-                    hz = o[2];
+                    x = src[0];
+                    y = src[1];
+                    z = src[2];
                 }
-                if (!__any(keep)) continue;
-                // ---- pair tests: every lane walks the candidates of its record
-                const int lx = (key & (F_TS - 1)) + 1, ly = key / F_TS + 1;
-                const unsigned short *row = ctab + (ly - 1) * (F_W + 1) + lx - 1;
-                const unsigned c00 = row[0], c10 = row[F_W + 1], c20 = row[2 * (F_W + 1)];
-                const unsigned n0 = row[3] - c00, n1 = row[F_W + 4] - c10, n2 = row[2 * (F_W + 1) + 3] - c20;
-                const unsigned a0 = rowBase[ly - 1] + c00, n01 = n0 + n1, nAll = n01 + n2;
-                const unsigned b1 = rowBase[ly] + c10 - n0, b2 = rowBase[ly + 1] + c20 - n01;
-                const unsigned own = keep ? nAll : 0u;
-                const unsigned trv = (unsigned)sTf & 0xffffu;
-                const unsigned cword = trv >> 1, cinc = 1u << ((trv & 1u) * 16);
-                for (unsigned p0 = 0; __any(p0 < own); p0 += 2) {
+            };
+            // the raw points of W_DEPTH batches are requested together: one round trip per W_DEPTH x 64
+            // points (a wavefront that has 768 bytes in flight cannot hide a multi-microsecond latency)
+            for (unsigned g0 = 0; g0 < Pc; g0 += 64u * W_DEPTH) {
+                int blo[W_DEPTH];
+                bool bvalid[W_DEPTH];
+                float bx[W_DEPTH], by[W_DEPTH], bz[W_DEPTH];
 #pragma unroll
-                    for (unsigned u = 0; u < 2; ++u) {
-                        const unsigned p = p0 + u;
-                        const bool act = p < own;
-                        const unsigned ci = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
-                        const float4 q = live[ci];
-                        const float fx = q.x - hx, fy = q.y - hy, fz = q.z - hz;
-                        const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                        bool hit = act && d2 < r2lo;
-                        if (act && !hit && d2 <= r2hi) hit = pp_within(hx, hy, hz, q.x, q.y, q.z, r2);   // exact re-test
-                        if (hit) atomicAdd(&cntw[ci * Th + cword], cinc);
+                for (int k = 0; k < W_DEPTH; ++k) {
+                    blo[k] = 0;
+                    bvalid[k] = false;
+                    bx[k] = by[k] = bz[k] = 0.f;
+                    if (g0 + 64u * k < Pc) issue(g0 + 64u * k, blo[k], bvalid[k], bx[k], by[k], bz[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < W_DEPTH; ++k) {
+                    if (g0 + 64u * k >= Pc) break;
+                    const int lo = blo[k];
+                    const bool valid = bvalid[k];
+                    const float x = bx[k], y = by[k], z = bz[k];
+                    if (sinceFlush > 60000u) {   // 16-bit counters
+                        __builtin_amdgcn_wave_barrier();
+                        if (qn) pairs(qn);
+                        qn = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        flush(true);
+                        __builtin_amdgcn_wave_barrier();
+                        sinceFlush = 0;
+                    }
+                    sinceFlush += 64;
+                    const int sTf = __shfl(tf, lo);
+                    float rel[12];
+                    rel[0] = __shfl(m0.x, lo); rel[1] = __shfl(m0.y, lo); rel[2] = __shfl(m0.z, lo); rel[3] = __shfl(m0.w, lo);
+                    rel[4] = __shfl(m1.x, lo); rel[5] = __shfl(m1.y, lo); rel[6] = __shfl(m1.z, lo); rel[7] = __shfl(m1.w, lo);
+                    rel[8] = __shfl(m2.x, lo); rel[9] = __shfl(m2.y, lo); rel[10] = __shfl(m2.z, lo); rel[11] = __shfl(m2.w, lo);
+                    bool keep = false;
+                    float hx = 0.f, hy = 0.f, hz = 0.f;
+                    int key = 0;
+                    if (valid) {
+                        const bool drop = ((sTf >> 16) & F_FLAG_CENTER) && in_center_box(x, y);
+                        float o[3];
+                        rel_apply(rel, x, y, z, o);
+                        key = cell_in_tile(A, o[0], o[1], o[2], gtx, gty);
+                        keep = !drop && ((occ >> key) & 1ULL);
+                        hx = o[0];
+                        hy = o[1];
+                        hz = o[2];
+                    }
+                    // survivors join a wave-private queue; pair tests run on 64 queued records at a time, so
+                    // that every lane has a record (a dense tile's rectangle keeps few points of a batch)
+                    {
+                        const unsigned long long bal = __ballot(keep);
+                        if (keep) {
+                            const unsigned trv = (unsigned)sTf & 0xffffu;
+                            queue[qn + __popcll(bal & ((1ULL << lane) - 1ULL))] =
+                                make_float4(hx, hy, hz, __int_as_float(key | (int)(trv << 16)));
+                        }
+                        qn += (unsigned)__popcll(bal);
+                    }
+                    PP6_TICK(2)
+                    if (qn >= 64u) {
+                        __builtin_amdgcn_wave_barrier();
+                        pairs(64u);
+                        __builtin_amdgcn_wave_barrier();
+                        const float4 mv = (lane + 64u < qn) ? queue[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane + 64u < qn) queue[lane] = mv;
+                        qn -= 64u;
+                        PP6_TICK(3)
                     }
                 }
             }
         }
+        if (qn) {
+            __builtin_amdgcn_wave_barrier();
+            pairs(qn);
+            qn = 0;
+            PP6_TICK(3)
+        }
         __builtin_amdgcn_wave_barrier();
         flush(false);
         __builtin_amdgcn_wave_barrier();
+        PP6_TICK(4)
+        }   // live slices
     }
+    if (PROF && lane == 0)
+        for (int k = 0; k < 5; ++k) atomicAdd(&stats[8 + k], tprof[k]);
+#undef PP6_TICK
 }
 
 // entropy of a count matrix (same arithmetic as pp_count.hip's kernel; duplicated so that the two
@@ -1490,7 +1672,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
         const char *wm = getenv("MODEST_PP6_WMAX");
         const unsigned wmax = wm ? (unsigned)atoi(wm) : 1536u;
         pp5_plan<<<F_NTILE, PL_T, (size_t)(n_frames + 1) * 4, stream>>>(dframes, n_frames, live->tab_dev, live->TX0,
-                                                                        live->TY0, tileOcc, tileEdge, pmax,
+                                                                        live->TY0, tileOcc, tileEdge, cellPk, pmax,
                                                                         wave ? wmax : 0u, heavy, J_FMAX, runs,
                                                                         itemsH, itemsL, itemPts, tileTotal, ctrl);
         const char *pe = getenv("MODEST_PP5_PROF");
@@ -1517,21 +1699,31 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
         if (fused || wave) {
             const int grid = 2 * ctx->num_cus;
             const int nsh = wave ? PL_SHARDS : 2 * PL_SHARDS;   // wave path: the workgroup kernel takes class H only
-            if (prof) pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, true><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
+            const char *sk = getenv("MODEST_PP6_SKIP");
+            const int skip = sk ? atoi(sk) : 0;
+            if ((skip & 1) || wave) {   // wave path: every item is a wave item
+            } else if (prof) pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, true><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
             else pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, false><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
-            if (wave) {
+            if (wave && !(skip & 2)) {
                 const unsigned slice = pp6_slice_bytes(T);
                 static bool wattr = false;
                 if (!wattr) {
-                    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join),
+                    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join<false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
+                    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join<true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
                     wattr = true;
                 }
                 const char *wg = getenv("MODEST_PP6_WGS");
                 const int wgs = (wg ? atoi(wg) : 6) * ctx->num_cus;
-                pp6_wave_join<<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
-                    dframes, n_frames, runs, itemsL, ctrl, live->tab_dev, live->TX0, live->TY0, cellPk, sorted, A, counts, T,
-                    r2, slice);
+                if (prof)
+                    pp6_wave_join<true><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
+                        dframes, n_frames, runs, itemsL, ctrl, live->tab_dev, live->TX0, live->TY0, cellPk, sorted, A, counts,
+                        T, r2, slice, stats);
+                else
+                    pp6_wave_join<false><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
+                        dframes, n_frames, runs, itemsL, ctrl, live->tab_dev, live->TX0, live->TY0, cellPk, sorted, A, counts,
+                        T, r2, slice, stats);
             }
         } else {
             pp5_tile_scan<<<1, 1024, 0, stream>>>(tileTotal, tileBase);
@@ -1544,10 +1736,13 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
         }
 #undef PP5_ARGS
         if (prof) {
-            unsigned long long hs[8];
+            unsigned long long hs[16];
             unsigned hc[4];
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hs, stats, sizeof(hs), hipMemcpyDeviceToHost));
+            if (wave)
+                fprintf(stderr, "[pp6] wave-time (10 ns ticks, summed over wavefronts) window %llu chunk-header %llu "
+                                "gather+transform %llu pairs %llu flush %llu\n", hs[8], hs[9], hs[10], hs[11], hs[12]);
             {
                 unsigned sh[2 * PL_SHARDS];
                 MODEST_HIP_CHECK(hipMemcpy(sh, ctrl + 8, sizeof(sh), hipMemcpyDeviceToHost));
