@@ -251,7 +251,6 @@ __global__ __launch_bounds__(256) void pp5_live_index(const float *__restrict__ 
 //   shard s owns items[s * shardCap ...).
 constexpr int PL_T = 256;
 constexpr int PL_MAX_RECTS = 192;     // cell rectangles of a dense tile (wave path)
-constexpr int PL_DENSE_ITEMS = 256;   // rectangles x frame cuts of a dense tile
 constexpr int W_CAP = 128;   // live points a single wavefront keeps in its LDS slice (wave path)
 // wave item rectangle (item.w): all cells of the tile, all window rows
 __host__ __device__ __forceinline__ unsigned pp6_full_rect() { return 0u | (7u << 3) | (0u << 6) | (7u << 9) | (0u << 12) | (9u << 16); }
@@ -261,10 +260,11 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
                                                  const unsigned *__restrict__ ltab, int LTX0, int LTY0,
                                                  const unsigned long long *__restrict__ tileOcc,
                                                  const uint4 *__restrict__ tileEdge, const uint2 *__restrict__ cellPk,
-                                                 unsigned pmax, unsigned wmax,
+                                                 unsigned pmax, unsigned wmax, unsigned denseItems,
                                                  unsigned heavy, int fmax, uint2 *__restrict__ runs,
                                                  uint4 *__restrict__ itemsH, uint4 *__restrict__ itemsL,
                                                  unsigned *__restrict__ itemPts /* [2][shards][cap] points per item */,
+                                                 uint2 *__restrict__ winTab /* [tile][100] (count, start) of the window cells */,
                                                  unsigned *__restrict__ tileTotal, unsigned *__restrict__ ctrl) {
     extern __shared__ unsigned pre[];   // nFrames + 1 prefix of the run lengths
     __shared__ unsigned wsum[PL_T / 64];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
     // live points around a rectangle of cells (the rectangle grown by one cell) fit a wavefront's LDS
     // slice; a single cell that still does not fit is split by window row (and, beyond that, the
     // kernel walks its live points in slices).  Every rectangle re-gathers the tile's points and keeps
-    // the records of its own cells, so rectangles x frame cuts is capped at PL_DENSE_ITEMS.
+    // the records of its own cells, so rectangles x frame cuts is capped (`denseItems`).
     __shared__ unsigned rects[PL_MAX_RECTS];
     __shared__ unsigned nRects;
     __shared__ unsigned short wc[F_W * F_W];
@@ -375,17 +375,23 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
         rects[0] = pp6_full_rect();
         nRects = 1;
     }
-    if (dense) {   // uniform
-        if (tid < F_W * F_W) {
-            const int r = tid / F_W, cc = tid - r * F_W;
-            const int wx = tx * F_TS - 1 + cc, wy = ty * F_TS - 1 + r;
-            unsigned c = 0;
-            if (wx >= 0 && wy >= 0 && wx < F_NTF * F_TS && wy < F_NTF * F_TS) {
-                const int tile = (wy >> 3) * F_NTF + (wx >> 3);
-                if (ltab[tile + 1] > ltab[tile]) c = cellPk[(size_t)tile * F_NC + (wy & 7) * F_TS + (wx & 7)].y;
+    if (wmax != 0 && tid < F_W * F_W) {   // the window's cells, once per tile: wave items read them in one round trip
+        const int r = tid / F_W, cc = tid - r * F_W;
+        const int wx = tx * F_TS - 1 + cc, wy = ty * F_TS - 1 + r;
+        unsigned c = 0, g = 0;
+        if (wx >= 0 && wy >= 0 && wx < F_NTF * F_TS && wy < F_NTF * F_TS) {
+            const int tile = (wy >> 3) * F_NTF + (wx >> 3);
+            const unsigned ta = ltab[tile], tb = ltab[tile + 1];
+            if (tb > ta) {
+                const uint2 pk = cellPk[(size_t)tile * F_NC + (wy & 7) * F_TS + (wx & 7)];
+                c = pk.y;
+                g = ta + pk.x;
             }
-            wc[tid] = (unsigned short)min(c, 65535u);
         }
+        wc[tid] = (unsigned short)min(c, 65535u);
+        winTab[(size_t)t * (F_W * F_W) + tid] = make_uint2(c, g);
+    }
+    if (dense) {   // uniform
         __syncthreads();
         if (tid == 0) {
             for (int i = 0; i < (F_W + 1) * (F_W + 1); ++i) W2[i] = 0;
@@ -441,8 +447,8 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
         if (wt > heavy) step = max(pmax / min((wt + heavy - 1) / heavy, 8u), 256u);
         hv = total >= 2 * pmax;
     } else {
-        hv = false;
-        step = dense ? max(wmax, (total * nR + PL_DENSE_ITEMS - 1) / PL_DENSE_ITEMS) : wmax;
+        hv = dense;   // class H is dequeued first: the rectangles of dense tiles are the long items
+        step = dense ? max(wmax, (unsigned)(((unsigned long long)total * nR + denseItems - 1) / denseItems)) : wmax;
     }
     step = max(step, (total + 31) / 32);
     unsigned nc = 0;
@@ -1144,14 +1150,14 @@ __host__ __device__ __forceinline__ unsigned pp6_slice_bytes(int T) {
 template <bool PROF>
 __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev *__restrict__ frames, int nFrames,
                                                                 const uint2 *__restrict__ runs,
+                                                                const uint4 *__restrict__ itemsH,
                                                                 const uint4 *__restrict__ itemsL, unsigned *ctrl,
-                                                                const unsigned *__restrict__ ltab, int LTX0, int LTY0,
-                                                                const uint2 *__restrict__ cellPk,
+                                                                const uint2 *__restrict__ winTab, int LTX0, int LTY0,
                                                                 const float4 *__restrict__ sorted, Map24 A, int *counts,
                                                                 int T, double r2, unsigned sliceBytes,
                                                                 unsigned long long *stats) {
     extern __shared__ __align__(16) unsigned char dynsm[];
-    __shared__ unsigned shardEnd[W_WAVES][PL_SHARDS];
+    __shared__ unsigned shardEnd[W_WAVES][2 * PL_SHARDS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned char *slice = dynsm + (size_t)w * sliceBytes;
     const int Th = (T + 1) >> 1;
@@ -1169,17 +1175,18 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
         tprof[k] += now_ - tlast;                        \
         tlast = now_;                                    \
     }
-    {   // inclusive prefix of the light shards' item counts (per wavefront copy: no workgroup barrier)
-        const unsigned c0 = lane < PL_SHARDS ? min(ctrl[8 + PL_SHARDS + lane], PL_SHARD_CAP) : 0u;
+    {   // inclusive prefix of the shards' item counts, class H first (per wavefront copy: no workgroup barrier)
+        const unsigned c0 = min(ctrl[8 + lane], PL_SHARD_CAP);
         unsigned inc = c0;
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned u = __shfl_up(inc, o);
             if (lane >= o) inc += u;
         }
-        if (lane < PL_SHARDS) shardEnd[w][lane] = inc;
+        shardEnd[w][lane] = inc;
     }
+    static_assert(2 * PL_SHARDS == 64, "one lane per shard counter");
     __builtin_amdgcn_wave_barrier();
-    const unsigned nItems = shardEnd[w][PL_SHARDS - 1];
+    const unsigned nItems = shardEnd[w][2 * PL_SHARDS - 1];
     if (PROF) tlast = wall_clock64();
     for (;;) {
         unsigned id = 0;
@@ -1188,10 +1195,10 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
         if (id >= nItems) break;
         int sh = 0;
         while (shardEnd[w][sh] <= id) ++sh;
-        const uint4 it = itemsL[(size_t)sh * PL_SHARD_CAP + (id - (sh ? shardEnd[w][sh - 1] : 0u))];
+        const uint4 *isrc = sh < PL_SHARDS ? itemsH + (size_t)sh * PL_SHARD_CAP : itemsL + (size_t)(sh - PL_SHARDS) * PL_SHARD_CAP;
+        const uint4 it = isrc[id - (sh ? shardEnd[w][sh - 1] : 0u)];
         const int ttx = (int)(it.x % F_NTF), tty = (int)(it.x / F_NTF);
         const int gtx = LTX0 + ttx, gty = LTY0 + tty;
-        const int x0 = ttx * F_TS - 1, y0 = tty * F_TS - 1;
         const int cx0 = (int)(it.w & 7u), cx1 = (int)((it.w >> 3) & 7u), cy0 = (int)((it.w >> 6) & 7u);
         const int cy1 = (int)((it.w >> 9) & 7u), ry0 = (int)((it.w >> 12) & 15u), ry1 = (int)((it.w >> 16) & 15u);
         // live sub-window: window rows max(cy0, ry0) .. min(cy1 + 2, ry1), window columns cx0 .. cx1 + 2
@@ -1203,16 +1210,10 @@ __global__ __launch_bounds__(64 * W_WAVES, 3) void pp6_wave_join(const FrameDev 
             unsigned c = 0, g = 0;
             if (e < F_W * F_W) {
                 const int r = e / F_W, cc = e - r * F_W;
-                const int wx = x0 + cc, wy = y0 + r;
-                if (r >= wr0 && r <= wr1 && cc >= cx0 && cc <= cx1 + 2 && wx >= 0 && wy >= 0 && wx < F_NTF * F_TS &&
-                    wy < F_NTF * F_TS) {
-                    const int tile = (wy >> 3) * F_NTF + (wx >> 3);
-                    const unsigned ta = ltab[tile], tb = ltab[tile + 1];
-                    if (tb > ta) {
-                        const uint2 pk = cellPk[(size_t)tile * F_NC + (wy & 7) * F_TS + (wx & 7)];
-                        c = pk.y;
-                        g = ta + pk.x;
-                    }
+                if (r >= wr0 && r <= wr1 && cc >= cx0 && cc <= cx1 + 2) {
+                    const uint2 wt2 = winTab[(size_t)it.x * (F_W * F_W) + e];   // written by pp5_plan
+                    c = wt2.x;
+                    g = wt2.y;
                 }
                 ccnt[e] = (unsigned short)c;
             }
@@ -1609,7 +1610,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     MODEST_REQUIRE(n_frames < (1 << 15), "too many frames");
     const size_t descBytes = arena_sz((size_t)(n_frames > 0 ? n_frames : 1) * sizeof(FrameDev));
     size_t need = descBytes + arena_sz((size_t)N * 16) + arena_sz((size_t)F_NTILE * F_NC * 8) +
-                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz(1024) + 3 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
+                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz((size_t)F_NTILE * 100 * 8) + arena_sz(1024) + 3 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
                   arena_sz((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1) * 8) + 2 * arena_sz((size_t)F_NTILE * 4) +
                   arena_sz(shardItems * 2 * 4) + arena_sz((size_t)(totalPts + 1) * 16) +
                   arena_sz((size_t)N * T * 4);
@@ -1621,6 +1622,7 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     uint2 *cellPk = Ar.take<uint2>((size_t)F_NTILE * F_NC);
     unsigned long long *tileOcc = Ar.take<unsigned long long>(F_NTILE);
     uint4 *tileEdge = Ar.take<uint4>((size_t)F_NTILE * 2);
+    uint2 *winTab = Ar.take<uint2>((size_t)F_NTILE * 100);
     unsigned *ctrl = Ar.take<unsigned>(256);
     uint4 *itemsH = Ar.take<uint4>(shardItems);
     uint4 *itemsL = Ar.take<uint4>(shardItems);
@@ -1670,11 +1672,13 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
         const char *pm = getenv("MODEST_PP5_PMAX");
         const unsigned pmax = pm ? (unsigned)atoi(pm) : 6144u;
         const char *wm = getenv("MODEST_PP6_WMAX");
-        const unsigned wmax = wm ? (unsigned)atoi(wm) : 1536u;
+        const unsigned wmax = wm ? (unsigned)atoi(wm) : 768u;
+        const char *dm = getenv("MODEST_PP6_DENSE_ITEMS");
+        const unsigned denseItems = dm ? (unsigned)atoi(dm) : 1024u;
         pp5_plan<<<F_NTILE, PL_T, (size_t)(n_frames + 1) * 4, stream>>>(dframes, n_frames, live->tab_dev, live->TX0,
                                                                         live->TY0, tileOcc, tileEdge, cellPk, pmax,
-                                                                        wave ? wmax : 0u, heavy, J_FMAX, runs,
-                                                                        itemsH, itemsL, itemPts, tileTotal, ctrl);
+                                                                        wave ? wmax : 0u, denseItems, heavy, J_FMAX, runs,
+                                                                        itemsH, itemsL, itemPts, winTab, tileTotal, ctrl);
         const char *pe = getenv("MODEST_PP5_PROF");
         const bool prof = pe && atoi(pe);
         static bool attr = false;
@@ -1718,11 +1722,11 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
                 const int wgs = (wg ? atoi(wg) : 6) * ctx->num_cus;
                 if (prof)
                     pp6_wave_join<true><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
-                        dframes, n_frames, runs, itemsL, ctrl, live->tab_dev, live->TX0, live->TY0, cellPk, sorted, A, counts,
+                        dframes, n_frames, runs, itemsH, itemsL, ctrl, winTab, live->TX0, live->TY0, sorted, A, counts,
                         T, r2, slice, stats);
                 else
                     pp6_wave_join<false><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
-                        dframes, n_frames, runs, itemsL, ctrl, live->tab_dev, live->TX0, live->TY0, cellPk, sorted, A, counts,
+                        dframes, n_frames, runs, itemsH, itemsL, ctrl, winTab, live->TX0, live->TY0, sorted, A, counts,
                         T, r2, slice, stats);
             }
         } else {
