@@ -1,25 +1,31 @@
-// PP neighbour count over a FRAME STORE (round 2): no stacked history, no scatter pass.
+// Frame store (modest_frame_sort) and the one-pass gather-join over it (round 2).
 //
 // Reference steps replaced: pre_compute_pp_score.py:132-150 (per-frame transform_points +
 // remove_center + np.concatenate), :188-190 (cKDTree per traversal), :54-60 (count_neighbors).
 //
-// Design.  The V3 path (pp_v3.h) streams a stacked, arbitrarily ordered
-// history twice and moves every surviving record through HBM once more (601 MB for 130 MB of
-// input).  Here every raw frame is sorted ONCE, when it enters the frame store, by the 8x8-cell
-// tile of a WORLD lattice that all frames share (a frame serves ~70 scans), and keeps a prefix
-// table tile -> [start, end).  A scan is then a pure gather-join:
+// Every raw frame is sorted ONCE, when it enters the frame store, by the 8x8-cell tile of a WORLD
+// lattice that all frames share (a frame serves ~70 scans), and keeps a prefix table tile -> [start,
+// end).  modest_pp_score_frames reads frames through a descriptor table; by default the V3 streaming
+// kernels do (pp_count.hip: pose fused, no stacked history).  This file also holds the experimental
+// one-pass path (MODEST_PP_FRAMES_PATH=gather-wave), in which the history crosses HBM once and
+// nothing is written back:
 //
-//   pp5_live_index  one wavefront per live tile: cell-sort the live points inside their tile,
-//                   (offset, count) per cell; zeroes the count matrix.            (1 launch)
-//   pp5_plan        one workgroup: work items (tile, frame range), heavy ones first.
-//   pp5_join        persistent grid, dynamic dequeue.  An item looks up the run of ITS tile in
-//                   the table of every history frame (the runs of one tile in 360 frames are the
-//                   records V3 had to scatter into a list), gathers the raw points, applies the
-//                   frame's relative pose (the reference's float32 BLAS rounding), drops points
-//                   whose cell has no live point in its 3x3 neighbourhood, counting-sorts the
-//                   survivors by cell in LDS and joins them against the live points of the 10x10
-//                   cell window (wave-uniform groups + per-lane path, as in V3).  History bytes
-//                   cross HBM once: 12 B per point.
+//   pp5_live_index  one workgroup per four live tiles: cell-sort the live points inside their tile,
+//                   (offset, count) per cell, occupancy mask and border sums per tile; zeroes the
+//                   count matrix.
+//   pp5_plan        one workgroup per tile: exact window activity, the tile's run in every frame's
+//                   table, the window's cells, rectangle subdivision of dense tiles, items.
+//   pp6_wave_join   persistent wavefronts, dynamic dequeue.  An item = a tile (or a rectangle of its
+//                   cells) x a frame range: the wavefront gathers the runs of ITS tile from the frames
+//                   (the runs of one tile in 360 frames are the records V3 has to scatter into a
+//                   list), applies each frame's relative pose (the reference's float32 BLAS
+//                   rounding), drops points whose cell has no live point in its 3x3 neighbourhood,
+//                   queues the survivors and joins 64 of them at a time against the live points of
+//                   the window, which sit in a private LDS slice.  No workgroup barrier.
+//
+// A workgroup-per-tile version of the join (rounds of 3072 records sorted in LDS, V3's candidate
+// loops) was measured at 620-1900 us per scan and showed an intermittent memory fault in one
+// configuration; it was removed (DESIGN.md section 4.1 keeps its numbers).
 //
 // Cells.  A point's TILE is the one it was sorted into (float64 world lattice, at insertion).
 // Its CELL inside the tile is recomputed from its float32 common-frame coordinates through the
@@ -44,8 +50,6 @@ constexpr int F_NTILE = F_NTF * F_NTF;
 constexpr int F_NC = F_TS * F_TS;        // 64 cells per tile = sort keys
 constexpr int F_W = F_TS + 2;            // window incl. halo
 constexpr int F_MAXT = 64;               // one lane per traversal in the segmented popcount
-constexpr unsigned F_LANE_GROUPS = 2;    // chunks spanning at least this many cells take the per-lane path
-constexpr unsigned F_LANE_MAX = 64;      // ... for the lanes with at most this many candidates
 
 static_assert(F_NC == 64, "cell key = 6 bits");
 
@@ -242,13 +246,12 @@ __global__ __launch_bounds__(256) void pp5_live_index(const float *__restrict__ 
 // ---- plan ----------------------------------------------------------------------------------
 // One workgroup per tile of the live table.  A tile is active when its 10x10-cell window holds a live
 // point (exact, from the occupancy masks of the 3x3 tiles).  An active tile looks up ITS run in the
-// table of every history frame -- runs[tile * F + f] = (first point, length) -- and cuts the frame
-// list into items (tile, first frame, end frame, points) of about `pmax` points (fewer where many
-// live points surround the tile: the join costs records x candidates) and at most `fmax` frames.
-// Items of tiles with many points are dequeued first.  Item slots come from sharded counters
-// (one device atomic per item on ONE word would serialise at ~11 ns each):
-//   ctrl[8 + s] heavy items of shard s, ctrl[8 + PL_SHARDS + s] light items; shard = tile % PL_SHARDS;
-//   shard s owns items[s * shardCap ...).
+// table of every history frame -- runs[tile * F + f] = (first point, length) --, stores the window's
+// cells (count, start) for the wave items and cuts the frame list into items (tile, first frame, end
+// frame, cell rectangle) of about `wmax` points.  Item slots come from sharded counters (one device
+// atomic per item on ONE word would serialise at ~11 ns each):
+//   ctrl[8 + s] class-H items of shard s, ctrl[8 + PL_SHARDS + s] class-L items; shard = tile % PL_SHARDS;
+//   shard s owns items[s * shardCap ...).  Class H = the rectangles of dense tiles, dequeued first.
 constexpr int PL_T = 256;
 constexpr int PL_MAX_RECTS = 192;     // cell rectangles of a dense tile (wave path)
 constexpr int W_CAP = 128;   // live points a single wavefront keeps in its LDS slice (wave path)
@@ -260,12 +263,12 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
                                                  const unsigned *__restrict__ ltab, int LTX0, int LTY0,
                                                  const unsigned long long *__restrict__ tileOcc,
                                                  const uint4 *__restrict__ tileEdge, const uint2 *__restrict__ cellPk,
-                                                 unsigned pmax, unsigned wmax, unsigned denseItems,
-                                                 unsigned heavy, int fmax, uint2 *__restrict__ runs,
+                                                 unsigned wmax, unsigned denseItems, int fmax,
+                                                 uint2 *__restrict__ runs,
                                                  uint4 *__restrict__ itemsH, uint4 *__restrict__ itemsL,
                                                  unsigned *__restrict__ itemPts /* [2][shards][cap] points per item */,
                                                  uint2 *__restrict__ winTab /* [tile][100] (count, start) of the window cells */,
-                                                 unsigned *__restrict__ tileTotal, unsigned *__restrict__ ctrl) {
+                                                 unsigned *__restrict__ ctrl) {
     extern __shared__ unsigned pre[];   // nFrames + 1 prefix of the run lengths
     __shared__ unsigned wsum[PL_T / 64];
     __shared__ unsigned cuts[PL_ITEMS_PER_TILE + 2];
@@ -281,17 +284,7 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
                                    (occ(tx, ty - 1) & ROW7) | (occ(tx, ty + 1) & ROW0) |
                                    (occ(tx - 1, ty - 1) & (1ULL << 63)) | (occ(tx + 1, ty - 1) & (1ULL << 56)) |
                                    (occ(tx - 1, ty + 1) & (1ULL << 7)) | (occ(tx + 1, ty + 1) & 1ULL);
-    if (!any || nFrames <= 0) {   // uniform
-        if (threadIdx.x == 0) tileTotal[t] = 0;
-        return;
-    }
-    unsigned wt = 0;   // live points of the 3x3 tiles
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = ty + dy;
-        if (yy < 0 || yy >= F_NTF) continue;
-        const int xa = max(tx - 1, 0), xb = min(tx + 1, F_NTF - 1);
-        wt += ltab[yy * F_NTF + xb + 1] - ltab[yy * F_NTF + xa];
-    }
+    if (!any || nFrames <= 0) return;   // uniform
     // exact number of live points in the 10x10-cell window (own tile + the neighbours' border cells)
     unsigned wlive = ltab[t + 1] - ltab[t];
     {
@@ -350,16 +343,12 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
         pre[f] = run;
         run += v;
     }
-    if (tid == 0) {
-        pre[nFrames] = total;
-        tileTotal[t] = total;
-    }
+    if (tid == 0) pre[nFrames] = total;
     __syncthreads();
     if (total == 0) return;   // uniform
     // cuts: a new item starts at frame f when the points before it cross a multiple of `step`, or
     // at every multiple of fmax frames
-    // wmax == 0 (workgroup kernels): every tile is an item class by point count, heavy tiles first.
-    // wmax > 0 (wave path): every item goes to class L for single wavefronts.  A tile whose window
+    // Every item is a wave item.  A tile whose window
     // holds more than W_CAP live points is subdivided: its 8x8 cells are halved recursively until the
     // live points around a rectangle of cells (the rectangle grown by one cell) fit a wavefront's LDS
     // slice; a single cell that still does not fit is split by window row (and, beyond that, the
@@ -370,12 +359,12 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
     __shared__ unsigned short wc[F_W * F_W];
     __shared__ unsigned W2[(F_W + 1) * (F_W + 1)];
     __shared__ unsigned stack[64];
-    const bool dense = wmax != 0 && wlive > (unsigned)W_CAP;
+    const bool dense = wlive > (unsigned)W_CAP;
     if (tid == 0) {
         rects[0] = pp6_full_rect();
         nRects = 1;
     }
-    if (wmax != 0 && tid < F_W * F_W) {   // the window's cells, once per tile: wave items read them in one round trip
+    if (tid < F_W * F_W) {   // the window's cells, once per tile: wave items read them in one round trip
         const int r = tid / F_W, cc = tid - r * F_W;
         const int wx = tx * F_TS - 1 + cc, wy = ty * F_TS - 1 + r;
         unsigned c = 0, g = 0;
@@ -441,15 +430,8 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
     __syncthreads();
     const unsigned nR = nRects;
     if (nR == 0) return;   // uniform
-    unsigned step = pmax;
-    bool hv;
-    if (wmax == 0) {
-        if (wt > heavy) step = max(pmax / min((wt + heavy - 1) / heavy, 8u), 256u);
-        hv = total >= 2 * pmax;
-    } else {
-        hv = dense;   // class H is dequeued first: the rectangles of dense tiles are the long items
-        step = dense ? max(wmax, (unsigned)(((unsigned long long)total * nR + denseItems - 1) / denseItems)) : wmax;
-    }
+    const bool hv = dense;   // class H is dequeued first: the rectangles of dense tiles are the long items
+    unsigned step = dense ? max(wmax, (unsigned)(((unsigned long long)total * nR + denseItems - 1) / denseItems)) : wmax;
     step = max(step, (total + 31) / 32);
     unsigned nc = 0;
     for (int f = max(fa, 1); f < fb; ++f) nc += (pre[f] / step != pre[f - 1] / step) || (f % fmax == 0);
@@ -487,648 +469,17 @@ __global__ __launch_bounds__(PL_T) void pp5_plan(const FrameDev *__restrict__ fr
         const unsigned k = idx / nR, rr = idx - k * nR;   // the rectangles of one frame cut are neighbours
         const unsigned f0 = cuts[k], f1 = (k + 1 == n) ? (unsigned)nFrames : cuts[k + 1];
         if (slotBase + idx < PL_SHARD_CAP) {
-            dst[idx] = make_uint4((unsigned)t, f0, f1, wmax ? rects[rr] : pre[f0]);
+            dst[idx] = make_uint4((unsigned)t, f0, f1, rects[rr]);
             itemPts[((size_t)(hv ? 0 : 1) * PL_SHARDS + t % PL_SHARDS) * PL_SHARD_CAP + slotBase + idx] = pre[f1] - pre[f0];
         }
     }
 }
 
-// exclusive scan of the per-tile point totals: where a tile's records start (split kernels)
-__global__ __launch_bounds__(1024) void pp5_tile_scan(const unsigned *__restrict__ tileTotal,
-                                                      unsigned *__restrict__ tileBase) {
-    __shared__ unsigned wsum[16];
-    constexpr int PER = F_NTILE / 1024;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned v[PER], s = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        v[k] = tileTotal[tid * PER + k];
-        s += v[k];
-    }
-    unsigned inc = s;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned run = inc - s;
-    for (int k = 0; k < w; ++k) run += wsum[k];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        tileBase[tid * PER + k] = run;
-        run += v[k];
-    }
-}
-
-// ---- join -----------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ unsigned pp5_live_bytes(int T) { return 16u + 4u * (unsigned)((T + 1) >> 1); }
 
-struct JoinS5 {
-    unsigned cursor[F_NC];                 // cell histogram -> running cursor -> cell END offsets of the round
-    unsigned cnt[F_W * F_W];               // live points of a window cell
-    unsigned gst[F_W * F_W];               // ... and where they start in `sorted`
-    unsigned short ctab[F_W * (F_W + 1)];  // live points of window row r before column cc
-    unsigned rowBase[F_W + 1];
-    unsigned bandA[F_TS], bandB[F_TS], bandSlow[F_TS];
-    unsigned wsum[16];
-    unsigned nBands, ticket, itemId, nextId, total, nrec;
-    unsigned long long occ;   // bit k: cell k of the tile has a live point in its 3x3 neighbourhood
-    uint4 item, nextItem;
-    unsigned long long prof[8], tlast;   // PROF builds only
-};
-
-// dynamic LDS layout of a join workgroup
-template <int JT, int RPT, int CAP, int FMAX, int FCH>
-struct JoinCfg {
-    static constexpr size_t OFF_IDX = (size_t)CAP * 16;                      // unsigned short sidx[CAP]
-    static constexpr size_t OFF_PRE = OFF_IDX + (((size_t)CAP * 2 + 15) & ~(size_t)15);   // unsigned pre[FMAX + 4]
-    static constexpr size_t OFF_START = OFF_PRE + (size_t)(FMAX + 4) * 4;    // unsigned start[FMAX]
-    static constexpr size_t OFF_PTR = OFF_START + (size_t)FMAX * 4;          // const float *xyz[FMAX]
-    static constexpr size_t OFF_TF = OFF_PTR + (size_t)FMAX * 8;             // int trav_flags[FCH]
-    static constexpr size_t OFF_REL = OFF_TF + (size_t)FCH * 4;              // float rel[FCH][12]
-    static constexpr size_t OFF_LIVE = OFF_REL + (size_t)FCH * 48;           // live points + counters
-    static_assert(OFF_PTR % 8 == 0 && OFF_REL % 16 == 0 && OFF_LIVE % 16 == 0, "alignment");
-    static_assert(CAP < 65536, "16-bit index");
-};
-
-// MODE 0: gather and join fused in one kernel (records never leave the LDS);
-// MODE 1: gather only -- the surviving records of item k go to rec[tileBase[tile] + item.w ...), their
-//         number to itemSurv[k];   MODE 2: join only, from those records.
-// The split pair runs at twice the occupancy of the fused kernel (the gather's registers and the
-// join's LDS do not add up) at the price of one HBM round trip of the records.
-template <int MODE, int JT, int RPT, int CAP, int FMAX, int FCH, bool PROF>
-__global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
-                                               const FrameDev *__restrict__ frames, int nFrames,
-                                               const uint2 *__restrict__ runs, const uint4 *__restrict__ itemsH,
-                                               const uint4 *__restrict__ itemsL, unsigned *ctrl,
-                                               const unsigned *__restrict__ tileBase, float4 *rec,
-                                               unsigned *itemSurv,
-                                               const unsigned *__restrict__ ltab, int LTX0, int LTY0,
-                                               const uint2 *__restrict__ cellPk, const float4 *__restrict__ sorted,
-                                               Map24 A, int *counts, int T, double r2, unsigned ldsBytes,
-                                               unsigned long long *stats, int nShards) {
-    using C = JoinCfg<JT, RPT, CAP, FMAX, FCH>;
-    extern __shared__ __align__(16) unsigned char dynsm[];
-    __shared__ JoinS5 S;
-    float4 *srec = reinterpret_cast<float4 *>(dynsm);   // records of the round, in arrival order
-    unsigned short *sidx = reinterpret_cast<unsigned short *>(dynsm + C::OFF_IDX);   // ... sorted by cell
-    unsigned *fpre = reinterpret_cast<unsigned *>(dynsm + C::OFF_PRE);
-    unsigned *fstart = reinterpret_cast<unsigned *>(dynsm + C::OFF_START);
-    const float **fptr = reinterpret_cast<const float **>(dynsm + C::OFF_PTR);
-    int *ftf = reinterpret_cast<int *>(dynsm + C::OFF_TF);
-    float *frel = reinterpret_cast<float *>(dynsm + C::OFF_REL);
-    float4 *live = reinterpret_cast<float4 *>(dynsm + C::OFF_LIVE);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int Th = (T + 1) >> 1;
-    const unsigned liveBytes = pp5_live_bytes(T);
-    const unsigned lcap = (ldsBytes - (unsigned)C::OFF_LIVE) / liveBytes;
-    unsigned *cntw = reinterpret_cast<unsigned *>(live + lcap);
-    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
-    const float r2f = (float)r2, bandw = (float)(r2 * 1.5e-6);
-    __shared__ unsigned shardEnd[2 * PL_SHARDS];   // inclusive prefix of the shard counters, heavy shards first
-    if (tid < 64) {
-        const unsigned c0 = tid < nShards ? min(ctrl[8 + tid], PL_SHARD_CAP) : 0u;   // nShards = PL_SHARDS: class H only
-        unsigned inc = c0;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u = __shfl_up(inc, o);
-            if (lane >= o) inc += u;
-        }
-        if (tid < 2 * PL_SHARDS) shardEnd[tid] = inc;
-    }
-    if (PROF && tid < 8) S.prof[tid] = 0;
-    __syncthreads();
-    const unsigned nItems = shardEnd[nShards - 1];
-#define PP5_TICK(k)                                     \
-    if (PROF && tid == 0) {                              \
-        const unsigned long long now_ = wall_clock64(); \
-        S.prof[k] += now_ - S.tlast;                     \
-        S.tlast = now_;                                  \
-    }
-    auto fetch_item = [&](unsigned id) -> uint4 {
-        int lo = 0, hi = nShards - 1;   // first shard whose end exceeds id
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (shardEnd[mid] > id) hi = mid;
-            else lo = mid + 1;
-        }
-        const unsigned k = id - (lo ? shardEnd[lo - 1] : 0u);
-        const uint4 *src = lo < PL_SHARDS ? itemsH + (size_t)lo * PL_SHARD_CAP : itemsL + (size_t)(lo - PL_SHARDS) * PL_SHARD_CAP;
-        return src[k];
-    };
-    // counters of live points [0, Lb) -> the global count matrix
-    auto flush_counters = [&](unsigned Lb, bool clear) {
-        for (unsigned e = tid; e < Lb * Th; e += JT) {
-            const unsigned cw = cntw[e];
-            if (cw) {
-                const unsigned p = e / Th, tp = (e - p * Th) * 2;
-                const size_t row = (size_t)__float_as_int(live[p].w) * T;
-                if (cw & 0xffffu) atomicAdd(&counts[row + tp], (int)(cw & 0xffffu));
-                if (cw >> 16) atomicAdd(&counts[row + tp + 1], (int)(cw >> 16));
-                if (clear) cntw[e] = 0;
-            }
-        }
-    };
-    // live points of window rows [ya-1, yb] into LDS, their counters zeroed
-    auto load_live = [&](int ya, unsigned lbase, unsigned Lb) {
-        for (unsigned e = tid; e < Lb; e += JT) {
-            int r = ya - 1;
-            while (e + lbase >= S.rowBase[r + 1]) ++r;
-            const unsigned pos = e + lbase - S.rowBase[r];
-            const unsigned short *row = S.ctab + r * (F_W + 1);
-            int cc = 0;
-            while (pos >= row[cc + 1]) ++cc;
-            live[e] = sorted[S.gst[r * F_W + cc] + (pos - row[cc])];
-        }
-        for (unsigned e = tid; e < Lb * Th; e += JT) cntw[e] = 0;
-    };
-    if (tid == 0) {
-        const unsigned first = atomicAdd(&ctrl[1], 1u);
-        S.itemId = first;
-        if (first < nItems) S.item = fetch_item(first);
-    }
-    for (;;) {
-        __syncthreads();
-        if (PROF && tid == 0) S.tlast = wall_clock64();
-        const unsigned iid = S.itemId;
-        if (iid >= nItems) break;
-        const uint4 it = S.item;
-        __syncthreads();   // everyone holds the item: thread 0 may fetch the next one
-        if (tid == 0) S.nextId = atomicAdd(&ctrl[1], 1u);
-        const int ttx = (int)(it.x % F_NTF), tty = (int)(it.x / F_NTF);
-        const int gtx = LTX0 + ttx, gty = LTY0 + tty;
-        const int f0 = (int)it.y, nf = min((int)(it.z - it.y), FMAX);
-        const int x0 = ttx * F_TS - 1, y0 = tty * F_TS - 1;   // window origin in table-local cells
-
-        // ---- (a) window cells and the tile's runs (looked up by pp5_plan): one round trip ---------
-        if (tid < F_W * F_W) {
-            const int r = tid / F_W, cc = tid - r * F_W;
-            const int wx = x0 + cc, wy = y0 + r;
-            unsigned c = 0, g = 0;
-            if (wx >= 0 && wy >= 0 && wx < F_NTF * F_TS && wy < F_NTF * F_TS) {
-                const int tile = (wy >> 3) * F_NTF + (wx >> 3);
-                const unsigned ta = ltab[tile], tb = ltab[tile + 1];
-                if (tb > ta) {
-                    const uint2 pk = cellPk[(size_t)tile * F_NC + (wy & 7) * F_TS + (wx & 7)];
-                    c = pk.y;
-                    g = ta + pk.x;
-                }
-            }
-            S.cnt[tid] = c;
-            S.gst[tid] = g;
-        }
-        const size_t ibase = MODE ? (size_t)tileBase[it.x] + it.w : 0;   // the item's records (split kernels)
-        if (MODE == 2 && tid == JT - 1) S.total = itemSurv[iid];
-        for (int j = tid; MODE != 2 && j < nf; j += JT) {
-            const uint2 rn = runs[(size_t)it.x * nFrames + f0 + j];
-            const float2 h0 = *reinterpret_cast<const float2 *>(frames + f0 + j);
-            fstart[j] = rn.x;
-            fpre[j] = rn.y;   // scanned below
-            fptr[j] = reinterpret_cast<const float *>(
-                ((unsigned long long)__float_as_uint(h0.y) << 32) | (unsigned long long)__float_as_uint(h0.x));
-        }
-        if (tid == 0 && S.nextId < nItems) S.nextItem = fetch_item(S.nextId);
-        __syncthreads();
-        PP5_TICK(0)
-        // ---- (b) window tables, occupancy, bands, run prefix ------------------------------------
-        if (tid < 64) {   // dilated occupancy of the tile's own cells
-            const int kx = tid & 7, ky = tid >> 3;
-            unsigned s = 0;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) s |= S.cnt[(ky + dy) * F_W + kx + dx];
-            const unsigned long long bal = __ballot(s != 0u);
-            if (tid == 0) S.occ = bal;
-        } else if (tid < 64 + F_W) {   // positions inside a window row
-            const int r = tid - 64;
-            unsigned run = 0;
-            for (int cc = 0; cc < F_W; ++cc) {
-                S.ctab[r * (F_W + 1) + cc] = (unsigned short)min(run, 65535u);
-                run += S.cnt[r * F_W + cc];
-            }
-            S.ctab[r * (F_W + 1) + F_W] = (unsigned short)min(run, 65535u);
-        }
-        if constexpr (MODE != 2) {   // exclusive scan of the run lengths
-            constexpr int PER = (FMAX + JT - 1) / JT;
-            unsigned v[PER], s = 0;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int j = tid * PER + k;
-                v[k] = j < nf ? fpre[j] : 0u;
-                s += v[k];
-            }
-            unsigned inc = s;
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned u = __shfl_up(inc, o);
-                if (lane >= o) inc += u;
-            }
-            if (lane == 63) S.wsum[tid >> 6] = inc;
-            __syncthreads();
-            unsigned run = inc - s;
-            for (int k = 0; k < (tid >> 6); ++k) run += S.wsum[k];
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int j = tid * PER + k;
-                if (j < nf) fpre[j] = run;
-                run += v[k];
-            }
-            if (tid == JT - 1) {
-                fpre[nf] = run;
-                S.total = run;
-            }
-        }
-        if (tid == 0) {   // window rows -> prefix, bands of cell rows that fit the live budget
-            unsigned rl[F_W], run = 0;
-            for (int r = 0; r < F_W; ++r) {
-                unsigned s = 0;
-                for (int cc = 0; cc < F_W; ++cc) s += S.cnt[r * F_W + cc];
-                rl[r] = s;
-                S.rowBase[r] = run;
-                run += s;
-            }
-            S.rowBase[F_W] = run;
-            unsigned nb = 0;
-            int ya = 1;
-            while (ya <= F_TS) {
-                unsigned sum = rl[ya - 1] + rl[ya] + rl[ya + 1];
-                int yb = ya + 1;
-                const unsigned slow = (sum > lcap || sum > 65535u) ? 1u : 0u;
-                if (!slow)
-                    while (yb <= F_TS && sum + rl[yb + 1] <= lcap && sum + rl[yb + 1] <= 65535u) {
-                        sum += rl[yb + 1];
-                        ++yb;
-                    }
-                S.bandA[nb] = (unsigned)ya;
-                S.bandB[nb] = (unsigned)yb;
-                S.bandSlow[nb] = slow;
-                ++nb;
-                ya = yb;
-            }
-            S.nBands = nb;
-        }
-        __syncthreads();
-        const unsigned long long occ = S.occ;
-        const unsigned P = occ ? S.total : 0u;   // MODE 2: surviving records of the item
-        const unsigned nBands = S.nBands;
-        const bool single = nBands == 1 && !S.bandSlow[0];   // the whole window stays in LDS for the item
-        unsigned sinceFlush = 0;
-        PP5_TICK(1)
-        if (MODE != 1 && P && single) load_live(1, 0u, S.rowBase[F_W]);   // in flight while the first points are gathered
-        if (MODE == 1) {
-            if (tid == 0) S.nrec = 0;
-            __syncthreads();
-        }
-
-        // ---- rounds: gather up to CAP surviving records, sort them by cell, join ---------------
-        unsigned pos = 0;          // next point of the item (uniform)
-        int chunk = -1;            // frame chunk whose poses are in LDS
-        while (pos < P) {
-            __syncthreads();   // the previous round is done with the cursors and the records
-            if (MODE != 1) {
-                if (tid < F_NC) S.cursor[tid] = 0;
-                if (tid == 0) S.nrec = 0;
-                __syncthreads();
-            }
-            if (MODE == 2) {   // the records were gathered by the MODE 1 launch: contiguous copy
-                const unsigned n = min(P - pos, (unsigned)CAP);
-                for (unsigned s = tid; s < n; s += JT) {
-                    const float4 r = rec[ibase + pos + s];
-                    srec[s] = r;
-                    atomicAdd(&S.cursor[__float_as_int(r.w) & (F_NC - 1)], 1u);
-                }
-                if (tid == 0) S.nrec = n;
-                pos += n;
-                __syncthreads();
-            }
-            // ---- (c) gather + transform + filter, appended in arrival order -------------------
-            for (; MODE != 2;) {
-                int c = chunk < 0 ? 0 : chunk;
-                while (fpre[min((c + 1) * FCH, nf)] <= pos) ++c;   // chunk holding `pos` (skips empty ones)
-                const int c0 = c * FCH, c1 = min(c0 + FCH, nf);
-                const unsigned cend = fpre[c1];
-                float4 m0, m1, m2;
-                int tfv = 0;
-                const bool loadRel = c != chunk && tid < c1 - c0;
-                if (loadRel) {
-                    const float4 *q = reinterpret_cast<const float4 *>(frames + f0 + c0 + tid);
-                    tfv = __float_as_int(q[1].w);
-                    m0 = q[2];
-                    m1 = q[3];
-                    m2 = q[4];
-                }
-                float px[RPT], py[RPT], pz[RPT];
-                int pj[RPT];
-#pragma unroll
-                for (int u = 0; u < RPT; ++u) {
-                    const unsigned i = pos + tid + u * JT;
-                    pj[u] = -1;
-                    px[u] = py[u] = pz[u] = 0.f;
-                    if (i < cend) {
-                        int lo = c0, hi = c1;   // largest j with fpre[j] <= i
-                        while (hi - lo > 1) {
-                            const int mid = (lo + hi) >> 1;
-                            if (fpre[mid] <= i) lo = mid;
-                            else hi = mid;
-                        }
-                        const float *src = fptr[lo] + 3 * (size_t)(fstart[lo] + (i - fpre[lo]));
-                        px[u] = src[0];
-                        py[u] = src[1];
-                        pz[u] = src[2];
-                        pj[u] = lo - c0;
-                    }
-                }
-                if (c != chunk) {   // uniform
-                    __syncthreads();   // nobody still reads the previous chunk's poses
-                    if (loadRel) {
-                        ftf[tid] = tfv;
-                        float4 *rd = reinterpret_cast<float4 *>(frel + 12 * tid);
-                        rd[0] = m0;
-                        rd[1] = m1;
-                        rd[2] = m2;
-                    }
-                    chunk = c;
-                    __syncthreads();
-                }
-#pragma unroll
-                for (int u = 0; u < RPT; ++u) {
-                    bool keep = false;
-                    float4 recv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    int key = 0;
-                    if (pj[u] >= 0) {
-                        const int tf = ftf[pj[u]];
-                        const bool drop = ((tf >> 16) & F_FLAG_CENTER) && (px[u] < 1.75f) && (px[u] >= -1.15f) &&
-                                          (py[u] < 0.65f) && (py[u] >= -0.65f);
-                        float o[3];
-                        rel_apply(frel + 12 * pj[u], px[u], py[u], pz[u], o);
-                        key = cell_in_tile(A, o[0], o[1], o[2], gtx, gty);
-                        keep = !drop && ((occ >> key) & 1ULL);
-                        recv = make_float4(o[0], o[1], o[2], __int_as_float(key | ((tf & 0xffff) << 16)));
-                    }
-                    const unsigned long long bal = __ballot(keep);
-                    if (bal) {
-                        unsigned base = 0;
-                        if (lane == 0) base = atomicAdd(&S.nrec, (unsigned)__popcll(bal));
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (keep) {
-                            const unsigned slot = base + __popcll(bal & ((1ULL << lane) - 1ULL));
-                            if (MODE == 1) {
-                                rec[ibase + slot] = recv;
-                            } else {
-                                srec[slot] = recv;
-                                atomicAdd(&S.cursor[key], 1u);
-                            }
-                        }
-                    }
-                }
-                pos = min(pos + (unsigned)(JT * RPT), cend);
-                __syncthreads();
-                if (pos >= P || (MODE == 0 && S.nrec + (unsigned)(JT * RPT) > (unsigned)CAP)) break;
-            }
-            PP5_TICK(2)
-            if (MODE == 1) continue;   // gather only: pos == P
-            const unsigned nRec = S.nrec;
-            if (nRec == 0) continue;
-            // ---- sort: cell offsets, then the index of the records by cell -----------------------
-            if (tid < 64) {
-                const unsigned c0 = S.cursor[tid];
-                unsigned inc = c0;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned u = __shfl_up(inc, o);
-                    if (lane >= o) inc += u;
-                }
-                S.cursor[tid] = inc - c0;
-            }
-            __syncthreads();
-            for (unsigned s = tid; s < nRec; s += JT) {
-                const int pk = __float_as_int(srec[s].w);
-                sidx[atomicAdd(&S.cursor[pk & (F_NC - 1)], 1u)] = (unsigned short)s;
-            }
-            // cursor[k] is now the END of cell k; cell k starts at cursor[k-1]
-            const bool resident = single;   // loaded before the first round
-            if (sinceFlush + nRec > 60000u) {   // 16-bit counters: flush before they can overflow
-                __syncthreads();
-                if (resident) flush_counters(S.rowBase[F_W], true);
-                sinceFlush = 0;
-            }
-            sinceFlush += nRec;
-            __syncthreads();
-            PP5_TICK(3)
-
-            // ---- (d) bands of cell rows ------------------------------------------------------
-            for (unsigned b = 0; b < nBands; ++b) {
-                const int ya = (int)S.bandA[b], yb = (int)S.bandB[b];
-                const unsigned lbase = S.rowBase[ya - 1];
-                const unsigned Lb = S.rowBase[yb + 1] - lbase;
-                const bool slow = S.bandSlow[b] != 0;
-                const unsigned kA = (unsigned)(ya - 1) * F_TS, kB = (unsigned)(yb - 1) * F_TS;
-                const unsigned ra = kA ? S.cursor[kA - 1] : 0u, rb = S.cursor[kB - 1];
-                if (ra == rb) continue;   // uniform: no record in these rows
-                if (slow) {
-                    // a single row of cells whose three live rows exceed the LDS budget: global index
-                    for (unsigned j = ra + tid; j < rb; j += JT) {
-                        const float4 h = srec[sidx[j]];
-                        const int pk = __float_as_int(h.w);
-                        const int tr = pk >> 16;
-                        const int lx = (pk & (F_TS - 1)) + 1, ly = ((pk & (F_NC - 1)) / F_TS) + 1;
-                        for (int yy = ly - 1; yy <= ly + 1; ++yy)
-                            for (int xx = lx - 1; xx <= lx + 1; ++xx) {
-                                const unsigned g = S.gst[yy * F_W + xx], e = g + S.cnt[yy * F_W + xx];
-                                for (unsigned i = g; i < e; ++i) {
-                                    const float4 q = sorted[i];
-                                    if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2))
-                                        atomicAdd(&counts[(size_t)__float_as_int(q.w) * T + tr], 1);
-                                }
-                            }
-                    }
-                    continue;
-                }
-                if (!resident) {
-                    __syncthreads();   // previous band's flush complete
-                    load_live(ya, lbase, Lb);
-                }
-                if (tid == 0) S.ticket = 0;
-                __syncthreads();
-                PP5_TICK(4)
-
-                // 64-record chunks of the sorted band range, dealt to wavefronts
-                const unsigned nChunks = (rb - ra + 63) / 64;
-                for (;;) {
-                    unsigned ck = 0;
-                    if (lane == 0) ck = atomicAdd(&S.ticket, 1u);
-                    ck = __builtin_amdgcn_readfirstlane(ck);
-                    if (ck >= nChunks) break;
-                    const unsigned j = ra + ck * 64 + lane;
-                    const bool valid = j < rb;
-                    const float4 h = valid ? srec[sidx[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int pk = valid ? __float_as_int(h.w) : -1;
-                    const int key = pk & (F_NC - 1);
-                    const unsigned trv = (unsigned)(pk >> 16) & 63u;
-                    int lq = lane;
-                    asm volatile("" : "+v"(lq));
-                    const unsigned sel0 = (lq & 1) ? 0u : ~0u, sel1 = (lq & 2) ? 0u : ~0u;
-                    const unsigned sel2 = (lq & 4) ? 0u : ~0u, sel3 = (lq & 8) ? 0u : ~0u, sel4 = (lq & 16) ? 0u : ~0u;
-                    const unsigned cshift = (lq & 1) * 16;
-                    const unsigned laneWord = (unsigned)lq >> 1;
-                    // traversal segment masks: lane t keeps the lanes whose record belongs to traversal t
-                    unsigned long long seg = __ballot(valid);
-                    {
-                        const unsigned long long B0 = __ballot(trv & 1u), B1 = __ballot(trv & 2u);
-                        const unsigned long long B2 = __ballot(trv & 4u), B3 = __ballot(trv & 8u), B4 = __ballot(trv & 16u);
-                        const unsigned long long s0 = ((unsigned long long)sel0 << 32) | sel0;
-                        const unsigned long long s1 = ((unsigned long long)sel1 << 32) | sel1;
-                        const unsigned long long s2 = ((unsigned long long)sel2 << 32) | sel2;
-                        const unsigned long long s3 = ((unsigned long long)sel3 << 32) | sel3;
-                        const unsigned long long s4 = ((unsigned long long)sel4 << 32) | sel4;
-                        seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3) & (B4 ^ s4);
-                        if (T > 32) {
-                            const unsigned sel5 = (lq & 32) ? 0u : ~0u;
-                            seg &= __ballot(trv & 32u) ^ (((unsigned long long)sel5 << 32) | sel5);
-                        }
-                    }
-                    const unsigned segLo = (unsigned)seg, segHi = (unsigned)(seg >> 32);
-                    unsigned long long todo = __ballot(valid);
-                    {   // sparse chunks: every lane walks its own candidate list
-                        const int prevKey = __shfl_up(key, 1);
-                        const unsigned nG = __popcll(__ballot(valid && (lane == 0 || key != prevKey)));
-                        if (nG >= F_LANE_GROUPS) {
-                            const int lx = (key & (F_TS - 1)) + 1, ly = key / F_TS + 1;
-                            const unsigned short *row = S.ctab + (ly - 1) * (F_W + 1) + lx - 1;
-                            const unsigned c00 = row[0], c10 = row[F_W + 1], c20 = row[2 * (F_W + 1)];
-                            const unsigned n0 = row[3] - c00, n1 = row[F_W + 4] - c10;
-                            const unsigned n2 = row[2 * (F_W + 1) + 3] - c20;
-                            const unsigned a0 = S.rowBase[ly - 1] - lbase + c00;
-                            const unsigned n01 = n0 + n1, nAll = n01 + n2;
-                            const unsigned b1 = S.rowBase[ly] - lbase + c10 - n0;
-                            const unsigned b2 = S.rowBase[ly + 1] - lbase + c20 - n01;
-                            const bool mine = valid && nAll <= F_LANE_MAX;
-                            const unsigned own = mine ? nAll : 0u;
-                            const unsigned cword = trv >> 1, cinc = 1u << ((trv & 1u) * 16);
-                            for (unsigned p0 = 0; __any(p0 < own); p0 += 4) {
-                                unsigned bandBits = 0;
-#pragma unroll
-                                for (unsigned u = 0; u < 4; ++u) {
-                                    const unsigned p = p0 + u;
-                                    const bool act = p < own;
-                                    const unsigned i = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
-                                    const float4 q = live[i];
-                                    const float fx = q.x - h.x, fy = q.y - h.y, fz = q.z - h.z;
-                                    const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                    const bool hit = act && d2 < r2lo;
-                                    bandBits |= (act && !hit && d2 <= r2hi) ? (1u << u) : 0u;
-                                    if (hit) atomicAdd(&cntw[i * Th + cword], cinc);
-                                }
-                                while (bandBits) {   // practically never: exact float64 re-test
-                                    const unsigned u = __ffs((int)bandBits) - 1;
-                                    bandBits &= bandBits - 1;
-                                    const unsigned p = p0 + u;
-                                    const unsigned i = p + (p < n0 ? a0 : (p < n01 ? b1 : b2));
-                                    const float4 q = live[i];
-                                    if (pp_within(h.x, h.y, h.z, q.x, q.y, q.z, r2)) atomicAdd(&cntw[i * Th + cword], cinc);
-                                }
-                            }
-                            todo = __ballot(valid && !mine);
-                        }
-                    }
-                    while (todo) {   // one cell group at a time (wave-uniform)
-                        const int src = __ffsll((long long)todo) - 1;
-                        const int gkey = __builtin_amdgcn_readlane(key, src);
-                        const unsigned long long grp = __ballot(valid && key == gkey);
-                        todo &= ~grp;
-                        const int lcx = (gkey & (F_TS - 1)) + 1, lcy = gkey / F_TS + 1;
-                        const unsigned short *row = S.ctab + (lcy - 1) * (F_W + 1) + lcx - 1;
-                        const unsigned rb0 = S.rowBase[lcy - 1] - lbase, rb1 = S.rowBase[lcy] - lbase;
-                        const unsigned rb2 = S.rowBase[lcy + 1] - lbase;
-                        const unsigned c00 = row[0], c03 = row[3], c10 = row[F_W + 1], c13 = row[F_W + 4];
-                        const unsigned c20 = row[2 * (F_W + 1)], c23 = row[2 * (F_W + 1) + 3];
-                        const unsigned a0 = __builtin_amdgcn_readfirstlane(rb0 + c00);
-                        const unsigned n0 = __builtin_amdgcn_readfirstlane(c03 - c00);
-                        const unsigned a1 = __builtin_amdgcn_readfirstlane(rb1 + c10);
-                        const unsigned n1 = __builtin_amdgcn_readfirstlane(c13 - c10);
-                        const unsigned a2 = __builtin_amdgcn_readfirstlane(rb2 + c20);
-                        const unsigned n2 = __builtin_amdgcn_readfirstlane(c23 - c20);
-                        float dmin = 3.0e38f;
-#pragma unroll 1
-                        for (int rr = 0; rr < 3; ++rr) {
-                            const unsigned ra_ = rr == 0 ? a0 : (rr == 1 ? a1 : a2);
-                            const unsigned re_ = ra_ + (rr == 0 ? n0 : (rr == 1 ? n1 : n2));
-                            for (unsigned i = ra_; i < re_; i += 4) {
-                                // reads past the end of a run see the next row or the counters: masked out
-                                const float4 q0 = live[i], q1 = live[i + 1], q2 = live[i + 2], q3 = live[i + 3];
-                                float fx, fy, fz;
-                                fx = q0.x - h.x, fy = q0.y - h.y, fz = q0.z - h.z;
-                                const float d0 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                fx = q1.x - h.x, fy = q1.y - h.y, fz = q1.z - h.z;
-                                const float d1 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                fx = q2.x - h.x, fy = q2.y - h.y, fz = q2.z - h.z;
-                                const float d2_ = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                fx = q3.x - h.x, fy = q3.y - h.y, fz = q3.z - h.z;
-                                const float d3 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                const unsigned long long h0 = __ballot(d0 < r2lo) & grp;
-                                const unsigned long long h1 = (i + 1 < re_) ? (__ballot(d1 < r2lo) & grp) : 0ULL;
-                                const unsigned long long h2 = (i + 2 < re_) ? (__ballot(d2_ < r2lo) & grp) : 0ULL;
-                                const unsigned long long h3 = (i + 3 < re_) ? (__ballot(d3 < r2lo) & grp) : 0ULL;
-                                dmin = fminf(dmin, fminf(fminf(fabsf(d0 - r2f), fabsf(d1 - r2f)),
-                                                         fminf(fabsf(d2_ - r2f), fabsf(d3 - r2f))));
-                                if (h0 | h1 | h2 | h3) {
-                                    const unsigned c0 = __popc((unsigned)h0 & segLo) + __popc((unsigned)(h0 >> 32) & segHi);
-                                    const unsigned c1 = __popc((unsigned)h1 & segLo) + __popc((unsigned)(h1 >> 32) & segHi);
-                                    const unsigned c2 = __popc((unsigned)h2 & segLo) + __popc((unsigned)(h2 >> 32) & segHi);
-                                    const unsigned c3 = __popc((unsigned)h3 & segLo) + __popc((unsigned)(h3 >> 32) & segHi);
-                                    if (lane < T) {
-                                        unsigned *cw = cntw + i * Th + laneWord;
-                                        atomicAdd(cw, c0 << cshift);
-                                        if (i + 1 < re_) atomicAdd(cw + Th, c1 << cshift);
-                                        if (i + 2 < re_) atomicAdd(cw + 2 * Th, c2 << cshift);
-                                        if (i + 3 < re_) atomicAdd(cw + 3 * Th, c3 << cshift);
-                                    }
-                                }
-                            }
-                        }
-                        if (__ballot(dmin <= bandw) & grp) {   // practically never: exact float64 re-test
-                            const unsigned n01 = n0 + n1, nAll = n01 + n2;
-                            const unsigned b1 = a1 - n0, b2 = a2 - n01;
-                            for (unsigned i = 0; i < nAll; ++i) {
-                                const unsigned p = i + (i < n0 ? a0 : (i < n01 ? b1 : b2));
-                                const float4 qq = live[p];
-                                const float fx = qq.x - h.x, fy = qq.y - h.y, fz = qq.z - h.z;
-                                const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                const bool inBand = (d2 >= r2lo) && (fabsf(d2 - r2f) <= bandw);
-                                const unsigned long long hx =
-                                    __ballot(inBand && pp_within(h.x, h.y, h.z, qq.x, qq.y, qq.z, r2)) & grp;
-                                if (hx) {
-                                    const unsigned cN = __popc((unsigned)hx & segLo) + __popc((unsigned)(hx >> 32) & segHi);
-                                    if (lane < T && cN) atomicAdd(&cntw[p * Th + laneWord], cN << cshift);
-                                }
-                            }
-                        }
-                    }
-                                }
-                __syncthreads();
-                PP5_TICK(5)
-                if (!resident) {   // flush this band's counters (a resident window is flushed once per item)
-                    flush_counters(Lb, false);
-                    sinceFlush = 0;
-                }
-            }
-        }
-        __syncthreads();
-        if (MODE != 1 && P && single) flush_counters(S.rowBase[F_W], false);
-        if (MODE == 1 && tid == 0) itemSurv[iid] = P ? S.nrec : 0u;
-        PP5_TICK(6)
-        if (tid == 0) {
-            S.itemId = S.nextId;
-            S.item = S.nextItem;
-        }
-    }
-    if (PROF && tid == 0)
-        for (int k = 0; k < 7; ++k) atomicAdd(&stats[k], S.prof[k]);
-#undef PP5_TICK
-}
-
 // ---- wave-autonomous join (MODEST_PP_FRAMES_PATH=gather-wave) ----------------------------------
-// The workgroup-sized items of pp5_join are latency bound: chains of
-// dependent round trips fenced by workgroup barriers, 16 wavefronts per CU.  Here ONE wavefront owns
+// Workgroup-sized items were latency bound: chains of dependent round trips
+// fenced by workgroup barriers, 16 wavefronts per CU.  Here ONE wavefront owns
 // an item end to end: a tile (or a rectangle of its cells) x a frame range of about a thousand points
 // x a range of window rows whose live points (<= W_CAP) and counters sit in a private LDS slice.
 // There is no workgroup barrier; every wavefront of the chip works on its own item and their round
@@ -1141,6 +492,7 @@ __global__ __launch_bounds__(JT, MODE == 0 ? 1 : 2 * JT / 256) void pp5_join(
 // item joins and the window rows (0..9) whose live points it holds.
 constexpr int W_WAVES = 4;   // wavefronts per workgroup (they never synchronise with each other)
 constexpr int W_DEPTH = 4;   // batches of 64 points whose loads are in flight together
+constexpr int W_FMAX = 384;  // frames per item (an item's frame list is walked 64 at a time; the cut keeps items short)
 __host__ __device__ __forceinline__ unsigned pp6_slice_bytes(int T) {
     // live points + counters + cell counts (u16 [100]) + row tables (u16 [10][11], u32 [11]), 16-B multiple
     // ... + the queue of surviving records (128 x 16 B)
@@ -1504,21 +856,6 @@ __global__ void pp5_entropy_kernel(const int *__restrict__ counts, int n, int T,
     H[i] = (float)(res / log((double)T));
 }
 
-// launch geometry.  Fused kernel: two 512-thread workgroups per CU, gather rounds of 1536 points, up
-// to 3072 surviving records sorted and joined at a time.  Split kernels: gather = 256-thread
-// workgroups with no record buffer in LDS; join = two 512-thread workgroups per CU, 3072 records.
-constexpr int J_JT = 512, J_RPT = 3, J_CAP = 3072, J_FMAX = 384, J_FCH = 128;
-using JCfg = JoinCfg<J_JT, J_RPT, J_CAP, J_FMAX, J_FCH>;
-constexpr unsigned J_LDS = 78 * 1024;
-static_assert(JCfg::OFF_LIVE + 4096 < J_LDS, "room for the live window");
-constexpr int G_JT = 256, G_RPT = 4;
-using GCfg = JoinCfg<G_JT, G_RPT, 0, J_FMAX, J_FCH>;
-constexpr unsigned G_LDS = (unsigned)GCfg::OFF_LIVE + 64;
-constexpr int K_JT = 512, K_CAP = 3072;
-using KCfg = JoinCfg<K_JT, 1, K_CAP, 4, 4>;
-constexpr unsigned K_LDS = 78 * 1024;
-static_assert(KCfg::OFF_LIVE + 4096 < K_LDS, "room for the live window");
-
 }  // namespace
 
 extern "C" int modest_frame_table_tiles(void) { return F_NTF; }
@@ -1594,26 +931,19 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     // Default: the V3 streaming kernels read the frames through the descriptor table with the pose
-    // fused (pp_count.hip).  MODEST_PP_FRAMES_PATH=gather / gather-fused selects the gather-join
-    // of this file (one pass over the history, measured slower so far: DESIGN.md section 4.1).
+    // fused (pp_count.hip).  MODEST_PP_FRAMES_PATH=gather-wave selects the one-pass gather-join of this
+    // file (wave-autonomous items; measured slower so far: DESIGN.md section 4.1).
     const char *path = getenv("MODEST_PP_FRAMES_PATH");
-    if (!path || strncmp(path, "gather", 6) != 0)
+    if (!path || strcmp(path, "gather-wave") != 0)
         return modest_pp3_frames(ctx, live, live_perm_dev, frames, n_frames, n_trav, radius, counts_dev, H_dev, stream);
 
     const size_t shardItems = (size_t)PL_SHARDS * PL_SHARD_CAP;
-    const bool fused = strcmp(path, "gather-fused") == 0;
-    const bool wave = strcmp(path, "gather-wave") == 0;   // dense tiles: fused workgroup kernel, the rest: one wavefront per item
-    size_t totalPts = 0;
-    if (!fused && !wave)
-        for (int f = 0; f < n_frames; ++f) totalPts += (size_t)frames[f].n;
-    MODEST_REQUIRE(totalPts < (1ULL << 31), "history must hold fewer than 2^31 points");
     MODEST_REQUIRE(n_frames < (1 << 15), "too many frames");
     const size_t descBytes = arena_sz((size_t)(n_frames > 0 ? n_frames : 1) * sizeof(FrameDev));
     size_t need = descBytes + arena_sz((size_t)N * 16) + arena_sz((size_t)F_NTILE * F_NC * 8) +
-                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz((size_t)F_NTILE * 100 * 8) + arena_sz(1024) + 3 * arena_sz(shardItems * 16) + arena_sz(64 * 8) +
-                  arena_sz((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1) * 8) + 2 * arena_sz((size_t)F_NTILE * 4) +
-                  arena_sz(shardItems * 2 * 4) + arena_sz((size_t)(totalPts + 1) * 16) +
-                  arena_sz((size_t)N * T * 4);
+                  arena_sz((size_t)F_NTILE * 8) + arena_sz((size_t)F_NTILE * 32) + arena_sz((size_t)F_NTILE * 100 * 8) +
+                  arena_sz(1024) + 2 * arena_sz(shardItems * 16) + arena_sz(shardItems * 2 * 4) + arena_sz(64 * 8) +
+                  arena_sz((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1) * 8) + arena_sz((size_t)N * T * 4);
     int rc = modest_ctx_reserve(ctx, need);
     if (rc) return rc;
     Arena Ar(ctx->scratch);
@@ -1628,10 +958,6 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     uint4 *itemsL = Ar.take<uint4>(shardItems);
     unsigned *itemPts = Ar.take<unsigned>(shardItems * 2);
     uint2 *runs = Ar.take<uint2>((size_t)F_NTILE * (n_frames > 0 ? n_frames : 1));
-    unsigned *tileTotal = Ar.take<unsigned>(F_NTILE);
-    unsigned *tileBase = Ar.take<unsigned>(F_NTILE);
-    unsigned *itemSurv = Ar.take<unsigned>(shardItems * 2);
-    float4 *rec = Ar.take<float4>(totalPts + 1);
     unsigned long long *stats = Ar.take<unsigned long long>(64);
     int32_t *counts = counts_dev ? counts_dev : Ar.take<int32_t>((size_t)N * T);
 
@@ -1667,118 +993,61 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
                                                            live->TY0, rel, A, sorted, cellPk, tileOcc, tileEdge, counts,
                                                            (size_t)N * T, ctrl);
     if (n_frames > 0) {
-        const char *hv = getenv("MODEST_PP5_HEAVY");
-        const unsigned heavy = hv ? (unsigned)atoi(hv) : 256u;
-        const char *pm = getenv("MODEST_PP5_PMAX");
-        const unsigned pmax = pm ? (unsigned)atoi(pm) : 6144u;
         const char *wm = getenv("MODEST_PP6_WMAX");
-        const unsigned wmax = wm ? (unsigned)atoi(wm) : 768u;
+        const unsigned wmax = wm && atoi(wm) > 0 ? (unsigned)atoi(wm) : 768u;
         const char *dm = getenv("MODEST_PP6_DENSE_ITEMS");
-        const unsigned denseItems = dm ? (unsigned)atoi(dm) : 1024u;
+        const unsigned denseItems = dm && atoi(dm) > 0 ? (unsigned)atoi(dm) : 256u;
         pp5_plan<<<F_NTILE, PL_T, (size_t)(n_frames + 1) * 4, stream>>>(dframes, n_frames, live->tab_dev, live->TX0,
-                                                                        live->TY0, tileOcc, tileEdge, cellPk, pmax,
-                                                                        wave ? wmax : 0u, denseItems, heavy, J_FMAX, runs,
-                                                                        itemsH, itemsL, itemPts, winTab, tileTotal, ctrl);
+                                                                        live->TY0, tileOcc, tileEdge, cellPk, wmax,
+                                                                        denseItems, W_FMAX, runs, itemsH, itemsL, itemPts,
+                                                                        winTab, ctrl);
         const char *pe = getenv("MODEST_PP5_PROF");
         const bool prof = pe && atoi(pe);
-        static bool attr = false;
-        if (!attr) {
-            MODEST_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void *>(pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)J_LDS));
-            MODEST_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void *>(pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, true>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)J_LDS));
-            MODEST_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void *>(pp5_join<2, K_JT, 1, K_CAP, 4, 4, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)K_LDS));
-            MODEST_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void *>(pp5_join<2, K_JT, 1, K_CAP, 4, 4, true>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)K_LDS));
-            attr = true;
-        }
         if (prof) MODEST_HIP_CHECK(hipMemsetAsync(stats, 0, 64 * 8, stream));
-#define PP5_ARGS dframes, n_frames, runs, itemsH, itemsL, ctrl, tileBase, rec, itemSurv, live->tab_dev, live->TX0, \
-                 live->TY0, cellPk, sorted, A, counts, T, r2
-        if (fused || wave) {
-            const int grid = 2 * ctx->num_cus;
-            const int nsh = wave ? PL_SHARDS : 2 * PL_SHARDS;   // wave path: the workgroup kernel takes class H only
-            const char *sk = getenv("MODEST_PP6_SKIP");
-            const int skip = sk ? atoi(sk) : 0;
-            if ((skip & 1) || wave) {   // wave path: every item is a wave item
-            } else if (prof) pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, true><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
-            else pp5_join<0, J_JT, J_RPT, J_CAP, J_FMAX, J_FCH, false><<<grid, J_JT, J_LDS, stream>>>(PP5_ARGS, J_LDS, stats, nsh);
-            if (wave && !(skip & 2)) {
-                const unsigned slice = pp6_slice_bytes(T);
-                static bool wattr = false;
-                if (!wattr) {
-                    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join<false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
-                    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join<true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
-                    wattr = true;
-                }
-                const char *wg = getenv("MODEST_PP6_WGS");
-                const int wgs = (wg ? atoi(wg) : 6) * ctx->num_cus;
-                if (prof)
-                    pp6_wave_join<true><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
-                        dframes, n_frames, runs, itemsH, itemsL, ctrl, winTab, live->TX0, live->TY0, sorted, A, counts,
-                        T, r2, slice, stats);
-                else
-                    pp6_wave_join<false><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
-                        dframes, n_frames, runs, itemsH, itemsL, ctrl, winTab, live->TX0, live->TY0, sorted, A, counts,
-                        T, r2, slice, stats);
-            }
-        } else {
-            pp5_tile_scan<<<1, 1024, 0, stream>>>(tileTotal, tileBase);
-            const int ggrid = 8 * ctx->num_cus;
-            pp5_join<1, G_JT, G_RPT, 0, J_FMAX, J_FCH, false><<<ggrid, G_JT, G_LDS, stream>>>(PP5_ARGS, G_LDS, stats, 2 * PL_SHARDS);
-            MODEST_HIP_CHECK(hipMemsetAsync(ctrl + 1, 0, 4, stream));   // dequeue head of the second pass
-            const int grid = 2 * ctx->num_cus;
-            if (prof) pp5_join<2, K_JT, 1, K_CAP, 4, 4, true><<<grid, K_JT, K_LDS, stream>>>(PP5_ARGS, K_LDS, stats, 2 * PL_SHARDS);
-            else pp5_join<2, K_JT, 1, K_CAP, 4, 4, false><<<grid, K_JT, K_LDS, stream>>>(PP5_ARGS, K_LDS, stats, 2 * PL_SHARDS);
+        const unsigned slice = pp6_slice_bytes(T);
+        static bool wattr = false;
+        if (!wattr) {
+            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
+            MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp6_wave_join<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2));
+            wattr = true;
         }
-#undef PP5_ARGS
+        MODEST_REQUIRE((size_t)slice * W_WAVES <= 80 * 1024, "too many traversals for the wave path's LDS slices");
+        const char *wg = getenv("MODEST_PP6_WGS");
+        const int wgs = (wg && atoi(wg) > 0 ? atoi(wg) : 4) * ctx->num_cus;
+        if (prof)
+            pp6_wave_join<true><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
+                dframes, n_frames, runs, itemsH, itemsL, ctrl, winTab, live->TX0, live->TY0, sorted, A, counts, T, r2, slice,
+                stats);
+        else
+            pp6_wave_join<false><<<wgs, 64 * W_WAVES, (size_t)slice * W_WAVES, stream>>>(
+                dframes, n_frames, runs, itemsH, itemsL, ctrl, winTab, live->TX0, live->TY0, sorted, A, counts, T, r2, slice,
+                stats);
         if (prof) {
             unsigned long long hs[16];
-            unsigned hc[4];
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hs, stats, sizeof(hs), hipMemcpyDeviceToHost));
-            if (wave)
-                fprintf(stderr, "[pp6] wave-time (10 ns ticks, summed over wavefronts) window %llu chunk-header %llu "
-                                "gather+transform %llu pairs %llu flush %llu\n", hs[8], hs[9], hs[10], hs[11], hs[12]);
-            {
-                unsigned sh[2 * PL_SHARDS];
-                MODEST_HIP_CHECK(hipMemcpy(sh, ctrl + 8, sizeof(sh), hipMemcpyDeviceToHost));
-                hc[0] = hc[1] = 0;
+            unsigned sh[2 * PL_SHARDS];
+            MODEST_HIP_CHECK(hipMemcpy(sh, ctrl + 8, sizeof(sh), hipMemcpyDeviceToHost));
+            unsigned long long pts[2] = {0, 0}, mx[2] = {0, 0}, cnt[2] = {0, 0};
+            std::vector<unsigned> buf(PL_SHARD_CAP);
+            for (int c = 0; c < 2; ++c)
                 for (int k = 0; k < PL_SHARDS; ++k) {
-                    hc[0] += sh[k];
-                    hc[1] += sh[PL_SHARDS + k];
-                }
-            }
-            {   // points per class
-                unsigned sh[2 * PL_SHARDS];
-                MODEST_HIP_CHECK(hipMemcpy(sh, ctrl + 8, sizeof(sh), hipMemcpyDeviceToHost));
-                unsigned long long pts[2] = {0, 0}, mx[2] = {0, 0};
-                std::vector<unsigned> buf(PL_SHARD_CAP);
-                for (int c = 0; c < 2; ++c)
-                    for (int k = 0; k < PL_SHARDS; ++k) {
-                        const unsigned n = sh[c * PL_SHARDS + k] < PL_SHARD_CAP ? sh[c * PL_SHARDS + k] : PL_SHARD_CAP;
-                        if (!n) continue;
-                        MODEST_HIP_CHECK(hipMemcpy(buf.data(), itemPts + ((size_t)c * PL_SHARDS + k) * PL_SHARD_CAP, n * 4,
-                                                   hipMemcpyDeviceToHost));
-                        for (unsigned q = 0; q < n; ++q) {
-                            pts[c] += buf[q];
-                            if (buf[q] > mx[c]) mx[c] = buf[q];
-                        }
+                    const unsigned n = sh[c * PL_SHARDS + k] < PL_SHARD_CAP ? sh[c * PL_SHARDS + k] : PL_SHARD_CAP;
+                    cnt[c] += n;
+                    if (!n) continue;
+                    MODEST_HIP_CHECK(hipMemcpy(buf.data(), itemPts + ((size_t)c * PL_SHARDS + k) * PL_SHARD_CAP, n * 4,
+                                               hipMemcpyDeviceToHost));
+                    for (unsigned q = 0; q < n; ++q) {
+                        pts[c] += buf[q];
+                        if (buf[q] > mx[c]) mx[c] = buf[q];
                     }
-                fprintf(stderr, "[pp5] points class H %llu (max item %llu), class L %llu (max item %llu)\n", pts[0], mx[0],
-                        pts[1], mx[1]);
-            }
-            fprintf(stderr,
-                    "[pp5] items %u heavy + %u | wg-time (10 ns ticks, summed) lookups %llu tables %llu gather %llu sort %llu "
-                    "live-load %llu join %llu flush %llu\n",
-                    hc[0], hc[1], hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6]);
+                }
+            fprintf(stderr, "[pp6] items: %llu of dense tiles (%llu points gathered, largest %llu) + %llu (%llu points, "
+                            "largest %llu)\n", cnt[0], pts[0], mx[0], cnt[1], pts[1], mx[1]);
+            fprintf(stderr, "[pp6] wave-time (10 ns ticks, summed over wavefronts) window %llu chunk-header %llu "
+                            "gather+transform %llu pairs %llu flush %llu\n", hs[8], hs[9], hs[10], hs[11], hs[12]);
         }
     }
     modest_prof_mark(ctx, stream, 1);

@@ -211,7 +211,7 @@ class FrameStore:
         lv, arr, slots = desc
         # the streaming path reads frames as plain point lists; only the gather-join relies on the
         # tile tables (no outliers) and on the lattice agreeing with the relative poses
-        gather = os.environ.get("MODEST_PP_FRAMES_PATH", "").startswith("gather")
+        gather = os.environ.get("MODEST_PP_FRAMES_PATH", "") == "gather-wave"
         ok = (not force_stacked and T <= 64
               and (not gather or (bool(self._clean[slots].all())
                                   and self.consistent(slots, np.concatenate([rels, live_rel[None]]), A44))))

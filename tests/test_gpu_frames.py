@@ -21,10 +21,10 @@ def _store_scan(gpu, s, radius=0.3, nusc=False):
     return st, hist, np.stack(rels)
 
 
-@pytest.fixture(params=["stream", "gather", "gather-fused", "gather-wave"])
+@pytest.fixture(params=["stream", "gather-wave"])
 def frames_path(request, monkeypatch):
     """The three device paths behind modest_pp_score_frames: the V3 streaming kernels over the
-    descriptor table (default), the split / fused gather-join and its wave-autonomous variant (MODEST_PP_FRAMES_PATH)."""
+    descriptor table (default), and the experimental wave-autonomous gather-join (MODEST_PP_FRAMES_PATH=gather-wave)."""
     if request.param == "stream":
         monkeypatch.delenv("MODEST_PP_FRAMES_PATH", raising=False)
     else:

@@ -1,8 +1,8 @@
 #!/bin/bash
-# HBM traffic of the gather-join frame path (MODEST_PP_FRAMES_PATH=gather-fused): FETCH_SIZE and
+# HBM traffic of the gather-join frame path (MODEST_PP_FRAMES_PATH=gather-wave): FETCH_SIZE and
 # WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-export MODEST_PP_FRAMES_PATH=${1:-gather-fused}
+export MODEST_PP_FRAMES_PATH=${1:-gather-wave}
 for pass in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc5_$pass
   timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc5_$pass -o p -- python bench.py --steps 4 --warmup 1 --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 > gpurun_out/pmc5_$pass.log 2>&1

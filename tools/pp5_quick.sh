@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box: frame-store PP parity tests, then timings of the three frame paths
+# GPU box: frame-store PP parity tests, then timings of the two frame paths
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_gpu_frames.py -m gpu -q -x 2>&1 | tail -5
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for path in stream gather-fused gather-wave; do
+for path in stream gather-wave; do
   echo "== path $path"
   if [ $path = stream ]; then unset MODEST_PP_FRAMES_PATH; else export MODEST_PP_FRAMES_PATH=$path; fi
   timeout 300 python tools/pp5_microbench.py 2>&1 | tail -3 | cut -c1-200
