@@ -253,6 +253,23 @@ int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz_dev, const float 
                              int min_samples, int32_t *labels_dev, double *kth_d2_dev,
                              int32_t *n_clusters_host, void *stream);
 
+/* The per-scan body of generate_mask.py:57-88 as ONE call: above_plane + limit_range mask of the
+ * scan rows (modest_plane_range_mask), the affinity graph and DBSCAN of the kept rows
+ * (modest_cluster_dbscan_ex) and `labels[ptc_mask] = cluster labels` on an array preset to -1.
+ * The first kernel masks, compacts, presets the labels and counts the kept rows per cell of a grid
+ * fixed around limit_range (no bounding-box pass, no separate gathers of pp / intensity, no label
+ * scatter launch); one stream sync inside (the kept count sizes the launches that follow).
+ * pts [dev] (n,stride) f32 scan rows, pp [dev] (n) f32, labels [dev] (n) int32: -1 = masked out or
+ * noise, else the DBSCAN label.  n_kept_host / n_clusters_host: host words.  When the graph needs
+ * k neighbours and only n_kept <= k rows are kept the call fails with MODEST_ERR_ARG and the
+ * message sklearn's kneighbors raises (n_kept_host is valid).                                 */
+int modest_mask_cluster(modest_ctx *ctx, const float *pts_dev, int n, int stride, const float *pp_dev,
+                        const double *plane4, double offset, const double *only_range4,
+                        const double *limit_range4, int neighbor_type, int affinity_type,
+                        int k_neighbors, double radius, double eps, int min_samples,
+                        int32_t *labels_dev, int32_t *n_kept_host, int32_t *n_clusters_host,
+                        void *stream);
+
 /* ---- a14 filter_labels / is_valid_cluster statistics ------------------
  * (utils/clustering_utils.py:94-135).  For each label c in [0, n_clusters):
  * out[c*6 + {0: member count, 1: min, 2: max signed distance to `plane`

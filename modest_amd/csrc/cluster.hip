@@ -21,7 +21,11 @@
 // with cell edge = radius: one 64-lane wavefront per query point sweeps the 3x3
 // cell rows (contiguous in the cell-sorted array, so loads are coalesced).
 #include "common.h"
+#include "compact.h"
+#include "mask_pred.h"
 #include <cmath>
+
+using namespace modest;
 
 namespace {
 
@@ -42,7 +46,7 @@ __device__ __forceinline__ int cg_coord(float v, double o, double inv_c) {
 
 __global__ __launch_bounds__(1024) void cg_bbox(const float *__restrict__ xyz, int n, double c, CGrid *g,
                                                 unsigned *__restrict__ zeroed, int zero_words) {
-    // the cell / fill counters and flags of this call are cleared here (one memset launch less);
+    // the cell counters of this call are cleared here (one memset launch less);
     // the next kernel on the stream is their first user
     for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zeroed[i] = 0u;
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
@@ -96,10 +100,15 @@ __global__ void cg_count(const float *__restrict__ xyz, int n, const CGrid *g, u
 // exclusive scan of `n` counters into out[0..n] by one 1024-thread workgroup: every wavefront
 // owns a contiguous segment and walks it 64 counters at a time (coalesced, four rounds of loads
 // in flight), first for the segment totals, then for the prefixes with a running carry
-__global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in,
-                                                 unsigned *__restrict__ out, int n,
+// CELLS (the grid's cell counters): also writes the scatter cursors (= the prefixes), clears the
+// counters behind itself when `clear_in` is set (the persistent counters of the fused mask call
+// stay zero between calls) and clears the four flag words of the call.
+template <bool CELLS>
+__global__ __launch_bounds__(1024) void scan_u32(const unsigned *in, unsigned *__restrict__ out, int n,
                                                  unsigned *__restrict__ total_copy = nullptr,
-                                                 const int *__restrict__ flag_src = nullptr) {
+                                                 const int *__restrict__ flag_src = nullptr,
+                                                 unsigned *__restrict__ cursor = nullptr,
+                                                 unsigned *clear_in = nullptr, unsigned *flags = nullptr) {
     __shared__ unsigned wtot[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg = (((n + 15) / 16) + 63) & ~63;           // per-wavefront segment, multiple of 64
@@ -137,10 +146,17 @@ __global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in
                 if (lane >= o) inc += t;
             }
             const int k = k0 + u * 64 + lane;
-            if (k < e) out[k] = carry + inc - v[u];
+            if (k < e) {
+                out[k] = carry + inc - v[u];
+                if (CELLS) {
+                    cursor[k] = carry + inc - v[u];
+                    if (clear_in) clear_in[k] = 0u;
+                }
+            }
             carry += __shfl(inc, 63);
         }
     }
+    if (CELLS && flags && threadIdx.x < 4) flags[threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
         out[n] = total;
         // pinned host memory: [overflow flag, total] are there when the stream has been synchronised
@@ -151,16 +167,52 @@ __global__ __launch_bounds__(1024) void scan_u32(const unsigned *__restrict__ in
     }
 }
 
+// idx == NULL: pp (and intensity) are per input point.  idx != NULL (fused mask call): the input
+// points are the kept rows of a scan, idx their row numbers; pp is the scan's array and the
+// intensity is column 3 of the scan rows (`rows`, `stride` floats apart).
 __global__ void cg_scatter(const float *__restrict__ xyz, const float *__restrict__ pp, int n,
-                           const CGrid *g, const unsigned *__restrict__ start, unsigned *fill,
-                           float4 *__restrict__ sorted, int *__restrict__ sidx) {
+                           const CGrid *g, unsigned *cursor, float4 *__restrict__ sorted, int *__restrict__ sidx,
+                           const int *__restrict__ idx, const float *__restrict__ inten_src,
+                           const float *__restrict__ rows, int stride, float *__restrict__ sortedI) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     const int cell = cg_coord(y, g->oy, g->inv_c) * CG + cg_coord(x, g->ox, g->inv_c);
-    const unsigned slot = start[cell] + atomicAdd(&fill[cell], 1u);
-    sorted[slot] = make_float4(x, y, z, pp[i]);
+    const unsigned slot = atomicAdd(&cursor[cell], 1u);
+    const int src = idx ? idx[i] : i;
+    sorted[slot] = make_float4(x, y, z, pp[src]);
     sidx[slot] = i;
+    if (sortedI) sortedI[slot] = rows ? rows[(size_t)src * stride + 3] : inten_src[src];
+}
+
+// Fused first kernel of modest_mask_cluster: above_plane + range mask of every scan row, ordered
+// compaction of the kept rows, their cell counts in the fixed grid G, labels = -1 everywhere.
+__global__ __launch_bounds__(1024) void mask_count_kernel(const float *__restrict__ pts, int n, int stride, MaskParams P,
+                                                          CGrid G, CGrid *__restrict__ g, unsigned *cnt,
+                                                          int *__restrict__ labels, float *__restrict__ kept,
+                                                          int *__restrict__ kept_idx, unsigned long long *state,
+                                                          int *n_kept) {
+    const unsigned blk = compact_ticket(state);
+    const long long i = (long long)blk * 1024 + threadIdx.x;
+    if (blk == 0 && threadIdx.x == 0) *g = G;
+    bool keep = false;
+    float x = 0, y = 0, z = 0;
+    if (i < n) {
+        const float *p = pts + i * stride;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+        keep = mask_keep(P, x, y, z);
+        labels[i] = -1;
+        if (keep) atomicAdd(&cnt[cg_coord(y, G.oy, G.inv_c) * CG + cg_coord(x, G.ox, G.inv_c)], 1u);
+    }
+    const unsigned long long dst = compact_offset(keep, blk, gridDim.x, state, n_kept);
+    if (keep) {
+        kept[3 * dst + 0] = x;
+        kept[3 * dst + 1] = y;
+        kept[3 * dst + 2] = z;
+        kept_idx[dst] = (int)i;
+    }
 }
 
 __device__ __forceinline__ double dist2(const float4 &a, const float4 &b) {
@@ -466,13 +518,14 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
                                                          const unsigned char *__restrict__ coreS,
                                                          const int *__restrict__ sidx,
                                                          const int *__restrict__ root,
-                                                         const unsigned *__restrict__ rank, EdgeP ep, int *__restrict__ labels) {
+                                                         const unsigned *__restrict__ rank, EdgeP ep, int *__restrict__ labels,
+                                                         const int *__restrict__ oidx) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;
     const int me = sidx[s];
     if (coreS[s]) {
-        if (lane == 0) labels[me] = (int)rank[root[me]];
+        if (lane == 0) labels[oidx ? oidx[me] : me] = (int)rank[root[me]];
         return;
     }
     const float4 q = sorted[s];
@@ -486,7 +539,7 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
             if (edge_ok(q, kq, sorted[j], kthS[j], ep, s, j)) best = min(best, root[sidx[j]]);
         }
     for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
-    if (lane == 0) labels[me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
+    if (lane == 0) labels[oidx ? oidx[me] : me] = (best == 0x7fffffff) ? -1 : (int)rank[best];
 }
 
 // ---- explicit adjacency (the fast path) ----------------------------------------------
@@ -589,7 +642,7 @@ __global__ void union_adj_kernel(int n, int stride, const unsigned char *__restr
 __global__ void label_adj_kernel(int n, int stride, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
                                  const int *__restrict__ adj, const int *__restrict__ sidx,
                                  const int *__restrict__ root, const unsigned *__restrict__ rank,
-                                 int *__restrict__ labels) {
+                                 int *__restrict__ labels, const int *__restrict__ oidx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = t / AG, sub = t % AG;
     const bool on = s < n;
@@ -606,7 +659,7 @@ __global__ void label_adj_kernel(int n, int stride, const unsigned char *__restr
     for (int o = AG / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
     if (!on || sub) return;
     const int me = sidx[s];
-    labels[me] = core ? (int)rank[root[me]] : (best == 0x7fffffff) ? -1 : (int)rank[best];
+    labels[oidx ? oidx[me] : me] = core ? (int)rank[root[me]] : (best == 0x7fffffff) ? -1 : (int)rank[best];
 }
 
 // ---- k-NN graphs without a radius bound (neighbor_type knn / sym_knn / mutual_knn) ------------
@@ -794,9 +847,9 @@ __global__ void dir_roots_kernel(int n, const unsigned char *__restrict__ coreS,
     isroot[i] = (coreS[s] && L[s] == i) ? 1u : 0u;
 }
 __global__ void dir_label_kernel(int n, const int *__restrict__ root, const unsigned *__restrict__ rank,
-                                 int *__restrict__ labels) {
+                                 int *__restrict__ labels, const int *__restrict__ oidx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) labels[i] = (root[i] == 0x7fffffff) ? -1 : (int)rank[root[i]];
+    if (i < n) labels[oidx ? oidx[i] : i] = (root[i] == 0x7fffffff) ? -1 : (int)rank[root[i]];
 }
 
 __global__ void scatter_kth(const double *__restrict__ kthS, const int *__restrict__ sidx, int n,
@@ -807,56 +860,46 @@ __global__ void scatter_kth(const double *__restrict__ kthS, const int *__restri
 
 }  // namespace
 
-namespace {
-__global__ void gather_f32(const float *__restrict__ src, const int *__restrict__ sidx, int n,
-                           float *__restrict__ dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[sidx[i]];
-}
-}  // namespace
-
 // Rounds of min-root hooking before the exact union pass.  Measured on a 9 k-point scan
 // (hook + flatten 14 us per round): union_adj takes 305 / 220 / 59 / 19 us after 0 / 1 / 2 / 3 rounds.
 constexpr int HOOK_ROUNDS = 3;
 
-extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const float *pp,
-                                        const float *intensity, int n, int neighbor_type, int affinity_type,
-                                        int k_neighbors, double radius, double eps, int min_samples,
-                                        int32_t *labels, double *kth_d2, int32_t *n_clusters,
-                                        void *stream_) {
-    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
-    MODEST_REQUIRE(n >= 0, "n < 0");
-    MODEST_REQUIRE(k_neighbors >= 1 && radius > 0.0 && min_samples >= 1, "bad parameters");
-    MODEST_REQUIRE(neighbor_type >= MODEST_GRAPH_RADIUS_MUTUAL_KNN && neighbor_type <= MODEST_GRAPH_MUTUAL_KNN,
-                   "neighbor_type out of range");
-    const bool unbounded = neighbor_type >= MODEST_GRAPH_KNN;
-    MODEST_REQUIRE(!unbounded || n == 0 || n > k_neighbors, "k-NN graph: n_neighbors must be < n (sklearn raises too)");
-    MODEST_REQUIRE(affinity_type >= MODEST_AFFINITY_L1 && affinity_type <= MODEST_AFFINITY_L2_4D,
-                   "affinity_type must be l1, exp or 3d_l2_distance");
-    MODEST_REQUIRE(affinity_type != MODEST_AFFINITY_L2_4D || intensity != nullptr || n == 0,
-                   "3d_l2_distance needs the intensity column (the reference takes the norm of the (n,4) rows)");
-    if (n_clusters) *n_clusters = 0;
-    if (n == 0) return MODEST_OK;
-    MODEST_REQUIRE(xyz && pp && labels, "NULL buffer");
-    hipStream_t stream = as_stream(stream_);
-    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+namespace {
 
+// Input of the fused mask call: the kept rows were compacted, binned into the grid `G` (a fixed grid
+// around limit_range, no bounding-box pass) and counted per cell by mask_count_kernel.
+struct PreGrid {
+    const int *idx;      // [dev] row number of every kept point
+    const float *rows;   // [dev] the scan rows (intensity = column 3)
+    int stride;
+    CGrid *g;            // [dev] grid descriptor, written by mask_count_kernel
+    unsigned *cnt;       // [dev] persistent per-cell counters, left zeroed by the cell scan
+};
+
+size_t cluster_arena_bytes(int n, int neighbor_type, int k_neighbors) {
+    const bool unbounded = neighbor_type >= MODEST_GRAPH_KNN;
+    const int ustride = k_neighbors + (neighbor_type == MODEST_GRAPH_SYM_KNN ? 3 * k_neighbors : 0) + 8;
+    return arena_sz(sizeof(CGrid)) + arena_sz((CG_CELLS + 4) * 4) + 2 * arena_sz((CG_CELLS + 1) * 4) +
+           arena_sz((size_t)n * 16) + arena_sz((size_t)n * 4) + arena_sz((size_t)n * 8) + arena_sz((size_t)n) +
+           arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4) + arena_sz((size_t)n * 4) +
+           arena_sz((size_t)n * (unbounded ? (ustride > ADJ ? ustride : ADJ) : ADJ) * 4) + arena_sz((size_t)n * 4) * 3;
+}
+
+// The arena (ctx->scratch + arena_off, cluster_arena_bytes(n) reserved by the caller) holds every
+// intermediate.  pre == NULL: xyz / pp / intensity are per input point and labels[i] is written for
+// every input point; pre != NULL: see PreGrid, labels[pre->idx[i]] is written.
+int cluster_impl(modest_ctx *ctx, size_t arena_off, const float *xyz, const float *pp, const float *intensity, int n,
+                 int neighbor_type, int affinity_type, int k_neighbors, double radius, double eps, int min_samples,
+                 int32_t *labels, double *kth_d2, int32_t *n_clusters, hipStream_t stream, const PreGrid *pre) {
+    const bool unbounded = neighbor_type >= MODEST_GRAPH_KNN;
     const int ustride = k_neighbors + (neighbor_type == MODEST_GRAPH_SYM_KNN ? 3 * k_neighbors : 0) + 8;   // k-NN graph rows
-    const size_t zero_words = (size_t)2 * CG_CELLS + 4;   // cell counters, fill counters, overflow flag, changed flag
-    size_t need = arena_sz(sizeof(CGrid)) + arena_sz(zero_words * 4) + arena_sz((CG_CELLS + 1) * 4) +
-                  arena_sz((size_t)n * 16) + arena_sz((size_t)n * 4) + arena_sz((size_t)n * 8) +
-                  arena_sz((size_t)n) + arena_sz((size_t)n * 4) * 3 + arena_sz((size_t)(n + 1) * 4) +
-                  arena_sz((size_t)n * 4) + arena_sz((size_t)n * (unbounded ? (ustride > ADJ ? ustride : ADJ) : ADJ) * 4) +
-                  arena_sz((size_t)n * 4) * 3;
-    int rc = modest_ctx_reserve(ctx, need);
-    if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, 64);
-    if (rc) return rc;
-    Arena A(ctx->scratch);
+    const size_t zero_words = (size_t)CG_CELLS + 4;   // cell counters, overflow flag, changed flag
+    Arena A(ctx->scratch + arena_off);
     CGrid *g = A.take<CGrid>(1);
     unsigned *zeroed = A.take<unsigned>(zero_words);
-    unsigned *cnt = zeroed, *fill = zeroed + CG_CELLS;
+    unsigned *cnt = zeroed;
     unsigned *start = A.take<unsigned>(CG_CELLS + 1);
+    unsigned *cursor = A.take<unsigned>(CG_CELLS + 1);
     float4 *sorted = A.take<float4>(n);
     int *sidx = A.take<int>(n);
     double *kthS = A.take<double>(n);
@@ -870,24 +913,34 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     float *sortedI = A.take<float>(n);
     int *degOut = A.take<int>(n);
     int *Lmin = A.take<int>(n);
-    int *overflow = reinterpret_cast<int *>(zeroed + 2 * CG_CELLS);
+    int *overflow = reinterpret_cast<int *>(zeroed + CG_CELLS);
     unsigned *h_res = reinterpret_cast<unsigned *>(ctx->pinned);   // [overflow, number of clusters], written by the last scan
+    const int *oidx = pre ? pre->idx : nullptr;
 
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
     const int nb = (n + 255) / 256, nw = (n + WPB - 1) / WPB;
     const int nbA = (int)(((long long)n * AG + 255) / 256);
-    cg_bbox<<<1, 1024, 0, stream>>>(xyz, n, c, g, zeroed, (int)zero_words);
-    cg_count<<<nb, 256, 0, stream>>>(xyz, n, g, cnt);
-    scan_u32<<<1, 1024, 0, stream>>>(cnt, start, CG_CELLS);
-    cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, start, fill, sorted, sidx);
+    const bool l2 = affinity_type == MODEST_AFFINITY_L2_4D;
+    if (pre) {
+        g = pre->g;
+        scan_u32<true><<<1, 1024, 0, stream>>>(pre->cnt, start, CG_CELLS, nullptr, nullptr, cursor, pre->cnt,
+                                               reinterpret_cast<unsigned *>(overflow));
+        cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, cursor, sorted, sidx, pre->idx, nullptr, pre->rows, pre->stride,
+                                           l2 ? sortedI : nullptr);
+    } else {
+        cg_bbox<<<1, 1024, 0, stream>>>(xyz, n, c, g, zeroed, (int)zero_words);
+        cg_count<<<nb, 256, 0, stream>>>(xyz, n, g, cnt);
+        scan_u32<true><<<1, 1024, 0, stream>>>(cnt, start, CG_CELLS, nullptr, nullptr, cursor, nullptr, nullptr);
+        cg_scatter<<<nb, 256, 0, stream>>>(xyz, pp, n, g, cursor, sorted, sidx, nullptr, intensity, nullptr, 0,
+                                           l2 ? sortedI : nullptr);
+    }
     EdgeP ep;
     ep.r2 = r2;
     ep.eps = eps;
     ep.use_knn = neighbor_type == MODEST_GRAPH_RADIUS_MUTUAL_KNN;
     ep.affinity = affinity_type;
     ep.inten = sortedI;
-    if (affinity_type == MODEST_AFFINITY_L2_4D) gather_f32<<<nb, 256, 0, stream>>>(intensity, sidx, n, sortedI);
     if (unbounded) {
         // ---- knn / sym_knn / mutual_knn: exact k-th neighbour distance without a radius bound ----
         int *changed = overflow + 1;
@@ -911,8 +964,8 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
                 }
             }
             dir_roots_kernel<<<nb, 256, 0, stream>>>(n, coreS, sidx, Lmin, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
-            dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels);
+            scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
+            dir_label_kernel<<<nb, 256, 0, stream>>>(n, root, rank, labels, oidx);
         } else {
             uf_init<<<nb, 256, 0, stream>>>(parent, n);
             for (int round = 0; round < HOOK_ROUNDS; ++round) {
@@ -921,8 +974,8 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
             }
             union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
-            label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, root, rank, labels);
+            scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
+            label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ustride, coreS, deg, adj, sidx, root, rank, labels, oidx);
         }
         MODEST_HIP_CHECK(hipGetLastError());
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -943,8 +996,8 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     }
     union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
     compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-    scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
-    label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels);
+    scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
+    label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels, oidx);
     MODEST_HIP_CHECK(hipGetLastError());
     {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -954,9 +1007,9 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
             hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
             compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
+            scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
             label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, ep,
-                                                     labels);
+                                                     labels, oidx);
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         }
         if (n_clusters) *n_clusters = (int32_t)h_res[1];
@@ -964,6 +1017,111 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
     if (kth_d2) scatter_kth<<<nb, 256, 0, stream>>>(kthS, sidx, n, kth_d2);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
+}
+
+}  // namespace
+
+extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const float *pp,
+                                        const float *intensity, int n, int neighbor_type, int affinity_type,
+                                        int k_neighbors, double radius, double eps, int min_samples,
+                                        int32_t *labels, double *kth_d2, int32_t *n_clusters,
+                                        void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0, "n < 0");
+    MODEST_REQUIRE(k_neighbors >= 1 && radius > 0.0 && min_samples >= 1, "bad parameters");
+    MODEST_REQUIRE(neighbor_type >= MODEST_GRAPH_RADIUS_MUTUAL_KNN && neighbor_type <= MODEST_GRAPH_MUTUAL_KNN,
+                   "neighbor_type out of range");
+    const bool unbounded = neighbor_type >= MODEST_GRAPH_KNN;
+    MODEST_REQUIRE(!unbounded || n == 0 || n > k_neighbors, "k-NN graph: n_neighbors must be < n (sklearn raises too)");
+    MODEST_REQUIRE(affinity_type >= MODEST_AFFINITY_L1 && affinity_type <= MODEST_AFFINITY_L2_4D,
+                   "affinity_type must be l1, exp or 3d_l2_distance");
+    MODEST_REQUIRE(affinity_type != MODEST_AFFINITY_L2_4D || intensity != nullptr || n == 0,
+                   "3d_l2_distance needs the intensity column (the reference takes the norm of the (n,4) rows)");
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(xyz && pp && labels, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = modest_ctx_reserve(ctx, cluster_arena_bytes(n, neighbor_type, k_neighbors));
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, 64);
+    if (rc) return rc;
+    return cluster_impl(ctx, 0, xyz, pp, intensity, n, neighbor_type, affinity_type, k_neighbors, radius, eps,
+                        min_samples, labels, kth_d2, n_clusters, stream, nullptr);
+}
+
+extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
+                                   const double *plane4, double offset, const double *only_range4,
+                                   const double *limit_range4, int neighbor_type, int affinity_type, int k_neighbors,
+                                   double radius, double eps, int min_samples, int32_t *labels, int32_t *n_kept,
+                                   int32_t *n_clusters, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n >= 0 && (stride == 3 || stride == 4), "bad n/stride");
+    MODEST_REQUIRE(plane4 && limit_range4 && n_kept, "NULL argument");
+    MODEST_REQUIRE(k_neighbors >= 1 && radius > 0.0 && min_samples >= 1, "bad parameters");
+    MODEST_REQUIRE(neighbor_type >= MODEST_GRAPH_RADIUS_MUTUAL_KNN && neighbor_type <= MODEST_GRAPH_MUTUAL_KNN,
+                   "neighbor_type out of range");
+    MODEST_REQUIRE(affinity_type >= MODEST_AFFINITY_L1 && affinity_type <= MODEST_AFFINITY_L2_4D,
+                   "affinity_type must be l1, exp or 3d_l2_distance");
+    MODEST_REQUIRE(affinity_type != MODEST_AFFINITY_L2_4D || stride == 4,
+                   "3d_l2_distance needs the intensity column of the scan rows");
+    *n_kept = 0;
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts && pp && labels, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    // [kept xyz | kept idx | grid descriptor | n_kept word] then the clustering arena, reserved for the
+    // worst case (every row kept) so that nothing moves between the two halves of the call
+    const size_t own = arena_sz((size_t)n * 12) + arena_sz((size_t)n * 4) + arena_sz(sizeof(CGrid));
+    int rc = modest_ctx_reserve(ctx, own + cluster_arena_bytes(n, neighbor_type, k_neighbors));
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, 64);
+    if (rc) return rc;
+    Arena A(ctx->scratch);
+    float *kept = A.take<float>((size_t)n * 3);
+    int *kept_idx = A.take<int>(n);
+    CGrid *g = A.take<CGrid>(1);
+    int *h_kept = reinterpret_cast<int *>(ctx->pinned + 32);   // pinned: there after the sync, no copy
+    unsigned *cnt = nullptr;
+    rc = modest_ctx_zero_words(ctx, CG_CELLS, stream, &cnt);
+    if (rc) return rc;
+    ctx->zwords_dirty = 1;   // until the cell scan behind the counters has been enqueued
+    MaskParams P;
+    mask_params_fill(P, plane4, offset, only_range4, limit_range4);
+    // the kept rows lie inside limit_range: a fixed grid around it needs no bounding-box pass (cells
+    // beyond the grid are clamped; the sweeps stay exact, see cg_coord / rows_of)
+    const double c = radius * (1.0 + 1.0 / 1024.0);
+    double cx = 0.5 * ((double)P.lx0 + (double)P.lx1), cy = 0.5 * ((double)P.ly0 + (double)P.ly1);
+    if (!(fabs(cx) <= 1e30)) cx = 0.0;
+    if (!(fabs(cy) <= 1e30)) cy = 0.0;
+    CGrid G;
+    G.ox = cx - 0.5 * CG * c;
+    G.oy = cy - 0.5 * CG * c;
+    G.inv_c = 1.0 / c;
+    const int nblk = (n + 1023) / 1024;
+    unsigned long long *state = nullptr;
+    rc = modest_ctx_compact_state(ctx, (size_t)nblk, stream, &state);
+    if (rc) return rc;
+    mask_count_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, P, G, g, cnt, labels, kept, kept_idx, state, h_kept);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    const int m = *h_kept;
+    *n_kept = m;
+    if (m == 0) {
+        ctx->zwords_dirty = 0;   // nothing was counted
+        return MODEST_OK;
+    }
+    if (neighbor_type != MODEST_GRAPH_RADIUS && m <= k_neighbors) {   // sklearn's kneighbors raises
+        modest_set_error("modest_mask_cluster: Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, "
+                         "n_samples_fit = %d, n_samples = %d", k_neighbors + 1, m, m);
+        return MODEST_ERR_ARG;
+    }
+    PreGrid pre{kept_idx, pts, stride, g, cnt};
+    rc = cluster_impl(ctx, own, kept, pp, nullptr, m, neighbor_type, affinity_type, k_neighbors, radius, eps, min_samples,
+                      labels, nullptr, n_clusters, stream, &pre);
+    if (rc == MODEST_OK) ctx->zwords_dirty = 0;
+    return rc;
 }
 
 extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const float *pp, int n,

@@ -24,6 +24,12 @@ struct modest_ctx {
     // them zeroed, so no memset per launch
     unsigned long long *cstate;
     size_t cstate_blocks;
+    // per-cell counters of the fused mask + cluster call (cluster.hip): zero between calls (the cell
+    // scan clears them behind itself); `zwords_dirty` is set while a call is in flight on the host side
+    // and makes the next call clear them if an error return left them undefined
+    unsigned *zwords;
+    size_t zwords_count;
+    int zwords_dirty;
     // ring of pinned staging slots for small per-call tables that are copied to the device
     // asynchronously (frame descriptors of modest_pp_score_frames): a slot is reused only after the
     // event recorded behind its copy has completed
@@ -41,6 +47,10 @@ int modest_ctx_stage_commit(modest_ctx *ctx, hipStream_t stream);
 
 // persistent compaction state for `nblocks` blocks (allocated and zeroed on first use / growth)
 int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream, unsigned long long **out);
+
+// persistent zeroed counter words (see modest_ctx::zwords); cleared here on first use, growth, or
+// when the dirty mark is still set
+int modest_ctx_zero_words(modest_ctx *ctx, size_t words, hipStream_t stream, unsigned **out);
 
 // Record an event pair around a kernel when profiling is on (no-ops otherwise).
 void modest_prof_mark(modest_ctx *ctx, hipStream_t stream, int end);

@@ -62,6 +62,9 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->pp_attr_done = 0;
     c->cstate = nullptr;
     c->cstate_blocks = 0;
+    c->zwords = nullptr;
+    c->zwords_count = 0;
+    c->zwords_dirty = 0;
     for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
         c->stage[i] = nullptr;
         c->stage_bytes[i] = 0;
@@ -78,6 +81,7 @@ extern "C" int modest_ctx_destroy(modest_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->cstate) (void)hipFree(ctx->cstate);
+    if (ctx->zwords) (void)hipFree(ctx->zwords);
     for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
         if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
@@ -102,6 +106,26 @@ int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream
         ctx->cstate_blocks = want;
     }
     *out = ctx->cstate;
+    return MODEST_OK;
+}
+
+int modest_ctx_zero_words(modest_ctx *ctx, size_t words, hipStream_t stream, unsigned **out) {
+    if (words > ctx->zwords_count) {
+        MODEST_HIP_CHECK(hipDeviceSynchronize());
+        if (ctx->zwords) MODEST_HIP_CHECK(hipFree(ctx->zwords));
+        ctx->zwords = nullptr;
+        ctx->zwords_count = 0;
+        void *p = nullptr;
+        MODEST_HIP_CHECK(hipMalloc(&p, words * 4));
+        ctx->zwords = static_cast<unsigned *>(p);
+        ctx->zwords_count = words;
+        ctx->zwords_dirty = 1;
+    }
+    if (ctx->zwords_dirty) {
+        MODEST_HIP_CHECK(hipMemsetAsync(ctx->zwords, 0, ctx->zwords_count * 4, stream));
+        ctx->zwords_dirty = 0;
+    }
+    *out = ctx->zwords;
     return MODEST_OK;
 }
 

@@ -9,6 +9,7 @@
 // with deterministic (fixed-order) reductions.
 #include "common.h"
 #include "compact.h"
+#include "mask_pred.h"
 #include <cmath>
 #include <vector>
 
@@ -503,15 +504,6 @@ __global__ void refit_reduce_kernel(const double *__restrict__ partial, int nblo
 }
 
 // ---- above_plane + range mask ----------------------------------------------------
-struct MaskParams {
-    double n0, n1, n2, d, norm, offset;
-    // range bounds are compared in float32, as numpy compares a float32 array
-    // with Python scalars (weak-scalar promotion)
-    float ox0, ox1, oy0, oy1;   // only_range (strict)
-    float lx0, lx1, ly0, ly1;   // limit_range (lo, hi]
-    int use_only_range;
-};
-
 __global__ __launch_bounds__(1024) void mask_kernel(const float *__restrict__ pts, int n, int stride,
                                                     MaskParams P, unsigned char *__restrict__ mask,
                                                     float *__restrict__ kept, int *__restrict__ kept_idx,
@@ -525,17 +517,7 @@ __global__ __launch_bounds__(1024) void mask_kernel(const float *__restrict__ pt
         x = p[0];
         y = p[1];
         z = p[2];
-        // ptc @ plane[:3] + plane[3], float64: x*n0, fma(y,n1,.), fma(z,n2,.), then + d, then / norm
-        double dist = (double)x * P.n0;
-        dist = fma((double)y, P.n1, dist);
-        dist = fma((double)z, P.n2, dist);
-        dist = dist + P.d;
-        dist = dist / P.norm;
-        bool below = dist < P.offset;
-        if (P.use_only_range)
-            below = below && (x < P.ox1) && (x > P.ox0) && (y < P.oy1) && (y > P.oy0);
-        const bool range = (x <= P.lx1) && (x > P.lx0) && (y <= P.ly1) && (y > P.ly0);
-        keep = (!below) && range;
+        keep = mask_keep(P, x, y, z);
         mask[i] = keep ? 1 : 0;
     }
     const unsigned long long dst = compact_offset(keep, blk, gridDim.x, state, n_kept);
@@ -782,26 +764,7 @@ extern "C" int modest_plane_range_mask(modest_ctx *ctx, const float *pts, int n,
     }
     MODEST_REQUIRE(pts && mask, "NULL buffer");
     MaskParams P;
-    P.n0 = plane4[0];
-    P.n1 = plane4[1];
-    P.n2 = plane4[2];
-    P.d = plane4[3];
-    // np.sqrt((plane[:3]**2).sum()): squares summed left to right (n < 8 -> sequential)
-    P.norm = sqrt((plane4[0] * plane4[0] + plane4[1] * plane4[1]) + plane4[2] * plane4[2]);
-    P.offset = offset;
-    P.use_only_range = only_range4 != nullptr;
-    if (only_range4) {
-        P.ox0 = (float)only_range4[0];
-        P.ox1 = (float)only_range4[1];
-        P.oy0 = (float)only_range4[2];
-        P.oy1 = (float)only_range4[3];
-    } else {
-        P.ox0 = P.ox1 = P.oy0 = P.oy1 = 0;
-    }
-    P.lx0 = (float)limit_range4[0];
-    P.lx1 = (float)limit_range4[1];
-    P.ly0 = (float)limit_range4[2];
-    P.ly1 = (float)limit_range4[3];
+    mask_params_fill(P, plane4, offset, only_range4, limit_range4);
     const int nblk = (n + 1023) / 1024;
     unsigned long long *state = nullptr;
     int rc = modest_ctx_compact_state(ctx, (size_t)nblk, stream, &state);

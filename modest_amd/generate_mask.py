@@ -52,27 +52,17 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     prep = prepare_planes(ptc_dev, [(pe.max_hs, pe.range), FILTER_PLANE_SPEC]) if planes is None else (None, None)
     plane = planes[0] if planes is not None else estimate_plane(
         ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state, prepared=prep[0])
-    _, kept_xyz, kept_idx = ops.plane_range_mask(ptc_dev, plane, pe.offset, pe.range, args.limit_range)
-    labels = np.zeros(ptc.shape[0], dtype=int) - 1
-    labels_dev = torch.full((ptc.shape[0],), -1, dtype=torch.int32, device=ptc_dev.device)
     if args.clustering.method != "DBSCAN":
         raise NotImplementedError(args.clustering.method)
     g = args.graph
     if g.neighbor_type not in ops.GRAPH_TYPES or g.affinity_type not in ops.AFFINITY_TYPES:
         raise NotImplementedError(f"graph {g.neighbor_type}/{g.affinity_type} (SURVEY.md §8f-3)")
-    n_kept = int(kept_xyz.shape[0])
-    if n_kept:
-        if g.neighbor_type != "radius" and n_kept <= g.n_neighbors:
-            raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {g.n_neighbors + 1}, "
-                             f"n_samples_fit = {n_kept}, n_samples = {n_kept}")
-        kept_long = kept_idx              # int32 indices: torch indexes with them as they are
-        inten = ptc_dev[kept_long, 3].contiguous() if g.affinity_type == "3d_l2_distance" else None
-        lab_kept, _ = ops.cluster_dbscan(kept_xyz, pp_dev[kept_long].contiguous(), g.n_neighbors, g.radius,
-                                         args.clustering.DBSCAN.eps, args.clustering.DBSCAN.min_samples,
-                                         neighbor_type=g.neighbor_type, affinity_type=g.affinity_type,
-                                         intensity=inten)
-        labels_dev[kept_long] = lab_kept          # device copy for the cluster statistics (plumbing)
-        labels = labels_dev.cpu().numpy().astype(int)
+    # mask, graph, DBSCAN and labels[ptc_mask] = ... in one device call (generate_mask.py:57-88)
+    labels_dev, n_kept = ops.mask_cluster(ptc_dev, pp_dev, plane, pe.offset, pe.range, args.limit_range,
+                                          g.n_neighbors, g.radius, args.clustering.DBSCAN.eps,
+                                          args.clustering.DBSCAN.min_samples, neighbor_type=g.neighbor_type,
+                                          affinity_type=g.affinity_type)
+    labels = labels_dev.cpu().numpy().astype(int)
     labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
                                     plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
                                     pp_dev=pp_dev, labels_dev=labels_dev, plane_prepared=prep[1], **args.filtering)

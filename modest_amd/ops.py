@@ -270,6 +270,38 @@ def cluster_dbscan(xyz: torch.Tensor, pp: torch.Tensor, n_neighbors: int = 70, r
     return (labels, int(ncl.value), kth) if return_kth else (labels, int(ncl.value))
 
 
+def mask_cluster(pts: torch.Tensor, pp: torch.Tensor, plane: np.ndarray, offset: float, only_range, limit_range,
+                 n_neighbors: int = 70, radius: float = 2.0, eps: float = 0.1, min_samples: int = 10,
+                 neighbor_type: str = "radius_mutual_knn", affinity_type: str = "l1",
+                 ctx: Optional[Context] = None):
+    """plane_range_mask + cluster_dbscan + ``labels[ptc_mask] = ...`` (generate_mask.py:57-88) in one
+    call.  Returns (labels (n,) int32 device, -1 = masked out or noise; number of kept rows)."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    _dev(pp, torch.float32, "pp")
+    if neighbor_type not in GRAPH_TYPES:
+        raise NotImplementedError(neighbor_type)
+    if affinity_type not in AFFINITY_TYPES:
+        raise NotImplementedError(affinity_type)
+    n = pts.shape[0]
+    assert pp.shape[0] == n
+    plane = np.ascontiguousarray(plane, dtype=np.float64).reshape(4)
+    lim = np.ascontiguousarray(np.asarray(limit_range, dtype=np.float64).reshape(4))
+    onl = None if only_range is None else np.ascontiguousarray(np.asarray(only_range, dtype=np.float64).reshape(4))
+    labels = torch.empty((n,), dtype=torch.int32, device=pts.device)
+    n_kept, ncl = C.c_int32(0), C.c_int32(0)
+    c = _ctx(ctx, pts)
+    rc = lib.modest_mask_cluster(c.handle, pts.data_ptr(), n, pts.shape[1], pp.data_ptr(), _np_ptr(plane), float(offset),
+                                 None if onl is None else _np_ptr(onl), _np_ptr(lim), GRAPH_TYPES[neighbor_type],
+                                 AFFINITY_TYPES[affinity_type], int(n_neighbors), float(radius), float(eps),
+                                 int(min_samples), labels.data_ptr(), C.byref(n_kept), C.byref(ncl), _stream())
+    if rc and neighbor_type != "radius" and 0 < n_kept.value <= n_neighbors:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {n_neighbors + 1}, "
+                         f"n_samples_fit = {n_kept.value}, n_samples = {n_kept.value}")
+    check(rc, "modest_mask_cluster")
+    return labels, int(n_kept.value)
+
+
 def cluster_stats(pts: torch.Tensor, pp: torch.Tensor, labels: torch.Tensor, n_clusters: int,
                   plane: np.ndarray, quantile: float, ctx: Optional[Context] = None) -> np.ndarray:
     """Per-cluster (count, min dist, max dist, a, b, gamma) for is_valid_cluster; (C,6) float64 host."""

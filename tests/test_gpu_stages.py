@@ -226,6 +226,49 @@ def test_cluster_dbscan_vs_sklearn_full_size(gpu):
     assert ncl == ref.max() + 1 and ncl > 3
 
 
+def test_mask_cluster_fused_equals_separate_calls(gpu):
+    """modest_mask_cluster (mask + grid count + DBSCAN + label scatter in one call) against
+    plane_range_mask -> cluster_dbscan -> labels[mask] = ..., every graph / weight variant, repeated calls
+    on one context (the persistent cell counters must come back zeroed), ranges that cut the grid."""
+    import torch
+    from modest_amd import ops, synth
+    s = synth.make_scan(23, n_live=30000, n_trav=2, n_frames=1)
+    rng = np.random.default_rng(5)
+    for rep, (n, lim, onl) in enumerate(((30000, [[-70, 70], [-40, 40]], [[-20, 70], [-20, 20]]),
+                                         (9000, [[0, 70], [-40, 40]], None),
+                                         (30000, [[-1000, 1000], [-1000, 1000]], [[-30, 30], [-30, 30]]),
+                                         (4000, [[-8, 8], [-8, 8]], None))):
+        ptc = np.ascontiguousarray(s.live_raw[rng.permutation(len(s.live_raw))[:n]])
+        ppv = np.clip(0.5 + 0.5 * np.sin(ptc[:, 0] * 0.3) + rng.normal(0, 0.03, n), 0, 1).astype(np.float32)
+        plane = np.array([0.01, -0.02, 1.0, 1.6])
+        d, p = torch.from_numpy(ptc).to(gpu), torch.from_numpy(ppv).to(gpu)
+        for nt, at, k, radius, eps in (("radius_mutual_knn", "l1", 70, 2.0, 0.1), ("radius", "3d_l2_distance", 70, 1.0, 0.45),
+                                       ("knn", "l1", 25, 1.0, 0.03), ("radius_mutual_knn", "exp", 70, 2.0, 1.0005)):
+            _, kept, idx = ops.plane_range_mask(d, plane, 0.05, onl, lim)
+            ref = torch.full((n,), -1, dtype=torch.int32, device=gpu)
+            if kept.shape[0]:
+                inten = d[idx.long(), 3].contiguous() if at == "3d_l2_distance" else None
+                lab, _ = ops.cluster_dbscan(kept, p[idx.long()].contiguous(), k, radius, eps, 10, neighbor_type=nt,
+                                            affinity_type=at, intensity=inten)
+                ref[idx.long()] = lab
+            got, n_kept = ops.mask_cluster(d, p, plane, 0.05, onl, lim, k, radius, eps, 10, neighbor_type=nt,
+                                           affinity_type=at)
+            assert n_kept == kept.shape[0]
+            assert torch.equal(got, ref), (rep, nt, at, int((got != ref).sum()))
+            assert int(ref.max()) >= 1 or n < 5000
+    # fewer kept rows than neighbours: the error sklearn raises, and the context stays usable
+    few = torch.from_numpy(np.ascontiguousarray(s.live_raw[:50])).to(gpu)
+    with pytest.raises(ValueError):
+        ops.mask_cluster(few, torch.zeros(50, device=gpu), np.array([0, 0, 1.0, 100.0]), 0.05, None, [[-70, 70], [-40, 40]])
+    lab, nk = ops.mask_cluster(few, torch.zeros(50, device=gpu), np.array([0, 0, 1.0, -100.0]), 0.05, None,
+                               [[-70, 70], [-40, 40]])
+    assert nk == 0 and bool((lab == -1).all())
+    got2, _ = ops.mask_cluster(d, p, plane, 0.05, onl, lim)
+    _, kept, idx = ops.plane_range_mask(d, plane, 0.05, onl, lim)
+    lab2, _ = ops.cluster_dbscan(kept, p[idx.long()].contiguous())
+    assert torch.equal(got2[idx.long()], lab2)
+
+
 def test_filter_and_boxes(gpu, ms):
     from modest_amd.utils import clustering_utils as cu
     from modest_amd.utils import pointcloud_utils as pcu
