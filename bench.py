@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-best-effort", type=int, default=16,
                     help="scans of the best-effort CPU baseline (one process per scan, workers=-1; 0 = skip)")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
+    ap.add_argument("--mask-only", action="store_true",
+                    help="diagnostic: stages 2 + 3 only (the PP score of every resident scan is computed once); "
+                         "not a BASELINE configuration")
     ap.add_argument("--stacked", action="store_true",
                     help="A/B: feed the PP stage a pre-stacked, pre-transformed history (round-1 bench input)")
     ap.add_argument("--procs", type=int, default=7,
@@ -192,7 +195,12 @@ class Runner:
 
     def step(self, i, ctx):
         a, sc = self.a, self.scans[i % len(self.scans)]
-        H = self.pp(sc, ctx)
+        if a.mask_only:   # diagnostic: the PP score of the scan is computed once, steps run stages 2 + 3
+            if getattr(sc, "_H", None) is None:
+                sc._H = self.pp(sc, ctx)
+            H = sc._H
+        else:
+            H = self.pp(sc, ctx)
         if a.pp_only:
             return H, None, None, None
         pp_host = H.cpu().numpy()

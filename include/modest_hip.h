@@ -170,6 +170,14 @@ int modest_mad_threshold(modest_ctx *ctx, const float *cand_xyz_dev,
 int modest_mad_threshold_batch(modest_ctx *ctx, const float *const *cand_xyz_dev,
                                const int32_t *n_cand, int count, float *mad_host,
                                void *stream);
+/* The RNG-independent part of the two ground fits of a scan (generate_mask.py:55-56 and
+ * clustering_utils.py:126) in one call: both candidate selections from one pass over the rows
+ * (modest_plane_candidates semantics, compacted in row order) and both MAD thresholds, two
+ * launches and one stream sync.  specs10 [host] = {max_hs, xlo, xhi, ylo, yhi} x 2;
+ * candA / candB [dev] (n,3) f32 outputs; n_cand2_host[2]; mad2_host[2] (NaN for an empty set). */
+int modest_plane_prepare(modest_ctx *ctx, const float *pts_dev, int n, int stride,
+                         const float *specs10, float *candA_dev, float *candB_dev,
+                         int32_t *n_cand2_host, float *mad2_host, void *stream);
 /* Score K trial models z = c0*x + c1*y + b (float32, pred = fma chain
  * fmaf(y,c1,x*c0)+b) against all candidates in ONE launch:
  *   n_inliers[k] = #{ |z - pred| <= thr },  sse[k], sy[k], syy[k] over the
@@ -309,6 +317,13 @@ int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz_dev,
                                double d0, int32_t *best_angle_host,
                                double *beta_host /* optional (C,n_angles) */,
                                void *stream);
+
+/* The same call for cluster points in HOST memory (get_obj's callers hold them there): the points
+ * travel with the offset / angle / summation-order tables in one staged copy.                    */
+int modest_fit_boxes_closeness_host(modest_ctx *ctx, const double *pts_xz_host,
+                                    const int32_t *offsets_host, int n_clusters,
+                                    const double *cossin_host, int n_angles, double d0,
+                                    int32_t *best_angle_host, void *stream);
 
 /* fit_method = 'variance_to_edge' (utils/pointcloud_utils.py:218-275): the same
  * angle table, criterion -var(Dx[Dx<Dy]) - var(Dy[Dy<Dx]) with numpy's var (pairwise sums of the

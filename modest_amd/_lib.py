@@ -49,11 +49,13 @@ SIGNATURES = {
                                         VP, VP, VP, VP]),
     "modest_cluster_dbscan_ex": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.c_int, VP, VP, VP, VP]),
+    "modest_plane_prepare": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP]),
     "modest_mask_cluster": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_double, VP, VP, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, VP, VP, VP, VP]),
     "modest_cluster_stats": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, C.c_double, VP, VP]),
     "modest_boxes_pp_stats": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP]),
     "modest_fit_boxes_closeness": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP, VP]),
+    "modest_fit_boxes_closeness_host": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP]),
     "modest_fit_boxes_variance": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, VP, VP, VP]),
     "modest_fit_boxes_pca": (C.c_int, [VP, VP, VP, C.c_int, VP, VP]),
     "modest_lowest_point": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),

@@ -160,6 +160,37 @@ __global__ __launch_bounds__(128) void closeness_kernel(const double *__restrict
     beta[(size_t)c * n_angles + a] = (n > 0) ? pw_sum(B, n) : 0.0;
 }
 
+// first strict maximum over the angles (pointcloud_utils.py:185-187) = largest value, ties to
+// the smallest index; one wavefront per cluster
+__device__ __forceinline__ int argmax_wave(const double *__restrict__ row, int n_angles, int lane) {
+    double mx = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int a = lane; a < n_angles; a += 64) {
+        const double v = __hip_atomic_load(row + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v > mx) {
+            mx = v;
+            arg = a;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(mx, o);
+        const int oa = __shfl_xor(arg, o);
+        if (ov > mx || (ov == mx && oa < arg)) {
+            mx = ov;
+            arg = oa;
+        }
+    }
+    return (arg == 0x7fffffff) ? -1 : arg;
+}
+
+__global__ __launch_bounds__(64) void argmax_kernel(const double *__restrict__ beta, int n_clusters,
+                                                    int n_angles, int *__restrict__ best) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= n_clusters) return;
+    const int arg = argmax_wave(beta + (size_t)c * n_angles, n_angles, lane);
+    if (lane == 0) best[c] = arg;
+}
+
 // The same sum, spread over the lanes of a block.  numpy's pairwise sum is a fixed binary tree
 // over the index range (of every 8192-element reduction buffer) whose leaves hold 65..128 elements (or everything when n <= 128); the host
 // lists the leaves of every cluster and the post-order "program" (0 = next leaf, 1 = add) that
@@ -177,7 +208,8 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
                                                              const int2 *__restrict__ leaves,
                                                              const int *__restrict__ progBase,
                                                              const unsigned char *__restrict__ prog,
-                                                             int maxLeaves, double *__restrict__ beta) {
+                                                             int maxLeaves, double *__restrict__ beta,
+                                                             unsigned *tickets, int *__restrict__ best_host) {
     constexpr int AB = 256 / P;
     extern __shared__ double ct_lsum[];          // [AB][maxLeaves]
     __shared__ double stk[AB][CT_STACK];
@@ -223,18 +255,34 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
         if (l < nl && (sub & 7) == 0) ls[l] = v;
     }
     __syncthreads();
-    if (sub != 0 || a >= n_angles) return;
-    double *st = stk[al];
-    int sp = 0, li = 0;
-    for (int t = progBase[c]; t < progBase[c + 1]; ++t) {
-        if (prog[t] == 0) {
-            st[sp++] = ls[li++];
-        } else {
-            const double r = st[--sp], l = st[--sp];
-            st[sp++] = l + r;
+    if (sub == 0 && a < n_angles) {
+        double *st = stk[al];
+        int sp = 0, li = 0;
+        for (int t = progBase[c]; t < progBase[c + 1]; ++t) {
+            if (prog[t] == 0) {
+                st[sp++] = ls[li++];
+            } else {
+                const double r = st[--sp], l = st[--sp];
+                st[sp++] = l + r;
+            }
         }
+        __hip_atomic_store(beta + (size_t)c * n_angles + a, (n > 0) ? st[0] : 0.0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    beta[(size_t)c * n_angles + a] = (n > 0) ? st[0] : 0.0;
+    // the block that finishes a cluster last picks the angle (tickets: one word per cluster, left at zero)
+    // (no __threadfence(): on this multi-XCD part it writes back / invalidates a whole L2; the betas are
+    // agent-scope write-through stores that the barrier waits for, the last block reads them the same way)
+    if (!tickets) return;
+    __shared__ unsigned last_s;
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = atomicAdd(tickets + c, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_s || threadIdx.x >= 64) return;
+    const int arg = argmax_wave(beta + (size_t)c * n_angles, n_angles, threadIdx.x);
+    if (threadIdx.x == 0) {
+        best_host[c] = arg;
+        tickets[c] = 0u;
+    }
 }
 
 // leaves and combine program of numpy's pairwise sum over n elements (host side)
@@ -250,32 +298,6 @@ static void pw_tree_host(int off, int n, std::vector<int> &leaf, std::vector<uns
     pw_tree_host(off, n2, leaf, prog);
     pw_tree_host(off + n2, n - n2, leaf, prog);
     prog.push_back(1);
-}
-
-// first strict maximum over the angles (pointcloud_utils.py:185-187) = largest value, ties to
-// the smallest index; one wavefront per cluster
-__global__ __launch_bounds__(64) void argmax_kernel(const double *__restrict__ beta, int n_clusters,
-                                                    int n_angles, int *__restrict__ best) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    if (c >= n_clusters) return;
-    double mx = -INFINITY;
-    int arg = 0x7fffffff;
-    for (int a = lane; a < n_angles; a += 64) {
-        const double v = beta[(size_t)c * n_angles + a];
-        if (v > mx) {
-            mx = v;
-            arg = a;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(mx, o);
-        const int oa = __shfl_xor(arg, o);
-        if (ov > mx || (ov == mx && oa < arg)) {
-            mx = ov;
-            arg = oa;
-        }
-    }
-    if (lane == 0) best[c] = (arg == 0x7fffffff) ? -1 : arg;
 }
 
 // ---- fit_method = 'variance_to_edge' (utils/pointcloud_utils.py:218-275) ---------------
@@ -508,19 +530,15 @@ struct Box6 {
     double cx, cz, l, w, c, s;
 };
 
-// order-preserving 64-bit key of a double; 0 is below every real value ("no point inside")
-__device__ __forceinline__ unsigned long long d2key(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
-}
-
-// grid (LOW_SPLIT point slices, boxes): a block scans its slice of the points for one box, reduces
-// in registers / LDS and posts one atomic.  (One atomic per wavefront with a point inside made
-// the 64-bit atomics on a handful of addresses the whole cost of the kernel.)
+// grid (LOW_SPLIT point slices, boxes): a block scans its slice of the points for one box and
+// reduces in registers / LDS; the block that finishes a box last (ticket per box, left at zero)
+// combines the LOW_SPLIT partial maxima and writes the result to pinned host memory.  The box
+// table is read from pinned host memory as well: no copy or memset launches around the kernel.
 constexpr int LOW_SPLIT = 8;
 __global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__ pts, int n,
                                                       const Box6 *__restrict__ boxes, int n_boxes,
-                                                      unsigned long long *__restrict__ out) {
+                                                      double *__restrict__ partial, unsigned *tickets,
+                                                      double *__restrict__ out_host) {
     const Box6 b = boxes[blockIdx.y];
     const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
     double best = -INFINITY;
@@ -537,19 +555,32 @@ __global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 16; ++k) best = fmax(best, red[k]);
-        if (best > -INFINITY) atomicMax(out + blockIdx.y, d2key(best));
+        __hip_atomic_store(partial + (size_t)blockIdx.y * LOW_SPLIT + blockIdx.x, best, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the write-through store has completed
+        if (atomicAdd(tickets + blockIdx.y, 1u) == LOW_SPLIT - 1) {
+            double m = -INFINITY;
+            for (int k = 0; k < LOW_SPLIT; ++k)
+                m = fmax(m, __hip_atomic_load(partial + (size_t)blockIdx.y * LOW_SPLIT + k, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT));
+            out_host[blockIdx.y] = m;   // -inf: no point inside
+            tickets[blockIdx.y] = 0u;
+        }
     }
 }
 
 }  // namespace
 
+// pts_host != NULL: the points are host memory and travel in the same upload block as the tables
+// (one copy for the whole call); otherwise pts_xz is device memory.
 static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz, const int32_t *offsets_host,
                             int n_clusters, const double *cossin_host, int n_angles, double d0,
-                            int32_t *best_angle_host, double *beta_host, void *stream_) {
+                            int32_t *best_angle_host, double *beta_host, void *stream_,
+                            const double *pts_host = nullptr) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n_clusters >= 0 && n_angles >= 1 && n_angles <= 65536, "bad sizes");
     if (n_clusters == 0) return MODEST_OK;
-    MODEST_REQUIRE(pts_xz && offsets_host && cossin_host && best_angle_host, "NULL buffer");
+    MODEST_REQUIRE((pts_xz || pts_host) && offsets_host && cossin_host && best_angle_host, "NULL buffer");
     MODEST_REQUIRE(n_clusters <= 65535, "too many clusters");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
@@ -581,7 +612,8 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
     const size_t u_pb = u_lb + arena_sz(leafBase.size() * 4);
     const size_t u_lf = u_pb + arena_sz(progBase.size() * 4);
     const size_t u_pg = u_lf + arena_sz(leaf.size() * 4);
-    const size_t b_up = u_pg + arena_sz(prog.size());
+    const size_t u_pts = u_pg + arena_sz(prog.size());
+    const size_t b_up = u_pts + (pts_host ? arena_sz((size_t)offsets_host[n_clusters] * 16) : 0);
     const size_t b_beta = arena_sz((size_t)n_clusters * n_angles * 8), b_best = arena_sz((size_t)n_clusters * 4);
     int rc = modest_ctx_reserve(ctx, b_up + b_beta + b_best);
     if (rc) return rc;
@@ -602,8 +634,20 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
         if (!leaf.empty()) memcpy(h + u_lf, leaf.data(), leaf.size() * 4);
         if (!prog.empty()) memcpy(h + u_pg, prog.data(), prog.size());
     }
+    if (pts_host) {
+        memcpy(h + u_pts, pts_host, (size_t)offsets_host[n_clusters] * 16);
+        pts_xz = reinterpret_cast<const double *>(d + u_pts);
+    }
     MODEST_HIP_CHECK(hipMemcpyAsync(d, h, b_up, hipMemcpyHostToDevice, stream));
     dim3 grid((n_angles + 127) / 128, n_clusters);
+    unsigned *tickets = nullptr;   // the tree kernel picks the best angle itself (a ticket word per cluster)
+    if (!variance && n_clusters <= (int)MODEST_ZW_TICKETS) {
+        unsigned *zw = nullptr;
+        rc = modest_ctx_zero_words(ctx, stream, &zw);
+        if (rc) return rc;
+        tickets = modest_tickets(zw);
+    }
+    bool picked = false;
     const int P = maxN > 4096 ? 64 : 16, AB = 256 / P;
     const size_t lds = (size_t)AB * maxLeaves * 8;
     if (variance) {
@@ -615,15 +659,16 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
         const unsigned char *d_pg = reinterpret_cast<const unsigned char *>(d + u_pg);
         if (P == 64)
             closeness_tree_kernel<64><<<g2, 256, lds, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_lb, d_lf, d_pb,
-                                                                d_pg, maxLeaves, d_beta);
+                                                                d_pg, maxLeaves, d_beta, tickets, h_best);
         else
             closeness_tree_kernel<16><<<g2, 256, lds, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_lb, d_lf, d_pb,
-                                                                d_pg, maxLeaves, d_beta);
+                                                                d_pg, maxLeaves, d_beta, tickets, h_best);
+        picked = tickets != nullptr;
     } else {   // a cluster of > 90 k points: one lane per (cluster, angle)
         closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
     }
     (void)d_best;
-    argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, h_best);   // pinned host memory
+    if (!picked) argmax_kernel<<<n_clusters, 64, 0, stream>>>(d_beta, n_clusters, n_angles, h_best);   // pinned host memory
     MODEST_HIP_CHECK(hipGetLastError());
     if (beta_host)
         MODEST_HIP_CHECK(hipMemcpyAsync(h_beta, d_beta, (size_t)n_clusters * n_angles * 8,
@@ -642,6 +687,14 @@ extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
                                           void *stream_) {
     return fit_boxes_angles(ctx, 0, pts_xz, offsets_host, n_clusters, cossin_host, n_angles, d0, best_angle_host,
                             beta_host, stream_);
+}
+
+extern "C" int modest_fit_boxes_closeness_host(modest_ctx *ctx, const double *pts_xz_host,
+                                               const int32_t *offsets_host, int n_clusters,
+                                               const double *cossin_host, int n_angles, double d0,
+                                               int32_t *best_angle_host, void *stream_) {
+    return fit_boxes_angles(ctx, 0, nullptr, offsets_host, n_clusters, cossin_host, n_angles, d0, best_angle_host,
+                            nullptr, stream_, pts_xz_host);
 }
 
 extern "C" int modest_fit_boxes_variance(modest_ctx *ctx, const double *pts_xz,
@@ -694,28 +747,28 @@ extern "C" int modest_lowest_point(modest_ctx *ctx, const double *pts_rect, int 
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t b_box = arena_sz((size_t)n_boxes * sizeof(Box6)), b_out = arena_sz((size_t)n_boxes * 8);
-    int rc = modest_ctx_reserve(ctx, b_box + b_out);
+    int rc = modest_ctx_reserve(ctx, arena_sz((size_t)n_boxes * LOW_SPLIT * 8));
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, b_box + b_out);
     if (rc) return rc;
-    Box6 *d_box = reinterpret_cast<Box6 *>(ctx->scratch);
-    unsigned long long *d_out = reinterpret_cast<unsigned long long *>(ctx->scratch + b_box);
-    double *h_box = reinterpret_cast<double *>(ctx->pinned);
-    unsigned long long *h_out = reinterpret_cast<unsigned long long *>(ctx->pinned + b_box);
-    for (int i = 0; i < 6 * n_boxes; ++i) h_box[i] = boxes6_host[i];
-    MODEST_HIP_CHECK(hipMemcpyAsync(d_box, h_box, (size_t)n_boxes * sizeof(Box6), hipMemcpyHostToDevice, stream));
-    MODEST_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)n_boxes * 8, stream));
-    if (n > 0)
-        lowest_kernel<<<dim3(LOW_SPLIT, n_boxes), 1024, 0, stream>>>(pts_rect, n, d_box, n_boxes, d_out);
-    MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_boxes * 8, hipMemcpyDeviceToHost, stream));
-    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-    for (int i = 0; i < n_boxes; ++i) {   // undo d2key; key 0 = no point inside = -inf
-        const unsigned long long k = h_out[i];
-        const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
-        double v;
-        memcpy(&v, &u, 8);
-        bottom_host[i] = k ? v : -INFINITY;
+    double *d_part = reinterpret_cast<double *>(ctx->scratch);
+    Box6 *h_box = reinterpret_cast<Box6 *>(ctx->pinned);
+    double *h_out = reinterpret_cast<double *>(ctx->pinned + b_box);
+    memcpy(h_box, boxes6_host, (size_t)n_boxes * sizeof(Box6));
+    if (n == 0) {
+        for (int i = 0; i < n_boxes; ++i) bottom_host[i] = -INFINITY;
+        return MODEST_OK;
     }
+    unsigned *zw = nullptr;
+    rc = modest_ctx_zero_words(ctx, stream, &zw);
+    if (rc) return rc;
+    for (int b0 = 0; b0 < n_boxes; b0 += (int)MODEST_ZW_TICKETS) {   // a ticket word per box of the launch
+        const int nb = std::min(n_boxes - b0, (int)MODEST_ZW_TICKETS);
+        lowest_kernel<<<dim3(LOW_SPLIT, nb), 1024, 0, stream>>>(pts_rect, n, h_box + b0, nb, d_part + (size_t)b0 * LOW_SPLIT,
+                                                               modest_tickets(zw), h_out + b0);
+    }
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_boxes; ++i) bottom_host[i] = h_out[i];
     return MODEST_OK;
 }

@@ -97,72 +97,90 @@ __global__ void cg_count(const float *__restrict__ xyz, int n, const CGrid *g, u
     atomicAdd(&cnt[cy * CG + cx], 1u);
 }
 
-// exclusive scan of `n` counters into out[0..n] by one 1024-thread workgroup: every wavefront
-// owns a contiguous segment and walks it 64 counters at a time (coalesced, four rounds of loads
-// in flight), first for the segment totals, then for the prefixes with a running carry
+// exclusive scan of `n` counters into out[0..n] by one 1024-thread workgroup, 8192 counters per
+// round.  A wavefront owns 512 consecutive counters: it loads them as 8 coalesced rows, turns
+// them through its LDS tile so that every lane holds 8 CONSECUTIVE counters (row stride 9 words:
+// next to no bank conflicts either way), scans lane sums with shuffles, and turns the prefixes back for
+// coalesced stores.  One pass over the data, one barrier per round.
 // CELLS (the grid's cell counters): also writes the scatter cursors (= the prefixes), clears the
 // counters behind itself when `clear_in` is set (the persistent counters of the fused mask call
 // stay zero between calls) and clears the four flag words of the call.
+constexpr int SCAN_IPT = 8;
 template <bool CELLS>
 __global__ __launch_bounds__(1024) void scan_u32(const unsigned *in, unsigned *__restrict__ out, int n,
                                                  unsigned *__restrict__ total_copy = nullptr,
                                                  const int *__restrict__ flag_src = nullptr,
                                                  unsigned *__restrict__ cursor = nullptr,
                                                  unsigned *clear_in = nullptr, unsigned *flags = nullptr) {
-    __shared__ unsigned wtot[16];
+    __shared__ unsigned tile[16][64 * (SCAN_IPT + 1)];
+    __shared__ unsigned wtot[2][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int seg = (((n + 15) / 16) + 63) & ~63;           // per-wavefront segment, multiple of 64
-    const int b = min(w * seg, n), e = min(b + seg, n);
-    unsigned s = 0;
-    for (int k0 = b; k0 < e; k0 += 256) {
-        unsigned v[4];
+    unsigned *T = tile[w];
+    unsigned carry = 0;
+    int buf = 0;
+    for (int t0 = 0; t0 < n; t0 += 1024 * SCAN_IPT, buf ^= 1) {
+        const int seg = t0 + w * 64 * SCAN_IPT;
+        unsigned v[SCAN_IPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * 64 + lane;
-            v[u] = k < e ? in[k] : 0u;
-        }
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) wtot[w] = s;
-    __syncthreads();
-    unsigned carry = 0, total = 0;
-    for (int q = 0; q < 16; ++q) {
-        if (q < w) carry += wtot[q];
-        total += wtot[q];
-    }
-    for (int k0 = b; k0 < e; k0 += 256) {
-        unsigned v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * 64 + lane;
-            v[u] = k < e ? in[k] : 0u;
+        for (int q = 0; q < SCAN_IPT; ++q) {
+            const int e = q * 64 + lane;
+            v[q] = seg + e < n ? in[seg + e] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            unsigned inc = v[u];
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = __shfl_up(inc, o);
-                if (lane >= o) inc += t;
-            }
-            const int k = k0 + u * 64 + lane;
-            if (k < e) {
-                out[k] = carry + inc - v[u];
+        for (int q = 0; q < SCAN_IPT; ++q) {
+            const int e = q * 64 + lane;
+            T[(e / SCAN_IPT) * (SCAN_IPT + 1) + (e % SCAN_IPT)] = v[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned mine = 0;
+#pragma unroll
+        for (int q = 0; q < SCAN_IPT; ++q) {
+            v[q] = T[lane * (SCAN_IPT + 1) + q];
+            mine += v[q];
+        }
+        unsigned inc = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wtot[buf][w] = inc;
+        __syncthreads();
+        unsigned before = carry, all = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned x = wtot[buf][q];
+            before += q < w ? x : 0u;
+            all += x;
+        }
+        unsigned run = before + inc - mine;
+#pragma unroll
+        for (int q = 0; q < SCAN_IPT; ++q) {
+            T[lane * (SCAN_IPT + 1) + q] = run;
+            run += v[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < SCAN_IPT; ++q) {
+            const int e = q * 64 + lane;
+            const unsigned x = T[(e / SCAN_IPT) * (SCAN_IPT + 1) + (e % SCAN_IPT)];
+            if (seg + e < n) {
+                out[seg + e] = x;
                 if (CELLS) {
-                    cursor[k] = carry + inc - v[u];
-                    if (clear_in) clear_in[k] = 0u;
+                    cursor[seg + e] = x;
+                    if (clear_in) clear_in[seg + e] = 0u;
                 }
             }
-            carry += __shfl(inc, 63);
         }
+        __builtin_amdgcn_wave_barrier();
+        carry += all;
     }
     if (CELLS && flags && threadIdx.x < 4) flags[threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
-        out[n] = total;
+        out[n] = carry;
         // pinned host memory: [overflow flag, total] are there when the stream has been synchronised
         if (total_copy) {
             total_copy[0] = flag_src ? (unsigned)*flag_src : 0u;
-            total_copy[1] = total;
+            total_copy[1] = carry;
         }
     }
 }
@@ -1084,7 +1102,8 @@ extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int
     CGrid *g = A.take<CGrid>(1);
     int *h_kept = reinterpret_cast<int *>(ctx->pinned + 32);   // pinned: there after the sync, no copy
     unsigned *cnt = nullptr;
-    rc = modest_ctx_zero_words(ctx, CG_CELLS, stream, &cnt);
+    static_assert(CG_CELLS == (int)MODEST_ZW_CELLS, "persistent cell counters");
+    rc = modest_ctx_zero_words(ctx, stream, &cnt);
     if (rc) return rc;
     ctx->zwords_dirty = 1;   // until the cell scan behind the counters has been enqueued
     MaskParams P;

@@ -48,9 +48,14 @@ int modest_ctx_stage_commit(modest_ctx *ctx, hipStream_t stream);
 // persistent compaction state for `nblocks` blocks (allocated and zeroed on first use / growth)
 int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream, unsigned long long **out);
 
-// persistent zeroed counter words (see modest_ctx::zwords); cleared here on first use, growth, or
-// when the dirty mark is still set
-int modest_ctx_zero_words(modest_ctx *ctx, size_t words, hipStream_t stream, unsigned **out);
+// persistent zeroed counter words (see modest_ctx::zwords); cleared here on first use or when the
+// dirty mark is still set.  Layout: [0, MODEST_ZW_CELLS) cell counters of the fused mask call,
+// [MODEST_ZW_CELLS, +MODEST_ZW_TICKETS) "last block done" tickets of kernels that finish their own
+// reduction (every such kernel leaves its tickets at zero).
+constexpr size_t MODEST_ZW_CELLS = 16384;
+constexpr size_t MODEST_ZW_TICKETS = 4096;
+int modest_ctx_zero_words(modest_ctx *ctx, hipStream_t stream, unsigned **out);
+static inline unsigned *modest_tickets(unsigned *zwords) { return zwords + MODEST_ZW_CELLS; }
 
 // Record an event pair around a kernel when profiling is on (no-ops otherwise).
 void modest_prof_mark(modest_ctx *ctx, hipStream_t stream, int end);

@@ -1,5 +1,6 @@
 // Context, error string and arena management for libmodest_hip.so.
 #include "common.h"
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <new>
@@ -55,6 +56,12 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->pinned = nullptr;
     c->pinned_bytes = 0;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // tuning knob: size the persistent PP grids for fewer CUs (leaves room for the small kernels of other
+    // host processes that share the GPU)
+    if (const char *e = getenv("MODEST_NUM_CUS")) {
+        const int v = atoi(e);
+        if (v >= 8 && v <= c->num_cus) c->num_cus = v;
+    }
     c->profiling = 0;
     c->prof_count = 0;
     c->prof_ev = nullptr;
@@ -109,7 +116,8 @@ int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream
     return MODEST_OK;
 }
 
-int modest_ctx_zero_words(modest_ctx *ctx, size_t words, hipStream_t stream, unsigned **out) {
+int modest_ctx_zero_words(modest_ctx *ctx, hipStream_t stream, unsigned **out) {
+    const size_t words = MODEST_ZW_CELLS + MODEST_ZW_TICKETS;
     if (words > ctx->zwords_count) {
         MODEST_HIP_CHECK(hipDeviceSynchronize());
         if (ctx->zwords) MODEST_HIP_CHECK(hipFree(ctx->zwords));

@@ -44,11 +44,46 @@ __global__ __launch_bounds__(1024) void candidates_kernel(const float *__restric
     }
 }
 
+// Both candidate selections of a scan (estimate_plane's and filter_labels') in one pass over the
+// rows: two ordered compactions side by side (own state block each, one shared block ticket).
+struct CandSpec {
+    float max_hs, xlo, xhi, ylo, yhi;
+};
+__global__ __launch_bounds__(1024) void candidates2_kernel(const float *__restrict__ pts, int n, int stride, CandSpec A,
+                                                           CandSpec B, float *__restrict__ candA,
+                                                           float *__restrict__ candB, unsigned long long *stateA,
+                                                           unsigned long long *stateB, int *n_out /* [2] */) {
+    const unsigned blk = compact_ticket(stateA);
+    const long long i = (long long)blk * 1024 + threadIdx.x;
+    bool ka = false, kb = false;
+    float x = 0, y = 0, z = 0;
+    if (i < n) {
+        const float *p = pts + i * stride;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+        ka = (z < A.max_hs) && (x > A.xlo) && (x < A.xhi) && (y > A.ylo) && (y < A.yhi);
+        kb = (z < B.max_hs) && (x > B.xlo) && (x < B.xhi) && (y > B.ylo) && (y < B.yhi);
+    }
+    const unsigned long long da = compact_offset(ka, blk, gridDim.x, stateA, n_out);
+    if (ka) {
+        candA[3 * da + 0] = x;
+        candA[3 * da + 1] = y;
+        candA[3 * da + 2] = z;
+    }
+    const unsigned long long db = compact_offset(kb, blk, gridDim.x, stateB, n_out + 1);
+    if (kb) {
+        candB[3 * db + 0] = x;
+        candB[3 * db + 1] = y;
+        candB[3 * db + 2] = z;
+    }
+}
+
 // ---- MAD(z): median and median absolute deviation, one workgroup ---------------------
 // One workgroup = one CU, and this kernel is bound by that CU's instruction issue (64 lanes x
 // 1 instruction per cycle for 16 wavefronts), so everything is about instructions per element
 // and pass: the order-preserving keys are computed once per median and kept in registers, a
-// select is three 11/11/10-bit histogram rounds of three barriers each, the scan zeroes the
+// select is two or three 2048-bin histogram rounds of three barriers each, the scan zeroes the
 // histogram for the next round as it reads it.
 __device__ __forceinline__ unsigned f2key(float f) {
     const unsigned u = __float_as_uint(f);
@@ -98,48 +133,49 @@ __device__ __forceinline__ void for_keys(const KeysGlobal &K, int n, F f) {
 struct MadShared {
     unsigned hist[2048];   // zero between rounds
     unsigned wsum[16];
-    unsigned sel[3], knew[3], cnt[3];
+    unsigned sel[3], knew[3];
     unsigned cntLess, maxLessKey;
+    unsigned kmin, kmax;   // 0xffffffff / 0 between selects
 };
 
-// hist[bin] += 1 for the lanes with act set; must be reached by the whole wavefront.
-// Ground heights crowd into a few bins and same-address LDS atomics serialise, so the two most
-// common bins of the wavefront are added once per wavefront; the rest go one by one.
-__device__ __forceinline__ void lds_hist_add(unsigned *hist, unsigned bin, bool act) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(act);
-    for (int r = 0; r < 2 && todo; ++r) {
-        const int lead = __ffsll((long long)todo) - 1;
-        const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)bin, lead);
-        const unsigned long long same = __ballot(act && bin == lb);
-        if (lane == lead) atomicAdd(&hist[lb], (unsigned)__popcll(same));
-        if (bin == lb) act = false;
-        todo &= ~same;
-    }
-    if (act) atomicAdd(&hist[bin], 1u);
-}
-
 // exact k-th smallest key (0-based).  S.hist is zero on entry and on exit.
+// Radix select over the RANGE the keys actually span: the first round spreads [min key, max key]
+// over the 2048 bins, every later round the selected bin, until a bin is one key value (at most
+// three rounds; two for ground heights).  Fixed bit fields put a scan's ground heights -- one or
+// two float exponents -- into a handful of bins, where same-address LDS atomics serialise; spread
+// bins take one plain atomic per element.
 template <class KS>
 __device__ __forceinline__ unsigned select_kth(const KS &K, int n, unsigned k, MadShared &S) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned prefix = 0, mask = 0, remaining = (unsigned)n;
-    const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
-#pragma unroll
-    for (int ps = 0; ps < 3; ++ps) {
-        const int shift = shifts[ps];
-        const unsigned bm = (1u << bitsv[ps]) - 1u;
-        // the aggregated add costs ~25 instructions per slot whether or not anything matches; once
-        // few elements are left, collisions cannot serialise for long and a plain atomic is cheaper
-        if (remaining > 4096u)
-            for_keys(K, n, [&](unsigned key, bool valid) {
-                lds_hist_add(S.hist, (key >> shift) & bm, valid && (key & mask) == prefix);
-            });
-        else
-            for_keys(K, n, [&](unsigned key, bool valid) {
-                if (valid && (key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & bm], 1u);
-            });
+    unsigned mn = 0xffffffffu, mx = 0u;
+    for_keys(K, n, [&](unsigned key, bool valid) {
+        if (valid) {
+            mn = min(mn, key);
+            mx = max(mx, key);
+        }
+    });
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    }
+    if (lane == 0) {
+        atomicMin(&S.kmin, mn);
+        atomicMax(&S.kmax, mx);
+    }
+    __syncthreads();
+    unsigned lo = S.kmin;
+    const unsigned range = S.kmax - lo;
+    int shift = max(0, 32 - (int)__clz(range) - 11);   // (range >> shift) < 2048
+    for (int ps = 0;; ++ps) {
+        for_keys(K, n, [&](unsigned key, bool valid) {
+            const unsigned b = (key - lo) >> shift;
+            if (valid && key >= lo && b < 2048u) atomicAdd(&S.hist[b], 1u);
+        });
         __syncthreads();
+        if (ps == 0 && tid == 0) {   // everybody has read the range: reset it for the next select
+            S.kmin = 0xffffffffu;
+            S.kmax = 0u;
+        }
         // block scan, two bins per thread; the bins are cleared for the next round on the way
         const unsigned v0 = S.hist[2 * tid], v1 = S.hist[2 * tid + 1];
         S.hist[2 * tid] = 0;
@@ -158,19 +194,17 @@ __device__ __forceinline__ unsigned select_kth(const KS &K, int n, unsigned k, M
         if (k >= excl && k < excl + v0) {
             S.sel[ps] = 2 * tid;
             S.knew[ps] = k - excl;
-            S.cnt[ps] = v0;
         } else if (k >= excl + v0 && k < incl) {
             S.sel[ps] = 2 * tid + 1;
             S.knew[ps] = k - excl - v0;
-            S.cnt[ps] = v1;
         }
         __syncthreads();
-        prefix |= S.sel[ps] << shift;
-        mask |= bm << shift;
+        lo += S.sel[ps] << shift;
         k = S.knew[ps];
-        remaining = S.cnt[ps];
+        if (shift == 0) break;
+        shift = max(0, shift - 11);
     }
-    return prefix;
+    return lo;
 }
 
 // numpy.median: odd -> middle element; even -> float32 mean of the two middle ones.  The lower
@@ -211,35 +245,42 @@ constexpr int MAD_SETS = 4;
 struct MadArgs {
     const float *cand[MAD_SETS];
     int n[MAD_SETS];
+    const int *n_dev[MAD_SETS];   // when set: the size is read from here (written by an earlier kernel)
+    int *n_host[MAD_SETS];        // when set: ... and mirrored to this pinned host word
     float *out[MAD_SETS];   // [median, mad] each; device or pinned host memory
 };
 
 __global__ __launch_bounds__(1024) void mad_kernel(MadArgs A) {
     __shared__ MadShared S;
     const float *__restrict__ cand = A.cand[blockIdx.x];
-    const int n = A.n[blockIdx.x];
+    const int n = A.n_dev[blockIdx.x] ? *A.n_dev[blockIdx.x] : A.n[blockIdx.x];
     float *out = A.out[blockIdx.x];
     const int tid = threadIdx.x;
+    if (A.n_host[blockIdx.x] && tid == 0) *A.n_host[blockIdx.x] = n;   // pinned mirror of a device-side size
+    if (n <= 0) {   // an empty set has no threshold (the fit raises on the host, as the reference does)
+        if (tid == 0) out[0] = out[1] = NAN;
+        return;
+    }
     S.hist[2 * tid] = 0;
     S.hist[2 * tid + 1] = 0;
     if (tid == 0) {
         S.cntLess = 0;
         S.maxLessKey = 0;
+        S.kmin = 0xffffffffu;
+        S.kmax = 0u;
     }
     float med, mad;
     if (n <= MAD_R * 1024) {
-        float z[MAD_R];
         KeysReg K;
 #pragma unroll
         for (int r = 0; r < MAD_R; ++r) {
             const int i = r * 1024 + tid;
-            z[r] = i < n ? cand[3 * (size_t)i + 2] : 0.f;
-            K.k[r] = f2key(z[r]);
+            K.k[r] = f2key(i < n ? cand[3 * (size_t)i + 2] : 0.f);
         }
         __syncthreads();
         med = median_np(K, n, S);
 #pragma unroll
-        for (int r = 0; r < MAD_R; ++r) K.k[r] = f2key(fabsf(z[r] - med));   // float32, as numpy
+        for (int r = 0; r < MAD_R; ++r) K.k[r] = f2key(fabsf(key2f(K.k[r]) - med));   // float32, as numpy (the key map is a bijection)
         mad = median_np(K, n, S);
     } else {
         __syncthreads();
@@ -317,9 +358,13 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
                                                               const float *__restrict__ models,
                                                               int K, const float *__restrict__ thr_ptr,
                                                               float thr_val /* used when thr_ptr is NULL */,
-                                                              double *__restrict__ partial, TripArg trip,
-                                                              float *__restrict__ models_host) {
+                                                              double *partial, TripArg trip,
+                                                              float *__restrict__ models_host, unsigned *ticket,
+                                                              double *__restrict__ out /* K*4, may be pinned host memory */,
+                                                              const float *__restrict__ thr_src,
+                                                              float *__restrict__ thr_dst) {
     __shared__ float sm[SCORE_KG][3];
+    __shared__ unsigned last_s;
     if (FUSED) {   // the block fits its own SCORE_KG planes; the first block column reports them
         const int k = blockIdx.y * SCORE_KG + (int)threadIdx.x;
         if (threadIdx.x < SCORE_KG && k < K) {
@@ -370,12 +415,38 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
         sy = wave_sum(sy);
         syy = wave_sum(syy);
         if (lane == 0) {
-            row[4 * k + 0] = (double)cnt;
-            row[4 * k + 1] = sse;
-            row[4 * k + 2] = sy;
-            row[4 * k + 3] = syy;
+            __hip_atomic_store(row + 4 * k + 0, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 4 * k + 1, sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 4 * k + 2, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 4 * k + 3, syy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // The block that finishes last (ticket, left at zero) adds the partial rows, one output per thread in
+    // row order (consecutive threads read consecutive words), and writes the totals.  No __threadfence():
+    // on this multi-XCD part it writes back / invalidates a whole L2.  The partial rows are agent-scope
+    // atomic stores (write-through) that the barrier waits for; the last block reads them with
+    // agent-scope loads, eight in flight per thread.
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_s) return;
+    const int nrows = gridDim.x * SCORE_WAVES;
+    for (int id = threadIdx.x; id < K * 4; id += SCORE_THREADS) {
+        double s = 0.0;
+        for (int r0 = 0; r0 < nrows; r0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = r0 + u < nrows ? __hip_atomic_load(partial + (size_t)(r0 + u) * K * 4 + id, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        out[id] = s;
+    }
+    if (threadIdx.x < 2 && thr_dst) thr_dst[threadIdx.x] = thr_src[threadIdx.x];
+    if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // exact-fit plane z = c0 x + c1 y + b through the three candidates of every trial: float64,
@@ -397,109 +468,67 @@ __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__r
     }
 }
 
-// one wavefront per output; lane-strided partial sums then a fixed shuffle tree (deterministic)
-__global__ __launch_bounds__(64) void score_reduce_kernel(const double *__restrict__ partial, int nblocks,
-                                                          int K, double *__restrict__ out /* K*4 */,
-                                                          const float *__restrict__ thr_src = nullptr,
-                                                          float *__restrict__ thr_dst = nullptr) {
-    const int id = blockIdx.x;
-    if (id >= K * 4) return;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * K * 4 + id];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) out[id] = s;   // `out` may be pinned host memory
-    if (thr_dst && id == 0 && threadIdx.x < 2) thr_dst[threadIdx.x] = thr_src[threadIdx.x];
-}
-
 // ---- refit ---------------------------------------------------------------------
-// pass 0: count, sum x, sum y, sum z over inliers; pass 1: centred 2nd moments
-// Sxx, Sxy, Syy, Sxz, Syz given the means.
-// PASS 1 first reduces pass 0's per-block partials itself (the lane-strided sums and shuffle tree
-// of refit_reduce_kernel, so the means are bit-identical in every block) -- one launch less.
-template <int PASS>
-__global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n,
-                                                              float c0, float c1, float b, float thr,
-                                                              const double *__restrict__ partial0, int nblocks0,
-                                                              double *__restrict__ acc,
-                                                              double *__restrict__ partial) {
-    constexpr int NV = PASS == 0 ? 4 : 5;
-    __shared__ double red[SCORE_WAVES][5];
-    __shared__ double means[3];
+// One pass: count and the first and second moments of the inliers about the pivot (0, 0, b) in
+// float64 (|x|, |y| <= a few hundred metres, n <= 1e6: centring the moments afterwards loses
+// ~1e-9 relative at worst, the plane is compared at 1e-4).  Every block writes its partial sums;
+// the block that finishes last (ticket, left at zero) adds the partials in block order and writes
+// the totals to pinned host memory.
+constexpr int REFIT_NV = 9;   // n, Sx, Sy, Sz, Sxx, Sxy, Syy, Sxz, Syz
+__global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n, float c0, float c1,
+                                                              float b, float thr, double *partial, unsigned *ticket,
+                                                              double *__restrict__ out_host) {
+    __shared__ double red[SCORE_WAVES][REFIT_NV];
+    __shared__ unsigned last_s;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (PASS == 1) {
-        if (w == 0) {
-            double s[4] = {0, 0, 0, 0};
-            for (int bb = lane; bb < nblocks0; bb += 64)
-                for (int q = 0; q < 4; ++q) s[q] += partial0[(size_t)bb * 5 + q];
-            for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
-            if (lane == 0) {
-                const double inv = s[0] > 0 ? 1.0 / s[0] : 0.0;
-                means[0] = s[1] * inv;
-                means[1] = s[2] * inv;
-                means[2] = s[3] * inv;
-                if (blockIdx.x == 0) {   // [0..3] sums, [4..6] means for the final reduction's mirror
-                    for (int q = 0; q < 4; ++q) acc[q] = s[q];
-                    acc[4] = means[0];
-                    acc[5] = means[1];
-                    acc[6] = means[2];
-                }
-            }
-        }
-        __syncthreads();
-    }
     const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
-    double v[5] = {0, 0, 0, 0, 0};
+    double v[REFIT_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i < n) {
         const float x = cand[3 * (size_t)i], y = cand[3 * (size_t)i + 1], z = cand[3 * (size_t)i + 2];
         if (fabsf(z - plane_pred(x, y, c0, c1, b)) <= thr) {
-            if (PASS == 0) {
-                v[0] = 1.0;
-                v[1] = x;
-                v[2] = y;
-                v[3] = z;
-            } else {
-                const double dx = (double)x - means[0], dy = (double)y - means[1], dz = (double)z - means[2];
-                v[0] = dx * dx;
-                v[1] = dx * dy;
-                v[2] = dy * dy;
-                v[3] = dx * dz;
-                v[4] = dy * dz;
-            }
+            const double dx = (double)x, dy = (double)y, dz = (double)z - (double)b;
+            v[0] = 1.0;
+            v[1] = dx;
+            v[2] = dy;
+            v[3] = dz;
+            v[4] = dx * dx;
+            v[5] = dx * dy;
+            v[6] = dy * dy;
+            v[7] = dx * dz;
+            v[8] = dy * dz;
         }
     }
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
+    for (int q = 0; q < REFIT_NV; ++q) {
         const double s = wave_sum(v[q]);
         if (lane == 0) red[w][q] = s;
     }
     __syncthreads();
-    if ((int)threadIdx.x < NV) {
+    if ((int)threadIdx.x < REFIT_NV) {
         double s = 0.0;
         for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][threadIdx.x];
-        partial[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
+        __hip_atomic_store(partial + (size_t)blockIdx.x * REFIT_NV + threadIdx.x, s, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-__global__ void refit_reduce_kernel(const double *__restrict__ partial, int nblocks, int pass,
-                                    double *__restrict__ acc /* [0..3] sums, [4..6] means, [8..12] moments */,
-                                    double *__restrict__ acc_host = nullptr /* pinned mirror, written by pass 1 */) {
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += 64)
-        for (int q = 0; q < 5; ++q) s[q] += partial[(size_t)b * 5 + q];
-    for (int q = 0; q < 5; ++q) s[q] = wave_sum(s[q]);
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (pass == 0) {
-        for (int q = 0; q < 4; ++q) acc[q] = s[q];
-        const double inv = s[0] > 0 ? 1.0 / s[0] : 0.0;
-        acc[4] = s[1] * inv;
-        acc[5] = s[2] * inv;
-        acc[6] = s[3] * inv;
-    } else {
-        for (int q = 0; q < 5; ++q) acc[8 + q] = s[q];
-        if (acc_host) {
-            for (int q = 0; q < 7; ++q) acc_host[q] = acc[q];
-            for (int q = 0; q < 5; ++q) acc_host[8 + q] = s[q];
-        }
+    __syncthreads();   // waits for the write-through stores above (no __threadfence(): see score_kernel)
+    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_s || w != 0) return;
+    double s[REFIT_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int bb = lane; bb < (int)gridDim.x; bb += 64) {
+        double t[REFIT_NV];
+#pragma unroll
+        for (int q = 0; q < REFIT_NV; ++q)
+            t[q] = __hip_atomic_load(partial + (size_t)bb * REFIT_NV + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < REFIT_NV; ++q) s[q] += t[q];
+    }
+#pragma unroll
+    for (int q = 0; q < REFIT_NV; ++q) s[q] = wave_sum(s[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < REFIT_NV; ++q) out_host[q] = s[q];
+        *ticket = 0u;
     }
 }
 
@@ -552,6 +581,50 @@ extern "C" int modest_plane_candidates(modest_ctx *ctx, const float *pts, int n,
     candidates_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, max_hs, xlo, xhi, ylo, yhi,
                                                              cand, cand_idx, state, n_cand);
     MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
+
+extern "C" int modest_plane_prepare(modest_ctx *ctx, const float *pts, int n, int stride, const float *specs10,
+                                    float *candA, float *candB, int32_t *n_cand2_host, float *mad2_host,
+                                    void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && specs10 && n_cand2_host && mad2_host, "NULL argument");
+    MODEST_REQUIRE(n >= 0 && (stride == 3 || stride == 4), "bad n/stride");
+    n_cand2_host[0] = n_cand2_host[1] = 0;
+    mad2_host[0] = mad2_host[1] = NAN;
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts && candA && candB, "NULL buffer");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = modest_ctx_reserve_pinned(ctx, 64);
+    if (rc) return rc;
+    const int nblk = (n + 1023) / 1024;
+    unsigned long long *state = nullptr;
+    rc = modest_ctx_compact_state(ctx, 2 * (size_t)nblk + 2, stream, &state);
+    if (rc) return rc;
+    rc = modest_ctx_reserve(ctx, 256);
+    if (rc) return rc;
+    int *d_n = reinterpret_cast<int *>(ctx->scratch);   // [2] counts: written by the selection, read by the MAD kernel
+    CandSpec A{specs10[0], specs10[1], specs10[2], specs10[3], specs10[4]};
+    CandSpec B{specs10[5], specs10[6], specs10[7], specs10[8], specs10[9]};
+    int *h_n = reinterpret_cast<int *>(ctx->pinned);          // [2] counts, pinned: valid after the sync
+    float *h_mad = reinterpret_cast<float *>(ctx->pinned + 16);   // [median, mad] x 2
+    candidates2_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, A, B, candA, candB, state, state + 2 + nblk, d_n);
+    MadArgs M{};
+    M.cand[0] = candA;
+    M.cand[1] = candB;
+    M.n_dev[0] = d_n;
+    M.n_dev[1] = d_n + 1;
+    M.n_host[0] = h_n;
+    M.n_host[1] = h_n + 1;
+    M.out[0] = h_mad;
+    M.out[1] = h_mad + 2;
+    mad_kernel<<<2, 1024, 0, stream>>>(M);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    n_cand2_host[0] = h_n[0];
+    n_cand2_host[1] = h_n[1];
+    mad2_host[0] = h_mad[1];
+    mad2_host[1] = h_mad[3];
     return MODEST_OK;
 }
 
@@ -624,9 +697,11 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     for (int i = 0; i < K * 3; ++i) hm[i] = models_host[i];
     hm[K * 3] = thr;   // the kernel reads the threshold from device memory
     MODEST_HIP_CHECK(hipMemcpyAsync(dm, hm, (size_t)K * 12 + 4, hipMemcpyHostToDevice, stream));
+    unsigned *zw = nullptr;
+    rc = modest_ctx_zero_words(ctx, stream, &zw);
+    if (rc) return rc;
     score_kernel<false><<<dim3(nb, (K + SCORE_KG - 1) / SCORE_KG), SCORE_THREADS, 0, stream>>>(
-        cand, n_cand, dm, K, nullptr, thr, dp, TripArg{}, nullptr);
-    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(dp, nrows, K, dout);
+        cand, n_cand, dm, K, nullptr, thr, dp, TripArg{}, nullptr, modest_tickets(zw), dout, nullptr, nullptr);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipMemcpyAsync(hout, dout, (size_t)K * 32, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -679,20 +754,24 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
         mad_kernel<<<1, 1024, 0, stream>>>(A);
     }
     const dim3 sgrid(nb, (K + SCORE_KG - 1) / SCORE_KG);
+    unsigned *zw = nullptr;
+    rc = modest_ctx_zero_words(ctx, stream, &zw);
+    if (rc) return rc;
+    const float *thr_src = thr_known ? nullptr : d_thr;
+    float *thr_dst = thr_known ? nullptr : h_thr;
     if (K <= TRIP_MAX) {
         TripArg ta;
         for (int i = 0; i < 3 * K; ++i) ta.t[i] = trip_host[i];
         score_kernel<true><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, nullptr, K,
                                                                thr_known ? nullptr : d_thr + 1, thr_val, d_part, ta,
-                                                               h_models);
+                                                               h_models, modest_tickets(zw), h_outp, thr_src, thr_dst);
     } else {
         fit_kernel<<<(K + 63) / 64, 64, 0, stream>>>(cand, n_cand, h_tripp, K, d_models, h_models);
         score_kernel<false><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, d_models, K,
                                                                 thr_known ? nullptr : d_thr + 1, thr_val, d_part,
-                                                                TripArg{}, nullptr);
+                                                                TripArg{}, nullptr, modest_tickets(zw), h_outp, thr_src,
+                                                                thr_dst);
     }
-    score_reduce_kernel<<<K * 4, 64, 0, stream>>>(d_part, nrows, K, h_outp, thr_known ? nullptr : d_thr,
-                                                  thr_known ? nullptr : h_thr);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     *thr_inout = thr_known ? thr_val : h_thr[1];
@@ -717,26 +796,28 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
-    const size_t b_part = arena_sz((size_t)nb * 80), b_acc = arena_sz(16 * 8);
-    int rc = modest_ctx_reserve(ctx, b_part + b_acc);
+    int rc = modest_ctx_reserve(ctx, arena_sz((size_t)nb * REFIT_NV * 8));
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 16 * 8);
     if (rc) return rc;
+    unsigned *zw = nullptr;
+    rc = modest_ctx_zero_words(ctx, stream, &zw);
+    if (rc) return rc;
     double *dp = reinterpret_cast<double *>(ctx->scratch);
-    double *acc = reinterpret_cast<double *>(ctx->scratch + b_part);
     const float c0 = model_host[0], c1 = model_host[1], b = model_host[2];
-    double *dp1 = dp + (size_t)nb * 5;   // pass 1 reads pass 0's partials while it writes its own
-    refit_kernel<0><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, nullptr, 0, nullptr, dp);
-    refit_kernel<1><<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, nb, acc, dp1);
     double *h = reinterpret_cast<double *>(ctx->pinned);
-    refit_reduce_kernel<<<1, 64, 0, stream>>>(dp1, nb, 1, acc, h);   // results straight into pinned host memory
+    refit_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, modest_tickets(zw), h);   // totals straight into pinned host memory
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-    const double cnt = h[0], mx = h[4], my = h[5], mz = h[6];
-    const double sxx = h[8], sxy = h[9], syy = h[10], sxz = h[11], syz = h[12];
+    const double cnt = h[0];
+    const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
+    const double mx = h[1] * inv, my = h[2] * inv, mzs = h[3] * inv;   // mzs: mean of z - b
+    const double sxx = h[4] - h[1] * mx, sxy = h[5] - h[1] * my, syy = h[6] - h[2] * my;
+    const double sxz = h[7] - h[1] * mzs, syz = h[8] - h[2] * mzs;
+    const double mz = mzs + (double)b;
     if (n_inliers) *n_inliers = (int32_t)cnt;
     const double det = sxx * syy - sxy * sxy;
-    if (!(cnt >= 3.0) || !(fabs(det) > 0.0)) {
+    if (!(cnt >= 3.0) || !(fabs(det) > 1e-12 * fmax(sxx * syy, 1e-300))) {
         modest_set_error("modest_ransac_refit: degenerate inlier set (n=%d)", (int)cnt);
         return MODEST_ERR_ARG;
     }

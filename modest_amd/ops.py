@@ -135,6 +135,25 @@ def plane_candidates(pts: torch.Tensor, max_hs: float, ptc_range, ctx: Optional[
     return cand[:m], idx[:m]
 
 
+def plane_prepare(pts: torch.Tensor, specs, ctx: Optional[Context] = None):
+    """Candidates and MAD thresholds of two estimate_plane calls on one scan ((max_hs, ptc_range) each):
+    one pass over the rows, one stream sync.  Returns [(cand (m,3) f32 device, thr np.float32 | None)] x 2."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    assert len(specs) == 2
+    n = pts.shape[0]
+    flat = []
+    for max_hs, ((xlo, xhi), (ylo, yhi)) in specs:
+        flat += [max_hs, xlo, xhi, ylo, yhi]
+    spec = np.ascontiguousarray(flat, dtype=np.float32)
+    cands = [torch.empty((n, 3), dtype=torch.float32, device=pts.device) for _ in range(2)]
+    cnt, mad = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.float32)
+    c = _ctx(ctx, pts)
+    check(lib.modest_plane_prepare(c.handle, pts.data_ptr(), n, pts.shape[1], _np_ptr(spec), cands[0].data_ptr(),
+                                   cands[1].data_ptr(), _np_ptr(cnt), _np_ptr(mad), _stream()), "modest_plane_prepare")
+    return [(cands[k][: int(cnt[k])], np.float32(mad[k]) if cnt[k] >= 1 else None) for k in range(2)]
+
+
 def mad_threshold(cand: torch.Tensor, ctx: Optional[Context] = None) -> np.float32:
     lib = load()
     _dev(cand, torch.float32, "cand")
@@ -355,6 +374,23 @@ def fit_boxes_closeness(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np
                                          float(d0), _np_ptr(best), _np_ptr(beta) if return_beta else None,
                                          _stream()), "modest_fit_boxes_closeness")
     return (best, beta) if return_beta else best
+
+
+def fit_boxes_closeness_host(pts_xz: np.ndarray, offsets: Sequence[int], cossin: np.ndarray, d0: float = 1e-2,
+                             ctx: Optional[Context] = None) -> np.ndarray:
+    """fit_boxes_closeness for cluster points in host memory ((m,2) float64): points and tables go to
+    the device in one staged copy."""
+    lib = load()
+    pts = np.ascontiguousarray(pts_xz, dtype=np.float64).reshape(-1, 2)
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+    assert off[-1] == pts.shape[0]
+    cs = np.ascontiguousarray(cossin, dtype=np.float64).reshape(-1, 2)
+    ncl, na = off.shape[0] - 1, cs.shape[0]
+    best = np.full(ncl, -1, dtype=np.int32)
+    c = ctx if ctx is not None else default_context(torch.cuda.current_device())
+    check(lib.modest_fit_boxes_closeness_host(c.handle, _np_ptr(pts), _np_ptr(off), ncl, _np_ptr(cs), na, float(d0),
+                                              _np_ptr(best), _stream()), "modest_fit_boxes_closeness_host")
+    return best
 
 
 def fit_boxes_variance(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np.ndarray, return_crit: bool = False,

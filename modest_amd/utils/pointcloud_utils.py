@@ -92,6 +92,8 @@ def prepare_planes(pts_dev, specs):
     selection per (max_hs, ptc_range) and all MAD thresholds from ONE launch (a workgroup each).
     Returns a list of (candidates, threshold) for ``estimate_plane(..., prepared=...)``; a set with
     fewer than one candidate gets threshold None (the fit itself then raises, where the reference does)."""
+    if len(specs) == 2:   # a scan's two fits: one pass over the rows, one round trip
+        return ops.plane_prepare(pts_dev, specs)
     cands = [ops.plane_candidates(pts_dev, max_hs, rng)[0] for max_hs, rng in specs]
     live = [c for c in cands if c.shape[0] >= 1]
     thr = iter(ops.mad_threshold_batch(live)) if live else iter(())
@@ -157,8 +159,7 @@ def closeness_rectangles(clusters_xz: Sequence[np.ndarray], delta=0.1, d0=1e-2):
         return []
     ang, cs = _angles(delta)
     off = np.cumsum([0] + [len(c) for c in clusters_xz]).astype(np.int32)
-    pts = to_device(np.concatenate(clusters_xz).astype(np.float64), dtype=torch.float64)
-    best = ops.fit_boxes_closeness(pts, off, cs, d0)
+    best = ops.fit_boxes_closeness_host(np.concatenate(clusters_xz).astype(np.float64), off, cs, d0)
     return [rectangle_at_angle(c, ang[b]) for c, b in zip(clusters_xz, best)]
 
 

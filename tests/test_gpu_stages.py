@@ -73,6 +73,27 @@ def test_plane_candidates_mad_and_scoring(gpu, ms):
         assert abs(sy[k] - z[inl].astype(np.float64).sum()) <= 1e-9 * max(1.0, abs(sy[k]))
 
 
+def test_plane_prepare_equals_separate_calls(gpu, ms):
+    """modest_plane_prepare (both candidate sets from one pass + both MADs, one sync) against
+    plane_candidates x 2 + mad_threshold, incl. an empty set and repeated calls."""
+    import torch
+    from modest_amd import ops
+    from modest_amd.utils.clustering_utils import FILTER_PLANE_SPEC
+    dev = torch.from_numpy(ms["ptc"]).to(gpu)
+    for specs in ([(-1.5, [[-70, 70], [-20, 20]]), FILTER_PLANE_SPEC], [(-1.3, [[0, 70], [-40, 40]]), (-100.0, [[-1, 1], [-1, 1]])],
+                  [(-1.5, [[-70, 70], [-20, 20]]), FILTER_PLANE_SPEC]):
+        got = ops.plane_prepare(dev, specs)
+        for (cand, thr), (max_hs, rng_) in zip(got, specs):
+            ref, _ = ops.plane_candidates(dev, max_hs, rng_)
+            assert torch.equal(cand, ref)
+            if ref.shape[0]:
+                assert thr == ops.mad_threshold(ref)
+            else:
+                assert thr is None
+    e = ops.plane_prepare(dev[:0], [(-1.5, [[-70, 70], [-20, 20]]), FILTER_PLANE_SPEC])
+    assert e[0][0].shape[0] == 0 and e[0][1] is None and e[1][1] is None
+
+
 def test_ransac_trials_batch_paths_agree(gpu, ms):
     """One round trip per batch of trials: batches of up to 64 triplets travel as a kernel argument and
     are fitted inside the scoring kernel, larger ones through the separate fit kernel; both must give
@@ -172,7 +193,11 @@ def test_mad_threshold_exact(gpu):
     rng = np.random.RandomState(11)
     cases = [rng.normal(-1.7, 0.05, 14935), rng.normal(-1.7, 0.05, 14936), np.full(5000, -1.625),
              np.round(rng.normal(-1.7, 0.05, 20001), 2), rng.uniform(-3, 3, 3), rng.normal(0, 1, 40_001),
-             rng.normal(0, 1e-3, 32_768), np.array([0.5])]
+             rng.normal(0, 1e-3, 32_768), np.array([0.5]),
+             # the key range drives the bins: both signs, huge spread, denormals, two distinct values
+             np.concatenate([rng.normal(0, 1, 9000), [1e30, -1e30, 1e-40, -1e-40, 0.0, -0.0]]),
+             np.concatenate([np.full(3000, 2.0), np.full(3001, 2.0000002)]), rng.normal(0, 1, 2) * 1e-38,
+             np.concatenate([np.full(700, -1.5), rng.normal(-1.6, 0.3, 23_000)])]
     for z in cases:
         z = z.astype(np.float32)
         cand = np.zeros((z.size, 3), dtype=np.float32)

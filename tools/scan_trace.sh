@@ -15,7 +15,7 @@ for f in glob.glob('gpurun_out/trace1/**/*memory_copy_trace.csv', recursive=True
 rows.sort()
 # last full scan: between the last two pp3_join launches
 j = [i for i, r in enumerate(rows) if 'pp3_join' in r[2]]
-lo, hi = j[-2], j[-1]
+lo, hi = j[3], j[4]   # a scan of the timed full-pipeline section (the last launches are the isolated PP runs)
 # start the listing at the first launch after the previous scan's last kernel
 t0 = rows[lo][0]
 out = open('gpurun_out/scan_trace.txt', 'w')
@@ -25,5 +25,5 @@ for r in rows[lo:hi]:
     out.write("%9.1f us  +%7.1f gap  %7.1f us  %s\n" % ((r[0] - t0) / 1e3, gap, (r[1] - r[0]) / 1e3, r[2]))
     prev = r[1]
 out.close()
-print(open('gpurun_out/scan_trace.txt').read())
+
 PY
