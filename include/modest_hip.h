@@ -52,6 +52,15 @@ int modest_ctx_profile_begin(modest_ctx *ctx, int capacity);
 int modest_ctx_profile_collect(modest_ctx *ctx, float *ms_out_host, int cap,
                                int *n_out_host);
 
+/* Calibration.project_velo_to_rect (utils/kitti_util.py:327-329) of the scan rows, float64:
+ * out[i] = R0 @ (V2C @ [x y z 1]) with the rounding of numpy's two dgemm calls (one fma chain per
+ * output element).  The rect-frame copy of the scan that get_obj's lowest-point search reads
+ * (pointcloud_utils.py:278-290) is produced where it is consumed instead of being uploaded.
+ * pts [dev] (n,stride) f32; V2C12 / R09 [host] row-major 3x4 / 3x3 f64; out [dev] (n,3) f64. */
+int modest_project_velo_to_rect(modest_ctx *ctx, const float *pts_dev, int n, int stride,
+                                const double *V2C12, const double *R09, double *out_dev,
+                                void *stream);
+
 /* ---- a4  transform_points  (utils/pointcloud_utils.py:11-19) ----------
  * out[i] = (x*T[r][0] (+fma) y*T[r][1] (+fma) z*T[r][2]) + T[r][3], float32,
  * i.e. [p,1] @ T^T, rows 0..2.  `in_stride` is 3 or 4 floats per point

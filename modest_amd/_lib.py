@@ -49,6 +49,7 @@ SIGNATURES = {
                                         VP, VP, VP, VP]),
     "modest_cluster_dbscan_ex": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.c_int, VP, VP, VP, VP]),
+    "modest_project_velo_to_rect": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP]),
     "modest_plane_prepare": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP]),
     "modest_mask_cluster": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_double, VP, VP, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, VP, VP, VP, VP]),

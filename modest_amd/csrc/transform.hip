@@ -101,6 +101,36 @@ __global__ __launch_bounds__(1024) void transform_filter_kernel(const float *__r
     }
 }
 
+// project_velo_to_rect (utils/kitti_util.py:327-329): rect = (R0 @ ([p,1] @ V2C^T)^T)^T in float64.
+// numpy hands both products to dgemm, whose k loop is one fused multiply-add chain per output
+// element (first product rounded, then fma per further term; the appended 1 makes the last term
+// of the first product an exact addend).
+struct RectMats {
+    double v[12];   // V2C, row major 3x4
+    double r[9];    // R0, row major 3x3
+};
+__global__ __launch_bounds__(256) void velo_to_rect_kernel(const float *__restrict__ in, int n, int stride, RectMats M,
+                                                           double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = in + (size_t)i * stride;
+    const double x = p[0], y = p[1], z = p[2];
+    double ref[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double acc = __dmul_rn(x, M.v[4 * j]);
+        acc = fma(y, M.v[4 * j + 1], acc);
+        acc = fma(z, M.v[4 * j + 2], acc);
+        ref[j] = fma(1.0, M.v[4 * j + 3], acc);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double acc = __dmul_rn(M.r[3 * j], ref[0]);
+        acc = fma(M.r[3 * j + 1], ref[1], acc);
+        out[3 * (size_t)i + j] = fma(M.r[3 * j + 2], ref[2], acc);
+    }
+}
+
 }  // namespace
 
 extern "C" int modest_transform_points(modest_ctx *ctx, const float *in, int64_t n, int in_stride,
@@ -133,6 +163,22 @@ extern "C" int modest_transform_points(modest_ctx *ctx, const float *in, int64_t
         transform_filter_kernel<<<(int)blocks, 1024, 0, stream>>>(in, n, in_stride, T, out, state,
                                                                   reinterpret_cast<long long *>(n_out));
     }
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
+
+extern "C" int modest_project_velo_to_rect(modest_ctx *ctx, const float *pts, int n, int stride, const double *V2C12,
+                                           const double *R09, double *out, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && V2C12 && R09, "NULL argument");
+    MODEST_REQUIRE(n >= 0 && (stride == 3 || stride == 4), "bad n/stride");
+    if (n == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts && out, "NULL buffer");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    RectMats M;
+    for (int q = 0; q < 12; ++q) M.v[q] = V2C12[q];
+    for (int q = 0; q < 9; ++q) M.r[q] = R09[q];
+    velo_to_rect_kernel<<<(n + 255) / 256, 256, 0, stream>>>(pts, n, stride, M, out);
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }

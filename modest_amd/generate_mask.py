@@ -66,10 +66,19 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
                                     plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
                                     pp_dev=pp_dev, labels_dev=labels_dev, plane_prepared=prep[1], **args.filtering)
-    ptc_in_rect = calib.project_velo_to_rect(ptc[:, :3])
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
     members = members_by_label(labels_filtered, n_lab)
-    cand = get_objs([ptc_in_rect[m] for m in members], ptc_in_rect, fit_method=args.bbox_gen.fit_method)
+    # rect-frame points: the clusters' rows on the host (per-cluster numpy arithmetic of get_obj), the whole
+    # scan on the device, where the lowest-point search reads it (same rounding: one fma chain per element)
+    if members:
+        rect_m = calib.project_velo_to_rect(ptc[np.concatenate(members), :3])
+        cuts = np.cumsum([0] + [len(m) for m in members])
+        rect_m = np.ascontiguousarray(rect_m)
+        clusters = [rect_m[cuts[k]:cuts[k + 1]] for k in range(len(members))]
+        rect_dev = ops.project_velo_to_rect(ptc_dev, calib.V2C, calib.R0)
+    else:
+        clusters, rect_dev = [], None
+    cand = get_objs(clusters, rect_dev, fit_method=args.bbox_gen.fit_method)
     objs = []
     for m, obj in zip(members, cand):
         if obj.volume > args.filtering.min_volume and obj.volume < args.filtering.max_volume:

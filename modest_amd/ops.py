@@ -115,6 +115,20 @@ def transform_points(pts: torch.Tensor, T: np.ndarray, remove_center: bool = Fal
     return out[: int(n_out.item())]
 
 
+def project_velo_to_rect(pts: torch.Tensor, V2C: np.ndarray, R0: np.ndarray, ctx: Optional[Context] = None) -> torch.Tensor:
+    """Calibration.project_velo_to_rect (kitti_util.py:327-329) of the scan rows: (n,3) float64 on the
+    device, bit-identical to numpy's two dgemm products."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    v = np.ascontiguousarray(V2C, dtype=np.float64).reshape(12)
+    r = np.ascontiguousarray(R0, dtype=np.float64).reshape(9)
+    out = torch.empty((pts.shape[0], 3), dtype=torch.float64, device=pts.device)
+    c = _ctx(ctx, pts)
+    check(lib.modest_project_velo_to_rect(c.handle, pts.data_ptr(), pts.shape[0], pts.shape[1], _np_ptr(v), _np_ptr(r),
+                                          out.data_ptr(), _stream()), "modest_project_velo_to_rect")
+    return out
+
+
 # --------------------------------------------------------------------------- plane / RANSAC
 def plane_candidates(pts: torch.Tensor, max_hs: float, ptc_range, ctx: Optional[Context] = None):
     """Candidate mask of estimate_plane (pointcloud_utils.py:45-49), compacted in input order.

@@ -294,6 +294,30 @@ def test_mask_cluster_fused_equals_separate_calls(gpu):
     assert torch.equal(got2[idx.long()], lab2)
 
 
+def test_project_velo_to_rect_bit_exact(gpu, ms, golden_dir):
+    """The device copy of the rect-frame scan equals Calibration.project_velo_to_rect (numpy: two dgemm
+    calls) bit for bit -- on THIS host's BLAS, which is the one the host half of get_obj uses."""
+    import tempfile
+    import torch
+    from modest_amd import ops, synth
+    from modest_amd.utils import kitti_util
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+    rng = np.random.default_rng(4)
+    for ptc in (ms["ptc"], (rng.normal(0, 40, (50_001, 4))).astype(np.float32), ms["ptc"][:1], ms["ptc"][:0]):
+        got = ops.project_velo_to_rect(torch.from_numpy(np.ascontiguousarray(ptc)).to(gpu), calib.V2C, calib.R0)
+        ref = calib.project_velo_to_rect(ptc[:, :3])
+        assert np.array_equal(got.cpu().numpy(), ref)
+    # a calibration with a full rotation in both matrices
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    calib.V2C = np.hstack([q, rng.normal(0, 1, (3, 1))])
+    calib.R0 = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    ptc = (rng.normal(0, 40, (20_000, 4))).astype(np.float32)
+    got = ops.project_velo_to_rect(torch.from_numpy(ptc).to(gpu), calib.V2C, calib.R0)
+    assert np.array_equal(got.cpu().numpy(), calib.project_velo_to_rect(ptc[:, :3]))
+
+
 def test_filter_and_boxes(gpu, ms):
     from modest_amd.utils import clustering_utils as cu
     from modest_amd.utils import pointcloud_utils as pcu
