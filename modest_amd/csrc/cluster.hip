@@ -569,6 +569,11 @@ __global__ __launch_bounds__(64 * WPB) void label_kernel(const float4 *__restric
 constexpr int ADJ = 128;
 constexpr int AG = 16;    // lanes that share one adjacency row in the passes below
 
+// ORIG (the radius graphs): the rows hold ORIGINAL point numbers (sidx[j]) and a non-core point gets
+// the parent UF_NONE, so that the hooking / union / label passes below need one dependent load per
+// edge (parent or root of the neighbour) instead of three (core flag, point number, parent).
+constexpr int UF_NONE = 0x7fffffff;
+template <bool ORIG>
 __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__restrict__ sorted, int n,
                                                               const CGrid *g,
                                                               const unsigned *__restrict__ start,
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;
-    if (lane == 0) parent[sidx[s]] = sidx[s];   // uf_init, one launch less (sidx is a permutation)
+    if (!ORIG && lane == 0) parent[sidx[s]] = sidx[s];   // uf_init, one launch less (sidx is a permutation)
     const float4 q = sorted[s];
     const double kq = kthS[s];
     const Rows R = rows_of(q, g, start);
@@ -592,12 +597,13 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
             const bool e = j < R.e[r] && (int)j != s && edge_ok(q, kq, sorted[j], kthS[j], ep, s, j);
             const unsigned long long bal = __ballot(e);
             const unsigned pos = total + __popcll(bal & ((1ULL << lane) - 1ULL));
-            if (e && pos < (unsigned)ADJ) adj[(size_t)s * ADJ + pos] = (int)j;
+            if (e && pos < (unsigned)ADJ) adj[(size_t)s * ADJ + pos] = ORIG ? sidx[j] : (int)j;
             total += __popcll(bal);
         }
     if (lane == 0) {
         deg[s] = (int)min(total, (unsigned)ADJ);
         coreS[s] = ((int)total + 1 >= min_samples) ? 1 : 0;
+        if (ORIG) parent[sidx[s]] = ((int)total + 1 >= min_samples) ? sidx[s] : UF_NONE;
         if (total > (unsigned)ADJ) atomicOr(overflow, 1);
     }
 }
@@ -678,6 +684,84 @@ __global__ void label_adj_kernel(int n, int stride, const unsigned char *__restr
     if (!on || sub) return;
     const int me = sidx[s];
     labels[oidx ? oidx[me] : me] = core ? (int)rank[root[me]] : (best == 0x7fffffff) ? -1 : (int)rank[best];
+}
+
+// ---- the same passes over rows of original point numbers (degree_adj_kernel<true>) ----------
+__global__ void hook_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+                                 const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
+    const bool on = s < n && coreS[s];
+    int rme = 0, m = UF_NONE;
+    if (on) {
+        rme = parent[sidx[s]];
+        m = rme;
+        const int *row = adj + (size_t)s * ADJ;
+        const int d = deg[s];
+        for (int e = sub; e < d; e += AG) m = min(m, parent[row[e]]);   // UF_NONE for a non-core neighbour
+    }
+    for (int o = AG / 2; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+    if (on && sub == 0 && m < rme) atomicMin(parent + rme, m);
+}
+
+__global__ void flatten_orig_kernel(int *parent, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = uf_load(parent, i);
+    if (r == UF_NONE) return;
+    for (;;) {
+        const int p = uf_load(parent, r);
+        if (p == r) break;
+        r = p;
+    }
+    __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void union_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+                                  const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
+    if (s >= n || !coreS[s]) return;
+    const int me = sidx[s];
+    const int *row = adj + (size_t)s * ADJ;
+    const int d = deg[s];
+    for (int e = sub; e < d; e += AG) {
+        const int other = row[e];
+        if (other <= me) continue;   // every core-core edge is in both rows
+        const int po = uf_load(parent, other);
+        if (po == UF_NONE) continue;
+        if (uf_load(parent, me) != po) uf_unite(parent, me, other);
+    }
+}
+
+__global__ void compress_orig_kernel(int *parent, const unsigned char *__restrict__ coreS, const int *__restrict__ sidx,
+                                     int n, int *__restrict__ root, unsigned *__restrict__ isroot) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int i = sidx[s];
+    const int r = coreS[s] ? uf_find(parent, i) : UF_NONE;
+    root[i] = r;
+    isroot[i] = r == i ? 1u : 0u;
+}
+
+__global__ void label_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
+                                  const int *__restrict__ adj, const int *__restrict__ sidx, const int *__restrict__ root,
+                                  const unsigned *__restrict__ rank, int *__restrict__ labels,
+                                  const int *__restrict__ oidx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / AG, sub = t % AG;
+    const bool on = s < n;
+    const bool core = on && coreS[s];
+    int best = UF_NONE;
+    if (on && !core) {
+        const int *row = adj + (size_t)s * ADJ;
+        const int d = deg[s];
+        for (int e = sub; e < d; e += AG) best = min(best, root[row[e]]);   // UF_NONE for a non-core neighbour
+    }
+    for (int o = AG / 2; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if (!on || sub) return;
+    const int me = sidx[s];
+    labels[oidx ? oidx[me] : me] = core ? (int)rank[root[me]] : (best == UF_NONE) ? -1 : (int)rank[best];
 }
 
 // ---- k-NN graphs without a radius bound (neighbor_type knn / sym_knn / mutual_knn) ------------
@@ -1006,16 +1090,16 @@ int cluster_impl(modest_ctx *ctx, size_t arena_off, const float *xyz, const floa
     }
     if (ep.use_knn || kth_d2)
         knn_kth_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, k_neighbors, r2, kthS);
-    degree_adj_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
-                                                  overflow, sidx, parent);
-    for (int round = 0; round < HOOK_ROUNDS; ++round) {   // accelerators only: union_adj_kernel makes the result exact
-        hook_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
-        flatten_kernel<<<nb, 256, 0, stream>>>(parent, n);
+    degree_adj_kernel<true><<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj,
+                                                        overflow, sidx, parent);
+    for (int round = 0; round < HOOK_ROUNDS; ++round) {   // accelerators only: union_orig_kernel makes the result exact
+        hook_orig_kernel<<<nbA, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
+        flatten_orig_kernel<<<nb, 256, 0, stream>>>(parent, n);
     }
-    union_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, parent);
-    compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
+    union_orig_kernel<<<nbA, 256, 0, stream>>>(n, coreS, deg, adj, sidx, parent);
+    compress_orig_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
     scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
-    label_adj_kernel<<<nbA, 256, 0, stream>>>(n, ADJ, coreS, deg, adj, sidx, root, rank, labels, oidx);
+    label_orig_kernel<<<nbA, 256, 0, stream>>>(n, coreS, deg, adj, sidx, root, rank, labels, oidx);
     MODEST_HIP_CHECK(hipGetLastError());
     {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));

@@ -97,11 +97,22 @@ __global__ __launch_bounds__(256) void pp_live_bbox(const float *__restrict__ li
     }
 }
 
-__global__ void pp_live_count(const float *__restrict__ live, int n, const unsigned *bb, double c,
-                              unsigned *cellCount) {
+// bbPart != NULL (frame path): the bounding box arrives as per-block partial maxima of the key words
+// (pp3_live_prep); every block combines them, block 0 publishes bb[] for the kernels that follow.
+__global__ __launch_bounds__(256) void pp_live_count(const float *__restrict__ live, int n, unsigned *bb, double c,
+                                                     unsigned *cellCount, const unsigned *__restrict__ bbPart,
+                                                     int nPart) {
+    __shared__ unsigned sbb[4];
+    if (bbPart) {
+        if (threadIdx.x < 4) sbb[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int k = threadIdx.x; k < 4 * nPart; k += blockDim.x) atomicMax(&sbb[k & 3], bbPart[k]);
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < 4) bb[threadIdx.x] = sbb[threadIdx.x];
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PPGrid g = pp_grid(bb, c);
+    const PPGrid g = pp_grid(bbPart ? sbb : bb, c);
     const int cx = pp_cell_coord(live[3 * (size_t)i], g.ox, g.inv_c, PP_NX);
     const int cy = pp_cell_coord(live[3 * (size_t)i + 1], g.oy, g.inv_c, PP_NY);
     atomicAdd(&cellCount[cy * PP_NX + cx], 1u);
@@ -289,6 +300,77 @@ int check_offsets(const int64_t *off, int n_trav, TravOffsets &tr) {
 
 }  // namespace
 
+namespace {
+// live scan of the frame store (tile-sorted + perm) -> common frame, ORIGINAL point order
+__global__ void pp3_live_transform(const float *__restrict__ xyz, const unsigned *__restrict__ perm, int n,
+                                   FrameDev d, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[3];
+    rel_apply(d.rel, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], o);
+    const size_t j = perm[i];
+    out[3 * j] = o[0];
+    out[3 * j + 1] = o[1];
+    out[3 * j + 2] = o[2];
+}
+}  // namespace
+
+namespace {
+// First kernel of the frame path, one launch for what used to be two memsets and two kernels:
+// the live scan of the frame store (tile-sorted + perm) goes to the common frame in ORIGINAL point
+// order, every block that holds points leaves its bounding-box partial (pp_live_count combines
+// them: no atomics, nothing to pre-zero), and all blocks clear the zero-initialised control block
+// and the count matrix.
+struct RelM {
+    float m[12];
+};
+constexpr int PREP_BLOCKS = 512;
+__global__ __launch_bounds__(256) void pp3_live_prep(const float *__restrict__ xyz, const unsigned *__restrict__ perm,
+                                                     int n, RelM rel, float *__restrict__ out,
+                                                     unsigned *__restrict__ bbPart, uint4 *__restrict__ zero16,
+                                                     size_t nZero16, int *__restrict__ counts, size_t nCounts) {
+    const size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x, gs = (size_t)gridDim.x * 256;
+    for (size_t i = gt; i < nZero16; i += gs) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = gt; i < nCounts; i += gs) counts[i] = 0;
+    if ((long long)blockIdx.x * 1024 >= n) return;
+    unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    for (int r = 0; r < 4; ++r) {   // 1024 points per block
+        const int i = blockIdx.x * 1024 + r * 256 + threadIdx.x;
+        if (i < n) {
+            float o[3];
+            rel_apply(rel.m, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], o);
+            const size_t j = perm[i];
+            out[3 * j] = o[0];
+            out[3 * j + 1] = o[1];
+            out[3 * j + 2] = o[2];
+            const unsigned kx = pp_fkey(o[0]), ky = pp_fkey(o[1]);
+            k0 = max(k0, kx);
+            k1 = max(k1, ~kx);
+            k2 = max(k2, ky);
+            k3 = max(k3, ~ky);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        k0 = max(k0, (unsigned)__shfl_xor((int)k0, o));
+        k1 = max(k1, (unsigned)__shfl_xor((int)k1, o));
+        k2 = max(k2, (unsigned)__shfl_xor((int)k2, o));
+        k3 = max(k3, (unsigned)__shfl_xor((int)k3, o));
+    }
+    __shared__ unsigned red[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w] = k0;
+        red[1][w] = k1;
+        red[2][w] = k2;
+        red[3][w] = k3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        bbPart[4 * blockIdx.x + threadIdx.x] = max(max(red[threadIdx.x][0], red[threadIdx.x][1]),
+                                                   max(red[threadIdx.x][2], red[threadIdx.x][3]));
+}
+}  // namespace
+
 // Where the history comes from: a stacked (M,3) array with traversal offsets, or the frames of the
 // frame store through a descriptor table (chunkTab: one entry per 4096-point chunk of a frame).
 struct HistSrc {
@@ -300,6 +382,12 @@ struct HistSrc {
     int nchunks = 0;
     bool useFrames = false;
     long long totalPts = 0;
+    // frame path: the live scan as the frame store holds it (tile-sorted + perm); pp_count_run's first
+    // kernel transforms it into `liveOut` (original point order), in place of a separate launch
+    const float *liveXyz = nullptr;
+    const unsigned *livePerm = nullptr;
+    float liveRel[12] = {0};
+    float *liveOut = nullptr;
 };
 
 // `extra_bytes` of arena are reserved behind this call's own carve; `prepare` is called with that
@@ -331,7 +419,7 @@ static int pp_count_run(modest_ctx *ctx, const float *live, int n_live, HistSrc 
     size_t need = arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
                   arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)n_live * 16) +
                   arena_sz((size_t)nchunks * V3_CH * 16) + 2 * arena_sz((size_t)nwg3 * V3_NL * 4) +
-                  arena_sz(maxSlices * 16);
+                  arena_sz(maxSlices * 16) + arena_sz((size_t)PREP_BLOCKS * 16);
     int rc = modest_ctx_reserve(ctx, need + arena_sz(extra_bytes));
     if (rc) return rc;
     if (prepare) {
@@ -366,14 +454,31 @@ static int pp_count_run(modest_ctx *ctx, const float *live, int n_live, HistSrc 
     unsigned *wgTile = A.take<unsigned>((size_t)nwg3 * V3_NL);
     unsigned *wgOff = A.take<unsigned>((size_t)nwg3 * V3_NL);
     uint4 *slices = A.take<uint4>(maxSlices);
+    unsigned *bbPart = A.take<unsigned>((size_t)PREP_BLOCKS * 4);
 
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of one scan
-    MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
     const double c = radius * (1.0 + 1.0 / 1024.0);
     const double r2 = radius * radius;
     const int nb = (n_live + 255) / 256;
-    pp_live_bbox<<<(n_live + 1023) / 1024, 256, 0, stream>>>(live, n_live, bb, counts, (size_t)n_live * n_trav);
-    pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellCount);
+    const int nPart = (n_live + 1023) / 1024;
+    if (src.liveXyz && nPart <= PREP_BLOCKS) {   // frame path: transform + bbox partials + clears in one launch
+        RelM rm;
+        for (int q = 0; q < 12; ++q) rm.m[q] = src.liveRel[q];
+        pp3_live_prep<<<PREP_BLOCKS, 256, 0, stream>>>(src.liveXyz, src.livePerm, n_live, rm, src.liveOut, bbPart,
+                                                       reinterpret_cast<uint4 *>(zeroed), arena_sz(zero_words * 4) / 16,
+                                                       counts, (size_t)n_live * n_trav);
+        pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellCount, bbPart, nPart);
+    } else {
+        if (src.liveXyz) {   // a live scan of more than 512 k points: separate transform
+            FrameDev ld;
+            memset(&ld, 0, sizeof(ld));
+            for (int q = 0; q < 12; ++q) ld.rel[q] = src.liveRel[q];
+            pp3_live_transform<<<nb, 256, 0, stream>>>(src.liveXyz, src.livePerm, n_live, ld, src.liveOut);
+        }
+        MODEST_HIP_CHECK(hipMemsetAsync(zeroed, 0, zero_words * 4, stream));
+        pp_live_bbox<<<nPart, 256, 0, stream>>>(live, n_live, bb, counts, (size_t)n_live * n_trav);
+        pp_live_count<<<nb, 256, 0, stream>>>(live, n_live, bb, c, cellCount, nullptr, 0);
+    }
     pp_scan_bitmap<<<SCAN_NBLK + PP_NY, SCAN_BLOCK, 0, stream>>>(cellCount, cellStart, blockSum, bitmap);
     pp_scan_finish<<<SCAN_NBLK, SCAN_BLOCK, 0, stream>>>(cellStart, blockSum);
     const char *var_env = getenv("MODEST_PP_VARIANT");
@@ -471,21 +576,6 @@ static int pp_count_impl(modest_ctx *ctx, const float *live, int n_live, const f
 }
 
 // ---- frame path of the V3 kernels ------------------------------------------------------------
-namespace {
-// live scan of the frame store (tile-sorted + perm) -> common frame, ORIGINAL point order
-__global__ void pp3_live_transform(const float *__restrict__ xyz, const unsigned *__restrict__ perm, int n,
-                                   FrameDev d, float *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float o[3];
-    rel_apply(d.rel, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], o);
-    const size_t j = perm[i];
-    out[3 * j] = o[0];
-    out[3 * j + 1] = o[1];
-    out[3 * j + 2] = o[2];
-}
-}  // namespace
-
 int modest_pp3_frames(modest_ctx *ctx, const modest_pp_frame *live, const uint32_t *live_perm_dev,
                       const modest_pp_frame *frames, int n_frames, int n_trav, double radius,
                       int32_t *counts_dev, float *H_dev, hipStream_t stream) {
@@ -536,10 +626,10 @@ int modest_pp3_frames(modest_ctx *ctx, const modest_pp_frame *live, const uint32
             MODEST_HIP_CHECK(hipMemcpyAsync(dframes, hslot, descB + tabB, hipMemcpyHostToDevice, stream));
             r = modest_ctx_stage_commit(ctx, stream);
             if (r) return r;
-            FrameDev ld;
-            memset(&ld, 0, sizeof(ld));
-            for (int q = 0; q < 12; ++q) ld.rel[q] = live->rel[q];
-            if (N > 0) pp3_live_transform<<<(N + 255) / 256, 256, 0, stream>>>(live->xyz_dev, live_perm_dev, N, ld, dlive);
+            src.liveXyz = live->xyz_dev;   // transformed into dlive by pp_count_run's first kernel
+            src.livePerm = live_perm_dev;
+            for (int q = 0; q < 12; ++q) src.liveRel[q] = live->rel[q];
+            src.liveOut = dlive;
             *livep = dlive;
             src.frames = dframes;
             src.chunkTab = dtab;

@@ -1,10 +1,15 @@
 #!/bin/bash
-# GPU box: PP parity tests, phase timers, and the PP-only numbers with one scan at a time
+# GPU box: PP parity tests, then the ordered launch list of one scan
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_pp.py -m gpu -q -x 2>&1 | tail -2
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-MODEST_PP_DBG=128 timeout 300 python tools/pp_microbench.py 2>&1 | grep "pp3" | tail -2 | cut -c1-400
-rm -rf gpurun_out/prof_pp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pp -o bench -- python bench.py --pp-only --cpu-scans 0 --procs 1 --streams 1 --steps 16 --warmup 2 > gpurun_out/prof_pp.log 2>&1
-grep '^{"metric"' gpurun_out/prof_pp.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('pp-only 1 stream: %.0f scans/s, stage %.3f ms, isolated %.3f ms (frac %.4f)' % (d['value'], r['kernel_ms'], r['isolated']['kernel_ms'], r['isolated']['frac']))"
-python tools/kstats.py gpurun_out/prof_pp/bench_kernel_stats.csv 6
+timeout 1200 python -m pytest tests/test_gpu_pp.py tests/test_gpu_frames.py -m gpu -x -q 2>&1 | grep -i "passed\|failed\|error" | tail -3
+bash tools/scan_trace.sh > /dev/null 2>&1
+python - <<'PY'
+rows = [l.rstrip('\n') for l in open('gpurun_out/scan_trace.txt')]
+tot = 0.0; n = 0; pp = 0.0; npp = 0
+for l in rows[1:]:
+    f = l.split()
+    d = float(f[5]); name = ' '.join(f[7:])
+    if 'pp' in name: pp += d; npp += 1; print(l)
+    else: tot += d; n += 1
+print("pp kernels: %.1f us in %d launches; everything else %.1f us in %d launches" % (pp, npp, tot, n))
+PY
