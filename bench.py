@@ -73,7 +73,13 @@ def parse(argv=None):
                          "not a BASELINE configuration")
     ap.add_argument("--stacked", action="store_true",
                     help="A/B: feed the PP stage a pre-stacked, pre-transformed history (round-1 bench input)")
-    ap.add_argument("--procs", type=int, default=7,
+    ap.add_argument("--pp-cus", type=int, default=128,
+                    help="with several host processes per GPU: the CU count every process sizes its persistent PP grids "
+                         "for (MODEST_NUM_CUS).  Kernels of different processes do run side by side; a PP launch that "
+                         "fills all 256 CUs keeps the other processes' small mask-stage kernels waiting (measured: "
+                         "1.91 k scans/s at 256, 2.1-2.2 k at 64..192).  0 = all CUs.  The isolated roofline "
+                         "measurement always uses a context sized for the whole GPU.")
+    ap.add_argument("--procs", type=int, default=8,
                     help="host processes per GPU (per rank).  The host side of a scan is Python + ~60 HIP calls; one "
                          "process saturates at ~350 scans/s on its interpreter lock and HIP runtime locks while the "
                          "GPU is half idle, so every rank feeds its GPU from several helper processes (what the "
@@ -169,7 +175,13 @@ class Runner:
             # forced-switch interval (5 ms) is longer than a whole step, 0.5 ms measured best (+20 %)
             sys.setswitchinterval(float(os.environ.get("MODEST_SWITCH_INTERVAL", "0.0005")))
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_threads)]
+        shared = a.procs > 1 and a.pp_cus > 0 and "MODEST_NUM_CUS" not in os.environ
+        if shared:
+            os.environ["MODEST_NUM_CUS"] = str(a.pp_cus)
         self.ctxs = [_lib.Context(local) for _ in range(self.n_threads)]
+        if shared:
+            del os.environ["MODEST_NUM_CUS"]
+        self._lib, self.local, self.iso_ctx = _lib, local, None
         with tempfile.TemporaryDirectory() as d:
             open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
             calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
@@ -248,12 +260,15 @@ class Runner:
         """The PP stage alone on the GPU, cycling through ALL resident scans (>= 3 x 130 MB of
         distinct history: the 256 MiB Infinity Cache cannot hold the working set)."""
         reps = max(4 * len(self.scans), 12)
-        self.ctxs[0].profile_begin(reps + 4)
+        if self.iso_ctx is None:   # alone on the GPU: grids sized for all CUs
+            self.iso_ctx = self._lib.Context(self.local)
+        ctx = self.iso_ctx
+        ctx.profile_begin(reps + 4)
         with torch.cuda.stream(self.streams[0]):
             for i in range(reps):
-                self.pp(self.scans[i % len(self.scans)], self.ctxs[0])
+                self.pp(self.scans[i % len(self.scans)], ctx)
             self.streams[0].synchronize()
-        iso = self.ctxs[0].profile_collect(reps + 4)
+        iso = ctx.profile_collect(reps + 4)
         return float(np.mean(iso[len(self.scans):])) if len(iso) > len(self.scans) else None
 
 
@@ -511,7 +526,7 @@ def main():
                 traffic, traffic_src = tj["hbm_bytes_per_scan"], f"profiles/{tname} (" + tj["source"] + ")"
                 break
     roofline = {"bound": "hbm",
-                "kernel": "PP neighbour count of one scan = zero-fill + live transform + live index build (6 launches) + "
+                "kernel": "PP neighbour count of one scan = live prep (transform + bounding box + clears, 1 launch) + live index build (5 launches) + "
                           "pp3_stream<count> + pp3_scan + pp3_plan + pp3_stream<scatter> + pp3_join: ALL launches of the "
                           "stage, HIP events on the launch stream; the history is read from the frame store through the "
                           "descriptor table (pose fused), not from a stacked copy",
@@ -601,6 +616,7 @@ def main():
                                         "frame store + descriptor table (no stacked history)",
                        "host_processes_per_gpu": n_procs, "threads_per_process": n_threads,
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
+                       "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
                        "rccl_world_size": rccl_ws,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli, "steady_state": steady,

@@ -82,6 +82,9 @@ def run_workers(module: str, cfg, rank: int, ws: int, local: int) -> Optional[Di
         _config.save(c2, cpath, resolve=False)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         env.update(MODEST_PARENT_RANK=str(rank), MODEST_PARENT_WS=str(ws))
+        # processes that share a GPU size their persistent PP grids for half of it: a launch that fills all
+        # CUs keeps the other workers' small kernels waiting (bench.py --pp-cus has the measurements)
+        env.setdefault("MODEST_NUM_CUS", "128")
         procs = []
         for w in range(n):
             e = dict(env, MODEST_WORKER=f"{w}/{n}", MODEST_WORKER_RESULT=os.path.join(d, f"w{w}.json"))

@@ -1,6 +1,13 @@
 #!/bin/bash
-# throughput and in-region PP stage time vs host processes x threads per GPU
-for cfg in "1 4" "2 2" "4 1" "6 1" "7 1" "8 1" "9 1"; do
-  set -- $cfg
-  python bench.py --procs $1 --streams $2 --steps 240 --cpu-scans 0 2>/dev/null | grep '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('procs $1 threads $2: %.0f scans/s, PP stage in region %.3f ms (frac %.3f), isolated %.3f ms' % (d['value'], r['kernel_ms'], r['frac'], r['isolated']['kernel_ms']))"
+cd $GRAFT_REPO_ROOT
+python bench.py --cpu-scans 0 --cli-scans 0 > /dev/null 2>&1
+run() { python bench.py --cpu-scans 0 --cli-scans 0 --steps 600 "$@" 2>/dev/null | grep '^{"metric"' | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('cus=$MODEST_NUM_CUS $*', round(d['value'],1), 'scans/s')"; }
+for c in 128 96 64 48 32; do
+  export MODEST_NUM_CUS=$c
+  run --procs 8; run --procs 8
 done
+export MODEST_NUM_CUS=96
+run --procs 8 --pp-only
+export MODEST_NUM_CUS=256
+run --procs 8 --pp-only
