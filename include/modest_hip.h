@@ -179,6 +179,26 @@ int modest_mad_threshold(modest_ctx *ctx, const float *cand_xyz_dev,
 int modest_mad_threshold_batch(modest_ctx *ctx, const float *const *cand_xyz_dev,
                                const int32_t *n_cand, int count, float *mad_host,
                                void *stream);
+/* sklearn.linear_model.RANSACRegressor().fit as estimate_plane calls it (pointcloud_utils.py:52-53:
+ * LinearRegression, min_samples 3, residual threshold = MAD(z) passed in as `thr`, max_trials 100,
+ * stop_probability 0.99) behind one call: triplets drawn from numpy's legacy MT19937 stream exactly
+ * as sklearn's sample_without_replacement consumes it (key624 / pos = RandomState.get_state()[1:3],
+ * advanced in place by the EXECUTED trials), batches of `batch` <= 64 trials scored per device round
+ * trip, the sequential accept rule with the dynamic trial bound, the final least-squares refit.
+ * n_cand must exceed 300 (below that sklearn samples with another method: host path).
+ * model64_out[3] = (c0, c1, b) of the refit; best_model_out[3] the winning trial's float32 plane;
+ * triplets_out (max_trials,3) optional.  status_out: 0 ok, 1 no consensus set (sklearn raises
+ * ValueError), 2 degenerate consensus set (refit on the host from best_model_out).            */
+int modest_ransac_plane(modest_ctx *ctx, const float *cand_xyz_dev, int n_cand, float thr,
+                        uint32_t *mt_key624, int32_t *mt_pos, int max_trials,
+                        double stop_probability, int batch, double *model64_out,
+                        float *best_model_out, int32_t *triplets_out, int32_t *n_trials_out,
+                        int32_t *n_inliers_out, int32_t *status_out, void *stream);
+/* The generator half alone (host only, no device work): n_trials triplets of
+ * sample_without_replacement(n_population > 300, 3) from the same stream.                    */
+int modest_mt19937_triplets(uint32_t *mt_key624, int32_t *mt_pos, uint32_t n_population,
+                            int n_trials, int32_t *triplets_out);
+
 /* The RNG-independent part of the two ground fits of a scan (generate_mask.py:55-56 and
  * clustering_utils.py:126) in one call: both candidate selections from one pass over the rows
  * (modest_plane_candidates semantics, compacted in row order) and both MAD thresholds, two

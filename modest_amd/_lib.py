@@ -50,6 +50,9 @@ SIGNATURES = {
     "modest_cluster_dbscan_ex": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.c_int, VP, VP, VP, VP]),
     "modest_project_velo_to_rect": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP]),
+    "modest_ransac_plane": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, C.c_int, C.c_double, C.c_int, VP, VP, VP, VP, VP,
+                                      VP, VP]),
+    "modest_mt19937_triplets": (C.c_int, [VP, VP, C.c_uint32, C.c_int, VP]),
     "modest_plane_prepare": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP]),
     "modest_mask_cluster": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_double, VP, VP, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, VP, VP, VP, VP]),

@@ -11,6 +11,7 @@
 #include "compact.h"
 #include "mask_pred.h"
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 using namespace modest;
@@ -827,6 +828,164 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     out_model[1] = a1;
     out_model[2] = mz - a0 * mx - a1 * my;
     return MODEST_OK;
+}
+
+// ---- the RANSAC driver: sklearn's trial loop on the host side of the library --------------------
+// numpy's legacy generator (RandomState = MT19937) as sklearn's sample_without_replacement consumes
+// it: for n_samples > 300 ("tracking selection") one trial = RandomState.randint(n) until three
+// distinct indices are found, and randint(n) is the masked rejection `next_uint32 & mask` until
+// the value is < n (numpy/random/_bounded_integers: use_masked, 32-bit range).
+namespace {
+struct Mt19937 {
+    uint32_t key[624];
+    int pos;
+    void refill() {
+        const uint32_t U = 0x80000000u, L = 0x7fffffffu, A = 0x9908b0dfu;
+        int kk = 0;
+        for (; kk < 624 - 397; ++kk) {
+            const uint32_t y = (key[kk] & U) | (key[kk + 1] & L);
+            key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        for (; kk < 623; ++kk) {
+            const uint32_t y = (key[kk] & U) | (key[kk + 1] & L);
+            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        const uint32_t y = (key[623] & U) | (key[0] & L);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        pos = 0;
+    }
+    uint32_t next32() {
+        if (pos >= 624) refill();
+        uint32_t y = key[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t randint(uint32_t n) {   // RandomState.randint(n), 1 <= n <= 2^32 - 1
+        const uint32_t rng = n - 1;
+        if (rng == 0) return 0;
+        uint32_t mask = rng;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        uint32_t v;
+        while ((v = next32() & mask) > rng) {
+        }
+        return v;
+    }
+    void triplet(uint32_t n, int32_t *t) {   // sample_without_replacement(n, 3), tracking selection
+        int have = 0;
+        while (have < 3) {
+            const int32_t j = (int32_t)randint(n);
+            bool dup = false;
+            for (int q = 0; q < have; ++q) dup = dup || t[q] == j;
+            if (!dup) t[have++] = j;
+        }
+    }
+};
+
+double dynamic_max_trials(int n_inliers, int n_samples, double probability) {   // sklearn _dynamic_max_trials, min_samples = 3
+    const double eps = 2.220446049250313e-16;
+    const double ratio = (double)n_inliers / (double)n_samples;
+    const double nom = fmax(eps, 1.0 - probability);
+    const double denom = fmax(eps, 1.0 - pow(ratio, 3.0));
+    if (nom == 1.0) return 0.0;
+    if (denom == 1.0) return INFINITY;
+    return fabs(ceil(log(nom) / log(denom)));
+}
+
+double r2_from_sums(int n, double sse, double sy, double syy) {   // r2_score over the inliers
+    if (n < 2) return NAN;
+    const double den = syy - sy * sy / n;
+    if (den <= 0.0) return sse == 0.0 ? 1.0 : 0.0;
+    return 1.0 - sse / den;
+}
+}  // namespace
+
+extern "C" int modest_mt19937_triplets(uint32_t *key624, int32_t *pos, uint32_t n_population, int n_trials,
+                                       int32_t *triplets_out) {
+    MODEST_REQUIRE(key624 && pos && triplets_out, "NULL argument");
+    MODEST_REQUIRE(n_population > 300 && n_trials >= 0 && *pos >= 0 && *pos <= 624, "bad arguments");
+    Mt19937 g;
+    memcpy(g.key, key624, sizeof(g.key));
+    g.pos = *pos;
+    for (int k = 0; k < n_trials; ++k) g.triplet(n_population, triplets_out + 3 * k);
+    memcpy(key624, g.key, sizeof(g.key));
+    *pos = g.pos;
+    return MODEST_OK;
+}
+
+extern "C" int modest_ransac_plane(modest_ctx *ctx, const float *cand, int n_cand, float thr, uint32_t *key624,
+                                   int32_t *pos, int max_trials, double stop_probability, int batch,
+                                   double *model64_out, float *best_model_out, int32_t *triplets_out,
+                                   int32_t *n_trials_out, int32_t *n_inliers_out, int32_t *status_out, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && cand && key624 && pos && model64_out && best_model_out && n_trials_out && status_out,
+                   "NULL argument");
+    MODEST_REQUIRE(n_cand > 300, "fewer than 301 candidates: sklearn draws with another method there (host path)");
+    MODEST_REQUIRE(max_trials >= 1 && max_trials <= 4096 && batch >= 1 && batch <= TRIP_MAX, "bad max_trials / batch");
+    MODEST_REQUIRE(*pos >= 0 && *pos <= 624 && thr >= 0.f, "bad generator position / threshold");
+    Mt19937 g;
+    memcpy(g.key, key624, sizeof(g.key));
+    g.pos = *pos;
+    int n_best = 1, n_trials = 0;
+    double score_best = -INFINITY, limit = (double)max_trials;
+    bool have = false;
+    float best[3] = {0, 0, 0};
+    std::vector<int32_t> trip((size_t)3 * batch), n_in(batch);
+    std::vector<float> models((size_t)3 * batch);
+    std::vector<double> sse(batch), sy(batch), syy(batch);
+    *status_out = 0;
+    while ((double)n_trials < limit) {
+        const int nb = (int)fmin((double)batch, limit - (double)n_trials);
+        const Mt19937 before = g;
+        for (int k = 0; k < nb; ++k) g.triplet((uint32_t)n_cand, trip.data() + 3 * k);
+        float t = thr;
+        int rc = modest_ransac_trials(ctx, cand, n_cand, trip.data(), nb, &t, models.data(), n_in.data(), sse.data(),
+                                      sy.data(), syy.data(), stream_);
+        if (rc) return rc;
+        int used = 0;
+        for (int k = 0; k < nb; ++k) {
+            if (!((double)n_trials < limit)) break;
+            ++n_trials;
+            ++used;
+            const int nk = n_in[k];
+            if (nk < n_best) continue;
+            const double score = r2_from_sums(nk, sse[k], sy[k], syy[k]);
+            if (nk == n_best && score < score_best) continue;
+            n_best = nk;
+            score_best = score;
+            have = true;
+            for (int q = 0; q < 3; ++q) best[q] = models[3 * k + q];
+            limit = fmin(limit, dynamic_max_trials(n_best, n_cand, stop_probability));
+        }
+        if (triplets_out)
+            for (int q = 0; q < 3 * used; ++q) triplets_out[3 * (n_trials - used) + q] = trip[q];
+        if (used < nb) {   // the caller's stream advances by exactly the executed trials
+            g = before;
+            int32_t scratch[3];
+            for (int k = 0; k < used; ++k) g.triplet((uint32_t)n_cand, scratch);
+        }
+    }
+    memcpy(key624, g.key, sizeof(g.key));
+    *pos = g.pos;
+    *n_trials_out = n_trials;
+    if (!have) {
+        *status_out = 1;   // no consensus set: sklearn raises ValueError
+        return MODEST_OK;
+    }
+    for (int q = 0; q < 3; ++q) best_model_out[q] = best[q];
+    int32_t nfin = 0;
+    const int rc = modest_ransac_refit(ctx, cand, n_cand, best, thr, model64_out, &nfin, stream_);
+    if (n_inliers_out) *n_inliers_out = nfin;
+    if (rc == MODEST_ERR_ARG) {
+        *status_out = 2;   // degenerate consensus set: the caller takes the minimum-norm fit on the host
+        return MODEST_OK;
+    }
+    return rc;
 }
 
 extern "C" int modest_plane_range_mask(modest_ctx *ctx, const float *pts, int n, int stride,

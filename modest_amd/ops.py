@@ -227,6 +227,43 @@ def ransac_trials(cand: torch.Tensor, triplets: np.ndarray, thr: Optional[float]
     return np.float32(thr_io.value), models, n_in, sse, sy, syy
 
 
+def ransac_plane_native(cand: torch.Tensor, rs: np.random.RandomState, thr: float, max_trials: int = 100,
+                        stop_probability: float = 0.99, batch: int = 48, ctx: Optional[Context] = None):
+    """The whole RANSAC fit behind one library call (include/modest_hip.h: modest_ransac_plane): `rs`
+    (legacy MT19937 RandomState) is advanced in place by the executed trials.
+    Returns (status, model64 (3,), best_model (3,) f32, triplets (n_trials,3), n_trials, n_inliers)."""
+    lib = load()
+    _dev(cand, torch.float32, "cand")
+    st = rs.get_state()
+    assert st[0] == "MT19937"
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(st[2]))
+    model64, best = np.zeros(3, dtype=np.float64), np.zeros(3, dtype=np.float32)
+    trip = np.zeros((max_trials, 3), dtype=np.int32)
+    n_trials, n_in, status = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    c = _ctx(ctx, cand)
+    check(lib.modest_ransac_plane(c.handle, cand.data_ptr(), cand.shape[0], float(np.float32(thr)), _np_ptr(key),
+                                  C.byref(pos), int(max_trials), float(stop_probability), int(batch), _np_ptr(model64),
+                                  _np_ptr(best), _np_ptr(trip), C.byref(n_trials), C.byref(n_in), C.byref(status),
+                                  _stream()), "modest_ransac_plane")
+    rs.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return int(status.value), model64, best, trip[: n_trials.value].astype(np.int64), int(n_trials.value), int(n_in.value)
+
+
+def mt19937_triplets(rs: np.random.RandomState, n_population: int, n_trials: int) -> np.ndarray:
+    """n_trials draws of sklearn's sample_without_replacement(n_population > 300, 3) from `rs`, made by
+    the library's generator (host only); `rs` is advanced in place."""
+    lib = load()
+    st = rs.get_state()
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(st[2]))
+    out = np.zeros((n_trials, 3), dtype=np.int32)
+    check(lib.modest_mt19937_triplets(_np_ptr(key), C.byref(pos), int(n_population), int(n_trials), _np_ptr(out)),
+          "modest_mt19937_triplets")
+    rs.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out
+
+
 def ransac_refit(cand: torch.Tensor, model: np.ndarray, thr: float, ctx: Optional[Context] = None):
     lib = load()
     _dev(cand, torch.float32, "cand")

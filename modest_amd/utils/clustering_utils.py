@@ -101,7 +101,6 @@ def filter_labels(ptc, pp_score, labels, random_state=None, plane=None, ptc_dev=
     The second ground plane (hard-coded max_hs=-1.5, range ((-70,70),(-50,50))) and the
     per-cluster statistics (count, height extremes, PP-score percentile) are device work;
     the host keeps the four scalar comparisons per cluster."""
-    labels = labels.copy()
     dev_pts = to_device(ptc) if ptc_dev is None else ptc_dev
     if plane is None:
         plane = estimate_plane(dev_pts, max_hs=FILTER_PLANE_SPEC[0], ptc_range=FILTER_PLANE_SPEC[1],
@@ -116,8 +115,12 @@ def filter_labels(ptc, pp_score, labels, random_state=None, plane=None, ptc_dev=
         pct = percentile_from_order_stats(st[:, 3], st[:, 4], st[:, 5])
         valid = (n >= min_points) & ~(dmin > max_min_height) & ~(dmax < min_max_height) & \
             ~(pct > np.float32(min_percentile_pp_score))
-        member = labels >= 0
-        drop = np.zeros(labels.shape, dtype=bool)
-        drop[member] = ~valid[labels[member]]
-        labels[drop] = -1
+        # labels[dropped] = -1 and compact_labels in ONE table look-up over the scan: table[l + 1] = rank of
+        # label l among the surviving values.  Labels without members never occur in `labels`; -1
+        # survives iff it was there or a cluster is dropped.
+        valid &= n >= 1
+        has_neg = bool(labels.min() < 0) or bool((~valid & (n >= 1)).any())
+        table = np.zeros(n_lab + 1, dtype=labels.dtype)
+        table[1:][valid] = np.arange(int(valid.sum()), dtype=labels.dtype) + (1 if has_neg else 0)
+        return table[labels + 1]
     return compact_labels(labels)

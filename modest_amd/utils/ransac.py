@@ -32,6 +32,7 @@ from .. import ops
 from .._lib import ModestHipError
 
 _EPSILON = np.spacing(1)
+NATIVE_DRIVER = True   # tests switch it off to compare the library's trial loop with the Python statement below
 
 
 def dynamic_max_trials(n_inliers, n_samples, min_samples, probability):
@@ -115,6 +116,40 @@ def draw_triplets(rs, n_population, n_trials):
     return trip, used
 
 
+def _degenerate_refit(cand, best_model, thr):
+    """sklearn's LinearRegression on a degenerate consensus set (fewer than 3 points, or a singular normal
+    matrix) returns the minimum-norm least-squares fit; the device refit reports such sets instead of
+    dividing by zero.  Scalar work on the host, once in a blue moon."""
+    pts = cand.cpu().numpy().astype(np.float32)
+    pred = (pts[:, 1] * best_model[1] + pts[:, 0] * best_model[0]) + best_model[2]
+    inl = np.abs(pts[:, 2] - pred) <= np.float32(thr)
+    X, z = pts[inl, :2].astype(np.float64), pts[inl, 2].astype(np.float64)
+    xm, zm = X.mean(axis=0), z.mean()
+    coef = np.linalg.lstsq(X - xm, z - zm, rcond=None)[0]
+    return np.array([coef[0], coef[1], zm - xm @ coef]), int(inl.sum())
+
+
+def _ransac_plane_native(cand, rs, thr, max_trials, stop_probability, batch, ctx) -> "RansacResult":
+    """The loop below behind one library call (modest_ransac_plane: generator, batches, accept rule,
+    refit): same draws, same decisions, no interpreter between the device round trips."""
+    status, model64, best_model, trip, n_trials, n_final = ops.ransac_plane_native(
+        cand, rs, thr, max_trials, stop_probability, batch, ctx=ctx)
+    if status == 1:
+        raise ValueError("RANSAC could not find a valid consensus set. All `max_trials` iterations were "
+                         "skipped because each randomly chosen sub-sample failed the passing criteria.")
+    if status == 2:
+        model64, n_final = _degenerate_refit(cand, best_model, thr)
+    res = RansacResult()
+    res.coef = model64[:2].astype(np.float32)
+    res.intercept = np.float32(model64[2])
+    res.n_trials = n_trials
+    res.n_inliers = n_final
+    res.threshold = thr
+    res.triplets = trip
+    res.best_model = best_model
+    return res
+
+
 def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, stop_probability: float = 0.99,
                  batch: int = 48, ctx=None, thr=None) -> RansacResult:
     """cand: (m,3) float32 device tensor of candidate ground points (x, y, z).
@@ -125,6 +160,9 @@ def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, s
         raise ValueError("`min_samples` may not be larger than number of samples: n_samples = %d." % n_samples)
     rs = check_random_state(random_state)
     # thr None: MAD(z) is computed on the device with the first batch
+    if NATIVE_DRIVER and thr is not None and n_samples > 300 and batch <= 64 and isinstance(rs, np.random.RandomState) \
+            and rs.get_state()[0] == "MT19937":
+        return _ransac_plane_native(cand, rs, thr, max_trials, stop_probability, batch, ctx)
 
     n_inliers_best, score_best, best_model = 1, -np.inf, None
     n_trials, limit = 0, max_trials
@@ -164,16 +202,7 @@ def ransac_plane(cand: torch.Tensor, random_state=None, max_trials: int = 100, s
     try:
         model64, n_final = ops.ransac_refit(cand, best_model, thr, ctx=ctx)
     except ModestHipError:
-        # degenerate consensus set (fewer than 3 points, or a singular normal matrix): the device refit
-        # reports it instead of dividing by zero.  sklearn's LinearRegression returns the minimum-norm
-        # least-squares fit there; do the same on the host (scalar work, once in a blue moon).
-        pts = cand.cpu().numpy().astype(np.float32)
-        pred = (pts[:, 1] * best_model[1] + pts[:, 0] * best_model[0]) + best_model[2]
-        inl = np.abs(pts[:, 2] - pred) <= np.float32(thr)
-        X, z = pts[inl, :2].astype(np.float64), pts[inl, 2].astype(np.float64)
-        xm, zm = X.mean(axis=0), z.mean()
-        coef = np.linalg.lstsq(X - xm, z - zm, rcond=None)[0]
-        model64, n_final = np.array([coef[0], coef[1], zm - xm @ coef]), int(inl.sum())
+        model64, n_final = _degenerate_refit(cand, best_model, thr)
     res = RansacResult()
     res.coef = model64[:2].astype(np.float32)          # LinearRegression on float32 data stores float32
     res.intercept = np.float32(model64[2])

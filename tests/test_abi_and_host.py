@@ -114,6 +114,27 @@ def test_vectorised_triplet_stream_equals_sklearn():
                 assert np.array_equal(b.get_state()[1], c.get_state()[1]) and b.get_state()[2] == c.get_state()[2]
 
 
+def test_library_mt19937_triplets_equal_sklearn():
+    """The generator half of modest_ransac_plane (host code of the library): triplets AND the generator
+    state after them equal sklearn's sample_without_replacement on numpy's legacy RandomState, incl. a
+    stream that crosses several 624-word refills, a fresh generator (pos = 624) and one whose Gaussian
+    cache is occupied (left untouched)."""
+    from sklearn.utils.random import sample_without_replacement
+    from modest_amd import ops
+    for n_pop in (301, 1024, 1025, 9973, 17001, 2_000_000):
+        for seed in (0, 5, 123456789):
+            a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+            if seed == 5:
+                a.standard_normal(3), b.standard_normal(3)
+            for chunk in (1, 48, 500):
+                ref = np.stack([sample_without_replacement(n_pop, 3, random_state=a) for _ in range(chunk)])
+                got = ops.mt19937_triplets(b, n_pop, chunk)
+                assert np.array_equal(got, ref), (n_pop, seed, chunk)
+                sa, sb = a.get_state(), b.get_state()
+                assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+            assert a.randint(1 << 30) == b.randint(1 << 30)
+
+
 def test_percentile_lerp_equals_numpy():
     from modest_amd.utils.clustering_utils import percentile_from_order_stats
     rng = np.random.default_rng(3)

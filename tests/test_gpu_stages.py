@@ -73,6 +73,33 @@ def test_plane_candidates_mad_and_scoring(gpu, ms):
         assert abs(sy[k] - z[inl].astype(np.float64).sum()) <= 1e-9 * max(1.0, abs(sy[k]))
 
 
+def test_ransac_native_driver_equals_python_loop(gpu, ms):
+    """modest_ransac_plane (generator + batches + accept rule + refit in the library) against the Python
+    loop of utils/ransac.py on the same candidates: same triplets, same number of trials, same plane, and
+    the caller's generator ends in the same state (the next fit of the scan draws from it)."""
+    import torch
+    from modest_amd import ops
+    from modest_amd.utils import ransac
+    dev = torch.from_numpy(ms["ptc"]).to(gpu)
+    for max_hs, rng_ in ((-1.5, [[-70, 70], [-20, 20]]), (-1.5, [[-70, 70], [-50, 50]]), (-1.2, [[0, 40], [-10, 10]])):
+        cand, _ = ops.plane_candidates(dev, max_hs, rng_)
+        thr = ops.mad_threshold(cand)
+        for seed in range(12):
+            a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+            nat = ransac.ransac_plane(cand, random_state=a, thr=thr)
+            ransac.NATIVE_DRIVER = False   # the Python statement of the same loop
+            try:
+                ref = ransac.ransac_plane(cand, random_state=b, thr=thr)
+            finally:
+                ransac.NATIVE_DRIVER = True
+            assert np.array_equal(nat.triplets, ref.triplets), seed
+            assert nat.n_trials == ref.n_trials and nat.n_inliers == ref.n_inliers
+            assert np.array_equal(nat.coef, ref.coef) and nat.intercept == ref.intercept
+            assert np.array_equal(nat.best_model, ref.best_model)
+            sa, sb = a.get_state(), b.get_state()
+            assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:], seed
+
+
 def test_plane_prepare_equals_separate_calls(gpu, ms):
     """modest_plane_prepare (both candidate sets from one pass + both MADs, one sync) against
     plane_candidates x 2 + mad_threshold, incl. an empty set and repeated calls."""

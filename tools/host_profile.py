@@ -46,4 +46,4 @@ for i in range(N):
     one(i)
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats(sys.argv[2] if len(sys.argv) > 2 else "cumulative").print_stats(55)
