@@ -348,11 +348,17 @@ int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz_dev,
                                void *stream);
 
 /* The same call for cluster points in HOST memory (get_obj's callers hold them there): the points
- * travel with the offset / angle / summation-order tables in one staged copy.                    */
+ * travel with the offset / angle / summation-order tables in one staged copy.
+ * extents_host (optional, (C,8) f64) with cossin90_host = (cos, sin) of angle + pi/2 per table
+ * entry: the first half of rectangle_at_angle (pointcloud_utils.py:188-216) -- min_x, max_x,
+ * min_y, max_y of pts @ [[c, s], [-s, c]]^T at the chosen heading, then the same four at
+ * heading + pi/2 -- computed by the block that picked the heading (dgemm rounding: one fma per
+ * element); an error is returned when a cluster is too large for that kernel (> ~90 k points). */
 int modest_fit_boxes_closeness_host(modest_ctx *ctx, const double *pts_xz_host,
                                     const int32_t *offsets_host, int n_clusters,
                                     const double *cossin_host, int n_angles, double d0,
-                                    int32_t *best_angle_host, void *stream);
+                                    int32_t *best_angle_host, const double *cossin90_host,
+                                    double *extents_host, void *stream);
 
 /* fit_method = 'variance_to_edge' (utils/pointcloud_utils.py:218-275): the same
  * angle table, criterion -var(Dx[Dx<Dy]) - var(Dy[Dy<Dx]) with numpy's var (pairwise sums of the

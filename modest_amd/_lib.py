@@ -59,7 +59,7 @@ SIGNATURES = {
     "modest_cluster_stats": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, C.c_double, VP, VP]),
     "modest_boxes_pp_stats": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP]),
     "modest_fit_boxes_closeness": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP, VP]),
-    "modest_fit_boxes_closeness_host": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP]),
+    "modest_fit_boxes_closeness_host": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP, VP, VP]),
     "modest_fit_boxes_variance": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, VP, VP, VP]),
     "modest_fit_boxes_pca": (C.c_int, [VP, VP, VP, C.c_int, VP, VP]),
     "modest_lowest_point": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),

@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
                                                              const int *__restrict__ progBase,
                                                              const unsigned char *__restrict__ prog,
                                                              int maxLeaves, double *__restrict__ beta,
-                                                             unsigned *tickets, int *__restrict__ best_host) {
+                                                             unsigned *tickets, int *__restrict__ best_host,
+                                                             const double *__restrict__ cossin90,
+                                                             double *__restrict__ rect_host) {
     constexpr int AB = 256 / P;
     extern __shared__ double ct_lsum[];          // [AB][maxLeaves]
     __shared__ double stk[AB][CT_STACK];
@@ -277,11 +279,55 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
     __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(tickets + c, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
-    if (!last_s || threadIdx.x >= 64) return;
-    const int arg = argmax_wave(beta + (size_t)c * n_angles, n_angles, threadIdx.x);
-    if (threadIdx.x == 0) {
-        best_host[c] = arg;
-        tickets[c] = 0u;
+    if (!last_s) return;
+    __shared__ int arg_s;
+    if (threadIdx.x < 64) {
+        const int arg = argmax_wave(beta + (size_t)c * n_angles, n_angles, threadIdx.x);
+        if (threadIdx.x == 0) {
+            best_host[c] = arg;
+            tickets[c] = 0u;
+            arg_s = arg;
+        }
+    }
+    if (!rect_host) return;
+    // ... and the extents of the cluster along the chosen heading and along heading + pi/2
+    // (rectangle_at_angle, pointcloud_utils.py:188-216: projection = pts @ [[c, s], [-s, c]]^T, its
+    // column minima / maxima; the host keeps the scalar tail).  cossin90 holds cos / sin of
+    // angle + pi/2 as the host's numpy evaluates them.
+    __syncthreads();
+    const int arg = arg_s;
+    __shared__ double ext[8][4];   // [value][wavefront]
+    double e[8] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+    if (arg >= 0) {
+        const double c0 = cossin[2 * arg], s0 = cossin[2 * arg + 1], c1 = cossin90[2 * arg], s1 = cossin90[2 * arg + 1];
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double x = B.pts[2 * (size_t)i], z = B.pts[2 * (size_t)i + 1];
+            const double p0 = fma(z, s0, x * c0), p1 = fma(z, c0, x * -s0);
+            const double q0 = fma(z, s1, x * c1), q1 = fma(z, c1, x * -s1);
+            e[0] = fmin(e[0], p0);
+            e[1] = fmax(e[1], p0);
+            e[2] = fmin(e[2], p1);
+            e[3] = fmax(e[3], p1);
+            e[4] = fmin(e[4], q0);
+            e[5] = fmax(e[5], q0);
+            e[6] = fmin(e[6], q1);
+            e[7] = fmax(e[7], q1);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v = __shfl_xor(e[q], o);
+            e[q] = (q & 1) ? fmax(e[q], v) : fmin(e[q], v);
+        }
+        if ((threadIdx.x & 63) == 0) ext[q][threadIdx.x >> 6] = e[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int q = threadIdx.x;
+        double v = ext[q][0];
+        for (int w = 1; w < 4; ++w) v = (q & 1) ? fmax(v, ext[q][w]) : fmin(v, ext[q][w]);
+        rect_host[(size_t)c * 8 + q] = v;   // min_x, max_x, min_y, max_y at the heading; the same at heading + pi/2
     }
 }
 
@@ -576,7 +622,8 @@ __global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__
 static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz, const int32_t *offsets_host,
                             int n_clusters, const double *cossin_host, int n_angles, double d0,
                             int32_t *best_angle_host, double *beta_host, void *stream_,
-                            const double *pts_host = nullptr) {
+                            const double *pts_host = nullptr, const double *cossin90_host = nullptr,
+                            double *rect_host_out = nullptr) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n_clusters >= 0 && n_angles >= 1 && n_angles <= 65536, "bad sizes");
     if (n_clusters == 0) return MODEST_OK;
@@ -612,12 +659,14 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
     const size_t u_pb = u_lb + arena_sz(leafBase.size() * 4);
     const size_t u_lf = u_pb + arena_sz(progBase.size() * 4);
     const size_t u_pg = u_lf + arena_sz(leaf.size() * 4);
-    const size_t u_pts = u_pg + arena_sz(prog.size());
+    const size_t u_c90 = u_pg + arena_sz(prog.size());
+    const size_t u_pts = u_c90 + (cossin90_host ? arena_sz((size_t)n_angles * 16) : 0);
     const size_t b_up = u_pts + (pts_host ? arena_sz((size_t)offsets_host[n_clusters] * 16) : 0);
+    const size_t b_rect = rect_host_out ? arena_sz((size_t)n_clusters * 64) : 0;
     const size_t b_beta = arena_sz((size_t)n_clusters * n_angles * 8), b_best = arena_sz((size_t)n_clusters * 4);
     int rc = modest_ctx_reserve(ctx, b_up + b_beta + b_best);
     if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, b_up + b_best + (beta_host ? b_beta : 0));
+    rc = modest_ctx_reserve_pinned(ctx, b_up + b_best + (beta_host ? b_beta : 0) + b_rect);
     if (rc) return rc;
     char *d = ctx->scratch, *h = ctx->pinned;
     int *d_off = reinterpret_cast<int *>(d + u_off);
@@ -626,6 +675,9 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
     int *d_best = reinterpret_cast<int *>(d + b_up + b_beta);
     int *h_best = reinterpret_cast<int *>(h + b_up);
     double *h_beta = reinterpret_cast<double *>(h + b_up + b_best);
+    double *h_rect = rect_host_out ? reinterpret_cast<double *>(h + b_up + b_best + (beta_host ? b_beta : 0)) : nullptr;
+    const double *d_c90 = cossin90_host ? reinterpret_cast<const double *>(d + u_c90) : nullptr;
+    MODEST_REQUIRE(!rect_host_out || (cossin90_host && !variance), "extents need the heading + pi/2 table (closeness only)");
     memcpy(h + u_off, offsets_host, (size_t)(n_clusters + 1) * 4);
     memcpy(h + u_cs, cossin_host, (size_t)n_angles * 16);
     if (!variance) {
@@ -634,6 +686,7 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
         if (!leaf.empty()) memcpy(h + u_lf, leaf.data(), leaf.size() * 4);
         if (!prog.empty()) memcpy(h + u_pg, prog.data(), prog.size());
     }
+    if (cossin90_host) memcpy(h + u_c90, cossin90_host, (size_t)n_angles * 16);
     if (pts_host) {
         memcpy(h + u_pts, pts_host, (size_t)offsets_host[n_clusters] * 16);
         pts_xz = reinterpret_cast<const double *>(d + u_pts);
@@ -659,10 +712,10 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
         const unsigned char *d_pg = reinterpret_cast<const unsigned char *>(d + u_pg);
         if (P == 64)
             closeness_tree_kernel<64><<<g2, 256, lds, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_lb, d_lf, d_pb,
-                                                                d_pg, maxLeaves, d_beta, tickets, h_best);
+                                                                d_pg, maxLeaves, d_beta, tickets, h_best, d_c90, h_rect);
         else
             closeness_tree_kernel<16><<<g2, 256, lds, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_lb, d_lf, d_pb,
-                                                                d_pg, maxLeaves, d_beta, tickets, h_best);
+                                                                d_pg, maxLeaves, d_beta, tickets, h_best, d_c90, h_rect);
         picked = tickets != nullptr;
     } else {   // a cluster of > 90 k points: one lane per (cluster, angle)
         closeness_kernel<<<grid, 128, 0, stream>>>(pts_xz, d_off, d_cs, n_angles, d0, d_beta);
@@ -675,6 +728,10 @@ static int fit_boxes_angles(modest_ctx *ctx, int variance, const double *pts_xz,
                                         hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     for (int i = 0; i < n_clusters; ++i) best_angle_host[i] = h_best[i];
+    if (rect_host_out) {
+        MODEST_REQUIRE(picked, "extents are produced by the tree kernel only (cluster too large / too many clusters)");
+        memcpy(rect_host_out, h_rect, (size_t)n_clusters * 64);
+    }
     if (beta_host)
         for (size_t i = 0; i < (size_t)n_clusters * n_angles; ++i) beta_host[i] = h_beta[i];
     return MODEST_OK;
@@ -692,9 +749,10 @@ extern "C" int modest_fit_boxes_closeness(modest_ctx *ctx, const double *pts_xz,
 extern "C" int modest_fit_boxes_closeness_host(modest_ctx *ctx, const double *pts_xz_host,
                                                const int32_t *offsets_host, int n_clusters,
                                                const double *cossin_host, int n_angles, double d0,
-                                               int32_t *best_angle_host, void *stream_) {
+                                               int32_t *best_angle_host, const double *cossin90_host,
+                                               double *extents_host, void *stream_) {
     return fit_boxes_angles(ctx, 0, nullptr, offsets_host, n_clusters, cossin_host, n_angles, d0, best_angle_host,
-                            nullptr, stream_, pts_xz_host);
+                            nullptr, stream_, pts_xz_host, cossin90_host, extents_host);
 }
 
 extern "C" int modest_fit_boxes_variance(modest_ctx *ctx, const double *pts_xz,

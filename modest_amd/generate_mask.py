@@ -20,7 +20,7 @@ import torch
 
 from . import config, dist, ops
 from .utils import kitti_util
-from .utils.clustering_utils import FILTER_PLANE_SPEC, compact_labels, filter_labels, members_by_label
+from .utils.clustering_utils import FILTER_PLANE_SPEC, compact_labels, filter_labels, members_sorted, relabel_after_drop
 from .utils.pointcloud_utils import estimate_plane, get_objs, load_velo_scan, prepare_planes, to_device
 
 
@@ -67,25 +67,20 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
                                     plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
                                     pp_dev=pp_dev, labels_dev=labels_dev, plane_prepared=prep[1], **args.filtering)
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
-    members = members_by_label(labels_filtered, n_lab)
+    order, cuts = members_sorted(labels_filtered, n_lab)
     # rect-frame points: the clusters' rows on the host (per-cluster numpy arithmetic of get_obj), the whole
     # scan on the device, where the lowest-point search reads it (same rounding: one fma chain per element)
-    if members:
-        rect_m = calib.project_velo_to_rect(ptc[np.concatenate(members), :3])
-        cuts = np.cumsum([0] + [len(m) for m in members])
-        rect_m = np.ascontiguousarray(rect_m)
-        clusters = [rect_m[cuts[k]:cuts[k + 1]] for k in range(len(members))]
+    if n_lab:
+        rect_m = np.ascontiguousarray(calib.project_velo_to_rect(ptc[order, :3]))
+        clusters = [rect_m[cuts[k]:cuts[k + 1]] for k in range(n_lab)]
         rect_dev = ops.project_velo_to_rect(ptc_dev, calib.V2C, calib.R0)
     else:
         clusters, rect_dev = [], None
     cand = get_objs(clusters, rect_dev, fit_method=args.bbox_gen.fit_method)
-    objs = []
-    for m, obj in zip(members, cand):
-        if obj.volume > args.filtering.min_volume and obj.volume < args.filtering.max_volume:
-            objs.append(obj)
-        else:
-            labels_filtered[m] = 0
-    labels_filtered = compact_labels(labels_filtered)
+    lo, hi = args.filtering.min_volume, args.filtering.max_volume
+    keep = [bool(obj.volume > lo and obj.volume < hi) for obj in cand]
+    objs = [obj for obj, k in zip(cand, keep) if k]
+    labels_filtered = relabel_after_drop(labels_filtered, n_lab, keep) if n_lab else compact_labels(labels_filtered)
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
 
 

@@ -16,7 +16,13 @@ from . import _lib
 from ._lib import Context, check, default_context, load
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """handle of PyTorch's current HIP stream (the raw getter skips the Stream object: ~8 us per call)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -428,9 +434,10 @@ def fit_boxes_closeness(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np
 
 
 def fit_boxes_closeness_host(pts_xz: np.ndarray, offsets: Sequence[int], cossin: np.ndarray, d0: float = 1e-2,
-                             ctx: Optional[Context] = None) -> np.ndarray:
+                             cossin90: Optional[np.ndarray] = None, ctx: Optional[Context] = None):
     """fit_boxes_closeness for cluster points in host memory ((m,2) float64): points and tables go to
-    the device in one staged copy."""
+    the device in one staged copy.  With ``cossin90`` ((cos, sin) of every table angle + pi/2) also returns
+    the (C,8) extents of every cluster at the chosen heading and at heading + pi/2."""
     lib = load()
     pts = np.ascontiguousarray(pts_xz, dtype=np.float64).reshape(-1, 2)
     off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
@@ -438,10 +445,16 @@ def fit_boxes_closeness_host(pts_xz: np.ndarray, offsets: Sequence[int], cossin:
     cs = np.ascontiguousarray(cossin, dtype=np.float64).reshape(-1, 2)
     ncl, na = off.shape[0] - 1, cs.shape[0]
     best = np.full(ncl, -1, dtype=np.int32)
+    ext = None
+    if cossin90 is not None:
+        cossin90 = np.ascontiguousarray(cossin90, dtype=np.float64).reshape(na, 2)
+        ext = np.zeros((ncl, 8), dtype=np.float64)
     c = ctx if ctx is not None else default_context(torch.cuda.current_device())
     check(lib.modest_fit_boxes_closeness_host(c.handle, _np_ptr(pts), _np_ptr(off), ncl, _np_ptr(cs), na, float(d0),
-                                              _np_ptr(best), _stream()), "modest_fit_boxes_closeness_host")
-    return best
+                                              _np_ptr(best), None if ext is None else _np_ptr(cossin90),
+                                              None if ext is None else _np_ptr(ext), _stream()),
+          "modest_fit_boxes_closeness_host")
+    return best if ext is None else (best, ext)
 
 
 def fit_boxes_variance(pts_xz: torch.Tensor, offsets: Sequence[int], cossin: np.ndarray, return_crit: bool = False,

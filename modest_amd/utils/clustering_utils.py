@@ -79,16 +79,34 @@ def compact_labels(labels):
     return rank[labels - lo].astype(labels.dtype)
 
 
-def members_by_label(labels, n_lab):
-    """[np.flatnonzero(labels == i) for i in 1..n_lab] (ascending indices), from one stable sort
-    of the labelled points only (most points are background)."""
+def members_sorted(labels, n_lab):
+    """The members of labels 1..n_lab as one index array in label order (ascending indices inside a
+    label) plus the n_lab + 1 cut positions: one stable sort of the labelled points only (most points
+    are background; small labels take numpy's O(n) radix sort)."""
     idx = np.flatnonzero(labels > 0)
     sub = labels[idx]
+    if n_lab < 32768:
+        sub = sub.astype(np.int16)
     order = idx[np.argsort(sub, kind="stable")]
-    sl = labels[order]
-    ids = np.arange(1, n_lab + 1)
-    starts, ends = np.searchsorted(sl, ids, side="left"), np.searchsorted(sl, ids, side="right")
-    return [order[s:e] for s, e in zip(starts, ends)]
+    cuts = np.searchsorted(labels[order], np.arange(1, n_lab + 2), side="left")
+    return order, cuts
+
+
+def members_by_label(labels, n_lab):
+    """[np.flatnonzero(labels == i) for i in 1..n_lab] (ascending indices)."""
+    order, cuts = members_sorted(labels, n_lab)
+    return [order[cuts[k]:cuts[k + 1]] for k in range(n_lab)]
+
+
+def relabel_after_drop(labels, n_lab, keep):
+    """``labels[members of dropped clusters] = 0`` followed by compact_labels (generate_mask.py:94-103) as
+    one table look-up.  labels holds 0 (background) and 1..n_lab, every one of which has members;
+    keep (n_lab,) bool."""
+    keep = np.asarray(keep, dtype=bool)
+    has_zero = (not bool(keep.all())) or bool((labels == 0).any())
+    table = np.zeros(n_lab + 1, dtype=labels.dtype)
+    table[1:][keep] = np.arange(int(keep.sum()), dtype=labels.dtype) + (1 if has_zero else 0)
+    return table[labels]
 
 
 FILTER_PLANE_SPEC = (-1.5, ((-70, 70), (-50, 50)))   # the reference's hard-coded second ground fit (:126)

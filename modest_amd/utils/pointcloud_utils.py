@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .._lib import ModestHipError
 from . import kitti_util
 from .iou3d_nms import iou3d_nms_utils
 from .ransac import ransac_plane
@@ -133,20 +134,49 @@ def _angles(delta):
     return _ANGLES[delta]
 
 
+_ANGLES90 = {}
+
+
+def _angles90(delta):
+    """(cos, sin) of every table angle + pi/2, each evaluated as rectangle_at_angle evaluates it
+    (numpy scalar calls on ``angle + np.pi / 2``), once per process."""
+    if delta not in _ANGLES90:
+        ang, _ = _angles(delta)
+        _ANGLES90[delta] = np.array([[np.cos(a + np.pi / 2), np.sin(a + np.pi / 2)] for a in ang])
+    return _ANGLES90[delta]
+
+
+def rectangle_from_extents(choose_angle, ext):
+    """rectangle_at_angle given the cluster's extents along the heading (ext[:4]) and along
+    heading + pi/2 (ext[4:]) from the device: the scalar tail of (:188-216)."""
+    angle = choose_angle
+    min_x, max_x, min_y, max_y = ext[0], ext[1], ext[2], ext[3]
+    if (max_x - min_x) < (max_y - min_y):
+        angle = choose_angle + np.pi / 2
+        min_x, max_x, min_y, max_y = ext[4], ext[5], ext[6], ext[7]
+    c, s = np.cos(angle), np.sin(angle)
+    components = np.array([[c, s], [-s, c]])
+    area = (max_x - min_x) * (max_y - min_y)
+    rval = np.array([[max_x, min_y], [min_x, min_y], [min_x, max_y], [max_x, max_y]])
+    return rval @ components, angle, area
+
+
 def rectangle_at_angle(cluster_ptc, choose_angle):
     """(:188-216) tight rectangle at the chosen heading; rotated by 90 degrees when
     needed so that the first side is the long one.  Host numpy, per cluster."""
     angle = choose_angle
-    components = np.array([[np.cos(angle), np.sin(angle)], [-np.sin(angle), np.cos(angle)]])
+    c, s = np.cos(angle), np.sin(angle)   # (each is evaluated twice in the reference: same values)
+    components = np.array([[c, s], [-s, c]])
     projection = cluster_ptc @ components.T
-    min_x, max_x = projection[:, 0].min(), projection[:, 0].max()
-    min_y, max_y = projection[:, 1].min(), projection[:, 1].max()
+    px, py = projection[:, 0], projection[:, 1]
+    min_x, max_x, min_y, max_y = px.min(), px.max(), py.min(), py.max()
     if (max_x - min_x) < (max_y - min_y):
         angle = choose_angle + np.pi / 2
-        components = np.array([[np.cos(angle), np.sin(angle)], [-np.sin(angle), np.cos(angle)]])
+        c, s = np.cos(angle), np.sin(angle)
+        components = np.array([[c, s], [-s, c]])
         projection = cluster_ptc @ components.T
-        min_x, max_x = projection[:, 0].min(), projection[:, 0].max()
-        min_y, max_y = projection[:, 1].min(), projection[:, 1].max()
+        px, py = projection[:, 0], projection[:, 1]
+        min_x, max_x, min_y, max_y = px.min(), px.max(), py.min(), py.max()
     area = (max_x - min_x) * (max_y - min_y)
     rval = np.array([[max_x, min_y], [min_x, min_y], [min_x, max_y], [max_x, max_y]])
     return rval @ components, angle, area
@@ -159,8 +189,13 @@ def closeness_rectangles(clusters_xz: Sequence[np.ndarray], delta=0.1, d0=1e-2):
         return []
     ang, cs = _angles(delta)
     off = np.cumsum([0] + [len(c) for c in clusters_xz]).astype(np.int32)
-    best = ops.fit_boxes_closeness_host(np.concatenate(clusters_xz).astype(np.float64), off, cs, d0)
-    return [rectangle_at_angle(c, ang[b]) for c, b in zip(clusters_xz, best)]
+    pts = np.concatenate(clusters_xz).astype(np.float64)
+    try:      # heading and the cluster's extents along it from one launch
+        best, ext = ops.fit_boxes_closeness_host(pts, off, cs, d0, cossin90=_angles90(delta))
+    except ModestHipError:   # a cluster too large for that kernel: extents on the host
+        best = ops.fit_boxes_closeness_host(pts, off, cs, d0)
+        return [rectangle_at_angle(c, ang[b]) for c, b in zip(clusters_xz, best)]
+    return [rectangle_from_extents(ang[b], e) for b, e in zip(best, ext)]
 
 
 def variance_rectangles(clusters_xz: Sequence[np.ndarray], delta=0.1):

@@ -381,6 +381,32 @@ def test_filter_and_boxes(gpu, ms):
     assert np.array_equal(beta[0], np.array(ref))
 
 
+def test_rectangle_extents_from_device_equal_host_numpy(gpu):
+    """closeness_rectangles takes the extents of every cluster along the chosen heading (and heading + pi/2)
+    from the kernel that picked the heading; the rectangles must equal rectangle_at_angle (numpy: dgemm
+    projection + column min / max) bit for bit, incl. elongated clusters that take the rotated branch."""
+    from modest_amd import ops
+    from modest_amd.utils import pointcloud_utils as pu
+    rng = np.random.default_rng(9)
+    clusters = []
+    for k in range(60):
+        n = int(rng.choice([10, 11, 64, 65, 129, 500, 2049, 5000]))
+        th = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        ext = rng.uniform(0.2, 6.0, 2) * (rng.random(2) < 0.9)          # some degenerate (zero-width) clusters
+        clusters.append((rng.uniform(-0.5, 0.5, (n, 2)) * ext) @ R.T + rng.uniform(-60, 60, 2))
+    got = pu.closeness_rectangles(clusters)
+    ang, cs = pu._angles(0.1)
+    off = np.cumsum([0] + [len(c) for c in clusters]).astype(np.int32)
+    best = ops.fit_boxes_closeness_host(np.concatenate(clusters), off, cs, 1e-2)
+    rotated = 0
+    for c, b, (corners, angle, area) in zip(clusters, best, got):
+        rc, ra, rarea = pu.rectangle_at_angle(c, ang[b])
+        assert np.array_equal(corners, rc) and angle == ra and area == rarea
+        rotated += ra != ang[b]
+    assert 5 < rotated < 55
+
+
 def test_closeness_criterion_tree_sizes(gpu):
     """The closeness criterion of every (cluster, angle) equals numpy's pairwise sum bit for bit at
     the sizes where numpy's summation tree changes shape (8-accumulator leaves, 128-element leaves,
