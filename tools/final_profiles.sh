@@ -29,3 +29,10 @@ for f in $F/bench_*.json; do python -c "
 import json,sys; d=json.load(open('$f')); r=d['roofline']
 print('$f'.split('/')[-1], '%.0f scans/s' % d['value'], 'stage %.3f ms frac %.4f' % (r['kernel_ms'], r['frac']), 'isolated %.3f ms %.4f' % (r['isolated']['kernel_ms'], r['isolated']['frac']), d.get('speedup_vs_cpu'))"; done
 python tools/kstats.py $F/bench_full_1proc_kernel_stats.csv 70
+# ordered launch list of one full-pipeline scan (one scan at a time)
+bash tools/scan_trace.sh > /dev/null 2>&1; cp gpurun_out/scan_trace.txt $F/scan_trace.txt
+# diagnostics: each half of the pipeline alone from the default process pool
+python bench.py --cpu-scans 0 --cli-scans 0 --mask-only 2>/dev/null | line > $F/bench_mask_only.json
+MODEST_PP_FRAMES_PATH=gather-wave python tools/pp5_microbench.py 2>/dev/null | tail -1 > $F/pp_gather_wave_microbench.json
+python tools/pp5_microbench.py 2>/dev/null | tail -1 > $F/pp_stream_microbench.json
+python tools/host_profile.py 100 cumulative 2>&1 | grep -v amdgpu.ids | sed "s#$GRAFT_REPO_ROOT/##g; s#/usr/local/lib/python3.10/dist-packages/##g" | head -40 | cut -c1-160 > $F/host_profile.txt
