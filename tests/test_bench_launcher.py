@@ -9,11 +9,11 @@ sys.path.insert(0, ROOT)
 
 def test_helper_count_keeps_a_minimum_of_steps_per_helper():
     import bench
-    assert bench.MIN_STEPS_PER_HELPER >= 4
-    n20 = bench.helper_count(7, 20)                # the driver's 20-step run: fewer helpers, not seven x 3 steps
-    assert n20 == 20 // bench.MIN_STEPS_PER_HELPER and n20 < 7
-    assert bench.helper_count(7, 560) == 7
-    assert bench.helper_count(7, 3) == 1
+    assert bench.MIN_STEPS_PER_HELPER >= 2
+    n20 = bench.helper_count(8, 20)                # the driver's 20-step run: the whole pool, 2-3 steps each
+    assert n20 == min(8, 20 // bench.MIN_STEPS_PER_HELPER)
+    assert bench.helper_count(8, 560) == 8
+    assert bench.helper_count(8, 3) == max(1, 3 // bench.MIN_STEPS_PER_HELPER)
     assert bench.helper_count(1, 560) == 1
     assert sum(bench._split(20, n20)) == 20 and min(bench._split(20, n20)) >= bench.MIN_STEPS_PER_HELPER
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the driver's command (--steps 20 --warmup 5): value, spread, and the steady state of the full pool
 cd $GRAFT_REPO_ROOT
-for m in 4; do
+for m in 2 3 4 5; do
   for rep in 1 2 3 4; do
     MODEST_MIN_STEPS_PER_HELPER=$m timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-scans 0 --cli-scans 0 2>/dev/null | python -c "
 import sys,json
