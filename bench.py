@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-best-effort", type=int, default=16,
                     help="scans of the best-effort CPU baseline (one process per scan, workers=-1; 0 = skip)")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="A/B: do not enqueue the next scan's PP stage under the host tail of the current scan's label stage "
+                         "(same stream, same context; default on)")
     ap.add_argument("--overlap", action="store_true",
                     help="a worker issues the PP stage of its NEXT scan on a second HIP stream (own modest_ctx) before it "
                          "starts the host work of the current scan's mask stage.  One process: 530 -> 590 scans/s.  Off by "
@@ -187,6 +190,7 @@ class Runner:
             os.environ["MODEST_NUM_CUS"] = str(a.pp_cus)
         self.ctxs = [_lib.Context(local) for _ in range(self.n_threads)]
         self.overlap = a.overlap and not (a.pp_only or a.mask_only)
+        self.prefetch = not (a.no_prefetch or a.overlap or a.pp_only or a.mask_only)
         # the PP stage of the next scan runs on its own stream with its own context (scratch arena)
         self.pp_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_threads)] if self.overlap else self.streams
         self.pp_ctxs = [_lib.Context(local) for _ in range(self.n_threads)] if self.overlap else self.ctxs
@@ -216,10 +220,14 @@ class Runner:
         return self.store.pp_score(sc.live_key, sc.live_rel, sc.hist_keys, sc.rels, sc.A44, sc.T, ctx=ctx,
                                    desc=sc.desc, return_counts=return_counts)
 
-    def step(self, i, ctx, H=None):
+    def step(self, i, ctx, H=None, next_i=None):
+        """One scan through the pipeline.  H: the scan's PP score when it was enqueued ahead of time;
+        next_i: the worker's next step -- its PP stage is enqueued (same stream, same context) as soon
+        as this scan has no device work left, i.e. under the host tail of the label stage.
+        Returns (H, labels, objs, text, H of step next_i or None)."""
         a, sc = self.a, self.scans[i % len(self.scans)]
         if H is not None:
-            pass   # issued ahead of time by the worker (overlap)
+            pass   # enqueued ahead of time
         elif a.mask_only:   # diagnostic: the PP score of the scan is computed once, steps run stages 2 + 3
             if getattr(sc, "_H", None) is None:
                 sc._H = self.pp(sc, ctx)
@@ -227,12 +235,16 @@ class Runner:
         else:
             H = self.pp(sc, ctx)
         if a.pp_only:
-            return H, None, None, None
+            return H, None, None, None, None
         pp_host = H.cpu().numpy()
         labels, objs, _ = self._generate_mask_scan(sc.live_host, pp_host, sc.calib, self.margs,
                                                    random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H)
-        text, kept = self._gen_label_scan(objs, sc.calib, self.largs)
-        return H, labels, objs, text
+        ahead = []
+        hook = None
+        if next_i is not None and self.prefetch:
+            hook = lambda: ahead.append(self.pp(self.scans[next_i % len(self.scans)], ctx))   # noqa: E731
+        text, kept = self._gen_label_scan(objs, sc.calib, self.largs, after_device=hook)
+        return H, labels, objs, text, (ahead[0] if ahead else None)
 
     def issue_pp(self, i, w):
         """PP stage of step i on worker w's PP stream; returns (H, event recorded behind it)"""
@@ -260,8 +272,9 @@ class Runner:
                             H.record_stream(self.streams[w])
                             self.step(i, self.ctxs[w], H=H)
                     else:
-                        for i in idx:
-                            self.step(i, self.ctxs[w])
+                        H = None
+                        for k, i in enumerate(idx):
+                            H = self.step(i, self.ctxs[w], H=H, next_i=idx[k + 1] if k + 1 < len(idx) else None)[4]
                     self.streams[w].synchronize()
             except Exception as e:   # surfaced after join
                 errs.append(e)
@@ -606,7 +619,7 @@ def main():
         parity = {"pp_counts_equal": bool(np.array_equal(cg.cpu().numpy().astype(np.int64), cref)),
                   "pp_max_abs_err": float(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - Href)))}
         if ref is not None:
-            _, labels, objs, text = pr.step(0, pr.ctxs[0])
+            _, labels, objs, text, _ = pr.step(0, pr.ctxs[0])
             parity["labels_equal"] = bool(np.array_equal(labels, ref["labels"]))
             parity["n_objs"] = [len(objs), len(ref["objs"])]
             parity["label_text_equal"] = bool(text == ref["text"][0])
@@ -647,6 +660,7 @@ def main():
                                         "frame store + descriptor table (no stacked history)",
                        "host_processes_per_gpu": n_procs, "threads_per_process": n_threads,
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
+                       "pp_stage_prefetch": (not (a.no_prefetch or a.overlap or a.pp_only or a.mask_only)),
                        "pp_stage_overlap": ("next scan's PP stage on a second stream per worker" if (a.overlap and not (a.pp_only or a.mask_only)) else "none"),
                        "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
                        "rccl_world_size": rccl_ws,

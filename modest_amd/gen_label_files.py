@@ -33,10 +33,15 @@ def display_args(args):
     eprint("==========================================")
 
 
-def gen_label_scan(objs, calib, args):
-    """gen_label_files.py:44-52 for one scan -> (label text, kept objs)."""
+def gen_label_scan(objs, calib, args, after_device=None):
+    """gen_label_files.py:44-52 for one scan -> (label text, kept objs).
+    ``after_device`` (optional callable) runs as soon as the stage has no device work left -- its only
+    device call is the IoU matrix of the NMS; a pipeline uses it to enqueue the next scan's device work
+    under the host tail of this one (greedy NMS, FOV filter, label text)."""
     if args.nms.enable and len(objs) > 0:
-        objs = objs_nms(objs, nms_threshold=args.nms.threshold)
+        objs = objs_nms(objs, nms_threshold=args.nms.threshold, after_device=after_device)
+    elif after_device is not None:
+        after_device()
     if args.fov_only:
         objs = [obj for obj in objs if is_within_fov(obj, calib, args.image_shape)]
     return objs2label(objs, calib), objs

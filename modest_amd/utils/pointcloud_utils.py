@@ -313,12 +313,15 @@ def get_obj(ptc, full_ptc, fit_method="min_zx_area_fit"):
     return get_objs([np.asarray(ptc, dtype=np.float64)], full_ptc, fit_method)[0]
 
 
-def objs_nms(objs, use_score_rank=False, nms_threshold=0.1):
-    """(:320-344) BEV NMS of boxes in the rect frame; keeps the original order."""
+def objs_nms(objs, use_score_rank=False, nms_threshold=0.1, after_device=None):
+    """(:320-344) BEV NMS of boxes in the rect frame; keeps the original order.
+    ``after_device``: called once when the device part (the IoU matrix) is done and only host work is left."""
     boxes = np.array([[obj.t[0], obj.t[2], 0, obj.l, obj.w, obj.h, -obj.ry] for obj in objs])
     # float32 boxes as the reference's .float() makes them; the IoU kernel reads them from and writes
     # the matrix to pinned host memory (same kernel as iou3d_nms_utils.boxes_iou_bev)
     overlaps_bev = ops.boxes_iou_bev_host(boxes.astype(np.float32), boxes.astype(np.float32))
+    if after_device is not None:
+        after_device()
     mask = np.ones(overlaps_bev.shape[0], dtype=bool)
     if use_score_rank:
         order = np.argsort([obj.score for obj in objs])[::-1]
