@@ -307,6 +307,48 @@ int modest_mask_cluster(modest_ctx *ctx, const float *pts_dev, int n, int stride
                         int32_t *labels_dev, int32_t *n_kept_host, int32_t *n_clusters_host,
                         void *stream);
 
+/* ---- the mask stage of one scan behind one call ------------------------------------------
+ * generate_mask.py:52-88 + clustering_utils.py:119-135: estimate_plane (RANSAC) for the mask and for
+ * filter_labels, above_plane + limit_range mask, affinity graph + DBSCAN, labels[ptc_mask] = ...,
+ * is_valid_cluster on every cluster, relabelling to 0 = background / 1..C -- i.e. everything of
+ * generate_mask_scan up to `labels_filtered`, with no interpreter between the device round trips.
+ * The pieces are the entry points above (modest_plane_prepare, modest_ransac_plane x 2,
+ * modest_mask_cluster, modest_cluster_stats); the scalar glue (plane_from_linear_model, the four
+ * comparisons per cluster incl. numpy's float32 percentile interpolation, the relabel table) is
+ * restated in the library with numpy's rounding.
+ * mt_key624 / mt_pos: numpy RandomState (MT19937) words, advanced by the executed trials of both fits
+ * (pass copies and commit them when info_out[3] == 0).  labels_out [host] (n) int64 = the
+ * `labels_filtered` array; plane1_out / plane2_out [host] (4) f64.
+ * info_out[8]: {kept rows, DBSCAN clusters, largest final label, status, candidates of fit 1, of fit 2,
+ * trials of fit 1, of fit 2}.  status != 0: nothing was committed, take the host path --
+ * SMALL_SET (a candidate set of <= 300 points: sklearn samples those with another method),
+ * NO_CONSENSUS, DEGENERATE (consensus set without a unique plane), TOO_FEW_KEPT (sklearn's
+ * kneighbors raises).                                                                          */
+typedef struct modest_mask_params {
+    float max_hs1, range1[4];        /* plane_estimate.max_hs, .range {xlo, xhi, ylo, yhi}           */
+    float max_hs2, range2[4];        /* filter_labels' hard-coded second fit (clustering_utils.py:126) */
+    double offset;                   /* plane_estimate.offset                                        */
+    int32_t use_only_range;
+    double only_range[4];            /* above_plane only_range                                       */
+    double limit_range[4];
+    int32_t neighbor_type, affinity_type, k_neighbors, min_samples;
+    double radius, eps;
+    int32_t min_points;              /* filtering.*                                                  */
+    double max_min_height, min_max_height;
+    double quantile;                 /* np.true_divide(percentile, np.float32(100)) as a double      */
+    float min_percentile_pp_score;
+    int32_t max_trials, batch;       /* RANSACRegressor defaults: 100; trials per device round trip  */
+    double stop_probability;
+} modest_mask_params;
+#define MODEST_STAGE_SMALL_SET 1
+#define MODEST_STAGE_NO_CONSENSUS 2
+#define MODEST_STAGE_DEGENERATE 3
+#define MODEST_STAGE_TOO_FEW_KEPT 4
+int modest_mask_stage(modest_ctx *ctx, const float *pts_dev, int n, int stride, const float *pp_dev,
+                      const modest_mask_params *params, uint32_t *mt_key624, int32_t *mt_pos,
+                      double *plane1_out, double *plane2_out, int64_t *labels_out, int32_t *info_out,
+                      void *stream);
+
 /* ---- a14 filter_labels / is_valid_cluster statistics ------------------
  * (utils/clustering_utils.py:94-135).  For each label c in [0, n_clusters):
  * out[c*6 + {0: member count, 1: min, 2: max signed distance to `plane`

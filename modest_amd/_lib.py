@@ -54,6 +54,7 @@ SIGNATURES = {
                                       VP, VP]),
     "modest_mt19937_triplets": (C.c_int, [VP, VP, C.c_uint32, C.c_int, VP]),
     "modest_plane_prepare": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP]),
+    "modest_mask_stage": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "modest_mask_cluster": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_double, VP, VP, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, VP, VP, VP, VP]),
     "modest_cluster_stats": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, C.c_double, VP, VP]),

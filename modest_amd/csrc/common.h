@@ -30,6 +30,12 @@ struct modest_ctx {
     unsigned *zwords;
     size_t zwords_count;
     int zwords_dirty;
+    // buffers of the per-scan driver (scan_driver.hip) that live across its sub-calls, which carve their
+    // own temporaries from `scratch` / `pinned` at offset 0: grow-only, device and pinned host
+    char *hold;
+    size_t hold_bytes;
+    char *hold_pinned;
+    size_t hold_pinned_bytes;
     // ring of pinned staging slots for small per-call tables that are copied to the device
     // asynchronously (frame descriptors of modest_pp_score_frames): a slot is reused only after the
     // event recorded behind its copy has completed
@@ -83,6 +89,7 @@ void modest_set_error(const char *fmt, ...);
 // Ensure the context arena holds at least `bytes`; returns 0 or error code.
 int modest_ctx_reserve(modest_ctx *ctx, size_t bytes);
 int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes);
+int modest_ctx_reserve_hold(modest_ctx *ctx, size_t dev_bytes, size_t pinned_bytes);
 
 // Bump allocator over the arena (256-byte aligned carves).
 struct Arena {

@@ -72,6 +72,10 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->zwords = nullptr;
     c->zwords_count = 0;
     c->zwords_dirty = 0;
+    c->hold = nullptr;
+    c->hold_bytes = 0;
+    c->hold_pinned = nullptr;
+    c->hold_pinned_bytes = 0;
     for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
         c->stage[i] = nullptr;
         c->stage_bytes[i] = 0;
@@ -89,6 +93,8 @@ extern "C" int modest_ctx_destroy(modest_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->cstate) (void)hipFree(ctx->cstate);
     if (ctx->zwords) (void)hipFree(ctx->zwords);
+    if (ctx->hold) (void)hipFree(ctx->hold);
+    if (ctx->hold_pinned) (void)hipHostFree(ctx->hold_pinned);
     for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
         if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
@@ -163,6 +169,32 @@ int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes) {
     MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     ctx->pinned = static_cast<char *>(p);
     ctx->pinned_bytes = want;
+    return MODEST_OK;
+}
+
+int modest_ctx_reserve_hold(modest_ctx *ctx, size_t dev_bytes, size_t pinned_bytes) {
+    if (dev_bytes > ctx->hold_bytes) {
+        MODEST_HIP_CHECK(hipDeviceSynchronize());
+        if (ctx->hold) MODEST_HIP_CHECK(hipFree(ctx->hold));
+        ctx->hold = nullptr;
+        ctx->hold_bytes = 0;
+        const size_t want = dev_bytes + dev_bytes / 4 + (1u << 20);
+        void *p = nullptr;
+        MODEST_HIP_CHECK(hipMalloc(&p, want));
+        ctx->hold = static_cast<char *>(p);
+        ctx->hold_bytes = want;
+    }
+    if (pinned_bytes > ctx->hold_pinned_bytes) {
+        MODEST_HIP_CHECK(hipDeviceSynchronize());
+        if (ctx->hold_pinned) MODEST_HIP_CHECK(hipHostFree(ctx->hold_pinned));
+        ctx->hold_pinned = nullptr;
+        ctx->hold_pinned_bytes = 0;
+        const size_t want = pinned_bytes + pinned_bytes / 4 + (64u << 10);
+        void *p = nullptr;
+        MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        ctx->hold_pinned = static_cast<char *>(p);
+        ctx->hold_pinned_bytes = want;
+    }
     return MODEST_OK;
 }
 

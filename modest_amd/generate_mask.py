@@ -47,25 +47,23 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     pe = args.plane_estimate
     ptc_dev = to_device(ptc) if ptc_dev is None else ptc_dev   # (N,4) float32 resident copy
     pp_dev = to_device(pp_score) if pp_dev is None else pp_dev
-    # both ground fits of the scan (here and in filter_labels) need their candidates and MAD
-    # thresholds before any random draw: selected and computed together, one launch for the two MADs
-    prep = prepare_planes(ptc_dev, [(pe.max_hs, pe.range), FILTER_PLANE_SPEC]) if planes is None else (None, None)
-    plane = planes[0] if planes is not None else estimate_plane(
-        ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state, prepared=prep[0])
     if args.clustering.method != "DBSCAN":
         raise NotImplementedError(args.clustering.method)
     g = args.graph
     if g.neighbor_type not in ops.GRAPH_TYPES or g.affinity_type not in ops.AFFINITY_TYPES:
         raise NotImplementedError(f"graph {g.neighbor_type}/{g.affinity_type} (SURVEY.md §8f-3)")
-    # mask, graph, DBSCAN and labels[ptc_mask] = ... in one device call (generate_mask.py:57-88)
-    labels_dev, n_kept = ops.mask_cluster(ptc_dev, pp_dev, plane, pe.offset, pe.range, args.limit_range,
-                                          g.n_neighbors, g.radius, args.clustering.DBSCAN.eps,
-                                          args.clustering.DBSCAN.min_samples, neighbor_type=g.neighbor_type,
-                                          affinity_type=g.affinity_type)
-    labels = labels_dev.cpu().numpy().astype(int)
-    labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
-                                    plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
-                                    pp_dev=pp_dev, labels_dev=labels_dev, plane_prepared=prep[1], **args.filtering)
+    staged = None
+    if planes is None and NATIVE_STAGE and ptc.shape[0] >= 1:
+        rs = np.random.mtrand._rand if random_state is None else random_state
+        if isinstance(rs, np.random.RandomState) and rs.get_state()[0] == "MT19937":
+            # both ground fits, mask, graph + DBSCAN, cluster statistics, validity rules and the relabelling
+            # behind one library call (no interpreter between the device round trips of these steps)
+            staged = ops.mask_stage(ptc_dev, pp_dev, _stage_params(args), rs)
+    if staged is not None:
+        labels_filtered, plane, _, info = staged
+        n_kept = int(info[0])
+    else:
+        labels_filtered, plane, n_kept = _mask_stage_host(ptc, pp_score, args, random_state, planes, ptc_dev, pp_dev)
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
     order, cuts = members_sorted(labels_filtered, n_lab)
     # rect-frame points: the clusters' rows on the host (per-cluster numpy arithmetic of get_obj), the whole
@@ -82,6 +80,64 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     objs = [obj for obj, k in zip(cand, keep) if k]
     labels_filtered = relabel_after_drop(labels_filtered, n_lab, keep) if n_lab else compact_labels(labels_filtered)
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
+
+
+NATIVE_STAGE = True   # tests switch it off to compare the library's stage driver with the Python statement
+
+
+def _stage_params(args) -> "ops.MaskParams":
+    """the config keys of the stage as the library's parameter block (cached per config object)"""
+    cached = _PARAMS.get(id(args))
+    if cached is not None and cached[0] is args:
+        return cached[1]
+    pe, g, f = args.plane_estimate, args.graph, args.filtering
+    P = ops.MaskParams()
+    P.max_hs1 = pe.max_hs
+    P.range1[:] = [pe.range[0][0], pe.range[0][1], pe.range[1][0], pe.range[1][1]]
+    P.max_hs2 = FILTER_PLANE_SPEC[0]
+    r2 = FILTER_PLANE_SPEC[1]
+    P.range2[:] = [r2[0][0], r2[0][1], r2[1][0], r2[1][1]]
+    P.offset = pe.offset
+    P.use_only_range = 0 if pe.range is None else 1
+    if pe.range is not None:
+        P.only_range[:] = [pe.range[0][0], pe.range[0][1], pe.range[1][0], pe.range[1][1]]
+    lim = np.asarray(args.limit_range, dtype=np.float64).reshape(4)
+    P.limit_range[:] = list(lim)
+    P.neighbor_type, P.affinity_type = ops.GRAPH_TYPES[g.neighbor_type], ops.AFFINITY_TYPES[g.affinity_type]
+    P.k_neighbors, P.min_samples = int(g.n_neighbors), int(args.clustering.DBSCAN.min_samples)
+    P.radius, P.eps = float(g.radius), float(args.clustering.DBSCAN.eps)
+    P.min_points = int(f.get("min_points", 10))
+    P.max_min_height, P.min_max_height = float(f.get("max_min_height", 4)), float(f.get("min_max_height", 0))
+    P.quantile = float(np.true_divide(f.get("percentile", 10), np.float32(100)))
+    P.min_percentile_pp_score = float(np.float32(f.get("min_percentile_pp_score", 0.7)))
+    P.max_trials, P.batch, P.stop_probability = 100, 48, 0.99
+    _PARAMS.clear()
+    _PARAMS[id(args)] = (args, P)
+    return P
+
+
+_PARAMS = {}
+
+
+def _mask_stage_host(ptc, pp_score, args, random_state, planes, ptc_dev, pp_dev):
+    """The stage as separate calls with the interpreter in between (also: injected planes, integer
+    seeds, the rare inputs the library hands back).  Returns (labels_filtered, plane, n_kept)."""
+    pe, g = args.plane_estimate, args.graph
+    # both ground fits of the scan (here and in filter_labels) need their candidates and MAD
+    # thresholds before any random draw: selected and computed together, one launch for the two MADs
+    prep = prepare_planes(ptc_dev, [(pe.max_hs, pe.range), FILTER_PLANE_SPEC]) if planes is None else (None, None)
+    plane = planes[0] if planes is not None else estimate_plane(
+        ptc_dev, max_hs=pe.max_hs, ptc_range=pe.range, random_state=random_state, prepared=prep[0])
+    # mask, graph, DBSCAN and labels[ptc_mask] = ... in one device call (generate_mask.py:57-88)
+    labels_dev, n_kept = ops.mask_cluster(ptc_dev, pp_dev, plane, pe.offset, pe.range, args.limit_range,
+                                          g.n_neighbors, g.radius, args.clustering.DBSCAN.eps,
+                                          args.clustering.DBSCAN.min_samples, neighbor_type=g.neighbor_type,
+                                          affinity_type=g.affinity_type)
+    labels = labels_dev.cpu().numpy().astype(int)
+    labels_filtered = filter_labels(ptc, pp_score, labels, random_state=random_state,
+                                    plane=None if planes is None else planes[1], ptc_dev=ptc_dev,
+                                    pp_dev=pp_dev, labels_dev=labels_dev, plane_prepared=prep[1], **args.filtering)
+    return labels_filtered, plane, n_kept
 
 
 def _pooled(args, rank, ws, local):

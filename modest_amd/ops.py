@@ -378,6 +378,48 @@ def mask_cluster(pts: torch.Tensor, pp: torch.Tensor, plane: np.ndarray, offset:
     return labels, int(n_kept.value)
 
 
+class MaskParams(C.Structure):
+    """modest_mask_params (include/modest_hip.h)"""
+    _fields_ = [("max_hs1", C.c_float), ("range1", C.c_float * 4), ("max_hs2", C.c_float), ("range2", C.c_float * 4),
+                ("offset", C.c_double), ("use_only_range", C.c_int32), ("only_range", C.c_double * 4),
+                ("limit_range", C.c_double * 4), ("neighbor_type", C.c_int32), ("affinity_type", C.c_int32),
+                ("k_neighbors", C.c_int32), ("min_samples", C.c_int32), ("radius", C.c_double), ("eps", C.c_double),
+                ("min_points", C.c_int32), ("max_min_height", C.c_double), ("min_max_height", C.c_double),
+                ("quantile", C.c_double), ("min_percentile_pp_score", C.c_float), ("max_trials", C.c_int32),
+                ("batch", C.c_int32), ("stop_probability", C.c_double)]
+
+
+STAGE_STATUS = {1: "small candidate set", 2: "no consensus set", 3: "degenerate consensus set", 4: "too few kept rows"}
+
+
+def mask_stage(pts: torch.Tensor, pp: torch.Tensor, params: MaskParams, rs: np.random.RandomState,
+               ctx: Optional[Context] = None):
+    """generate_mask_scan up to ``labels_filtered`` behind one library call (modest_mask_stage).
+    Returns None when the library hands the scan back to the host statement (rare inputs: see
+    STAGE_STATUS; ``rs`` is untouched then), else (labels_filtered (n,) int64, plane1, plane2, info):
+    ``rs`` has been advanced by the executed RANSAC trials of both fits."""
+    lib = load()
+    _dev(pts, torch.float32, "pts")
+    _dev(pp, torch.float32, "pp")
+    n = pts.shape[0]
+    assert pp.shape[0] == n and n >= 1
+    st = rs.get_state()
+    assert st[0] == "MT19937"
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(st[2]))
+    plane1, plane2 = np.zeros(4, dtype=np.float64), np.zeros(4, dtype=np.float64)
+    labels = np.empty(n, dtype=np.int64)
+    info = np.zeros(8, dtype=np.int32)
+    c = _ctx(ctx, pts)
+    check(lib.modest_mask_stage(c.handle, pts.data_ptr(), n, pts.shape[1], pp.data_ptr(), C.byref(params), _np_ptr(key),
+                                C.byref(pos), _np_ptr(plane1), _np_ptr(plane2), _np_ptr(labels), _np_ptr(info),
+                                _stream()), "modest_mask_stage")
+    if info[3] != 0:
+        return None
+    rs.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return labels, plane1, plane2, info
+
+
 def cluster_stats(pts: torch.Tensor, pp: torch.Tensor, labels: torch.Tensor, n_clusters: int,
                   plane: np.ndarray, quantile: float, ctx: Optional[Context] = None) -> np.ndarray:
     """Per-cluster (count, min dist, max dist, a, b, gamma) for is_valid_cluster; (C,6) float64 host."""

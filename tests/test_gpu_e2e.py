@@ -180,6 +180,69 @@ def test_scan_pipeline_equals_oracle_on_synthetic_scans(gpu, case):
     assert text == ref_text
 
 
+def test_library_stage_driver_equals_python_statement(gpu):
+    """modest_mask_stage (both RANSAC fits, mask, graph + DBSCAN, cluster statistics, validity rules and
+    relabelling behind one library call) against the Python statement of the same steps: labels, boxes,
+    label text AND the generator state after the scan (the CLI keeps one stream per scan; the reference
+    its global one) -- Lyft and nuScenes-style configurations, several scans and seeds, the global
+    generator, and an input the library hands back (a tiny scan)."""
+    import os
+    import tempfile
+    import torch
+    from modest_amd import config, generate_mask as gm, synth
+    from modest_amd.gen_label_files import gen_label_scan
+    from modest_amd.utils import kitti_util
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+    largs = config.compose("generate_label_files", ["data_root=/unused"])
+    cfgs = [config.compose("generate_mask", ["data_root=/unused"]),
+            config.compose("generate_mask", ["data_root=/unused", "plane_estimate.max_hs=-1.3", "filtering.percentile=10",
+                                             "graph.n_neighbors=40", "limit_range=[[0,70],[-40,40]]"])]
+    rng = np.random.default_rng(0)
+    n_boxes = 0
+    for k in range(6):
+        sc = synth.make_scan(100 + k, n_live=int(rng.choice([4000, 12000, 30000])), n_trav=2, n_frames=1)
+        raw = sc.live_raw
+        pp = np.clip(0.45 + 0.5 * np.sin(raw[:, 0] * 0.3) + rng.normal(0, 0.05, len(raw)), 0, 1).astype(np.float32)
+        dev, ppd = torch.from_numpy(raw).to(gpu), torch.from_numpy(pp).to(gpu)
+        margs = cfgs[k % 2]
+        out = []
+        for native in (True, False):
+            gm.NATIVE_STAGE = native
+            try:
+                if k == 5:    # the reference's own mode: numpy's global generator
+                    np.random.seed(77)
+                    rs = None
+                else:
+                    rs = np.random.RandomState(40 + k)
+                labels, objs, info = gm.generate_mask_scan(raw, pp, calib, margs, random_state=rs, ptc_dev=dev, pp_dev=ppd)
+                text, _ = gen_label_scan(objs, calib, largs)
+                st = (np.random.mtrand._rand if rs is None else rs).get_state()
+                out.append((labels, [(*o.t, o.l, o.w, o.h, o.ry, o.volume) for o in objs], text, info["plane"], st))
+            finally:
+                gm.NATIVE_STAGE = True
+        a, b = out
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], k
+        assert np.array_equal(a[3], b[3])
+        assert np.array_equal(a[4][1], b[4][1]) and a[4][2:] == b[4][2:], k
+        n_boxes += len(a[1])
+    assert n_boxes >= 10
+    # a scan with fewer ground candidates than sklearn's tracking selection needs: handed back, same result
+    sc = synth.make_scan(7, n_live=700, n_trav=2, n_frames=1)
+    raw, pp = sc.live_raw, np.full(len(sc.live_raw), 0.2, dtype=np.float32)
+    res = []
+    for native in (True, False):
+        gm.NATIVE_STAGE = native
+        try:
+            res.append(gm.generate_mask_scan(raw, pp, calib, cfgs[0], random_state=np.random.RandomState(1))[0])
+        except ValueError as e:
+            res.append(str(e))
+        finally:
+            gm.NATIVE_STAGE = True
+    assert (isinstance(res[0], str) and res[0] == res[1]) or np.array_equal(res[0], res[1])
+
+
 def test_bench_contract_json_line(gpu):
     """`python bench.py` prints exactly one JSON line with the driver's contract fields, the roofline
     object of the PP stage and the cpu_baseline object (small sizes, two helper processes)."""
@@ -207,7 +270,8 @@ def test_bench_contract_json_line(gpu):
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["launches_timed"] == 16 and rf["isolated"]["kernel_ms"] > 0
     assert d["config"]["host_processes_per_gpu"] == 2 and d["config"]["rccl_world_size"] == 1
-    assert "steady_state" in d and d["steady_state"] is None   # 8 steps per helper: the pool was used whole
+    # 8 steps per helper: the pool was used whole; fewer than 24 per helper: the steady-state figure is added
+    assert d["steady_state"]["host_processes_per_gpu"] == 2 and d["steady_state"]["value"] > 0
     assert d["config"]["history_input"].startswith("frame store")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
