@@ -1152,11 +1152,15 @@ extern "C" int modest_cluster_dbscan_ex(modest_ctx *ctx, const float *xyz, const
                         min_samples, labels, kth_d2, n_clusters, stream, nullptr);
 }
 
-extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
-                                   const double *plane4, double offset, const double *only_range4,
-                                   const double *limit_range4, int neighbor_type, int affinity_type, int k_neighbors,
-                                   double radius, double eps, int min_samples, int32_t *labels, int32_t *n_kept,
-                                   int32_t *n_clusters, void *stream_) {
+// phase & 1: enqueue the mask / compaction / cell-count kernel (no synchronise); phase & 2: continue with
+// the kept count (after the caller's synchronise, or this function's own when both bits are set).  The
+// kept count sits at byte 192 of the context's pinned block (clear of a RANSAC refit's 128 bytes: the two
+// may be in flight together, scan_driver.hip).
+int modest_mask_cluster_phase(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
+                              const double *plane4, double offset, const double *only_range4,
+                              const double *limit_range4, int neighbor_type, int affinity_type, int k_neighbors,
+                              double radius, double eps, int min_samples, int32_t *labels, int32_t *n_kept,
+                              int32_t *n_clusters, void *stream_, int phase) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n >= 0 && (stride == 3 || stride == 4), "bad n/stride");
     MODEST_REQUIRE(plane4 && limit_range4 && n_kept, "NULL argument");
@@ -1167,8 +1171,10 @@ extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int
                    "affinity_type must be l1, exp or 3d_l2_distance");
     MODEST_REQUIRE(affinity_type != MODEST_AFFINITY_L2_4D || stride == 4,
                    "3d_l2_distance needs the intensity column of the scan rows");
-    *n_kept = 0;
-    if (n_clusters) *n_clusters = 0;
+    if (phase & 1) {
+        *n_kept = 0;
+        if (n_clusters) *n_clusters = 0;
+    }
     if (n == 0) return MODEST_OK;
     MODEST_REQUIRE(pts && pp && labels, "NULL buffer");
     hipStream_t stream = as_stream(stream_);
@@ -1178,18 +1184,23 @@ extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int
     const size_t own = arena_sz((size_t)n * 12) + arena_sz((size_t)n * 4) + arena_sz(sizeof(CGrid));
     int rc = modest_ctx_reserve(ctx, own + cluster_arena_bytes(n, neighbor_type, k_neighbors));
     if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, 64);
+    rc = modest_ctx_reserve_pinned(ctx, 256);
     if (rc) return rc;
     Arena A(ctx->scratch);
     float *kept = A.take<float>((size_t)n * 3);
     int *kept_idx = A.take<int>(n);
     CGrid *g = A.take<CGrid>(1);
-    int *h_kept = reinterpret_cast<int *>(ctx->pinned + 32);   // pinned: there after the sync, no copy
+    int *h_kept = reinterpret_cast<int *>(ctx->pinned + 192);   // pinned: there after the sync, no copy
     unsigned *cnt = nullptr;
     static_assert(CG_CELLS == (int)MODEST_ZW_CELLS, "persistent cell counters");
-    rc = modest_ctx_zero_words(ctx, stream, &cnt);
-    if (rc) return rc;
-    ctx->zwords_dirty = 1;   // until the cell scan behind the counters has been enqueued
+    if (phase & 1) {
+        rc = modest_ctx_zero_words(ctx, stream, &cnt);
+        if (rc) return rc;
+        ctx->zwords_dirty = 1;   // until the cell scan behind the counters has been enqueued
+        ctx->zwords_live = 1;    // ... and nobody may clear them in between
+    } else {
+        cnt = ctx->zwords;
+    }
     MaskParams P;
     mask_params_fill(P, plane4, offset, only_range4, limit_range4);
     // the kept rows lie inside limit_range: a fixed grid around it needs no bounding-box pass (cells
@@ -1202,13 +1213,17 @@ extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int
     G.ox = cx - 0.5 * CG * c;
     G.oy = cy - 0.5 * CG * c;
     G.inv_c = 1.0 / c;
-    const int nblk = (n + 1023) / 1024;
-    unsigned long long *state = nullptr;
-    rc = modest_ctx_compact_state(ctx, (size_t)nblk, stream, &state);
-    if (rc) return rc;
-    mask_count_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, P, G, g, cnt, labels, kept, kept_idx, state, h_kept);
-    MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    if (phase & 1) {
+        const int nblk = (n + 1023) / 1024;
+        unsigned long long *state = nullptr;
+        rc = modest_ctx_compact_state(ctx, (size_t)nblk, stream, &state);
+        if (rc) return rc;
+        mask_count_kernel<<<nblk, 1024, 0, stream>>>(pts, n, stride, P, G, g, cnt, labels, kept, kept_idx, state, h_kept);
+        MODEST_HIP_CHECK(hipGetLastError());
+    }
+    if (!(phase & 2)) return MODEST_OK;
+    if (phase & 1) MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    ctx->zwords_live = 0;
     const int m = *h_kept;
     *n_kept = m;
     if (m == 0) {
@@ -1225,6 +1240,16 @@ extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int
                       labels, nullptr, n_clusters, stream, &pre);
     if (rc == MODEST_OK) ctx->zwords_dirty = 0;
     return rc;
+}
+
+extern "C" int modest_mask_cluster(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
+                                   const double *plane4, double offset, const double *only_range4,
+                                   const double *limit_range4, int neighbor_type, int affinity_type, int k_neighbors,
+                                   double radius, double eps, int min_samples, int32_t *labels, int32_t *n_kept,
+                                   int32_t *n_clusters, void *stream_) {
+    return modest_mask_cluster_phase(ctx, pts, n, stride, pp, plane4, offset, only_range4, limit_range4, neighbor_type,
+                                     affinity_type, k_neighbors, radius, eps, min_samples, labels, n_kept, n_clusters,
+                                     stream_, 3);
 }
 
 extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const float *pp, int n,

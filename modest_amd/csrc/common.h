@@ -30,6 +30,7 @@ struct modest_ctx {
     unsigned *zwords;
     size_t zwords_count;
     int zwords_dirty;
+    int zwords_live;   // the cell counters hold a scan's counts (between the two phases of the fused mask call): never clear
     // buffers of the per-scan driver (scan_driver.hip) that live across its sub-calls, which carve their
     // own temporaries from `scratch` / `pinned` at offset 0: grow-only, device and pinned host
     char *hold;
@@ -90,6 +91,21 @@ void modest_set_error(const char *fmt, ...);
 int modest_ctx_reserve(modest_ctx *ctx, size_t bytes);
 int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes);
 int modest_ctx_reserve_hold(modest_ctx *ctx, size_t dev_bytes, size_t pinned_bytes);
+
+// Two-phase forms of three blocking entry points (phase & 1: enqueue, no synchronise; phase & 2: read the
+// results after a synchronise -- the caller's, or the function's own when both bits are set).  The per-scan
+// driver keeps a RANSAC refit in flight together with the next trial batch or the mask kernel; their result
+// areas in the context's pinned block are disjoint (refit [0,128), kept count [192,196), batch [576,...)).
+int modest_ransac_trials_phase(modest_ctx *ctx, const float *cand, int n_cand, const int32_t *trip_host, int K,
+                               float *thr_inout, float *models_out, int32_t *n_inliers, double *sse, double *sy,
+                               double *syy, void *stream, int phase);
+int modest_ransac_refit_phase(modest_ctx *ctx, const float *cand, int n_cand, const float *model_host, float thr,
+                              double *out_model, int32_t *n_inliers, void *stream, int phase);
+int modest_mask_cluster_phase(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
+                              const double *plane4, double offset, const double *only_range4,
+                              const double *limit_range4, int neighbor_type, int affinity_type, int k_neighbors,
+                              double radius, double eps, int min_samples, int32_t *labels, int32_t *n_kept,
+                              int32_t *n_clusters, void *stream, int phase);
 
 // Bump allocator over the arena (256-byte aligned carves).
 struct Arena {

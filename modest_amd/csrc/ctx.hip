@@ -72,6 +72,7 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->zwords = nullptr;
     c->zwords_count = 0;
     c->zwords_dirty = 0;
+    c->zwords_live = 0;
     c->hold = nullptr;
     c->hold_bytes = 0;
     c->hold_pinned = nullptr;
@@ -135,7 +136,7 @@ int modest_ctx_zero_words(modest_ctx *ctx, hipStream_t stream, unsigned **out) {
         ctx->zwords_count = words;
         ctx->zwords_dirty = 1;
     }
-    if (ctx->zwords_dirty) {
+    if (ctx->zwords_dirty && !ctx->zwords_live) {
         MODEST_HIP_CHECK(hipMemsetAsync(ctx->zwords, 0, ctx->zwords_count * 4, stream));
         ctx->zwords_dirty = 0;
     }

@@ -10,6 +10,8 @@
 #include "common.h"
 #include "compact.h"
 #include "mask_pred.h"
+#include "ransac_host.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -715,9 +717,13 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
     return MODEST_OK;
 }
 
-extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_cand, const int32_t *trip_host,
-                                    int K, float *thr_inout, float *models_out, int32_t *n_inliers,
-                                    double *sse, double *sy, double *syy, void *stream_) {
+// phase & 1: enqueue (no synchronise); phase & 2: read the results (after the caller's synchronise, or
+// after this function's own when both bits are set).  The results of a batch live in the context's
+// pinned block from byte 576 on (K <= 64), those of a refit in its first 128 bytes: one of each may be
+// in flight on a stream at the same time (scan_driver.hip).
+int modest_ransac_trials_phase(modest_ctx *ctx, const float *cand, int n_cand, const int32_t *trip_host, int K,
+                               float *thr_inout, float *models_out, int32_t *n_inliers, double *sse, double *sy,
+                               double *syy, void *stream_, int phase) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n_cand >= 3 && K >= 1 && K <= 4096, "bad n_cand / K");
     MODEST_REQUIRE(cand && trip_host && thr_inout && models_out && n_inliers, "NULL buffer");
@@ -732,7 +738,7 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     const size_t b_part = arena_sz((size_t)nrows * K * 32);
     int rc = modest_ctx_reserve(ctx, b_models + b_thr + b_part);
     if (rc) return rc;
-    const size_t h_trip = ((size_t)K * 12 + 63) & ~size_t(63);
+    const size_t h_trip = std::max<size_t>(576, ((size_t)K * 12 + 63) & ~size_t(63));   // clear of a refit's 128 bytes
     rc = modest_ctx_reserve_pinned(ctx, h_trip + n_out + n_models + 8);
     if (rc) return rc;
     char *d = ctx->scratch;
@@ -744,9 +750,11 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     double *h_outp = reinterpret_cast<double *>(h_res);
     float *h_models = reinterpret_cast<float *>(h_res + n_out);
     float *h_thr = reinterpret_cast<float *>(h_res + n_out + n_models);
-    for (int i = 0; i < 3 * K; ++i) h_tripp[i] = trip_host[i];
     const bool thr_known = !(*thr_inout < 0.f);
     const float thr_val = *thr_inout;
+    if (phase & 1) {
+    if (K > TRIP_MAX)
+        for (int i = 0; i < 3 * K; ++i) h_tripp[i] = trip_host[i];
     if (!thr_known) {   // residual threshold = MAD of the candidates, computed on the device
         MadArgs A{};
         A.cand[0] = cand;
@@ -774,7 +782,9 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
                                                                 thr_dst);
     }
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    if (!(phase & 2)) return MODEST_OK;
+    if (phase & 1) MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     *thr_inout = thr_known ? thr_val : h_thr[1];
     for (int k = 0; k < K; ++k) {
         n_inliers[k] = (int32_t)h_outp[4 * k];
@@ -788,12 +798,18 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
     return MODEST_OK;
 }
 
-extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_cand,
-                                   const float *model_host, float thr, double *out_model,
-                                   int32_t *n_inliers, void *stream_) {
+extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_cand, const int32_t *trip_host,
+                                    int K, float *thr_inout, float *models_out, int32_t *n_inliers,
+                                    double *sse, double *sy, double *syy, void *stream_) {
+    return modest_ransac_trials_phase(ctx, cand, n_cand, trip_host, K, thr_inout, models_out, n_inliers, sse, sy, syy,
+                                      stream_, 3);
+}
+
+int modest_ransac_refit_phase(modest_ctx *ctx, const float *cand, int n_cand, const float *model_host, float thr,
+                              double *out_model, int32_t *n_inliers, void *stream_, int phase) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
     MODEST_REQUIRE(n_cand >= 1, "bad n_cand");
-    MODEST_REQUIRE(cand && model_host && out_model, "NULL buffer");
+    MODEST_REQUIRE(cand && model_host && (out_model || !(phase & 2)), "NULL buffer");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     const int nb = (n_cand + SCORE_THREADS - 1) / SCORE_THREADS;
@@ -801,15 +817,20 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     if (rc) return rc;
     rc = modest_ctx_reserve_pinned(ctx, 16 * 8);
     if (rc) return rc;
-    unsigned *zw = nullptr;
-    rc = modest_ctx_zero_words(ctx, stream, &zw);
-    if (rc) return rc;
     double *dp = reinterpret_cast<double *>(ctx->scratch);
     const float c0 = model_host[0], c1 = model_host[1], b = model_host[2];
     double *h = reinterpret_cast<double *>(ctx->pinned);
-    refit_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, modest_tickets(zw), h);   // totals straight into pinned host memory
-    MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    if (phase & 1) {
+        // (not in the read-back phase: a context whose cell counters are live -- between the two phases of
+        // modest_mask_cluster_phase -- is marked dirty, and this call would clear them)
+        unsigned *zw = nullptr;
+        rc = modest_ctx_zero_words(ctx, stream, &zw);
+        if (rc) return rc;
+        refit_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, modest_tickets(zw), h);   // totals straight into pinned host memory
+        MODEST_HIP_CHECK(hipGetLastError());
+    }
+    if (!(phase & 2)) return MODEST_OK;
+    if (phase & 1) MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     const double cnt = h[0];
     const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
     const double mx = h[1] * inv, my = h[2] * inv, mzs = h[3] * inv;   // mzs: mean of z - b
@@ -830,82 +851,14 @@ extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_can
     return MODEST_OK;
 }
 
+extern "C" int modest_ransac_refit(modest_ctx *ctx, const float *cand, int n_cand,
+                                   const float *model_host, float thr, double *out_model,
+                                   int32_t *n_inliers, void *stream_) {
+    return modest_ransac_refit_phase(ctx, cand, n_cand, model_host, thr, out_model, n_inliers, stream_, 3);
+}
+
 // ---- the RANSAC driver: sklearn's trial loop on the host side of the library --------------------
-// numpy's legacy generator (RandomState = MT19937) as sklearn's sample_without_replacement consumes
-// it: for n_samples > 300 ("tracking selection") one trial = RandomState.randint(n) until three
-// distinct indices are found, and randint(n) is the masked rejection `next_uint32 & mask` until
-// the value is < n (numpy/random/_bounded_integers: use_masked, 32-bit range).
-namespace {
-struct Mt19937 {
-    uint32_t key[624];
-    int pos;
-    void refill() {
-        const uint32_t U = 0x80000000u, L = 0x7fffffffu, A = 0x9908b0dfu;
-        int kk = 0;
-        for (; kk < 624 - 397; ++kk) {
-            const uint32_t y = (key[kk] & U) | (key[kk + 1] & L);
-            key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
-        }
-        for (; kk < 623; ++kk) {
-            const uint32_t y = (key[kk] & U) | (key[kk + 1] & L);
-            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
-        }
-        const uint32_t y = (key[623] & U) | (key[0] & L);
-        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
-        pos = 0;
-    }
-    uint32_t next32() {
-        if (pos >= 624) refill();
-        uint32_t y = key[pos++];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
-    }
-    uint32_t randint(uint32_t n) {   // RandomState.randint(n), 1 <= n <= 2^32 - 1
-        const uint32_t rng = n - 1;
-        if (rng == 0) return 0;
-        uint32_t mask = rng;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        uint32_t v;
-        while ((v = next32() & mask) > rng) {
-        }
-        return v;
-    }
-    void triplet(uint32_t n, int32_t *t) {   // sample_without_replacement(n, 3), tracking selection
-        int have = 0;
-        while (have < 3) {
-            const int32_t j = (int32_t)randint(n);
-            bool dup = false;
-            for (int q = 0; q < have; ++q) dup = dup || t[q] == j;
-            if (!dup) t[have++] = j;
-        }
-    }
-};
-
-double dynamic_max_trials(int n_inliers, int n_samples, double probability) {   // sklearn _dynamic_max_trials, min_samples = 3
-    const double eps = 2.220446049250313e-16;
-    const double ratio = (double)n_inliers / (double)n_samples;
-    const double nom = fmax(eps, 1.0 - probability);
-    const double denom = fmax(eps, 1.0 - pow(ratio, 3.0));
-    if (nom == 1.0) return 0.0;
-    if (denom == 1.0) return INFINITY;
-    return fabs(ceil(log(nom) / log(denom)));
-}
-
-double r2_from_sums(int n, double sse, double sy, double syy) {   // r2_score over the inliers
-    if (n < 2) return NAN;
-    const double den = syy - sy * sy / n;
-    if (den <= 0.0) return sse == 0.0 ? 1.0 : 0.0;
-    return 1.0 - sse / den;
-}
-}  // namespace
-
+// (generator, accept rule and the fit's state machine: ransac_host.h)
 extern "C" int modest_mt19937_triplets(uint32_t *key624, int32_t *pos, uint32_t n_population, int n_trials,
                                        int32_t *triplets_out) {
     MODEST_REQUIRE(key624 && pos && triplets_out, "NULL argument");
@@ -931,60 +884,34 @@ extern "C" int modest_ransac_plane(modest_ctx *ctx, const float *cand, int n_can
     Mt19937 g;
     memcpy(g.key, key624, sizeof(g.key));
     g.pos = *pos;
-    int n_best = 1, n_trials = 0;
-    double score_best = -INFINITY, limit = (double)max_trials;
-    bool have = false;
-    float best[3] = {0, 0, 0};
-    std::vector<int32_t> trip((size_t)3 * batch), n_in(batch);
-    std::vector<float> models((size_t)3 * batch);
-    std::vector<double> sse(batch), sy(batch), syy(batch);
+    hipStream_t stream = as_stream(stream_);
+    RansacFit fit;
+    fit.init(ctx, cand, n_cand, thr, &g, max_trials, stop_probability, batch, stream_);
+    fit.triplets_out = triplets_out;
     *status_out = 0;
-    while ((double)n_trials < limit) {
-        const int nb = (int)fmin((double)batch, limit - (double)n_trials);
-        const Mt19937 before = g;
-        for (int k = 0; k < nb; ++k) g.triplet((uint32_t)n_cand, trip.data() + 3 * k);
-        float t = thr;
-        int rc = modest_ransac_trials(ctx, cand, n_cand, trip.data(), nb, &t, models.data(), n_in.data(), sse.data(),
-                                      sy.data(), syy.data(), stream_);
+    while (!fit.done()) {
+        int rc = fit.enqueue_batch();
         if (rc) return rc;
-        int used = 0;
-        for (int k = 0; k < nb; ++k) {
-            if (!((double)n_trials < limit)) break;
-            ++n_trials;
-            ++used;
-            const int nk = n_in[k];
-            if (nk < n_best) continue;
-            const double score = r2_from_sums(nk, sse[k], sy[k], syy[k]);
-            if (nk == n_best && score < score_best) continue;
-            n_best = nk;
-            score_best = score;
-            have = true;
-            for (int q = 0; q < 3; ++q) best[q] = models[3 * k + q];
-            limit = fmin(limit, dynamic_max_trials(n_best, n_cand, stop_probability));
-        }
-        if (triplets_out)
-            for (int q = 0; q < 3 * used; ++q) triplets_out[3 * (n_trials - used) + q] = trip[q];
-        if (used < nb) {   // the caller's stream advances by exactly the executed trials
-            g = before;
-            int32_t scratch[3];
-            for (int k = 0; k < used; ++k) g.triplet((uint32_t)n_cand, scratch);
-        }
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        rc = fit.finish_batch();
+        if (rc) return rc;
     }
     memcpy(key624, g.key, sizeof(g.key));
     *pos = g.pos;
-    *n_trials_out = n_trials;
-    if (!have) {
+    *n_trials_out = fit.n_trials;
+    if (!fit.have) {
         *status_out = 1;   // no consensus set: sklearn raises ValueError
         return MODEST_OK;
     }
-    for (int q = 0; q < 3; ++q) best_model_out[q] = best[q];
+    for (int q = 0; q < 3; ++q) best_model_out[q] = fit.best[q];
+    int rc = fit.enqueue_refit();
+    if (rc) return rc;
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     int32_t nfin = 0;
-    const int rc = modest_ransac_refit(ctx, cand, n_cand, best, thr, model64_out, &nfin, stream_);
+    bool degenerate = false;
+    rc = fit.finish_refit(model64_out, &nfin, &degenerate);
     if (n_inliers_out) *n_inliers_out = nfin;
-    if (rc == MODEST_ERR_ARG) {
-        *status_out = 2;   // degenerate consensus set: the caller takes the minimum-norm fit on the host
-        return MODEST_OK;
-    }
+    if (degenerate) *status_out = 2;   // the caller takes the minimum-norm fit on the host
     return rc;
 }
 

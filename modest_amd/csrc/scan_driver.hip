@@ -5,9 +5,12 @@
 // own entry points (their temporaries come from the context arena at offset 0; what has to live
 // across them -- candidate sets, the scan-sized labels -- sits in the context's hold buffers).
 #include "common.h"
+#include "ransac_host.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
+
+using namespace modest;
 
 namespace {
 
@@ -56,32 +59,74 @@ extern "C" int modest_mask_stage(modest_ctx *ctx, const float *pts, int n, int s
         info_out[3] = MODEST_STAGE_SMALL_SET;
         return MODEST_OK;
     }
-    // 2. the two RANSAC fits, in the order the reference draws from its generator
-    const float *cand[2] = {candA, candB};
-    double *plane_out[2] = {plane1_out, plane2_out};
-    for (int f = 0; f < 2; ++f) {
-        double model64[3];
-        float best[3];
-        int32_t n_trials = 0, n_in = 0, status = 0;
-        rc = modest_ransac_plane(ctx, cand[f], n_cand[f], mad[f], mt_key624, mt_pos, P->max_trials, P->stop_probability,
-                                 P->batch, model64, best, nullptr, &n_trials, &n_in, &status, stream_);
-        if (rc) return rc;
-        info_out[6 + f] = n_trials;
-        if (status == 1) {
-            info_out[3] = MODEST_STAGE_NO_CONSENSUS;
-            return MODEST_OK;
-        }
-        if (status == 2) {   // degenerate consensus set: the host statement handles it (never seen on LiDAR scans)
-            info_out[3] = MODEST_STAGE_DEGENERATE;
-            return MODEST_OK;
-        }
-        plane_from_model(model64, plane_out[f]);
+    // 2. the two RANSAC fits, in the order the reference draws from its generator, and the mask kernel.
+    //    Round trips: [batch A]* , [refit A + first batch B] , [batch B]* , [refit B + mask / compaction /
+    //    cell count with plane A] -- a refit rides along with the next independent launch (their result
+    //    areas in the pinned block are disjoint, common.h).  The pinned block is sized here once: growing
+    //    it between an enqueue and its read-back would free results.
+    rc = modest_ctx_reserve_pinned(ctx, 16384);
+    if (rc) return rc;
+    Mt19937 g;
+    memcpy(g.key, mt_key624, sizeof(g.key));
+    g.pos = *mt_pos;
+    RansacFit A, B;
+    A.init(ctx, candA, n_cand[0], mad[0], &g, P->max_trials, P->stop_probability, P->batch, stream_);
+    B.init(ctx, candB, n_cand[1], mad[1], &g, P->max_trials, P->stop_probability, P->batch, stream_);
+    while (!A.done()) {
+        if ((rc = A.enqueue_batch())) return rc;
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        if ((rc = A.finish_batch())) return rc;
+    }
+    info_out[6] = A.n_trials;
+    if (!A.have) {
+        info_out[3] = MODEST_STAGE_NO_CONSENSUS;
+        return MODEST_OK;
+    }
+    if ((rc = A.enqueue_refit())) return rc;
+    if ((rc = B.enqueue_batch())) return rc;
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    double model64[3];
+    int32_t n_in = 0;
+    bool degenerate = false;
+    if ((rc = A.finish_refit(model64, &n_in, &degenerate))) return rc;
+    if (degenerate) {   // the host statement handles it (never seen on LiDAR scans)
+        info_out[3] = MODEST_STAGE_DEGENERATE;
+        return MODEST_OK;
+    }
+    plane_from_model(model64, plane1_out);
+    if ((rc = B.finish_batch())) return rc;
+    while (!B.done()) {
+        if ((rc = B.enqueue_batch())) return rc;
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        if ((rc = B.finish_batch())) return rc;
+    }
+    info_out[7] = B.n_trials;
+    if (!B.have) {
+        info_out[3] = MODEST_STAGE_NO_CONSENSUS;
+        return MODEST_OK;
     }
     // 3. mask + graph + DBSCAN + labels[ptc_mask] = ...
     int32_t n_kept = 0, n_clusters = 0;
-    rc = modest_mask_cluster(ctx, pts, n, stride, pp, plane1_out, P->offset, P->use_only_range ? P->only_range : nullptr,
-                             P->limit_range, P->neighbor_type, P->affinity_type, P->k_neighbors, P->radius, P->eps,
-                             P->min_samples, labels_dev, &n_kept, &n_clusters, stream_);
+    const double *only = P->use_only_range ? P->only_range : nullptr;
+    if ((rc = B.enqueue_refit())) return rc;
+    rc = modest_mask_cluster_phase(ctx, pts, n, stride, pp, plane1_out, P->offset, only, P->limit_range, P->neighbor_type,
+                                   P->affinity_type, P->k_neighbors, P->radius, P->eps, P->min_samples, labels_dev, &n_kept,
+                                   &n_clusters, stream_, 1);
+    if (rc) return rc;
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    if ((rc = B.finish_refit(model64, &n_in, &degenerate))) return rc;
+    if (degenerate) {
+        info_out[3] = MODEST_STAGE_DEGENERATE;
+        ctx->zwords_dirty = 1;   // the cell counters hold this scan's counts
+        ctx->zwords_live = 0;
+        return MODEST_OK;
+    }
+    plane_from_model(model64, plane2_out);
+    memcpy(mt_key624, g.key, sizeof(g.key));
+    *mt_pos = g.pos;
+    rc = modest_mask_cluster_phase(ctx, pts, n, stride, pp, plane1_out, P->offset, only, P->limit_range, P->neighbor_type,
+                                   P->affinity_type, P->k_neighbors, P->radius, P->eps, P->min_samples, labels_dev, &n_kept,
+                                   &n_clusters, stream_, 2);
     info_out[0] = n_kept;
     info_out[1] = n_clusters;
     if (rc) {
