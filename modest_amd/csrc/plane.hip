@@ -367,6 +367,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
                                                               const float *__restrict__ thr_src,
                                                               float *__restrict__ thr_dst) {
     __shared__ float sm[SCORE_KG][3];
+    __shared__ double red[SCORE_WAVES][SCORE_KG][4];
     __shared__ unsigned last_s;
     if (FUSED) {   // the block fits its own SCORE_KG planes; the first block column reports them
         const int k = blockIdx.y * SCORE_KG + (int)threadIdx.x;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
         z[p] = valid[p] ? cand[3 * (size_t)i + 2] : 0.f;
     }
     const int k0 = blockIdx.y * SCORE_KG, k1 = min(k0 + SCORE_KG, K);
-    double *row = partial + ((size_t)(blockIdx.x * SCORE_WAVES + w) * K) * 4;
+    double *row = partial + ((size_t)blockIdx.x * K) * 4;   // one row per block (the wavefronts combine in LDS)
     for (int k = k0; k < k1; ++k) {
         const float c0 = FUSED ? sm[k - k0][0] : models[3 * k], c1 = FUSED ? sm[k - k0][1] : models[3 * k + 1];
         const float b = FUSED ? sm[k - k0][2] : models[3 * k + 2];
@@ -418,11 +419,18 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
         sy = wave_sum(sy);
         syy = wave_sum(syy);
         if (lane == 0) {
-            __hip_atomic_store(row + 4 * k + 0, (double)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(row + 4 * k + 1, sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(row + 4 * k + 2, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(row + 4 * k + 3, syy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[w][k - k0][0] = (double)cnt;
+            red[w][k - k0][1] = sse;
+            red[w][k - k0][2] = sy;
+            red[w][k - k0][3] = syy;
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < (k1 - k0) * 4) {   // the four wavefronts' sums, in wavefront order
+        const int kk = threadIdx.x >> 2, q = threadIdx.x & 3;
+        double s = 0.0;
+        for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][kk][q];
+        __hip_atomic_store(row + 4 * (k0 + kk) + q, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // The block that finishes last (ticket, left at zero) adds the partial rows, one output per thread in
     // row order (consecutive threads read consecutive words), and writes the totals.  No __threadfence():
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
     if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
     __syncthreads();
     if (!last_s) return;
-    const int nrows = gridDim.x * SCORE_WAVES;
+    const int nrows = gridDim.x;
     for (int id = threadIdx.x; id < K * 4; id += SCORE_THREADS) {
         double s = 0.0;
         for (int r0 = 0; r0 < nrows; r0 += 8) {
