@@ -20,6 +20,11 @@
 // sklearn's KDTree (float64) compares.  Region queries run on a uniform grid
 // with cell edge = radius: one 64-lane wavefront per query point sweeps the 3x3
 // cell rows (contiguous in the cell-sorted array, so loads are coalesced).
+//
+// modest_mask_cluster puts generate_mask.py:57-65 in front of it (above_plane +
+// limit_range mask, ordered compaction of the kept rows, their cell counts on a
+// grid fixed around limit_range) and `labels[ptc_mask] = ...` behind it, as one
+// call with one synchronise in the middle (the kept count sizes the launches).
 #include "common.h"
 #include "compact.h"
 #include "mask_pred.h"

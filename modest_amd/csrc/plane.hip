@@ -4,9 +4,11 @@
 // <= thr, all float32), the final least-squares refit, and above_plane +
 // range mask (pointcloud_utils.py:68-81, generate_mask.py:57-65).
 //
-// The sequential accept rule and the random triplets stay on the host (they
-// are a few dozen scalar decisions); every O(N) or O(N*trials) loop is here,
-// with deterministic (fixed-order) reductions.
+// Every O(N) or O(N*trials) loop is a kernel with deterministic (fixed-order)
+// reductions.  The sequential accept rule and the random triplets are host code
+// (a few dozen scalar decisions): of the library since round 2 (ransac_host.h,
+// modest_ransac_plane: numpy's MT19937 stream as sklearn consumes it), or of the
+// caller (modest_ransac_trials / _refit with its own triplets).
 #include "common.h"
 #include "compact.h"
 #include "mask_pred.h"
