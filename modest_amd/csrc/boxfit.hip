@@ -281,9 +281,39 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
     __syncthreads();
     if (!last_s) return;
     __shared__ int arg_s;
-    if (threadIdx.x < 64) {
-        const int arg = argmax_wave(beta + (size_t)c * n_angles, n_angles, threadIdx.x);
+    {   // first strict maximum over the angles, all four wavefronts: larger value wins, equal values the smaller index
+        __shared__ double wmx[4];
+        __shared__ int warg[4];
+        const double *row = beta + (size_t)c * n_angles;
+        double mx = -INFINITY;
+        int arg = 0x7fffffff;
+        for (int a2 = threadIdx.x; a2 < n_angles; a2 += 256) {
+            const double v = __hip_atomic_load(row + a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v > mx) {
+                mx = v;
+                arg = a2;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(mx, o);
+            const int oa = __shfl_xor(arg, o);
+            if (ov > mx || (ov == mx && oa < arg)) {
+                mx = ov;
+                arg = oa;
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wmx[threadIdx.x >> 6] = mx;
+            warg[threadIdx.x >> 6] = arg;
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
+            for (int w2 = 1; w2 < 4; ++w2)
+                if (wmx[w2] > mx || (wmx[w2] == mx && warg[w2] < arg)) {
+                    mx = wmx[w2];
+                    arg = warg[w2];
+                }
+            arg = (arg == 0x7fffffff) ? -1 : arg;
             best_host[c] = arg;
             tickets[c] = 0u;
             arg_s = arg;
