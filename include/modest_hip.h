@@ -111,9 +111,9 @@ int modest_pp_score(modest_ctx *ctx, const float *live_xyz_dev, int n_live,
  * (cell edge c = r*(1+2^-10), the lattice is shared by all frames of a data set) and writes the
  * prefix table tile -> first point.  A scan then names its frames by descriptor
  * (modest_pp_frame: store buffers + traversal id + the float32 relative pose of
- * get_relative_pose, :27-28) and modest_pp_score_frames gathers, per live tile, the run of that
- * tile from every frame's table, applies the pose (transform_points' float32 rounding) and counts
- * neighbours: history bytes cross HBM once and no stacked copy exists.
+ * get_relative_pose, :27-28) and modest_pp_score_frames streams the frames through that table,
+ * applies the pose on the fly (transform_points' float32 rounding) and counts neighbours: no
+ * stacked, transformed copy of the history exists.
  *
  * W [host] 2x4 float64, rows x and y of (1/c) * (raw frame -> world lattice metres).
  * TX0, TY0: global tile coordinates of the table's first tile; the table covers

@@ -9,10 +9,8 @@ relative pose) to ``modest_pp_score_frames`` -- no stacked history is ever built
 
 World lattice: ``lattice = (world_xy - anchor_xy) / c`` with ``world = W @ [p, 1]`` for the frame's
 raw->world matrix ``W = E @ L @ K`` (ego pose, lidar-to-ego, KITTI2NU; the factors of
-``get_relative_pose``, ``pre_compute_pp_score.py:27-28``).  The gather-join path recomputes a
-point's cell from its float32 common-frame coordinates through ``A = (fixed frame -> world)``; the
-two must agree to better than ``r/1024`` (checked per scan at 1e-4 m; otherwise, or when a frame has
-points outside its table, the scan takes the stacked path ``ops.pp_score``).
+``get_relative_pose``, ``pre_compute_pp_score.py:27-28``).  ``consistent()`` checks a scan's relative
+poses against the lattice (``A = fixed frame -> world``); the streaming kernels do not depend on it.
 """
 from __future__ import annotations
 
@@ -209,12 +207,10 @@ class FrameStore:
         if desc is None:
             desc = self.describe(live_key, live_rel, [k for k, _ in hist], [t for _, t in hist], rels, remove_center)
         lv, arr, slots = desc
-        # the streaming path reads frames as plain point lists; only the gather-join relies on the
-        # tile tables (no outliers) and on the lattice agreeing with the relative poses
-        gather = os.environ.get("MODEST_PP_FRAMES_PATH", "") == "gather-wave"
-        ok = (not force_stacked and T <= 64
-              and (not gather or (bool(self._clean[slots].all())
-                                  and self.consistent(slots, np.concatenate([rels, live_rel[None]]), A44))))
+        # the streaming kernels read frames as plain point lists (tile order only helps their scatter
+        # pass): outliers and a lattice that disagrees with the poses are harmless; > 64 traversals take
+        # the stacked path
+        ok = not force_stacked and T <= 64
         if not ok:
             frames = [self.frames[k] for k, _ in hist]
             return self._pp_score_stacked(live, live_rel, frames, [t for _, t in hist], rels, T, remove_center,

@@ -21,19 +21,8 @@ def _store_scan(gpu, s, radius=0.3, nusc=False):
     return st, hist, np.stack(rels)
 
 
-@pytest.fixture(params=["stream", "gather-wave"])
-def frames_path(request, monkeypatch):
-    """The three device paths behind modest_pp_score_frames: the V3 streaming kernels over the
-    descriptor table (default), and the experimental wave-autonomous gather-join (MODEST_PP_FRAMES_PATH=gather-wave)."""
-    if request.param == "stream":
-        monkeypatch.delenv("MODEST_PP_FRAMES_PATH", raising=False)
-    else:
-        monkeypatch.setenv("MODEST_PP_FRAMES_PATH", request.param)
-    return request.param
-
-
 @pytest.mark.parametrize("nusc", [False, True])
-def test_frames_vs_oracle(gpu, nusc, frames_path):
+def test_frames_vs_oracle(gpu, nusc):
     from modest_amd import synth
     from oracle import pp_score as opp
     s = synth.make_scan(21, n_live=20000, n_trav=5, n_frames=8, n_per_frame=20000, keep_frames=True, nusc=nusc)
@@ -81,10 +70,9 @@ def _rigid(rng, yaw_range=3.1, shift=20.0):
 
 
 @pytest.mark.parametrize("T,radius", [(1, 0.3), (7, 0.5), (33, 0.3), (64, 0.3), (65, 0.3)])
-def test_frames_edge_cases(gpu, frames_path, T, radius):
-    """Ragged inputs through the frame API on every device path: empty frames, a frame far outside
-    the live window, a frame with points beyond its own table (outliers: the gather paths must fall
-    back), duplicated points, arbitrary rigid poses with roll/pitch, 1..65 traversals (65 takes the
+def test_frames_edge_cases(gpu, T, radius):
+    """Ragged inputs through the frame API: empty frames, a frame far outside the live window, a frame
+    with points beyond its own table (outliers), duplicated points, arbitrary rigid poses with roll/pitch, 1..65 traversals (65 takes the
     stacked path), another radius.  Counts are compared with the brute-force oracle on the
     reference-transformed points."""
     import torch
