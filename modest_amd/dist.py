@@ -48,8 +48,10 @@ def shard(idx_list, total_part: int = 1, part: int = 0, rank: Optional[int] = No
         idx_list = np.array_split(idx_list, total_part)[part]
     if rank is None or ws is None:
         rank, ws, _ = world()
-        if "MODEST_PARENT_WS" in os.environ:   # worker process: the rank split of its parent
-            rank, ws = int(os.environ["MODEST_PARENT_RANK"]), int(os.environ["MODEST_PARENT_WS"])
+    if os.environ.get("MODEST_WORKER") and "MODEST_PARENT_WS" in os.environ:
+        # A worker process of a rank (run_workers strips RANK / WORLD_SIZE from its environment, so its
+        # own dist.init() says (0, 1)): the rank split is its PARENT's, whatever the caller passed.
+        rank, ws = int(os.environ["MODEST_PARENT_RANK"]), int(os.environ["MODEST_PARENT_WS"])
     if ws > 1:
         idx_list = np.array_split(idx_list, ws)[rank]
     w = os.environ.get("MODEST_WORKER")

@@ -110,8 +110,13 @@ class FrameStore:
         return self._free.pop()
 
     # ------------------------------------------------------------------ insertion
-    def insert_many(self, items: Sequence[Tuple[Hashable, torch.Tensor, np.ndarray]], ctx=None) -> None:
-        """items: (key, raw (n,3|4) f32 device tensor, W (4,4) f64 raw->world).  One launch."""
+    def insert_many(self, items: Sequence[Tuple[Hashable, torch.Tensor, np.ndarray]], ctx=None,
+                    protect: Optional[Sequence[Hashable]] = None) -> None:
+        """items: (key, raw (n,3|4) f32 device tensor, W (4,4) f64 raw->world).  One launch.
+        `protect`: keys that must stay resident whatever the capacity says -- the frames of the scan
+        that is being prepared (its resident history frames have not been touched yet when the missing
+        ones are inserted; evicting them would also hand their slots, which the scan's descriptor table
+        names, to other frames).  A scan whose own working set exceeds the capacity simply overshoots it."""
         seen, todo = set(), []
         for it in items:
             if it[0] not in self.frames and it[0] not in seen:
@@ -147,10 +152,15 @@ class FrameStore:
             self._clean[sf.slot] = sf.n_inside == n
             self.frames[key] = sf
             self.bytes += sf.nbytes
-        while self.bytes > self.cap and len(self.frames) > len(todo):
-            _, old = self.frames.popitem(last=False)
-            self.bytes -= old.nbytes
-            self._free.append(old.slot)
+        if self.bytes > self.cap:
+            keep = set(protect) if protect is not None else set()
+            keep.update(k for k, *_ in made)
+            for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first
+                if self.bytes <= self.cap:
+                    break
+                old = self.frames.pop(key)
+                self.bytes -= old.nbytes
+                self._free.append(old.slot)
 
     def insert(self, key, raw: torch.Tensor, W: np.ndarray) -> StoredFrame:
         self.insert_many([(key, raw, W)])

@@ -86,11 +86,17 @@ NATIVE_STAGE = True   # tests switch it off to compare the library's stage drive
 
 
 def _stage_params(args) -> "ops.MaskParams":
-    """the config keys of the stage as the library's parameter block (cached per config object)"""
-    cached = _PARAMS.get(id(args))
-    if cached is not None and cached[0] is args:
-        return cached[1]
+    """the config keys of the stage as the library's parameter block.  Cached on the VALUES it is built
+    from (a config node mutated in place -- a parameter sweep, a test changing clustering.DBSCAN.eps --
+    must not run the native stage with the previous values while the host path reads the live ones)."""
     pe, g, f = args.plane_estimate, args.graph, args.filtering
+    key = (pe.max_hs, repr(pe.range), pe.offset, repr(args.limit_range), g.neighbor_type, g.affinity_type,
+           g.n_neighbors, g.radius, args.clustering.DBSCAN.min_samples, args.clustering.DBSCAN.eps,
+           f.get("min_points", 10), f.get("max_min_height", 4), f.get("min_max_height", 0), f.get("percentile", 10),
+           f.get("min_percentile_pp_score", 0.7))
+    cached = _PARAMS.get("last")
+    if cached is not None and cached[0] == key:
+        return cached[1]
     P = ops.MaskParams()
     P.max_hs1 = pe.max_hs
     P.range1[:] = [pe.range[0][0], pe.range[0][1], pe.range[1][0], pe.range[1][1]]
@@ -111,8 +117,7 @@ def _stage_params(args) -> "ops.MaskParams":
     P.quantile = float(np.true_divide(f.get("percentile", 10), np.float32(100)))
     P.min_percentile_pp_score = float(np.float32(f.get("min_percentile_pp_score", 0.7)))
     P.max_trials, P.batch, P.stop_probability = 100, 48, 0.99
-    _PARAMS.clear()
-    _PARAMS[id(args)] = (args, P)
+    _PARAMS["last"] = (key, P)
     return P
 
 

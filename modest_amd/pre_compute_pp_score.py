@@ -87,7 +87,7 @@ class FrameLoader:
             for i in missing:
                 raw = load_velo_scan(osp.join(self.dir, f"{i:06d}.bin"))
                 items.append((i, torch.from_numpy(raw).to(self.store.device), self.world[i]))
-            self.store.insert_many(items)
+            self.store.insert_many(items, protect=file_ids)
         for i in file_ids:
             self.store.get(i)   # LRU touch + hit statistics
 

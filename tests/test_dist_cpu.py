@@ -50,6 +50,8 @@ def test_worker_split_env(monkeypatch):
             monkeypatch.setenv("MODEST_PARENT_WS", "2")
             monkeypatch.setenv("MODEST_WORKER", f"{w}/3")
             pieces.append(dist.shard(idx, 1, 0))
+            # what the CLIs do inside a worker: they pass the (0, 1) their own dist.init() returned
+            assert np.array_equal(dist.shard(idx, 1, 0, rank=0, ws=1), pieces[-1])
     assert np.array_equal(np.concatenate(pieces), idx)
     monkeypatch.delenv("MODEST_WORKER")
     monkeypatch.delenv("MODEST_PARENT_RANK")
