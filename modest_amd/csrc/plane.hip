@@ -336,13 +336,33 @@ __device__ __forceinline__ void fit_triplet(const float *__restrict__ cand, int 
         syz += dy * dz;
     }
     const double det = sxx * syy - sxy * sxy;
-    *c0 = *c1 = *b = NAN;
+    double a0 = 0.0, a1 = 0.0;
     if (fabs(det) > 1e-12 * fmax(sxx * syy, 1e-300)) {
-        const double a0 = (sxz * syy - syz * sxy) / det, a1 = (syz * sxx - sxz * sxy) / det;
-        *c0 = (float)a0;
-        *c1 = (float)a1;
-        *b = (float)(mz - a0 * mx - a1 * my);
+        a0 = (sxz * syy - syz * sxy) / det;
+        a1 = (syz * sxx - sxz * sxy) / det;
+    } else if (sxx + syy > 0.0) {
+        // Collinear in xy (a duplicated point in the triplet, in practice): sklearn's LinearRegression ->
+        // lstsq returns the MINIMUM-NORM solution of the rank-one centred system, a legitimate trial model
+        // that can win (a line on flat ground extends to the ground plane).  w = v (v . X'z) / lambda with
+        // (lambda, v) the leading eigenpair of X'X.  (Three coincident xy: w = 0, b = mean z.)
+        const double h = 0.5 * (sxx - syy), l1 = 0.5 * (sxx + syy) + sqrt(h * h + sxy * sxy);
+        double vx = l1 - syy, vy = sxy;
+        if (fabs(l1 - sxx) > fabs(l1 - syy)) {
+            vx = sxy;
+            vy = l1 - sxx;
+        }
+        const double nv = sqrt(vx * vx + vy * vy);
+        if (nv > 0.0) {
+            vx /= nv;
+            vy /= nv;
+            const double pr = (vx * sxz + vy * syz) / l1;
+            a0 = vx * pr;
+            a1 = vy * pr;
+        }
     }
+    *c0 = (float)a0;
+    *c1 = (float)a1;
+    *b = (float)(mz - a0 * mx - a1 * my);
 }
 
 // The triplets of a batch travel as a kernel argument (no upload, no separate fit launch).
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
 
 // exact-fit plane z = c0 x + c1 y + b through the three candidates of every trial: float64,
 // centred 2x2 normal equations, rounded to float32 (what LinearRegression stores for float32
-// data); a degenerate (collinear in xy) triplet yields NaN = a trial without inliers
+// data); a degenerate (collinear in xy) triplet gets lstsq's minimum-norm model (fit_triplet)
 __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__restrict__ trip, int K,
                            float *__restrict__ models, float *__restrict__ models_host) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

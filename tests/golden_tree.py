@@ -24,5 +24,6 @@ def unpack_tree(golden_dir, dst, name="e2e_tree.npz"):
                  idx_list=os.path.join(meta, "train_idx.txt"))
     pickle.dump(track, open(paths["track_path"], "wb"))
     pickle.dump(valid, open(paths["idx_info"], "wb"))
-    open(paths["idx_list"], "w").write(f"{int(g['origin']):06d}")
+    origins = [int(g["origin"])] if "origin" in g.files else [int(x) for x in g["origins"]]
+    open(paths["idx_list"], "w").write("\n".join(f"{o:06d}" for o in origins))
     return g, train, paths

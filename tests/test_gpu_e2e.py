@@ -279,3 +279,52 @@ def test_bench_contract_json_line(gpu):
     assert d["parity"]["pp_counts_equal"] is True and d["parity"]["labels_equal"] is True
     assert d["parity"]["label_text_equal"] is True
     assert d["cli"]["label_files"] == 3 and d["cli"]["pp_scans_per_s"] > 0 and d["cli"]["mask_scans_per_s"] > 0
+
+
+def _pp_cli(tmp_path, golden_dir, tag, extra):
+    from modest_amd import config, pre_compute_pp_score
+    from tests.golden_tree import unpack_tree
+    root = tmp_path / tag
+    g, train, paths = unpack_tree(golden_dir, str(root), name="pp_branches.npz")
+    out = str(root / "out")
+    ov = [f"data_root={train}"] + [f"data_paths.{k}={v}" for k, v in paths.items()] + [f"data_paths.pp_score_path={out}/pp"]
+    tot = pre_compute_pp_score.main(config.compose("pp_score", ov + extra))
+    return g, out, tot
+
+
+def test_pp_cli_non_default_branches(gpu, golden_dir, tmp_path):
+    """SURVEY 8f-3, the PP CLI's own branches against what the REFERENCE's pre_compute_pp_score.main wrote on
+    the same tree (tools/make_golden_pp_branches.py: three history traversals, two live scans):
+    limit_traversals (:181-186), add_random_noise (:175-179; numpy's global generator, consumed scan after
+    scan, left in the same state), the two dump options (:152-155, :168-171) and skip_ephe (:172-173)."""
+    import pickle
+    g, out, tot = _pp_cli(tmp_path, golden_dir, "default", [])
+    origins = [int(x) for x in g["origins"]]
+    assert tot["scans"] == len(origins) == 2
+    for o in origins:
+        assert np.max(np.abs(np.load(f"{out}/pp/{o:06d}.npy").astype(np.float64) - g[f"pp_default_{o}"])) <= 1e-6
+    # limit_traversals=2 of the three history traversals
+    g, out, tot = _pp_cli(tmp_path, golden_dir, "limit2", ["limit_traversals=2"])
+    for o in origins:
+        pp = np.load(f"{out}/pp/{o:06d}.npy")
+        assert pp.dtype == np.float32 and np.max(np.abs(pp.astype(np.float64) - g[f"pp_limit2_{o}"])) <= 1e-6
+        assert np.max(np.abs(pp - g[f"pp_default_{o}"])) > 1e-3          # the branch does something
+    # add_random_noise: seeded as the reference run was; the draws of scan 2 follow those of scan 1
+    np.random.seed(int(g["noise_seed"]))
+    g, out, tot = _pp_cli(tmp_path, golden_dir, "noise", ["add_random_noise=0.05"])
+    for o in origins:
+        assert np.max(np.abs(np.load(f"{out}/pp/{o:06d}.npy").astype(np.float64) - g[f"pp_noise_{o}"])) <= 1e-6
+    assert np.random.uniform() == float(g["noise_next_draw"])
+    # dumps + skip_ephe: relative pose of the live scan and the stacked, transformed history per traversal
+    lid, tm = str(tmp_path / "lid"), str(tmp_path / "tm")
+    g, out, tot = _pp_cli(tmp_path, golden_dir, "dumps",
+                          [f"data_paths.load_precomputed_lidars={lid}", f"data_paths.load_save_precomputed_trans_mat={tm}",
+                           "skip_ephe=True"])
+    assert tot["scans"] == 0 and not os.listdir(f"{out}/pp")
+    for o in origins:
+        t = np.load(f"{tm}/{o:06d}.npy")
+        assert t.dtype == np.float32 and np.array_equal(t, g[f"trans_{o}"])
+        comb = pickle.load(open(f"{lid}/{o:06d}.pkl", "rb"))
+        assert sorted(comb) == [int(k) for k in g[f"lidar_keys_{o}"]]
+        for k in comb:
+            assert comb[k].dtype == np.float32 and np.array_equal(comb[k], g[f"lidar_{o}_{k}"]), (o, k)

@@ -54,3 +54,31 @@ def test_pose_and_transform(golden_dir):
     # bit-identical to the BLAS product the reference ran in the build container
     assert np.array_equal(opp.transform_points_fma(t["pts"], t["T"]), t["out"])
     assert np.array_equal(opp.remove_center(t["pts"]), t["kept"])
+
+
+def test_kitti2nu_against_independent_rotation():
+    """The K matrices of tests/golden/pose.npz were written by the oracle's own restatement of pyquaternion
+    (absent from the image): checked here against two independent statements of the same rotations --
+    scipy's Rotation and the closed form of a rotation about z -- and against what pyquaternion's
+    algorithm guarantees (orthonormal, det +1, homogeneous row)."""
+    from scipy.spatial.transform import Rotation
+    for nusc, angle in ((False, np.pi), (True, np.pi / 2)):
+        K = opp.kitti2nu(nusc)
+        ref = np.eye(4)
+        ref[:3, :3] = Rotation.from_euler("z", angle).as_matrix()
+        assert np.max(np.abs(K - ref)) <= 2.5e-16          # both are within an ulp of cos/sin of the angle
+        c, s = np.cos(angle), np.sin(angle)
+        closed = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        assert np.max(np.abs(K - closed)) <= 2.5e-16
+        assert np.max(np.abs(K[:3, :3] @ K[:3, :3].T - np.eye(3))) <= 4e-16 and abs(np.linalg.det(K[:3, :3]) - 1) <= 4e-16
+        assert np.array_equal(K[3], [0, 0, 0, 1]) and np.array_equal(K[:3, 3], [0, 0, 0])
+        # what the rotation is FOR (pre_compute_pp_score.py:22-24): KITTI velodyne axes -> nuScenes lidar axes
+        fwd = K[:3, :3] @ np.array([1.0, 0.0, 0.0])
+        assert np.allclose(fwd, [-1, 0, 0] if not nusc else [0, 1, 0], atol=1e-15)
+        # the float32 relative pose (the only thing that leaves get_relative_pose) does not see the last ulp
+        rng = np.random.default_rng(5)
+        E = np.eye(4)
+        E[:3, :3] = Rotation.from_euler("xyz", rng.uniform(-0.1, 0.1, 3)).as_matrix()
+        E[:3, 3] = rng.uniform(-50, 50, 3)
+        assert np.array_equal(opp.get_relative_pose(np.eye(4), np.eye(4), np.eye(4), E, K),
+                              opp.get_relative_pose(np.eye(4), np.eye(4), np.eye(4), E, ref))
