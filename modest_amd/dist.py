@@ -32,11 +32,61 @@ def init(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MODEST_DIST_BACKEND=gloo: ranks that SHARE a GPU (more ranks than devices: RCCL refuses two
+            # ranks on one device) still get the barrier / counter all-reduce / work queue, over TCP
+            backend = os.environ.get("MODEST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            if local >= torch.cuda.device_count():
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} has no GPU of its own ({torch.cuda.device_count()} "
+                                   "visible); set MODEST_DIST_BACKEND=gloo to let ranks share devices")
             torch.cuda.set_device(local)
         torch.distributed.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local
+
+
+def device_index(local: int, ws: int, cfg) -> int:
+    """The GPU of this process: LOCAL_RANK under a multi-rank launch (wrapped around the visible devices when
+    ranks share GPUs, see init), the config's `device` otherwise."""
+    if ws > 1:
+        n = max(torch.cuda.device_count(), 1)
+        return local % n
+    return int(cfg.get("device", 0))
+
+
+class WorkQueue:
+    """Chunked dynamic work queue over the scans of a shard (optional there): per-scan cost varies
+    (cluster count, RANSAC trials, new frames to load), a static contiguous split leaves the fast ranks idle.
+    Chunks of `chunk` consecutive scans (consecutive scans share history frames: the frame store stays warm)
+    are handed out by an atomic counter in the process group's key-value store (served by rank 0, the same TCP
+    store the rendezvous used) -- no collective, so ranks may finish at different times.  Which rank writes
+    which file changes, the set of files does not.  `static` (default) is the reference's split."""
+
+    def __init__(self, items, rank: int, ws: int, mode: str = "static", chunk: int = 32, name: str = "q"):
+        self.items = np.asarray(items)
+        self.dynamic = (mode == "dynamic" and ws > 1 and torch.distributed.is_available()
+                        and torch.distributed.is_initialized() and not os.environ.get("MODEST_WORKER"))
+        self.chunk = max(int(chunk), 1)
+        if self.dynamic:
+            from torch.distributed import distributed_c10d as c10d
+            self.store, self.key = c10d._get_default_store(), f"modest_wq_{name}"
+        else:
+            self.mine = np.array_split(self.items, ws)[rank] if ws > 1 else self.items
+        self.taken = 0
+
+    def __iter__(self):
+        if not self.dynamic:
+            for x in self.mine:
+                self.taken += 1
+                yield x
+            return
+        n_chunks = (len(self.items) + self.chunk - 1) // self.chunk
+        while True:
+            c = int(self.store.add(self.key, 1)) - 1     # atomic fetch-and-add on the store
+            if c >= n_chunks:
+                return
+            for x in self.items[c * self.chunk:(c + 1) * self.chunk]:
+                self.taken += 1
+                yield x
 
 
 def shard(idx_list, total_part: int = 1, part: int = 0, rank: Optional[int] = None, ws: Optional[int] = None):
@@ -61,6 +111,35 @@ def shard(idx_list, total_part: int = 1, part: int = 0, rank: Optional[int] = No
     return idx_list
 
 
+def scans_of(idx_list, cfg, rank: int, ws: int, name: str):
+    """The scans this process works through: the reference's total_part/part piece, then either the static
+    per-rank split (`work_queue: static`, the default) or the chunked dynamic queue shared by the ranks
+    (`work_queue: dynamic`, `queue_chunk`), then -- inside a worker -- the worker's piece."""
+    mode = str(cfg.get("work_queue", "static"))
+    if mode == "dynamic" and ws > 1 and not os.environ.get("MODEST_WORKER") and int(cfg.get("workers", 1) or 1) <= 1:
+        part = shard(idx_list, cfg.total_part, cfg.part, rank=0, ws=1)
+        return WorkQueue(part, rank, ws, "dynamic", int(cfg.get("queue_chunk", 32)), name)
+    return WorkQueue(shard(idx_list, cfg.total_part, cfg.part, rank, ws), 0, 1)
+
+
+def rank_report(tag: str, done: int, t0: float, rank: int, ws: int, extra: Optional[Dict[str, float]] = None) -> Dict[str, float]:
+    """End of a CLI loop: this rank's busy time (before the barrier), then barrier + all-reduce.  Reports the
+    spread between the ranks (scans and busy seconds): what a dynamic queue would have to absorb."""
+    busy = time.perf_counter() - t0
+    barrier()
+    c = dict(scans=done, max_seconds=time.perf_counter() - t0, max_busy_seconds=busy, min_busy_seconds=busy,
+             max_rank_scans=done, min_rank_scans=done)
+    c.update(extra or {})
+    tot = reduce_counters(c)
+    tot["imbalance"] = (tot["max_busy_seconds"] - tot["min_busy_seconds"]) / max(tot["max_busy_seconds"], 1e-9)
+    if rank == 0 and ws > 1:
+        import sys
+        print("[%s] ranks: scans %d..%d, busy %.2f..%.2f s (imbalance %.1f %%)"
+              % (tag, tot["min_rank_scans"], tot["max_rank_scans"], tot["min_busy_seconds"], tot["max_busy_seconds"],
+                 100.0 * tot["imbalance"]), file=sys.stderr, flush=True)
+    return tot
+
+
 def run_workers(module: str, cfg, rank: int, ws: int, local: int) -> Optional[Dict[str, float]]:
     """``workers=N`` of the CLIs: the host side of a scan (Python + ~60 HIP calls + blocking round
     trips) saturates one process long before the GPU, which is why the reference is run as several
@@ -80,7 +159,7 @@ def run_workers(module: str, cfg, rank: int, ws: int, local: int) -> Optional[Di
         cpath = os.path.join(d, "cfg.yaml")
         c2 = _config.ConfigNode(cfg.to_container(resolve=True))
         c2["workers"] = 1
-        c2["device"] = local if ws > 1 else int(cfg.get("device", 0))
+        c2["device"] = device_index(local, ws, cfg)
         _config.save(c2, cpath, resolve=False)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         env.update(MODEST_PARENT_RANK=str(rank), MODEST_PARENT_WS=str(ws))
@@ -97,7 +176,12 @@ def run_workers(module: str, cfg, rank: int, ws: int, local: int) -> Optional[Di
         tot: Dict[str, float] = {}
         for w in range(n):
             for k, v in json.load(open(os.path.join(d, f"w{w}.json"))).items():
-                tot[k] = max(tot.get(k, 0.0), v) if k.startswith("max_") else tot.get(k, 0.0) + v
+                if k.startswith("max_"):
+                    tot[k] = max(tot.get(k, 0.0), v)
+                elif k.startswith("min_"):
+                    tot[k] = min(tot.get(k, v), v)
+                else:
+                    tot[k] = tot.get(k, 0.0) + v
     return tot
 
 
@@ -123,23 +207,20 @@ def barrier() -> None:
 
 
 def reduce_counters(counters: Dict[str, float]) -> Dict[str, float]:
-    """Sum scalar counters over ranks ("max_" prefixed keys take the maximum)."""
+    """Sum scalar counters over ranks ("max_" / "min_" prefixed keys take the maximum / minimum)."""
     if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
         return dict(counters)
     keys = sorted(counters)
     dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
-    sums = torch.tensor([float(counters[k]) for k in keys if not k.startswith("max_")], dtype=torch.float64, device=dev)
-    maxs = torch.tensor([float(counters[k]) for k in keys if k.startswith("max_")], dtype=torch.float64, device=dev)
-    if sums.numel():
-        torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM)
-    if maxs.numel():
-        torch.distributed.all_reduce(maxs, op=torch.distributed.ReduceOp.MAX)
-    out, si, mi = {}, 0, 0
-    for k in keys:
-        if k.startswith("max_"):
-            out[k] = float(maxs[mi]); mi += 1
-        else:
-            out[k] = float(sums[si]); si += 1
+    out = {}
+    for prefix, op in (("max_", torch.distributed.ReduceOp.MAX), ("min_", torch.distributed.ReduceOp.MIN),
+                       (None, torch.distributed.ReduceOp.SUM)):
+        ks = [k for k in keys if (k.startswith(prefix) if prefix else not k.startswith(("max_", "min_")))]
+        if not ks:
+            continue
+        t = torch.tensor([float(counters[k]) for k in ks], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=op)
+        out.update({k: float(v) for k, v in zip(ks, t.tolist())})
     return out
 
 

@@ -68,10 +68,10 @@ def main(args):
     rank, ws, local = dist.init()
     if rank == 0:
         display_args(args)
-    torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))
+    torch.cuda.set_device(torch.device("cuda", dist.device_index(local, ws, args)))
     dp = args.data_paths
     idx_list = np.array([int(x) for x in open(dp.idx_list).readlines()])
-    shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
+    shard = dist.scans_of(idx_list, args, rank, ws, "labels")
     os.makedirs(dp.label_file_save_dst, exist_ok=True)
     if int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER"):
         return _pooled(args, rank, ws, local)
@@ -85,8 +85,7 @@ def main(args):
         with open(osp.join(dp.label_file_save_dst, f"{idx:06d}.txt"), "w") as f:
             f.write(text)
         done += 1
-    dist.barrier()
-    tot = dist.reduce_counters(dict(scans=done, max_seconds=time.perf_counter() - t0))
+    tot = dist.rank_report("gen_label_files", done, t0, rank, ws)
     if rank == 0:
         eprint("[gen_label_files] %d scans, %.2f s on %d GPU(s)" % (tot["scans"], tot["max_seconds"], ws))
     return tot

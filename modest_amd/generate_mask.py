@@ -166,11 +166,11 @@ def main(args):
     rank, ws, local = dist.init()
     if rank == 0:
         display_args(args)
-    torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))
+    torch.cuda.set_device(torch.device("cuda", dist.device_index(local, ws, args)))
     dp = args.data_paths
     pooled = int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER")
     idx_list = np.array([int(x) for x in open(dp.idx_list).readlines()])
-    shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
+    shard = dist.scans_of(idx_list, args, rank, ws, "mask")
     os.makedirs(dp.seg_save_dst, exist_ok=True)
     if rank == 0 and not osp.exists(osp.join(dp.seg_save_dst, "configs.yaml")):
         config.save(config=args, f=osp.join(dp.seg_save_dst, "configs.yaml"))
@@ -199,8 +199,7 @@ def main(args):
         np.save(osp.join(dp.seg_save_dst, f"{idx:06d}.npy"), labels)
         done += 1
     torch.cuda.synchronize()
-    dist.barrier()
-    tot = dist.reduce_counters(dict(scans=done, max_seconds=time.perf_counter() - t0))
+    tot = dist.rank_report("generate_mask", done, t0, rank, ws)
     if rank == 0:
         eprint("[generate_mask] %d scans, %.2f s, %.2f scans/s on %d GPU(s)"
                % (tot["scans"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9), ws))

@@ -144,7 +144,7 @@ def main(args):
     rank, ws, local = dist.init()
     if rank == 0:
         display_args(args)
-    device = torch.device("cuda", local if ws > 1 else int(args.get("device", 0)))
+    device = torch.device("cuda", dist.device_index(local, ws, args))
     torch.cuda.set_device(device)
     dp = args.data_paths
     if int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER"):
@@ -158,7 +158,7 @@ def main(args):
         idx_list = [int(x) for x in open(dp.idx_list).readlines()]
     else:
         idx_list = [x for x in valid_idx]
-    shard = dist.shard(idx_list, args.total_part, args.part, rank, ws)
+    shard = dist.scans_of(idx_list, args, rank, ws, "pp")
     for d in (dp.load_save_precomputed_trans_mat, dp.load_precomputed_lidars):
         if d is not None:
             os.makedirs(d, exist_ok=True)
@@ -231,8 +231,7 @@ def main(args):
         done += 1
         pts += int(sum(store.frames[i].n for i, _ in hist))
     torch.cuda.synchronize()
-    dist.barrier()
-    tot = dist.reduce_counters(dict(scans=done, hist_points=pts, max_seconds=time.perf_counter() - t0))
+    tot = dist.rank_report("pp_score", done, t0, rank, ws, dict(hist_points=pts))
     if rank == 0:
         eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame store %d hits / %d misses"
                % (tot["scans"], tot["hist_points"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9),

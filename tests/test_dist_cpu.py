@@ -57,3 +57,27 @@ def test_worker_split_env(monkeypatch):
     monkeypatch.delenv("MODEST_PARENT_RANK")
     monkeypatch.delenv("MODEST_PARENT_WS")
     assert np.array_equal(dist.shard(idx, 1, 0), idx)
+
+
+def test_dynamic_work_queue_two_ranks_gloo(tmp_path):
+    """SURVEY 8e's chunked dynamic queue: the ranks' chunks partition the list (whole chunks of consecutive
+    scans), the slower rank ends up with fewer scans, reduce_counters carries min_/max_ spreads."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29537",
+           os.path.join(ROOT, "tests", "_dist_queue_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = [json.load(open(tmp_path / f"q{k}.json")) for k in range(2)]
+    idx = np.arange(1000, 1093)
+    assert sorted(outs[0]["got"] + outs[1]["got"]) == list(idx)
+    for o in outs:                                            # whole chunks of 5 consecutive scans
+        g = np.array(o["got"])
+        assert np.all((g[::5] - 1000) % 5 == 0) and np.all(np.diff(g)[np.arange(len(g) - 1) % 5 != 4] == 1)
+    assert len(outs[0]["got"]) < len(outs[1]["got"])          # rank 0 slept 4x longer per scan
+    assert sorted(outs[0]["got2"] + outs[1]["got2"]) == list(np.array_split(idx, 3)[1])
+    for k in range(2):
+        assert outs[k]["got3"] == [int(x) for x in np.array_split(idx, 2)[k]]
+        t = outs[k]["tot"]
+        assert t["scans"] == 93 and t["min_rank_scans"] == len(outs[0]["got"]) and t["max_rank_scans"] == len(outs[1]["got"])
+        assert 0.0 <= t["imbalance"] < 0.5 and t["min_busy_seconds"] <= t["max_busy_seconds"]

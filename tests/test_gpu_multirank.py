@@ -1,0 +1,85 @@
+"""GPU: the N > 1 path of the three CLIs on the HIP path without a multi-GPU node (BASELINE
+config 4 in small): WORLD_SIZE = 2 with both ranks computing on GPU 0 (MODEST_DIST_BACKEND=gloo: RCCL refuses
+two ranks on one device; the collectives here are a barrier and a counter all-reduce) over a 200-scan
+synthetic KITTI tree.  The union of the output files must be byte-identical to a one-rank run, to the
+reference's manual total_part=2 runs (pre_compute_pp_score.py:114-116) and to a run with the dynamic work
+queue; the per-rank scan counts and busy times are written to gpurun_out/multirank_report.json."""
+import filecmp
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SCANS = 200
+CLIS = ("pre_compute_pp_score", "generate_mask", "gen_label_files")
+CFG = {"pre_compute_pp_score": "pp", "generate_mask": "seg", "gen_label_files": "labels"}
+
+
+def _overrides(train, paths, out):
+    return [f"data_root={train}"] + \
+           [f"data_paths.{k}={v}" for k, v in paths.items()] + \
+           [f"data_paths.pp_score_path={out}/pp", f"data_paths.seg_save_dst={out}/seg",
+            f"data_paths.bbox_info_save_dst={out}/bbox", f"data_paths.label_file_save_dst={out}/labels"]
+
+
+def _run(module, ov, ranks, port, extra_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if ranks == 1:
+        cmd = [sys.executable, "-m", f"modest_amd.{module}"] + ov
+    else:
+        env["MODEST_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", f"modest_amd.{module}"] + ov
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (module, r.stderr[-3000:])
+    return r.stderr
+
+
+def _same_tree(a, b):
+    for sub in ("pp", "seg", "bbox", "labels"):
+        fa = sorted(f for f in os.listdir(os.path.join(a, sub)) if f != "configs.yaml")
+        fb = sorted(f for f in os.listdir(os.path.join(b, sub)) if f != "configs.yaml")
+        assert fa == fb and len(fa) == N_SCANS, (sub, len(fa), len(fb))
+        match, mismatch, err = filecmp.cmpfiles(os.path.join(a, sub), os.path.join(b, sub), fa, shallow=False)
+        assert not mismatch and not err, (sub, mismatch[:5], err[:5])
+
+
+def test_three_clis_two_ranks_one_gpu(gpu, tmp_path):
+    from modest_amd import synth
+    root, meta = str(tmp_path / "data"), str(tmp_path / "meta")
+    paths = synth.write_kitti_tree(root, meta, n_seq=3, n_frames=N_SCANS + 6, n_pts=3000, origins=tuple(range(N_SCANS)),
+                                   hist_frames=6, max_range=60.0)
+    train = os.path.join(root, "training")
+    outs = {k: str(tmp_path / k) for k in ("one", "two", "parts", "queue")}
+    report = {}
+    for m in CLIS:                                                     # one rank
+        _run(m, _overrides(train, paths, outs["one"]), 1, 0)
+    for i, m in enumerate(CLIS):                                       # two ranks, static split
+        err = _run(m, _overrides(train, paths, outs["two"]), 2, 29541 + i)
+        mm = re.search(r"ranks: scans (\d+)\.\.(\d+), busy ([\d.]+)\.\.([\d.]+) s \(imbalance ([\d.]+) %\)", err)
+        assert mm, err[-1500:]
+        assert int(mm.group(1)) + int(mm.group(2)) == N_SCANS and int(mm.group(1)) == N_SCANS // 2
+        report[m] = dict(rank_scans=[int(mm.group(1)), int(mm.group(2))], busy_seconds=[float(mm.group(3)), float(mm.group(4))],
+                         imbalance_percent=float(mm.group(5)))
+    for m in CLIS:                                                     # the reference's manual split
+        for part in range(2):
+            _run(m, _overrides(train, paths, outs["parts"]) + ["total_part=2", f"part={part}"], 1, 0)
+    for i, m in enumerate(CLIS):                                       # two ranks, dynamic queue
+        err = _run(m, _overrides(train, paths, outs["queue"]) + ["work_queue=dynamic", "queue_chunk=16"], 2, 29551 + i)
+        mm = re.search(r"ranks: scans (\d+)\.\.(\d+), busy ([\d.]+)\.\.([\d.]+) s \(imbalance ([\d.]+) %\)", err)
+        assert mm and int(mm.group(1)) + int(mm.group(2)) == N_SCANS, err[-1500:]
+        report[m + "_dynamic"] = dict(rank_scans=[int(mm.group(1)), int(mm.group(2))],
+                                      busy_seconds=[float(mm.group(3)), float(mm.group(4))], imbalance_percent=float(mm.group(5)))
+    for k in ("two", "parts", "queue"):
+        _same_tree(outs["one"], outs[k])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "multirank_report.json"), "w") as f:
+        json.dump(dict(scans=N_SCANS, world_size=2, note="both ranks on GPU 0, gloo collectives", per_cli=report), f, indent=1)
