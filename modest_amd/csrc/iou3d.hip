@@ -13,12 +13,15 @@
 #include "common.h"
 #include "trig_f32.h"
 #include <cmath>
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace {
 
 constexpr float IOU_EPS = 1e-8f;
 constexpr int NMS_TPB = 64;  // one wavefront per block, 64-bit suppression words
+constexpr size_t NMS_CHUNK_BYTES = 32u << 20;   // suppression words per D2H chunk of the host walk (nms_impl)
 
 struct Pt {
     float x, y;
@@ -216,13 +219,11 @@ __global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__
 //   nms_tiles     UPPER-TRIANGULAR grid of 64 x 64 tiles (linear tile id -> (row block, column block
 //                 >= row block): no launched-then-exited blocks), one wavefront per tile, the 64 column
 //                 boxes and their trig in LDS; bit j of word (i, cb) = box i suppresses box 64 cb + j;
-//   nms_reduce    ONE wavefront walks the sorted order on the device, 64 boxes at a time: the 64
-//                 diagonal words of the block sit in the lanes and the in-block chain is resolved with
-//                 cross-lane reads (no memory in the loop); the words of the surviving rows are then
-//                 OR-ed into the running `removed` words of all later blocks, one lane per column block,
-//                 all row loads in flight together.  The keep list and its length are written straight
-//                 into pinned host memory: nothing of size n^2/64 ever crosses PCIe, the host does no
-//                 reduction.
+//   the walk      the sorted order is resolved on the HOST (src/iou3d_nms.cpp:116-135), the suppression words
+//                 crossing PCIe in row chunks of <= 32 MB.  A device-side walk (one wavefront, 64 boxes at a
+//                 time from cross-lane reads of the diagonal words) was built in round 2 and removed in
+//                 round 3: it is a serial chain of ~10 us per 64 boxes and lost to the host loop at every
+//                 size (profiles/r03_nms_bench.txt: 5.4 vs 2.2 ms at 20 000 axis-aligned boxes).
 __global__ void nms_trig(const float *__restrict__ boxes, int n, float4 *__restrict__ trig) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) trig[i] = device_trig(boxes[(size_t)i * 7 + 6]);
@@ -262,113 +263,6 @@ __global__ __launch_bounds__(NMS_TPB) void nms_tiles(int n, int cb, float thresh
     mask[(size_t)cur * cb + c] = w;
 }
 
-__global__ __launch_bounds__(NMS_TPB) void nms_reduce(int n, int cb, const unsigned long long *__restrict__ mask,
-                                                      long long *__restrict__ keep, int *__restrict__ num_keep) {
-    extern __shared__ unsigned long long removed[];   // cb running suppression words
-    const int lane = threadIdx.x;
-    for (int c = lane; c < cb; c += NMS_TPB) removed[c] = 0ULL;
-    __syncthreads();
-    int kept = 0;
-    for (int b = 0; b < cb; ++b) {
-        const int row = b * NMS_TPB + lane;
-        // suppression inside the block: lane i holds the diagonal word of row i (bits j > i only)
-        const unsigned long long diag = row < n ? mask[(size_t)row * cb + b] : 0ULL;
-        unsigned long long dead = removed[b];   // written by this wavefront in earlier iterations
-        const int rows = min(n - b * NMS_TPB, NMS_TPB);
-        if (rows < NMS_TPB) dead |= ~0ULL << rows;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        for (int i = 0; i < rows; ++i) {
-            if (!((dead >> i) & 1ULL)) {
-                const unsigned lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
-                dead |= ((unsigned long long)hi << 32) | lo;
-            }
-        }
-        const unsigned long long alive = ~dead & (rows < NMS_TPB ? ((1ULL << rows) - 1ULL) : ~0ULL);
-        // keep list (ascending) and the suppression of all later blocks by the surviving rows
-        if ((alive >> lane) & 1ULL) keep[kept + __popcll(alive & ((1ULL << lane) - 1ULL))] = row;
-        kept += __popcll(alive);
-        for (int c0 = b + 1; c0 < cb; c0 += NMS_TPB) {
-            const int c = c0 + lane;
-            unsigned long long acc = 0;
-            if (c < cb) {
-                unsigned long long m = alive;
-                while (m) {   // the loads of all surviving rows are independent: one latency, not 64
-                    const int i = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    acc |= mask[(size_t)(b * NMS_TPB + i) * cb + c];
-                }
-                removed[c] |= acc;
-            }
-        }
-        __syncthreads();   // `removed` is re-read by other lanes in the next iteration
-    }
-    if (lane == 0) *num_keep = kept;
-}
-
-// The same reduction for up to 4096 boxes (cb <= 64), four wavefronts: the words of block b+1's 64
-// rows are fetched into registers by all 256 threads while wavefront 0 resolves block b from the
-// slab that already sits in LDS, then parked in the other half of the LDS double buffer -- the
-// global latency of a block is hidden behind the previous block's chain.
-constexpr int NMS_RT = 256;
-__global__ __launch_bounds__(NMS_RT) void nms_reduce_lds(int n, int cb, const unsigned long long *__restrict__ mask,
-                                                         long long *__restrict__ keep, int *__restrict__ num_keep) {
-    __shared__ unsigned long long slab[2][NMS_TPB * NMS_TPB];   // [row in block][column block]
-    __shared__ unsigned long long removed[NMS_TPB];
-    const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int PER = NMS_TPB * NMS_TPB / NMS_RT;   // 16 words per thread
-    if (tid < NMS_TPB) removed[tid] = 0ULL;
-    unsigned long long pre[PER];
-    auto fetch = [&](int b) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = tid + k * NMS_RT, r = e / NMS_TPB, c = e % NMS_TPB;
-            const int row = b * NMS_TPB + r;
-            pre[k] = (b < cb && row < n && c >= b && c < cb) ? mask[(size_t)row * cb + c] : 0ULL;
-        }
-    };
-    auto park = [&](int b) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) slab[b & 1][tid + k * NMS_RT] = pre[k];
-    };
-    fetch(0);
-    park(0);
-    __syncthreads();
-    int kept = 0;
-    for (int b = 0; b < cb; ++b) {
-        fetch(b + 1);   // in flight during the chain below
-        if (tid < NMS_TPB) {
-            const unsigned long long *S = slab[b & 1];
-            const int row = b * NMS_TPB + lane;
-            const unsigned long long diag = S[lane * NMS_TPB + b];
-            unsigned long long dead = removed[b];
-            const int rows = min(n - b * NMS_TPB, NMS_TPB);
-            if (rows < NMS_TPB) dead |= ~0ULL << rows;
-            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            for (int i = 0; i < rows; ++i) {
-                if (!((dead >> i) & 1ULL)) {
-                    const unsigned lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
-                    dead |= ((unsigned long long)hi << 32) | lo;
-                }
-            }
-            const unsigned long long alive = ~dead & (rows < NMS_TPB ? ((1ULL << rows) - 1ULL) : ~0ULL);
-            if ((alive >> lane) & 1ULL) keep[kept + __popcll(alive & ((1ULL << lane) - 1ULL))] = row;
-            kept += __popcll(alive);
-            if (lane > b && lane < cb) {   // lane = later column block
-                unsigned long long acc = 0, m = alive;
-                while (m) {
-                    const int i = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    acc |= S[i * NMS_TPB + lane];
-                }
-                removed[lane] |= acc;
-            }
-        }
-        park(b + 1);
-        __syncthreads();
-    }
-    if (tid == 0) *num_keep = kept;
-}
-
 int pair_launch(bool iou, const float *a, int na, const float *b, int nb, float *out, void *stream) {
     MODEST_REQUIRE(na >= 0 && nb >= 0, "negative box count");
     if (na == 0 || nb == 0) return MODEST_OK;
@@ -395,16 +289,17 @@ int nms_impl(bool rotated, modest_ctx *ctx, const float *boxes, int n, float thr
     hipStream_t stream = as_stream(stream_);
     const int cb = (n + NMS_TPB - 1) / NMS_TPB;
     const size_t words = (size_t)n * cb;
-    MODEST_REQUIRE(cb <= 6144, "at most 393216 boxes (the running suppression words live in LDS)");
+    MODEST_REQUIRE(cb <= 6144, "at most 393216 boxes");
     const size_t trigB = arena_sz((size_t)n * 16), maskB = arena_sz(words * 8);
     int rc = modest_ctx_reserve(ctx, trigB + maskB);
     if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, (size_t)n * 8 + 64);
+    // the suppression words cross PCIe in chunks of whole rows (<= NMS_CHUNK_BYTES of pinned memory)
+    const size_t rowB = (size_t)cb * 8;
+    const int rowsPer = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, NMS_CHUNK_BYTES / rowB));
+    rc = modest_ctx_reserve_pinned(ctx, (size_t)rowsPer * rowB + 64);
     if (rc) return rc;
     float4 *trig = reinterpret_cast<float4 *>(ctx->scratch);
     unsigned long long *dmask = reinterpret_cast<unsigned long long *>(ctx->scratch + trigB);
-    int *hcount = reinterpret_cast<int *>(ctx->pinned);
-    long long *hkeep = reinterpret_cast<long long *>(ctx->pinned + 64);
     const long long tiles = (long long)cb * (cb + 1) / 2;
     MODEST_REQUIRE(tiles < (1LL << 31), "too many boxes");
     if (rotated) {
@@ -413,12 +308,24 @@ int nms_impl(bool rotated, modest_ctx *ctx, const float *boxes, int n, float thr
     } else {
         nms_tiles<false><<<(unsigned)tiles, NMS_TPB, 0, stream>>>(n, cb, thresh, boxes, trig, dmask);
     }
-    if (cb <= NMS_TPB) nms_reduce_lds<<<1, NMS_RT, 0, stream>>>(n, cb, dmask, hkeep, hcount);
-    else nms_reduce<<<1, NMS_TPB, (size_t)cb * 8, stream>>>(n, cb, dmask, hkeep, hcount);
     MODEST_HIP_CHECK(hipGetLastError());
-    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-    const int kept = *hcount;
-    for (int i = 0; i < kept; ++i) keep[i] = hkeep[i];
+    // src/iou3d_nms.cpp:116-135: box i survives unless an earlier survivor suppressed it; its row then
+    // suppresses later boxes (only the column blocks >= i / 64 exist: the tile grid is upper triangular)
+    unsigned long long *hmask = reinterpret_cast<unsigned long long *>(ctx->pinned + 64);
+    std::vector<unsigned long long> remv((size_t)cb, 0ULL);
+    int kept = 0;
+    for (int r0 = 0; r0 < n; r0 += rowsPer) {
+        const int r1 = std::min(n, r0 + rowsPer);
+        MODEST_HIP_CHECK(hipMemcpyAsync(hmask, dmask + (size_t)r0 * cb, (size_t)(r1 - r0) * rowB, hipMemcpyDeviceToHost, stream));
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int i = r0; i < r1; ++i) {
+            const int nb = i / NMS_TPB, inb = i % NMS_TPB;
+            if (remv[(size_t)nb] & (1ULL << inb)) continue;
+            keep[kept++] = i;
+            const unsigned long long *row = hmask + (size_t)(i - r0) * cb;
+            for (int j = nb; j < cb; ++j) remv[(size_t)j] |= row[j];
+        }
+    }
     *num_keep = kept;
     return MODEST_OK;
 }

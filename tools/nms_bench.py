@@ -10,7 +10,7 @@ def bench(path, tag):
     ctx = C.c_void_p()
     assert lib.modest_ctx_create(0, C.byref(ctx)) == 0
     rng = np.random.default_rng(0)
-    for n in (512, 2048, 4096, 5000):
+    for n in (512, 2048, 4096, 5000, 12000, 20000):
         side = 12.0 * np.sqrt(n / 300.0)
         big = np.c_[rng.uniform(-side, side, (n, 2)), np.zeros(n), rng.uniform(1, 5, (n, 2)), np.ones(n),
                     rng.uniform(-3.2, 3.2, n)].astype(np.float32)
@@ -24,11 +24,11 @@ def bench(path, tag):
             assert fn(ctx, b.data_ptr(), n, 0.1, keep.ctypes.data, C.byref(nk), None) == 0
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(20):
                 fn(ctx, b.data_ptr(), n, 0.1, keep.ctypes.data, C.byref(nk), None)
-            ms = (time.perf_counter() - t0) / 5 * 1e3
+            ms = (time.perf_counter() - t0) / 20 * 1e3
             ok = None
-            if n <= 2048 or n == 5000:
+            if n <= 2048 or n in (5000, 20000):
                 ok = bool(np.array_equal(keep[: nk.value], ol.nms(srt, 0.1, rotated=rotated)))
             print(f"[{tag}] n={n} rotated={rotated}: {ms:.3f} ms/call, kept {nk.value}, equals oracle: {ok}", flush=True)
 
