@@ -362,6 +362,51 @@ int modest_cluster_stats(modest_ctx *ctx, const float *pts_dev, int n, int strid
                          int n_clusters, const double *plane4_host,
                          double quantile, double *out_host, void *stream);
 
+/* ---- a15-a19, a21 the second half of a scan behind three calls (generate_mask.py:88-103,
+ * gen_label_files.py:44-52) ------------------------------------------------------------------------
+ * modest_scan_boxes: labels_inout [host] (n) int64 holds `labels_filtered` (0 = background, 1..n_lab, every
+ * label with members) and receives the final labels (generate_mask.py:100-103).  For every cluster: its
+ * rect-frame points (Calibration.project_velo_to_rect, kitti_util.py:327-329), the closeness fit
+ * (pointcloud_utils.py:167-216; 901 headings on the device, rectangle_at_angle's tail on the host),
+ * get_obj (:292-317) with the lowest point from the device, the volume gate (generate_mask.py:91-98).
+ * pts_dev / pts_host: the same (n,stride) float32 scan in both memories.  angles / cossin / cossin90 [host]:
+ * the caller's numpy tables (heading, (cos, sin) of it, (cos, sin) of heading + pi/2): the library takes
+ * no cosine of its own, so the host's numpy defines them as in the reference.
+ * objs_out [host] (n_lab,8) float64 rows {t0, t1, t2, l, w, h, ry, volume} of ALL clusters in label order,
+ * keep_out [host] (n_lab) int32 = passed the volume gate.  info_out[2]: {boxes kept, status}; status != 0:
+ * nothing was written, take the host statement (1: a cluster too large for the extents kernel, 2: a box
+ * footprint without any scan point -- numpy raises there).  Blocking (two round trips).               */
+typedef struct modest_boxes_params {
+    double V2C[12], R0[9];          /* Calibration, row major 3x4 / 3x3                                  */
+    const double *angles;           /* (n_angles) headings of closeness_rectangle (:170-175)             */
+    const double *cossin;           /* (n_angles,2)                                                      */
+    const double *cossin90;         /* (n_angles,2) of heading + pi/2                                    */
+    int32_t n_angles;
+    double d0;                      /* closeness criterion floor (1e-2)                                  */
+    double min_volume, max_volume;  /* filtering.min_volume / max_volume                                 */
+} modest_boxes_params;
+int modest_scan_boxes(modest_ctx *ctx, const float *pts_dev, const float *pts_host, int n, int stride,
+                      int64_t *labels_inout_host, int n_lab, const modest_boxes_params *params,
+                      double *objs_out_host, int32_t *keep_out_host, int32_t *info_out_host, void *stream);
+/* objs_nms' boxes [t0, t2, 0, l, w, h, -ry] as float32 (pointcloud_utils.py:322-324) and their BEV IoU
+ * matrix (iou3d_nms_utils.boxes_iou_bev) -> iou_out [host] (k,k) float32.  Blocking.                  */
+int modest_objs_iou(modest_ctx *ctx, const double *objs8_host, int k, float *iou_out_host, void *stream);
+/* objs_nms' greedy walk (pointcloud_utils.py:329-343) in the caller's `order` -- the reference's
+ * np.diag(iou).argsort()[::-1], a numpy call whose tie order is numpy's own --, is_within_fov (:373-379),
+ * objs2label (:347-370).  cossin_ry [host] (k,2) = numpy's (cos, sin) of every obj.ry (roty, kitti_util.py:
+ * 383-389).  kept_out [host] (k) int32: indices of the boxes written, text_out: the label file's text
+ * (lines joined by '\n', no trailing newline, fields %.4f).  Pure host code, no context.               */
+typedef struct modest_labels_params {
+    double P[12];                   /* Calibration.P (P2), row major 3x4                                 */
+    int32_t nms_enable;
+    float nms_threshold;
+    int32_t fov_only;
+    double image_h, image_w;        /* image_shape = [h, w]                                              */
+} modest_labels_params;
+int modest_label_lines(const double *objs8_host, const double *cossin_ry_host, int k, const int64_t *order_host,
+                       const float *iou_host, const modest_labels_params *params, int32_t *kept_out_host,
+                       int32_t *n_kept_out_host, char *text_out_host, int32_t text_cap, int32_t *text_len_out_host);
+
 /* ---- §8f-2 combine_labels.py: filter_by_ppscore (combine_labels.py:41-60) -------
  * For each detector box the reference masks the scan's rect-frame points (offsets from the box
  * centre rotated into the box frame by `ptc_xz @ rot.T`, strict half-extent tests in x and z,

@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from . import config, dist
+from . import config, dist, ops
 from .utils import kitti_util
 from .utils.pointcloud_utils import is_within_fov, objs2label, objs_nms
 
@@ -33,11 +33,30 @@ def display_args(args):
     eprint("==========================================")
 
 
+NATIVE_LABELS = True   # tests switch it off to compare the library's label stage with the Python statement
+
+
 def gen_label_scan(objs, calib, args, after_device=None):
     """gen_label_files.py:44-52 for one scan -> (label text, kept objs).
     ``after_device`` (optional callable) runs as soon as the stage has no device work left -- its only
     device call is the IoU matrix of the NMS; a pipeline uses it to enqueue the next scan's device work
     under the host tail of this one (greedy NMS, FOV filter, label text)."""
+    if NATIVE_LABELS:
+        # the float32 boxes + IoU matrix (device), ONE numpy call for the order of the walk (its tie order is
+        # numpy's: SURVEY H6), then greedy walk + FOV filter + label text in the library
+        rows = objs if isinstance(objs, np.ndarray) else \
+            np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs], dtype=np.float64).reshape(-1, 8)
+        nms = bool(args.nms.enable) and len(rows) > 0
+        iou = ops.objs_iou(rows) if nms else None
+        if after_device is not None:
+            after_device()
+        order = np.diag(iou).argsort()[::-1] if nms else None
+        text, kept = ops.label_lines(rows, order, iou, calib.P, nms, args.nms.threshold if nms else 0.0,
+                                     bool(args.fov_only), args.image_shape)
+        return text, (rows[kept] if isinstance(objs, np.ndarray) else [objs[i] for i in kept])
+    if isinstance(objs, np.ndarray):
+        from .generate_mask import objs_from_rows
+        objs = objs_from_rows(objs)
     if args.nms.enable and len(objs) > 0:
         objs = objs_nms(objs, nms_threshold=args.nms.threshold, after_device=after_device)
     elif after_device is not None:

@@ -35,15 +35,29 @@ def display_args(args):
     eprint("=====================================")
 
 
+def objs_from_rows(rows):
+    """(k,8) rows {t0, t1, t2, l, w, h, ry, volume} -> the reference's SimpleNamespace objects (get_obj,
+    pointcloud_utils.py:292-317; what bbox_info_save_dst pickles hold)."""
+    import types
+    out = []
+    for r in rows:
+        o = types.SimpleNamespace()
+        o.t = np.array([r[0], r[1], r[2]])
+        o.l, o.w, o.h, o.ry, o.volume = r[3], r[4], r[5], r[6], r[7]    # numpy float64 scalars, as in the reference
+        out.append(o)
+    return out
+
+
 def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=None, ptc_dev=None,
-                       pp_dev=None):
+                       pp_dev=None, as_rows=False):
     """The body of the reference's per-scan loop (generate_mask.py:52-103).
 
     ptc (N,4) float32 numpy, pp_score (N,) float32 numpy, calib a Calibration.
     ``random_state`` feeds both RANSAC calls in order (the reference consumes
     numpy's global stream in that order); ``planes`` = (plane1, plane2) injects
     the two ground planes instead (stage-wise parity tests).
-    Returns (labels (N,) int64 with 0 = background, objs list, info dict)."""
+    Returns (labels (N,) int64 with 0 = background, objs list, info dict); ``as_rows``: the boxes as a
+    (k,8) float64 array {t0, t1, t2, l, w, h, ry, volume} instead of objects (in-memory pipelines)."""
     pe = args.plane_estimate
     ptc_dev = to_device(ptc) if ptc_dev is None else ptc_dev   # (N,4) float32 resident copy
     pp_dev = to_device(pp_score) if pp_dev is None else pp_dev
@@ -65,6 +79,18 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     else:
         labels_filtered, plane, n_kept = _mask_stage_host(ptc, pp_score, args, random_state, planes, ptc_dev, pp_dev)
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
+    lo, hi = args.filtering.min_volume, args.filtering.max_volume
+    if NATIVE_BOXES and n_lab and args.bbox_gen.fit_method == "closeness_to_edge" and ptc.dtype == np.float32 \
+            and ptc.flags.c_contiguous:
+        # members, rect points, closeness fit, get_obj, volume gate and relabelling behind one library call
+        from .utils.pointcloud_utils import _angles, _angles90
+        ang, cs = _angles(0.1)
+        done = ops.scan_boxes(ptc_dev, ptc, labels_filtered, n_lab, calib.V2C, calib.R0, ang, cs, _angles90(0.1), 1e-2,
+                              lo, hi)
+        if done is not None:
+            labels_final, rows, keep = done
+            rows = rows[keep]
+            return labels_final, (rows if as_rows else objs_from_rows(rows)), dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
     order, cuts = members_sorted(labels_filtered, n_lab)
     # rect-frame points: the clusters' rows on the host (per-cluster numpy arithmetic of get_obj), the whole
     # scan on the device, where the lowest-point search reads it (same rounding: one fma chain per element)
@@ -75,14 +101,16 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     else:
         clusters, rect_dev = [], None
     cand = get_objs(clusters, rect_dev, fit_method=args.bbox_gen.fit_method)
-    lo, hi = args.filtering.min_volume, args.filtering.max_volume
     keep = [bool(obj.volume > lo and obj.volume < hi) for obj in cand]
     objs = [obj for obj, k in zip(cand, keep) if k]
     labels_filtered = relabel_after_drop(labels_filtered, n_lab, keep) if n_lab else compact_labels(labels_filtered)
+    if as_rows:
+        objs = np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs], dtype=np.float64).reshape(-1, 8)
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
 
 
 NATIVE_STAGE = True   # tests switch it off to compare the library's stage driver with the Python statement
+NATIVE_BOXES = True   # ... and the library's box tail (modest_scan_boxes) with get_objs + the volume gate
 
 
 def _stage_params(args) -> "ops.MaskParams":

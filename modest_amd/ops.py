@@ -420,6 +420,89 @@ def mask_stage(pts: torch.Tensor, pp: torch.Tensor, params: MaskParams, rs: np.r
     return labels, plane1, plane2, info
 
 
+class BoxesParams(C.Structure):
+    """modest_boxes_params (include/modest_hip.h)"""
+    _fields_ = [("V2C", C.c_double * 12), ("R0", C.c_double * 9), ("angles", C.c_void_p), ("cossin", C.c_void_p),
+                ("cossin90", C.c_void_p), ("n_angles", C.c_int32), ("d0", C.c_double), ("min_volume", C.c_double),
+                ("max_volume", C.c_double)]
+
+
+class LabelsParams(C.Structure):
+    """modest_labels_params (include/modest_hip.h)"""
+    _fields_ = [("P", C.c_double * 12), ("nms_enable", C.c_int32), ("nms_threshold", C.c_float), ("fov_only", C.c_int32),
+                ("image_h", C.c_double), ("image_w", C.c_double)]
+
+
+def scan_boxes(pts_dev: torch.Tensor, pts_host: np.ndarray, labels_filtered: np.ndarray, n_lab: int, V2C, R0,
+               angles: np.ndarray, cossin: np.ndarray, cossin90: np.ndarray, d0: float, min_volume: float,
+               max_volume: float, ctx: Optional[Context] = None):
+    """The box tail of generate_mask.py:88-103 behind one library call (modest_scan_boxes): members, rect
+    points, closeness fit, get_obj, volume gate, relabelling.  Returns None when the library hands the scan
+    back to the host statement, else (final labels (n,) int64, objs (n_lab,8) float64 rows
+    {t0, t1, t2, l, w, h, ry, volume}, keep (n_lab,) bool)."""
+    lib = load()
+    _dev(pts_dev, torch.float32, "pts")
+    assert pts_host.dtype == np.float32 and pts_host.flags.c_contiguous and pts_host.shape == tuple(pts_dev.shape)
+    n = pts_host.shape[0]
+    P = BoxesParams()
+    P.V2C[:] = [float(x) for x in np.asarray(V2C, dtype=np.float64).reshape(12)]
+    P.R0[:] = [float(x) for x in np.asarray(R0, dtype=np.float64).reshape(9)]
+    assert angles.dtype == np.float64 and cossin.dtype == np.float64 and cossin90.dtype == np.float64
+    assert cossin.flags.c_contiguous and cossin90.flags.c_contiguous and angles.flags.c_contiguous
+    P.angles, P.cossin, P.cossin90, P.n_angles = _np_ptr(angles), _np_ptr(cossin), _np_ptr(cossin90), angles.shape[0]
+    P.d0, P.min_volume, P.max_volume = float(d0), float(min_volume), float(max_volume)
+    labels = np.ascontiguousarray(labels_filtered, dtype=np.int64).copy()
+    objs = np.zeros((max(n_lab, 1), 8), dtype=np.float64)
+    keep = np.zeros(max(n_lab, 1), dtype=np.int32)
+    info = np.zeros(2, dtype=np.int32)
+    c = _ctx(ctx, pts_dev)
+    check(lib.modest_scan_boxes(c.handle, pts_dev.data_ptr(), _np_ptr(pts_host), n, pts_host.shape[1], _np_ptr(labels),
+                                int(n_lab), C.byref(P), _np_ptr(objs), _np_ptr(keep), _np_ptr(info), _stream()),
+          "modest_scan_boxes")
+    if info[1] != 0:
+        return None
+    return labels, objs[:n_lab], keep[:n_lab].astype(bool)
+
+
+def objs_iou(objs8: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
+    """BEV IoU matrix (k,k) float32 of objs_nms' float32 boxes (modest_objs_iou)."""
+    lib = load()
+    objs8 = np.ascontiguousarray(objs8, dtype=np.float64).reshape(-1, 8)
+    k = objs8.shape[0]
+    out = np.zeros((k, k), dtype=np.float32)
+    if k:
+        c = ctx if ctx is not None else default_context(torch.cuda.current_device())
+        check(lib.modest_objs_iou(c.handle, _np_ptr(objs8), k, _np_ptr(out), _stream()), "modest_objs_iou")
+    return out
+
+
+def label_lines(objs8: np.ndarray, order: Optional[np.ndarray], iou: Optional[np.ndarray], P34, nms_enable: bool,
+                nms_threshold: float, fov_only: bool, image_shape) -> tuple:
+    """objs_nms' greedy walk in `order`, is_within_fov, objs2label (modest_label_lines): (text, kept indices)."""
+    lib = load()
+    objs8 = np.ascontiguousarray(objs8, dtype=np.float64).reshape(-1, 8)
+    k = objs8.shape[0]
+    if k == 0:
+        return "", np.zeros(0, dtype=np.int32)
+    cs = np.ascontiguousarray(np.stack([np.cos(objs8[:, 6]), np.sin(objs8[:, 6])], axis=1))   # numpy's roty values
+    Q = LabelsParams()
+    Q.P[:] = [float(x) for x in np.asarray(P34, dtype=np.float64).reshape(12)]
+    Q.nms_enable, Q.nms_threshold, Q.fov_only = int(bool(nms_enable)), float(nms_threshold), int(bool(fov_only))
+    Q.image_h, Q.image_w = float(image_shape[0]), float(image_shape[1])
+    if nms_enable:
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        iou = np.ascontiguousarray(iou, dtype=np.float32)
+        assert order.shape == (k,) and iou.shape == (k, k)
+    kept = np.zeros(k, dtype=np.int32)
+    nk, tl = C.c_int32(0), C.c_int32(0)
+    cap = 256 * k + 16
+    buf = C.create_string_buffer(cap)
+    check(lib.modest_label_lines(_np_ptr(objs8), _np_ptr(cs), k, _np_ptr(order) if nms_enable else None,
+                                 _np_ptr(iou) if nms_enable else None, C.byref(Q), _np_ptr(kept), C.byref(nk), buf, cap,
+                                 C.byref(tl)), "modest_label_lines")
+    return buf.raw[: tl.value].decode("ascii"), kept[: nk.value]
+
+
 def cluster_stats(pts: torch.Tensor, pp: torch.Tensor, labels: torch.Tensor, n_clusters: int,
                   plane: np.ndarray, quantile: float, ctx: Optional[Context] = None) -> np.ndarray:
     """Per-cluster (count, min dist, max dist, a, b, gamma) for is_valid_cluster; (C,6) float64 host."""

@@ -181,15 +181,17 @@ def test_scan_pipeline_equals_oracle_on_synthetic_scans(gpu, case):
 
 
 def test_library_stage_driver_equals_python_statement(gpu):
-    """modest_mask_stage (both RANSAC fits, mask, graph + DBSCAN, cluster statistics, validity rules and
-    relabelling behind one library call) against the Python statement of the same steps: labels, boxes,
+    """The WHOLE scan in the library -- modest_mask_stage (both RANSAC fits, mask, graph + DBSCAN, cluster
+    statistics, validity rules, relabelling), modest_scan_boxes (members, rect points, box fit, get_obj, volume
+    gate, final labels), modest_objs_iou + modest_label_lines (NMS walk, FOV filter, label text) -- against the
+    Python statement of the same steps: labels, boxes,
     label text AND the generator state after the scan (the CLI keeps one stream per scan; the reference
     its global one) -- Lyft and nuScenes-style configurations, several scans and seeds, the global
     generator, and an input the library hands back (a tiny scan)."""
     import os
     import tempfile
     import torch
-    from modest_amd import config, generate_mask as gm, synth
+    from modest_amd import config, generate_mask as gm, gen_label_files as glf, synth
     from modest_amd.gen_label_files import gen_label_scan
     from modest_amd.utils import kitti_util
     with tempfile.TemporaryDirectory() as d:
@@ -209,7 +211,7 @@ def test_library_stage_driver_equals_python_statement(gpu):
         margs = cfgs[k % 2]
         out = []
         for native in (True, False):
-            gm.NATIVE_STAGE = native
+            gm.NATIVE_STAGE = gm.NATIVE_BOXES = glf.NATIVE_LABELS = native
             try:
                 if k == 5:    # the reference's own mode: numpy's global generator
                     np.random.seed(77)
@@ -221,7 +223,7 @@ def test_library_stage_driver_equals_python_statement(gpu):
                 st = (np.random.mtrand._rand if rs is None else rs).get_state()
                 out.append((labels, [(*o.t, o.l, o.w, o.h, o.ry, o.volume) for o in objs], text, info["plane"], st))
             finally:
-                gm.NATIVE_STAGE = True
+                gm.NATIVE_STAGE = gm.NATIVE_BOXES = glf.NATIVE_LABELS = True
         a, b = out
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], k
         assert np.array_equal(a[3], b[3])
@@ -328,3 +330,55 @@ def test_pp_cli_non_default_branches(gpu, golden_dir, tmp_path):
         assert sorted(comb) == [int(k) for k in g[f"lidar_keys_{o}"]]
         for k in comb:
             assert comb[k].dtype == np.float32 and np.array_equal(comb[k], g[f"lidar_{o}_{k}"]), (o, k)
+
+
+def test_native_box_and_label_stage_many_scans(gpu):
+    """modest_scan_boxes / modest_objs_iou / modest_label_lines against the Python statement (get_objs, the
+    volume gate, relabel_after_drop, objs_nms, is_within_fov, objs2label) on 40 scans with the mask stage
+    shared: boxes field by field, final labels, the boxes NMS + FOV keep, label text; row mode == object mode."""
+    import os
+    import tempfile
+    import torch
+    from modest_amd import config, generate_mask as gm, gen_label_files as glf, synth
+    from modest_amd.utils import kitti_util
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
+        calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
+    largs = [config.compose("generate_label_files", ["data_root=/unused"]),
+             config.compose("generate_label_files", ["data_root=/unused", "image_shape=[900,1600]", "nms.threshold=0.3"]),
+             config.compose("generate_label_files", ["data_root=/unused", "fov_only=False", "nms.enable=False"])]
+    margs = config.compose("generate_mask", ["data_root=/unused"])
+    rng = np.random.default_rng(3)
+    n_boxes = n_lines = 0
+    worst = 0.0
+    for k in range(40):
+        sc = synth.make_scan(300 + k, n_live=int(rng.choice([8000, 20000, 30000])), n_trav=2, n_frames=1)
+        raw = np.ascontiguousarray(sc.live_raw)
+        pp = np.clip(0.45 + 0.5 * np.sin(raw[:, 0] * 0.3 + k) + rng.normal(0, 0.05, len(raw)), 0, 1).astype(np.float32)
+        dev, ppd = torch.from_numpy(raw).to(gpu), torch.from_numpy(pp).to(gpu)
+        res = []
+        for native in (True, False):
+            gm.NATIVE_BOXES = glf.NATIVE_LABELS = native
+            try:
+                labels, objs, _ = gm.generate_mask_scan(raw, pp, calib, margs, random_state=np.random.RandomState(k),
+                                                        ptc_dev=dev, pp_dev=ppd)
+                text, kept = glf.gen_label_scan(objs, calib, largs[k % 3])
+                res.append((labels, np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs]).reshape(-1, 8), text,
+                            np.array([[*o.t, o.l] for o in kept]).reshape(-1, 4)))
+            finally:
+                gm.NATIVE_BOXES = glf.NATIVE_LABELS = True
+        a, b = res
+        assert np.array_equal(a[0], b[0]) and a[1].shape == b[1].shape, k
+        if a[1].size:
+            worst = max(worst, float(np.max(np.abs(a[1] - b[1]) / np.maximum(np.abs(b[1]), 1e-6))))
+        assert np.allclose(a[1], b[1], rtol=1e-12, atol=1e-13), (k, np.abs(a[1] - b[1]).max())
+        assert a[2] == b[2] and np.allclose(a[3], b[3], rtol=1e-12, atol=1e-13), k
+        # row mode (what an in-memory pipeline uses) gives the same text
+        labels_r, rows, _ = gm.generate_mask_scan(raw, pp, calib, margs, random_state=np.random.RandomState(k),
+                                                   ptc_dev=dev, pp_dev=ppd, as_rows=True)
+        assert isinstance(rows, np.ndarray) and np.array_equal(rows, a[1]) and np.array_equal(labels_r, a[0])
+        assert glf.gen_label_scan(rows, calib, largs[k % 3])[0] == a[2]
+        n_boxes += len(a[1])
+        n_lines += len(a[2].splitlines())
+    print("boxes", n_boxes, "label lines", n_lines, "largest relative difference", worst)
+    assert n_boxes >= 200 and n_lines >= 40
