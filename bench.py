@@ -237,8 +237,11 @@ class Runner:
         if a.pp_only:
             return H, None, None, None, None
         pp_host = H.cpu().numpy()
+        # boxes stay (k,8) rows between the stages: the SimpleNamespace objects of the reference exist for its
+        # pickle files, which the CLIs write and this in-memory pipeline does not
         labels, objs, _ = self._generate_mask_scan(sc.live_host, pp_host, sc.calib, self.margs,
-                                                   random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H)
+                                                   random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H,
+                                                   as_rows=True)
         ahead = []
         hook = None
         if next_i is not None and self.prefetch:
@@ -436,9 +439,11 @@ def cli_bench(a, local):
         out["workers"] = W
         out["pp_scans_per_s_workers"] = pp("W", W)
         out["mask_scans_per_s_workers"] = mask("W", W)
-        same = all(open(f"{root}/seg1/{f}", "rb").read() == open(f"{root}/segW/{f}", "rb").read()
-                   for f in os.listdir(f"{root}/seg1") if f.endswith(".npy"))
-        out["workers_outputs_identical"] = bool(same)
+        diff = [f for f in sorted(os.listdir(f"{root}/seg1")) if f.endswith(".npy") and
+                open(f"{root}/seg1/{f}", "rb").read() != open(f"{root}/segW/{f}", "rb").read()]
+        out["workers_outputs_identical"] = not diff
+        if diff:
+            out["workers_outputs_differing"] = diff[:8]
     out["scans"] = n_scan
     out["note"] = (f"{n_scan} live scans x {T} traversals x {F} frames of {a.n_live} points, one GPU, tree on "
                    + (base or "the default tmp dir") + "; cold: the first scan of a process uploads and sorts all 361 "

@@ -273,9 +273,11 @@ __global__ __launch_bounds__(256) void closeness_tree_kernel(const double *__res
     }
     // the block that finishes a cluster last picks the angle (tickets: one word per cluster, left at zero)
     // (no __threadfence(): on this multi-XCD part it writes back / invalidates a whole L2; the betas are
-    // agent-scope write-through stores that the barrier waits for, the last block reads them the same way)
+    // agent-scope write-through stores, drained by every wavefront before the barrier (common.h), the last
+    // block reads them with agent-scope loads)
     if (!tickets) return;
     __shared__ unsigned last_s;
+    modest_drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(tickets + c, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__
         for (int k = 1; k < 16; ++k) best = fmax(best, red[k]);
         __hip_atomic_store(partial + (size_t)blockIdx.y * LOW_SPLIT + blockIdx.x, best, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the write-through store has completed
+        modest_drain_stores();   // the write-through store has landed before the ticket
         if (atomicAdd(tickets + blockIdx.y, 1u) == LOW_SPLIT - 1) {
             double m = -INFINITY;
             for (int k = 0; k < LOW_SPLIT; ++k)

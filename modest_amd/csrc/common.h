@@ -17,6 +17,17 @@
 #error "libmodest_hip is written for gfx950 only: its last-block reductions rely on gfx950's write-through sc1 stores"
 #endif
 
+// ... and the publishing side must DRAIN its write-through stores before the workgroup barrier that precedes
+// the ticket: __syncthreads() does not wait for global stores (hipcc emits `s_waitcnt lgkmcnt(0); s_barrier`
+// there), so a ticket taken by wavefront 0 could overtake the partial results of wavefronts 1..3 -- found in
+// round 3 as 11 differing results in 14 400 repeated scans under an 8-process load (tools/soak_mask.py).  Inline
+// asm because the compiler drops a redundant-looking s_waitcnt (MI355X_MICROARCH.md, compiler hazard).
+__device__ __forceinline__ void modest_drain_stores() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 constexpr int MODEST_STAGE_SLOTS = 8;
 
 struct modest_ctx {

@@ -453,12 +453,13 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
         double s = 0.0;
         for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][kk][q];
         __hip_atomic_store(row + 4 * (k0 + kk) + q, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        modest_drain_stores();
     }
     // The block that finishes last (ticket, left at zero) adds the partial rows, one output per thread in
     // row order (consecutive threads read consecutive words), and writes the totals.  No __threadfence():
     // on this multi-XCD part it writes back / invalidates a whole L2.  The partial rows are agent-scope
-    // atomic stores (write-through) that the barrier waits for; the last block reads them with
-    // agent-scope loads, eight in flight per thread.
+    // atomic stores (write-through), drained by the storing wavefronts before the barrier (common.h); the
+    // last block reads them with agent-scope loads, eight in flight per thread.
     __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
     __syncthreads();
@@ -542,8 +543,9 @@ __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__res
         for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][threadIdx.x];
         __hip_atomic_store(partial + (size_t)blockIdx.x * REFIT_NV + threadIdx.x, s, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+        modest_drain_stores();   // the write-through stores have landed before the ticket (no __threadfence(): see score_kernel)
     }
-    __syncthreads();   // waits for the write-through stores above (no __threadfence(): see score_kernel)
+    __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!last_s || w != 0) return;

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Hashable, List, Optional, Sequence, Tuple
@@ -78,11 +79,13 @@ class FrameStore:
         self.ntf = int(load().modest_frame_table_tiles())
         self.hits = self.misses = 0
         self.ctx = ctx
+        self.lock = threading.RLock()   # an ingest thread inserts while the compute loop describes scans
         # slot tables: the static part of every frame's descriptor, gathered per scan by fancy indexing
         self._rec = np.zeros(1024, dtype=PP_FRAME)
         self._W = np.zeros((1024, 4, 4))
         self._clean = np.zeros(1024, dtype=bool)   # no point outside the table
         self._free: List[int] = list(range(1023, -1, -1))
+        self._slot_index = np.full(1 << 16, -1, dtype=np.int64)   # integer key -> slot (-1: not resident)
 
     # ------------------------------------------------------------------ lattice
     def lattice_rows(self, M44: np.ndarray) -> np.ndarray:
@@ -118,23 +121,29 @@ class FrameStore:
         ones are inserted; evicting them would also hand their slots, which the scan's descriptor table
         names, to other frames).  A scan whose own working set exceeds the capacity simply overshoots it."""
         seen, todo = set(), []
-        for it in items:
-            if it[0] not in self.frames and it[0] not in seen:
-                seen.add(it[0])
-                todo.append(it)
+        with self.lock:
+            for it in items:
+                if it[0] not in self.frames and it[0] not in seen:
+                    seen.add(it[0])
+                    todo.append(it)
+            if todo and self.anchor is None:
+                self.anchor = np.floor(np.asarray(todo[0][2], dtype=np.float64)[:3, 3])
         if not todo:
             return
         lib = load()
-        if self.anchor is None:
-            self.anchor = np.floor(np.asarray(todo[0][2], dtype=np.float64)[:3, 3])
         jobs = (SortJob * len(todo))()
         made = []
+        # one allocation per output kind for the whole batch (frames are views: three allocator calls instead
+        # of three per frame; a block lives as long as any of its frames)
+        tw = self.ntf * self.ntf + 1
+        offs = np.cumsum([0] + [int(raw.shape[0]) for _, raw, _ in todo])
+        xyz_all = torch.empty((int(offs[-1]), 3), dtype=torch.float32, device=self.device)
+        perm_all = torch.empty((int(offs[-1]),), dtype=torch.int32, device=self.device)
+        tab_all = torch.empty((len(todo), tw), dtype=torch.int32, device=self.device)
         for k, (key, raw, W) in enumerate(todo):
             assert raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous() and raw.ndim == 2
             n = int(raw.shape[0])
-            xyz = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-            perm = torch.empty((n,), dtype=torch.int32, device=self.device)
-            tab = torch.empty((self.ntf * self.ntf + 1,), dtype=torch.int32, device=self.device)
+            xyz, perm, tab = xyz_all[offs[k]:offs[k + 1]], perm_all[offs[k]:offs[k + 1]], tab_all[k]
             TX0, TY0 = self._table_origin(W)
             j = jobs[k]
             j.raw_dev, j.n, j.stride, j.TX0, j.TY0 = raw.data_ptr(), n, int(raw.shape[1]), TX0, TY0
@@ -144,36 +153,46 @@ class FrameStore:
         inside = (C.c_int32 * len(todo))()
         check(lib.modest_frame_sort(self._ctx(ctx).handle, jobs, len(todo), inside,
                                     torch.cuda.current_stream().cuda_stream), "modest_frame_sort")
-        for k, (key, xyz, perm, tab, n, TX0, TY0, W) in enumerate(made):
-            sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, int(inside[k]), W, self._take_slot())
-            r = self._rec[sf.slot]
-            r["xyz_dev"], r["tab_dev"], r["n"], r["TX0"], r["TY0"] = xyz.data_ptr(), tab.data_ptr(), n, TX0, TY0
-            self._W[sf.slot] = W
-            self._clean[sf.slot] = sf.n_inside == n
-            self.frames[key] = sf
-            self.bytes += sf.nbytes
-        if self.bytes > self.cap:
-            keep = set(protect) if protect is not None else set()
-            keep.update(k for k, *_ in made)
-            for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first
-                if self.bytes <= self.cap:
-                    break
-                old = self.frames.pop(key)
-                self.bytes -= old.nbytes
-                self._free.append(old.slot)
+        with self.lock:
+            for k, (key, xyz, perm, tab, n, TX0, TY0, W) in enumerate(made):
+                sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, int(inside[k]), W, self._take_slot())
+                r = self._rec[sf.slot]
+                r["xyz_dev"], r["tab_dev"], r["n"], r["TX0"], r["TY0"] = xyz.data_ptr(), tab.data_ptr(), n, TX0, TY0
+                self._W[sf.slot] = W
+                self._clean[sf.slot] = sf.n_inside == n
+                self.frames[key] = sf
+                self.bytes += sf.nbytes
+                if isinstance(key, (int, np.integer)) and key >= 0:
+                    if key >= self._slot_index.shape[0]:
+                        grown = np.full(max(2 * self._slot_index.shape[0], int(key) + 1), -1, dtype=np.int64)
+                        grown[: self._slot_index.shape[0]] = self._slot_index
+                        self._slot_index = grown
+                    self._slot_index[key] = sf.slot
+            if self.bytes > self.cap:
+                keep = set(protect) if protect is not None else set()
+                keep.update(k for k, *_ in made)
+                for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first
+                    if self.bytes <= self.cap:
+                        break
+                    old = self.frames.pop(key)
+                    self.bytes -= old.nbytes
+                    self._free.append(old.slot)
+                    if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
+                        self._slot_index[key] = -1
 
     def insert(self, key, raw: torch.Tensor, W: np.ndarray) -> StoredFrame:
         self.insert_many([(key, raw, W)])
         return self.frames[key]
 
     def get(self, key) -> Optional[StoredFrame]:
-        f = self.frames.get(key)
-        if f is not None:
-            self.frames.move_to_end(key)
-            self.hits += 1
-        else:
-            self.misses += 1
-        return f
+        with self.lock:
+            f = self.frames.get(key)
+            if f is not None:
+                self.frames.move_to_end(key)
+                self.hits += 1
+            else:
+                self.misses += 1
+            return f
 
     def __contains__(self, key) -> bool:
         return key in self.frames
@@ -187,17 +206,33 @@ class FrameStore:
         dev = np.abs(D[:, :2, :3]).sum(axis=2) * reach + np.abs(D[:, :2, 3])
         return bool(np.all(np.isfinite(dev)) and dev.max() < tol)
 
+    def slots_of(self, keys) -> np.ndarray:
+        """slot of every key (call under the lock); small non-negative integer keys (file ids) go through an
+        index array instead of one dictionary look-up each"""
+        if len(keys) and isinstance(keys[0], (int, np.integer)):
+            k = np.asarray(keys, dtype=np.int64)
+            if k.min() >= 0 and k.max() < self._slot_index.shape[0]:
+                s = self._slot_index[k]
+                if (s >= 0).all():
+                    return s
+        return np.fromiter((self.frames[k].slot for k in keys), dtype=np.int64, count=len(keys))
+
+    def points_of(self, keys) -> int:
+        with self.lock:
+            return int(self._rec["n"][self.slots_of(list(keys))].sum()) if len(keys) else 0
+
     def describe(self, live_key, live_rel: np.ndarray, hist_keys: Sequence[Hashable], travs: Sequence[int],
                  rels: np.ndarray, remove_center: bool = False):
         """Descriptor table of a scan: (live record (1,), history records (F,), slots (F+1,))."""
-        slots = np.fromiter((self.frames[k].slot for k in hist_keys), dtype=np.int64, count=len(hist_keys))
-        arr = self._rec[slots] if len(slots) else np.zeros(1, dtype=PP_FRAME)
+        with self.lock:
+            slots = self.slots_of(hist_keys) if len(hist_keys) else np.zeros(0, dtype=np.int64)
+            arr = self._rec[slots] if len(slots) else np.zeros(1, dtype=PP_FRAME)
+            lslot = self.frames[live_key].slot
+            lv = self._rec[[lslot]]
         if len(slots):
             arr["trav"] = np.asarray(travs, dtype=np.int32)
             arr["flags"] = REMOVE_CENTER if remove_center else 0
             arr["rel"] = np.asarray(rels, dtype=np.float32).reshape(len(slots), 4, 4)[:, :3, :].reshape(len(slots), 12)
-        lslot = self.frames[live_key].slot
-        lv = self._rec[[lslot]]
         lv["rel"] = np.asarray(live_rel, dtype=np.float32).reshape(4, 4)[:3, :].reshape(1, 12)
         return lv, arr, np.concatenate([slots, [lslot]])
 

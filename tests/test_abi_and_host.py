@@ -237,3 +237,35 @@ def test_frame_store_eviction_protects_the_scan(monkeypatch):
         st.bytes -= old.nbytes
         st._free.append(old.slot)
     assert list(st.frames) == [0, 1, 9] and st._free == [2]      # 2 went, although 0 and 1 were older
+
+
+def test_batched_relative_poses_equal_per_frame_calls(golden_dir):
+    """relative_poses (one gesv per nesting level with all frames' columns as right-hand sides) is bit-identical
+    to get_relative_pose called per frame (pre_compute_pp_score.py:27-28; what the reference's loop does), also
+    on the reference-generated pose fixture, for both KITTI2NU matrices."""
+    from scipy.spatial.transform import Rotation as R
+    from modest_amd import pre_compute_pp_score as pcs
+    rng = np.random.default_rng(9)
+
+    def pose(scale):
+        t = np.eye(4)
+        t[:3, :3] = R.from_euler("xyz", np.r_[rng.uniform(-0.05, 0.05, 2), rng.uniform(-3.1, 3.1)]).as_matrix()
+        t[:3, 3] = rng.uniform(-scale, scale, 3)
+        return t.astype(np.float32)
+    for K in (pcs._KITTI2NU_lyft, pcs._KITTI2NU_nusc):
+        for trial in range(20):
+            fe, fl = pose(2000.0), pose(2.0)
+            qs = [(pose(2000.0), pose(2.0)) for _ in range(int(rng.integers(1, 400)))]
+            W = np.stack([qe @ ql @ K for qe, ql in qs])
+            got = pcs.relative_poses(fl, fe, W, K)
+            ref = np.stack([pcs.get_relative_pose(fl, fe, ql, qe, K) for qe, ql in qs])
+            assert got.dtype == np.float32 and np.array_equal(got, ref), trial
+    g = np.load(os.path.join(golden_dir, "pose.npz"))
+    for i in range(len(g["fixed_ego"])):
+        W = (g["query_ego"][i] @ g["query_l2e"][i] @ pcs._KITTI2NU_lyft)[None]
+        assert np.array_equal(pcs.relative_poses(g["fixed_l2e"][i], g["fixed_ego"][i], W, pcs._KITTI2NU_lyft)[0],
+                              pcs.get_relative_pose(g["fixed_l2e"][i], g["fixed_ego"][i], g["query_l2e"][i], g["query_ego"][i],
+                                                    pcs._KITTI2NU_lyft))
+    # WorldTable gathers what the per-frame dictionary held
+    wt = pcs.WorldTable({5: np.eye(4) * 2, 9: np.eye(4) * 3}).freeze()
+    assert np.array_equal(wt.stack([9, 5, 9]), np.stack([np.eye(4) * 3, np.eye(4) * 2, np.eye(4) * 3]))

@@ -382,3 +382,18 @@ def test_native_box_and_label_stage_many_scans(gpu):
         n_lines += len(a[2].splitlines())
     print("boxes", n_boxes, "label lines", n_lines, "largest relative difference", worst)
     assert n_boxes >= 200 and n_lines >= 40
+
+
+def test_results_do_not_depend_on_load(gpu):
+    """Determinism soak (tools/soak_mask.py): 6 processes repeat the same scans through the PP stage and the
+    mask / box / label stages and compare every result with their first.  Round 3 found 11 differing results
+    in 14 400 runs here -- the "last block finishes the reduction" kernels took their ticket before the other
+    wavefronts' partial results had left the CU -- and fixed it (csrc/common.h: modest_drain_stores); with the
+    bug this test fails with probability ~0.9."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_mask.py"), "6", "200"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout, r.stdout[-2000:]

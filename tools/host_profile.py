@@ -29,7 +29,7 @@ ptc_dev, pp_dev = torch.from_numpy(s.live_raw).to(dev), torch.from_numpy(pp).to(
 
 def one(i):
     labels, objs, _ = generate_mask_scan(s.live_raw, pp, calib, margs, random_state=np.random.RandomState(i),
-                                         ptc_dev=ptc_dev, pp_dev=pp_dev)
+                                         ptc_dev=ptc_dev, pp_dev=pp_dev, as_rows=True)
     return gen_label_scan(objs, calib, largs)
 
 
