@@ -135,6 +135,13 @@ typedef struct {
 int modest_frame_table_tiles(void);   /* MODEST_FRAME_NTF of the built library */
 int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *jobs_host, int n_jobs,
                       int32_t *n_inside_host, void *stream);
+/* The same sort, NOT blocking (an ingest thread keeps several batches in flight behind the compute stream's
+ * kernels).  jobs_scratch_dev [dev]: n_jobs * MODEST_FRAME_SORT_JOB_BYTES, caller-owned, alive until the
+ * launch has run; n_inside_pinned [PINNED host] (n_jobs) int32: written by the kernel itself, readable once
+ * `stream` has passed the launch.                                                                     */
+#define MODEST_FRAME_SORT_JOB_BYTES 128
+int modest_frame_sort_async(modest_ctx *ctx, const modest_frame_sort_job *jobs_host, int n_jobs,
+                            void *jobs_scratch_dev, int32_t *n_inside_pinned_host, void *stream);
 
 #define MODEST_FRAME_REMOVE_CENTER 1   /* remove_center, pre_compute_pp_score.py:48-52 */
 typedef struct {

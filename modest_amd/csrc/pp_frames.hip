@@ -112,6 +112,28 @@ __global__ __launch_bounds__(1024) void frame_sort_kernel(const SortJob *__restr
 
 extern "C" int modest_frame_table_tiles(void) { return F_NTF; }
 
+namespace {
+int fill_jobs(modest_ctx *ctx, const modest_frame_sort_job *jobs, int n_jobs, SortJob *hj, int *n_inside_dst) {
+    for (int k = 0; k < n_jobs; ++k) {
+        const modest_frame_sort_job &j = jobs[k];
+        MODEST_REQUIRE(j.n >= 0 && (j.stride == 3 || j.stride == 4), "bad frame");
+        MODEST_REQUIRE(j.n == 0 || (j.raw_dev && j.xyz_dev && j.perm_dev), "NULL frame buffer");
+        MODEST_REQUIRE(j.tab_dev != nullptr, "NULL table");
+        hj[k].raw = j.raw_dev;
+        hj[k].n = j.n;
+        hj[k].stride = j.stride;
+        hj[k].TX0 = j.TX0;
+        hj[k].TY0 = j.TY0;
+        for (int q = 0; q < 8; ++q) hj[k].W.a[q] = j.W[q];
+        hj[k].xyz = j.xyz_dev;
+        hj[k].perm = j.perm_dev;
+        hj[k].tab = j.tab_dev;
+        hj[k].n_inside = n_inside_dst + k;
+    }
+    return MODEST_OK;
+}
+}  // namespace
+
 extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *jobs, int n_jobs,
                                  int32_t *n_inside_host, void *stream_) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
@@ -128,22 +150,8 @@ extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *j
     // the pinned staging area is reused by the next call: this entry point is blocking
     SortJob *hj = reinterpret_cast<SortJob *>(ctx->pinned);
     int32_t *hin = reinterpret_cast<int32_t *>(ctx->pinned + (size_t)n_jobs * sizeof(SortJob));
-    for (int k = 0; k < n_jobs; ++k) {
-        const modest_frame_sort_job &j = jobs[k];
-        MODEST_REQUIRE(j.n >= 0 && (j.stride == 3 || j.stride == 4), "bad frame");
-        MODEST_REQUIRE(j.n == 0 || (j.raw_dev && j.xyz_dev && j.perm_dev), "NULL frame buffer");
-        MODEST_REQUIRE(j.tab_dev != nullptr, "NULL table");
-        hj[k].raw = j.raw_dev;
-        hj[k].n = j.n;
-        hj[k].stride = j.stride;
-        hj[k].TX0 = j.TX0;
-        hj[k].TY0 = j.TY0;
-        for (int q = 0; q < 8; ++q) hj[k].W.a[q] = j.W[q];
-        hj[k].xyz = j.xyz_dev;
-        hj[k].perm = j.perm_dev;
-        hj[k].tab = j.tab_dev;
-        hj[k].n_inside = reinterpret_cast<int *>(ctx->scratch + arena_sz((size_t)n_jobs * sizeof(SortJob))) + k;
-    }
+    rc = fill_jobs(ctx, jobs, n_jobs, hj, reinterpret_cast<int *>(ctx->scratch + arena_sz((size_t)n_jobs * sizeof(SortJob))));
+    if (rc) return rc;
     SortJob *dj = reinterpret_cast<SortJob *>(ctx->scratch);
     MODEST_HIP_CHECK(hipMemcpyAsync(dj, hj, (size_t)n_jobs * sizeof(SortJob), hipMemcpyHostToDevice, stream));
     const size_t lds = (size_t)(F_NTILE + 1) * 4;
@@ -157,6 +165,38 @@ extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *j
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     if (n_inside_host)
         for (int k = 0; k < n_jobs; ++k) n_inside_host[k] = hin[k];
+    return MODEST_OK;
+}
+
+// The same sort without a synchronise (an ingest thread keeps several batches in flight behind the compute
+// stream's kernels): the job table travels in the launch's own device buffer `jobs_scratch_dev`
+// (n_jobs * MODEST_FRAME_SORT_JOB_BYTES, caller-owned, alive until the launch has run) through one of the
+// context's pinned staging slots, and every job's count of points inside its table is written by the kernel
+// straight into `n_inside_pinned` (n_jobs int32 of PINNED host memory, readable once the stream has passed
+// the launch).
+extern "C" int modest_frame_sort_async(modest_ctx *ctx, const modest_frame_sort_job *jobs, int n_jobs,
+                                       void *jobs_scratch_dev, int32_t *n_inside_pinned, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(n_jobs >= 0, "n_jobs < 0");
+    if (n_jobs == 0) return MODEST_OK;
+    MODEST_REQUIRE(jobs && jobs_scratch_dev && n_inside_pinned, "NULL argument");
+    static_assert(sizeof(SortJob) <= MODEST_FRAME_SORT_JOB_BYTES, "header and kernel disagree on the job size");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    SortJob *hj = nullptr;
+    int rc = modest_ctx_stage_slot(ctx, (size_t)n_jobs * sizeof(SortJob), reinterpret_cast<void **>(&hj));
+    if (rc) return rc;
+    rc = fill_jobs(ctx, jobs, n_jobs, hj, reinterpret_cast<int *>(n_inside_pinned));
+    if (rc) return rc;
+    SortJob *dj = reinterpret_cast<SortJob *>(jobs_scratch_dev);
+    MODEST_HIP_CHECK(hipMemcpyAsync(dj, hj, (size_t)n_jobs * sizeof(SortJob), hipMemcpyHostToDevice, stream));
+    rc = modest_ctx_stage_commit(ctx, stream);
+    if (rc) return rc;
+    const size_t lds = (size_t)(F_NTILE + 1) * 4;
+    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(frame_sort_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    frame_sort_kernel<<<n_jobs, 1024, lds, stream>>>(dj);
+    MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
 

@@ -166,6 +166,10 @@ def run_workers(module: str, cfg, rank: int, ws: int, local: int) -> Optional[Di
         # processes that share a GPU size their persistent PP grids for half of it: a launch that fills all
         # CUs keeps the other workers' small kernels waiting (bench.py --pp-cus has the measurements)
         env.setdefault("MODEST_NUM_CUS", "128")
+        # N interpreters x (BLAS pool of one thread per core, spinning) oversubscribe the host: the per-scan
+        # linear algebra here is 4x4 (poses) and a few dozen box corners
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env.setdefault(k, "1")
         procs = []
         for w in range(n):
             e = dict(env, MODEST_WORKER=f"{w}/{n}", MODEST_WORKER_RESULT=os.path.join(d, f"w{w}.json"))

@@ -41,6 +41,44 @@ assert PP_FRAME.itemsize == 88
 
 REMOVE_CENTER = 1
 
+# modest_frame_sort_job as a numpy record: the ingest thread fills a batch of jobs vectorised
+SORT_JOB = np.dtype([("raw_dev", "u8"), ("n", "i4"), ("stride", "i4"), ("TX0", "i4"), ("TY0", "i4"), ("W", "f8", (8,)),
+                     ("xyz_dev", "u8"), ("perm_dev", "u8"), ("tab_dev", "u8")], align=True)
+assert SORT_JOB.itemsize == C.sizeof(SortJob)
+
+
+class BlockFrame:
+    """A stored frame that is a slice of a batch's blocks (insert_block): the tensor views are made on demand
+    (the compute path only needs the addresses, which sit in the store's descriptor records)."""
+    __slots__ = ("_xyz", "_perm", "_tab", "a", "b", "k", "n", "TX0", "TY0", "inside", "W", "slot")
+
+    def __init__(self, xyz_all, perm_all, tab_all, a, b, k, TX0, TY0, inside, W, slot):
+        self._xyz, self._perm, self._tab, self.a, self.b, self.k = xyz_all, perm_all, tab_all, a, b, k
+        self.n, self.TX0, self.TY0, self.inside, self.W, self.slot = b - a, TX0, TY0, inside, W, slot
+
+    xyz = property(lambda self: self._xyz[self.a:self.b])
+    perm = property(lambda self: self._perm[self.a:self.b])
+    tab = property(lambda self: self._tab[self.k])
+
+    @property
+    def n_inside(self) -> int:
+        if not isinstance(self.inside, int):
+            pin, k, ev = self.inside
+            ev.synchronize()
+            self.inside = int(pin[k])
+        return self.inside
+
+    @property
+    def nbytes(self) -> int:
+        return self.n * 16 + self._tab.shape[1] * 4
+
+    def original_order(self) -> torch.Tensor:
+        """(n,3) raw points in file order (for the stacked fallback path)."""
+        xyz = self.xyz
+        out = torch.empty_like(xyz)
+        out[self.perm.long()] = xyz
+        return out
+
 
 @dataclass
 class StoredFrame:
@@ -50,9 +88,18 @@ class StoredFrame:
     n: int
     TX0: int
     TY0: int
-    n_inside: int            # points inside the table (== n unless the frame has outliers)
+    inside: object           # points inside the table: an int, or (pinned int32 tensor, index, event) of an async sort
     W: np.ndarray            # (4,4) f64 raw frame -> world metres
     slot: int = -1
+
+    @property
+    def n_inside(self) -> int:
+        """points inside the table (== n unless the frame has outliers)"""
+        if not isinstance(self.inside, int):
+            pin, k, ev = self.inside
+            ev.synchronize()
+            self.inside = int(pin[k])
+        return self.inside
 
     @property
     def nbytes(self) -> int:
@@ -80,6 +127,14 @@ class FrameStore:
         self.hits = self.misses = 0
         self.ctx = ctx
         self.lock = threading.RLock()   # an ingest thread inserts while the compute loop describes scans
+        import collections
+        self._inflight = collections.deque()   # (event, job table, raw inputs) of asynchronous sorts
+        self._pin, self._pin_pos = None, 0
+        # device memory of block insertions comes from slabs taken from the driver in large pieces: hipMalloc costs
+        # milliseconds per call (and a lock shared by every process on the GPU); PyTorch's caching allocator grows
+        # in 20 MB segments, i.e. one driver call every two or three scans once its cache is used up (measured:
+        # the PP CLI dropped from 810 to 290 scans/s at that point)
+        self._slab, self._slab_off, self.slab_bytes = None, 0, 256 << 20
         # slot tables: the static part of every frame's descriptor, gathered per scan by fancy indexing
         self._rec = np.zeros(1024, dtype=PP_FRAME)
         self._W = np.zeros((1024, 4, 4))
@@ -114,12 +169,15 @@ class FrameStore:
 
     # ------------------------------------------------------------------ insertion
     def insert_many(self, items: Sequence[Tuple[Hashable, torch.Tensor, np.ndarray]], ctx=None,
-                    protect: Optional[Sequence[Hashable]] = None) -> None:
+                    protect: Optional[Sequence[Hashable]] = None, blocking: bool = True) -> None:
         """items: (key, raw (n,3|4) f32 device tensor, W (4,4) f64 raw->world).  One launch.
         `protect`: keys that must stay resident whatever the capacity says -- the frames of the scan
         that is being prepared (its resident history frames have not been touched yet when the missing
         ones are inserted; evicting them would also hand their slots, which the scan's descriptor table
-        names, to other frames).  A scan whose own working set exceeds the capacity simply overshoots it."""
+        names, to other frames).  A scan whose own working set exceeds the capacity simply overshoots it.
+        `blocking=False`: the sort is only enqueued on the current stream (modest_frame_sort_async): the frames
+        are usable by work that is ordered behind it; the raw inputs must stay alive until then (the store
+        keeps a reference for the last few batches)."""
         seen, todo = set(), []
         with self.lock:
             for it in items:
@@ -150,16 +208,36 @@ class FrameStore:
             j.W[:] = list(self.lattice_rows(W))
             j.xyz_dev, j.perm_dev, j.tab_dev = xyz.data_ptr(), perm.data_ptr(), tab.data_ptr()
             made.append((key, xyz, perm, tab, n, TX0, TY0, np.asarray(W, dtype=np.float64).copy()))
-        inside = (C.c_int32 * len(todo))()
-        check(lib.modest_frame_sort(self._ctx(ctx).handle, jobs, len(todo), inside,
-                                    torch.cuda.current_stream().cuda_stream), "modest_frame_sort")
+        if blocking:
+            inside = (C.c_int32 * len(todo))()
+            check(lib.modest_frame_sort(self._ctx(ctx).handle, jobs, len(todo), inside,
+                                        torch.cuda.current_stream().cuda_stream), "modest_frame_sort")
+            inside_of = [int(v) for v in inside]
+        else:
+            # the kernel writes every frame's inside-count into pinned host memory: one pool per store (a pinned
+            # allocation per batch is a driver call that takes a lock shared by every process on the GPU)
+            if self._pin is None or self._pin_pos + len(todo) > self._pin.shape[0]:
+                self._pin = torch.empty((max(1 << 18, len(todo)),), dtype=torch.int32, pin_memory=True)
+                self._pin_pos = 0
+            pin = self._pin[self._pin_pos:self._pin_pos + len(todo)]
+            self._pin_pos += len(todo)
+            jdev = torch.empty((len(todo) * 128,), dtype=torch.uint8, device=self.device)
+            check(lib.modest_frame_sort_async(self._ctx(ctx).handle, jobs, len(todo), jdev.data_ptr(), pin.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "modest_frame_sort_async")
+            ev = torch.cuda.Event()
+            ev.record()
+            inside_of = [(pin, k, ev) for k in range(len(todo))]
+            # raw inputs and the job table live until the launch has run: keep the last batches, drop finished ones
+            self._inflight.append((ev, jdev, [raw for _, raw, _ in todo]))
+            while len(self._inflight) > 2 and self._inflight[0][0].query():
+                self._inflight.popleft()
         with self.lock:
             for k, (key, xyz, perm, tab, n, TX0, TY0, W) in enumerate(made):
-                sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, int(inside[k]), W, self._take_slot())
+                sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, inside_of[k], W, self._take_slot())
                 r = self._rec[sf.slot]
                 r["xyz_dev"], r["tab_dev"], r["n"], r["TX0"], r["TY0"] = xyz.data_ptr(), tab.data_ptr(), n, TX0, TY0
                 self._W[sf.slot] = W
-                self._clean[sf.slot] = sf.n_inside == n
+                self._clean[sf.slot] = (sf.inside == n) if isinstance(sf.inside, int) else True   # (async: checked on demand)
                 self.frames[key] = sf
                 self.bytes += sf.nbytes
                 if isinstance(key, (int, np.integer)) and key >= 0:
@@ -180,6 +258,96 @@ class FrameStore:
                     if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
                         self._slot_index[key] = -1
 
+    def reserve(self, nbytes: int) -> None:
+        """take `nbytes` of device memory for future block insertions in ONE driver call"""
+        nbytes = int(min(max(nbytes, 0), self.cap))
+        if nbytes > 0 and (self._slab is None or self._slab.shape[0] - self._slab_off < nbytes):
+            self._slab, self._slab_off = torch.empty((nbytes,), dtype=torch.uint8, device=self.device), 0
+
+    def _carve(self, nbytes: int) -> torch.Tensor:
+        nbytes = (int(nbytes) + 255) & ~255
+        if self._slab is None or self._slab.shape[0] - self._slab_off < nbytes:
+            self._slab, self._slab_off = torch.empty((max(self.slab_bytes, nbytes),), dtype=torch.uint8, device=self.device), 0
+        out = self._slab[self._slab_off:self._slab_off + nbytes]
+        self._slab_off += nbytes
+        return out
+
+    def insert_block(self, keys: Sequence[int], raw_block: torch.Tensor, offs: np.ndarray, Ws: np.ndarray, ctx=None,
+                     protect: Optional[Sequence[Hashable]] = None) -> None:
+        """The ingest path: `keys` (none resident, all distinct) are the frames raw_block[offs[k]:offs[k+1]] of ONE
+        (P,4) float32 device block, Ws (k,4,4) their raw->world matrices.  Everything per frame is vectorised
+        (job table, descriptor records, table origins); the sort is enqueued, not awaited (insert_many has the
+        general, blocking form)."""
+        lib = load()
+        nf = len(keys)
+        if nf == 0:
+            return
+        Ws = np.ascontiguousarray(Ws, dtype=np.float64).reshape(nf, 4, 4)
+        with self.lock:
+            if self.anchor is None:
+                self.anchor = np.floor(Ws[0, :3, 3])
+        tw = self.ntf * self.ntf + 1
+        P = int(offs[-1])
+        xyz_all = self._carve(12 * P)[:12 * P].view(torch.float32).view(P, 3)
+        perm_all = self._carve(4 * P)[:4 * P].view(torch.int32)
+        tab_all = self._carve(4 * tw * nf)[:4 * tw * nf].view(torch.int32).view(nf, tw)
+        a, b = np.asarray(offs[:-1], dtype=np.int64), np.asarray(offs[1:], dtype=np.int64)
+        o = (Ws[:, :2, 3] - self.anchor[:2]) / self.cell
+        T0 = np.floor(o / 8.0).astype(np.int64) - self.ntf // 2
+        rows = Ws[:, :2, :].copy()
+        rows[:, :, 3] -= self.anchor[:2]
+        jobs = np.zeros(nf, dtype=SORT_JOB)
+        jobs["raw_dev"] = raw_block.data_ptr() + 16 * a
+        jobs["n"], jobs["stride"] = b - a, 4
+        jobs["TX0"], jobs["TY0"] = T0[:, 0], T0[:, 1]
+        jobs["W"] = (rows / self.cell).reshape(nf, 8)
+        jobs["xyz_dev"] = xyz_all.data_ptr() + 12 * a
+        jobs["perm_dev"] = perm_all.data_ptr() + 4 * a
+        jobs["tab_dev"] = tab_all.data_ptr() + 4 * tw * np.arange(nf, dtype=np.int64)
+        if self._pin is None or self._pin_pos + nf > self._pin.shape[0]:
+            self._pin = torch.empty((max(1 << 18, nf),), dtype=torch.int32, pin_memory=True)
+            self._pin_pos = 0
+        pin = self._pin[self._pin_pos:self._pin_pos + nf]
+        self._pin_pos += nf
+        jdev = self._carve(nf * 128)
+        check(lib.modest_frame_sort_async(self._ctx(ctx).handle, jobs.ctypes.data, nf, jdev.data_ptr(), pin.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "modest_frame_sort_async")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight.append((ev, jdev, raw_block))
+        while len(self._inflight) > 2 and self._inflight[0][0].query():
+            self._inflight.popleft()
+        with self.lock:
+            slots = np.array([self._take_slot() for _ in range(nf)], dtype=np.int64)
+            rec = self._rec
+            rec["xyz_dev"][slots], rec["tab_dev"][slots] = jobs["xyz_dev"], jobs["tab_dev"]
+            rec["n"][slots], rec["TX0"][slots], rec["TY0"][slots] = jobs["n"], jobs["TX0"], jobs["TY0"]
+            self._W[slots] = Ws
+            self._clean[slots] = True   # (async: inside-counts are read on demand)
+            kmax = int(max(keys))
+            if kmax >= self._slot_index.shape[0]:
+                grown = np.full(max(2 * self._slot_index.shape[0], kmax + 1), -1, dtype=np.int64)
+                grown[: self._slot_index.shape[0]] = self._slot_index
+                self._slot_index = grown
+            self._slot_index[np.asarray(keys, dtype=np.int64)] = slots
+            fr = self.frames
+            for k, key in enumerate(keys):
+                fr[key] = BlockFrame(xyz_all, perm_all, tab_all, int(a[k]), int(b[k]), k, int(T0[k, 0]), int(T0[k, 1]),
+                                     (pin, k, ev), Ws[k], int(slots[k]))
+            self.bytes += 16 * P + 4 * tw * nf
+            if self.bytes > self.cap:
+                self._evict(set(protect) | set(keys) if protect is not None else set(keys))
+
+    def _evict(self, keep) -> None:
+        for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first (call under the lock)
+            if self.bytes <= self.cap:
+                break
+            old = self.frames.pop(key)
+            self.bytes -= old.nbytes
+            self._free.append(old.slot)
+            if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
+                self._slot_index[key] = -1
+
     def insert(self, key, raw: torch.Tensor, W: np.ndarray) -> StoredFrame:
         self.insert_many([(key, raw, W)])
         return self.frames[key]
@@ -196,6 +364,31 @@ class FrameStore:
 
     def __contains__(self, key) -> bool:
         return key in self.frames
+
+    def missing(self, keys) -> list:
+        """the distinct keys that are not resident, in first-occurrence order"""
+        with self.lock:
+            if len(keys) and isinstance(keys[0], (int, np.integer)):
+                k = np.asarray(keys, dtype=np.int64)
+                if k.min() >= 0:
+                    res = np.ones(len(k), dtype=bool)
+                    inr = k < self._slot_index.shape[0]
+                    res[inr] = self._slot_index[k[inr]] < 0
+                    if not res.any():
+                        return []
+                    return list(dict.fromkeys(int(x) for x in k[res]))
+            return [k for k in dict.fromkeys(keys) if k not in self.frames]
+
+    def touch(self, keys) -> None:
+        """LRU order + hit statistics of a scan's frames, one lock round trip"""
+        with self.lock:
+            fr = self.frames
+            for k in keys:
+                if k in fr:
+                    fr.move_to_end(k)
+                    self.hits += 1
+                else:
+                    self.misses += 1
 
     # ------------------------------------------------------------------ the PP stage of one scan
     def consistent(self, slots: np.ndarray, rels: np.ndarray, A44: np.ndarray, tol: float = 1e-4,

@@ -28,6 +28,14 @@ from .frame_store import FrameStore
 from .utils.pointcloud_utils import load_velo_scan
 
 
+TRACE = [] if os.environ.get("MODEST_PP_TRACE") == "2" else None
+
+
+def _tr(tag, k):
+    if TRACE is not None:
+        TRACE.append((tag, k, time.perf_counter()))
+
+
 def eprint(*args, **kwargs):
     print(*args, file=sys.stderr, **kwargs)
 
@@ -83,8 +91,13 @@ class FrameLoader:
         from concurrent.futures import ThreadPoolExecutor
         self.dir, self.store, self.world, self.ctx = velodyne_dir, store, world, ctx
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(readers)))
-        self.pinned = None
+        self.pinned = [None, None, None]      # ring: a buffer is refilled only after its last upload has run
+        self.pinned_ev = [None, None, None]
+        self.turn = 0
+        self.chunk = 32   # frames per staged piece
         self.read_bytes = 0
+        self.t_read = self.t_insert = self.t_touch = 0.0   # seconds of the ingest thread, by phase
+        self.n_frames = 0
 
     def _read_batch(self, ids):
         """the .bin files of `ids` -> one pinned float32 buffer; returns (buffer (P,4), point offsets)"""
@@ -93,9 +106,12 @@ class FrameLoader:
         assert all(sz % 16 == 0 for sz in sizes), "velodyne .bin files hold (n,4) float32 rows"
         offs = np.cumsum([0] + [sz // 16 for sz in sizes])
         need = int(offs[-1])
-        if self.pinned is None or self.pinned.shape[0] < need:
-            self.pinned = torch.empty((max(need, 1 << 16), 4), dtype=torch.float32, pin_memory=True)
-        host = self.pinned.numpy()
+        r = self.turn = (self.turn + 1) % len(self.pinned)
+        if self.pinned_ev[r] is not None:
+            self.pinned_ev[r].synchronize()
+        if self.pinned[r] is None or self.pinned[r].shape[0] < need:
+            self.pinned[r] = torch.empty((max(need, 1 << 16), 4), dtype=torch.float32, pin_memory=True)
+        host = self.pinned[r].numpy()
 
         def rd(k):
             with open(paths[k], "rb", buffering=0) as f:
@@ -104,20 +120,39 @@ class FrameLoader:
                 raise IOError(f"short read of {paths[k]}")
         list(self.pool.map(rd, range(len(ids))))
         self.read_bytes += int(sum(sizes))
-        return self.pinned[:need], offs
+        return self.pinned[r][:need], offs
 
-    def ensure(self, file_ids, protect=None):
+    def ensure(self, file_ids, protect=None, blocking=True):
         """Read + upload + sort (one copy, one launch) every frame of `file_ids` that is not resident, on
-        the CURRENT stream."""
-        missing = [i for i in dict.fromkeys(file_ids) if i not in self.store]
-        if missing:
+        the CURRENT stream.  blocking=False: upload and sort are only enqueued (work ordered behind them on the
+        stream, or behind an event recorded after this call, sees the frames)."""
+        t0 = time.perf_counter()
+        todo = self.store.missing(file_ids)
+        # a cold scan (hundreds of frames) goes in pieces: the pinned staging buffers stay small (pinning
+        # 170 MB at once takes tens of milliseconds inside the driver, serialised across worker processes)
+        # and the first piece is uploading while the next one is read
+        for c0 in range(0, len(todo), self.chunk):
+            missing = todo[c0:c0 + self.chunk]
             host, offs = self._read_batch(missing)
+            t1 = time.perf_counter()
             dev = torch.empty(host.shape, dtype=torch.float32, device=self.store.device)
             dev.copy_(host, non_blocking=True)
-            items = [(i, dev[offs[k]:offs[k + 1]], self.world[i]) for k, i in enumerate(missing)]
-            self.store.insert_many(items, ctx=self.ctx, protect=protect if protect is not None else file_ids)   # blocking
-        for i in file_ids:
-            self.store.get(i)   # LRU touch + hit statistics
+            if blocking:
+                items = [(i, dev[offs[k]:offs[k + 1]], self.world[i]) for k, i in enumerate(missing)]
+                self.store.insert_many(items, ctx=self.ctx, protect=protect if protect is not None else file_ids)
+            else:
+                self.store.insert_block(missing, dev, offs, self.world.stack(missing), ctx=self.ctx,
+                                        protect=protect if protect is not None else file_ids)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pinned_ev[self.turn] = ev
+            t2 = time.perf_counter()
+            self.t_read += t1 - t0
+            self.t_insert += t2 - t1
+            self.n_frames += len(missing)
+            t0 = t2
+        self.store.touch(file_ids)   # LRU order + hit statistics
+        self.t_touch += time.perf_counter() - t0
 
 
 class IngestPipeline:
@@ -128,12 +163,15 @@ class IngestPipeline:
     `done()` releases the window behind a finished scan.  Frames named by a scan inside the window are never
     evicted."""
 
-    def __init__(self, loader: FrameLoader, plans, device, depth: int = 4):
+    def __init__(self, loader: FrameLoader, plans, device, depth: int = 4, own_stream: bool = True):
         import collections
         import queue
         import threading
         self.loader, self.plans, self.depth, self.device = loader, plans, max(1, int(depth)), device
-        self.stream = torch.cuda.Stream(device=device)
+        # own_stream=False: uploads and sorts are enqueued on the compute stream itself (the hand-over of a plan
+        # already orders them before the scan's kernels).  A GPU shared by several worker processes has 8
+        # hardware queues in all (DESIGN.md section 5): a second stream per worker halves everybody's rate.
+        self.stream = torch.cuda.Stream(device=device) if own_stream else torch.cuda.current_stream(device)
         self.window = threading.Semaphore(self.depth)
         self.inflight = collections.deque()
         self.lock = threading.Lock()
@@ -146,13 +184,16 @@ class IngestPipeline:
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.stream):
                 for plan in self.plans:
+                    _tr("L.want", plan["origin"])
                     self.window.acquire()
+                    _tr("L.start", plan["origin"])
                     with self.lock:
                         self.inflight.append(plan["frames"])
                         protect = [i for ids in self.inflight for i in ids]
-                    self.loader.ensure(plan["frames"], protect=protect)
+                    self.loader.ensure(plan["frames"], protect=protect, blocking=False)
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
+                    _tr("L.done", plan["origin"])
                     self.q.put((plan, ev))
             self.q.put(None)
         except BaseException as e:   # surfaced by the iterator
@@ -167,6 +208,7 @@ class IngestPipeline:
                 raise item
             plan, ev = item
             torch.cuda.current_stream().wait_event(ev)
+            _tr("M.got", plan["origin"])
             yield plan
 
     def done(self):
@@ -200,7 +242,9 @@ class OutputWriter:
             ev, slot, n, path = item
             try:
                 ev.synchronize()
+                _tr("W.gpu", path[-10:-4])
                 save_npy_atomic(path, self.buf[slot][:n].numpy())
+                _tr("W.saved", path[-10:-4])
             except BaseException as e:
                 self.error = e
             self.free.put(slot)
@@ -320,6 +364,15 @@ def main(args):
         raise NotImplementedError(args.ephe_type)
     radius = float(args.max_neighbor_dist)
     store = FrameStore(device, radius, float(args.get("frame_cache_gb", 64)) * 2 ** 30)
+    # device memory for the frames this process will hold, taken from the driver in one call (frame_store.py:
+    # reserve): every frame of the data set, bounded by the cache size and by frame_prealloc_gb (0: no reservation,
+    # slabs of 256 MB on demand)
+    try:
+        n_all = sum(len(seq) for seq in track_list)
+        per = os.path.getsize(osp.join(args.data_root, "velodyne", f"{track_list[0][0]:06d}.bin")) + 4 * (store.ntf ** 2 + 1) + 512
+        store.reserve(min(n_all * per * 1.05, float(args.get("frame_prealloc_gb", 16.0)) * 2 ** 30))
+    except (OSError, IndexError):
+        pass
     world = frame_world_matrices(track_list, poses, l2es, K)
     # ingest: reader threads -> pinned buffer -> one copy + one sort launch per scan, `ingest_depth` scans ahead
     # of the kernels (own stream, own library context); scores leave through a writer thread
@@ -349,8 +402,13 @@ def main(args):
                        frames=hist_ids + [live_id])
 
     t0, done, pts = time.perf_counter(), 0, 0
+    trace = bool(os.environ.get("MODEST_PP_TRACE")) and os.environ.get("MODEST_WORKER", "0/1").startswith("0/")
     dist.barrier()
-    pipe = IngestPipeline(loader, plans(), device, depth=int(args.get("ingest_depth", 4)))
+    # the ingest / writer threads hand the GIL back and forth with this loop: CPython's default forced-switch
+    # interval (5 ms) is longer than a whole scan
+    sys.setswitchinterval(float(os.environ.get("MODEST_SWITCH_INTERVAL", "0.0002")))
+    pipe = IngestPipeline(loader, plans(), device, depth=int(args.get("ingest_depth", 4)),
+                          own_stream=not os.environ.get("MODEST_WORKER"))
     writer = OutputWriter(1 << 16)
     for plan in pipe:
         origin_idx, out_path, traversals = plan["origin"], plan["out"], plan["traversals"]
@@ -393,17 +451,28 @@ def main(args):
         else:
             A44 = first_pose.astype(np.float64) @ np.asarray(first_l2e, dtype=np.float64) @ K
             H = store.pp_score(live_id, trans_mat, hist, rels[keep], A44, n_trav, remove_center=bool(args.nusc))
+        _tr("M.enq", origin_idx)
         writer.submit(H, out_path)
+        _tr("M.sub", origin_idx)
         done += 1
+        if trace and (done <= 4 or done % 8 == 0):
+            eprint("[pp_score trace] scan %d submitted at %.1f ms" % (done, 1e3 * (time.perf_counter() - t0)))
         pts += store.points_of([i for i, _ in hist])
         pipe.done()
     writer.close()
+    if TRACE is not None:
+        base = TRACE[0][2]
+        for tag, k, t in TRACE:
+            if int(os.environ.get("MODEST_PP_TRACE_FROM", "150")) <= int(k) < int(os.environ.get("MODEST_PP_TRACE_FROM", "150")) + 4:
+                eprint("[pp_score trace2] %-8s scan %s at %.3f ms" % (tag, k, 1e3 * (t - base)))
     torch.cuda.synchronize()
     tot = dist.rank_report("pp_score", done, t0, rank, ws, dict(hist_points=pts))
     if rank == 0:
-        eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame store %d hits / %d misses"
+        eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame store %d hits / %d misses; "
+               "ingest thread of rank 0: %d frames, %.1f MB read in %.3f s, upload + sort %.3f s, bookkeeping %.3f s"
                % (tot["scans"], tot["hist_points"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9),
-                  ws, store.hits, store.misses))
+                  ws, store.hits, store.misses, loader.n_frames, loader.read_bytes / 1e6, loader.t_read, loader.t_insert,
+                  loader.t_touch))
     return tot
 
 

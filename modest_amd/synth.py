@@ -46,8 +46,10 @@ class World:
 
 
 def make_world(seed: int, length: float = 400.0) -> World:
+    """Static boxes and poles along x in [-100, length]; their number grows with the length (160 boxes and 120
+    poles per 500 m, the density every fixture was generated with at the default length)."""
     rng = np.random.default_rng(10_000 + seed)
-    nb = 160
+    nb = int(round(160 * (length + 100.0) / 500.0))
     side = rng.choice([-1.0, 1.0], nb)
     cx = rng.uniform(-100.0, length, nb)
     cy = side * rng.uniform(5.5, 10.5, nb)
@@ -55,7 +57,8 @@ def make_world(seed: int, length: float = 400.0) -> World:
     w = rng.uniform(1.6, 3.0, nb)
     h = rng.uniform(1.3, 3.5, nb)
     boxes = np.stack([cx, cy, h / 2, l, w, h], axis=1)
-    poles = np.stack([rng.uniform(-100.0, length, 120), rng.choice([-1.0, 1.0], 120) * rng.uniform(4.0, 11.5, 120)], 1)
+    npole = int(round(120 * (length + 100.0) / 500.0))
+    poles = np.stack([rng.uniform(-100.0, length, npole), rng.choice([-1.0, 1.0], npole) * rng.uniform(4.0, 11.5, npole)], 1)
     return World(boxes=boxes, poles=poles, seed=seed)
 
 
@@ -255,7 +258,10 @@ def write_kitti_tree(root: str, meta: str, n_seq: int = 3, n_frames: int = 12, n
     for d in ("velodyne", "oxts", "l2e", "calib"):
         os.makedirs(os.path.join(train, d), exist_ok=True)
     os.makedirs(meta, exist_ok=True)
-    world = make_world(world_seed)
+    # the world reaches past the end of the track (frames are 2 m apart): a scan beyond it would see no static
+    # boxes, and sample_frame would then put its box points on boxes hundreds of metres away -- one clamped border
+    # cell of the live grid with a million history points (found as a 20x slower pp3_join from scan ~210 on)
+    world = make_world(world_seed, length=max(400.0, 2.0 * n_frames + 150.0))
     l2e = default_l2e()
     track, idx = [], 0
     rng = np.random.default_rng(40_000 + world_seed)

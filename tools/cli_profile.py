@@ -17,7 +17,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as root:
     data = f"data_root={root}/kitti/training"
     common = [data, f"data_paths.track_path={paths['track_path']}", f"data_paths.idx_info={paths['idx_info']}",
               f"data_paths.idx_list={paths['idx_list']}"]
-    sys.stderr = open(os.devnull, "w")
+    import io
+    sys.stderr = cap = io.StringIO()
     if which == "pp":
         pre_compute_pp_score.main(argv=common + [f"data_paths.pp_score_path={root}/warm"])     # warm-up (kernels, allocator)
         pr = cProfile.Profile()
@@ -37,5 +38,6 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as root:
         pr.disable()
     dt = time.perf_counter() - t0
     sys.stderr = sys.__stderr__
+    print("\n".join(l for l in cap.getvalue().splitlines() if l.startswith("[pp_score]") or l.startswith("[generate_mask]")))
     print("%s CLI: %d scans in %.3f s = %.1f scans/s (loop clock %.3f s)" % (which, tot["scans"], dt, tot["scans"] / dt, tot["max_seconds"]))
     pstats.Stats(pr).sort_stats("tottime").print_stats(28)
