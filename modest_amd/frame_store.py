@@ -338,6 +338,18 @@ class FrameStore:
             if self.bytes > self.cap:
                 self._evict(set(protect) | set(keys) if protect is not None else set(keys))
 
+    def drop(self, keys) -> None:
+        """forget frames (their slab memory is reused only with the whole slab; descriptor slots are recycled)"""
+        with self.lock:
+            for key in keys:
+                old = self.frames.pop(key, None)
+                if old is None:
+                    continue
+                self.bytes -= old.nbytes
+                self._free.append(old.slot)
+                if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
+                    self._slot_index[key] = -1
+
     def _evict(self, keep) -> None:
         for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first (call under the lock)
             if self.bytes <= self.cap:

@@ -183,6 +183,9 @@ class ScanInputs:
     live_rel: np.ndarray = None       # (4,4) f32 relative pose of the live scan
     live_W: np.ndarray = None         # (4,4) f64 live raw frame -> world
     world_from_ref: np.ndarray = None  # (4,4) f64 common (first history frame) system -> world
+    first_pose: np.ndarray = None      # (4,4) f64 ego pose of the first history frame (fixed_ego of get_relative_pose)
+    l2e: np.ndarray = None             # (4,4) f64 lidar -> ego (fixed_l2e and every frame's query_l2e)
+    K: np.ndarray = None               # (4,4) KITTI2NU
 
 
 def _transform_f32(pts_xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
@@ -233,7 +236,8 @@ def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: in
     rel_live = relative_pose(l2e, first_pose, l2e, live_pose, K)
     live_xyz = _transform_f32(live_raw[:, :3], rel_live)
     return ScanInputs(live_raw=live_raw, live_xyz=np.ascontiguousarray(live_xyz), hist=hist, frames=frames,
-                      live_rel=rel_live, live_W=live_pose @ l2e @ K, world_from_ref=first_pose @ l2e @ K)
+                      live_rel=rel_live, live_W=live_pose @ l2e @ K, world_from_ref=first_pose @ l2e @ K,
+                      first_pose=first_pose, l2e=l2e, K=K)
 
 
 CALIB_TXT = (
