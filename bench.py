@@ -609,8 +609,8 @@ def main():
     if runner is not None:
         M = runner.scans[0].M
     alg_bytes = 12 * M + 16 * a.n_live
-    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-    contended = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else None   # None, not NaN: the line must stay strict JSON
+    contended = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms else None
     # top level = the stage alone on the GPU (the figure that follows from profiles/*_pp_only_kernel_stats.csv);
     # the event pairs of the timed region also bracket the other scans' kernels and are reported as `in_pipeline`
     achieved = alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms else contended

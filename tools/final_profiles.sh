@@ -6,6 +6,8 @@ line() { grep '^{"metric"' | tail -1; }
 python bench.py --cpu-scans 0 --cli-scans 0 > /dev/null 2>&1   # warm the box (clocks, page cache)
 python bench.py 2>/dev/null | line > $F/bench_full.json
 python bench.py --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_full_1proc.json
+python bench.py --cpu-scans 0 --cli-scans 0 --procs 1 --streams 6 2>/dev/null | line > $F/bench_full_1proc_6threads.json
+python bench.py --steps 20 --warmup 5 --cpu-scans 0 --cli-scans 0 2>/dev/null | line > $F/bench_driver_steps20.json
 python bench.py --pp-only --cpu-scans 0 --cli-scans 0 2>/dev/null | line > $F/bench_pp_only.json
 python bench.py --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 2>/dev/null | line > $F/bench_pp_only_1stream.json
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -33,6 +35,6 @@ python tools/kstats.py $F/bench_full_1proc_kernel_stats.csv 70
 bash tools/scan_trace.sh > /dev/null 2>&1; cp gpurun_out/scan_trace.txt $F/scan_trace.txt
 # diagnostics: each half of the pipeline alone from the default process pool
 python bench.py --cpu-scans 0 --cli-scans 0 --mask-only 2>/dev/null | line > $F/bench_mask_only.json
-MODEST_PP_FRAMES_PATH=gather-wave python tools/pp5_microbench.py 2>/dev/null | tail -1 > $F/pp_gather_wave_microbench.json
-python tools/pp5_microbench.py 2>/dev/null | tail -1 > $F/pp_stream_microbench.json
-python tools/host_profile.py 100 cumulative 2>&1 | grep -v amdgpu.ids | sed "s#$GRAFT_REPO_ROOT/##g; s#/usr/local/lib/python3.10/dist-packages/##g" | head -40 | cut -c1-160 > $F/host_profile.txt
+python tools/pp_frames_microbench.py 2>/dev/null | tail -1 > $F/pp_stream_microbench.json
+python tools/host_profile.py 100 tottime 2>&1 | grep -v amdgpu.ids | sed "s#$GRAFT_REPO_ROOT/##g; s#/usr/local/lib/python3.10/dist-packages/##g" | head -40 | cut -c1-160 > $F/host_profile.txt
+python tools/soak_mask.py 8 1500 2>&1 | grep -v amdgpu.ids | tail -3 > $F/determinism_soak.txt
