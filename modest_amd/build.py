@@ -62,6 +62,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             and stamp.read_text() == digest):
         return LIB
     OBJDIR.mkdir(parents=True, exist_ok=True)
+    for stale in set(OBJDIR.glob("*.o")) - {OBJDIR / (x.stem + ".o") for x in srcs}:
+        stale.unlink()   # object of a source file that no longer exists
     hipcc = _hipcc()
 
     resources = {}
