@@ -162,6 +162,18 @@ int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *live_host,
                            int n_frames, int n_trav, const double *A8_host, double radius,
                            int32_t *counts_dev, float *H_dev, void *stream);
 
+/* The same operation for SEVERAL scans in one chain of launches (the reference's scan loop,
+ * pre_compute_pp_score.py:122-196, has no dependency between iterations): every kernel of the chain takes the
+ * scan as a second grid dimension, so the nine sub-10 us launches are paid once per batch and the persistent
+ * join workgroups take slices of any scan of the batch.  Results are those of n_scans separate calls, bit for
+ * bit.  Arrays of n_scans entries [host]; counts_dev / H_dev (arrays or entries) may be NULL as above; scans the
+ * batched kernels do not cover (no live points, no history) make the call fall back to separate calls.
+ * Scratch: ~0.26 GB per Lyft-shape scan of the batch.  Not blocking.                                      */
+int modest_pp_score_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_frame *const *live_host,
+                                 const uint32_t *const *live_perm_dev, const modest_pp_frame *const *frames_host,
+                                 const int32_t *n_frames, int n_trav, double radius,
+                                 int32_t *const *counts_dev, float *const *H_dev, void *stream);
+
 /* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
  * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).
  * Candidate selection: z<max_hs, xlo<x<xhi, ylo<y<yhi (strict), compacted in

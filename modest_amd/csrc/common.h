@@ -43,6 +43,7 @@ struct modest_ctx {
     hipEvent_t *prof_ev;   // 2 * prof_cap events
     int prof_cap;
     int pp_attr_done;      // dynamic-LDS limits of the PP kernels raised on this device
+    int ppb_attr_done;     // ... of the batched PP kernels
     // zeroed state words of the order-preserving compaction kernels (compact.h); the kernels leave
     // them zeroed, so no memset per launch
     unsigned long long *cstate;

@@ -67,6 +67,7 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->prof_ev = nullptr;
     c->prof_cap = 0;
     c->pp_attr_done = 0;
+    c->ppb_attr_done = 0;
     c->cstate = nullptr;
     c->cstate_blocks = 0;
     c->zwords = nullptr;

@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <vector>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -99,23 +101,24 @@ __global__ __launch_bounds__(256) void pp_live_bbox(const float *__restrict__ li
 
 // bbPart != NULL (frame path): the bounding box arrives as per-block partial maxima of the key words
 // (pp3_live_prep); every block combines them, block 0 publishes bb[] for the kernels that follow.
-__global__ __launch_bounds__(256) void pp_live_count(const float *__restrict__ live, int n, unsigned *bb, double c,
-                                                     unsigned *cellCount, const unsigned *__restrict__ bbPart,
-                                                     int nPart) {
+__device__ __forceinline__ void pp_live_count_body(const float *__restrict__ live, int n, unsigned *bb, double c, unsigned *cellCount, const unsigned *__restrict__ bbPart, int nPart, const unsigned bx, const unsigned gx) {
     __shared__ unsigned sbb[4];
     if (bbPart) {
         if (threadIdx.x < 4) sbb[threadIdx.x] = 0u;
         __syncthreads();
         for (int k = threadIdx.x; k < 4 * nPart; k += blockDim.x) atomicMax(&sbb[k & 3], bbPart[k]);
         __syncthreads();
-        if (blockIdx.x == 0 && threadIdx.x < 4) bb[threadIdx.x] = sbb[threadIdx.x];
+        if (bx == 0 && threadIdx.x < 4) bb[threadIdx.x] = sbb[threadIdx.x];
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const PPGrid g = pp_grid(bbPart ? sbb : bb, c);
     const int cx = pp_cell_coord(live[3 * (size_t)i], g.ox, g.inv_c, PP_NX);
     const int cy = pp_cell_coord(live[3 * (size_t)i + 1], g.oy, g.inv_c, PP_NY);
     atomicAdd(&cellCount[cy * PP_NX + cx], 1u);
+}
+__global__ __launch_bounds__(256) void pp_live_count(const float *__restrict__ live, int n, unsigned *bb, double c, unsigned *cellCount, const unsigned *__restrict__ bbPart, int nPart) {
+    pp_live_count_body(live, n, bb, c, cellCount, bbPart, nPart, blockIdx.x, gridDim.x);
 }
 
 // Dilated occupancy bitmap: bit(cell) = any live point in the 3x3 cells around it.
@@ -173,27 +176,29 @@ __device__ __forceinline__ void pp_scan_block(const unsigned *__restrict__ cnt, 
 
 // One launch for the two independent consumers of the cell counters: blocks [0, SCAN_NBLK) scan,
 // blocks [SCAN_NBLK, SCAN_NBLK + PP_NY) build one row of the dilated bitmap each.
-__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_bitmap(const unsigned *__restrict__ cnt,
-                                                             unsigned *__restrict__ start,
-                                                             unsigned *__restrict__ blockSum,
-                                                             unsigned *__restrict__ bitmap) {
-    if (blockIdx.x < SCAN_NBLK) pp_scan_block(cnt, start, blockSum, (int)blockIdx.x);
-    else pp_bitmap_row(cnt, bitmap, (int)blockIdx.x - SCAN_NBLK);
+__device__ __forceinline__ void pp_scan_bitmap_body(const unsigned *__restrict__ cnt, unsigned *__restrict__ start, unsigned *__restrict__ blockSum, unsigned *__restrict__ bitmap, const unsigned bx, const unsigned gx) {
+    if (bx < SCAN_NBLK) pp_scan_block(cnt, start, blockSum, (int)bx);
+    else pp_bitmap_row(cnt, bitmap, (int)bx - SCAN_NBLK);
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_bitmap(const unsigned *__restrict__ cnt, unsigned *__restrict__ start, unsigned *__restrict__ blockSum, unsigned *__restrict__ bitmap) {
+    pp_scan_bitmap_body(cnt, start, blockSum, bitmap, blockIdx.x, gridDim.x);
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_finish(unsigned *__restrict__ start,
-                                                             const unsigned *__restrict__ blockSum) {
+__device__ __forceinline__ void pp_scan_finish_body(unsigned *__restrict__ start, const unsigned *__restrict__ blockSum, const unsigned bx, const unsigned gx) {
     __shared__ unsigned red[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned v = (tid < (int)blockIdx.x) ? blockSum[tid] : 0u;   // sums of the earlier blocks
+    unsigned v = (tid < (int)bx) ? blockSum[tid] : 0u;   // sums of the earlier blocks
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if (lane == 0) red[w] = v;
     __syncthreads();
     unsigned off = 0;
     for (int k = 0; k < 16; ++k) off += red[k];
-    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + tid;
+    const size_t i = (size_t)bx * SCAN_BLOCK + tid;
     start[i] += off;
-    if (blockIdx.x == SCAN_NBLK - 1 && tid == SCAN_BLOCK - 1) start[PP_NCELL] = off + blockSum[SCAN_NBLK - 1];
+    if (bx == SCAN_NBLK - 1 && tid == SCAN_BLOCK - 1) start[PP_NCELL] = off + blockSum[SCAN_NBLK - 1];
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void pp_scan_finish(unsigned *__restrict__ start, const unsigned *__restrict__ blockSum) {
+    pp_scan_finish_body(start, blockSum, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ void pp_live_scatter_one(int i, const float *__restrict__ live, int n, const unsigned *bb,
@@ -258,9 +263,8 @@ __device__ __forceinline__ double pp_term(int c, double denom) {
 
 // numpy's pairwise summation order for a contiguous run of n <= 128 doubles
 // (8 interleaved accumulators, then the remainder sequentially).
-__global__ void pp_entropy_kernel(const int *__restrict__ counts, int n, int T,
-                                  float *__restrict__ H) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pp_entropy_kernel_body(const int *__restrict__ counts, int n, int T, float *__restrict__ H, const unsigned bx, const unsigned gx) {
+    const int i = bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int *c = counts + (size_t)i * T;
     long long s = 0;
@@ -283,6 +287,9 @@ __global__ void pp_entropy_kernel(const int *__restrict__ counts, int n, int T,
         for (; t < T; ++t) res += pp_term(c[t], denom);
     }
     H[i] = (float)(res / log((double)T));
+}
+__global__  void pp_entropy_kernel(const int *__restrict__ counts, int n, int T, float *__restrict__ H) {
+    pp_entropy_kernel_body(counts, n, T, H, blockIdx.x, gridDim.x);
 }
 
 int check_offsets(const int64_t *off, int n_trav, TravOffsets &tr) {
@@ -325,17 +332,14 @@ struct RelM {
     float m[12];
 };
 constexpr int PREP_BLOCKS = 512;
-__global__ __launch_bounds__(256) void pp3_live_prep(const float *__restrict__ xyz, const unsigned *__restrict__ perm,
-                                                     int n, RelM rel, float *__restrict__ out,
-                                                     unsigned *__restrict__ bbPart, uint4 *__restrict__ zero16,
-                                                     size_t nZero16, int *__restrict__ counts, size_t nCounts) {
-    const size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x, gs = (size_t)gridDim.x * 256;
+__device__ __forceinline__ void pp3_live_prep_body(const float *__restrict__ xyz, const unsigned *__restrict__ perm, int n, RelM rel, float *__restrict__ out, unsigned *__restrict__ bbPart, uint4 *__restrict__ zero16, size_t nZero16, int *__restrict__ counts, size_t nCounts, const unsigned bx, const unsigned gx) {
+    const size_t gt = (size_t)bx * 256 + threadIdx.x, gs = (size_t)gx * 256;
     for (size_t i = gt; i < nZero16; i += gs) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     for (size_t i = gt; i < nCounts; i += gs) counts[i] = 0;
-    if ((long long)blockIdx.x * 1024 >= n) return;
+    if ((long long)bx * 1024 >= n) return;
     unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     for (int r = 0; r < 4; ++r) {   // 1024 points per block
-        const int i = blockIdx.x * 1024 + r * 256 + threadIdx.x;
+        const int i = bx * 1024 + r * 256 + threadIdx.x;
         if (i < n) {
             float o[3];
             rel_apply(rel.m, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], o);
@@ -366,8 +370,11 @@ __global__ __launch_bounds__(256) void pp3_live_prep(const float *__restrict__ x
     }
     __syncthreads();
     if (threadIdx.x < 4)
-        bbPart[4 * blockIdx.x + threadIdx.x] = max(max(red[threadIdx.x][0], red[threadIdx.x][1]),
+        bbPart[4 * bx + threadIdx.x] = max(max(red[threadIdx.x][0], red[threadIdx.x][1]),
                                                    max(red[threadIdx.x][2], red[threadIdx.x][3]));
+}
+__global__ __launch_bounds__(256) void pp3_live_prep(const float *__restrict__ xyz, const unsigned *__restrict__ perm, int n, RelM rel, float *__restrict__ out, unsigned *__restrict__ bbPart, uint4 *__restrict__ zero16, size_t nZero16, int *__restrict__ counts, size_t nCounts) {
+    pp3_live_prep_body(xyz, perm, n, rel, out, bbPart, zero16, nZero16, counts, nCounts, blockIdx.x, gridDim.x);
 }
 }  // namespace
 
@@ -637,6 +644,309 @@ int modest_pp3_frames(modest_ctx *ctx, const modest_pp_frame *live, const uint32
         });
     if (rc) return rc;
     if (H_dev && N > 0) return modest_pp_entropy(ctx, cnt_used, N, T, H_dev, stream);
+    return MODEST_OK;
+}
+
+
+// ---- several scans per launch ---------------------------------------------------------
+// The chain above, once per BATCH of scans: every kernel gets the scan as blockIdx.y and reads that
+// scan's pointers from a device table (PPB); the bodies are the very functions the single-scan kernels
+// call.  Per scan nothing changes (same lists, slices, records, counts); what changes is that the nine
+// sub-10 us launches are paid once per batch, that the streaming workgroups of one scan start while
+// those of another finish, and that the start-up and the tail of the persistent join are paid once.
+namespace {
+struct PPB {
+    const float *liveXyz;
+    const unsigned *livePerm;
+    float *live;
+    uint4 *zero16;
+    unsigned long long nZero16, nCounts;
+    unsigned *cellCount, *fill, *bb, *ctrl3, *listTotal, *tileBase, *listLive, *dense, *denseBlock, *blockLive;
+    unsigned *cellStart, *blockSum, *bitmap, *bbPart, *wgTile, *wgOff;
+    float4 *sorted, *rec;
+    uint4 *slices;
+    int *counts;
+    float *H;
+    const FrameDev *frames;
+    const uint2 *chunkTab;
+    float liveRel[12];
+    int n_live, n_trav, nb, nPart, nchunks, nwg3, pair, sgrid;
+    unsigned sliceCap, maxSlices;
+};
+
+__global__ __launch_bounds__(256) void ppb_live_prep(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    RelM rm;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) rm.m[q] = S.liveRel[q];
+    pp3_live_prep_body(S.liveXyz, S.livePerm, S.n_live, rm, S.live, S.bbPart, S.zero16, (size_t)S.nZero16, S.counts,
+                       (size_t)S.nCounts, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void ppb_live_count(const PPB *__restrict__ tab, double c) {
+    const PPB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nb) return;
+    pp_live_count_body(S.live, S.n_live, S.bb, c, S.cellCount, S.bbPart, S.nPart, blockIdx.x, (unsigned)S.nb);
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void ppb_scan_bitmap(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    pp_scan_bitmap_body(S.cellCount, S.cellStart, S.blockSum, S.bitmap, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void ppb_scan_finish(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    pp_scan_finish_body(S.cellStart, S.blockSum, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void ppb_scatter_blocklive(const PPB *__restrict__ tab, double c) {
+    const PPB &S = tab[blockIdx.y];
+    pp3_scatter_blocklive_body(S.live, S.n_live, S.bb, c, S.cellStart, S.fill, S.sorted, S.nb, S.blockLive, blockIdx.x,
+                               gridDim.x);
+}
+__global__ __launch_bounds__(1024) void ppb_blocks(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    pp3_blocks_body(S.blockLive, S.dense, S.denseBlock, S.listLive, blockIdx.x, gridDim.x);
+}
+__device__ TravOffsets ppb_no_tr;   // stacked-history arguments of the stream body: never read when FRAMES
+__device__ ChunkMap3 ppb_no_cm;
+template <bool SCATTER>
+__global__ __launch_bounds__(1024, 8) void ppb_stream(const PPB *__restrict__ tab, double c) {
+    const PPB &S = tab[blockIdx.y];
+    const unsigned g = (unsigned)(SCATTER ? S.sgrid : S.nwg3);
+    if (blockIdx.x >= g) return;
+    pp3_stream_body<SCATTER, true>(nullptr, ppb_no_tr, ppb_no_cm, S.frames, S.chunkTab, S.nchunks, S.bb, c, S.bitmap, S.dense, S.wgTile,
+                                   S.wgOff, S.tileBase, S.rec, S.pair, blockIdx.x, g);
+}
+__global__ __launch_bounds__(1024) void ppb_scan(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    pp3_scan_body(S.wgTile, S.wgOff, S.nwg3, S.listTotal, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(1024) void ppb_plan(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    pp3_plan_body(S.listTotal, S.listLive, S.n_trav, S.sliceCap, S.tileBase, S.slices, S.maxSlices, S.ctrl3, blockIdx.x,
+                  gridDim.x);
+}
+// The join's pointers travel in the kernel-argument segment (loads from it are invariant: the compiler reloads them
+// instead of keeping them in registers; read from the device table they cost the register that makes the kernel spill).
+constexpr int PPB_MAX = 8;   // scans per batch
+struct JoinArgs {
+    const float4 *rec;
+    const uint4 *slices;
+    unsigned *ctrl3;
+    const unsigned *denseBlock, *cellStart;
+    const float4 *sorted;
+    int *counts;
+    int T, pad;
+};
+struct JoinArgsB {
+    JoinArgs a[PPB_MAX];
+};
+__global__ __launch_bounds__(V3_JT, 8) void ppb_join(const JoinArgsB A, double r2) {
+    // every scan keeps its own slice queue and its share of the persistent workgroups
+    const JoinArgs &S = A.a[blockIdx.y];
+    pp3_join_body<false>(S.rec, S.slices, S.ctrl3, S.denseBlock, S.cellStart, S.sorted, S.counts, S.T, r2, 0, nullptr,
+                         blockIdx.x);
+}
+__global__ void ppb_entropy(const PPB *__restrict__ tab) {
+    const PPB &S = tab[blockIdx.y];
+    if (S.H == nullptr || (int)blockIdx.x >= S.nb) return;
+    pp_entropy_kernel_body(S.counts, S.n_live, S.n_trav, S.H, blockIdx.x, gridDim.x);
+}
+}  // namespace
+
+int modest_pp3_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_frame *const *live,
+                            const uint32_t *const *live_perm_dev, const modest_pp_frame *const *frames,
+                            const int *n_frames, int n_trav, double radius, int32_t *const *counts_dev,
+                            float *const *H_dev, hipStream_t stream) {
+    MODEST_REQUIRE(n_scans >= 1 && n_scans <= 64, "1 <= n_scans <= 64");
+    if (n_scans > PPB_MAX) {   // groups of at most PPB_MAX scans
+        for (int s0 = 0; s0 < n_scans; s0 += PPB_MAX) {
+            const int m = n_scans - s0 < PPB_MAX ? n_scans - s0 : PPB_MAX;
+            int rc = modest_pp3_frames_batch(ctx, m, live + s0, live_perm_dev + s0, frames + s0, n_frames + s0, n_trav, radius,
+                                             counts_dev ? counts_dev + s0 : nullptr, H_dev ? H_dev + s0 : nullptr, stream);
+            if (rc) return rc;
+        }
+        return MODEST_OK;
+    }
+    const int T = n_trav;
+    bool plain = false;   // a scan the batched kernels do not cover: every scan takes the single-scan call
+    for (int s = 0; s < n_scans; ++s) {
+        long long pts = 0;
+        for (int f = 0; f < n_frames[s]; ++f) pts += frames[s][f].n;
+        if (live[s]->n == 0 || pts == 0 || (live[s]->n + 1023) / 1024 > PREP_BLOCKS) plain = true;
+    }
+    if (plain || n_scans == 1 || getenv("MODEST_PP_NOBATCH")) {
+        for (int s = 0; s < n_scans; ++s) {
+            int rc = modest_pp3_frames(ctx, live[s], live_perm_dev[s], frames[s], n_frames[s], n_trav, radius,
+                                       counts_dev ? counts_dev[s] : nullptr, H_dev ? H_dev[s] : nullptr, stream);
+            if (rc) return rc;
+        }
+        return MODEST_OK;
+    }
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    int nwg3 = 2 * ctx->num_cus < V3_MAXWG ? 2 * ctx->num_cus : V3_MAXWG;
+    {
+        const char *nw_env = getenv("MODEST_PP_NWG");
+        if (nw_env && atoi(nw_env) > 0 && atoi(nw_env) <= V3_MAXWG) nwg3 = atoi(nw_env);
+    }
+    const char *sr_env = getenv("MODEST_PP_SLICE");
+    unsigned sliceCap = sr_env ? (unsigned)atoi(sr_env) : V3_SLICE_MAX;
+    sliceCap = sliceCap < 256u ? 256u : (sliceCap > V3_SLICE_MAX ? V3_SLICE_MAX : sliceCap);
+    const size_t zero_words = (size_t)(PP_NCELL + 1) + PP_NCELL + 4 + 4 + 3 * V3_NL + 2 * V3_DWORDS + V3_DMAX + V3_NBLK + 68 +
+                              2 * (64 + 3 * 1024);
+    struct Lay {
+        int N, nch, nwg, pair, sgrid;
+        size_t maxSlices, descB, tabB, off, stageOff;
+    };
+    std::vector<Lay> L((size_t)n_scans);
+    size_t total = 0, stageB = 0;
+    int maxNb = 1, maxNwg = 1, maxSgrid = 1;
+    for (int s = 0; s < n_scans; ++s) {
+        Lay &l = L[(size_t)s];
+        l.N = live[s]->n;
+        long long nch = 0, pts = 0;
+        for (int f = 0; f < n_frames[s]; ++f) {
+            nch += (frames[s][f].n + V3_CH - 1) / V3_CH;
+            pts += frames[s][f].n;
+        }
+        MODEST_REQUIRE(nch < (1LL << 19) && pts < (1LL << 31), "history too large for the routed path");
+        l.nch = (int)nch;
+        l.nwg = nwg3 > l.nch ? l.nch : nwg3;
+        l.pair = (l.nwg % 2 == 0 && l.nwg >= 4 && !getenv("MODEST_PP_NOPAIR")) ? 1 : 0;
+        l.sgrid = l.pair ? l.nwg / 2 : l.nwg;
+        l.maxSlices = (size_t)V3_NL + (size_t)l.nch * V3_CH / 64 + 2;
+        l.descB = arena_sz((size_t)n_frames[s] * sizeof(FrameDev));
+        l.tabB = arena_sz((size_t)l.nch * sizeof(uint2));
+        l.off = total;
+        l.stageOff = stageB;
+        stageB += l.descB + l.tabB;
+        total += arena_sz(zero_words * 4) + arena_sz((size_t)(PP_NCELL + 1) * 4) + arena_sz(SCAN_NBLK * 4) +
+                 arena_sz(PP_BITWORDS * 4) + arena_sz((size_t)l.N * 16) + arena_sz((size_t)l.nch * V3_CH * 16) +
+                 2 * arena_sz((size_t)l.nwg * V3_NL * 4) + arena_sz(l.maxSlices * 16) + arena_sz((size_t)PREP_BLOCKS * 16) +
+                 arena_sz((size_t)l.N * 12 + 16) + arena_sz((size_t)l.N * T * 4);
+        maxNb = std::max(maxNb, (l.N + 255) / 256);
+        maxNwg = std::max(maxNwg, l.nwg);
+        maxSgrid = std::max(maxSgrid, l.sgrid);
+    }
+    const size_t tabOff = total, tableB = arena_sz((size_t)n_scans * sizeof(PPB));
+    // device: [scan arenas][PPB table][staged block]; the staged block = [scan 0: frames | chunks] [scan 1: ...] ...
+    // and the table travel through one pinned staging slot
+    int rc = modest_ctx_reserve(ctx, total + tableB + stageB);
+    if (rc) return rc;
+    char *hslot = nullptr;
+    rc = modest_ctx_stage_slot(ctx, stageB + tableB, reinterpret_cast<void **>(&hslot));
+    if (rc) return rc;
+    char *stageDev = ctx->scratch + total + tableB;
+    PPB *htab = reinterpret_cast<PPB *>(hslot + stageB);
+    for (int s = 0; s < n_scans; ++s) {
+        const Lay &l = L[(size_t)s];
+        FrameDev *hd = reinterpret_cast<FrameDev *>(hslot + l.stageOff);
+        uint2 *ht = reinterpret_cast<uint2 *>(hslot + l.stageOff + l.descB);
+        size_t k = 0;
+        for (int f = 0; f < n_frames[s]; ++f) {
+            const modest_pp_frame &fr = frames[s][f];
+            FrameDev &d = hd[f];
+            d.xyz = fr.xyz_dev;
+            d.tab = fr.tab_dev;
+            d.n = fr.n;
+            d.TX0 = fr.TX0;
+            d.TY0 = fr.TY0;
+            d.trav_flags = fr.trav | (fr.flags << 16);
+            for (int q = 0; q < 12; ++q) d.rel[q] = fr.rel[q];
+            for (int p0 = 0; p0 < fr.n; p0 += V3_CH) ht[k++] = make_uint2((unsigned)f, (unsigned)p0);
+        }
+        Arena A(ctx->scratch + l.off);
+        PPB &b = htab[s];
+        memset(&b, 0, sizeof(b));
+        unsigned *zeroed = A.take<unsigned>(zero_words);
+        b.zero16 = reinterpret_cast<uint4 *>(zeroed);
+        b.nZero16 = arena_sz(zero_words * 4) / 16;
+        b.cellCount = zeroed;
+        b.fill = b.cellCount + (PP_NCELL + 1);
+        b.bb = b.fill + PP_NCELL;
+        b.ctrl3 = b.bb + 4;
+        b.listTotal = b.ctrl3 + 4;
+        b.tileBase = b.listTotal + V3_NL;
+        b.listLive = b.tileBase + V3_NL;
+        b.dense = b.listLive + V3_NL;
+        b.denseBlock = b.dense + 2 * V3_DWORDS;
+        b.blockLive = b.denseBlock + V3_DMAX;
+        b.cellStart = A.take<unsigned>(PP_NCELL + 1);
+        b.blockSum = A.take<unsigned>(SCAN_NBLK);
+        b.bitmap = A.take<unsigned>(PP_BITWORDS);
+        b.sorted = A.take<float4>(l.N);
+        b.rec = A.take<float4>((size_t)l.nch * V3_CH);
+        b.wgTile = A.take<unsigned>((size_t)l.nwg * V3_NL);
+        b.wgOff = A.take<unsigned>((size_t)l.nwg * V3_NL);
+        b.slices = A.take<uint4>(l.maxSlices);
+        b.bbPart = A.take<unsigned>((size_t)PREP_BLOCKS * 4);
+        b.live = A.take<float>((size_t)l.N * 3 + 4);   // arena_sz(N * 12 + 16) above
+        int32_t *cscr = A.take<int32_t>((size_t)l.N * T);
+        b.counts = (counts_dev && counts_dev[s]) ? counts_dev[s] : cscr;
+        b.nCounts = (unsigned long long)l.N * T;
+        b.H = H_dev ? H_dev[s] : nullptr;
+        b.frames = reinterpret_cast<const FrameDev *>(stageDev + l.stageOff);
+        b.chunkTab = reinterpret_cast<const uint2 *>(stageDev + l.stageOff + l.descB);
+        b.liveXyz = live[s]->xyz_dev;
+        b.livePerm = live_perm_dev[s];
+        for (int q = 0; q < 12; ++q) b.liveRel[q] = live[s]->rel[q];
+        b.n_live = l.N;
+        b.n_trav = T;
+        b.nb = (l.N + 255) / 256;
+        b.nPart = (l.N + 1023) / 1024;
+        b.nchunks = l.nch;
+        b.nwg3 = l.nwg;
+        b.pair = l.pair;
+        b.sgrid = l.sgrid;
+        b.sliceCap = sliceCap;
+        b.maxSlices = (unsigned)l.maxSlices;
+    }
+    // one copy: [frames | chunks]* then the table (device layout: table at tabOff, staged block behind it)
+    MODEST_HIP_CHECK(hipMemcpyAsync(stageDev, hslot, stageB, hipMemcpyHostToDevice, stream));
+    MODEST_HIP_CHECK(hipMemcpyAsync(ctx->scratch + tabOff, hslot + stageB, (size_t)n_scans * sizeof(PPB),
+                                    hipMemcpyHostToDevice, stream));
+    rc = modest_ctx_stage_commit(ctx, stream);
+    if (rc) return rc;
+    const PPB *tab = reinterpret_cast<const PPB *>(ctx->scratch + tabOff);
+    if (!ctx->pp_attr_done) {
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_join<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pp3_scan),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_MAXWG * V3_SCAN_L * 4));
+        ctx->pp_attr_done = 1;
+    }
+    if (!ctx->ppb_attr_done) {
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ppb_join),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_JOIN_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ppb_scan),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, V3_MAXWG * V3_SCAN_L * 4));
+        ctx->ppb_attr_done = 1;
+    }
+    const double c = radius * (1.0 + 1.0 / 1024.0), r2 = radius * radius;
+    const unsigned B = (unsigned)n_scans;
+    modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the batch
+    ppb_live_prep<<<dim3(PREP_BLOCKS, B), 256, 0, stream>>>(tab);
+    ppb_live_count<<<dim3((unsigned)maxNb, B), 256, 0, stream>>>(tab, c);
+    ppb_scan_bitmap<<<dim3(SCAN_NBLK + PP_NY, B), SCAN_BLOCK, 0, stream>>>(tab);
+    ppb_scan_finish<<<dim3(SCAN_NBLK, B), SCAN_BLOCK, 0, stream>>>(tab);
+    ppb_scatter_blocklive<<<dim3((unsigned)maxNb + (V3_NBLK + 255) / 256, B), 256, 0, stream>>>(tab, c);
+    ppb_blocks<<<dim3(1, B), 1024, 0, stream>>>(tab);
+    ppb_stream<false><<<dim3((unsigned)maxNwg, B), 1024, 0, stream>>>(tab, c);
+    ppb_scan<<<dim3(V3_NL / V3_SCAN_L, B), 1024, (size_t)maxNwg * V3_SCAN_L * 4, stream>>>(tab);
+    ppb_plan<<<dim3(1, B), 1024, 0, stream>>>(tab);
+    ppb_stream<true><<<dim3((unsigned)maxSgrid, B), 1024, 0, stream>>>(tab, c);
+    // the join keeps the single-scan grid in total: two workgroups per CU, dealt over the scans
+    unsigned jx = (unsigned)(2 * ctx->num_cus) / B;
+    if (jx < 1) jx = 1;
+    JoinArgsB ja;
+    memset(&ja, 0, sizeof(ja));
+    for (int s = 0; s < n_scans; ++s) {
+        const PPB &b = htab[s];   // (the staging slot stays valid until its commit is overtaken)
+        ja.a[s] = JoinArgs{b.rec, b.slices, b.ctrl3, b.denseBlock, b.cellStart, b.sorted, b.counts, T, 0};
+    }
+    ppb_join<<<dim3(jx, B), V3_JT, V3_JOIN_LDS_DYN, stream>>>(ja, r2);
+    modest_prof_mark(ctx, stream, 1);
+    ppb_entropy<<<dim3((unsigned)maxNb, B), 256, 0, stream>>>(tab);
+    MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
 

@@ -39,3 +39,9 @@ __device__ __forceinline__ bool in_center_box(float x, float y) {
 int modest_pp3_frames(modest_ctx *ctx, const modest_pp_frame *live, const uint32_t *live_perm_dev,
                       const modest_pp_frame *frames, int n_frames, int n_trav, double radius,
                       int32_t *counts_dev, float *H_dev, hipStream_t stream);
+// the same chain once for a batch of scans (every kernel takes the scan as blockIdx.y), called by
+// modest_pp_score_frames_batch
+int modest_pp3_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_frame *const *live,
+                            const uint32_t *const *live_perm_dev, const modest_pp_frame *const *frames,
+                            const int *n_frames, int n_trav, double radius, int32_t *const *counts_dev,
+                            float *const *H_dev, hipStream_t stream);

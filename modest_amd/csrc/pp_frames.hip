@@ -224,3 +224,29 @@ extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *li
     // lattice against the poses, the kernels do not need it.
     return modest_pp3_frames(ctx, live, live_perm_dev, frames, n_frames, n_trav, radius, counts_dev, H_dev, stream);
 }
+
+extern "C" int modest_pp_score_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_frame *const *live,
+                                            const uint32_t *const *live_perm_dev,
+                                            const modest_pp_frame *const *frames, const int32_t *n_frames,
+                                            int n_trav, double radius, int32_t *const *counts_dev,
+                                            float *const *H_dev, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && live != nullptr && live_perm_dev != nullptr && frames != nullptr && n_frames != nullptr,
+                   "NULL argument");
+    MODEST_REQUIRE(n_scans >= 1 && n_scans <= 64, "1 <= n_scans <= 64");
+    MODEST_REQUIRE(n_trav >= 1 && n_trav <= F_MAXT, "1 <= n_trav <= 64 on the frame path");
+    MODEST_REQUIRE(radius > 0.0 && radius < 1e6, "radius must be positive and finite");
+    MODEST_REQUIRE(counts_dev != nullptr || H_dev != nullptr, "no output requested");
+    for (int s = 0; s < n_scans; ++s) {
+        MODEST_REQUIRE(live[s] != nullptr && live[s]->n >= 0 && live[s]->n < (1 << 24), "bad live scan");
+        MODEST_REQUIRE(live[s]->n == 0 || (live[s]->xyz_dev && live[s]->tab_dev && live_perm_dev[s]), "NULL live buffer");
+        MODEST_REQUIRE(n_frames[s] >= 0 && (n_frames[s] == 0 || frames[s] != nullptr), "bad frame list");
+        MODEST_REQUIRE((counts_dev && counts_dev[s]) || (H_dev && H_dev[s]) || live[s]->n == 0, "a scan without an output");
+        for (int f = 0; f < n_frames[s]; ++f) {
+            MODEST_REQUIRE(frames[s][f].trav >= 0 && frames[s][f].trav < n_trav, "frame traversal out of range");
+            MODEST_REQUIRE(frames[s][f].n >= 0 && frames[s][f].tab_dev != nullptr, "bad frame");
+            MODEST_REQUIRE(frames[s][f].n == 0 || frames[s][f].xyz_dev != nullptr, "NULL frame points");
+        }
+    }
+    return modest_pp3_frames_batch(ctx, n_scans, live, live_perm_dev, frames, n_frames, n_trav, radius, counts_dev, H_dev,
+                                   as_stream(stream_));
+}

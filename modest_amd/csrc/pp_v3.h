@@ -124,19 +124,17 @@ __device__ __forceinline__ void pp3_block_live_one(int b, const unsigned *__rest
 
 // last step of the live index build, one launch for two independent jobs: blocks [0, nb) place
 // the live points into their cells, the others count the live points of every block window
-__global__ __launch_bounds__(256) void pp3_scatter_blocklive(const float *__restrict__ live, int n, const unsigned *bb,
-                                                             double c, const unsigned *__restrict__ cellStart,
-                                                             unsigned *fill, float4 *__restrict__ sorted, int nb,
-                                                             unsigned *__restrict__ blockLive) {
-    if ((int)blockIdx.x < nb)
-        pp_live_scatter_one(blockIdx.x * 256 + threadIdx.x, live, n, bb, c, cellStart, fill, sorted);
+__device__ __forceinline__ void pp3_scatter_blocklive_body(const float *__restrict__ live, int n, const unsigned *bb, double c, const unsigned *__restrict__ cellStart, unsigned *fill, float4 *__restrict__ sorted, int nb, unsigned *__restrict__ blockLive, const unsigned bx, const unsigned gx) {
+    if ((int)bx < nb)
+        pp_live_scatter_one(bx * 256 + threadIdx.x, live, n, bb, c, cellStart, fill, sorted);
     else
-        pp3_block_live_one(((int)blockIdx.x - nb) * 256 + threadIdx.x, cellStart, blockLive);
+        pp3_block_live_one(((int)bx - nb) * 256 + threadIdx.x, cellStart, blockLive);
+}
+__global__ __launch_bounds__(256) void pp3_scatter_blocklive(const float *__restrict__ live, int n, const unsigned *bb, double c, const unsigned *__restrict__ cellStart, unsigned *fill, float4 *__restrict__ sorted, int nb, unsigned *__restrict__ blockLive) {
+    pp3_scatter_blocklive_body(live, n, bb, c, cellStart, fill, sorted, nb, blockLive, blockIdx.x, gridDim.x);
 }
 
-__global__ __launch_bounds__(1024) void pp3_blocks(const unsigned *__restrict__ blockLive, unsigned *__restrict__ dense,
-                                                   unsigned *__restrict__ denseBlock,
-                                                   unsigned *__restrict__ listLive) {
+__device__ __forceinline__ void pp3_blocks_body(const unsigned *__restrict__ blockLive, unsigned *__restrict__ dense, unsigned *__restrict__ denseBlock, unsigned *__restrict__ listLive, const unsigned bx, const unsigned gx) {
     __shared__ unsigned bits[V3_DWORDS];
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -180,6 +178,9 @@ __global__ __launch_bounds__(1024) void pp3_blocks(const unsigned *__restrict__ 
         dense[V3_DWORDS + tid] = before;
     }
 }
+__global__ __launch_bounds__(1024) void pp3_blocks(const unsigned *__restrict__ blockLive, unsigned *__restrict__ dense, unsigned *__restrict__ denseBlock, unsigned *__restrict__ listLive) {
+    pp3_blocks_body(blockLive, dense, denseBlock, listLive, blockIdx.x, gridDim.x);
+}
 
 // Cell of a history point, tested against the dilated bitmap: returns the list or -1;
 // *key = (cell row in the block << 3) | cell column in the block.
@@ -219,16 +220,16 @@ __device__ __forceinline__ void pp3_load4(const float *__restrict__ hist, long l
 // the fly (transform_points' float32 rounding, pp_frames.h; the pose is wave-uniform: scalar loads),
 // remove_center drops points before the transform (pre_compute_pp_score.py:141-142).
 template <bool SCATTER, bool FRAMES>
-__global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ hist, TravOffsets tr, ChunkMap3 cm,
-                                                      const FrameDev *__restrict__ frames,
-                                                      const uint2 *__restrict__ chunkTab, int nchunks,
-                                                      const unsigned *bb, double c,
-                                                      const unsigned *__restrict__ bitmap,
-                                                      const unsigned *__restrict__ dense,
-                                                      unsigned *__restrict__ wgTile /* [grid][NL] counts */,
-                                                      const unsigned *__restrict__ wgOff /* [grid][NL] offsets in the list */,
-                                                      const unsigned *__restrict__ tileBase,
-                                                      float4 *__restrict__ rec, int pair) {
+__device__ __forceinline__ void pp3_stream_body(const float *__restrict__ hist, const TravOffsets &tr, const ChunkMap3 &cm,
+                                                const FrameDev *__restrict__ frames,
+                                                const uint2 *__restrict__ chunkTab, int nchunks,
+                                                const unsigned *bb, double c,
+                                                const unsigned *__restrict__ bitmap,
+                                                const unsigned *__restrict__ dense,
+                                                unsigned *__restrict__ wgTile /* [grid][NL] counts */,
+                                                const unsigned *__restrict__ wgOff /* [grid][NL] offsets in the list */,
+                                                const unsigned *__restrict__ tileBase,
+                                                float4 *__restrict__ rec, int pair, const unsigned bx, const unsigned gx) {
     __shared__ unsigned sbits[PP_BITWORDS];
     __shared__ unsigned cur[V3_NL];
     __shared__ unsigned sdense[2 * V3_DWORDS];
@@ -238,13 +239,13 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
     // list) write streams let the L2 merge more of the 16-byte stores: 98 -> 80 us).  Scatter
     // workgroup v takes the chunks of count workgroups v and v + G/2, whose rows 2v and 2v+1 of the
     // matrix are adjacent, so its range of every list is contiguous.
-    const size_t row = !pair ? blockIdx.x
-                             : (SCATTER ? 2u * blockIdx.x : (blockIdx.x % (gridDim.x / 2)) * 2u + blockIdx.x / (gridDim.x / 2));
+    const size_t row = !pair ? bx
+                             : (SCATTER ? 2u * bx : (bx % (gx / 2)) * 2u + bx / (gx / 2));
     for (int i = tid; i < V3_NL; i += 1024) cur[i] = SCATTER ? tileBase[i] + wgOff[row * V3_NL + i] : 0u;
     if (tid < 2 * V3_DWORDS) sdense[tid] = dense[tid];
     const PPGrid g = pp_grid(bb, c);
     __syncthreads();
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (int chunk = bx; chunk < nchunks; chunk += gx) {
         int t = 0;
         long long p0, pend;
         const float *src = hist;
@@ -300,18 +301,31 @@ __global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ 
         for (int i = tid; i < V3_NL; i += 1024) wgTile[row * V3_NL + i] = cur[i];
     }
 }
+template <bool SCATTER, bool FRAMES>
+__global__ __launch_bounds__(1024, 8) void pp3_stream(const float *__restrict__ hist, TravOffsets tr, ChunkMap3 cm,
+                                                      const FrameDev *__restrict__ frames,
+                                                      const uint2 *__restrict__ chunkTab, int nchunks,
+                                                      const unsigned *bb, double c,
+                                                      const unsigned *__restrict__ bitmap,
+                                                      const unsigned *__restrict__ dense,
+                                                      unsigned *__restrict__ wgTile,
+                                                      const unsigned *__restrict__ wgOff,
+                                                      const unsigned *__restrict__ tileBase,
+                                                      float4 *__restrict__ rec, int pair) {
+    pp3_stream_body<SCATTER, FRAMES>(hist, tr, cm, frames, chunkTab, nchunks, bb, c, bitmap, dense, wgTile, wgOff, tileBase,
+                                     rec, pair, blockIdx.x, gridDim.x);
+}
 
 // ctrl3: [0] = #slices, [1] = dequeue head, [2] = total records
 // pp3_scan: a workgroup owns 64 consecutive lists.  The [workgroup][list] count matrix is read in
 // 256-byte pieces (coalesced), transposed through LDS, scanned along the workgroup axis in place
 // and written back as offsets inside each list; list totals go to listTotal.
 constexpr int V3_SCAN_L = 64;   // lists per scan workgroup
-__global__ __launch_bounds__(1024) void pp3_scan(const unsigned *__restrict__ wgTile, unsigned *__restrict__ wgOff,
-                                                 int nwg, unsigned *__restrict__ listTotal) {
+__device__ __forceinline__ void pp3_scan_body(const unsigned *__restrict__ wgTile, unsigned *__restrict__ wgOff, int nwg, unsigned *__restrict__ listTotal, const unsigned bx, const unsigned gx) {
     extern __shared__ unsigned m[];             // [nwg][64]
     __shared__ unsigned segSum[16][V3_SCAN_L];
     const int tid = threadIdx.x, j = tid & 63, seg = tid >> 6;
-    const int l0 = blockIdx.x * V3_SCAN_L;
+    const int l0 = bx * V3_SCAN_L;
     for (int k = seg; k < nwg; k += 16) m[k * V3_SCAN_L + j] = wgTile[(size_t)k * V3_NL + l0 + j];
     __syncthreads();
     const int per = (nwg + 15) / 16, k0 = seg * per, k1 = min(k0 + per, nwg);
@@ -334,6 +348,9 @@ __global__ __launch_bounds__(1024) void pp3_scan(const unsigned *__restrict__ wg
     __syncthreads();
     for (int k = seg; k < nwg; k += 16) wgOff[(size_t)k * V3_NL + l0 + j] = m[k * V3_SCAN_L + j];
 }
+__global__ __launch_bounds__(1024) void pp3_scan(const unsigned *__restrict__ wgTile, unsigned *__restrict__ wgOff, int nwg, unsigned *__restrict__ listTotal) {
+    pp3_scan_body(wgTile, wgOff, nwg, listTotal, blockIdx.x, gridDim.x);
+}
 
 // LDS bytes per live point of a band: float4 + T 16-bit counters (rounded up to a 32-bit pair)
 __host__ __device__ __forceinline__ unsigned pp3_live_bytes(int T) { return 16u + 4u * (unsigned)((T + 1) >> 1); }
@@ -341,11 +358,7 @@ __host__ __device__ __forceinline__ unsigned pp3_live_bytes(int T) { return 16u 
 // pp3_plan: one workgroup; list bases and the slice list, seven lists per thread in PROCESS
 // order (dense quadrant lists first, then the base lists centre-out).  A slice is sized so that
 // its records and the block's live points (+counters) share the LDS of one join workgroup.
-__global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ listTotal,
-                                                 const unsigned *__restrict__ listLive, int T,
-                                                 unsigned sliceCap, unsigned *__restrict__ tileBase,
-                                                 uint4 *__restrict__ slices, unsigned maxSlices,
-                                                 unsigned *ctrl3) {
+__device__ __forceinline__ void pp3_plan_body(const unsigned *__restrict__ listTotal, const unsigned *__restrict__ listLive, int T, unsigned sliceCap, unsigned *__restrict__ tileBase, uint4 *__restrict__ slices, unsigned maxSlices, unsigned *ctrl3, const unsigned bx, const unsigned gx) {
     __shared__ unsigned tot[16], nsl[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned lb = pp3_live_bytes(T);
@@ -403,6 +416,9 @@ __global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ li
         sBase += ns[j];
     }
 }
+__global__ __launch_bounds__(1024) void pp3_plan(const unsigned *__restrict__ listTotal, const unsigned *__restrict__ listLive, int T, unsigned sliceCap, unsigned *__restrict__ tileBase, uint4 *__restrict__ slices, unsigned maxSlices, unsigned *ctrl3) {
+    pp3_plan_body(listTotal, listLive, T, sliceCap, tileBase, slices, maxSlices, ctrl3, blockIdx.x, gridDim.x);
+}
 
 struct JoinShared {
     unsigned cursor[V3_NC];                   // cell histogram -> running cursor -> cell END offsets in the slice
@@ -416,12 +432,12 @@ struct JoinShared {
 };
 
 template <bool PROF>
-__global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ rec,
-                                                     const uint4 *__restrict__ slices, unsigned *ctrl3,
-                                                     const unsigned *__restrict__ denseBlock,
-                                                     const unsigned *__restrict__ cellStart,
-                                                     const float4 *__restrict__ sorted, int *counts, int T,
-                                                     double r2, int dbg, unsigned long long *stats) {
+__device__ __forceinline__ void pp3_join_body(const float4 *__restrict__ rec,
+                                              const uint4 *__restrict__ slices, unsigned *ctrl3,
+                                              const unsigned *__restrict__ denseBlock,
+                                              const unsigned *__restrict__ cellStart,
+                                              const float4 *__restrict__ sorted, int *counts, int T,
+                                              double r2, int dbg, unsigned long long *stats, const unsigned bx) {
     extern __shared__ __align__(16) unsigned char dynsm[];
     __shared__ JoinShared S;
     float4 *srec = reinterpret_cast<float4 *>(dynsm);   // the slice, sorted by cell
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         S.prof[k] += now_ - S.tlast;                     \
         S.tlast = now_;                                  \
     }
-    if (prof && tid == 0) stats[64 + blockIdx.x] = wall_clock64();
+    if (prof && tid == 0) stats[64 + bx] = wall_clock64();
     unsigned nMine = 0;
     if (tid == 0) {   // the first slice; later ones are fetched while the previous slice is processed
         const unsigned first = atomicAdd(&ctrl3[1], 1u);
@@ -785,7 +801,7 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
             const unsigned long long packed = (dur << 32) | sid;
             if (atomicMax(&stats[13], packed) < packed) {
                 for (int k = 0; k < 5; ++k) stats[16 + k] = S.prof[k] - S.prev[k];
-                stats[21] = S.prof[7] - stats[64 + blockIdx.x];   // start of the slice, relative to this WG's start
+                stats[21] = S.prof[7] - stats[64 + bx];   // start of the slice, relative to this WG's start
             }
             for (int k = 0; k < 5; ++k) S.prev[k] = S.prof[k];
         }
@@ -795,8 +811,8 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         }
     }
     if (prof && tid == 0) {   // per-workgroup start / end / slice count
-        stats[64 + 1024 + blockIdx.x] = wall_clock64();
-        stats[64 + 2048 + blockIdx.x] = nMine;
+        stats[64 + 1024 + bx] = wall_clock64();
+        stats[64 + 2048 + bx] = nMine;
     }
     if (prof) {
         if (tid == 0) {
@@ -814,4 +830,13 @@ __global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ 
         }
     }
 #undef PP3_TICK
+}
+template <bool PROF>
+__global__ __launch_bounds__(V3_JT, 8) void pp3_join(const float4 *__restrict__ rec,
+                                                     const uint4 *__restrict__ slices, unsigned *ctrl3,
+                                                     const unsigned *__restrict__ denseBlock,
+                                                     const unsigned *__restrict__ cellStart,
+                                                     const float4 *__restrict__ sorted, int *counts, int T,
+                                                     double r2, int dbg, unsigned long long *stats) {
+    pp3_join_body<PROF>(rec, slices, ctrl3, denseBlock, cellStart, sorted, counts, T, r2, dbg, stats, blockIdx.x);
 }

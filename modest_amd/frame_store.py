@@ -475,6 +475,38 @@ class FrameStore:
               "modest_pp_score_frames")
         return (H, counts) if return_counts else H
 
+    def pp_score_batch(self, live_keys, descs, n_trav: int, outs=None, return_counts: bool = False, ctx=None):
+        """PP scores of several scans in ONE chain of launches (modest_pp_score_frames_batch).  live_keys: the live
+        frame of every scan; descs: their tables from describe() (the frames must be resident).  Returns [H] (and
+        [counts]); results are those of separate pp_score calls, bit for bit."""
+        lib = load()
+        B, T = len(descs), int(n_trav)
+        if T > 64:
+            raise ValueError("the batched path takes at most 64 traversals")
+        Hs, cs = [], []
+        livep, permp, framep = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
+        Hp, cp = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
+        nfr = np.zeros(B, dtype=np.int32)
+        keep = []
+        for i, (lv, arr, slots) in enumerate(descs):
+            lv, arr = np.ascontiguousarray(lv), np.ascontiguousarray(arr)
+            keep.append((lv, arr))
+            N = int(lv["n"][0])
+            H = outs[i] if outs is not None and outs[i] is not None else torch.empty((N,), dtype=torch.float32, device=self.device)
+            c = torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None
+            Hs.append(H)
+            cs.append(c)
+            livep[i], framep[i], nfr[i] = lv.ctypes.data, arr.ctypes.data, len(slots) - 1
+            permp[i] = self.frames[live_keys[i]].perm.data_ptr()
+            Hp[i] = H.data_ptr()
+            cp[i] = c.data_ptr() if c is not None else 0
+        check(lib.modest_pp_score_frames_batch(self._ctx(ctx).handle, B, livep.ctypes.data, permp.ctypes.data,
+                                               framep.ctypes.data, nfr.ctypes.data, T, self.radius,
+                                               cp.ctypes.data if return_counts else None, Hp.ctypes.data,
+                                               torch.cuda.current_stream().cuda_stream),
+              "modest_pp_score_frames_batch")
+        return (Hs, cs) if return_counts else Hs
+
     def _pp_score_stacked(self, live, live_rel, frames, travs, rels, T, remove_center, return_counts, out, ctx):
         """Stacked path (V3 kernels on a transformed copy) for scans the frame path does not take:
         frames with outliers, more than 64 traversals, a lattice that disagrees with the poses."""

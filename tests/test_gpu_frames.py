@@ -122,3 +122,54 @@ def test_frames_edge_cases(gpu, T, radius):
     if T > 1:
         Href = opp.compute_ephe_score(cref)
         assert np.max(np.abs(H.cpu().numpy().astype(np.float64) - Href)) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_batched_chain_equals_separate_calls(gpu):
+    """modest_pp_score_frames_batch: several scans through one chain of launches (scan = blockIdx.y) give the
+    counts and scores of separate calls bit for bit -- scans of different size, traversal count below the
+    batch's, one scan without history (falls back to separate calls), more scans than one group takes."""
+    import torch
+    from modest_amd.frame_store import FrameStore
+    rng = np.random.default_rng(11)
+    T = 5
+    st = FrameStore(gpu, 0.3)
+    keys, descs, lives = [], [], []
+    key = 0
+    for sid in range(11):
+        n_live = int(rng.integers(800, 6000))
+        n_frames = int(rng.integers(1, 9)) if sid != 4 else 0
+        yaw = rng.uniform(-0.2, 0.2)
+        base = np.eye(4)
+        base[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
+        base[:3, 3] = rng.uniform(-3, 3, 3) * [1, 1, 0.05]
+        items, hist_keys, travs, rels = [], [], [], []
+        cloud = rng.uniform(-25, 25, (20000, 3)).astype(np.float32) * np.float32([1, 1, 0.04])
+        for f in range(n_frames):
+            sel = rng.choice(len(cloud), int(rng.integers(500, 9000)), replace=False)
+            raw = cloud[sel] + rng.normal(0, 0.05, (len(sel), 3)).astype(np.float32)
+            items.append((key, torch.from_numpy(np.ascontiguousarray(raw)).to(gpu), base.copy()))
+            hist_keys.append(key)
+            travs.append(int(rng.integers(0, T)))
+            rels.append(np.eye(4, dtype=np.float32))
+            key += 1
+        live_raw = cloud[rng.choice(len(cloud), n_live, replace=False)]
+        items.append((key, torch.from_numpy(np.ascontiguousarray(live_raw)).to(gpu), base.copy()))
+        lk = key
+        key += 1
+        st.insert_many(items)
+        rel = np.eye(4, dtype=np.float32)
+        desc = st.describe(lk, rel, hist_keys, travs, np.stack(rels) if rels else np.zeros((0, 4, 4), np.float32), sid % 2 == 1)
+        keys.append(lk)
+        descs.append(desc)
+        lives.append((rel, list(zip(hist_keys, travs)), np.stack(rels) if rels else np.zeros((0, 4, 4), np.float32), base, sid % 2 == 1))
+    single = []
+    for lk, d, (rel, hist, rels, base, rc) in zip(keys, descs, lives):
+        single.append(st.pp_score(lk, rel, hist, rels, base, T, remove_center=rc, return_counts=True, desc=d))
+    for group in (list(range(11)), [0, 1, 2, 3], [5, 6]):
+        Hs, cs = st.pp_score_batch([keys[i] for i in group], [descs[i] for i in group], T, return_counts=True)
+        torch.cuda.synchronize()
+        for i, H, c in zip(group, Hs, cs):
+            assert torch.equal(c, single[i][1]), i
+            assert torch.equal(H, single[i][0]), i
+    assert any(int(c.sum()) > 0 for _, c in single)

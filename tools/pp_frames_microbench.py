@@ -48,5 +48,35 @@ def main():
         bytes_alg = 12 * M + 16 * 30000
         print(json.dumps(dict(M=M, ms_per_scan=ms, alg_GBps=bytes_alg / ms / 1e6, frac_of_8TBps=bytes_alg / ms / 1e6 / 8000)), flush=True)
 
+    # several scans per chain of launches (modest_pp_score_frames_batch)
+    descs = []
+    for (s, st, hist, rels) in scans:
+        descs.append(st.describe("live", s.live_rel, [k for k, _ in hist], [t for _, t in hist], rels, False))
+    if all(sc[1] is scans[0][1] for sc in scans) or True:
+        pass
+    for B in (1, 2, 3, 4, 6, 8):
+        if B > nscan:
+            break
+        # one store per scan here: the batch call only needs resident frames, so borrow the first store's method
+        st0 = scans[0][1]
+        outs = [torch.empty((30000,), dtype=torch.float32, device=dev) for _ in range(B)]
+        for i in range(B):   # the live frames of the other stores must be found by key
+            st0.frames[("live", i)] = scans[i][1].frames["live"]
+        keys = [("live", i) for i in range(B)]
+        Hs = st0.pp_score_batch(keys, descs[:B], T, outs=outs)
+        torch.cuda.synchronize()
+        ok = all(bool(torch.equal(Hs[i], scans[i][1].pp_score("live", scans[i][0].live_rel, scans[i][2], scans[i][3],
+                                                               scans[i][0].world_from_ref, T))) for i in range(B))
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            K = 6
+            torch.cuda.synchronize()
+            e0.record()
+            for k in range(K):
+                st0.pp_score_batch(keys, descs[:B], T, outs=outs)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / K / B
+        print(json.dumps(dict(batch=B, equal_single=ok, ms_per_scan=ms, frac_of_8TBps=(12 * M + 16 * 30000) / ms / 1e6 / 8000)), flush=True)
+
 if __name__ == "__main__":
     main()
