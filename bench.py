@@ -66,7 +66,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=560)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--scans", type=int, default=3, help="distinct resident scans per host process, cycled through")
+    ap.add_argument("--scans", type=int, default=4, help="distinct resident scans per host process, cycled through")
+    ap.add_argument("--pp-batch", type=int, default=4,
+                    help="scans whose PP stage goes through ONE chain of launches (modest_pp_score_frames_batch); "
+                         "clamped to --scans; 1 = one chain per scan")
     ap.add_argument("--n-live", type=int, default=30000)
     ap.add_argument("--traversals", type=int, default=10)
     ap.add_argument("--frames", type=int, default=36)
@@ -198,6 +201,8 @@ class Runner:
             os.environ["MODEST_NUM_CUS"] = str(a.pp_cus)
         self.ctxs = [_lib.Context(local) for _ in range(self.n_threads)]
         self.prefetch = not (a.no_prefetch or a.pp_only or a.mask_only)
+        self.B = max(1, min(int(a.pp_batch), int(a.scans)))
+        self.mark_batch = [[] for _ in range(self.n_threads)]   # scans per profile mark, per thread
         self.pp_ctxs = self.ctxs
         if shared:
             del os.environ["MODEST_NUM_CUS"]
@@ -217,9 +222,13 @@ class Runner:
         self.ingest = False
         self.scan_locks = [threading.Lock() for _ in self.scans]   # ingest mode re-inserts a scan's frames: one step at a time per scan
         # every thread (stream + scratch arena + kernel attributes) runs before any clock starts
-        self.n_warm = max(a.warmup, 2 * self.n_threads)
+        self.n_warm = max(a.warmup, 2 * self.n_threads, self.B * self.n_threads)   # at least one full chain per thread
         self.run(0, self.n_warm)
         torch.cuda.synchronize()
+
+    def scan_of(self, i):
+        """step -> resident scan: a thread's consecutive steps take distinct scans (a batch never holds one twice)"""
+        return self.scans[(i // self.n_threads + i % self.n_threads) % len(self.scans)]
 
     def pp(self, sc, ctx, return_counts=False):
         if self.ingest:
@@ -227,33 +236,57 @@ class Runner:
         return self.store.pp_score(sc.live_key, sc.live_rel, sc.hist_keys, sc.rels, sc.A44, sc.T, ctx=ctx,
                                    desc=sc.desc, return_counts=return_counts)
 
-    def pp_with_ingest(self, sc, ctx):
+    def pp_many(self, scs, w):
+        """PP stage of several scans: one chain of launches for all of them (B > 1) -> [H]"""
+        ctx = self.ctxs[w]
+        self.mark_batch[w].append(len(scs))
+        if len(scs) == 1:
+            return [self.pp(scs[0], ctx)]
+        if not self.ingest:
+            return self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx)
+        order = sorted(range(len(scs)), key=lambda q: self.scans.index(scs[q]))
+        locks = [self.scan_locks[self.scans.index(scs[q])] for q in order]
+        for lk in locks:
+            lk.acquire()
+        try:
+            made = [self._ingest(sc, ctx) for sc in scs]
+            return self.store.pp_score_batch([k for k, _ in made], [d for _, d in made], scs[0].T, ctx=ctx)
+        finally:
+            for lk in reversed(locks):
+                lk.release()
+
+    def _ingest(self, sc, ctx):
         """What a scan of a Lyft shard costs before its kernels can start (consecutive scans share 35
         of 36 frames per traversal): its 11 new frames travel from pinned host memory to the device and are
         tile-sorted (one copy, one launch), the relative poses of all 361 frames are solved from the raw pose
         factors (get_relative_pose), and the descriptor table is built from the store -- nothing of the scan's
-        table is reused from a previous step."""
+        table is reused from a previous step.  -> (live key, descriptor table)"""
         from modest_amd.pre_compute_pp_score import relative_poses
-        with self.scan_locks[self.scans.index(sc)]:
-            sc.gen += 1
-            keys = [sc.slot_base + 16 * (sc.gen & 1) + j for j in range(len(sc.new_offs) - 1)]
-            old = [sc.slot_base + 16 * ((sc.gen + 1) & 1) + j for j in range(len(sc.new_offs) - 1)]
-            dev = torch.empty(sc.new_pinned.shape, dtype=torch.float32, device=self.dev)
-            dev.copy_(sc.new_pinned, non_blocking=True)
-            self.store.drop(old)
-            self.store.insert_block(keys, dev, sc.new_offs, sc.new_W, ctx=ctx)
-            rels = relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K)
-            hist_keys = list(sc.hist_keys)
-            for j, pos in enumerate(sc.new_pos):
-                hist_keys[pos] = (keys[j], hist_keys[pos][1])
-            return self.store.pp_score(keys[-1], rels[-1], hist_keys, rels[:-1], sc.A44, sc.T, ctx=ctx)
+        sc.gen += 1
+        keys = [sc.slot_base + 16 * (sc.gen & 1) + j for j in range(len(sc.new_offs) - 1)]
+        old = [sc.slot_base + 16 * ((sc.gen + 1) & 1) + j for j in range(len(sc.new_offs) - 1)]
+        dev = torch.empty(sc.new_pinned.shape, dtype=torch.float32, device=self.dev)
+        dev.copy_(sc.new_pinned, non_blocking=True)
+        self.store.drop(old)
+        self.store.insert_block(keys, dev, sc.new_offs, sc.new_W, ctx=ctx)
+        rels = relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K)
+        hist_keys = list(sc.hist_keys)
+        for j, pos in enumerate(sc.new_pos):
+            hist_keys[pos] = (keys[j], hist_keys[pos][1])
+        return keys[-1], self.store.describe(keys[-1], rels[-1], [k for k, _ in hist_keys], [t for _, t in hist_keys],
+                                             rels[:-1])
 
-    def step(self, i, ctx, H=None, next_i=None):
-        """One scan through the pipeline.  H: the scan's PP score when it was enqueued ahead of time;
-        next_i: the worker's next step -- its PP stage is enqueued (same stream, same context) as soon
-        as this scan has no device work left, i.e. under the host tail of the label stage.
-        Returns (H, labels, objs, text, H of step next_i or None)."""
-        a, sc = self.a, self.scans[i % len(self.scans)]
+    def pp_with_ingest(self, sc, ctx):
+        with self.scan_locks[self.scans.index(sc)]:
+            key, desc = self._ingest(sc, ctx)
+            return self.store.pp_score_batch([key], [desc], sc.T, ctx=ctx)[0]   # one scan: the library takes the single-scan chain
+
+    def step(self, i, w, H=None, after=None):
+        """One scan through the pipeline on thread w.  H: the scan's PP score when it was enqueued ahead of time;
+        after: called (same stream, same context) as soon as this scan has no device work left, i.e. under the
+        host tail of the label stage -- the worker enqueues the PP stage of its next batch of scans there.
+        Returns (H, labels, objs, text)."""
+        a, sc, ctx = self.a, self.scan_of(i), self.ctxs[w]
         if H is not None:
             pass   # enqueued ahead of time
         elif a.mask_only:   # diagnostic: the PP score of the scan is computed once, steps run stages 2 + 3
@@ -261,21 +294,17 @@ class Runner:
                 sc._H = self.pp(sc, ctx)
             H = sc._H
         else:
-            H = self.pp(sc, ctx)
+            H = self.pp_many([sc], w)[0]
         if a.pp_only:
-            return H, None, None, None, None
+            return H, None, None, None
         pp_host = H.cpu().numpy()
         # boxes stay (k,8) rows between the stages: the SimpleNamespace objects of the reference exist for its
         # pickle files, which the CLIs write and this in-memory pipeline does not
         labels, objs, _ = self._generate_mask_scan(sc.live_host, pp_host, sc.calib, self.margs,
                                                    random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H,
                                                    as_rows=True)
-        ahead = []
-        hook = None
-        if next_i is not None and self.prefetch:
-            hook = lambda: ahead.append(self.pp(self.scans[next_i % len(self.scans)], ctx))   # noqa: E731
-        text, kept = self._gen_label_scan(objs, sc.calib, self.largs, after_device=hook)
-        return H, labels, objs, text, (ahead[0] if ahead else None)
+        text, kept = self._gen_label_scan(objs, sc.calib, self.largs, after_device=after)
+        return H, labels, objs, text
 
     def run(self, lo, hi):
         """steps lo..hi-1, dealt round-robin to the worker threads"""
@@ -286,9 +315,22 @@ class Runner:
                 torch.cuda.set_device(self.dev)
                 with torch.cuda.stream(self.streams[w]):
                     idx = list(range(lo + w, hi, self.n_threads))
-                    H = None
+                    B, Hq = self.B, {}
+
+                    def enqueue(k0):   # the PP stage of steps idx[k0 : k0 + B]: one chain of launches
+                        js = idx[k0:k0 + B]
+                        if js:
+                            Hq.update(zip(js, self.pp_many([self.scan_of(j) for j in js], w)))
+
                     for k, i in enumerate(idx):
-                        H = self.step(i, self.ctxs[w], H=H, next_i=idx[k + 1] if k + 1 < len(idx) else None)[4]
+                        if self.a.mask_only:
+                            self.step(i, w)
+                            continue
+                        if i not in Hq:
+                            enqueue(k)
+                        last = (k + 1) % B == 0 or k + 1 == len(idx)   # last step of its batch: the next batch goes out
+                        hook = (lambda k1=k + 1: enqueue(k1)) if (self.prefetch and last and k + 1 < len(idx)) else None
+                        self.step(i, w, H=Hq.pop(i), after=hook)
                     self.streams[w].synchronize()
             except Exception as e:   # surfaced after join
                 errs.append(e)
@@ -307,32 +349,46 @@ class Runner:
     def timed(self, n_steps, ingest=False):
         """n_steps steps -> (seconds, HIP-event times of every PP stage launched)"""
         self.ingest = bool(ingest)
-        if ingest:   # a few untimed steps in this mode first (allocator, slot tables)
-            self.run(0, 2 * self.n_threads)
+        if ingest:   # two untimed chains per thread in this mode first (allocator, slab, slot tables)
+            self.run(0, 2 * self.B * self.n_threads)
             torch.cuda.synchronize()
-        for c_ in self.pp_ctxs:
+        for w, c_ in enumerate(self.pp_ctxs):
             c_.profile_begin(n_steps + 8)
+            self.mark_batch[w] = []
         t0 = time.perf_counter()
         self.run(self.n_warm, self.n_warm + n_steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         self.ingest = False
-        return dt, np.concatenate([c_.profile_collect(n_steps + 8) for c_ in self.pp_ctxs])
+        per_scan = []   # a mark brackets the chain of a whole batch: report it per scan, once per scan
+        for w, c_ in enumerate(self.pp_ctxs):
+            ms = c_.profile_collect(n_steps + 8)
+            sizes = self.mark_batch[w][-len(ms):] if len(ms) else []
+            for m, b in zip(ms, sizes):
+                per_scan.extend([float(m) / b] * b)
+        return dt, np.asarray(per_scan, dtype=np.float32)
 
     def isolated_pp_ms(self):
-        """The PP stage alone on the GPU, cycling through ALL resident scans (>= 3 x 130 MB of
-        distinct history: the 256 MiB Infinity Cache cannot hold the working set)."""
-        reps = max(4 * len(self.scans), 12)
+        """The PP stage alone on the GPU: chains of B scans (all resident scans, >= 4 x 130 MB of distinct
+        history: the 256 MiB Infinity Cache cannot hold the working set), HIP events around every chain.
+        -> (ms per chain, scans per chain)"""
+        B = self.B
+        reps = 8
         if self.iso_ctx is None:   # alone on the GPU: grids sized for all CUs
             self.iso_ctx = self._lib.Context(self.local)
         ctx = self.iso_ctx
         ctx.profile_begin(reps + 4)
         with torch.cuda.stream(self.streams[0]):
             for i in range(reps):
-                self.pp(self.scans[i % len(self.scans)], ctx)
+                scs = [self.scans[(i * B + q) % len(self.scans)] for q in range(B)]
+                if B == 1:
+                    self.store.pp_score(scs[0].live_key, scs[0].live_rel, scs[0].hist_keys, scs[0].rels, scs[0].A44, scs[0].T,
+                                        ctx=ctx, desc=scs[0].desc)
+                else:
+                    self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx)
             self.streams[0].synchronize()
         iso = ctx.profile_collect(reps + 4)
-        return float(np.mean(iso[len(self.scans):])) if len(iso) > len(self.scans) else None
+        return (float(np.mean(iso[2:])), B) if len(iso) > 2 else None
 
 
 def scan_seed(rank, slot, i):
@@ -593,13 +649,15 @@ def main():
 
     # the same stage with nothing else on the GPU (the timed region has several scans in flight, so its
     # event pairs also see the other scans' kernels): informational, not the reported `achieved`
-    iso_ms = None
+    iso_ms, iso_B = None, 1
     if rank == 0:
         if helpers:
             helpers[0][1].send(("iso", None))
-            iso_ms = helpers[0][1].recv()[1]
+            iso = helpers[0][1].recv()[1]
         else:
-            iso_ms = runner.isolated_pp_ms()
+            iso = runner.isolated_pp_ms()
+        if iso:
+            iso_ms, iso_B = float(iso[0]), int(iso[1])   # ms per chain of launches, scans per chain
     for p, pc in helpers:
         pc.send(("exit", None))
     for p, pc in helpers:
@@ -613,7 +671,7 @@ def main():
     contended = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms else None
     # top level = the stage alone on the GPU (the figure that follows from profiles/*_pp_only_kernel_stats.csv);
     # the event pairs of the timed region also bracket the other scans' kernels and are reported as `in_pipeline`
-    achieved = alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms else contended
+    achieved = iso_B * alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms else contended
     traffic, traffic_src = None, None
     for tname in ("r03_pp_traffic.json", "r02_pp_traffic.json", "r01_pp_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
@@ -622,25 +680,32 @@ def main():
             if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
                 traffic, traffic_src = tj["hbm_bytes_per_scan"], f"profiles/{tname} (" + tj["source"] + ")"
                 break
+    pp_B = max(1, min(a.pp_batch, a.scans))
     roofline = {"bound": "hbm",
-                "kernel": "PP neighbour count of one scan = live prep (transform + bounding box + clears, 1 launch) + live index build (5 launches) + "
-                          "pp3_stream<count> + pp3_scan + pp3_plan + pp3_stream<scatter> + pp3_join: ALL launches of the "
-                          "stage, HIP events on the launch stream; the history is read from the frame store through the "
-                          "descriptor table (pose fused), not from a stacked copy",
+                "kernel": f"PP neighbour count, ONE chain of launches for {iso_B} scan(s) (modest_pp_score_frames_batch: every "
+                          "kernel takes the scan as blockIdx.y) = live prep (transform + bounding box + clears) + live index "
+                          "build (5 launches) + pp3_stream<count> + pp3_scan + pp3_plan + pp3_stream<scatter> + pp3_join: ALL "
+                          "launches of the stage, HIP events on the launch stream; the history is read from the frame store "
+                          "through the descriptor table (pose fused), not from a stacked copy",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": iso_ms if iso_ms else k_ms,
-                "measured": (f"HIP events on the launch stream around the stage, one scan at a time on an otherwise idle GPU, "
-                             f"cycling {a.scans} distinct scans (> 256 MiB of history: the Infinity Cache cannot hold them), "
-                             "after the timed region") if iso_ms else "HIP events in the timed region",
-                "in_pipeline": {"kernel_ms": k_ms, "achieved": contended,
+                "scans_per_launch": iso_B if iso_ms else 1,
+                "algorithmic_bytes_per_launch": (iso_B if iso_ms else 1) * alg_bytes,
+                "algorithmic_bytes_per_scan": alg_bytes,
+                "kernel_ms": iso_ms if iso_ms else k_ms,
+                "kernel_ms_per_scan": (iso_ms / iso_B) if iso_ms else k_ms,
+                "measured": (f"HIP events on the launch stream around the chain, one chain at a time on an otherwise idle GPU, "
+                             f"the {a.scans} distinct resident scans (> 256 MiB of history: the Infinity Cache cannot hold "
+                             "them), after the timed region") if iso_ms else "HIP events in the timed region",
+                "in_pipeline": {"kernel_ms_per_scan": k_ms, "achieved": contended,
                                 "frac": (contended / HBM_PEAK_GBPS) if contended else None,
-                                "launches_timed": int(len(kernel_ms)),
-                                "note": "the same event pairs inside the timed region: several scans are in flight on grids "
-                                        "sized for part of the GPU, a pair also brackets the other scans' kernels"},
-                "isolated": {"kernel_ms": iso_ms,
-                             "frac": (alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso_ms else None}}
+                                "scans_timed": int(len(kernel_ms)), "scans_per_launch": pp_B,
+                                "note": "the same event pairs inside the timed region, divided by the scans of their chain: "
+                                        "several chains are in flight on grids sized for part of the GPU, a pair also brackets "
+                                        "the other processes' kernels"},
+                "isolated": {"kernel_ms": iso_ms, "scans_per_launch": iso_B,
+                             "frac": (iso_B * alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if iso_ms else None}}
 
     cpu_baseline = None
     parity = None
@@ -670,14 +735,20 @@ def main():
         tc = time.perf_counter() - tc
         # parity of the measured path against the checker on the first sampled scan, outside every timed region
         pa = argparse.Namespace(**vars(a))
-        pa.scans, pa.warmup, pa.streams = 1, 0, 1
+        pa.scans, pa.warmup, pa.streams = n_cpu, 0, 1
+        pa.pp_batch = min(max(a.pp_batch, 1), n_cpu)
         pr = Runner(pa, rank, local, 0)
-        Hg, cg = pr.pp(pr.scans[0], pr.ctxs[0], return_counts=True)
+        # every sampled scan through ONE chain of launches, as the timed region runs them
+        Hgs, cgs = pr.store.pp_score_batch([sc.live_key for sc in pr.scans], [sc.desc for sc in pr.scans], pr.scans[0].T,
+                                           ctx=pr.ctxs[0], return_counts=True)
         Href, cref, ref = refs[0]
-        parity = {"pp_counts_equal": bool(np.array_equal(cg.cpu().numpy().astype(np.int64), cref)),
-                  "pp_max_abs_err": float(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - Href)))}
+        parity = {"pp_counts_equal": bool(all(np.array_equal(cg.cpu().numpy().astype(np.int64), r[1])
+                                              for cg, r in zip(cgs, refs))),
+                  "pp_max_abs_err": float(max(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - r[0]))
+                                              for Hg, r in zip(Hgs, refs))),
+                  "pp_scans_per_launch": len(cgs)}
         if ref is not None:
-            _, labels, objs, text, _ = pr.step(0, pr.ctxs[0])
+            _, labels, objs, text = pr.step(0, 0)
             parity["labels_equal"] = bool(np.array_equal(labels, ref["labels"]))
             parity["n_objs"] = [len(objs), len(ref["objs"])]
             parity["label_text_equal"] = bool(text == ref["text"][0])
@@ -718,6 +789,7 @@ def main():
                        "host_processes_per_gpu": n_procs, "threads_per_process": n_threads,
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
                        "pp_stage_prefetch": (not (a.no_prefetch or a.pp_only or a.mask_only)),
+                       "pp_scans_per_launch": max(1, min(a.pp_batch, a.scans)),
                        "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
                        "rccl_world_size": rccl_ws,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},

@@ -407,9 +407,29 @@ def main(args):
     # the ingest / writer threads hand the GIL back and forth with this loop: CPython's default forced-switch
     # interval (5 ms) is longer than a whole scan
     sys.setswitchinterval(float(os.environ.get("MODEST_SWITCH_INTERVAL", "0.0002")))
-    pipe = IngestPipeline(loader, plans(), device, depth=int(args.get("ingest_depth", 4)),
+    # pp_batch consecutive scans go through ONE chain of launches (modest_pp_score_frames_batch): the loop below
+    # collects their descriptor tables and flushes; the ingest window must hold a whole batch plus the scans ahead
+    n_batch = max(1, int(args.get("pp_batch", 4)))
+    pipe = IngestPipeline(loader, plans(), device, depth=int(args.get("ingest_depth", 4)) + (n_batch - 1),
                           own_stream=not os.environ.get("MODEST_WORKER"))
     writer = OutputWriter(1 << 16)
+    pend = []   # (live frame, descriptor table, output path, scan id, traversals) of the scans waiting for the flush
+
+    def flush():
+        if not pend:
+            return
+        if len(pend) == 1:   # the library would take the single-scan chain anyway
+            Hs = store.pp_score_batch([pend[0][0]], [pend[0][1]], pend[0][4])
+        else:
+            Hs = store.pp_score_batch([q[0] for q in pend], [q[1] for q in pend], pend[0][4])
+        for q, H in zip(pend, Hs):
+            _tr("M.enq", q[3])
+            writer.submit(H, q[2])
+            _tr("M.sub", q[3])
+        for _ in pend:
+            pipe.done()
+        pend.clear()
+
     for plan in pipe:
         origin_idx, out_path, traversals = plan["origin"], plan["out"], plan["traversals"]
         live_id, hist_ids, travs = plan["live"], plan["hist"], plan["travs"]
@@ -428,6 +448,7 @@ def main(args):
                 combined[sq] = np.concatenate(parts) if parts else np.zeros((0, 3), np.float32)
             pickle.dump(combined, open(osp.join(dp.load_precomputed_lidars, f"{origin_idx:06d}.pkl"), "wb"))
         if args.skip_ephe:
+            flush()
             pipe.done()
             continue
         n_trav = len(traversals)
@@ -435,6 +456,20 @@ def main(args):
             n_trav = min(n_trav, int(args.limit_traversals))
         keep = [k for k, t in enumerate(travs) if t < n_trav]
         hist = [(hist_ids[k], travs[k]) for k in keep]
+        batched = not (args.add_random_noise > 0) and n_trav <= 64
+        if batched:
+            if pend and pend[0][4] != n_trav:
+                flush()
+            pend.append((live_id, store.describe(live_id, trans_mat, [i for i, _ in hist], [t for _, t in hist], rels[keep],
+                                                 bool(args.nusc)), out_path, origin_idx, n_trav))
+            done += 1
+            pts += store.points_of([i for i, _ in hist])
+            if len(pend) >= n_batch:
+                flush()
+            if trace and (done <= 4 or done % 8 == 0):
+                eprint("[pp_score trace] scan %d submitted at %.1f ms" % (done, 1e3 * (time.perf_counter() - t0)))
+            continue
+        flush()   # scans leave the ingest window in plan order
         if args.add_random_noise > 0:            # (:175-179) host draw, same numpy expressions; stacked path
             noise = np.random.randn(3)
             noise /= np.linalg.norm(noise)
@@ -459,6 +494,7 @@ def main(args):
             eprint("[pp_score trace] scan %d submitted at %.1f ms" % (done, 1e3 * (time.perf_counter() - t0)))
         pts += store.points_of([i for i, _ in hist])
         pipe.done()
+    flush()
     writer.close()
     if TRACE is not None:
         base = TRACE[0][2]

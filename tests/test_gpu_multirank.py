@@ -80,6 +80,14 @@ def test_three_clis_two_ranks_one_gpu(gpu, tmp_path):
                                       busy_seconds=[float(mm.group(3)), float(mm.group(4))], imbalance_percent=float(mm.group(5)))
     for k in ("two", "parts", "queue"):
         _same_tree(outs["one"], outs[k])
+    # scans per chain of launches (pp_batch, default 4) do not change a score file
+    for nb in (1, 7):
+        o = str(tmp_path / f"batch{nb}")
+        _run(CLIS[0], _overrides(train, paths, o) + [f"pp_batch={nb}"], 1, 0)
+        fa = sorted(f for f in os.listdir(os.path.join(o, "pp")) if f != "configs.yaml")
+        assert len(fa) == N_SCANS
+        match, mismatch, err = filecmp.cmpfiles(os.path.join(outs["one"], "pp"), os.path.join(o, "pp"), fa, shallow=False)
+        assert not mismatch and not err, (nb, mismatch[:5], err[:5])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "multirank_report.json"), "w") as f:
         json.dump(dict(scans=N_SCANS, world_size=2, note="both ranks on GPU 0, gloo collectives", per_cli=report), f, indent=1)
