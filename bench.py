@@ -678,7 +678,7 @@ def main():
         if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
             tj = json.load(open(tpath))
             if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
-                traffic, traffic_src = tj["hbm_bytes_per_scan"], f"profiles/{tname} (" + tj["source"] + ")"
+                traffic, traffic_src = tj["hbm_bytes_per_scan"] * (iso_B if iso_ms else 1), f"profiles/{tname} (" + tj["source"] + ")"   # per launch, like `achieved`
                 break
     pp_B = max(1, min(a.pp_batch, a.scans))
     roofline = {"bound": "hbm",
@@ -690,6 +690,7 @@ def main():
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_per_scan": (traffic / (iso_B if iso_ms else 1)) if traffic else None,
                 "scans_per_launch": iso_B if iso_ms else 1,
                 "algorithmic_bytes_per_launch": (iso_B if iso_ms else 1) * alg_bytes,
                 "algorithmic_bytes_per_scan": alg_bytes,

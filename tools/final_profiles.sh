@@ -21,7 +21,7 @@ rm -rf gpurun_out/prof_single
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_single -o bench -- python bench.py --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 --steps 64 > gpurun_out/prof_single.log 2>&1
 cp gpurun_out/prof_single/bench_kernel_stats.csv $F/bench_full_1proc_kernel_stats.csv
 rm -rf gpurun_out/prof_pp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pp -o bench -- python bench.py --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 --steps 16 --warmup 2 > gpurun_out/prof_pp.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pp -o bench -- python bench.py --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 --steps 32 --warmup 4 > gpurun_out/prof_pp.log 2>&1
 cp gpurun_out/prof_pp/bench_kernel_stats.csv $F/pp_only_kernel_stats.csv
 rm -f gpurun_out/prof_single/*kernel_trace.csv gpurun_out/prof_pp/*kernel_trace.csv
 bash tools/pp_pmc.sh > $F/pp_pmc.log 2>&1
@@ -29,7 +29,7 @@ cp gpurun_out/pp_pmc.json $F/pp_pmc_counters.json; cp gpurun_out/pp_traffic.json
 tail -1 $F/pp_pmc.log
 for f in $F/bench_*.json; do python -c "
 import json,sys; d=json.load(open('$f')); r=d['roofline']
-print('$f'.split('/')[-1], '%.0f scans/s' % d['value'], 'stage %.3f ms frac %.4f' % (r['kernel_ms'], r['frac']), 'isolated %.3f ms %.4f' % (r['isolated']['kernel_ms'], r['isolated']['frac']), d.get('speedup_vs_cpu'))"; done
+print('$f'.split('/')[-1], '%.0f scans/s' % d['value'], 'chain of %d scans %.3f ms frac %.4f' % (r['scans_per_launch'], r['kernel_ms'], r['frac']), d.get('speedup_vs_cpu'))"; done
 python tools/kstats.py $F/bench_full_1proc_kernel_stats.csv 70
 # ordered launch list of one full-pipeline scan (one scan at a time)
 bash tools/scan_trace.sh > /dev/null 2>&1; cp gpurun_out/scan_trace.txt $F/scan_trace.txt

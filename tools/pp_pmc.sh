@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for pass in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf gpurun_out/pmc_$tag
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_$tag -o p -- python bench.py --steps 4 --warmup 1 --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 > gpurun_out/pmc_$tag.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_$tag -o p -- python bench.py --steps 8 --warmup 4 --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 > gpurun_out/pmc_$tag.log 2>&1
 done
 python - <<'PY'
 import csv,glob,collections,json

@@ -1,28 +1,32 @@
 """HBM bytes per scan of the PP stage from the PMC passes of tools/pp_pmc.sh (gpurun_out/pp_pmc.json):
-FETCH_SIZE / WRITE_SIZE are reported in KiB per launch; both are calibrated on pp3_stream<count>,
-whose traffic is known (it reads the 12-byte history points once and writes its count matrix).
-Writes gpurun_out/pp_traffic.json (copied to profiles/r02_pp_traffic.json, which bench.py reads)."""
+FETCH_SIZE / WRITE_SIZE are reported in KiB per launch; a launch of the batched chain (ppb_*) processes PP_BATCH
+scans (bench.py --pp-batch, default 4).  Both counters are calibrated on the count pass (ppb_stream<false>), whose
+traffic is known (it reads the 12-byte history points once and writes its count matrix).
+Writes gpurun_out/pp_traffic.json (copied to profiles/rNN_pp_traffic.json, which bench.py reads)."""
 import json
+import os
 
 M, N_WG, N_LIST = 10_800_000, 512, 7168
-d = json.load(open("gpurun_out/pp_pmc.json"))
-per_scan = {k: (2 if "fillBuffer" in k else 1) for k in d}      # launches per scan
+B = int(os.environ.get("PP_BATCH", "4"))
+d = {k: v for k, v in json.load(open("gpurun_out/pp_pmc.json")).items() if k.startswith("ppb_")}
+per_scan = {k: 1.0 / B for k in d}      # launches per scan
 fetch = sum(v.get("FETCH_SIZE", 0.0) * 1024 * per_scan[k] for k, v in d.items())
 write = sum(v.get("WRITE_SIZE", 0.0) * 1024 * per_scan[k] for k, v in d.items())
-cnt = [v for k, v in d.items() if "pp3_stream<false" in k][0]
-f_fac = (12.0 * M + 28 * 1024) / (cnt["FETCH_SIZE"] * 1024)
-w_fac = (N_WG * N_LIST * 4.0) / (cnt["WRITE_SIZE"] * 1024)
+cnt = [v for k, v in d.items() if "ppb_stream<false" in k][0]
+f_fac = B * (12.0 * M + 28 * 1024) / (cnt["FETCH_SIZE"] * 1024)
+w_fac = B * (N_WG * N_LIST * 4.0) / (cnt["WRITE_SIZE"] * 1024)
 out = {
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 "
-              "--warmup 1 --pp-only --cpu-scans 0 --procs 1 --streams 1; tools/pp_pmc.sh + tools/pp_traffic.py",
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 8 "
+              "--warmup 4 --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1; tools/pp_pmc.sh + tools/pp_traffic.py",
+    "scans_per_launch": B,
     "fetch_raw_bytes_per_scan": fetch,
     "write_raw_bytes_per_scan": write,
     "fetch_calibration": {
-        "kernel": "pp3_stream<count> reads 12 B x 10.8 M points (frame store, through the descriptor table) + 28 KB of tables with 16-byte coalesced loads",
+        "kernel": "ppb_stream<count> reads 12 B x 10.8 M points per scan (frame store, through the descriptor table) + 28 KB of tables with 16-byte coalesced loads",
         "factor": f_fac,
         "note": "MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read on gfx950 -> doubled",
     },
-    "write_calibration": {"kernel": "pp3_stream<false> writes its 512 x 7168 x 4 B count matrix", "factor": w_fac},
+    "write_calibration": {"kernel": "ppb_stream<false> writes a 512 x 7168 x 4 B count matrix per scan", "factor": w_fac},
     "hbm_bytes_per_scan": fetch * f_fac + write * w_fac,
     "algorithmic_bytes_per_scan": 12.0 * M + 16.0 * 30_000,
     "per_kernel_bytes": {k: {"fetch": v.get("FETCH_SIZE", 0.0) * 1024 * f_fac * per_scan[k],
