@@ -178,6 +178,7 @@ class Runner:
 
     def __init__(self, a, rank, local, slot):
         import threading
+        self.slot = int(slot)
         from modest_amd import _lib, config, ops, synth
         from modest_amd.frame_store import FrameStore
         from modest_amd.gen_label_files import gen_label_scan
@@ -249,36 +250,47 @@ class Runner:
         for lk in locks:
             lk.acquire()
         try:
-            made = [self._ingest(sc, ctx) for sc in scs]
+            made = self._ingest(scs, ctx)
             return self.store.pp_score_batch([k for k, _ in made], [d for _, d in made], scs[0].T, ctx=ctx)
         finally:
             for lk in reversed(locks):
                 lk.release()
 
-    def _ingest(self, sc, ctx):
-        """What a scan of a Lyft shard costs before its kernels can start (consecutive scans share 35
-        of 36 frames per traversal): its 11 new frames travel from pinned host memory to the device and are
-        tile-sorted (one copy, one launch), the relative poses of all 361 frames are solved from the raw pose
-        factors (get_relative_pose), and the descriptor table is built from the store -- nothing of the scan's
-        table is reused from a previous step.  -> (live key, descriptor table)"""
+    def _ingest(self, scs, ctx):
+        """What the scans of a Lyft shard cost before their kernels can start (consecutive scans share 35
+        of 36 frames per traversal): the 11 new frames of every scan travel from pinned host memory to the device and
+        are tile-sorted (one device block and ONE sort launch for the whole chain), the relative poses of all 361 frames
+        are solved from the raw pose factors (get_relative_pose), and the descriptor tables are built from the store --
+        nothing of a scan's table is reused from a previous step.  -> [(live key, descriptor table)]"""
         from modest_amd.pre_compute_pp_score import relative_poses
-        sc.gen += 1
-        keys = [sc.slot_base + 16 * (sc.gen & 1) + j for j in range(len(sc.new_offs) - 1)]
-        old = [sc.slot_base + 16 * ((sc.gen + 1) & 1) + j for j in range(len(sc.new_offs) - 1)]
-        dev = torch.empty(sc.new_pinned.shape, dtype=torch.float32, device=self.dev)
-        dev.copy_(sc.new_pinned, non_blocking=True)
-        self.store.drop(old)
-        self.store.insert_block(keys, dev, sc.new_offs, sc.new_W, ctx=ctx)
-        rels = relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K)
-        hist_keys = list(sc.hist_keys)
-        for j, pos in enumerate(sc.new_pos):
-            hist_keys[pos] = (keys[j], hist_keys[pos][1])
-        return keys[-1], self.store.describe(keys[-1], rels[-1], [k for k, _ in hist_keys], [t for _, t in hist_keys],
-                                             rels[:-1])
+        keys_all, offs, Ws, base = [], [0], [], 0
+        dev = torch.empty((sum(int(sc.new_pinned.shape[0]) for sc in scs), 4), dtype=torch.float32, device=self.dev)
+        per = []
+        for sc in scs:
+            sc.gen += 1
+            keys = [sc.slot_base + 16 * (sc.gen & 1) + j for j in range(len(sc.new_offs) - 1)]
+            self.store.drop([sc.slot_base + 16 * ((sc.gen + 1) & 1) + j for j in range(len(sc.new_offs) - 1)])
+            n = int(sc.new_pinned.shape[0])
+            dev[base:base + n].copy_(sc.new_pinned, non_blocking=True)
+            keys_all += keys
+            offs += [base + int(o) for o in sc.new_offs[1:]]
+            Ws.append(sc.new_W)
+            base += n
+            per.append(keys)
+        self.store.insert_block(keys_all, dev, np.asarray(offs), np.concatenate(Ws), ctx=ctx)
+        out = []
+        for sc, keys in zip(scs, per):
+            rels = relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K)
+            hist_keys = list(sc.hist_keys)
+            for j, pos in enumerate(sc.new_pos):
+                hist_keys[pos] = (keys[j], hist_keys[pos][1])
+            out.append((keys[-1], self.store.describe(keys[-1], rels[-1], [k for k, _ in hist_keys],
+                                                      [t for _, t in hist_keys], rels[:-1])))
+        return out
 
     def pp_with_ingest(self, sc, ctx):
         with self.scan_locks[self.scans.index(sc)]:
-            key, desc = self._ingest(sc, ctx)
+            key, desc = self._ingest([sc], ctx)[0]
             return self.store.pp_score_batch([key], [desc], sc.T, ctx=ctx)[0]   # one scan: the library takes the single-scan chain
 
     def step(self, i, w, H=None, after=None):
@@ -316,11 +328,15 @@ class Runner:
                 with torch.cuda.stream(self.streams[w]):
                     idx = list(range(lo + w, hi, self.n_threads))
                     B, Hq = self.B, {}
+                    cuts = list(range(0, len(idx), B)) + [len(idx)]
+                    end_of = {}
+                    for c0, c1 in zip(cuts[:-1], cuts[1:]):
+                        for k in range(c0, c1):
+                            end_of[k] = c1
 
-                    def enqueue(k0):   # the PP stage of steps idx[k0 : k0 + B]: one chain of launches
-                        js = idx[k0:k0 + B]
-                        if js:
-                            Hq.update(zip(js, self.pp_many([self.scan_of(j) for j in js], w)))
+                    def enqueue(k0):   # the PP stage of the chain that starts at step idx[k0]: one chain of launches
+                        js = idx[k0:end_of[k0]]
+                        Hq.update(zip(js, self.pp_many([self.scan_of(j) for j in js], w)))
 
                     for k, i in enumerate(idx):
                         if self.a.mask_only:
@@ -328,7 +344,7 @@ class Runner:
                             continue
                         if i not in Hq:
                             enqueue(k)
-                        last = (k + 1) % B == 0 or k + 1 == len(idx)   # last step of its batch: the next batch goes out
+                        last = end_of[k] == k + 1   # last step of its chain: the next chain goes out under its label tail
                         hook = (lambda k1=k + 1: enqueue(k1)) if (self.prefetch and last and k + 1 < len(idx)) else None
                         self.step(i, w, H=Hq.pop(i), after=hook)
                     self.streams[w].synchronize()
