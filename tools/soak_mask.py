@@ -45,13 +45,19 @@ def work(args):
     st.insert_many(items)
     rels = np.stack(rels)
     c0 = None
+    desc = st.describe("live", sp.live_rel, [k for k, _ in hist], [t for _, t in hist], rels, False)
     for r in range(max(reps // 4, 1)):
-        _, c = st.pp_score("live", sp.live_rel, hist, rels, sp.world_from_ref, 5, return_counts=True)
-        c = c.cpu().numpy()
-        if c0 is None:
-            c0 = c
-        elif not np.array_equal(c, c0):
-            bad.append((pid, r, "pp", ["counts"], int((c != c0).sum())))
+        if r % 2 == 0:
+            _, c = st.pp_score("live", sp.live_rel, hist, rels, sp.world_from_ref, 5, return_counts=True)
+            cs = [c]
+        else:   # the chain of several scans per launch (modest_pp_score_frames_batch): three times the same scan
+            _, cs = st.pp_score_batch(["live"] * 3, [desc] * 3, 5, return_counts=True)
+        for c in cs:
+            c = c.cpu().numpy()
+            if c0 is None:
+                c0 = c
+            elif not np.array_equal(c, c0):
+                bad.append((pid, r, "pp", ["counts"], int((c != c0).sum())))
     for r in range(reps):
         for k, (raw, pp, rd, pd) in enumerate(scans):
             labels, rows, info = generate_mask_scan(raw, pp, calib, margs, random_state=np.random.RandomState(k), ptc_dev=rd,
