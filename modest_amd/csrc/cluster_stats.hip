@@ -8,6 +8,7 @@
 #include "common.h"
 #include "radix_select.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -210,6 +211,111 @@ __global__ __launch_bounds__(CSS_THREADS) void cs_stats(const float *__restrict_
     }
 }
 
+
+// The same statistics WITHOUT the grouping pass: workgroup c walks the scan's labels itself (30 k labels = 120 KB out of
+// the L2, coalesced), folds the plane distance of every member into its extremes and appends the member's PP key to LDS
+// (the order of the keys does not matter to an order statistic).  One launch instead of two; a cluster with more
+// than CS_LDS_KEYS members raises *overflow and the caller takes the grouped path.
+__global__ __launch_bounds__(CSS_THREADS) void cs_stats_direct(const float *__restrict__ pts, int stride,
+                                                              const float *__restrict__ pp,
+                                                              const int *__restrict__ labels, int nAll, PlaneP P,
+                                                              double *__restrict__ out, int *overflow) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wsum[CSS_THREADS / 64], sel[2];
+    __shared__ double rmin[CSS_THREADS / 64], rmax[CSS_THREADS / 64];
+    __shared__ unsigned keys[CS_LDS_KEYS];
+    __shared__ unsigned nKeys;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) nKeys = 0;
+    __syncthreads();
+    double mn = INFINITY, mx = -INFINITY;
+    for (int base = 0; base < nAll; base += CSS_THREADS) {
+        const int i = base + tid;
+        const bool mine = i < nAll && labels[i] == c;
+        const unsigned long long bal = __ballot(mine);
+        if (bal == 0ULL) continue;   // wave-uniform
+        unsigned pos = 0;
+        if (lane == 0) pos = atomicAdd(&nKeys, (unsigned)__popcll(bal));
+        pos = __builtin_amdgcn_readfirstlane(pos) + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
+        if (mine) {
+            if (pos < (unsigned)CS_LDS_KEYS) keys[pos] = cs_key(pp[i]);
+            const float *p = pts + (size_t)i * stride;
+            double dist = (double)p[0] * P.n0;
+            dist = fma((double)p[1], P.n1, dist);
+            dist = fma((double)p[2], P.n2, dist);
+            dist = (dist + P.d) / P.norm;
+            mn = fmin(mn, dist);
+            mx = fmax(mx, dist);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, o));
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) {
+        rmin[tid >> 6] = mn;
+        rmax[tid >> 6] = mx;
+    }
+    __syncthreads();
+    const int n = (int)nKeys;
+    if (n > CS_LDS_KEYS) {   // uniform
+        if (tid == 0) *reinterpret_cast<volatile int *>(overflow) = 1;   // pinned host word: a plain store, any writer writes 1
+        return;
+    }
+    double a = 0.0, b = 0.0, gamma = 0.0;
+    if (n > 0) {
+        const float qf = (float)P.q;
+        const float vi = (float)(n - 1) * qf;
+        const float fl = floorf(vi);
+        int prev = (int)fl, next = prev + 1;
+        if (vi >= (float)(n - 1)) prev = next = n - 1;
+        if (vi < 0.f) prev = next = 0;
+        next = min(next, n - 1);
+        gamma = (double)(vi - fl);
+        const auto key_at = [&](int i) { return keys[i]; };
+        const float af = cs_select_keys<CSS_THREADS>(key_at, n, (unsigned)prev, hist, wsum, sel);
+        a = (double)af;
+        b = a;
+        if (next != prev) {
+            const unsigned akey = cs_key(af);
+            if (tid == 0) {
+                sel[0] = 0;
+                sel[1] = 0xffffffffu;
+            }
+            __syncthreads();
+            unsigned cle = 0, mgt = 0xffffffffu;
+            for (int i = tid; i < n; i += CSS_THREADS) {
+                const unsigned k = keys[i];
+                cle += k <= akey ? 1u : 0u;
+                mgt = k > akey ? min(mgt, k) : mgt;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                cle += __shfl_xor(cle, o);
+                mgt = min(mgt, (unsigned)__shfl_xor((int)mgt, o));
+            }
+            if (lane == 0) {
+                atomicAdd(&sel[0], cle);
+                atomicMin(&sel[1], mgt);
+            }
+            __syncthreads();
+            b = sel[0] > (unsigned)next ? a : (double)cs_unkey(sel[1]);
+        }
+    }
+    if (tid == 0) {
+        out[6 * c + 0] = (double)n;
+        double mn_ = rmin[0], mx_ = rmax[0];
+        for (int q = 1; q < CSS_THREADS / 64; ++q) {
+            mn_ = fmin(mn_, rmin[q]);
+            mx_ = fmax(mx_, rmax[q]);
+        }
+        out[6 * c + 1] = mn_;
+        out[6 * c + 2] = mx_;
+        out[6 * c + 3] = a;
+        out[6 * c + 4] = b;
+        out[6 * c + 5] = gamma;
+    }
+}
+
 }  // namespace
 
 extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
@@ -226,7 +332,7 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
     const size_t b_mem = arena_sz((size_t)n * 4), b_out = arena_sz((size_t)n_clusters * 48);
     int rc = modest_ctx_reserve(ctx, b_cnt + b_start + b_mem + b_out);
     if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, (size_t)n_clusters * 48);
+    rc = modest_ctx_reserve_pinned(ctx, (size_t)n_clusters * 48 + 64);
     if (rc) return rc;
     unsigned *cnt = reinterpret_cast<unsigned *>(ctx->scratch);
     unsigned *fill = cnt + n_clusters;
@@ -240,6 +346,21 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
     P.d = plane4[3];
     P.norm = sqrt((plane4[0] * plane4[0] + plane4[1] * plane4[1]) + plane4[2] * plane4[2]);
     P.q = quantile;
+    // the usual case in one launch: every cluster's workgroup finds its members itself; the overflow word sits behind
+    // the results in pinned memory
+    int *h_over = reinterpret_cast<int *>(ctx->pinned + (size_t)n_clusters * 48);
+    if (!getenv("MODEST_CS_GROUPED")) {
+        *h_over = 0;
+        cs_stats_direct<<<n_clusters, CSS_THREADS, 0, stream>>>(pts, stride, pp, labels, n, P,
+                                                                reinterpret_cast<double *>(ctx->pinned), h_over);
+        MODEST_HIP_CHECK(hipGetLastError());
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        if (*h_over == 0) {
+            const double *hd = reinterpret_cast<const double *>(ctx->pinned);
+            for (size_t i = 0; i < (size_t)n_clusters * 6; ++i) out_host[i] = hd[i];
+            return MODEST_OK;
+        }
+    }
     if (n_clusters <= CS_GROUP_MAXC) {
         cs_group<<<1, 1024, 0, stream>>>(labels, n, n_clusters, start, members);
     } else {
