@@ -224,22 +224,41 @@ __global__ __launch_bounds__(CSS_THREADS) void cs_stats_direct(const float *__re
     __shared__ unsigned wsum[CSS_THREADS / 64], sel[2];
     __shared__ double rmin[CSS_THREADS / 64], rmax[CSS_THREADS / 64];
     __shared__ unsigned keys[CS_LDS_KEYS];
+    __shared__ int midx[CS_LDS_KEYS];
     __shared__ unsigned nKeys;
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) nKeys = 0;
     __syncthreads();
     double mn = INFINITY, mx = -INFINITY;
-    for (int base = 0; base < nAll; base += CSS_THREADS) {
-        const int i = base + tid;
-        const bool mine = i < nAll && labels[i] == c;
-        const unsigned long long bal = __ballot(mine);
-        if (bal == 0ULL) continue;   // wave-uniform
-        unsigned pos = 0;
-        if (lane == 0) pos = atomicAdd(&nKeys, (unsigned)__popcll(bal));
-        pos = __builtin_amdgcn_readfirstlane(pos) + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
-        if (mine) {
-            if (pos < (unsigned)CS_LDS_KEYS) keys[pos] = cs_key(pp[i]);
-            const float *p = pts + (size_t)i * stride;
+    // 1. the members' point numbers, compacted into LDS: eight labels per thread and round, loaded before they are
+    //    looked at (one load latency per round), one LDS atomic per wavefront and label slot
+    for (int base = 0; base < nAll; base += 8 * CSS_THREADS) {
+        int l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * CSS_THREADS + tid;
+            l[u] = i < nAll ? labels[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool mine = l[u] == c;
+            const unsigned long long bal = __ballot(mine);
+            if (bal == 0ULL) continue;   // wave-uniform
+            unsigned pos = 0;
+            if (lane == 0) pos = atomicAdd(&nKeys, (unsigned)__popcll(bal));
+            pos = __builtin_amdgcn_readfirstlane(pos) + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
+            if (mine && pos < (unsigned)CS_LDS_KEYS) midx[pos] = base + u * CSS_THREADS + tid;
+        }
+    }
+    __syncthreads();
+    // 2. keys and plane distances of the members, all lanes busy
+    {
+        const int nm = min((int)nKeys, CS_LDS_KEYS);
+        for (int i = tid; i < nm; i += CSS_THREADS) {
+            const int m = midx[i];
+            keys[i] = cs_key(pp[m]);
+            const float *p = pts + (size_t)m * stride;
+            // ptc @ plane[:3] + plane[3] then / norm: the float64 rounding of numpy's product
             double dist = (double)p[0] * P.n0;
             dist = fma((double)p[1], P.n1, dist);
             dist = fma((double)p[2], P.n2, dist);
