@@ -786,6 +786,12 @@ int modest_pp3_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_frame 
         const char *nw_env = getenv("MODEST_PP_NWG");
         if (nw_env && atoi(nw_env) > 0 && atoi(nw_env) <= V3_MAXWG) nwg3 = atoi(nw_env);
     }
+    if (!getenv("MODEST_PP_NWG") && !getenv("MODEST_PP_CHAIN_FULL")) {
+        // the chain's streaming launches keep the footprint of a single scan's (2 workgroups per CU in total, dealt over
+        // the scans): other processes' kernels find wave slots while a chain runs; alone on the GPU it costs nothing
+        nwg3 = (nwg3 / n_scans) & ~1;
+        if (nwg3 < 32) nwg3 = 32;
+    }
     const char *sr_env = getenv("MODEST_PP_SLICE");
     unsigned sliceCap = sr_env ? (unsigned)atoi(sr_env) : V3_SLICE_MAX;
     sliceCap = sliceCap < 256u ? 256u : (sliceCap > V3_SLICE_MAX ? V3_SLICE_MAX : sliceCap);
