@@ -6,8 +6,9 @@ Writes gpurun_out/pp_traffic.json (copied to profiles/rNN_pp_traffic.json, which
 import json
 import os
 
-M, N_WG, N_LIST = 10_800_000, 512, 7168
+M, N_LIST = 10_800_000, 7168
 B = int(os.environ.get("PP_BATCH", "4"))
+N_WG = max(32, (512 // B) & ~1)   # streaming workgroups per scan of a chain on a 256-CU context (pp_count.hip)
 d = {k: v for k, v in json.load(open("gpurun_out/pp_pmc.json")).items() if k.startswith("ppb_")}
 per_scan = {k: 1.0 / B for k in d}      # launches per scan
 fetch = sum(v.get("FETCH_SIZE", 0.0) * 1024 * per_scan[k] for k, v in d.items())
@@ -26,7 +27,7 @@ out = {
         "factor": f_fac,
         "note": "MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read on gfx950 -> doubled",
     },
-    "write_calibration": {"kernel": "ppb_stream<false> writes a 512 x 7168 x 4 B count matrix per scan", "factor": w_fac},
+    "write_calibration": {"kernel": "ppb_stream<false> writes a %d x 7168 x 4 B count matrix per scan" % N_WG, "factor": w_fac},
     "hbm_bytes_per_scan": fetch * f_fac + write * w_fac,
     "algorithmic_bytes_per_scan": 12.0 * M + 16.0 * 30_000,
     "per_kernel_bytes": {k: {"fetch": v.get("FETCH_SIZE", 0.0) * 1024 * f_fac * per_scan[k],
