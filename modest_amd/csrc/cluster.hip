@@ -272,63 +272,33 @@ __device__ __forceinline__ Rows rows_of(const float4 &q, const CGrid *g, const u
 // keys find it (instead of eight over the float64 bit pattern; the distances are recomputed in
 // every pass), and the exact float64 value is then taken from the candidates that share the key
 // -- one more pass when the key is unique, a min/count loop over the ties otherwise.
-constexpr int KTH_CAP = 384;   // in-radius candidates of a query kept in LDS between the passes (per wavefront)
 __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restrict__ sorted, int n,
                                                            const CGrid *g,
                                                            const unsigned *__restrict__ start, int k,
                                                            double r2, double *__restrict__ kthS) {
     __shared__ unsigned hist_all[WPB][256];
-    __shared__ unsigned ckey_all[WPB][KTH_CAP];
-    __shared__ unsigned cidx_all[WPB][KTH_CAP];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= n) return;   // whole wave exits together
-    unsigned *hist = hist_all[w], *ckey = ckey_all[w], *cidx = cidx_all[w];
+    unsigned *hist = hist_all[w];
     const float4 q = sorted[s];
     const Rows R = rows_of(q, g, start);
     unsigned prefix = 0, mask = 0, cntF = 0;
     int kk = k - 1;
     bool enough = true;
-    // The first pass walks the three cell rows, computes the distances and keeps the in-radius candidates (float32 key
-    // + point number) in LDS; the later passes and the exact float64 step read that list.  A query with more than
-    // KTH_CAP candidates inside the radius (`cached` false, wave-uniform) recomputes the distances in every pass.
-    unsigned nc = 0;
-    bool cached = true;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int b = lane; b < 256; b += 64) hist[b] = 0;
         __builtin_amdgcn_wave_barrier();
-        if (shift == 24 || !cached) {
-#pragma unroll
-            for (int r = 0; r < R.n; ++r)
-                for (unsigned jb = R.s[r]; jb < R.e[r]; jb += 64) {   // wave-uniform trip count
-                    const unsigned j = jb + lane;
-                    bool in = false;
-                    unsigned key = 0;
-                    if (j < R.e[r] && (int)j != s) {
-                        const double d2 = dist2(q, sorted[j]);
-                        if (d2 <= r2) {
-                            in = true;
-                            key = __float_as_uint((float)d2);
-                            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-                        }
-                    }
-                    if (shift == 24) {
-                        const unsigned long long bal = __ballot(in);
-                        const unsigned pos = nc + __popcll(bal & ((1ULL << lane) - 1ULL));
-                        if (in && pos < (unsigned)KTH_CAP) {
-                            ckey[pos] = key;
-                            cidx[pos] = j;
-                        }
-                        nc += __popcll(bal);
-                    }
+    #pragma unroll
+    for (int r = 0; r < R.n; ++r)
+            for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
+                if ((int)j == s) continue;
+                const double d2 = dist2(q, sorted[j]);
+                if (d2 <= r2) {
+                    const unsigned key = __float_as_uint((float)d2);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
                 }
-            if (shift == 24) cached = nc <= (unsigned)KTH_CAP;
-        } else {
-            for (unsigned e = lane; e < nc; e += 64) {
-                const unsigned key = ckey[e];
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
             }
-        }
         __builtin_amdgcn_wave_barrier();
         // lane l owns bins 4l..4l+3
         const unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2],
@@ -373,39 +343,13 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
         __builtin_amdgcn_wave_barrier();
     }
     double result = D_INF;
-    if (enough && cached) {
-        // kk = rank (0-based) among the cntF in-radius candidates whose float32 key is `prefix`: their exact float64
-        // distances, recomputed from the cached point numbers
+    if (enough) {
+        // kk = rank (0-based) among the cntF in-radius candidates whose float32 key is `prefix`
         double lo = -1.0;
         for (;;) {
             double m = D_INF;
-            for (unsigned e = lane; e < nc; e += 64)
-                if (ckey[e] == prefix) {
-                    const double d2 = dist2(q, sorted[cidx[e]]);
-                    if (d2 > lo) m = fmin(m, d2);
-                }
-            for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));
-            if (cntF == 1) {
-                result = m;
-                break;
-            }
-            unsigned c = 0;
-            for (unsigned e = lane; e < nc; e += 64)
-                if (ckey[e] == prefix && dist2(q, sorted[cidx[e]]) == m) ++c;
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            if (kk < (int)c || c == 0) {
-                result = m;
-                break;
-            }
-            kk -= (int)c;
-            lo = m;
-        }
-    } else if (enough) {
-        double lo = -1.0;
-        for (;;) {
-            double m = D_INF;
-#pragma unroll
-            for (int r = 0; r < R.n; ++r)
+        #pragma unroll
+    for (int r = 0; r < R.n; ++r)
                 for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
                     if ((int)j == s) continue;
                     const double d2 = dist2(q, sorted[j]);
@@ -417,8 +361,8 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
                 break;
             }
             unsigned c = 0;
-#pragma unroll
-            for (int r = 0; r < R.n; ++r)
+        #pragma unroll
+    for (int r = 0; r < R.n; ++r)
                 for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64)
                     if ((int)j != s && dist2(q, sorted[j]) == m) ++c;
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
