@@ -368,6 +368,27 @@ int modest_mask_stage(modest_ctx *ctx, const float *pts_dev, int n, int stride, 
                       double *plane1_out, double *plane2_out, int64_t *labels_out, int32_t *info_out,
                       void *stream);
 
+/* The same stage for a CHAIN of scans (the reference's scan loop, generate_mask.py:52, has no dependency between
+ * iterations): the ground fits stay per scan, from the mask kernel on the scans advance together -- one launch per
+ * kernel of the mask / graph / DBSCAN block and of the cluster statistics for the whole chain (the scan is a second
+ * grid dimension), three round trips per chain instead of three per scan.  Every scan works in its OWN context
+ * (scratch, pinned words, persistent counters); arguments per scan as in modest_mask_stage.  Results are those of
+ * separate calls, bit for bit; configurations the chain does not cover (k-NN graphs without a radius,
+ * 3d_l2_distance) and chains of one scan take the separate calls.  Blocking.                                    */
+typedef struct modest_mask_stage_scan {
+    modest_ctx *ctx;
+    const float *pts_dev;
+    int32_t n, stride;
+    const float *pp_dev;
+    uint32_t *mt_key624;
+    int32_t *mt_pos;
+    double *plane1_out, *plane2_out;
+    int64_t *labels_out;
+    int32_t *info_out;
+} modest_mask_stage_scan;
+int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int n_scans, const modest_mask_params *params,
+                            void *stream);
+
 /* ---- a14 filter_labels / is_valid_cluster statistics ------------------
  * (utils/clustering_utils.py:94-135).  For each label c in [0, n_clusters):
  * out[c*6 + {0: member count, 1: min, 2: max signed distance to `plane`

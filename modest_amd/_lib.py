@@ -59,6 +59,7 @@ SIGNATURES = {
     "modest_mask_stage": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "modest_mask_cluster": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_double, VP, VP, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, VP, VP, VP, VP]),
+    "modest_mask_stage_batch": (C.c_int, [VP, C.c_int, VP, VP]),
     "modest_cluster_stats": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, C.c_double, VP, VP]),
     "modest_boxes_pp_stats": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, VP, VP]),
     "modest_fit_boxes_closeness": (C.c_int, [VP, VP, VP, C.c_int, VP, C.c_int, C.c_double, VP, VP, VP]),

@@ -112,11 +112,9 @@ __global__ void cg_count(const float *__restrict__ xyz, int n, const CGrid *g, u
 // stay zero between calls) and clears the four flag words of the call.
 constexpr int SCAN_IPT = 8;
 template <bool CELLS>
-__global__ __launch_bounds__(1024) void scan_u32(const unsigned *in, unsigned *__restrict__ out, int n,
-                                                 unsigned *__restrict__ total_copy = nullptr,
-                                                 const int *__restrict__ flag_src = nullptr,
-                                                 unsigned *__restrict__ cursor = nullptr,
-                                                 unsigned *clear_in = nullptr, unsigned *flags = nullptr) {
+__device__ __forceinline__ void scan_u32_body(const unsigned *in, unsigned *__restrict__ out, int n,
+                                              unsigned *__restrict__ total_copy, const int *__restrict__ flag_src,
+                                              unsigned *__restrict__ cursor, unsigned *clear_in, unsigned *flags) {
     __shared__ unsigned tile[16][64 * (SCAN_IPT + 1)];
     __shared__ unsigned wtot[2][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -189,15 +187,20 @@ __global__ __launch_bounds__(1024) void scan_u32(const unsigned *in, unsigned *_
         }
     }
 }
+template <bool CELLS>
+__global__ __launch_bounds__(1024) void scan_u32(const unsigned *in, unsigned *__restrict__ out, int n,
+                                                 unsigned *__restrict__ total_copy = nullptr,
+                                                 const int *__restrict__ flag_src = nullptr,
+                                                 unsigned *__restrict__ cursor = nullptr,
+                                                 unsigned *clear_in = nullptr, unsigned *flags = nullptr) {
+    scan_u32_body<CELLS>(in, out, n, total_copy, flag_src, cursor, clear_in, flags);
+}
 
 // idx == NULL: pp (and intensity) are per input point.  idx != NULL (fused mask call): the input
 // points are the kept rows of a scan, idx their row numbers; pp is the scan's array and the
 // intensity is column 3 of the scan rows (`rows`, `stride` floats apart).
-__global__ void cg_scatter(const float *__restrict__ xyz, const float *__restrict__ pp, int n,
-                           const CGrid *g, unsigned *cursor, float4 *__restrict__ sorted, int *__restrict__ sidx,
-                           const int *__restrict__ idx, const float *__restrict__ inten_src,
-                           const float *__restrict__ rows, int stride, float *__restrict__ sortedI) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cg_scatter_body(const float *__restrict__ xyz, const float *__restrict__ pp, int n, const CGrid *g, unsigned *cursor, float4 *__restrict__ sorted, int *__restrict__ sidx, const int *__restrict__ idx, const float *__restrict__ inten_src, const float *__restrict__ rows, int stride, float *__restrict__ sortedI, const unsigned bx, const unsigned gx) {
+    const int i = bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     const int cell = cg_coord(y, g->oy, g->inv_c) * CG + cg_coord(x, g->ox, g->inv_c);
@@ -207,14 +210,13 @@ __global__ void cg_scatter(const float *__restrict__ xyz, const float *__restric
     sidx[slot] = i;
     if (sortedI) sortedI[slot] = rows ? rows[(size_t)src * stride + 3] : inten_src[src];
 }
+__global__  void cg_scatter(const float *__restrict__ xyz, const float *__restrict__ pp, int n, const CGrid *g, unsigned *cursor, float4 *__restrict__ sorted, int *__restrict__ sidx, const int *__restrict__ idx, const float *__restrict__ inten_src, const float *__restrict__ rows, int stride, float *__restrict__ sortedI) {
+    cg_scatter_body(xyz, pp, n, g, cursor, sorted, sidx, idx, inten_src, rows, stride, sortedI, blockIdx.x, gridDim.x);
+}
 
 // Fused first kernel of modest_mask_cluster: above_plane + range mask of every scan row, ordered
 // compaction of the kept rows, their cell counts in the fixed grid G, labels = -1 everywhere.
-__global__ __launch_bounds__(1024) void mask_count_kernel(const float *__restrict__ pts, int n, int stride, MaskParams P,
-                                                          CGrid G, CGrid *__restrict__ g, unsigned *cnt,
-                                                          int *__restrict__ labels, float *__restrict__ kept,
-                                                          int *__restrict__ kept_idx, unsigned long long *state,
-                                                          int *n_kept) {
+__device__ __forceinline__ void mask_count_kernel_body(const float *__restrict__ pts, int n, int stride, MaskParams P, CGrid G, CGrid *__restrict__ g, unsigned *cnt, int *__restrict__ labels, float *__restrict__ kept, int *__restrict__ kept_idx, unsigned long long *state, int *n_kept, const unsigned bx, const unsigned gx) {
     const unsigned blk = compact_ticket(state);
     const long long i = (long long)blk * 1024 + threadIdx.x;
     if (blk == 0 && threadIdx.x == 0) *g = G;
@@ -229,13 +231,16 @@ __global__ __launch_bounds__(1024) void mask_count_kernel(const float *__restric
         labels[i] = -1;
         if (keep) atomicAdd(&cnt[cg_coord(y, G.oy, G.inv_c) * CG + cg_coord(x, G.ox, G.inv_c)], 1u);
     }
-    const unsigned long long dst = compact_offset(keep, blk, gridDim.x, state, n_kept);
+    const unsigned long long dst = compact_offset(keep, blk, gx, state, n_kept);
     if (keep) {
         kept[3 * dst + 0] = x;
         kept[3 * dst + 1] = y;
         kept[3 * dst + 2] = z;
         kept_idx[dst] = (int)i;
     }
+}
+__global__ __launch_bounds__(1024) void mask_count_kernel(const float *__restrict__ pts, int n, int stride, MaskParams P, CGrid G, CGrid *__restrict__ g, unsigned *cnt, int *__restrict__ labels, float *__restrict__ kept, int *__restrict__ kept_idx, unsigned long long *state, int *n_kept) {
+    mask_count_kernel_body(pts, n, stride, P, G, g, cnt, labels, kept, kept_idx, state, n_kept, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ double dist2(const float4 &a, const float4 &b) {
@@ -272,13 +277,10 @@ __device__ __forceinline__ Rows rows_of(const float4 &q, const CGrid *g, const u
 // keys find it (instead of eight over the float64 bit pattern; the distances are recomputed in
 // every pass), and the exact float64 value is then taken from the candidates that share the key
 // -- one more pass when the key is unique, a min/count loop over the ties otherwise.
-__global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restrict__ sorted, int n,
-                                                           const CGrid *g,
-                                                           const unsigned *__restrict__ start, int k,
-                                                           double r2, double *__restrict__ kthS) {
+__device__ __forceinline__ void knn_kth_kernel_body(const float4 *__restrict__ sorted, int n, const CGrid *g, const unsigned *__restrict__ start, int k, double r2, double *__restrict__ kthS, const unsigned bx, const unsigned gx) {
     __shared__ unsigned hist_all[WPB][256];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * WPB + w;
+    const int s = bx * WPB + w;
     if (s >= n) return;   // whole wave exits together
     unsigned *hist = hist_all[w];
     const float4 q = sorted[s];
@@ -375,6 +377,9 @@ __global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restr
         }
     }
     if (lane == 0) kthS[s] = result;
+}
+__global__ __launch_bounds__(64 * WPB) void knn_kth_kernel(const float4 *__restrict__ sorted, int n, const CGrid *g, const unsigned *__restrict__ start, int k, double r2, double *__restrict__ kthS) {
+    knn_kth_kernel_body(sorted, n, g, start, k, r2, kthS, blockIdx.x, gridDim.x);
 }
 
 // Graph / weight variants of precompute_affinity_matrix (utils/clustering_utils.py:16-56):
@@ -579,16 +584,15 @@ constexpr int AG = 16;    // lanes that share one adjacency row in the passes be
 // edge (parent or root of the neighbour) instead of three (core flag, point number, parent).
 constexpr int UF_NONE = 0x7fffffff;
 template <bool ORIG>
-__global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__restrict__ sorted, int n,
-                                                              const CGrid *g,
-                                                              const unsigned *__restrict__ start,
-                                                              const double *__restrict__ kthS, EdgeP ep, int min_samples,
-                                                              unsigned char *__restrict__ coreS,
-                                                              int *__restrict__ deg, int *__restrict__ adj,
-                                                              int *overflow, const int *__restrict__ sidx,
-                                                              int *__restrict__ parent) {
+__device__ __forceinline__ void degree_adj_kernel_body(const float4 *__restrict__ sorted, int n, const CGrid *g,
+                                                       const unsigned *__restrict__ start,
+                                                       const double *__restrict__ kthS, const EdgeP &ep, int min_samples,
+                                                       unsigned char *__restrict__ coreS, int *__restrict__ deg,
+                                                       int *__restrict__ adj, int *overflow,
+                                                       const int *__restrict__ sidx, int *__restrict__ parent,
+                                                       const unsigned bx) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * WPB + w;
+    const int s = bx * WPB + w;
     if (s >= n) return;
     if (!ORIG && lane == 0) parent[sidx[s]] = sidx[s];   // uf_init, one launch less (sidx is a permutation)
     const float4 q = sorted[s];
@@ -611,6 +615,17 @@ __global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__re
         if (ORIG) parent[sidx[s]] = ((int)total + 1 >= min_samples) ? sidx[s] : UF_NONE;
         if (total > (unsigned)ADJ) atomicOr(overflow, 1);
     }
+}
+template <bool ORIG>
+__global__ __launch_bounds__(64 * WPB) void degree_adj_kernel(const float4 *__restrict__ sorted, int n,
+                                                              const CGrid *g,
+                                                              const unsigned *__restrict__ start,
+                                                              const double *__restrict__ kthS, EdgeP ep, int min_samples,
+                                                              unsigned char *__restrict__ coreS,
+                                                              int *__restrict__ deg, int *__restrict__ adj,
+                                                              int *overflow, const int *__restrict__ sidx,
+                                                              int *__restrict__ parent) {
+    degree_adj_kernel_body<ORIG>(sorted, n, g, start, kthS, ep, min_samples, coreS, deg, adj, overflow, sidx, parent, blockIdx.x);
 }
 
 // one round of min-root hooking: the root of every core point is hung under the smallest root
@@ -692,9 +707,8 @@ __global__ void label_adj_kernel(int n, int stride, const unsigned char *__restr
 }
 
 // ---- the same passes over rows of original point numbers (degree_adj_kernel<true>) ----------
-__global__ void hook_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
-                                 const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void hook_orig_kernel_body(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg, const int *__restrict__ adj, const int *__restrict__ sidx, int *parent, const unsigned bx, const unsigned gx) {
+    const int t = bx * blockDim.x + threadIdx.x;
     const int s = t / AG, sub = t % AG;
     const bool on = s < n && coreS[s];
     int rme = 0, m = UF_NONE;
@@ -708,9 +722,12 @@ __global__ void hook_orig_kernel(int n, const unsigned char *__restrict__ coreS,
     for (int o = AG / 2; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
     if (on && sub == 0 && m < rme) atomicMin(parent + rme, m);
 }
+__global__  void hook_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg, const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
+    hook_orig_kernel_body(n, coreS, deg, adj, sidx, parent, blockIdx.x, gridDim.x);
+}
 
-__global__ void flatten_orig_kernel(int *parent, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void flatten_orig_kernel_body(int *parent, int n, const unsigned bx, const unsigned gx) {
+    const int i = bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int r = uf_load(parent, i);
     if (r == UF_NONE) return;
@@ -721,10 +738,12 @@ __global__ void flatten_orig_kernel(int *parent, int n) {
     }
     __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__global__  void flatten_orig_kernel(int *parent, int n) {
+    flatten_orig_kernel_body(parent, n, blockIdx.x, gridDim.x);
+}
 
-__global__ void union_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
-                                  const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void union_orig_kernel_body(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg, const int *__restrict__ adj, const int *__restrict__ sidx, int *parent, const unsigned bx, const unsigned gx) {
+    const int t = bx * blockDim.x + threadIdx.x;
     const int s = t / AG, sub = t % AG;
     if (s >= n || !coreS[s]) return;
     const int me = sidx[s];
@@ -738,22 +757,24 @@ __global__ void union_orig_kernel(int n, const unsigned char *__restrict__ coreS
         if (uf_load(parent, me) != po) uf_unite(parent, me, other);
     }
 }
+__global__  void union_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg, const int *__restrict__ adj, const int *__restrict__ sidx, int *parent) {
+    union_orig_kernel_body(n, coreS, deg, adj, sidx, parent, blockIdx.x, gridDim.x);
+}
 
-__global__ void compress_orig_kernel(int *parent, const unsigned char *__restrict__ coreS, const int *__restrict__ sidx,
-                                     int n, int *__restrict__ root, unsigned *__restrict__ isroot) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void compress_orig_kernel_body(int *parent, const unsigned char *__restrict__ coreS, const int *__restrict__ sidx, int n, int *__restrict__ root, unsigned *__restrict__ isroot, const unsigned bx, const unsigned gx) {
+    const int s = bx * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const int i = sidx[s];
     const int r = coreS[s] ? uf_find(parent, i) : UF_NONE;
     root[i] = r;
     isroot[i] = r == i ? 1u : 0u;
 }
+__global__  void compress_orig_kernel(int *parent, const unsigned char *__restrict__ coreS, const int *__restrict__ sidx, int n, int *__restrict__ root, unsigned *__restrict__ isroot) {
+    compress_orig_kernel_body(parent, coreS, sidx, n, root, isroot, blockIdx.x, gridDim.x);
+}
 
-__global__ void label_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg,
-                                  const int *__restrict__ adj, const int *__restrict__ sidx, const int *__restrict__ root,
-                                  const unsigned *__restrict__ rank, int *__restrict__ labels,
-                                  const int *__restrict__ oidx) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void label_orig_kernel_body(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg, const int *__restrict__ adj, const int *__restrict__ sidx, const int *__restrict__ root, const unsigned *__restrict__ rank, int *__restrict__ labels, const int *__restrict__ oidx, const unsigned bx, const unsigned gx) {
+    const int t = bx * blockDim.x + threadIdx.x;
     const int s = t / AG, sub = t % AG;
     const bool on = s < n;
     const bool core = on && coreS[s];
@@ -767,6 +788,9 @@ __global__ void label_orig_kernel(int n, const unsigned char *__restrict__ coreS
     if (!on || sub) return;
     const int me = sidx[s];
     labels[oidx ? oidx[me] : me] = core ? (int)rank[root[me]] : (best == UF_NONE) ? -1 : (int)rank[best];
+}
+__global__  void label_orig_kernel(int n, const unsigned char *__restrict__ coreS, const int *__restrict__ deg, const int *__restrict__ adj, const int *__restrict__ sidx, const int *__restrict__ root, const unsigned *__restrict__ rank, int *__restrict__ labels, const int *__restrict__ oidx) {
+    label_orig_kernel_body(n, coreS, deg, adj, sidx, root, rank, labels, oidx, blockIdx.x, gridDim.x);
 }
 
 // ---- k-NN graphs without a radius bound (neighbor_type knn / sym_knn / mutual_knn) ------------
@@ -983,6 +1007,22 @@ struct PreGrid {
     unsigned *cnt;       // [dev] persistent per-cell counters, left zeroed by the cell scan
 };
 
+// more than ADJ edges at some point (dozens of exactly tied k-th distances): the passes that re-walk the
+// cell rows instead of reading adjacency rows
+void cluster_overflow_path(const float4 *sorted, int n, const CGrid *g, const unsigned *start, const double *kthS,
+                           const EdgeP &ep, int min_samples, unsigned char *coreS, int *parent, const int *sidx, int *root,
+                           unsigned *isroot, unsigned *rank, unsigned *h_res, int *overflow, int32_t *labels,
+                           const int *oidx, hipStream_t stream) {
+    const int nb = (n + 255) / 256, nw = (n + WPB - 1) / WPB;
+    degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS);
+    uf_init<<<nb, 256, 0, stream>>>(parent, n);
+    hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
+    union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
+    compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
+    scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
+    label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, ep, labels, oidx);
+}
+
 size_t cluster_arena_bytes(int n, int neighbor_type, int k_neighbors) {
     const bool unbounded = neighbor_type >= MODEST_GRAPH_KNN;
     const int ustride = k_neighbors + (neighbor_type == MODEST_GRAPH_SYM_KNN ? 3 * k_neighbors : 0) + 8;
@@ -1109,14 +1149,8 @@ int cluster_impl(modest_ctx *ctx, size_t arena_off, const float *xyz, const floa
     {   // more than ADJ edges at some point (dozens of exactly tied k-th distances): recompute path
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         if (h_res[0]) {
-            degree_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, ep, min_samples, coreS);
-            uf_init<<<nb, 256, 0, stream>>>(parent, n);
-            hook_min_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
-            union_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, ep, parent);
-            compress_kernel<<<nb, 256, 0, stream>>>(parent, coreS, sidx, n, root, isroot);
-            scan_u32<false><<<1, 1024, 0, stream>>>(isroot, rank, n, h_res, overflow);
-            label_kernel<<<nw, 64 * WPB, 0, stream>>>(sorted, n, g, start, kthS, coreS, sidx, root, rank, ep,
-                                                     labels, oidx);
+            cluster_overflow_path(sorted, n, g, start, kthS, ep, min_samples, coreS, parent, sidx, root, isroot, rank, h_res,
+                                  overflow, labels, oidx, stream);
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         }
         if (n_clusters) *n_clusters = (int32_t)h_res[1];
@@ -1263,4 +1297,287 @@ extern "C" int modest_cluster_dbscan(modest_ctx *ctx, const float *xyz, const fl
                                      void *stream_) {
     return modest_cluster_dbscan_ex(ctx, xyz, pp, nullptr, n, MODEST_GRAPH_RADIUS_MUTUAL_KNN, MODEST_AFFINITY_L1,
                                     k_neighbors, radius, eps, min_samples, labels, kth_d2, n_clusters, stream_);
+}
+
+// ---- the mask / graph / DBSCAN block for a CHAIN of scans ---------------------------------------------
+// What modest_mask_cluster_phase does for one scan, done once for several: every kernel takes the scan as blockIdx.y
+// and reads that scan's pointers from a device table (MCB); the bodies are the functions the single-scan kernels call,
+// the arenas are carved exactly as the single-scan call carves them (each scan in its OWN context: scratch, pinned
+// words and persistent cell counters are per scan).  15 launches and 2 round trips per chain instead of per scan.
+// Radius graphs only (the default and `radius`); other configurations take the single-scan calls.
+#include "mask_chain.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+struct MCB {
+    const float *pts, *pp;
+    MaskParams P;
+    CGrid G;
+    CGrid *g;
+    unsigned *cnt;
+    int *labels;
+    float *kept;
+    int *kept_idx;
+    unsigned long long *state;
+    int *h_kept;
+    unsigned *start, *cursor, *flags;
+    float4 *sorted;
+    int *sidx;
+    double *kthS;
+    unsigned char *coreS;
+    int *parent, *root;
+    unsigned *isroot, *rank;
+    int *deg, *adj;
+    unsigned *h_res;
+    int n, stride, nblk, m, nb, nw, nbA, pad;
+};
+
+__global__ __launch_bounds__(1024) void mcb_mask_count(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nblk) return;
+    mask_count_kernel_body(S.pts, S.n, S.stride, S.P, S.G, S.g, S.cnt, S.labels, S.kept, S.kept_idx, S.state, S.h_kept,
+                           blockIdx.x, (unsigned)S.nblk);
+}
+template <bool CELLS>
+__global__ __launch_bounds__(1024) void mcb_scan(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if (S.m <= 0) return;
+    if (CELLS)
+        scan_u32_body<true>(S.cnt, S.start, CG_CELLS, nullptr, nullptr, S.cursor, S.cnt, S.flags);
+    else
+        scan_u32_body<false>(S.isroot, S.rank, S.m, S.h_res, reinterpret_cast<const int *>(S.flags), nullptr, nullptr, nullptr);
+}
+__global__ void mcb_cg_scatter(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nb) return;
+    cg_scatter_body(S.kept, S.pp, S.m, S.g, S.cursor, S.sorted, S.sidx, S.kept_idx, nullptr, S.pts, S.stride, nullptr,
+                    blockIdx.x, (unsigned)S.nb);
+}
+__global__ __launch_bounds__(64 * WPB) void mcb_knn_kth(const MCB *__restrict__ tab, int k, double r2) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nw) return;
+    knn_kth_kernel_body(S.sorted, S.m, S.g, S.start, k, r2, S.kthS, blockIdx.x, (unsigned)S.nw);
+}
+__global__ __launch_bounds__(64 * WPB) void mcb_degree_adj(const MCB *__restrict__ tab, EdgeP ep, int min_samples) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nw) return;
+    degree_adj_kernel_body<true>(S.sorted, S.m, S.g, S.start, S.kthS, ep, min_samples, S.coreS, S.deg, S.adj,
+                                 reinterpret_cast<int *>(S.flags), S.sidx, S.parent, blockIdx.x);
+}
+__global__ void mcb_hook(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nbA) return;
+    hook_orig_kernel_body(S.m, S.coreS, S.deg, S.adj, S.sidx, S.parent, blockIdx.x, (unsigned)S.nbA);
+}
+__global__ void mcb_flatten(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nb) return;
+    flatten_orig_kernel_body(S.parent, S.m, blockIdx.x, (unsigned)S.nb);
+}
+__global__ void mcb_union(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nbA) return;
+    union_orig_kernel_body(S.m, S.coreS, S.deg, S.adj, S.sidx, S.parent, blockIdx.x, (unsigned)S.nbA);
+}
+__global__ void mcb_compress(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nb) return;
+    compress_orig_kernel_body(S.parent, S.coreS, S.sidx, S.m, S.root, S.isroot, blockIdx.x, (unsigned)S.nb);
+}
+__global__ void mcb_label(const MCB *__restrict__ tab) {
+    const MCB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nbA) return;
+    label_orig_kernel_body(S.m, S.coreS, S.deg, S.adj, S.sidx, S.root, S.rank, S.labels, S.kept_idx, blockIdx.x,
+                           (unsigned)S.nbA);
+}
+
+// the table travels through a staging slot of the first scan's context into that context's chain table
+int mcb_upload(modest_ctx *ctx0, const std::vector<MCB> &tab, hipStream_t stream, const MCB **dev) {
+    char *d = nullptr, *h = nullptr;
+    const size_t bytes = tab.size() * sizeof(MCB);
+    int rc = modest_ctx_chain_tab(ctx0, bytes, &d);
+    if (rc) return rc;
+    rc = modest_ctx_stage_slot(ctx0, bytes, reinterpret_cast<void **>(&h));
+    if (rc) return rc;
+    memcpy(h, tab.data(), bytes);
+    MODEST_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+    rc = modest_ctx_stage_commit(ctx0, stream);
+    if (rc) return rc;
+    *dev = reinterpret_cast<const MCB *>(d);
+    return MODEST_OK;
+}
+}  // namespace
+
+bool modest_mask_chain_supported(int neighbor_type, int affinity_type) {
+    return (neighbor_type == MODEST_GRAPH_RADIUS_MUTUAL_KNN || neighbor_type == MODEST_GRAPH_RADIUS) &&
+           affinity_type != MODEST_AFFINITY_L2_4D;
+}
+
+struct modest_mask_chain_state {
+    std::vector<MCB> tab;
+    std::vector<size_t> own;
+};
+
+int modest_mask_chain_count(modest_mask_chain_scan *S, int B, double offset, const double *only_range4,
+                            const double *limit_range4, int neighbor_type, int k_neighbors, double radius,
+                            modest_mask_chain_state **state_out, hipStream_t stream) {
+    MODEST_REQUIRE(S != nullptr && B >= 1 && B <= 64 && limit_range4 != nullptr && state_out != nullptr, "bad chain");
+    auto *st = new modest_mask_chain_state;
+    *state_out = st;
+    st->tab.resize((size_t)B);
+    st->own.resize((size_t)B);
+    const double c = radius * (1.0 + 1.0 / 1024.0);
+    int maxblk = 1;
+    for (int s = 0; s < B; ++s) {
+        modest_mask_chain_scan &q = S[s];
+        MCB &b = st->tab[(size_t)s];
+        memset(&b, 0, sizeof(b));
+        q.n_kept = q.n_clusters = 0;
+        q.alone = 0;
+        MODEST_REQUIRE(q.ctx && q.pts && q.pp && q.labels && q.plane4 && q.n >= 1 && (q.stride == 3 || q.stride == 4),
+                       "bad scan of the chain");
+        modest_ctx *ctx = q.ctx;
+        const size_t own = arena_sz((size_t)q.n * 12) + arena_sz((size_t)q.n * 4) + arena_sz(sizeof(CGrid));
+        st->own[(size_t)s] = own;
+        int rc = modest_ctx_reserve(ctx, own + cluster_arena_bytes(q.n, neighbor_type, k_neighbors));
+        if (rc) return rc;
+        rc = modest_ctx_reserve_pinned(ctx, 256);
+        if (rc) return rc;
+        Arena A(ctx->scratch);
+        b.kept = A.take<float>((size_t)q.n * 3);
+        b.kept_idx = A.take<int>(q.n);
+        b.g = A.take<CGrid>(1);
+        b.h_kept = reinterpret_cast<int *>(ctx->pinned + 192);
+        unsigned *cnt = nullptr;
+        rc = modest_ctx_zero_words(ctx, stream, &cnt);
+        if (rc) return rc;
+        ctx->zwords_dirty = 1;
+        ctx->zwords_live = 1;
+        b.cnt = cnt;
+        mask_params_fill(b.P, q.plane4, offset, only_range4, limit_range4);
+        double cx = 0.5 * ((double)b.P.lx0 + (double)b.P.lx1), cy = 0.5 * ((double)b.P.ly0 + (double)b.P.ly1);
+        if (!(fabs(cx) <= 1e30)) cx = 0.0;
+        if (!(fabs(cy) <= 1e30)) cy = 0.0;
+        b.G.ox = cx - 0.5 * CG * c;
+        b.G.oy = cy - 0.5 * CG * c;
+        b.G.inv_c = 1.0 / c;
+        b.nblk = (q.n + 1023) / 1024;
+        rc = modest_ctx_compact_state(ctx, (size_t)b.nblk, stream, &b.state);
+        if (rc) return rc;
+        b.pts = q.pts;
+        b.pp = q.pp;
+        b.labels = q.labels;
+        b.n = q.n;
+        b.stride = q.stride;
+        maxblk = std::max(maxblk, b.nblk);
+    }
+    const MCB *dev = nullptr;
+    int rc = mcb_upload(S[0].ctx, st->tab, stream, &dev);
+    if (rc) return rc;
+    mcb_mask_count<<<dim3((unsigned)maxblk, (unsigned)B), 1024, 0, stream>>>(dev);
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
+
+void modest_mask_chain_free(modest_mask_chain_state *st) { delete st; }
+
+// after the caller's synchronise: kept counts -> the chain of graph / DBSCAN launches -> synchronise -> cluster counts
+int modest_mask_chain_cluster(modest_mask_chain_scan *S, int B, modest_mask_chain_state *st, int neighbor_type,
+                              int affinity_type, int k_neighbors, double radius, double eps, int min_samples,
+                              hipStream_t stream) {
+    MODEST_REQUIRE(S != nullptr && st != nullptr && (int)st->tab.size() == B, "bad chain");
+    const double r2 = radius * radius;
+    EdgeP ep;
+    ep.r2 = r2;
+    ep.eps = eps;
+    ep.use_knn = neighbor_type == MODEST_GRAPH_RADIUS_MUTUAL_KNN;
+    ep.affinity = affinity_type;
+    ep.inten = nullptr;
+    int maxnb = 1, maxnw = 1, maxnbA = 1, live = 0;
+    for (int s = 0; s < B; ++s) {
+        modest_mask_chain_scan &q = S[s];
+        MCB &b = st->tab[(size_t)s];
+        modest_ctx *ctx = q.ctx;
+        ctx->zwords_live = 0;
+        const int m = *b.h_kept;
+        q.n_kept = m;
+        b.m = m;
+        if (q.alone) {   // taken out of the chain by the caller: the cell counters keep this scan's counts (dirty)
+            b.m = 0;
+            continue;
+        }
+        if (m == 0) {
+            ctx->zwords_dirty = 0;   // nothing was counted
+            continue;
+        }
+        if (neighbor_type != MODEST_GRAPH_RADIUS && m <= k_neighbors) {   // sklearn's kneighbors raises: the caller decides
+            q.alone = 1;
+            b.m = 0;
+            continue;
+        }
+        ++live;
+        // the clustering arena of cluster_impl(ctx, own, kept, ..., m, ...) in the same order
+        Arena A(ctx->scratch + st->own[(size_t)s]);
+        A.take<CGrid>(1);
+        unsigned *zeroed = A.take<unsigned>((size_t)CG_CELLS + 4);
+        b.start = A.take<unsigned>(CG_CELLS + 1);
+        b.cursor = A.take<unsigned>(CG_CELLS + 1);
+        b.sorted = A.take<float4>(m);
+        b.sidx = A.take<int>(m);
+        b.kthS = A.take<double>(m);
+        b.coreS = A.take<unsigned char>(m);
+        b.parent = A.take<int>(m);
+        b.root = A.take<int>(m);
+        b.isroot = A.take<unsigned>(m);
+        b.rank = A.take<unsigned>(m + 1);
+        b.deg = A.take<int>(m);
+        b.adj = A.take<int>((size_t)m * ADJ);
+        b.flags = zeroed + CG_CELLS;
+        b.h_res = reinterpret_cast<unsigned *>(ctx->pinned);
+        b.nb = (m + 255) / 256;
+        b.nw = (m + WPB - 1) / WPB;
+        b.nbA = (int)(((long long)m * AG + 255) / 256);
+        maxnb = std::max(maxnb, b.nb);
+        maxnw = std::max(maxnw, b.nw);
+        maxnbA = std::max(maxnbA, b.nbA);
+    }
+    if (live == 0) return MODEST_OK;
+    const MCB *dev = nullptr;
+    int rc = mcb_upload(S[0].ctx, st->tab, stream, &dev);
+    if (rc) return rc;
+    const unsigned Bu = (unsigned)B;
+    mcb_scan<true><<<dim3(1, Bu), 1024, 0, stream>>>(dev);
+    mcb_cg_scatter<<<dim3((unsigned)maxnb, Bu), 256, 0, stream>>>(dev);
+    if (ep.use_knn) mcb_knn_kth<<<dim3((unsigned)maxnw, Bu), 64 * WPB, 0, stream>>>(dev, k_neighbors, r2);
+    mcb_degree_adj<<<dim3((unsigned)maxnw, Bu), 64 * WPB, 0, stream>>>(dev, ep, min_samples);
+    for (int round = 0; round < HOOK_ROUNDS; ++round) {
+        mcb_hook<<<dim3((unsigned)maxnbA, Bu), 256, 0, stream>>>(dev);
+        mcb_flatten<<<dim3((unsigned)maxnb, Bu), 256, 0, stream>>>(dev);
+    }
+    mcb_union<<<dim3((unsigned)maxnbA, Bu), 256, 0, stream>>>(dev);
+    mcb_compress<<<dim3((unsigned)maxnb, Bu), 256, 0, stream>>>(dev);
+    mcb_scan<false><<<dim3(1, Bu), 1024, 0, stream>>>(dev);
+    mcb_label<<<dim3((unsigned)maxnbA, Bu), 256, 0, stream>>>(dev);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    bool again = false;
+    for (int s = 0; s < B; ++s) {
+        MCB &b = st->tab[(size_t)s];
+        if (b.m == 0) continue;
+        if (b.h_res[0]) {   // a row of more than ADJ edges: the passes that re-walk the cell rows, for this scan alone
+            cluster_overflow_path(b.sorted, b.m, b.g, b.start, b.kthS, ep, min_samples, b.coreS, b.parent, b.sidx, b.root,
+                                  b.isroot, b.rank, b.h_res, reinterpret_cast<int *>(b.flags), b.labels, b.kept_idx, stream);
+            again = true;
+        }
+    }
+    if (again) MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int s = 0; s < B; ++s) {
+        MCB &b = st->tab[(size_t)s];
+        if (b.m == 0) continue;
+        S[s].n_clusters = (int32_t)b.h_res[1];
+        S[s].ctx->zwords_dirty = 0;
+    }
+    return MODEST_OK;
 }

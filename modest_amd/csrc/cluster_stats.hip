@@ -216,17 +216,17 @@ __global__ __launch_bounds__(CSS_THREADS) void cs_stats(const float *__restrict_
 // the L2, coalesced), folds the plane distance of every member into its extremes and appends the member's PP key to LDS
 // (the order of the keys does not matter to an order statistic).  One launch instead of two; a cluster with more
 // than CS_LDS_KEYS members raises *overflow and the caller takes the grouped path.
-__global__ __launch_bounds__(CSS_THREADS) void cs_stats_direct(const float *__restrict__ pts, int stride,
-                                                              const float *__restrict__ pp,
-                                                              const int *__restrict__ labels, int nAll, PlaneP P,
-                                                              double *__restrict__ out, int *overflow) {
+__device__ __forceinline__ void cs_stats_direct_body(const float *__restrict__ pts, int stride,
+                                                     const float *__restrict__ pp, const int *__restrict__ labels,
+                                                     int nAll, const PlaneP &P, double *__restrict__ out, int *overflow,
+                                                     const int c) {
     __shared__ unsigned hist[2048];
     __shared__ unsigned wsum[CSS_THREADS / 64], sel[2];
     __shared__ double rmin[CSS_THREADS / 64], rmax[CSS_THREADS / 64];
     __shared__ unsigned keys[CS_LDS_KEYS];
     __shared__ int midx[CS_LDS_KEYS];
     __shared__ unsigned nKeys;
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) nKeys = 0;
     __syncthreads();
     double mn = INFINITY, mx = -INFINITY;
@@ -334,6 +334,27 @@ __global__ __launch_bounds__(CSS_THREADS) void cs_stats_direct(const float *__re
         out[6 * c + 5] = gamma;
     }
 }
+__global__ __launch_bounds__(CSS_THREADS) void cs_stats_direct(const float *__restrict__ pts, int stride,
+                                                              const float *__restrict__ pp,
+                                                              const int *__restrict__ labels, int nAll, PlaneP P,
+                                                              double *__restrict__ out, int *overflow) {
+    cs_stats_direct_body(pts, stride, pp, labels, nAll, P, out, overflow, (int)blockIdx.x);
+}
+
+// a chain of scans: the scan is blockIdx.y, its pointers come from a device table
+struct CSB {
+    const float *pts, *pp;
+    const int *labels;
+    double *out;
+    int *overflow;
+    PlaneP P;
+    int stride, nAll, n_clusters, pad;
+};
+__global__ __launch_bounds__(CSS_THREADS) void csb_stats(const CSB *__restrict__ tab) {
+    const CSB &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.n_clusters) return;
+    cs_stats_direct_body(S.pts, S.stride, S.pp, S.labels, S.nAll, S.P, S.out, S.overflow, (int)blockIdx.x);
+}
 
 }  // namespace
 
@@ -397,5 +418,70 @@ extern "C" int modest_cluster_stats(modest_ctx *ctx, const float *pts, int n, in
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     const double *h = reinterpret_cast<const double *>(ctx->pinned);
     for (size_t i = 0; i < (size_t)n_clusters * 6; ++i) out_host[i] = h[i];
+    return MODEST_OK;
+}
+
+#include "mask_chain.h"
+#include <cstring>
+#include <vector>
+
+int modest_cluster_stats_chain(modest_stats_chain_scan *S, int B, double quantile, hipStream_t stream) {
+    MODEST_REQUIRE(S != nullptr && B >= 1 && B <= 64, "bad chain");
+    MODEST_REQUIRE(quantile >= 0.0 && quantile <= 1.0, "quantile must be in [0,1]");
+    std::vector<CSB> tab((size_t)B);
+    int maxC = 0;
+    for (int s = 0; s < B; ++s) {
+        modest_stats_chain_scan &q = S[s];
+        CSB &b = tab[(size_t)s];
+        memset(&b, 0, sizeof(b));
+        if (q.n_clusters <= 0) continue;
+        MODEST_REQUIRE(q.ctx && q.pts && q.pp && q.labels && q.plane4 && q.out_host, "NULL buffer");
+        int rc = modest_ctx_reserve_pinned(q.ctx, (size_t)q.n_clusters * 48 + 64);
+        if (rc) return rc;
+        b.pts = q.pts;
+        b.pp = q.pp;
+        b.labels = q.labels;
+        b.out = reinterpret_cast<double *>(q.ctx->pinned);
+        b.overflow = reinterpret_cast<int *>(q.ctx->pinned + (size_t)q.n_clusters * 48);
+        *b.overflow = 0;
+        b.P.n0 = q.plane4[0];
+        b.P.n1 = q.plane4[1];
+        b.P.n2 = q.plane4[2];
+        b.P.d = q.plane4[3];
+        b.P.norm = sqrt((q.plane4[0] * q.plane4[0] + q.plane4[1] * q.plane4[1]) + q.plane4[2] * q.plane4[2]);
+        b.P.q = quantile;
+        b.stride = q.stride;
+        b.nAll = q.n;
+        b.n_clusters = q.n_clusters;
+        maxC = maxC > q.n_clusters ? maxC : q.n_clusters;
+    }
+    if (maxC > 0) {
+        char *d = nullptr, *h = nullptr;
+        const size_t bytes = tab.size() * sizeof(CSB);
+        int rc = modest_ctx_chain_tab(S[0].ctx, bytes, &d);
+        if (rc) return rc;
+        rc = modest_ctx_stage_slot(S[0].ctx, bytes, reinterpret_cast<void **>(&h));
+        if (rc) return rc;
+        memcpy(h, tab.data(), bytes);
+        MODEST_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+        rc = modest_ctx_stage_commit(S[0].ctx, stream);
+        if (rc) return rc;
+        csb_stats<<<dim3((unsigned)maxC, (unsigned)B), CSS_THREADS, 0, stream>>>(reinterpret_cast<const CSB *>(d));
+        MODEST_HIP_CHECK(hipGetLastError());
+    }
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int s = 0; s < B; ++s) {
+        modest_stats_chain_scan &q = S[s];
+        if (q.n_clusters <= 0) continue;
+        const CSB &b = tab[(size_t)s];
+        if (*b.overflow) {   // a cluster of more than CS_LDS_KEYS points: the grouped path, for this scan alone
+            int rc = modest_cluster_stats(q.ctx, q.pts, q.n, q.stride, q.pp, q.labels, q.n_clusters, q.plane4, quantile,
+                                          q.out_host, stream);
+            if (rc) return rc;
+            continue;
+        }
+        const double *hd = reinterpret_cast<const double *>(q.ctx->pinned);
+        for (size_t i = 0; i < (size_t)q.n_clusters * 6; ++i) q.out_host[i] = hd[i];
+    }
     return MODEST_OK;
 }

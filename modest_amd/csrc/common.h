@@ -69,12 +69,16 @@ struct modest_ctx {
     hipEvent_t stage_ev[MODEST_STAGE_SLOTS];
     int stage_used[MODEST_STAGE_SLOTS];
     int stage_next;
+    // device table of a chain of scans (mask_chain.h): grow-only
+    char *chain_tab;
+    size_t chain_tab_bytes;
 };
 
 // next staging slot with at least `bytes` (waits for the slot's previous copy); commit records the
 // event behind the copy that was just enqueued from it
 int modest_ctx_stage_slot(modest_ctx *ctx, size_t bytes, void **out);
 int modest_ctx_stage_commit(modest_ctx *ctx, hipStream_t stream);
+int modest_ctx_chain_tab(modest_ctx *ctx, size_t bytes, char **out);
 
 // persistent compaction state for `nblocks` blocks (allocated and zeroed on first use / growth)
 int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream, unsigned long long **out);

@@ -78,6 +78,8 @@ extern "C" int modest_ctx_create(int device, modest_ctx **out) {
     c->hold_bytes = 0;
     c->hold_pinned = nullptr;
     c->hold_pinned_bytes = 0;
+    c->chain_tab = nullptr;
+    c->chain_tab_bytes = 0;
     for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
         c->stage[i] = nullptr;
         c->stage_bytes[i] = 0;
@@ -97,6 +99,7 @@ extern "C" int modest_ctx_destroy(modest_ctx *ctx) {
     if (ctx->zwords) (void)hipFree(ctx->zwords);
     if (ctx->hold) (void)hipFree(ctx->hold);
     if (ctx->hold_pinned) (void)hipHostFree(ctx->hold_pinned);
+    if (ctx->chain_tab) (void)hipFree(ctx->chain_tab);
     for (int i = 0; i < MODEST_STAGE_SLOTS; ++i) {
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
         if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
@@ -266,5 +269,25 @@ extern "C" int modest_ctx_profile_collect(modest_ctx *ctx, float *ms_out, int ca
     }
     *n_out = n;
     ctx->profiling = 0;
+    return MODEST_OK;
+}
+
+// device table of a chain of scans: grow-only, never moved while a launch that reads it may be in flight
+// (a grow synchronises the device first)
+int modest_ctx_chain_tab(modest_ctx *ctx, size_t bytes, char **out) {
+    MODEST_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    if (bytes > ctx->chain_tab_bytes) {
+        MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+        MODEST_HIP_CHECK(hipDeviceSynchronize());
+        if (ctx->chain_tab) MODEST_HIP_CHECK(hipFree(ctx->chain_tab));
+        ctx->chain_tab = nullptr;
+        ctx->chain_tab_bytes = 0;
+        const size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
+        void *p = nullptr;
+        MODEST_HIP_CHECK(hipMalloc(&p, want));
+        ctx->chain_tab = static_cast<char *>(p);
+        ctx->chain_tab_bytes = want;
+    }
+    *out = ctx->chain_tab;
     return MODEST_OK;
 }

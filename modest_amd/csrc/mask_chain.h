@@ -1,0 +1,40 @@
+// The mask / graph / DBSCAN block and the cluster statistics for a chain of scans (cluster.hip, cluster_stats.hip),
+// used by modest_mask_stage_batch (scan_driver.hip).  Host-side plan of one scan of the chain:
+#pragma once
+#include "common.h"
+
+struct modest_mask_chain_scan {
+    modest_ctx *ctx;        // the scan's OWN context (scratch, pinned words, persistent cell counters)
+    const float *pts;       // [dev] (n, stride) scan rows
+    int n, stride;
+    const float *pp;        // [dev] (n) PP scores
+    const double *plane4;   // [host] the plane of the mask
+    int32_t *labels;        // [dev] (n) int32
+    int32_t n_kept, n_clusters;
+    int alone;              // set when the scan has to be finished by the single-scan calls
+};
+struct modest_mask_chain_state;
+
+bool modest_mask_chain_supported(int neighbor_type, int affinity_type);
+// enqueue only: mask / compaction / cell count of every scan in one launch
+int modest_mask_chain_count(modest_mask_chain_scan *S, int B, double offset, const double *only_range4,
+                            const double *limit_range4, int neighbor_type, int k_neighbors, double radius,
+                            modest_mask_chain_state **state_out, hipStream_t stream);
+// after the caller's synchronise: the graph / DBSCAN launches of the chain, a synchronise, n_kept / n_clusters filled
+int modest_mask_chain_cluster(modest_mask_chain_scan *S, int B, modest_mask_chain_state *st, int neighbor_type,
+                              int affinity_type, int k_neighbors, double radius, double eps, int min_samples,
+                              hipStream_t stream);
+void modest_mask_chain_free(modest_mask_chain_state *st);
+
+// cluster statistics of every scan of the chain in one launch (cluster_stats.hip); out_host[s]: 6 doubles per cluster
+struct modest_stats_chain_scan {
+    modest_ctx *ctx;
+    const float *pts;
+    int n, stride;
+    const float *pp;
+    const int32_t *labels;   // [dev]
+    int n_clusters;
+    const double *plane4;    // [host]
+    double *out_host;        // (n_clusters, 6)
+};
+int modest_cluster_stats_chain(modest_stats_chain_scan *S, int B, double quantile, hipStream_t stream);

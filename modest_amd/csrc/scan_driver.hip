@@ -6,7 +6,9 @@
 // across them -- candidate sets, the scan-sized labels -- sits in the context's hold buffers).
 #include "common.h"
 #include "ransac_host.h"
+#include "mask_chain.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -25,6 +27,39 @@ void plane_from_model(const double *model64, double *plane4) {
     plane4[1] = -(c1 / norm);
     plane4[2] = -(-1.0 / norm);
     plane4[3] = -((double)b32 / norm);
+}
+
+// is_valid_cluster (clustering_utils.py:94-117) + relabelling (:131-135) as one table look-up:
+// table[l + 1] = rank of label l among the surviving values; -1 survives iff it occurs or a cluster is dropped
+void finish_labels(const modest_mask_params *P, int n, int n_clusters, const std::vector<double> &st, const int32_t *labels_h,
+                   int64_t *labels_out, int32_t *info_out) {
+    std::vector<int64_t> table((size_t)n_clusters + 1, 0);
+    bool has_neg = false;
+    for (int i = 0; i < n && !has_neg; ++i) has_neg = labels_h[i] < 0;
+    std::vector<char> valid(n_clusters > 0 ? n_clusters : 1, 0);
+    int n_valid = 0;
+    for (int c = 0; c < n_clusters; ++c) {
+        const double cnt = st[6 * c], dmin = st[6 * c + 1], dmax = st[6 * c + 2];
+        // numpy.percentile(float32 data, method='linear'): _lerp in float32, the upper form from t = 0.5 on
+        const float a = (float)st[6 * c + 3], b = (float)st[6 * c + 4], t = (float)st[6 * c + 5];
+        const float diff = b - a;
+        const float lo = a + diff * t, hi = b - diff * (1.0f - t);
+        const float pct = t >= 0.5f ? hi : lo;
+        const bool ok = cnt >= (double)P->min_points && !(dmin > P->max_min_height) && !(dmax < P->min_max_height) &&
+                        !(pct > P->min_percentile_pp_score) && cnt >= 1.0;
+        valid[c] = ok ? 1 : 0;
+        n_valid += ok;
+        if (!ok && cnt >= 1.0) has_neg = true;
+    }
+    int64_t next = has_neg ? 1 : 0;
+    for (int c = 0; c < n_clusters; ++c)
+        if (valid[c]) table[(size_t)c + 1] = next++;
+    for (int i = 0; i < n; ++i) labels_out[i] = table[(size_t)(labels_h[i] + 1)];
+    info_out[2] = n_valid > 0 ? (int32_t)(next - 1) : 0;   // largest final label = number of box candidates
+    if (n_clusters == 0) {   // compact_labels of the raw labels: all -1 -> all 0
+        for (int i = 0; i < n; ++i) labels_out[i] = 0;
+        info_out[2] = 0;
+    }
 }
 
 }  // namespace
@@ -146,35 +181,192 @@ extern "C" int modest_mask_stage(modest_ctx *ctx, const float *pts, int n, int s
     } else {
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     }
-    // 5. is_valid_cluster (clustering_utils.py:94-117) + relabelling (:131-135) as one table look-up:
-    //    table[l + 1] = rank of label l among the surviving values; -1 survives iff it occurs or a
-    //    cluster is dropped
-    std::vector<int64_t> table((size_t)n_clusters + 1, 0);
-    bool has_neg = false;
-    for (int i = 0; i < n && !has_neg; ++i) has_neg = labels_h[i] < 0;
-    std::vector<char> valid(n_clusters > 0 ? n_clusters : 1, 0);
-    int n_valid = 0;
-    for (int c = 0; c < n_clusters; ++c) {
-        const double cnt = st[6 * c], dmin = st[6 * c + 1], dmax = st[6 * c + 2];
-        // numpy.percentile(float32 data, method='linear'): _lerp in float32, the upper form from t = 0.5 on
-        const float a = (float)st[6 * c + 3], b = (float)st[6 * c + 4], t = (float)st[6 * c + 5];
-        const float diff = b - a;
-        const float lo = a + diff * t, hi = b - diff * (1.0f - t);
-        const float pct = t >= 0.5f ? hi : lo;
-        const bool ok = cnt >= (double)P->min_points && !(dmin > P->max_min_height) && !(dmax < P->min_max_height) &&
-                        !(pct > P->min_percentile_pp_score) && cnt >= 1.0;
-        valid[c] = ok ? 1 : 0;
-        n_valid += ok;
-        if (!ok && cnt >= 1.0) has_neg = true;
+    // 5. is_valid_cluster + relabelling
+    finish_labels(P, n, n_clusters, st, labels_h, labels_out, info_out);
+    return MODEST_OK;
+}
+
+// ---- the same stage for a CHAIN of scans -----------------------------------------------------------------------
+// The ground fits stay per scan (their trial loops are data dependent: three round trips each); from the mask kernel
+// on the scans advance together: ONE launch per kernel of the mask / graph / DBSCAN block and of the cluster
+// statistics for the whole chain (cluster.hip, cluster_stats.hip: the scan is blockIdx.y), three round trips per
+// chain.  Every scan works in its own context; results are those of separate modest_mask_stage calls, bit for bit.
+extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int n_scans, const modest_mask_params *P,
+                                       void *stream_) {
+    MODEST_REQUIRE(scans != nullptr && P != nullptr && n_scans >= 1 && n_scans <= 64, "bad chain");
+    if (n_scans == 1 || !modest_mask_chain_supported(P->neighbor_type, P->affinity_type) || getenv("MODEST_MASK_NOCHAIN")) {
+        for (int s = 0; s < n_scans; ++s) {
+            const modest_mask_stage_scan &q = scans[s];
+            int rc = modest_mask_stage(q.ctx, q.pts_dev, q.n, q.stride, q.pp_dev, P, q.mt_key624, q.mt_pos, q.plane1_out,
+                                       q.plane2_out, q.labels_out, q.info_out, stream_);
+            if (rc) return rc;
+        }
+        return MODEST_OK;
     }
-    int64_t next = has_neg ? 1 : 0;
-    for (int c = 0; c < n_clusters; ++c)
-        if (valid[c]) table[(size_t)c + 1] = next++;
-    for (int i = 0; i < n; ++i) labels_out[i] = table[(size_t)(labels_h[i] + 1)];
-    info_out[2] = n_valid > 0 ? (int32_t)(next - 1) : 0;   // largest final label = number of box candidates
-    if (n_clusters == 0) {   // compact_labels of the raw labels: all -1 -> all 0
-        for (int i = 0; i < n; ++i) labels_out[i] = 0;
-        info_out[2] = 0;
+    hipStream_t stream = as_stream(stream_);
+    struct Run {
+        Mt19937 g;
+        RansacFit A, B;
+        int32_t *labels_dev = nullptr, *labels_h = nullptr;
+        bool alive = false;
+    };
+    std::vector<Run> R((size_t)n_scans);
+    for (int s = 0; s < n_scans; ++s)
+        for (int k = s + 1; k < n_scans; ++k) MODEST_REQUIRE(scans[s].ctx != scans[k].ctx, "every scan of a chain needs its own context");
+    // 1 + 2 per scan: candidates, thresholds, both trial loops; the second refit stays in flight
+    for (int s = 0; s < n_scans; ++s) {
+        const modest_mask_stage_scan &q = scans[s];
+        Run &r = R[(size_t)s];
+        modest_ctx *ctx = q.ctx;
+        MODEST_REQUIRE(ctx && q.mt_key624 && q.mt_pos && q.plane1_out && q.plane2_out && q.labels_out && q.info_out, "NULL argument");
+        MODEST_REQUIRE(q.n >= 1 && (q.stride == 3 || q.stride == 4) && q.pts_dev && q.pp_dev, "bad scan");
+        MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+        for (int k = 0; k < 8; ++k) q.info_out[k] = 0;
+        const size_t b_cand = arena_sz((size_t)q.n * 12), b_lab = arena_sz((size_t)q.n * 4);
+        int rc = modest_ctx_reserve_hold(ctx, 2 * b_cand + b_lab, b_lab);
+        if (rc) return rc;
+        float *candA = reinterpret_cast<float *>(ctx->hold), *candB = reinterpret_cast<float *>(ctx->hold + b_cand);
+        r.labels_dev = reinterpret_cast<int32_t *>(ctx->hold + 2 * b_cand);
+        r.labels_h = reinterpret_cast<int32_t *>(ctx->hold_pinned);
+        const float specs[10] = {P->max_hs1, P->range1[0], P->range1[1], P->range1[2], P->range1[3],
+                                 P->max_hs2, P->range2[0], P->range2[1], P->range2[2], P->range2[3]};
+        int32_t n_cand[2];
+        float mad[2];
+        rc = modest_plane_prepare(ctx, q.pts_dev, q.n, q.stride, specs, candA, candB, n_cand, mad, stream_);
+        if (rc) return rc;
+        q.info_out[4] = n_cand[0];
+        q.info_out[5] = n_cand[1];
+        if (n_cand[0] <= 300 || n_cand[1] <= 300) {
+            q.info_out[3] = MODEST_STAGE_SMALL_SET;
+            continue;
+        }
+        rc = modest_ctx_reserve_pinned(ctx, 16384);
+        if (rc) return rc;
+        memcpy(r.g.key, q.mt_key624, sizeof(r.g.key));
+        r.g.pos = *q.mt_pos;
+        r.A.init(ctx, candA, n_cand[0], mad[0], &r.g, P->max_trials, P->stop_probability, P->batch, stream_);
+        r.B.init(ctx, candB, n_cand[1], mad[1], &r.g, P->max_trials, P->stop_probability, P->batch, stream_);
+        while (!r.A.done()) {
+            if ((rc = r.A.enqueue_batch())) return rc;
+            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+            if ((rc = r.A.finish_batch())) return rc;
+        }
+        q.info_out[6] = r.A.n_trials;
+        if (!r.A.have) {
+            q.info_out[3] = MODEST_STAGE_NO_CONSENSUS;
+            continue;
+        }
+        if ((rc = r.A.enqueue_refit())) return rc;
+        if ((rc = r.B.enqueue_batch())) return rc;
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        double model64[3];
+        int32_t n_in = 0;
+        bool degenerate = false;
+        if ((rc = r.A.finish_refit(model64, &n_in, &degenerate))) return rc;
+        if (degenerate) {
+            q.info_out[3] = MODEST_STAGE_DEGENERATE;
+            continue;
+        }
+        plane_from_model(model64, q.plane1_out);
+        if ((rc = r.B.finish_batch())) return rc;
+        while (!r.B.done()) {
+            if ((rc = r.B.enqueue_batch())) return rc;
+            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+            if ((rc = r.B.finish_batch())) return rc;
+        }
+        q.info_out[7] = r.B.n_trials;
+        if (!r.B.have) {
+            q.info_out[3] = MODEST_STAGE_NO_CONSENSUS;
+            continue;
+        }
+        if ((rc = r.B.enqueue_refit())) return rc;
+        r.alive = true;
+    }
+    // 3. the mask kernel of every scan that got this far, one launch
+    std::vector<modest_mask_chain_scan> C;
+    std::vector<int> who;
+    for (int s = 0; s < n_scans; ++s)
+        if (R[(size_t)s].alive) {
+            const modest_mask_stage_scan &q = scans[s];
+            modest_mask_chain_scan c{};
+            c.ctx = q.ctx;
+            c.pts = q.pts_dev;
+            c.n = q.n;
+            c.stride = q.stride;
+            c.pp = q.pp_dev;
+            c.plane4 = q.plane1_out;
+            c.labels = R[(size_t)s].labels_dev;
+            C.push_back(c);
+            who.push_back(s);
+        }
+    if (C.empty()) return MODEST_OK;
+    const int B = (int)C.size();
+    const double *only = P->use_only_range ? P->only_range : nullptr;
+    modest_mask_chain_state *cst = nullptr;
+    int rc = modest_mask_chain_count(C.data(), B, P->offset, only, P->limit_range, P->neighbor_type, P->k_neighbors, P->radius,
+                                     &cst, stream);
+    struct Free {
+        modest_mask_chain_state *p;
+        ~Free() { modest_mask_chain_free(p); }
+    } guard{cst};
+    if (rc) return rc;
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < B; ++i) {
+        const modest_mask_stage_scan &q = scans[who[(size_t)i]];
+        Run &r = R[(size_t)who[(size_t)i]];
+        double model64[3];
+        int32_t n_in = 0;
+        bool degenerate = false;
+        if ((rc = r.B.finish_refit(model64, &n_in, &degenerate))) return rc;
+        if (degenerate) {
+            q.info_out[3] = MODEST_STAGE_DEGENERATE;
+            C[(size_t)i].alone = 1;   // out of the chain; its cell counters hold this scan's counts
+            continue;
+        }
+        plane_from_model(model64, q.plane2_out);
+        memcpy(q.mt_key624, r.g.key, sizeof(r.g.key));
+        *q.mt_pos = r.g.pos;
+    }
+    // 4. graph + DBSCAN + labels[ptc_mask] = ... of the chain
+    rc = modest_mask_chain_cluster(C.data(), B, cst, P->neighbor_type, P->affinity_type, P->k_neighbors, P->radius, P->eps,
+                                   P->min_samples, stream);
+    if (rc) return rc;
+    // 5. labels to the host + cluster statistics of the chain (one launch, one synchronise)
+    std::vector<modest_stats_chain_scan> T((size_t)B);
+    std::vector<std::vector<double>> st((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        const modest_mask_stage_scan &q = scans[who[(size_t)i]];
+        Run &r = R[(size_t)who[(size_t)i]];
+        modest_stats_chain_scan &t = T[(size_t)i];
+        memset(&t, 0, sizeof(t));
+        if (C[(size_t)i].alone) {
+            if (q.info_out[3] == 0) {
+                q.info_out[0] = C[(size_t)i].n_kept;
+                q.info_out[3] = MODEST_STAGE_TOO_FEW_KEPT;
+            }
+            continue;
+        }
+        q.info_out[0] = C[(size_t)i].n_kept;
+        q.info_out[1] = C[(size_t)i].n_clusters;
+        MODEST_HIP_CHECK(hipMemcpyAsync(r.labels_h, r.labels_dev, (size_t)q.n * 4, hipMemcpyDeviceToHost, stream));
+        st[(size_t)i].assign((size_t)(C[(size_t)i].n_clusters > 0 ? C[(size_t)i].n_clusters : 1) * 6, 0.0);
+        t.ctx = q.ctx;
+        t.pts = q.pts_dev;
+        t.n = q.n;
+        t.stride = q.stride;
+        t.pp = q.pp_dev;
+        t.labels = r.labels_dev;
+        t.n_clusters = C[(size_t)i].n_clusters;
+        t.plane4 = q.plane2_out;
+        t.out_host = st[(size_t)i].data();
+    }
+    T[0].ctx = T[0].ctx ? T[0].ctx : scans[who[0]].ctx;   // the chain table lives in the first scan's context
+    rc = modest_cluster_stats_chain(T.data(), B, P->quantile, stream);
+    if (rc) return rc;
+    for (int i = 0; i < B; ++i) {
+        if (C[(size_t)i].alone) continue;
+        const modest_mask_stage_scan &q = scans[who[(size_t)i]];
+        finish_labels(P, q.n, C[(size_t)i].n_clusters, st[(size_t)i], R[(size_t)who[(size_t)i]].labels_h, q.labels_out, q.info_out);
     }
     return MODEST_OK;
 }

@@ -48,8 +48,11 @@ def objs_from_rows(rows):
     return out
 
 
+_UNSET = object()
+
+
 def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=None, ptc_dev=None,
-                       pp_dev=None, as_rows=False):
+                       pp_dev=None, as_rows=False, staged=_UNSET):
     """The body of the reference's per-scan loop (generate_mask.py:52-103).
 
     ptc (N,4) float32 numpy, pp_score (N,) float32 numpy, calib a Calibration.
@@ -66,13 +69,15 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     g = args.graph
     if g.neighbor_type not in ops.GRAPH_TYPES or g.affinity_type not in ops.AFFINITY_TYPES:
         raise NotImplementedError(f"graph {g.neighbor_type}/{g.affinity_type} (SURVEY.md §8f-3)")
-    staged = None
-    if planes is None and NATIVE_STAGE and ptc.shape[0] >= 1:
-        rs = np.random.mtrand._rand if random_state is None else random_state
-        if isinstance(rs, np.random.RandomState) and rs.get_state()[0] == "MT19937":
-            # both ground fits, mask, graph + DBSCAN, cluster statistics, validity rules and the relabelling
-            # behind one library call (no interpreter between the device round trips of these steps)
-            staged = ops.mask_stage(ptc_dev, pp_dev, _stage_params(args), rs)
+    if staged is _UNSET:
+        staged = None
+        if planes is None and NATIVE_STAGE and ptc.shape[0] >= 1:
+            rs = np.random.mtrand._rand if random_state is None else random_state
+            if isinstance(rs, np.random.RandomState) and rs.get_state()[0] == "MT19937":
+                # both ground fits, mask, graph + DBSCAN, cluster statistics, validity rules and the relabelling
+                # behind one library call (no interpreter between the device round trips of these steps)
+                staged = ops.mask_stage(ptc_dev, pp_dev, _stage_params(args), rs)
+    # else: the stage ran in a chain of scans (generate_mask_chain): its result, or None = host statement
     if staged is not None:
         labels_filtered, plane, _, info = staged
         n_kept = int(info[0])
@@ -107,6 +112,33 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     if as_rows:
         objs = np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs], dtype=np.float64).reshape(-1, 8)
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
+
+
+def generate_mask_chain(scans, calib, args, as_rows=False, ctxs=None):
+    """generate_mask_scan for a CHAIN of scans: the mask stage of all of them as one library call
+    (modest_mask_stage_batch: one launch per kernel of the mask / graph / DBSCAN block and of the cluster statistics
+    for the whole chain), then boxes per scan.  scans: [dict(ptc=, pp_score=, random_state=, ptc_dev=, pp_dev=)];
+    calib: one Calibration or one per scan.  Returns [generate_mask_scan's result] -- identical to separate calls."""
+    calibs = calib if isinstance(calib, (list, tuple)) else [calib] * len(scans)
+    staged = [_UNSET] * len(scans)
+    if NATIVE_STAGE and len(scans) > 1:
+        items, who = [], []
+        for i, sc in enumerate(scans):
+            rs = sc.get("random_state")
+            rs = np.random.mtrand._rand if rs is None else rs
+            if sc["ptc"].shape[0] >= 1 and isinstance(rs, np.random.RandomState) and rs.get_state()[0] == "MT19937":
+                if sc.get("ptc_dev") is None:
+                    sc["ptc_dev"] = to_device(sc["ptc"])
+                if sc.get("pp_dev") is None:
+                    sc["pp_dev"] = to_device(sc["pp_score"])
+                items.append((sc["ptc_dev"], sc["pp_dev"], rs))
+                who.append(i)
+        if len(items) > 1 and len({id(it[2]) for it in items}) == len(items):   # one generator per scan: no draw order between scans
+            for i, res in zip(who, ops.mask_stage_batch(items, _stage_params(args), ctxs=ctxs)):
+                staged[i] = res
+    return [generate_mask_scan(sc["ptc"], sc["pp_score"], cb, args, random_state=sc.get("random_state"),
+                               ptc_dev=sc.get("ptc_dev"), pp_dev=sc.get("pp_dev"), as_rows=as_rows, staged=staged[i])
+            for i, (sc, cb) in enumerate(zip(scans, calibs))]
 
 
 NATIVE_STAGE = True   # tests switch it off to compare the library's stage driver with the Python statement

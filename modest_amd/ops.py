@@ -420,6 +420,69 @@ def mask_stage(pts: torch.Tensor, pp: torch.Tensor, params: MaskParams, rs: np.r
     return labels, plane1, plane2, info
 
 
+class MaskStageScan(C.Structure):
+    """modest_mask_stage_scan (include/modest_hip.h)"""
+    _fields_ = [("ctx", C.c_void_p), ("pts_dev", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32), ("pp_dev", C.c_void_p),
+                ("mt_key624", C.c_void_p), ("mt_pos", C.c_void_p), ("plane1_out", C.c_void_p), ("plane2_out", C.c_void_p),
+                ("labels_out", C.c_void_p), ("info_out", C.c_void_p)]
+
+
+_CHAIN_CTXS = {}
+
+
+def chain_contexts(n: int, device: int = 0):
+    """`n` library contexts of the calling thread for the scans of a chain (every scan of a chain works in its own
+    context: scratch, pinned words, persistent counters)"""
+    import threading
+    key = (threading.get_ident(), int(device))
+    have = _CHAIN_CTXS.setdefault(key, [])
+    while len(have) < n:
+        have.append(Context(int(device)))
+    return have[:n]
+
+
+def mask_stage_batch(items, params: MaskParams, ctxs=None):
+    """modest_mask_stage_batch: generate_mask_scan up to ``labels_filtered`` for a CHAIN of scans -- the ground fits per
+    scan, the mask / graph / DBSCAN block and the cluster statistics as one launch per kernel for the whole chain.
+    items: [(pts_dev (n,3|4) f32, pp_dev (n,) f32, RandomState)]; returns a list with, per scan, what mask_stage
+    returns (None: the library hands that scan back to the host statement, its generator untouched)."""
+    lib = load()
+    B = len(items)
+    if B == 0:
+        return []
+    if ctxs is None:
+        ctxs = chain_contexts(B, items[0][0].device.index or 0)
+    arr = (MaskStageScan * B)()
+    keep = []
+    for i, (pts, pp, rs) in enumerate(items):
+        _dev(pts, torch.float32, "pts")
+        _dev(pp, torch.float32, "pp")
+        n = pts.shape[0]
+        assert pp.shape[0] == n and n >= 1
+        st = rs.get_state()
+        assert st[0] == "MT19937"
+        key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        pos = np.array([int(st[2])], dtype=np.int32)
+        plane1, plane2 = np.zeros(4, dtype=np.float64), np.zeros(4, dtype=np.float64)
+        labels = np.empty(n, dtype=np.int64)
+        info = np.zeros(8, dtype=np.int32)
+        keep.append((st, key, pos, plane1, plane2, labels, info))
+        a = arr[i]
+        a.ctx = C.cast(ctxs[i].handle, C.c_void_p).value
+        a.pts_dev, a.n, a.stride, a.pp_dev = pts.data_ptr(), n, pts.shape[1], pp.data_ptr()
+        a.mt_key624, a.mt_pos = _np_ptr(key), _np_ptr(pos)
+        a.plane1_out, a.plane2_out, a.labels_out, a.info_out = _np_ptr(plane1), _np_ptr(plane2), _np_ptr(labels), _np_ptr(info)
+    check(lib.modest_mask_stage_batch(C.byref(arr), B, C.byref(params), _stream()), "modest_mask_stage_batch")
+    out = []
+    for (pts, pp, rs), (st, key, pos, plane1, plane2, labels, info) in zip(items, keep):
+        if info[3] != 0:
+            out.append(None)
+            continue
+        rs.set_state((st[0], key, int(pos[0]), st[3], st[4]))
+        out.append((labels, plane1, plane2, info))
+    return out
+
+
 class BoxesParams(C.Structure):
     """modest_boxes_params (include/modest_hip.h)"""
     _fields_ = [("V2C", C.c_double * 12), ("R0", C.c_double * 9), ("angles", C.c_void_p), ("cossin", C.c_void_p),

@@ -401,3 +401,39 @@ def test_results_do_not_depend_on_load(gpu):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_mask_stage_chain_equals_separate_calls(gpu, tmp_path):
+    """modest_mask_stage_batch: the mask stage of several scans as one chain of launches (mask / graph / DBSCAN block and
+    cluster statistics: the scan is a second grid dimension) gives the labels, planes, boxes and generator states of
+    separate calls -- scans of different size, a scan whose candidate set is too small (handed back to the host
+    statement inside a chain), a chain of seven."""
+    import torch
+    from modest_amd import config, generate_mask as gm, synth
+    from modest_amd.utils import kitti_util
+    open(tmp_path / "c.txt", "w").write(synth.CALIB_TXT)
+    calib = kitti_util.Calibration(str(tmp_path / "c.txt"))
+    args = config.compose("generate_mask", ["data_root=/unused"])
+    scans = []
+    for k, n_live in enumerate([30000, 12000, 21000, 400, 30000, 8000, 17000]):
+        s = synth.make_scan(70 + k, n_live=n_live, n_trav=2, n_frames=1)
+        raw = np.ascontiguousarray(s.live_raw)
+        rng = np.random.default_rng(k)
+        pp = np.clip(0.5 + 0.5 * np.sin(raw[:, 0] * 0.3) + rng.normal(0, 0.03, len(raw)), 0, 1).astype(np.float32)
+        scans.append((raw, pp, torch.from_numpy(raw).to(gpu), torch.from_numpy(pp).to(gpu)))
+    single, states = [], []
+    for k, (raw, pp, rd, pd) in enumerate(scans):
+        rs = np.random.RandomState(100 + k)
+        single.append(gm.generate_mask_scan(raw, pp, calib, args, random_state=rs, ptc_dev=rd, pp_dev=pd, as_rows=True))
+        states.append(rs.get_state())
+    for group in ([0, 1, 2, 3, 4, 5, 6], [4, 0], [1, 2, 5]):
+        rss = [np.random.RandomState(100 + k) for k in group]
+        chain = gm.generate_mask_chain([dict(ptc=scans[k][0], pp_score=scans[k][1], random_state=rs, ptc_dev=scans[k][2],
+                                             pp_dev=scans[k][3]) for k, rs in zip(group, rss)], calib, args, as_rows=True)
+        for k, rs, (labels, rows, info) in zip(group, rss, chain):
+            assert np.array_equal(labels, single[k][0]), k
+            assert np.array_equal(rows, single[k][1]), k
+            assert np.array_equal(info["plane"], single[k][2]["plane"]) and info["n_kept"] == single[k][2]["n_kept"], k
+            a, b = rs.get_state(), states[k]
+            assert a[2] == b[2] and np.array_equal(a[1], b[1]), k
+    assert any(len(r[1]) > 0 for r in single)
