@@ -66,6 +66,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=560)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-mask-chain", action="store_true",
+                    help="A/B: the mask stage scan by scan (modest_mask_stage) instead of one call per chain of --pp-batch scans")
     ap.add_argument("--scans", type=int, default=4, help="distinct resident scans per host process, cycled through")
     ap.add_argument("--pp-batch", type=int, default=4,
                     help="scans whose PP stage goes through ONE chain of launches (modest_pp_score_frames_batch); "
@@ -182,10 +184,11 @@ class Runner:
         from modest_amd import _lib, config, ops, synth
         from modest_amd.frame_store import FrameStore
         from modest_amd.gen_label_files import gen_label_scan
-        from modest_amd.generate_mask import generate_mask_scan
+        from modest_amd.generate_mask import generate_mask_chain, generate_mask_scan
         from modest_amd.utils import kitti_util
         self.a, self.ops, self.threading = a, ops, threading
         self._gen_label_scan, self._generate_mask_scan = gen_label_scan, generate_mask_scan
+        self._generate_mask_chain = generate_mask_chain
         _lib.load()
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -205,6 +208,8 @@ class Runner:
         self.B = max(1, min(int(a.pp_batch), int(a.scans)))
         self.mark_batch = [[] for _ in range(self.n_threads)]   # scans per profile mark, per thread
         self.pp_ctxs = self.ctxs
+        # the mask stage of a chain runs every scan in its own context (the thread's + B - 1 more)
+        self.chain_ctxs = [[self.ctxs[w]] + [_lib.Context(local) for _ in range(self.B - 1)] for w in range(self.n_threads)]
         if shared:
             del os.environ["MODEST_NUM_CUS"]
         self._lib, self.local, self.iso_ctx = _lib, local, None
@@ -294,29 +299,45 @@ class Runner:
             return self.store.pp_score_batch([key], [desc], sc.T, ctx=ctx)[0]   # one scan: the library takes the single-scan chain
 
     def step(self, i, w, H=None, after=None):
-        """One scan through the pipeline on thread w.  H: the scan's PP score when it was enqueued ahead of time;
-        after: called (same stream, same context) as soon as this scan has no device work left, i.e. under the
-        host tail of the label stage -- the worker enqueues the PP stage of its next batch of scans there.
-        Returns (H, labels, objs, text)."""
-        a, sc, ctx = self.a, self.scan_of(i), self.ctxs[w]
-        if H is not None:
-            pass   # enqueued ahead of time
-        elif a.mask_only:   # diagnostic: the PP score of the scan is computed once, steps run stages 2 + 3
-            if getattr(sc, "_H", None) is None:
-                sc._H = self.pp(sc, ctx)
-            H = sc._H
+        """One scan through the pipeline on thread w (a chain of one).  Returns (H, labels, objs, text)."""
+        return self.steps([i], w, [H], after)[0]
+
+    def steps(self, js, w, Hs, after=None):
+        """The scans of one chain through the pipeline on thread w.  Hs: their PP scores when they were enqueued ahead
+        of time (None: computed here); the mask stage of the chain is ONE library call (generate_mask_chain: the mask /
+        graph / DBSCAN block and the cluster statistics as one launch per kernel for all of them), boxes and labels go
+        scan by scan; after: called (same stream, same context) as soon as the LAST scan has no device work left, i.e.
+        under the host tail of its label stage -- the worker enqueues the PP stage of its next chain there.
+        Returns [(H, labels, objs, text)]."""
+        a, ctx = self.a, self.ctxs[w]
+        scs = [self.scan_of(i) for i in js]
+        Hs = list(Hs)
+        if a.mask_only:   # diagnostic: the PP score of a scan is computed once, steps run stages 2 + 3
+            for q, sc in enumerate(scs):
+                if getattr(sc, "_H", None) is None:
+                    sc._H = self.pp(sc, ctx)
+                Hs[q] = sc._H
         else:
-            H = self.pp_many([sc], w)[0]
+            todo = [q for q, H in enumerate(Hs) if H is None]
+            if todo:
+                for q, H in zip(todo, self.pp_many([scs[q] for q in todo], w)):
+                    Hs[q] = H
         if a.pp_only:
-            return H, None, None, None
-        pp_host = H.cpu().numpy()
+            return [(H, None, None, None) for H in Hs]
         # boxes stay (k,8) rows between the stages: the SimpleNamespace objects of the reference exist for its
         # pickle files, which the CLIs write and this in-memory pipeline does not
-        labels, objs, _ = self._generate_mask_scan(sc.live_host, pp_host, sc.calib, self.margs,
-                                                   random_state=np.random.RandomState(i), ptc_dev=sc.live_raw, pp_dev=H,
-                                                   as_rows=True)
-        text, kept = self._gen_label_scan(objs, sc.calib, self.largs, after_device=after)
-        return H, labels, objs, text
+        items = [dict(ptc=sc.live_host, pp_score=H.cpu().numpy(), random_state=np.random.RandomState(i), ptc_dev=sc.live_raw,
+                      pp_dev=H) for i, sc, H in zip(js, scs, Hs)]
+        if len(items) > 1 and not a.no_mask_chain:
+            res = self._generate_mask_chain(items, scs[0].calib, self.margs, as_rows=True, ctxs=self.chain_ctxs[w][:len(items)])
+        else:
+            res = [self._generate_mask_scan(it["ptc"], it["pp_score"], scs[0].calib, self.margs, random_state=it["random_state"],
+                                            ptc_dev=it["ptc_dev"], pp_dev=it["pp_dev"], as_rows=True) for it in items]
+        out = []
+        for q, (H, (labels, objs, _)) in enumerate(zip(Hs, res)):
+            text, kept = self._gen_label_scan(objs, scs[q].calib, self.largs, after_device=after if q == len(res) - 1 else None)
+            out.append((H, labels, objs, text))
+        return out
 
     def run(self, lo, hi):
         """steps lo..hi-1, dealt round-robin to the worker threads"""
@@ -338,15 +359,13 @@ class Runner:
                         js = idx[k0:end_of[k0]]
                         Hq.update(zip(js, self.pp_many([self.scan_of(j) for j in js], w)))
 
-                    for k, i in enumerate(idx):
-                        if self.a.mask_only:
-                            self.step(i, w)
-                            continue
-                        if i not in Hq:
-                            enqueue(k)
-                        last = end_of[k] == k + 1   # last step of its chain: the next chain goes out under its label tail
-                        hook = (lambda k1=k + 1: enqueue(k1)) if (self.prefetch and last and k + 1 < len(idx)) else None
-                        self.step(i, w, H=Hq.pop(i), after=hook)
+                    for c0, c1 in zip(cuts[:-1], cuts[1:]):
+                        js = idx[c0:c1]
+                        if not self.a.mask_only and js[0] not in Hq:
+                            enqueue(c0)
+                        # the next chain's PP stage goes out under the label tail of this chain's last scan
+                        hook = (lambda k1=c1: enqueue(k1)) if (self.prefetch and c1 < len(idx)) else None
+                        self.steps(js, w, [Hq.pop(j, None) for j in js], after=hook)
                     self.streams[w].synchronize()
             except Exception as e:   # surfaced after join
                 errs.append(e)

@@ -6,7 +6,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 python - <<'PY'
 import csv
 rows = list(csv.DictReader(open('gpurun_out/prof_mask/m_kernel_stats.csv')))
-ns = sum(int(r['Calls']) for r in rows if 'mask_count_kernel' in r['Name'])
+import os
+B = int(os.environ.get('PP_BATCH', '4'))   # scans per chain (bench.py --pp-batch)
+ns = sum(int(r['Calls']) for r in rows if 'mask_count_kernel' in r['Name']) + B * sum(int(r['Calls']) for r in rows if 'mcb_mask_count' in r['Name'])
 tot, nl = 0.0, 0
 for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs'])):
     if any(k in r['Name'] for k in ('ppb_', 'pp3_', 'pp_', 'frame_sort')):
