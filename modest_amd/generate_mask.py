@@ -244,20 +244,38 @@ def main(args):
     seed = int(args.get("ransac_seed", 0))
     t0, done = time.perf_counter(), 0
     dist.barrier()
+    # mask_batch scans go through the stage as ONE chain of kernel launches (generate_mask_chain); the reads of a
+    # chain precede its device work, outputs are written scan by scan
+    n_batch = max(1, int(args.get("mask_batch", 4)))
+    pend = []
+
+    def flush():
+        if not pend:
+            return
+        if len(pend) == 1:
+            q = pend[0]
+            res = [generate_mask_scan(q["ptc"], q["pp_score"], q["calib"], args, random_state=q["random_state"])]
+        else:
+            res = generate_mask_chain(pend, [q["calib"] for q in pend], args)
+        for q, (labels, objs, _) in zip(pend, res):
+            if bbox_dst is not None:
+                pickle.dump(objs, open(osp.join(bbox_dst, f"{q['idx']:06d}.pkl"), "wb"))
+            np.save(osp.join(dp.seg_save_dst, f"{q['idx']:06d}.npy"), labels)
+        pend.clear()
+
     for idx in shard:
         idx = int(idx)
         if osp.exists(osp.join(dp.seg_save_dst, f"{idx:06d}.npy")) and \
                 (bbox_dst is None or osp.exists(osp.join(bbox_dst, f"{idx:06d}.pkl"))):
             continue
-        ptc = load_velo_scan(osp.join(args.ptc_path, f"{idx:06d}.bin"))
-        pp_score = np.load(osp.join(dp.pp_score_path, f"{idx:06d}.npy"))
-        calib = kitti_util.Calibration(osp.join(args.calib_path, f"{idx:06d}.txt"))
-        labels, objs, _ = generate_mask_scan(ptc, pp_score, calib, args,
-                                             random_state=np.random.RandomState(seed + idx))
-        if bbox_dst is not None:
-            pickle.dump(objs, open(osp.join(bbox_dst, f"{idx:06d}.pkl"), "wb"))
-        np.save(osp.join(dp.seg_save_dst, f"{idx:06d}.npy"), labels)
+        pend.append(dict(idx=idx, ptc=load_velo_scan(osp.join(args.ptc_path, f"{idx:06d}.bin")),
+                         pp_score=np.load(osp.join(dp.pp_score_path, f"{idx:06d}.npy")),
+                         calib=kitti_util.Calibration(osp.join(args.calib_path, f"{idx:06d}.txt")),
+                         random_state=np.random.RandomState(seed + idx)))
         done += 1
+        if len(pend) >= n_batch:
+            flush()
+    flush()
     torch.cuda.synchronize()
     tot = dist.rank_report("generate_mask", done, t0, rank, ws)
     if rank == 0:

@@ -80,6 +80,17 @@ def test_three_clis_two_ranks_one_gpu(gpu, tmp_path):
                                       busy_seconds=[float(mm.group(3)), float(mm.group(4))], imbalance_percent=float(mm.group(5)))
     for k in ("two", "parts", "queue"):
         _same_tree(outs["one"], outs[k])
+    # scans per chain of launches of the mask stage (mask_batch, default 4) do not change a label or box file
+    for nb in (1, 5):
+        o = str(tmp_path / f"mbatch{nb}")
+        ov = _overrides(train, paths, o)
+        ov = [x if not x.startswith("data_paths.pp_score_path=") else f"data_paths.pp_score_path={outs['one']}/pp" for x in ov]
+        _run(CLIS[1], ov + [f"mask_batch={nb}"], 1, 0)
+        for sub in ("seg", "bbox"):
+            fa = sorted(f for f in os.listdir(os.path.join(o, sub)) if f != "configs.yaml")
+            assert len(fa) == N_SCANS
+            match, mismatch, err = filecmp.cmpfiles(os.path.join(outs["one"], sub), os.path.join(o, sub), fa, shallow=False)
+            assert not mismatch and not err, (nb, sub, mismatch[:5], err[:5])
     # scans per chain of launches (pp_batch, default 4) do not change a score file
     for nb in (1, 7):
         o = str(tmp_path / f"batch{nb}")
