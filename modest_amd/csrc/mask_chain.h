@@ -38,3 +38,9 @@ struct modest_stats_chain_scan {
     double *out_host;        // (n_clusters, 6)
 };
 int modest_cluster_stats_chain(modest_stats_chain_scan *S, int B, double quantile, hipStream_t stream);
+
+// candidates + MAD thresholds of both fits for every scan of a chain (plane.hip): one synchronise; n_cand2_host /
+// mad2_host: 2 entries per scan
+int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts, const int *n, const int *stride, int B,
+                               const float *specs10, float *const *candA, float *const *candB, int32_t *n_cand2_host,
+                               float *mad2_host, hipStream_t stream);

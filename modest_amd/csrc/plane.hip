@@ -246,7 +246,7 @@ __device__ __forceinline__ float median_np(const KS &K, int n, MadShared &S) {
 
 // up to MAD_SETS candidate sets per launch, one workgroup (= one CU) each: the two ground-plane fits
 // of a scan get their thresholds from one launch, side by side
-constexpr int MAD_SETS = 4;
+constexpr int MAD_SETS = 16;   // (the two sets of every scan of a chain of 8 in one launch)
 struct MadArgs {
     const float *cand[MAD_SETS];
     int n[MAD_SETS];
@@ -663,6 +663,61 @@ extern "C" int modest_plane_prepare(modest_ctx *ctx, const float *pts, int n, in
     return MODEST_OK;
 }
 
+// modest_plane_prepare for a chain of scans: every scan's selection is its own launch in its own context, the 2 B MAD
+// thresholds come from ONE launch (a workgroup per set, up to MAD_SETS sets) and one synchronise
+int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts, const int *n, const int *stride, int B,
+                               const float *specs10, float *const *candA, float *const *candB, int32_t *n_cand2_host,
+                               float *mad2_host, hipStream_t stream) {
+    MODEST_REQUIRE(ctxs && pts && n && stride && specs10 && candA && candB && n_cand2_host && mad2_host && B >= 1, "bad chain");
+    CandSpec SA{specs10[0], specs10[1], specs10[2], specs10[3], specs10[4]};
+    CandSpec SB{specs10[5], specs10[6], specs10[7], specs10[8], specs10[9]};
+    MadArgs M{};
+    int used = 0;
+    for (int s = 0; s < B; ++s) {
+        modest_ctx *ctx = ctxs[s];
+        MODEST_REQUIRE(ctx && pts[s] && candA[s] && candB[s] && n[s] >= 1, "bad scan of the chain");
+        int rc = modest_ctx_reserve_pinned(ctx, 64);
+        if (rc) return rc;
+        const int nblk = (n[s] + 1023) / 1024;
+        unsigned long long *state = nullptr;
+        rc = modest_ctx_compact_state(ctx, 2 * (size_t)nblk + 2, stream, &state);
+        if (rc) return rc;
+        rc = modest_ctx_reserve(ctx, 256);
+        if (rc) return rc;
+        int *d_n = reinterpret_cast<int *>(ctx->scratch);
+        int *h_n = reinterpret_cast<int *>(ctx->pinned);
+        float *h_mad = reinterpret_cast<float *>(ctx->pinned + 16);
+        candidates2_kernel<<<nblk, 1024, 0, stream>>>(pts[s], n[s], stride[s], SA, SB, candA[s], candB[s], state,
+                                                      state + 2 + nblk, d_n);
+        if (used + 2 > MAD_SETS) {
+            mad_kernel<<<used, 1024, 0, stream>>>(M);
+            M = MadArgs{};
+            used = 0;
+        }
+        M.cand[used] = candA[s];
+        M.cand[used + 1] = candB[s];
+        M.n_dev[used] = d_n;
+        M.n_dev[used + 1] = d_n + 1;
+        M.n_host[used] = h_n;
+        M.n_host[used + 1] = h_n + 1;
+        M.out[used] = h_mad;
+        M.out[used + 1] = h_mad + 2;
+        used += 2;
+    }
+    if (used) mad_kernel<<<used, 1024, 0, stream>>>(M);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int s = 0; s < B; ++s) {
+        const int *h_n = reinterpret_cast<const int *>(ctxs[s]->pinned);
+        const float *h_mad = reinterpret_cast<const float *>(ctxs[s]->pinned + 16);
+        n_cand2_host[2 * s] = h_n[0];
+        n_cand2_host[2 * s + 1] = h_n[1];
+        mad2_host[2 * s] = h_mad[1];
+        mad2_host[2 * s + 1] = h_mad[3];
+    }
+    return MODEST_OK;
+}
+
 extern "C" int modest_mad_threshold(modest_ctx *ctx, const float *cand, int n_cand, float *mad_host,
                                     void *stream_) {
     MODEST_REQUIRE(ctx != nullptr && mad_host != nullptr, "NULL argument");
@@ -688,7 +743,7 @@ extern "C" int modest_mad_threshold(modest_ctx *ctx, const float *cand, int n_ca
 extern "C" int modest_mad_threshold_batch(modest_ctx *ctx, const float *const *cand, const int32_t *n_cand,
                                           int count, float *mad_host, void *stream_) {
     MODEST_REQUIRE(ctx != nullptr && cand != nullptr && n_cand != nullptr && mad_host != nullptr, "NULL argument");
-    MODEST_REQUIRE(count >= 1 && count <= MAD_SETS, "1..4 candidate sets per call");
+    MODEST_REQUIRE(count >= 1 && count <= 4, "1..4 candidate sets per call");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     int rc = modest_ctx_reserve_pinned(ctx, 64);

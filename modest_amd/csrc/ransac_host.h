@@ -96,6 +96,7 @@ struct RansacFit {
     int n_best = 1, n_trials = 0, nb = 0;
     double score_best = -INFINITY, limit = 100.0;
     bool have = false;
+    bool pending = false;   // a batch is in flight (drivers that keep several fits going: scan_driver.hip)
     float best[3] = {0, 0, 0};
     Mt19937 before;
     std::vector<int32_t> trip, n_in;

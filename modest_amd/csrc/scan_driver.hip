@@ -213,7 +213,15 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
     std::vector<Run> R((size_t)n_scans);
     for (int s = 0; s < n_scans; ++s)
         for (int k = s + 1; k < n_scans; ++k) MODEST_REQUIRE(scans[s].ctx != scans[k].ctx, "every scan of a chain needs its own context");
-    // 1 + 2 per scan: candidates, thresholds, both trial loops; the second refit stays in flight
+    // 1. candidates + thresholds of both fits of every scan: one launch per selection, ONE for all thresholds
+    const float specs[10] = {P->max_hs1, P->range1[0], P->range1[1], P->range1[2], P->range1[3],
+                             P->max_hs2, P->range2[0], P->range2[1], P->range2[2], P->range2[3]};
+    std::vector<modest_ctx *> ctxs((size_t)n_scans);
+    std::vector<const float *> ptsv((size_t)n_scans);
+    std::vector<int> nv((size_t)n_scans), sv((size_t)n_scans);
+    std::vector<float *> cA((size_t)n_scans), cB((size_t)n_scans);
+    std::vector<int32_t> n_cand((size_t)2 * n_scans);
+    std::vector<float> mad((size_t)2 * n_scans);
     for (int s = 0; s < n_scans; ++s) {
         const modest_mask_stage_scan &q = scans[s];
         Run &r = R[(size_t)s];
@@ -225,61 +233,124 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         const size_t b_cand = arena_sz((size_t)q.n * 12), b_lab = arena_sz((size_t)q.n * 4);
         int rc = modest_ctx_reserve_hold(ctx, 2 * b_cand + b_lab, b_lab);
         if (rc) return rc;
-        float *candA = reinterpret_cast<float *>(ctx->hold), *candB = reinterpret_cast<float *>(ctx->hold + b_cand);
+        rc = modest_ctx_reserve_pinned(ctx, 16384);   // sized once: growing it between an enqueue and its read-back would free results
+        if (rc) return rc;
+        cA[(size_t)s] = reinterpret_cast<float *>(ctx->hold);
+        cB[(size_t)s] = reinterpret_cast<float *>(ctx->hold + b_cand);
         r.labels_dev = reinterpret_cast<int32_t *>(ctx->hold + 2 * b_cand);
         r.labels_h = reinterpret_cast<int32_t *>(ctx->hold_pinned);
-        const float specs[10] = {P->max_hs1, P->range1[0], P->range1[1], P->range1[2], P->range1[3],
-                                 P->max_hs2, P->range2[0], P->range2[1], P->range2[2], P->range2[3]};
-        int32_t n_cand[2];
-        float mad[2];
-        rc = modest_plane_prepare(ctx, q.pts_dev, q.n, q.stride, specs, candA, candB, n_cand, mad, stream_);
+        ctxs[(size_t)s] = ctx;
+        ptsv[(size_t)s] = q.pts_dev;
+        nv[(size_t)s] = q.n;
+        sv[(size_t)s] = q.stride;
+    }
+    {
+        int rc = modest_plane_prepare_chain(ctxs.data(), ptsv.data(), nv.data(), sv.data(), n_scans, specs, cA.data(), cB.data(),
+                                            n_cand.data(), mad.data(), stream);
         if (rc) return rc;
-        q.info_out[4] = n_cand[0];
-        q.info_out[5] = n_cand[1];
-        if (n_cand[0] <= 300 || n_cand[1] <= 300) {
+    }
+    // 2. the trial loops of all scans in lockstep: every round trip carries one batch (or refit) of every scan that
+    //    still needs one.  A scan's own generator is drawn from in the reference's order (fit A, then fit B).
+    std::vector<char> inA((size_t)n_scans, 0), inB((size_t)n_scans, 0);
+    for (int s = 0; s < n_scans; ++s) {
+        const modest_mask_stage_scan &q = scans[s];
+        Run &r = R[(size_t)s];
+        q.info_out[4] = n_cand[(size_t)2 * s];
+        q.info_out[5] = n_cand[(size_t)2 * s + 1];
+        if (n_cand[(size_t)2 * s] <= 300 || n_cand[(size_t)2 * s + 1] <= 300) {
             q.info_out[3] = MODEST_STAGE_SMALL_SET;
             continue;
         }
-        rc = modest_ctx_reserve_pinned(ctx, 16384);
-        if (rc) return rc;
         memcpy(r.g.key, q.mt_key624, sizeof(r.g.key));
         r.g.pos = *q.mt_pos;
-        r.A.init(ctx, candA, n_cand[0], mad[0], &r.g, P->max_trials, P->stop_probability, P->batch, stream_);
-        r.B.init(ctx, candB, n_cand[1], mad[1], &r.g, P->max_trials, P->stop_probability, P->batch, stream_);
-        while (!r.A.done()) {
-            if ((rc = r.A.enqueue_batch())) return rc;
-            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-            if ((rc = r.A.finish_batch())) return rc;
-        }
-        q.info_out[6] = r.A.n_trials;
-        if (!r.A.have) {
-            q.info_out[3] = MODEST_STAGE_NO_CONSENSUS;
-            continue;
-        }
-        if ((rc = r.A.enqueue_refit())) return rc;
-        if ((rc = r.B.enqueue_batch())) return rc;
+        r.A.init(q.ctx, cA[(size_t)s], n_cand[(size_t)2 * s], mad[(size_t)2 * s], &r.g, P->max_trials, P->stop_probability, P->batch, stream_);
+        r.B.init(q.ctx, cB[(size_t)s], n_cand[(size_t)2 * s + 1], mad[(size_t)2 * s + 1], &r.g, P->max_trials, P->stop_probability, P->batch,
+                 stream_);
+        inA[(size_t)s] = 1;
+    }
+    for (;;) {   // fit A
+        int active = 0;
+        for (int s = 0; s < n_scans; ++s)
+            if (inA[(size_t)s] && !R[(size_t)s].A.done()) {
+                int rc = R[(size_t)s].A.enqueue_batch();
+                if (rc) return rc;
+                R[(size_t)s].A.pending = true;
+                ++active;
+            }
+        if (!active) break;
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-        double model64[3];
-        int32_t n_in = 0;
-        bool degenerate = false;
-        if ((rc = r.A.finish_refit(model64, &n_in, &degenerate))) return rc;
-        if (degenerate) {
-            q.info_out[3] = MODEST_STAGE_DEGENERATE;
-            continue;
-        }
-        plane_from_model(model64, q.plane1_out);
-        if ((rc = r.B.finish_batch())) return rc;
-        while (!r.B.done()) {
+        for (int s = 0; s < n_scans; ++s)
+            if (inA[(size_t)s] && R[(size_t)s].A.pending) {
+                R[(size_t)s].A.pending = false;
+                int rc = R[(size_t)s].A.finish_batch();
+                if (rc) return rc;
+            }
+    }
+    {   // refit A + first batch of B
+        int active = 0;
+        for (int s = 0; s < n_scans; ++s) {
+            if (!inA[(size_t)s]) continue;
+            const modest_mask_stage_scan &q = scans[s];
+            Run &r = R[(size_t)s];
+            q.info_out[6] = r.A.n_trials;
+            if (!r.A.have) {
+                q.info_out[3] = MODEST_STAGE_NO_CONSENSUS;
+                continue;
+            }
+            int rc = r.A.enqueue_refit();
+            if (rc) return rc;
             if ((rc = r.B.enqueue_batch())) return rc;
-            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+            inB[(size_t)s] = 1;
+            ++active;
+        }
+        if (active) MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int s = 0; s < n_scans; ++s) {
+            if (!inB[(size_t)s]) continue;
+            const modest_mask_stage_scan &q = scans[s];
+            Run &r = R[(size_t)s];
+            double model64[3];
+            int32_t n_in = 0;
+            bool degenerate = false;
+            int rc = r.A.finish_refit(model64, &n_in, &degenerate);
+            if (rc) return rc;
+            if (degenerate) {
+                q.info_out[3] = MODEST_STAGE_DEGENERATE;
+                inB[(size_t)s] = 0;
+                continue;
+            }
+            plane_from_model(model64, q.plane1_out);
             if ((rc = r.B.finish_batch())) return rc;
         }
+    }
+    for (;;) {   // the rest of fit B
+        int active = 0;
+        for (int s = 0; s < n_scans; ++s)
+            if (inB[(size_t)s] && !R[(size_t)s].B.done()) {
+                int rc = R[(size_t)s].B.enqueue_batch();
+                if (rc) return rc;
+                R[(size_t)s].B.pending = true;
+                ++active;
+            }
+        if (!active) break;
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int s = 0; s < n_scans; ++s)
+            if (inB[(size_t)s] && R[(size_t)s].B.pending) {
+                R[(size_t)s].B.pending = false;
+                int rc = R[(size_t)s].B.finish_batch();
+                if (rc) return rc;
+            }
+    }
+    for (int s = 0; s < n_scans; ++s) {   // the second refit stays in flight: it rides along with the mask kernel
+        if (!inB[(size_t)s]) continue;
+        const modest_mask_stage_scan &q = scans[s];
+        Run &r = R[(size_t)s];
         q.info_out[7] = r.B.n_trials;
         if (!r.B.have) {
             q.info_out[3] = MODEST_STAGE_NO_CONSENSUS;
             continue;
         }
-        if ((rc = r.B.enqueue_refit())) return rc;
+        int rc = r.B.enqueue_refit();
+        if (rc) return rc;
         r.alive = true;
     }
     // 3. the mask kernel of every scan that got this far, one launch
