@@ -428,6 +428,20 @@ typedef struct modest_boxes_params {
 int modest_scan_boxes(modest_ctx *ctx, const float *pts_dev, const float *pts_host, int n, int stride,
                       int64_t *labels_inout_host, int n_lab, const modest_boxes_params *params,
                       double *objs_out_host, int32_t *keep_out_host, int32_t *info_out_host, void *stream);
+/* The same for a CHAIN of scans: the host phases per scan, ONE closeness launch over all clusters of the chain and ONE
+ * lowest-point launch over all boxes (two round trips per chain instead of two per scan).  Every scan in its own
+ * context; arguments per scan as above.  info_out[1] == 1 on every scan when some cluster of the chain is too large
+ * for the extents kernel (go scan by scan then).  Results are those of separate calls.  Blocking.               */
+typedef struct modest_boxes_scan {
+    modest_ctx *ctx;
+    const float *pts_dev, *pts_host;
+    int32_t n, stride;
+    int64_t *labels_inout;
+    int32_t n_lab;
+    double *objs_out;
+    int32_t *keep_out, *info_out;
+} modest_boxes_scan;
+int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_scans, const modest_boxes_params *params, void *stream);
 /* objs_nms' boxes [t0, t2, 0, l, w, h, -ry] as float32 (pointcloud_utils.py:322-324) and their BEV IoU
  * matrix (iou3d_nms_utils.boxes_iou_bev) -> iou_out [host] (k,k) float32.  Blocking.                  */
 int modest_objs_iou(modest_ctx *ctx, const double *objs8_host, int k, float *iou_out_host, void *stream);

@@ -613,11 +613,20 @@ struct Box6 {
 // combines the LOW_SPLIT partial maxima and writes the result to pinned host memory.  The box
 // table is read from pinned host memory as well: no copy or memset launches around the kernel.
 constexpr int LOW_SPLIT = 8;
+struct BoxSrc {   // boxes of several scans in one launch: the points a box looks at
+    const double *pts;
+    long long n;
+};
 __global__ __launch_bounds__(1024) void lowest_kernel(const double *__restrict__ pts, int n,
                                                       const Box6 *__restrict__ boxes, int n_boxes,
                                                       double *__restrict__ partial, unsigned *tickets,
-                                                      double *__restrict__ out_host) {
+                                                      double *__restrict__ out_host,
+                                                      const BoxSrc *__restrict__ src = nullptr) {
     const Box6 b = boxes[blockIdx.y];
+    if (src) {
+        pts = src[blockIdx.y].pts;
+        n = (int)src[blockIdx.y].n;
+    }
     const double hl = b.l / 2, hw = b.w / 2, ns = -b.s;
     double best = -INFINITY;
     for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += LOW_SPLIT * 1024) {
@@ -823,6 +832,43 @@ extern "C" int modest_fit_boxes_pca(modest_ctx *ctx, const double *pts_xz, const
     MODEST_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)n_clusters * 64, hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     for (size_t i = 0; i < (size_t)n_clusters * 8; ++i) out8_host[i] = h_out[i];
+    return MODEST_OK;
+}
+
+// the lowest point inside each of n_boxes footprints whose points are different arrays (the boxes of a chain of
+// scans): pts_rect[k] / n_pts[k] of box k; one launch, one synchronise
+int modest_lowest_point_multi(modest_ctx *ctx, const double *const *pts_rect, const int *n_pts, const double *boxes6_host,
+                              int n_boxes, double *bottom_host, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && n_boxes >= 0, "bad arguments");
+    if (n_boxes == 0) return MODEST_OK;
+    MODEST_REQUIRE(pts_rect && n_pts && boxes6_host && bottom_host, "NULL buffer");
+    MODEST_REQUIRE(n_boxes <= (int)MODEST_ZW_TICKETS, "too many boxes for one launch");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t b_box = arena_sz((size_t)n_boxes * sizeof(Box6)), b_out = arena_sz((size_t)n_boxes * 8);
+    const size_t b_src = arena_sz((size_t)n_boxes * sizeof(BoxSrc));
+    int rc = modest_ctx_reserve(ctx, arena_sz((size_t)n_boxes * LOW_SPLIT * 8));
+    if (rc) return rc;
+    rc = modest_ctx_reserve_pinned(ctx, b_box + b_out + b_src);
+    if (rc) return rc;
+    double *d_part = reinterpret_cast<double *>(ctx->scratch);
+    Box6 *h_box = reinterpret_cast<Box6 *>(ctx->pinned);
+    double *h_out = reinterpret_cast<double *>(ctx->pinned + b_box);
+    BoxSrc *h_src = reinterpret_cast<BoxSrc *>(ctx->pinned + b_box + b_out);
+    memcpy(h_box, boxes6_host, (size_t)n_boxes * sizeof(Box6));
+    for (int i = 0; i < n_boxes; ++i) {
+        MODEST_REQUIRE(n_pts[i] >= 1 && pts_rect[i], "a box without points to look at");
+        h_src[i].pts = pts_rect[i];
+        h_src[i].n = n_pts[i];
+    }
+    unsigned *zw = nullptr;
+    rc = modest_ctx_zero_words(ctx, stream, &zw);
+    if (rc) return rc;
+    lowest_kernel<<<dim3(LOW_SPLIT, n_boxes), 1024, 0, stream>>>(nullptr, 0, h_box, n_boxes, d_part, modest_tickets(zw), h_out,
+                                                                h_src);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_boxes; ++i) bottom_host[i] = h_out[i];
     return MODEST_OK;
 }
 

@@ -44,3 +44,7 @@ int modest_cluster_stats_chain(modest_stats_chain_scan *S, int B, double quantil
 int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts, const int *n, const int *stride, int B,
                                const float *specs10, float *const *candA, float *const *candB, int32_t *n_cand2_host,
                                float *mad2_host, hipStream_t stream);
+
+// lowest point inside each box footprint, boxes of several scans in one launch (boxfit.hip)
+int modest_lowest_point_multi(modest_ctx *ctx, const double *const *pts_rect, const int *n_pts, const double *boxes6_host,
+                              int n_boxes, double *bottom_host, void *stream);

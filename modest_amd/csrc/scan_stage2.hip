@@ -22,6 +22,7 @@
 // output with the Python statement (exact on the test scans; the contract of the existing tests is 1e-9 on
 // box values, identical decisions, byte-identical label text).
 #include "common.h"
+#include "mask_chain.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -53,65 +54,81 @@ inline void velo_to_rect(const float *p, const double *V2C, const double *R0, do
 
 }  // namespace
 
-extern "C" int modest_scan_boxes(modest_ctx *ctx, const float *pts_dev, const float *pts_host, int n, int stride,
-                                 int64_t *labels_inout, int n_lab, const modest_boxes_params *P, double *objs_out,
-                                 int32_t *keep_out, int32_t *info_out, void *stream_) {
-    MODEST_REQUIRE(ctx && pts_dev && pts_host && labels_inout && P && objs_out && keep_out && info_out, "NULL argument");
-    MODEST_REQUIRE(n >= 1 && (stride == 3 || stride == 4) && n_lab >= 0, "bad scan");
-    MODEST_REQUIRE(P->angles && P->cossin && P->cossin90 && P->n_angles >= 1, "angle tables missing");
-    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    info_out[0] = info_out[1] = 0;
-    // ---- members_sorted (clustering_utils): the members of labels 1..n_lab, ascending indices inside a label
-    std::vector<int32_t> off((size_t)n_lab + 2, 0);
-    bool any_zero = false;
+namespace {
+// modest_scan_boxes in three host phases around the two device steps, so that a chain of scans can share the device
+// steps (one closeness launch over all clusters of the chain, one lowest-point launch over all boxes)
+struct BoxRun {
+    // inputs
+    modest_ctx *ctx = nullptr;
+    const float *pts_dev = nullptr, *pts_host = nullptr;
+    int n = 0, stride = 0, n_lab = 0;
+    int64_t *labels = nullptr;
+    double *objs_out = nullptr;
+    int32_t *keep_out = nullptr, *info_out = nullptr;
+    // state
+    bool any_zero = false, active = false;
+    int m = 0;
+    std::vector<int32_t> off, coff;
+    std::vector<double> xz, miny, boxes6, area, cx, cz;
+    double *rect_dev = nullptr;
+};
+
+// members_sorted (clustering_utils) + the members' rect-frame points; enqueues the scan's rect projection
+int boxes_begin(BoxRun &r, const modest_boxes_params *P, void *stream_) {
+    const int n = r.n, n_lab = r.n_lab, stride = r.stride;
+    r.info_out[0] = r.info_out[1] = 0;
+    r.off.assign((size_t)n_lab + 2, 0);
     for (int i = 0; i < n; ++i) {
-        const int64_t l = labels_inout[i];
+        const int64_t l = r.labels[i];
         MODEST_REQUIRE(l >= 0 && l <= n_lab, "label out of range");
-        if (l > 0) ++off[(size_t)l + 1];
-        else any_zero = true;
+        if (l > 0) ++r.off[(size_t)l + 1];
+        else r.any_zero = true;
     }
-    for (int c = 1; c <= n_lab + 1; ++c) off[(size_t)c] += off[(size_t)c - 1];   // off[c] = first member of label c, off[n_lab + 1] = total
-    const int m = off[(size_t)n_lab + 1];
+    for (int c = 1; c <= n_lab + 1; ++c) r.off[(size_t)c] += r.off[(size_t)c - 1];   // off[c] = first member of label c
+    r.m = r.off[(size_t)n_lab + 1];
     if (n_lab == 0) {   // compact_labels of an all-background scan
-        for (int i = 0; i < n; ++i) labels_inout[i] = 0;
+        for (int i = 0; i < n; ++i) r.labels[i] = 0;
         return MODEST_OK;
     }
-    for (int c = 1; c <= n_lab; ++c) MODEST_REQUIRE(off[(size_t)c + 1] > off[(size_t)c], "a label without members");
-    std::vector<double> xz((size_t)m * 2), miny((size_t)n_lab, INFINITY);
+    for (int c = 1; c <= n_lab; ++c) MODEST_REQUIRE(r.off[(size_t)c + 1] > r.off[(size_t)c], "a label without members");
+    r.xz.resize((size_t)r.m * 2);
+    r.miny.assign((size_t)n_lab, INFINITY);
     {
-        std::vector<int32_t> cur(off.begin(), off.end());
+        std::vector<int32_t> cur(r.off.begin(), r.off.end());
         for (int i = 0; i < n; ++i) {
-            const int64_t l = labels_inout[i];
+            const int64_t l = r.labels[i];
             if (l <= 0) continue;
-            double r[3];
-            velo_to_rect(pts_host + (size_t)i * stride, P->V2C, P->R0, r);
+            double q[3];
+            velo_to_rect(r.pts_host + (size_t)i * stride, P->V2C, P->R0, q);
             const int pos = cur[(size_t)l]++;
-            xz[2 * (size_t)pos] = r[0];
-            xz[2 * (size_t)pos + 1] = r[2];
-            miny[(size_t)l - 1] = std::min(miny[(size_t)l - 1], r[1]);   // ptc[:, 1].min() of get_obj
+            r.xz[2 * (size_t)pos] = q[0];
+            r.xz[2 * (size_t)pos + 1] = q[2];
+            r.miny[(size_t)l - 1] = std::min(r.miny[(size_t)l - 1], q[1]);   // ptc[:, 1].min() of get_obj
         }
     }
-    // ---- the whole scan in the rect frame on the device (the lowest-point search reads it), then the fit
-    int rc = modest_ctx_reserve_hold(ctx, arena_sz((size_t)n * 24), 0);
+    // the whole scan in the rect frame on the device (the lowest-point search reads it)
+    int rc = modest_ctx_reserve_hold(r.ctx, arena_sz((size_t)n * 24), 0);
     if (rc) return rc;
-    double *rect_dev = reinterpret_cast<double *>(ctx->hold);
-    rc = modest_project_velo_to_rect(ctx, pts_dev, n, stride, P->V2C, P->R0, rect_dev, stream_);
+    r.rect_dev = reinterpret_cast<double *>(r.ctx->hold);
+    rc = modest_project_velo_to_rect(r.ctx, r.pts_dev, n, stride, P->V2C, P->R0, r.rect_dev, stream_);
     if (rc) return rc;
-    std::vector<int32_t> best((size_t)n_lab), coff((size_t)n_lab + 1);
-    for (int c = 0; c <= n_lab; ++c) coff[(size_t)c] = off[(size_t)c + 1];
-    std::vector<double> ext((size_t)n_lab * 8);
-    rc = modest_fit_boxes_closeness_host(ctx, xz.data(), coff.data(), n_lab, P->cossin, P->n_angles, P->d0, best.data(),
-                                         P->cossin90, ext.data(), stream_);
-    if (rc) {   // a cluster too large for the extents kernel: the caller's host statement takes the scan
-        info_out[1] = 1;
-        return MODEST_OK;
-    }
-    // ---- rectangle_at_angle's tail + get_obj up to the lowest-point search
-    std::vector<double> boxes6((size_t)n_lab * 6), area((size_t)n_lab), cx((size_t)n_lab), cz((size_t)n_lab);
+    r.coff.resize((size_t)n_lab + 1);
+    for (int c = 0; c <= n_lab; ++c) r.coff[(size_t)c] = r.off[(size_t)c + 1];
+    r.active = true;
+    return MODEST_OK;
+}
+
+// rectangle_at_angle's tail + get_obj up to the lowest-point search; best / ext: this scan's clusters
+int boxes_tail(BoxRun &r, const modest_boxes_params *P, const int32_t *best, const double *ext) {
+    const int n_lab = r.n_lab;
+    r.boxes6.resize((size_t)n_lab * 6);
+    r.area.resize((size_t)n_lab);
+    r.cx.resize((size_t)n_lab);
+    r.cz.resize((size_t)n_lab);
     for (int c = 0; c < n_lab; ++c) {
-        const int b = best[(size_t)c];
+        const int b = best[c];
         MODEST_REQUIRE(b >= 0 && b < P->n_angles, "bad heading index");
-        const double *e = ext.data() + 8 * (size_t)c;
+        const double *e = ext + 8 * (size_t)c;
         double angle = P->angles[b], co = P->cossin[2 * b], si = P->cossin[2 * b + 1];
         double min_x = e[0], max_x = e[1], min_y = e[2], max_y = e[3];
         if ((max_x - min_x) < (max_y - min_y)) {
@@ -120,7 +137,7 @@ extern "C" int modest_scan_boxes(modest_ctx *ctx, const float *pts_dev, const fl
             si = P->cossin90[2 * b + 1];
             min_x = e[4], max_x = e[5], min_y = e[6], max_y = e[7];
         }
-        area[(size_t)c] = (max_x - min_x) * (max_y - min_y);
+        r.area[(size_t)c] = (max_x - min_x) * (max_y - min_y);
         // rval @ components, components = [[c, s], [-s, c]]
         const double rv[4][2] = {{max_x, min_y}, {min_x, min_y}, {min_x, max_y}, {max_x, max_y}};
         double cor[4][2];
@@ -132,48 +149,162 @@ extern "C" int modest_scan_boxes(modest_ctx *ctx, const float *pts_dev, const fl
         const double d01x = cor[0][0] - cor[1][0], d01y = cor[0][1] - cor[1][1];
         const double d03x = cor[0][0] - cor[3][0], d03y = cor[0][1] - cor[3][1];
         const double l = std::sqrt(dot2(d01x, d01x, d01y, d01y)), w = std::sqrt(dot2(d03x, d03x, d03y, d03y));
-        cx[(size_t)c] = (cor[0][0] + cor[2][0]) / 2;
-        cz[(size_t)c] = (cor[0][1] + cor[2][1]) / 2;
-        double *o = objs_out + 8 * (size_t)c;
+        r.cx[(size_t)c] = (cor[0][0] + cor[2][0]) / 2;
+        r.cz[(size_t)c] = (cor[0][1] + cor[2][1]) / 2;
+        double *o = r.objs_out + 8 * (size_t)c;
         o[3] = l;
         o[4] = w;
         o[6] = ry;
-        double *bx = boxes6.data() + 6 * (size_t)c;
-        bx[0] = cx[(size_t)c];
-        bx[1] = cz[(size_t)c];
+        double *bx = r.boxes6.data() + 6 * (size_t)c;
+        bx[0] = r.cx[(size_t)c];
+        bx[1] = r.cz[(size_t)c];
         bx[2] = l;
         bx[3] = w;
         bx[4] = co;    // cos(ry) = cos(-angle)
         bx[5] = -si;   // sin(ry)
     }
-    std::vector<double> bottom((size_t)n_lab);
-    rc = modest_lowest_point(ctx, rect_dev, n, boxes6.data(), n_lab, bottom.data(), stream_);
-    if (rc) return rc;
+    return MODEST_OK;
+}
+
+// get_obj's remaining fields, the volume gate and the relabelling (generate_mask.py:91-103)
+void boxes_finish(BoxRun &r, const modest_boxes_params *P, const double *bottom) {
+    const int n_lab = r.n_lab;
     for (int c = 0; c < n_lab; ++c)
-        if (std::isinf(bottom[(size_t)c])) {   // numpy raises on the empty maximum: the host statement reports it
-            info_out[1] = 2;
-            return MODEST_OK;
+        if (std::isinf(bottom[c])) {   // numpy raises on the empty maximum: the host statement reports it
+            r.info_out[1] = 2;
+            return;
         }
-    // ---- get_obj's remaining fields, the volume gate and the relabelling (generate_mask.py:91-103)
     int n_keep = 0;
     for (int c = 0; c < n_lab; ++c) {
-        double *o = objs_out + 8 * (size_t)c;
-        const double h = bottom[(size_t)c] - miny[(size_t)c];
-        o[0] = cx[(size_t)c];
-        o[1] = bottom[(size_t)c];
-        o[2] = cz[(size_t)c];
+        double *o = r.objs_out + 8 * (size_t)c;
+        const double h = bottom[c] - r.miny[(size_t)c];
+        o[0] = r.cx[(size_t)c];
+        o[1] = bottom[c];
+        o[2] = r.cz[(size_t)c];
         o[5] = h;
-        o[7] = area[(size_t)c] * h;
-        keep_out[c] = (o[7] > P->min_volume && o[7] < P->max_volume) ? 1 : 0;
-        n_keep += keep_out[c];
+        o[7] = r.area[(size_t)c] * h;
+        r.keep_out[c] = (o[7] > P->min_volume && o[7] < P->max_volume) ? 1 : 0;
+        n_keep += r.keep_out[c];
     }
-    const bool has_zero = n_keep != n_lab || any_zero;
+    const bool has_zero = n_keep != n_lab || r.any_zero;
     std::vector<int64_t> table((size_t)n_lab + 1, 0);
     int64_t next = has_zero ? 1 : 0;
     for (int c = 0; c < n_lab; ++c)
-        if (keep_out[c]) table[(size_t)c + 1] = next++;
-    for (int i = 0; i < n; ++i) labels_inout[i] = table[(size_t)labels_inout[i]];
-    info_out[0] = n_keep;
+        if (r.keep_out[c]) table[(size_t)c + 1] = next++;
+    for (int i = 0; i < r.n; ++i) r.labels[i] = table[(size_t)r.labels[i]];
+    r.info_out[0] = n_keep;
+}
+}  // namespace
+
+extern "C" int modest_scan_boxes(modest_ctx *ctx, const float *pts_dev, const float *pts_host, int n, int stride,
+                                 int64_t *labels_inout, int n_lab, const modest_boxes_params *P, double *objs_out,
+                                 int32_t *keep_out, int32_t *info_out, void *stream_) {
+    MODEST_REQUIRE(ctx && pts_dev && pts_host && labels_inout && P && objs_out && keep_out && info_out, "NULL argument");
+    MODEST_REQUIRE(n >= 1 && (stride == 3 || stride == 4) && n_lab >= 0, "bad scan");
+    MODEST_REQUIRE(P->angles && P->cossin && P->cossin90 && P->n_angles >= 1, "angle tables missing");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    BoxRun r;
+    r.ctx = ctx, r.pts_dev = pts_dev, r.pts_host = pts_host, r.n = n, r.stride = stride, r.n_lab = n_lab;
+    r.labels = labels_inout, r.objs_out = objs_out, r.keep_out = keep_out, r.info_out = info_out;
+    int rc = boxes_begin(r, P, stream_);
+    if (rc || !r.active) return rc;
+    std::vector<int32_t> best((size_t)n_lab);
+    std::vector<double> ext((size_t)n_lab * 8);
+    rc = modest_fit_boxes_closeness_host(ctx, r.xz.data(), r.coff.data(), n_lab, P->cossin, P->n_angles, P->d0, best.data(),
+                                         P->cossin90, ext.data(), stream_);
+    if (rc) {   // a cluster too large for the extents kernel: the caller's host statement takes the scan
+        info_out[1] = 1;
+        return MODEST_OK;
+    }
+    rc = boxes_tail(r, P, best.data(), ext.data());
+    if (rc) return rc;
+    std::vector<double> bottom((size_t)n_lab);
+    rc = modest_lowest_point(ctx, r.rect_dev, n, r.boxes6.data(), n_lab, bottom.data(), stream_);
+    if (rc) return rc;
+    boxes_finish(r, P, bottom.data());
+    return MODEST_OK;
+}
+
+// The same for a chain of scans: host phases per scan, ONE closeness launch over all clusters of the chain and ONE
+// lowest-point launch over all boxes (two round trips per chain).  Every scan in its own context (its rect-frame
+// copy lives there); the shared launches run in the first scan's.  Results are those of separate calls.
+extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_scans, const modest_boxes_params *P,
+                                       void *stream_) {
+    MODEST_REQUIRE(scans && P && n_scans >= 1 && n_scans <= 64, "bad chain");
+    MODEST_REQUIRE(P->angles && P->cossin && P->cossin90 && P->n_angles >= 1, "angle tables missing");
+    std::vector<BoxRun> R((size_t)n_scans);
+    int total_lab = 0, total_m = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const modest_boxes_scan &q = scans[s];
+        MODEST_REQUIRE(q.ctx && q.pts_dev && q.pts_host && q.labels_inout && q.objs_out && q.keep_out && q.info_out, "NULL argument");
+        MODEST_REQUIRE(q.n >= 1 && (q.stride == 3 || q.stride == 4) && q.n_lab >= 0, "bad scan");
+        for (int k = 0; k < s; ++k) MODEST_REQUIRE(scans[k].ctx != q.ctx, "every scan of a chain needs its own context");
+        MODEST_HIP_CHECK(hipSetDevice(q.ctx->device));
+        BoxRun &r = R[(size_t)s];
+        r.ctx = q.ctx, r.pts_dev = q.pts_dev, r.pts_host = q.pts_host, r.n = q.n, r.stride = q.stride, r.n_lab = q.n_lab;
+        r.labels = q.labels_inout, r.objs_out = q.objs_out, r.keep_out = q.keep_out, r.info_out = q.info_out;
+        int rc = boxes_begin(r, P, stream_);
+        if (rc) return rc;
+        if (r.active) {
+            total_lab += r.n_lab;
+            total_m += r.m;
+        }
+    }
+    if (total_lab == 0) return MODEST_OK;
+    // all clusters of the chain as one list
+    std::vector<double> xz((size_t)total_m * 2);
+    std::vector<int32_t> coff((size_t)total_lab + 1, 0), best((size_t)total_lab);
+    std::vector<double> ext((size_t)total_lab * 8);
+    {
+        int c0 = 0, m0 = 0;
+        for (BoxRun &r : R) {
+            if (!r.active) continue;
+            memcpy(xz.data() + 2 * (size_t)m0, r.xz.data(), (size_t)r.m * 16);
+            for (int c = 0; c <= r.n_lab; ++c) coff[(size_t)c0 + c] = m0 + r.coff[(size_t)c];
+            c0 += r.n_lab;
+            m0 += r.m;
+        }
+    }
+    modest_ctx *ctx0 = nullptr;
+    for (BoxRun &r : R)
+        if (r.active) {
+            ctx0 = r.ctx;
+            break;
+        }
+    int rc = modest_fit_boxes_closeness_host(ctx0, xz.data(), coff.data(), total_lab, P->cossin, P->n_angles, P->d0, best.data(),
+                                             P->cossin90, ext.data(), stream_);
+    if (rc) {   // a cluster too large for the extents kernel somewhere: every scan reports it, the caller goes scan by scan
+        for (BoxRun &r : R)
+            if (r.active) r.info_out[1] = 1;
+        return MODEST_OK;
+    }
+    std::vector<double> boxes6((size_t)total_lab * 6), bottom((size_t)total_lab);
+    std::vector<const double *> src((size_t)total_lab);
+    std::vector<int> nsrc((size_t)total_lab);
+    {
+        int c0 = 0;
+        for (BoxRun &r : R) {
+            if (!r.active) continue;
+            rc = boxes_tail(r, P, best.data() + c0, ext.data() + 8 * (size_t)c0);
+            if (rc) return rc;
+            memcpy(boxes6.data() + 6 * (size_t)c0, r.boxes6.data(), (size_t)r.n_lab * 48);
+            for (int c = 0; c < r.n_lab; ++c) {
+                src[(size_t)c0 + c] = r.rect_dev;
+                nsrc[(size_t)c0 + c] = r.n;
+            }
+            c0 += r.n_lab;
+        }
+    }
+    rc = modest_lowest_point_multi(ctx0, src.data(), nsrc.data(), boxes6.data(), total_lab, bottom.data(), stream_);
+    if (rc) return rc;
+    {
+        int c0 = 0;
+        for (BoxRun &r : R) {
+            if (!r.active) continue;
+            boxes_finish(r, P, bottom.data() + c0);
+            c0 += r.n_lab;
+        }
+    }
     return MODEST_OK;
 }
 

@@ -52,7 +52,7 @@ _UNSET = object()
 
 
 def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=None, ptc_dev=None,
-                       pp_dev=None, as_rows=False, staged=_UNSET):
+                       pp_dev=None, as_rows=False, staged=_UNSET, boxed=_UNSET):
     """The body of the reference's per-scan loop (generate_mask.py:52-103).
 
     ptc (N,4) float32 numpy, pp_score (N,) float32 numpy, calib a Calibration.
@@ -85,13 +85,15 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
         labels_filtered, plane, n_kept = _mask_stage_host(ptc, pp_score, args, random_state, planes, ptc_dev, pp_dev)
     n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
     lo, hi = args.filtering.min_volume, args.filtering.max_volume
-    if NATIVE_BOXES and n_lab and args.bbox_gen.fit_method == "closeness_to_edge" and ptc.dtype == np.float32 \
-            and ptc.flags.c_contiguous:
+    if boxed is not _UNSET or _native_boxes_ok(ptc, n_lab, args):
         # members, rect points, closeness fit, get_obj, volume gate and relabelling behind one library call
-        from .utils.pointcloud_utils import _angles, _angles90
-        ang, cs = _angles(0.1)
-        done = ops.scan_boxes(ptc_dev, ptc, labels_filtered, n_lab, calib.V2C, calib.R0, ang, cs, _angles90(0.1), 1e-2,
-                              lo, hi)
+        if boxed is not _UNSET:
+            done = boxed   # the box tail ran in a chain of scans (generate_mask_chain): its result, or None = host statement
+        else:
+            from .utils.pointcloud_utils import _angles, _angles90
+            ang, cs = _angles(0.1)
+            done = ops.scan_boxes(ptc_dev, ptc, labels_filtered, n_lab, calib.V2C, calib.R0, ang, cs, _angles90(0.1), 1e-2,
+                                  lo, hi)
         if done is not None:
             labels_final, rows, keep = done
             rows = rows[keep]
@@ -112,6 +114,11 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
     if as_rows:
         objs = np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs], dtype=np.float64).reshape(-1, 8)
     return labels_filtered, objs, dict(plane=plane, n_kept=n_kept, dbscan_kept=None)
+
+
+def _native_boxes_ok(ptc, n_lab, args) -> bool:
+    return bool(NATIVE_BOXES and n_lab and args.bbox_gen.fit_method == "closeness_to_edge" and ptc.dtype == np.float32
+                and ptc.flags.c_contiguous)
 
 
 def generate_mask_chain(scans, calib, args, as_rows=False, ctxs=None):
@@ -136,8 +143,29 @@ def generate_mask_chain(scans, calib, args, as_rows=False, ctxs=None):
         if len(items) > 1 and len({id(it[2]) for it in items}) == len(items):   # one generator per scan: no draw order between scans
             for i, res in zip(who, ops.mask_stage_batch(items, _stage_params(args), ctxs=ctxs)):
                 staged[i] = res
+    # the box tail of the chain: scans whose stage result is known here (the library's) and that share one calibration
+    boxed = [_UNSET] * len(scans)
+    cand = [i for i in range(len(scans)) if staged[i] is not _UNSET and staged[i] is not None]
+    if len(cand) > 1:
+        c0 = calibs[cand[0]]
+        same = [i for i in cand if np.array_equal(calibs[i].V2C, c0.V2C) and np.array_equal(calibs[i].R0, c0.R0)]
+        items, who = [], []
+        for i in same:
+            labels_filtered = staged[i][0]
+            n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
+            if _native_boxes_ok(scans[i]["ptc"], n_lab, args):
+                items.append((scans[i]["ptc_dev"], scans[i]["ptc"], labels_filtered, n_lab))
+                who.append(i)
+        if len(items) > 1:
+            from .utils.pointcloud_utils import _angles, _angles90
+            ang, cs = _angles(0.1)
+            res = ops.scan_boxes_batch(items, c0.V2C, c0.R0, ang, cs, _angles90(0.1), 1e-2, args.filtering.min_volume,
+                                       args.filtering.max_volume, ctxs=None if ctxs is None else [ctxs[i] for i in who])
+            for i, r in zip(who, res):
+                boxed[i] = r
     return [generate_mask_scan(sc["ptc"], sc["pp_score"], cb, args, random_state=sc.get("random_state"),
-                               ptc_dev=sc.get("ptc_dev"), pp_dev=sc.get("pp_dev"), as_rows=as_rows, staged=staged[i])
+                               ptc_dev=sc.get("ptc_dev"), pp_dev=sc.get("pp_dev"), as_rows=as_rows, staged=staged[i],
+                               boxed=boxed[i])
             for i, (sc, cb) in enumerate(zip(scans, calibs))]
 
 

@@ -527,6 +527,51 @@ def scan_boxes(pts_dev: torch.Tensor, pts_host: np.ndarray, labels_filtered: np.
     return labels, objs[:n_lab], keep[:n_lab].astype(bool)
 
 
+class BoxesScan(C.Structure):
+    """modest_boxes_scan (include/modest_hip.h)"""
+    _fields_ = [("ctx", C.c_void_p), ("pts_dev", C.c_void_p), ("pts_host", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32),
+                ("labels_inout", C.c_void_p), ("n_lab", C.c_int32), ("objs_out", C.c_void_p), ("keep_out", C.c_void_p),
+                ("info_out", C.c_void_p)]
+
+
+def scan_boxes_batch(items, V2C, R0, angles: np.ndarray, cossin: np.ndarray, cossin90: np.ndarray, d0: float,
+                     min_volume: float, max_volume: float, ctxs=None):
+    """modest_scan_boxes_batch: the box tail of a CHAIN of scans (one calibration) -- host phases per scan, one
+    closeness launch over all clusters, one lowest-point launch over all boxes.  items: [(pts_dev, pts_host,
+    labels_filtered, n_lab)]; returns per scan what scan_boxes returns (None: host statement)."""
+    lib = load()
+    B = len(items)
+    if B == 0:
+        return []
+    if ctxs is None:
+        ctxs = chain_contexts(B, items[0][0].device.index or 0)
+    P = BoxesParams()
+    P.V2C[:] = [float(x) for x in np.asarray(V2C, dtype=np.float64).reshape(12)]
+    P.R0[:] = [float(x) for x in np.asarray(R0, dtype=np.float64).reshape(9)]
+    assert angles.dtype == np.float64 and cossin.dtype == np.float64 and cossin90.dtype == np.float64
+    assert cossin.flags.c_contiguous and cossin90.flags.c_contiguous and angles.flags.c_contiguous
+    P.angles, P.cossin, P.cossin90, P.n_angles = _np_ptr(angles), _np_ptr(cossin), _np_ptr(cossin90), angles.shape[0]
+    P.d0, P.min_volume, P.max_volume = float(d0), float(min_volume), float(max_volume)
+    arr = (BoxesScan * B)()
+    keepalive = []
+    for i, (pts_dev, pts_host, labels_filtered, n_lab) in enumerate(items):
+        _dev(pts_dev, torch.float32, "pts")
+        assert pts_host.dtype == np.float32 and pts_host.flags.c_contiguous and pts_host.shape == tuple(pts_dev.shape)
+        labels = np.ascontiguousarray(labels_filtered, dtype=np.int64).copy()
+        objs = np.zeros((max(n_lab, 1), 8), dtype=np.float64)
+        keep = np.zeros(max(n_lab, 1), dtype=np.int32)
+        info = np.zeros(2, dtype=np.int32)
+        keepalive.append((labels, objs, keep, info, int(n_lab)))
+        a = arr[i]
+        a.ctx = C.cast(ctxs[i].handle, C.c_void_p).value
+        a.pts_dev, a.pts_host, a.n, a.stride = pts_dev.data_ptr(), _np_ptr(pts_host), pts_host.shape[0], pts_host.shape[1]
+        a.labels_inout, a.n_lab = _np_ptr(labels), int(n_lab)
+        a.objs_out, a.keep_out, a.info_out = _np_ptr(objs), _np_ptr(keep), _np_ptr(info)
+    check(lib.modest_scan_boxes_batch(C.byref(arr), B, C.byref(P), _stream()), "modest_scan_boxes_batch")
+    return [None if info[1] != 0 else (labels, objs[:n_lab], keep[:n_lab].astype(bool))
+            for labels, objs, keep, info, n_lab in keepalive]
+
+
 def objs_iou(objs8: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
     """BEV IoU matrix (k,k) float32 of objs_nms' float32 boxes (modest_objs_iou)."""
     lib = load()
