@@ -48,3 +48,9 @@ int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts,
 // lowest point inside each box footprint, boxes of several scans in one launch (boxfit.hip)
 int modest_lowest_point_multi(modest_ctx *ctx, const double *const *pts_rect, const int *n_pts, const double *boxes6_host,
                               int n_boxes, double *bottom_host, void *stream);
+
+// RANSAC launches of a chain (plane.hip): between begin and launch the enqueue halves of the trial / refit phases on
+// this thread are recorded; launch runs all recorded refits as ONE launch, then all recorded trial batches as ONE
+struct modest_ransac_capture;
+modest_ransac_capture *modest_ransac_capture_begin();
+int modest_ransac_capture_launch(modest_ctx *ctx0, modest_ransac_capture *cap, hipStream_t stream);

@@ -15,6 +15,7 @@
 #include "ransac_host.h"
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <cstring>
 #include <vector>
 
@@ -379,27 +380,27 @@ constexpr int SCORE_PPT = 4;
 constexpr int SCORE_PTS = SCORE_THREADS * SCORE_PPT;
 constexpr int SCORE_KG = 8;
 template <bool FUSED>
-__global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
+__device__ __forceinline__ void score_kernel_body(const float *__restrict__ cand, int n,
                                                               const float *__restrict__ models,
                                                               int K, const float *__restrict__ thr_ptr,
                                                               float thr_val /* used when thr_ptr is NULL */,
-                                                              double *partial, TripArg trip,
+                                                              double *partial, const TripArg &trip,
                                                               float *__restrict__ models_host, unsigned *ticket,
                                                               double *__restrict__ out /* K*4, may be pinned host memory */,
                                                               const float *__restrict__ thr_src,
-                                                              float *__restrict__ thr_dst) {
+                                                              float *__restrict__ thr_dst, const unsigned bx, const unsigned by, const unsigned gx, const unsigned gy) {
     __shared__ float sm[SCORE_KG][3];
     __shared__ double red[SCORE_WAVES][SCORE_KG][4];
     __shared__ unsigned last_s;
     if (FUSED) {   // the block fits its own SCORE_KG planes; the first block column reports them
-        const int k = blockIdx.y * SCORE_KG + (int)threadIdx.x;
+        const int k = by * SCORE_KG + (int)threadIdx.x;
         if (threadIdx.x < SCORE_KG && k < K) {
             float c0, c1, b;
             fit_triplet(cand, n, trip.t[3 * k], trip.t[3 * k + 1], trip.t[3 * k + 2], &c0, &c1, &b);
             sm[threadIdx.x][0] = c0;
             sm[threadIdx.x][1] = c1;
             sm[threadIdx.x][2] = b;
-            if (blockIdx.x == 0) {
+            if (bx == 0) {
                 models_host[3 * k] = c0;
                 models_host[3 * k + 1] = c1;
                 models_host[3 * k + 2] = b;
@@ -414,14 +415,14 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
 #pragma unroll
     for (int p = 0; p < SCORE_PPT; ++p) {
         // consecutive lanes take consecutive points, as the summation order has always been
-        const int i = blockIdx.x * SCORE_PTS + (w * SCORE_PPT + p) * 64 + lane;
+        const int i = bx * SCORE_PTS + (w * SCORE_PPT + p) * 64 + lane;
         valid[p] = i < n;
         x[p] = valid[p] ? cand[3 * (size_t)i] : 0.f;
         y[p] = valid[p] ? cand[3 * (size_t)i + 1] : 0.f;
         z[p] = valid[p] ? cand[3 * (size_t)i + 2] : 0.f;
     }
-    const int k0 = blockIdx.y * SCORE_KG, k1 = min(k0 + SCORE_KG, K);
-    double *row = partial + ((size_t)blockIdx.x * K) * 4;   // one row per block (the wavefronts combine in LDS)
+    const int k0 = by * SCORE_KG, k1 = min(k0 + SCORE_KG, K);
+    double *row = partial + ((size_t)bx * K) * 4;   // one row per block (the wavefronts combine in LDS)
     for (int k = k0; k < k1; ++k) {
         const float c0 = FUSED ? sm[k - k0][0] : models[3 * k], c1 = FUSED ? sm[k - k0][1] : models[3 * k + 1];
         const float b = FUSED ? sm[k - k0][2] : models[3 * k + 2];
@@ -461,10 +462,10 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
     // atomic stores (write-through), drained by the storing wavefronts before the barrier (common.h); the
     // last block reads them with agent-scope loads, eight in flight per thread.
     __syncthreads();
-    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gx * gy - 1 ? 1u : 0u;
     __syncthreads();
     if (!last_s) return;
-    const int nrows = gridDim.x;
+    const int nrows = gx;
     for (int id = threadIdx.x; id < K * 4; id += SCORE_THREADS) {
         double s = 0.0;
         for (int r0 = 0; r0 < nrows; r0 += 8) {
@@ -481,6 +482,19 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__res
     }
     if (threadIdx.x < 2 && thr_dst) thr_dst[threadIdx.x] = thr_src[threadIdx.x];
     if (threadIdx.x == 0) *ticket = 0u;
+}
+template <bool FUSED>
+__global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
+                                                              const float *__restrict__ models,
+                                                              int K, const float *__restrict__ thr_ptr,
+                                                              float thr_val /* used when thr_ptr is NULL */,
+                                                              double *partial, TripArg trip,
+                                                              float *__restrict__ models_host, unsigned *ticket,
+                                                              double *__restrict__ out /* K*4, may be pinned host memory */,
+                                                              const float *__restrict__ thr_src,
+                                                              float *__restrict__ thr_dst) {
+    score_kernel_body<FUSED>(cand, n, models, K, thr_ptr, thr_val, partial, trip, models_host, ticket, out, thr_src, thr_dst,
+                             blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // exact-fit plane z = c0 x + c1 y + b through the three candidates of every trial: float64,
@@ -509,13 +523,13 @@ __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__r
 // the block that finishes last (ticket, left at zero) adds the partials in block order and writes
 // the totals to pinned host memory.
 constexpr int REFIT_NV = 9;   // n, Sx, Sy, Sz, Sxx, Sxy, Syy, Sxz, Syz
-__global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n, float c0, float c1,
-                                                              float b, float thr, double *partial, unsigned *ticket,
-                                                              double *__restrict__ out_host) {
+__device__ __forceinline__ void refit_kernel_body(const float *__restrict__ cand, int n, float c0, float c1, float b,
+                                                  float thr, double *partial, unsigned *ticket,
+                                                  double *__restrict__ out_host, const unsigned bx, const unsigned gx) {
     __shared__ double red[SCORE_WAVES][REFIT_NV];
     __shared__ unsigned last_s;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
+    const int i = bx * SCORE_THREADS + threadIdx.x;
     double v[REFIT_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i < n) {
         const float x = cand[3 * (size_t)i], y = cand[3 * (size_t)i + 1], z = cand[3 * (size_t)i + 2];
@@ -541,16 +555,16 @@ __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__res
     if ((int)threadIdx.x < REFIT_NV) {
         double s = 0.0;
         for (int ww = 0; ww < SCORE_WAVES; ++ww) s += red[ww][threadIdx.x];
-        __hip_atomic_store(partial + (size_t)blockIdx.x * REFIT_NV + threadIdx.x, s, __ATOMIC_RELAXED,
+        __hip_atomic_store(partial + (size_t)bx * REFIT_NV + threadIdx.x, s, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         modest_drain_stores();   // the write-through stores have landed before the ticket (no __threadfence(): see score_kernel)
     }
     __syncthreads();
-    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gx - 1 ? 1u : 0u;
     __syncthreads();
     if (!last_s || w != 0) return;
     double s[REFIT_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int bb = lane; bb < (int)gridDim.x; bb += 64) {
+    for (int bb = lane; bb < (int)gx; bb += 64) {
         double t[REFIT_NV];
 #pragma unroll
         for (int q = 0; q < REFIT_NV; ++q)
@@ -565,6 +579,42 @@ __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__res
         for (int q = 0; q < REFIT_NV; ++q) out_host[q] = s[q];
         *ticket = 0u;
     }
+}
+__global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n, float c0, float c1,
+                                                              float b, float thr, double *partial, unsigned *ticket,
+                                                              double *__restrict__ out_host) {
+    refit_kernel_body(cand, n, c0, c1, b, thr, partial, ticket, out_host, blockIdx.x, gridDim.x);
+}
+
+// ---- the same two kernels for a chain of scans: the fit is blockIdx.z, its arguments come from a device table ----
+struct ScoreLaunch {
+    const float *cand;
+    double *partial;
+    float *models_host;
+    unsigned *ticket;
+    double *out;
+    int n, K, gx, gy;
+    float thr_val;
+    TripArg trip;
+};
+struct RefitLaunch {
+    const float *cand;
+    double *partial;
+    unsigned *ticket;
+    double *out_host;
+    int n, gx;
+    float c0, c1, b, thr;
+};
+__global__ __launch_bounds__(SCORE_THREADS) void scb_score(const ScoreLaunch *__restrict__ tab) {
+    const ScoreLaunch &S = tab[blockIdx.z];
+    if ((int)blockIdx.x >= S.gx || (int)blockIdx.y >= S.gy) return;
+    score_kernel_body<true>(S.cand, S.n, nullptr, S.K, nullptr, S.thr_val, S.partial, S.trip, S.models_host, S.ticket, S.out,
+                            nullptr, nullptr, blockIdx.x, blockIdx.y, (unsigned)S.gx, (unsigned)S.gy);
+}
+__global__ __launch_bounds__(SCORE_THREADS) void scb_refit(const RefitLaunch *__restrict__ tab) {
+    const RefitLaunch &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.gx) return;
+    refit_kernel_body(S.cand, S.n, S.c0, S.c1, S.b, S.thr, S.partial, S.ticket, S.out_host, blockIdx.x, (unsigned)S.gx);
 }
 
 // ---- above_plane + range mask ----------------------------------------------------
@@ -808,6 +858,57 @@ extern "C" int modest_ransac_score_trials(modest_ctx *ctx, const float *cand, in
 // after this function's own when both bits are set).  The results of a batch live in the context's
 // pinned block from byte 576 on (K <= 64), those of a refit in its first 128 bytes: one of each may be
 // in flight on a stream at the same time (scan_driver.hip).
+// Launch capture (scan_driver.hip, chains of scans): while a capture is open on the calling thread, the enqueue
+// halves of modest_ransac_trials_phase / modest_ransac_refit_phase record their kernel arguments instead of
+// launching; modest_ransac_capture_launch then runs ALL recorded refits as one launch and all recorded trial
+// batches as one launch (the fit is a grid dimension).  Everything else of the two functions -- buffers, pinned
+// result areas, read-back halves -- is unchanged.
+struct modest_ransac_capture {
+    std::vector<ScoreLaunch> score;
+    std::vector<RefitLaunch> refit;
+};
+static thread_local modest_ransac_capture *g_capture = nullptr;
+
+modest_ransac_capture *modest_ransac_capture_begin() {
+    g_capture = new modest_ransac_capture;
+    return g_capture;
+}
+
+int modest_ransac_capture_launch(modest_ctx *ctx0, modest_ransac_capture *cap, hipStream_t stream) {
+    g_capture = nullptr;
+    std::unique_ptr<modest_ransac_capture> own(cap);
+    MODEST_REQUIRE(ctx0 != nullptr && cap != nullptr, "NULL argument");
+    const size_t bR = arena_sz(cap->refit.size() * sizeof(RefitLaunch)), bS = cap->score.size() * sizeof(ScoreLaunch);
+    if (bR + bS == 0) return MODEST_OK;
+    char *d = nullptr, *h = nullptr;
+    int rc = modest_ctx_chain_tab(ctx0, bR + bS, &d);
+    if (rc) return rc;
+    rc = modest_ctx_stage_slot(ctx0, bR + bS, reinterpret_cast<void **>(&h));
+    if (rc) return rc;
+    if (!cap->refit.empty()) memcpy(h, cap->refit.data(), cap->refit.size() * sizeof(RefitLaunch));
+    if (!cap->score.empty()) memcpy(h + bR, cap->score.data(), bS);
+    MODEST_HIP_CHECK(hipMemcpyAsync(d, h, bR + bS, hipMemcpyHostToDevice, stream));
+    rc = modest_ctx_stage_commit(ctx0, stream);
+    if (rc) return rc;
+    if (!cap->refit.empty()) {
+        int gx = 1;
+        for (const RefitLaunch &r : cap->refit) gx = std::max(gx, r.gx);
+        scb_refit<<<dim3((unsigned)gx, (unsigned)cap->refit.size()), SCORE_THREADS, 0, stream>>>(
+            reinterpret_cast<const RefitLaunch *>(d));
+    }
+    if (!cap->score.empty()) {
+        int gx = 1, gy = 1;
+        for (const ScoreLaunch &q : cap->score) {
+            gx = std::max(gx, q.gx);
+            gy = std::max(gy, q.gy);
+        }
+        scb_score<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)cap->score.size()), SCORE_THREADS, 0, stream>>>(
+            reinterpret_cast<const ScoreLaunch *>(d + bR));
+    }
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
+
 int modest_ransac_trials_phase(modest_ctx *ctx, const float *cand, int n_cand, const int32_t *trip_host, int K,
                                float *thr_inout, float *models_out, int32_t *n_inliers, double *sse, double *sy,
                                double *syy, void *stream_, int phase) {
@@ -855,7 +956,13 @@ int modest_ransac_trials_phase(modest_ctx *ctx, const float *cand, int n_cand, c
     if (rc) return rc;
     const float *thr_src = thr_known ? nullptr : d_thr;
     float *thr_dst = thr_known ? nullptr : h_thr;
-    if (K <= TRIP_MAX) {
+    if (K <= TRIP_MAX && thr_known && g_capture) {   // a chain of scans: launched together with the other fits' batches
+        ScoreLaunch L;
+        L.cand = cand, L.partial = d_part, L.models_host = h_models, L.ticket = modest_tickets(zw), L.out = h_outp;
+        L.n = n_cand, L.K = K, L.gx = (int)sgrid.x, L.gy = (int)sgrid.y, L.thr_val = thr_val;
+        for (int i = 0; i < 3 * K; ++i) L.trip.t[i] = trip_host[i];
+        g_capture->score.push_back(L);
+    } else if (K <= TRIP_MAX) {
         TripArg ta;
         for (int i = 0; i < 3 * K; ++i) ta.t[i] = trip_host[i];
         score_kernel<true><<<sgrid, SCORE_THREADS, 0, stream>>>(cand, n_cand, nullptr, K,
@@ -913,7 +1020,14 @@ int modest_ransac_refit_phase(modest_ctx *ctx, const float *cand, int n_cand, co
         unsigned *zw = nullptr;
         rc = modest_ctx_zero_words(ctx, stream, &zw);
         if (rc) return rc;
-        refit_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, modest_tickets(zw), h);   // totals straight into pinned host memory
+        if (g_capture) {   // a chain of scans: launched together with the other scans' refits
+            RefitLaunch L;
+            L.cand = cand, L.partial = dp, L.ticket = modest_tickets(zw), L.out_host = h;
+            L.n = n_cand, L.gx = nb, L.c0 = c0, L.c1 = c1, L.b = b, L.thr = thr;
+            g_capture->refit.push_back(L);
+        } else {
+            refit_kernel<<<nb, SCORE_THREADS, 0, stream>>>(cand, n_cand, c0, c1, b, thr, dp, modest_tickets(zw), h);   // totals straight into pinned host memory
+        }
         MODEST_HIP_CHECK(hipGetLastError());
     }
     if (!(phase & 2)) return MODEST_OK;

@@ -268,15 +268,24 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
                  stream_);
         inA[(size_t)s] = 1;
     }
+    modest_ctx *ctx0 = scans[0].ctx;   // the chained launches' tables live there
     for (;;) {   // fit A
         int active = 0;
+        modest_ransac_capture *cap = modest_ransac_capture_begin();
         for (int s = 0; s < n_scans; ++s)
             if (inA[(size_t)s] && !R[(size_t)s].A.done()) {
                 int rc = R[(size_t)s].A.enqueue_batch();
-                if (rc) return rc;
+                if (rc) {
+                    (void)modest_ransac_capture_launch(ctx0, cap, stream);
+                    return rc;
+                }
                 R[(size_t)s].A.pending = true;
                 ++active;
             }
+        {
+            int rc = modest_ransac_capture_launch(ctx0, cap, stream);   // one launch for the batches of all scans
+            if (rc) return rc;
+        }
         if (!active) break;
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         for (int s = 0; s < n_scans; ++s)
@@ -288,6 +297,7 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
     }
     {   // refit A + first batch of B
         int active = 0;
+        modest_ransac_capture *cap = modest_ransac_capture_begin();
         for (int s = 0; s < n_scans; ++s) {
             if (!inA[(size_t)s]) continue;
             const modest_mask_stage_scan &q = scans[s];
@@ -298,10 +308,17 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
                 continue;
             }
             int rc = r.A.enqueue_refit();
-            if (rc) return rc;
-            if ((rc = r.B.enqueue_batch())) return rc;
+            if (!rc) rc = r.B.enqueue_batch();
+            if (rc) {
+                (void)modest_ransac_capture_launch(ctx0, cap, stream);
+                return rc;
+            }
             inB[(size_t)s] = 1;
             ++active;
+        }
+        {
+            int rc = modest_ransac_capture_launch(ctx0, cap, stream);   // all refits as one launch, then all first batches as one
+            if (rc) return rc;
         }
         if (active) MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         for (int s = 0; s < n_scans; ++s) {
@@ -324,13 +341,21 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
     }
     for (;;) {   // the rest of fit B
         int active = 0;
+        modest_ransac_capture *cap = modest_ransac_capture_begin();
         for (int s = 0; s < n_scans; ++s)
             if (inB[(size_t)s] && !R[(size_t)s].B.done()) {
                 int rc = R[(size_t)s].B.enqueue_batch();
-                if (rc) return rc;
+                if (rc) {
+                    (void)modest_ransac_capture_launch(ctx0, cap, stream);
+                    return rc;
+                }
                 R[(size_t)s].B.pending = true;
                 ++active;
             }
+        {
+            int rc = modest_ransac_capture_launch(ctx0, cap, stream);
+            if (rc) return rc;
+        }
         if (!active) break;
         MODEST_HIP_CHECK(hipStreamSynchronize(stream));
         for (int s = 0; s < n_scans; ++s)
@@ -340,6 +365,7 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
                 if (rc) return rc;
             }
     }
+    modest_ransac_capture *capB = modest_ransac_capture_begin();
     for (int s = 0; s < n_scans; ++s) {   // the second refit stays in flight: it rides along with the mask kernel
         if (!inB[(size_t)s]) continue;
         const modest_mask_stage_scan &q = scans[s];
@@ -350,8 +376,15 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
             continue;
         }
         int rc = r.B.enqueue_refit();
-        if (rc) return rc;
+        if (rc) {
+            (void)modest_ransac_capture_launch(ctx0, capB, stream);
+            return rc;
+        }
         r.alive = true;
+    }
+    {
+        int rc = modest_ransac_capture_launch(ctx0, capB, stream);   // the second refits of all scans: one launch
+        if (rc) return rc;
     }
     // 3. the mask kernel of every scan that got this far, one launch
     std::vector<modest_mask_chain_scan> C;
