@@ -36,5 +36,6 @@ bash tools/scan_trace.sh > /dev/null 2>&1; cp gpurun_out/scan_trace.txt $F/scan_
 # diagnostics: each half of the pipeline alone from the default process pool
 python bench.py --cpu-scans 0 --cli-scans 0 --mask-only 2>/dev/null | line > $F/bench_mask_only.json
 python tools/pp_frames_microbench.py 2>/dev/null | tail -1 > $F/pp_stream_microbench.json
+bash tools/mask_kstats.sh > $F/mask_kernel_stats.txt 2>&1
 python tools/host_profile.py 100 tottime 2>&1 | grep -v amdgpu.ids | sed "s#$GRAFT_REPO_ROOT/##g; s#/usr/local/lib/python3.10/dist-packages/##g" | head -40 | cut -c1-160 > $F/host_profile.txt
 python tools/soak_mask.py 8 1500 2>&1 | grep -v amdgpu.ids | tail -3 > $F/determinism_soak.txt
