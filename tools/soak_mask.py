@@ -58,10 +58,17 @@ def work(args):
                 c0 = c
             elif not np.array_equal(c, c0):
                 bad.append((pid, r, "pp", ["counts"], int((c != c0).sum())))
+    from modest_amd.generate_mask import generate_mask_chain
     for r in range(reps):
+        if r % 2 == 1:   # every other repeat: the three scans as ONE chain of launches (what the CLI and bench.py run)
+            chain = generate_mask_chain([dict(ptc=raw, pp_score=pp, random_state=np.random.RandomState(k), ptc_dev=rd, pp_dev=pd)
+                                         for k, (raw, pp, rd, pd) in enumerate(scans)], calib, margs, as_rows=True)
         for k, (raw, pp, rd, pd) in enumerate(scans):
-            labels, rows, info = generate_mask_scan(raw, pp, calib, margs, random_state=np.random.RandomState(k), ptc_dev=rd,
-                                                    pp_dev=pd, as_rows=True)
+            if r % 2 == 1:
+                labels, rows, info = chain[k]
+            else:
+                labels, rows, info = generate_mask_scan(raw, pp, calib, margs, random_state=np.random.RandomState(k), ptc_dev=rd,
+                                                        pp_dev=pd, as_rows=True)
             text, _ = gen_label_scan(rows, calib, largs)
             cur = (labels, rows, text, info["plane"])
             if k not in first:
