@@ -183,12 +183,13 @@ class Runner:
         self.slot = int(slot)
         from modest_amd import _lib, config, ops, synth
         from modest_amd.frame_store import FrameStore
-        from modest_amd.gen_label_files import gen_label_scan
+        from modest_amd.gen_label_files import gen_label_chain, gen_label_scan
         from modest_amd.generate_mask import generate_mask_chain, generate_mask_scan
         from modest_amd.utils import kitti_util
         self.a, self.ops, self.threading = a, ops, threading
         self._gen_label_scan, self._generate_mask_scan = gen_label_scan, generate_mask_scan
         self._generate_mask_chain = generate_mask_chain
+        self._gen_label_chain = gen_label_chain
         _lib.load()
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -333,11 +334,12 @@ class Runner:
         else:
             res = [self._generate_mask_scan(it["ptc"], it["pp_score"], scs[0].calib, self.margs, random_state=it["random_state"],
                                             ptc_dev=it["ptc_dev"], pp_dev=it["pp_dev"], as_rows=True) for it in items]
-        out = []
-        for q, (H, (labels, objs, _)) in enumerate(zip(Hs, res)):
-            text, kept = self._gen_label_scan(objs, scs[q].calib, self.largs, after_device=after if q == len(res) - 1 else None)
-            out.append((H, labels, objs, text))
-        return out
+        if len(res) > 1 and not a.no_mask_chain:   # the IoU matrices of the chain's label stage: one launch
+            lab = self._gen_label_chain([r[1] for r in res], [sc.calib for sc in scs], self.largs, after_device=after)
+        else:
+            lab = [self._gen_label_scan(r[1], sc.calib, self.largs, after_device=after if q == len(res) - 1 else None)
+                   for q, (r, sc) in enumerate(zip(res, scs))]
+        return [(H, labels, objs, text) for H, (labels, objs, _), (text, kept) in zip(Hs, res, lab)]
 
     def run(self, lo, hi):
         """steps lo..hi-1, dealt round-robin to the worker threads"""

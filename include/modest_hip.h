@@ -445,6 +445,9 @@ int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_scans, const m
 /* objs_nms' boxes [t0, t2, 0, l, w, h, -ry] as float32 (pointcloud_utils.py:322-324) and their BEV IoU
  * matrix (iou3d_nms_utils.boxes_iou_bev) -> iou_out [host] (k,k) float32.  Blocking.                  */
 int modest_objs_iou(modest_ctx *ctx, const double *objs8_host, int k, float *iou_out_host, void *stream);
+/* ... of the box sets of a chain of scans: one launch and one round trip for all (k[s] boxes, (k[s],k[s]) out each). */
+int modest_objs_iou_batch(modest_ctx *ctx, const double *const *objs8_host, const int32_t *k, int n_sets,
+                          float *const *iou_out_host, void *stream);
 /* objs_nms' greedy walk (pointcloud_utils.py:329-343) in the caller's `order` -- the reference's
  * np.diag(iou).argsort()[::-1], a numpy call whose tie order is numpy's own --, is_within_fov (:373-379),
  * objs2label (:347-370).  cossin_ry [host] (k,2) = numpy's (cos, sin) of every obj.ry (roty, kitti_util.py:

@@ -74,6 +74,7 @@ SIGNATURES = {
     "modest_boxes_iou_bev_host": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),
     "modest_scan_boxes_batch": (C.c_int, [VP, C.c_int, VP, VP]),
     "modest_scan_boxes": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP]),
+    "modest_objs_iou_batch": (C.c_int, [VP, VP, VP, C.c_int, VP, VP]),
     "modest_objs_iou": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "modest_label_lines": (C.c_int, [VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, C.c_int32, VP]),
 }

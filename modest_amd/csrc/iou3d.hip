@@ -187,11 +187,10 @@ __device__ __forceinline__ float iou_normal(const float *a, const float *b) {
 // HOST's libm (modest_boxes_iou_bev_host: objs_nms orders boxes by float noise of their self-IoU,
 // SURVEY H6, so the label path uses the very cosf / sinf the reference's CPU path calls).
 template <bool IOU, bool HOSTTRIG>
-__global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__ A, int na,
-                                                       const float *__restrict__ B, int nb,
-                                                       float *__restrict__ out) {
+__device__ __forceinline__ void pair_kernel_body(const float *__restrict__ A, int na, const float *__restrict__ B, int nb,
+                                                 float *__restrict__ out, const unsigned bx) {
     __shared__ PolyLds L;
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long id = (long long)bx * blockDim.x + threadIdx.x;
     if (id >= (long long)na * nb) return;
     const int ia = (int)(id / nb), ib = (int)(id % nb);
     constexpr int STRIDE = HOSTTRIG ? 11 : 7;
@@ -211,6 +210,24 @@ __global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__
         tb = device_trig(b[6]);
     }
     out[id] = IOU ? iou_bev(a, b, ta, tb, L) : box_overlap(a, b, ta, tb, L);
+}
+template <bool IOU, bool HOSTTRIG>
+__global__ __launch_bounds__(NMS_TPB) void pair_kernel(const float *__restrict__ A, int na,
+                                                       const float *__restrict__ B, int nb,
+                                                       float *__restrict__ out) {
+    pair_kernel_body<IOU, HOSTTRIG>(A, na, B, nb, out, blockIdx.x);
+}
+
+// the self-IoU matrices of several box sets in one launch (the label stage of a chain of scans): set = blockIdx.y
+struct PairSet {
+    const float *boxes;   // rows of 11 floats (box + host trig)
+    float *out;           // (n, n)
+    int n, pad;
+};
+__global__ __launch_bounds__(NMS_TPB) void pair_sets_kernel(const PairSet *__restrict__ sets) {
+    const PairSet S = sets[blockIdx.y];
+    if ((long long)blockIdx.x * NMS_TPB >= (long long)S.n * S.n) return;
+    pair_kernel_body<true, true>(S.boxes, S.n, S.boxes, S.n, S.out, blockIdx.x);
 }
 
 // ---- NMS over score-sorted boxes (semantics: src/iou3d_nms.cpp:90-136, nms_gpu / nms_normal_gpu) ----
@@ -350,6 +367,54 @@ extern "C" int modest_nms_bev(modest_ctx *ctx, const float *boxes, int n, float 
 extern "C" int modest_nms_normal(modest_ctx *ctx, const float *boxes, int n, float thresh,
                                  int64_t *keep, int *num_keep, void *stream) {
     return nms_impl(false, ctx, boxes, n, thresh, keep, num_keep, stream);
+}
+
+// the (n_s, n_s) self-IoU matrix of every box set of a chain (objs_nms of B scans): boxes, host trig, the set table and
+// the results all live in the context's pinned block; one launch, one synchronise
+int modest_boxes_self_iou_bev_host_batch(modest_ctx *ctx, const float *const *boxes_host, const int *n, int B,
+                                         float *const *out_host, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && boxes_host && n && out_host && B >= 1, "bad arguments");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t need = arena_sz((size_t)B * sizeof(PairSet));
+    long long maxPairs = 0;
+    for (int s = 0; s < B; ++s) {
+        MODEST_REQUIRE(n[s] >= 0, "negative box count");
+        need += arena_sz((size_t)n[s] * 44) + arena_sz((size_t)n[s] * n[s] * 4);
+        maxPairs = std::max(maxPairs, (long long)n[s] * n[s]);
+    }
+    if (maxPairs == 0) return MODEST_OK;
+    int rc = modest_ctx_reserve_pinned(ctx, need);
+    if (rc) return rc;
+    PairSet *sets = reinterpret_cast<PairSet *>(ctx->pinned);
+    size_t off = arena_sz((size_t)B * sizeof(PairSet));
+    std::vector<float *> outs((size_t)B, nullptr);
+    for (int s = 0; s < B; ++s) {
+        float *pb = reinterpret_cast<float *>(ctx->pinned + off);
+        off += arena_sz((size_t)n[s] * 44);
+        float *po = reinterpret_cast<float *>(ctx->pinned + off);
+        off += arena_sz((size_t)n[s] * n[s] * 4);
+        MODEST_REQUIRE(n[s] == 0 || (boxes_host[s] && out_host[s]), "NULL buffer");
+        for (int i = 0; i < n[s]; ++i) {   // the host's libm evaluates the trig (modest_boxes_iou_bev_host)
+            float *d = pb + (size_t)i * 11;
+            memcpy(d, boxes_host[s] + (size_t)i * 7, 28);
+            const float h = d[6];
+            d[7] = cosf(h);
+            d[8] = sinf(h);
+            d[9] = cosf(-h);
+            d[10] = sinf(-h);
+        }
+        sets[s].boxes = pb;
+        sets[s].out = po;
+        sets[s].n = n[s];
+        sets[s].pad = 0;
+        outs[(size_t)s] = po;
+    }
+    pair_sets_kernel<<<dim3((unsigned)((maxPairs + NMS_TPB - 1) / NMS_TPB), (unsigned)B), NMS_TPB, 0, as_stream(stream_)>>>(sets);
+    MODEST_HIP_CHECK(hipGetLastError());
+    MODEST_HIP_CHECK(hipStreamSynchronize(as_stream(stream_)));
+    for (int s = 0; s < B; ++s)
+        if (n[s] > 0) memcpy(out_host[s], outs[(size_t)s], (size_t)n[s] * n[s] * 4);
+    return MODEST_OK;
 }
 
 extern "C" int modest_boxes_iou_bev_host(modest_ctx *ctx, const float *a_host, int na,

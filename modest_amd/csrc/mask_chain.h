@@ -54,3 +54,7 @@ int modest_lowest_point_multi(modest_ctx *ctx, const double *const *pts_rect, co
 struct modest_ransac_capture;
 modest_ransac_capture *modest_ransac_capture_begin();
 int modest_ransac_capture_launch(modest_ctx *ctx0, modest_ransac_capture *cap, hipStream_t stream);
+
+// self-IoU matrices of several box sets in one launch (iou3d.hip): boxes_host[s] (n[s],7) float32, out_host[s] (n[s],n[s])
+int modest_boxes_self_iou_bev_host_batch(modest_ctx *ctx, const float *const *boxes_host, const int *n, int B,
+                                         float *const *out_host, void *stream);

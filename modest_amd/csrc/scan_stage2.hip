@@ -328,6 +328,33 @@ extern "C" int modest_objs_iou(modest_ctx *ctx, const double *objs8, int k, floa
     return modest_boxes_iou_bev_host(ctx, boxes.data(), k, boxes.data(), k, iou_out, stream_);
 }
 
+// modest_objs_iou for the box sets of a chain of scans: one launch, one round trip
+extern "C" int modest_objs_iou_batch(modest_ctx *ctx, const double *const *objs8, const int32_t *k, int n_sets,
+                                     float *const *iou_out, void *stream_) {
+    MODEST_REQUIRE(ctx && objs8 && k && iou_out && n_sets >= 1 && n_sets <= 64, "bad arguments");
+    std::vector<std::vector<float>> boxes((size_t)n_sets);
+    std::vector<const float *> bp((size_t)n_sets);
+    std::vector<int> kv((size_t)n_sets);
+    for (int s = 0; s < n_sets; ++s) {
+        MODEST_REQUIRE(k[s] >= 0 && (k[s] == 0 || (objs8[s] && iou_out[s])), "bad box set");
+        boxes[(size_t)s].resize((size_t)k[s] * 7);
+        for (int i = 0; i < k[s]; ++i) {   // [t0, t2, 0, l, w, h, -ry] as float32 (pointcloud_utils.py:322-324)
+            const double *o = objs8[s] + 8 * (size_t)i;
+            float *b = boxes[(size_t)s].data() + 7 * (size_t)i;
+            b[0] = (float)o[0];
+            b[1] = (float)o[2];
+            b[2] = 0.f;
+            b[3] = (float)o[3];
+            b[4] = (float)o[4];
+            b[5] = (float)o[5];
+            b[6] = (float)(-o[6]);
+        }
+        bp[(size_t)s] = boxes[(size_t)s].data();
+        kv[(size_t)s] = k[s];
+    }
+    return modest_boxes_self_iou_bev_host_batch(ctx, bp.data(), kv.data(), n_sets, iou_out, stream_);
+}
+
 extern "C" int modest_label_lines(const double *objs8, const double *cossin_ry, int k, const int64_t *order,
                                   const float *iou, const modest_labels_params *P, int32_t *kept_out, int32_t *n_kept_out,
                                   char *text_out, int32_t text_cap, int32_t *text_len_out) {

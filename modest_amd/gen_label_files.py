@@ -36,7 +36,7 @@ def display_args(args):
 NATIVE_LABELS = True   # tests switch it off to compare the library's label stage with the Python statement
 
 
-def gen_label_scan(objs, calib, args, after_device=None):
+def gen_label_scan(objs, calib, args, after_device=None, iou=None):
     """gen_label_files.py:44-52 for one scan -> (label text, kept objs).
     ``after_device`` (optional callable) runs as soon as the stage has no device work left -- its only
     device call is the IoU matrix of the NMS; a pipeline uses it to enqueue the next scan's device work
@@ -47,7 +47,8 @@ def gen_label_scan(objs, calib, args, after_device=None):
         rows = objs if isinstance(objs, np.ndarray) else \
             np.array([[*o.t, o.l, o.w, o.h, o.ry, o.volume] for o in objs], dtype=np.float64).reshape(-1, 8)
         nms = bool(args.nms.enable) and len(rows) > 0
-        iou = ops.objs_iou(rows) if nms else None
+        if nms and iou is None:   # (iou given: computed for a chain of scans, gen_label_chain)
+            iou = ops.objs_iou(rows)
         if after_device is not None:
             after_device()
         order = np.diag(iou).argsort()[::-1] if nms else None
@@ -64,6 +65,19 @@ def gen_label_scan(objs, calib, args, after_device=None):
     if args.fov_only:
         objs = [obj for obj in objs if is_within_fov(obj, calib, args.image_shape)]
     return objs2label(objs, calib), objs
+
+
+def gen_label_chain(objs_list, calibs, args, after_device=None):
+    """gen_label_scan for a CHAIN of scans: the IoU matrices of all of them from ONE launch and one round trip
+    (modest_objs_iou_batch), then order, walk, FOV filter and label text scan by scan.  after_device runs once the
+    chain has no device work left.  Returns [(text, kept objs)] -- identical to separate calls."""
+    calibs = calibs if isinstance(calibs, (list, tuple)) else [calibs] * len(objs_list)
+    ious = [None] * len(objs_list)
+    if NATIVE_LABELS and bool(args.nms.enable) and all(isinstance(o, np.ndarray) for o in objs_list):
+        ious = ops.objs_iou_batch(objs_list)
+    if after_device is not None:
+        after_device()
+    return [gen_label_scan(o, cb, args, iou=(m if len(o) > 0 else None)) for o, cb, m in zip(objs_list, calibs, ious)]
 
 
 def _pooled(args, rank, ws, local):

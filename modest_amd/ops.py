@@ -584,6 +584,22 @@ def objs_iou(objs8: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
     return out
 
 
+def objs_iou_batch(objs_list, ctx: Optional[Context] = None):
+    """objs_iou of the box sets of a chain of scans: one launch, one round trip (modest_objs_iou_batch)."""
+    lib = load()
+    B = len(objs_list)
+    rows = [np.ascontiguousarray(o, dtype=np.float64).reshape(-1, 8) for o in objs_list]
+    outs = [np.zeros((r.shape[0], r.shape[0]), dtype=np.float32) for r in rows]
+    if B == 0 or not any(r.shape[0] for r in rows):
+        return outs
+    k = np.array([r.shape[0] for r in rows], dtype=np.int32)
+    ip = np.array([r.ctypes.data if r.shape[0] else 0 for r in rows], dtype=np.uint64)
+    op = np.array([o.ctypes.data if o.size else 0 for o in outs], dtype=np.uint64)
+    c = ctx if ctx is not None else default_context(torch.cuda.current_device())
+    check(lib.modest_objs_iou_batch(c.handle, ip.ctypes.data, k.ctypes.data, B, op.ctypes.data, _stream()), "modest_objs_iou_batch")
+    return outs
+
+
 def label_lines(objs8: np.ndarray, order: Optional[np.ndarray], iou: Optional[np.ndarray], P34, nms_enable: bool,
                 nms_threshold: float, fov_only: bool, image_shape) -> tuple:
     """objs_nms' greedy walk in `order`, is_within_fov, objs2label (modest_label_lines): (text, kept indices)."""

@@ -437,3 +437,25 @@ def test_mask_stage_chain_equals_separate_calls(gpu, tmp_path):
             a, b = rs.get_state(), states[k]
             assert a[2] == b[2] and np.array_equal(a[1], b[1]), k
     assert any(len(r[1]) > 0 for r in single)
+
+
+def test_label_chain_equals_separate_calls(gpu, tmp_path):
+    """gen_label_chain: the IoU matrices of several scans' box sets from one launch (modest_objs_iou_batch); label text
+    and kept boxes equal gen_label_scan's, incl. an empty box set inside the chain."""
+    from modest_amd import config, synth
+    from modest_amd.gen_label_files import gen_label_chain, gen_label_scan
+    from modest_amd.utils import kitti_util
+    open(tmp_path / "c.txt", "w").write(synth.CALIB_TXT)
+    calib = kitti_util.Calibration(str(tmp_path / "c.txt"))
+    args = config.compose("generate_label_files", ["data_root=/unused"])
+    rng = np.random.default_rng(5)
+    sets = []
+    for k in (13, 0, 40, 1, 7):
+        t = np.c_[rng.uniform(5, 40, k), rng.uniform(-1, 1, k), rng.uniform(-15, 15, k)]
+        sets.append(np.c_[t, rng.uniform(1, 5, k), rng.uniform(1, 2.5, k), rng.uniform(1, 2, k), rng.uniform(-3.1, 3.1, k),
+                          rng.uniform(2, 30, k)].astype(np.float64).reshape(-1, 8))
+    sets[2][5] = sets[2][4]   # a duplicate box: ties in the self-IoU order
+    single = [gen_label_scan(r, calib, args) for r in sets]
+    chain = gen_label_chain(sets, calib, args)
+    for (t0, k0), (t1, k1) in zip(single, chain):
+        assert t0 == t1 and np.array_equal(k0, k1)
