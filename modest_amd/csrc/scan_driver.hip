@@ -4,6 +4,9 @@
 // the device round trips of these steps.  Host code only: every device step is one of the library's
 // own entry points (their temporaries come from the context arena at offset 0; what has to live
 // across them -- candidate sets, the scan-sized labels -- sits in the context's hold buffers).
+// modest_mask_stage_batch (end of the file) drives the same stage for a CHAIN of scans: per-scan contexts, the fits of
+// all scans in lockstep, one launch per kernel for the whole chain (plane.hip launch capture, cluster.hip mcb_*,
+// cluster_stats.hip csb_stats).
 #include "common.h"
 #include "ransac_host.h"
 #include "mask_chain.h"
