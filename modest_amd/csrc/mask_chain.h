@@ -58,3 +58,7 @@ int modest_ransac_capture_launch(modest_ctx *ctx0, modest_ransac_capture *cap, h
 // self-IoU matrices of several box sets in one launch (iou3d.hip): boxes_host[s] (n[s],7) float32, out_host[s] (n[s],n[s])
 int modest_boxes_self_iou_bev_host_batch(modest_ctx *ctx, const float *const *boxes_host, const int *n, int B,
                                          float *const *out_host, void *stream);
+
+// Calibration.project_velo_to_rect of several scans in one launch (transform.hip)
+int modest_project_velo_to_rect_multi(modest_ctx *ctx, const float *const *pts, const int *n, const int *stride,
+                                      double *const *out, int B, const double *V2C12, const double *R09, void *stream);

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <utility>
 #include <cstring>
 #include <vector>
 
@@ -55,10 +56,11 @@ __global__ __launch_bounds__(1024) void candidates_kernel(const float *__restric
 struct CandSpec {
     float max_hs, xlo, xhi, ylo, yhi;
 };
-__global__ __launch_bounds__(1024) void candidates2_kernel(const float *__restrict__ pts, int n, int stride, CandSpec A,
-                                                           CandSpec B, float *__restrict__ candA,
-                                                           float *__restrict__ candB, unsigned long long *stateA,
-                                                           unsigned long long *stateB, int *n_out /* [2] */) {
+__device__ __forceinline__ void candidates2_kernel_body(const float *__restrict__ pts, int n, int stride, const CandSpec &A,
+                                                        const CandSpec &B, float *__restrict__ candA,
+                                                        float *__restrict__ candB, unsigned long long *stateA,
+                                                        unsigned long long *stateB, int *n_out /* [2] */,
+                                                        const unsigned gx) {
     const unsigned blk = compact_ticket(stateA);
     const long long i = (long long)blk * 1024 + threadIdx.x;
     bool ka = false, kb = false;
@@ -71,18 +73,38 @@ __global__ __launch_bounds__(1024) void candidates2_kernel(const float *__restri
         ka = (z < A.max_hs) && (x > A.xlo) && (x < A.xhi) && (y > A.ylo) && (y < A.yhi);
         kb = (z < B.max_hs) && (x > B.xlo) && (x < B.xhi) && (y > B.ylo) && (y < B.yhi);
     }
-    const unsigned long long da = compact_offset(ka, blk, gridDim.x, stateA, n_out);
+    const unsigned long long da = compact_offset(ka, blk, gx, stateA, n_out);
     if (ka) {
         candA[3 * da + 0] = x;
         candA[3 * da + 1] = y;
         candA[3 * da + 2] = z;
     }
-    const unsigned long long db = compact_offset(kb, blk, gridDim.x, stateB, n_out + 1);
+    const unsigned long long db = compact_offset(kb, blk, gx, stateB, n_out + 1);
     if (kb) {
         candB[3 * db + 0] = x;
         candB[3 * db + 1] = y;
         candB[3 * db + 2] = z;
     }
+}
+__global__ __launch_bounds__(1024) void candidates2_kernel(const float *__restrict__ pts, int n, int stride, CandSpec A,
+                                                           CandSpec B, float *__restrict__ candA,
+                                                           float *__restrict__ candB, unsigned long long *stateA,
+                                                           unsigned long long *stateB, int *n_out /* [2] */) {
+    candidates2_kernel_body(pts, n, stride, A, B, candA, candB, stateA, stateB, n_out, gridDim.x);
+}
+
+// the selections of a chain of scans in one launch: the scan is blockIdx.y
+struct CandLaunch {
+    const float *pts;
+    float *candA, *candB;
+    unsigned long long *stateA, *stateB;
+    int *n_out;
+    int n, stride, nblk, pad;
+};
+__global__ __launch_bounds__(1024) void cdb_candidates2(const CandLaunch *__restrict__ tab, CandSpec A, CandSpec B) {
+    const CandLaunch &S = tab[blockIdx.y];
+    if ((int)blockIdx.x >= S.nblk) return;   // before the block ticket: only the scan's own blocks take one
+    candidates2_kernel_body(S.pts, S.n, S.stride, A, B, S.candA, S.candB, S.stateA, S.stateB, S.n_out, (unsigned)S.nblk);
 }
 
 // ---- MAD(z): median and median absolute deviation, one workgroup ---------------------
@@ -722,7 +744,9 @@ int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts,
     CandSpec SA{specs10[0], specs10[1], specs10[2], specs10[3], specs10[4]};
     CandSpec SB{specs10[5], specs10[6], specs10[7], specs10[8], specs10[9]};
     MadArgs M{};
-    int used = 0;
+    int used = 0, maxblk = 1;
+    std::vector<CandLaunch> sel;
+    std::vector<std::pair<MadArgs, int>> mads;
     for (int s = 0; s < B; ++s) {
         modest_ctx *ctx = ctxs[s];
         MODEST_REQUIRE(ctx && pts[s] && candA[s] && candB[s] && n[s] >= 1, "bad scan of the chain");
@@ -737,10 +761,13 @@ int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts,
         int *d_n = reinterpret_cast<int *>(ctx->scratch);
         int *h_n = reinterpret_cast<int *>(ctx->pinned);
         float *h_mad = reinterpret_cast<float *>(ctx->pinned + 16);
-        candidates2_kernel<<<nblk, 1024, 0, stream>>>(pts[s], n[s], stride[s], SA, SB, candA[s], candB[s], state,
-                                                      state + 2 + nblk, d_n);
+        CandLaunch L;
+        L.pts = pts[s], L.candA = candA[s], L.candB = candB[s], L.stateA = state, L.stateB = state + 2 + nblk, L.n_out = d_n;
+        L.n = n[s], L.stride = stride[s], L.nblk = nblk, L.pad = 0;
+        sel.push_back(L);
+        maxblk = std::max(maxblk, nblk);
         if (used + 2 > MAD_SETS) {
-            mad_kernel<<<used, 1024, 0, stream>>>(M);
+            mads.push_back({M, used});
             M = MadArgs{};
             used = 0;
         }
@@ -754,7 +781,21 @@ int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts,
         M.out[used + 1] = h_mad + 2;
         used += 2;
     }
-    if (used) mad_kernel<<<used, 1024, 0, stream>>>(M);
+    if (used) mads.push_back({M, used});
+    {   // every scan's selection in ONE launch (table through the first context), then the thresholds
+        char *d = nullptr, *h = nullptr;
+        const size_t bytes = sel.size() * sizeof(CandLaunch);
+        int rc = modest_ctx_chain_tab(ctxs[0], bytes, &d);
+        if (rc) return rc;
+        rc = modest_ctx_stage_slot(ctxs[0], bytes, reinterpret_cast<void **>(&h));
+        if (rc) return rc;
+        memcpy(h, sel.data(), bytes);
+        MODEST_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+        rc = modest_ctx_stage_commit(ctxs[0], stream);
+        if (rc) return rc;
+        cdb_candidates2<<<dim3((unsigned)maxblk, (unsigned)B), 1024, 0, stream>>>(reinterpret_cast<const CandLaunch *>(d), SA, SB);
+    }
+    for (auto &m : mads) mad_kernel<<<m.second, 1024, 0, stream>>>(m.first);
     MODEST_HIP_CHECK(hipGetLastError());
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
     for (int s = 0; s < B; ++s) {

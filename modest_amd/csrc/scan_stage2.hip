@@ -74,7 +74,7 @@ struct BoxRun {
 };
 
 // members_sorted (clustering_utils) + the members' rect-frame points; enqueues the scan's rect projection
-int boxes_begin(BoxRun &r, const modest_boxes_params *P, void *stream_) {
+int boxes_begin(BoxRun &r, const modest_boxes_params *P, void *stream_, bool defer_rect = false) {
     const int n = r.n, n_lab = r.n_lab, stride = r.stride;
     r.info_out[0] = r.info_out[1] = 0;
     r.off.assign((size_t)n_lab + 2, 0);
@@ -110,8 +110,10 @@ int boxes_begin(BoxRun &r, const modest_boxes_params *P, void *stream_) {
     int rc = modest_ctx_reserve_hold(r.ctx, arena_sz((size_t)n * 24), 0);
     if (rc) return rc;
     r.rect_dev = reinterpret_cast<double *>(r.ctx->hold);
-    rc = modest_project_velo_to_rect(r.ctx, r.pts_dev, n, stride, P->V2C, P->R0, r.rect_dev, stream_);
-    if (rc) return rc;
+    if (!defer_rect) {   // (a chain projects all its scans in one launch)
+        rc = modest_project_velo_to_rect(r.ctx, r.pts_dev, n, stride, P->V2C, P->R0, r.rect_dev, stream_);
+        if (rc) return rc;
+    }
     r.coff.resize((size_t)n_lab + 1);
     for (int c = 0; c <= n_lab; ++c) r.coff[(size_t)c] = r.off[(size_t)c + 1];
     r.active = true;
@@ -243,7 +245,7 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
         BoxRun &r = R[(size_t)s];
         r.ctx = q.ctx, r.pts_dev = q.pts_dev, r.pts_host = q.pts_host, r.n = q.n, r.stride = q.stride, r.n_lab = q.n_lab;
         r.labels = q.labels_inout, r.objs_out = q.objs_out, r.keep_out = q.keep_out, r.info_out = q.info_out;
-        int rc = boxes_begin(r, P, stream_);
+        int rc = boxes_begin(r, P, stream_, true);
         if (rc) return rc;
         if (r.active) {
             total_lab += r.n_lab;
@@ -251,6 +253,21 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
         }
     }
     if (total_lab == 0) return MODEST_OK;
+    {   // the rect-frame copies of all active scans: one launch
+        std::vector<const float *> ins;
+        std::vector<double *> outs;
+        std::vector<int> ns, ss;
+        for (BoxRun &r : R)
+            if (r.active) {
+                ins.push_back(r.pts_dev);
+                outs.push_back(r.rect_dev);
+                ns.push_back(r.n);
+                ss.push_back(r.stride);
+            }
+        int rc = modest_project_velo_to_rect_multi(R[0].ctx, ins.data(), ns.data(), ss.data(), outs.data(), (int)ins.size(), P->V2C,
+                                                   P->R0, stream_);
+        if (rc) return rc;
+    }
     // all clusters of the chain as one list
     std::vector<double> xz((size_t)total_m * 2);
     std::vector<int32_t> coff((size_t)total_lab + 1, 0), best((size_t)total_lab);

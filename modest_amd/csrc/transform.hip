@@ -131,7 +131,59 @@ __global__ __launch_bounds__(256) void velo_to_rect_kernel(const float *__restri
     }
 }
 
+// the same for up to RECT_SETS scans in one launch (the box tail of a chain of scans): the scan is blockIdx.y
+constexpr int RECT_SETS = 8;
+struct RectSets {
+    const float *in[RECT_SETS];
+    double *out[RECT_SETS];
+    int n[RECT_SETS], stride[RECT_SETS];
+};
+__global__ __launch_bounds__(256) void velo_to_rect_sets_kernel(RectSets S, RectMats M) {
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.n[s]) return;
+    const float *p = S.in[s] + (size_t)i * S.stride[s];
+    const double x = p[0], y = p[1], z = p[2];
+    double ref[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double acc = __dmul_rn(x, M.v[4 * j]);
+        acc = fma(y, M.v[4 * j + 1], acc);
+        acc = fma(z, M.v[4 * j + 2], acc);
+        ref[j] = fma(1.0, M.v[4 * j + 3], acc);
+    }
+    double *out = S.out[s];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double acc = __dmul_rn(M.r[3 * j], ref[0]);
+        acc = fma(M.r[3 * j + 1], ref[1], acc);
+        out[3 * (size_t)i + j] = fma(M.r[3 * j + 2], ref[2], acc);
+    }
+}
+
 }  // namespace
+
+int modest_project_velo_to_rect_multi(modest_ctx *ctx, const float *const *pts, const int *n, const int *stride,
+                                      double *const *out, int B, const double *V2C12, const double *R09, void *stream_) {
+    MODEST_REQUIRE(ctx && pts && n && stride && out && V2C12 && R09 && B >= 1, "bad arguments");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    RectMats M;
+    for (int q = 0; q < 12; ++q) M.v[q] = V2C12[q];
+    for (int q = 0; q < 9; ++q) M.r[q] = R09[q];
+    for (int s0 = 0; s0 < B; s0 += RECT_SETS) {
+        const int m = B - s0 < RECT_SETS ? B - s0 : RECT_SETS;
+        RectSets S{};
+        int maxn = 1;
+        for (int s = 0; s < m; ++s) {
+            MODEST_REQUIRE(pts[s0 + s] && out[s0 + s] && n[s0 + s] >= 1 && (stride[s0 + s] == 3 || stride[s0 + s] == 4), "bad scan");
+            S.in[s] = pts[s0 + s], S.out[s] = out[s0 + s], S.n[s] = n[s0 + s], S.stride[s] = stride[s0 + s];
+            maxn = maxn > n[s0 + s] ? maxn : n[s0 + s];
+        }
+        velo_to_rect_sets_kernel<<<dim3((unsigned)((maxn + 255) / 256), (unsigned)m), 256, 0, as_stream(stream_)>>>(S, M);
+    }
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
 
 extern "C" int modest_transform_points(modest_ctx *ctx, const float *in, int64_t n, int in_stride,
                                        const float *T16, int remove_center, float *out,
