@@ -748,6 +748,13 @@ def main():
     cpu_baseline = None
     parity = None
     cli = None
+    # the CLI leg first: with the CPU baselines (and the joblib worker processes they leave behind) before it, the first CLI
+    # phase came out 3-4x slower in two of about ten default runs; stand-alone runs of the same CLI never did
+    if rank == 0 and ws == 1 and a.cli_scans > 0 and not a.pp_only:
+        try:
+            cli = cli_bench(a, local)
+        except Exception as e:
+            cli = {"error": repr(e)}
     if rank == 0 and ws == 1 and a.cpu_scans > 0:
         from oracle import labels as ol
         from oracle import mask as om
@@ -806,11 +813,6 @@ def main():
                               f"query_ball_point(workers=-1), sklearn n_jobs=-1; {secs:.1f} s"}
             except Exception as e:
                 cpu_baseline["best_effort"] = {"error": repr(e)}
-    if rank == 0 and ws == 1 and a.cli_scans > 0 and not a.pp_only:
-        try:
-            cli = cli_bench(a, local)
-        except Exception as e:
-            cli = {"error": repr(e)}
 
     if rank == 0:
         value = total_scans / dt_max
