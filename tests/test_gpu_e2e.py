@@ -459,3 +459,41 @@ def test_label_chain_equals_separate_calls(gpu, tmp_path):
     chain = gen_label_chain(sets, calib, args)
     for (t0, k0), (t1, k1) in zip(single, chain):
         assert t0 == t1 and np.array_equal(k0, k1)
+
+
+def test_mask_stage_chain_with_a_scan_that_keeps_too_few_rows(gpu, tmp_path):
+    """A chain in which one scan keeps fewer rows than the graph has neighbours (sklearn's kneighbors raises, the library
+    hands the scan back, the host statement raises): the chain raises like the separate call, and the contexts it used
+    (their persistent cell counters hold that scan's counts) serve the next chain correctly."""
+    import torch
+    from modest_amd import config, generate_mask as gm, synth
+    from modest_amd._lib import ModestHipError
+    from modest_amd.utils import kitti_util
+    open(tmp_path / "c.txt", "w").write(synth.CALIB_TXT)
+    calib = kitti_util.Calibration(str(tmp_path / "c.txt"))
+    args = config.compose("generate_mask", ["data_root=/unused"])
+    rng = np.random.default_rng(3)
+    # a flat ground (both fits find it, the mask removes it) and 40 points above it: 40 kept rows < 70 neighbours
+    g = np.c_[rng.uniform(-40, 40, 6000), rng.uniform(-15, 15, 6000), rng.normal(-1.7, 0.01, 6000), rng.uniform(0, 1, 6000)]
+    up = np.c_[rng.uniform(5, 8, 40), rng.uniform(-2, 2, 40), rng.uniform(-0.5, 0.5, 40), rng.uniform(0, 1, 40)]
+    few = np.ascontiguousarray(np.r_[g, up].astype(np.float32))
+    scans = [few]
+    for k in range(3):
+        scans.append(np.ascontiguousarray(synth.make_scan(90 + k, n_live=15000, n_trav=2, n_frames=1).live_raw))
+    pps = [np.clip(0.5 + 0.5 * np.sin(r[:, 0] * 0.3), 0, 1).astype(np.float32) for r in scans]
+    dev = [(torch.from_numpy(r).to(gpu), torch.from_numpy(p).to(gpu)) for r, p in zip(scans, pps)]
+
+    def items(idx):
+        return [dict(ptc=scans[k], pp_score=pps[k], random_state=np.random.RandomState(7 + k), ptc_dev=dev[k][0], pp_dev=dev[k][1])
+                for k in idx]
+
+    with pytest.raises((ModestHipError, ValueError)):
+        gm.generate_mask_scan(scans[0], pps[0], calib, args, random_state=np.random.RandomState(7), ptc_dev=dev[0][0], pp_dev=dev[0][1])
+    single = [gm.generate_mask_scan(scans[k], pps[k], calib, args, random_state=np.random.RandomState(7 + k), ptc_dev=dev[k][0],
+                                    pp_dev=dev[k][1], as_rows=True) for k in (1, 2, 3)]
+    with pytest.raises((ModestHipError, ValueError)):
+        gm.generate_mask_chain(items([1, 0, 2, 3]), calib, args, as_rows=True)
+    for _ in range(2):   # the same contexts again, twice: counters left by the failed chain must not leak into these
+        chain = gm.generate_mask_chain(items([1, 2, 3]), calib, args, as_rows=True)
+        for (l0, r0, i0), (l1, r1, i1) in zip(single, chain):
+            assert np.array_equal(l0, l1) and np.array_equal(r0, r1) and np.array_equal(i0["plane"], i1["plane"])
