@@ -497,3 +497,51 @@ def test_mask_stage_chain_with_a_scan_that_keeps_too_few_rows(gpu, tmp_path):
         chain = gm.generate_mask_chain(items([1, 2, 3]), calib, args, as_rows=True)
         for (l0, r0, i0), (l1, r1, i1) in zip(single, chain):
             assert np.array_equal(l0, l1) and np.array_equal(r0, r1) and np.array_equal(i0["plane"], i1["plane"])
+
+
+def test_mask_stage_chains_from_concurrent_threads(gpu, tmp_path):
+    """Three host threads (a stream and their own contexts each) run chains of scans at the same time: every result equals
+    the single-threaded, scan-by-scan one (launch capture, device tables and staging slots are per thread / per context)."""
+    import threading
+    import torch
+    from modest_amd import config, generate_mask as gm, synth
+    from modest_amd.gen_label_files import gen_label_chain, gen_label_scan
+    from modest_amd.utils import kitti_util
+    open(tmp_path / "c.txt", "w").write(synth.CALIB_TXT)
+    calib = kitti_util.Calibration(str(tmp_path / "c.txt"))
+    args = config.compose("generate_mask", ["data_root=/unused"])
+    largs = config.compose("generate_label_files", ["data_root=/unused"])
+    scans = []
+    for k in range(4):
+        raw = np.ascontiguousarray(synth.make_scan(120 + k, n_live=20000, n_trav=2, n_frames=1).live_raw)
+        pp = np.clip(0.5 + 0.5 * np.sin(raw[:, 0] * 0.3), 0, 1).astype(np.float32)
+        scans.append((raw, pp, torch.from_numpy(raw).to(gpu), torch.from_numpy(pp).to(gpu)))
+    single = []
+    for k, (raw, pp, rd, pd) in enumerate(scans):
+        labels, rows, _ = gm.generate_mask_scan(raw, pp, calib, args, random_state=np.random.RandomState(k), ptc_dev=rd, pp_dev=pd,
+                                                as_rows=True)
+        single.append((labels, rows, gen_label_scan(rows, calib, largs)[0]))
+    bad, errs = [], []
+
+    def work(t):
+        try:
+            torch.cuda.set_device(gpu)
+            with torch.cuda.stream(torch.cuda.Stream(device=gpu)):
+                for rep in range(6):
+                    order = [(t + rep + q) % 4 for q in range(4)]
+                    res = gm.generate_mask_chain([dict(ptc=scans[k][0], pp_score=scans[k][1], random_state=np.random.RandomState(k),
+                                                       ptc_dev=scans[k][2], pp_dev=scans[k][3]) for k in order], calib, args, as_rows=True)
+                    lab = gen_label_chain([r[1] for r in res], calib, largs)
+                    for k, (labels, rows, _), (text, _) in zip(order, res, lab):
+                        if not (np.array_equal(labels, single[k][0]) and np.array_equal(rows, single[k][1]) and text == single[k][2]):
+                            bad.append((t, rep, k))
+        except Exception as e:   # surfaced below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs[0]
+    assert not bad, bad[:5]
