@@ -174,6 +174,50 @@ int modest_pp_score_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_f
                                  const int32_t *n_frames, int n_trav, double radius,
                                  int32_t *const *counts_dev, float *const *H_dev, void *stream);
 
+/* ---- the same operation for a BLOCK of scans that share history frames -------------------------
+ * Consecutive scans of a shard share 35 of their 36 frames per traversal
+ * (data_preprocessing/lyft/split_traintest.py:64,97): the reference re-stacks and re-indexes them scan
+ * after scan (pre_compute_pp_score.py:132-150,188-190).  modest_pp_score_block takes the UNION of the
+ * block's frames once -- every point is copied, raw, into the list of its world-lattice tile (list sizes
+ * follow from the frames' prefix tables: no count pass) and every list is ordered by lattice cell -- and
+ * then joins every scan against that store: records are read straight into registers, the scan's own
+ * float32 relative pose (get_relative_pose, :27-28; transform_points' rounding) is applied per record,
+ * neighbours are counted with scipy's float64 predicate (:54-60).  Results are those of
+ * modest_pp_score_frames, bit for bit.
+ *
+ * frames_host [host] (n_frames): the union, each frame once.  lat = the 2x4 float64 map the frame was
+ *   sorted with (modest_frame_sort_job::W); flags: MODEST_FRAME_REMOVE_CENTER (all or none).
+ * scans_host [host] (n_scans): the live frame of the store (xyz / perm / tab, lat as above, rel = its float32
+ *   relative pose), the scan's history frames as (member_slot = index into frames_host, member_trav,
+ *   member_rel = rows 0..2 of the frame's float32 relative pose IN THIS SCAN), outputs as above.
+ * Requirements (the caller checks them; modest_pp_score_frames_batch has none of them): no frame has
+ *   points outside its table; every pose agrees with the lattice to 1e-4 m (lat == (1/cell) * W and
+ *   W ~ A * rel); cell >= radius * (1 + 2^-9); the live frames' tables lie within
+ *   modest_pp_block_limits() tiles of each other.  n_trav <= 64.  Not blocking.                      */
+typedef struct {
+    const float *xyz_dev;
+    const uint32_t *tab_dev;
+    int32_t n, TX0, TY0, flags;
+    double lat[8];
+} modest_pp_block_frame;
+typedef struct {
+    const float *xyz_dev;
+    const uint32_t *perm_dev;
+    const uint32_t *tab_dev;
+    int32_t n, TX0, TY0, n_members;
+    double lat[8];
+    float rel[12];
+    const int32_t *member_slot;   /* [host] */
+    const int32_t *member_trav;   /* [host] */
+    const float *member_rel;      /* [host] (n_members, 12) */
+    int32_t *counts_dev;          /* [dev] (n, n_trav) or NULL */
+    float *H_dev;                 /* [dev] (n) or NULL */
+} modest_pp_block_scan;
+int modest_pp_block_limits(int32_t *max_window_tiles, int32_t *max_scans, int32_t *max_frames);
+int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_frame *frames_host, int n_frames,
+                          const modest_pp_block_scan *scans_host, int n_scans, int n_trav, double radius,
+                          double cell, void *stream);
+
 /* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
  * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).
  * Candidate selection: z<max_hs, xlo<x<xhi, ylo<y<yhi (strict), compacted in

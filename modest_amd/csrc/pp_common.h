@@ -43,4 +43,38 @@ __device__ __forceinline__ bool pp_within(double hx, double hy, double hz, float
     return d <= r2;
 }
 
+// ---- entropy (compute_ephe_score, pre_compute_pp_score.py:68-75) -----------------------------
+__device__ __forceinline__ double pp_term(int c, double denom) {
+    const double P = (double)c / denom;
+    return (-P) * log(P + 1e-8);
+}
+
+// numpy's pairwise summation order for a contiguous run of n <= 128 doubles
+// (8 interleaved accumulators, then the remainder sequentially).
+__device__ __forceinline__ void pp_entropy_kernel_body(const int *__restrict__ counts, int n, int T, float *__restrict__ H, const unsigned bx, const unsigned gx) {
+    const int i = bx * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int *c = counts + (size_t)i * T;
+    long long s = 0;
+    for (int t = 0; t < T; ++t) s += c[t];
+    const double denom = (double)s + 1e-8;
+    double res;
+    if (T < 8) {
+        res = 0.0;
+        for (int t = 0; t < T; ++t) res += pp_term(c[t], denom);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = pp_term(c[j], denom);
+        int t = 8;
+        for (; t < T - (T % 8); t += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += pp_term(c[t + j], denom);
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; t < T; ++t) res += pp_term(c[t], denom);
+    }
+    H[i] = (float)(res / log((double)T));
+}
+
 }  // namespace modest

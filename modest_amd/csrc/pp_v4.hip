@@ -1,0 +1,1284 @@
+// PP neighbour count, BLOCK path ("V4"): several consecutive scans of a shard in one call.
+//
+// Reference steps replaced: pre_compute_pp_score.py:132-150 (history stacking), :188-190 (cKDTree per
+// traversal), :54-60 (count_neighbors) -- for a chain of scans at once.
+//
+// What the measurements of V3 (pp_v3.h) said: per scan it streams the 130 MB history twice (count +
+// scatter), writes and re-reads 97 MB of survivor records and sorts every 4096-record slice in LDS before
+// the pair phase -- yet consecutive scans of a Lyft shard share 35 of their 36 frames per traversal
+// (data_preprocessing/lyft/split_traintest.py:64,97), so almost all of that work is repeated scan after
+// scan.  The block path does the scan-independent part ONCE per chain of G scans:
+//
+//   * the frame store already keeps every frame sorted by the 8x8-cell tile of a WORLD lattice shared by all
+//     frames (pp_frames.hip), with a prefix table per frame.  The size of every tile list of the UNION of the
+//     chain's frames is therefore known before a single point is read (b4_counts / b4_lists / b4_bases:
+//     a column sum over the frame tables) -- no count pass, no count matrix, no occupancy bitmap;
+//   * b4_scatter streams the union frames once and copies every point, RAW (frame coordinates) plus its
+//     frame slot and lattice cell, to its final position in its tile list (the position follows from the
+//     tables: no atomics); tiles no scan of the chain has a live point near are skipped;
+//   * b4_seg_hist / b4_seg_scan / b4_seg_scatter order every tile list by cell (counting sort over 4096-record
+//     segments), so that the records of a cell are CONTIGUOUS in HBM for the whole chain;
+//   * per scan: the live scan is cell-sorted on the same lattice (b4_live_*), b4_plan_* cuts the work into
+//     items, and b4_join reads the records of the cells that have live points nearby straight into
+//     registers -- no slice sort, no LDS staging of records -- applies the scan's own float32 pose to every
+//     record (transform_points' rounding, per (scan, frame)) and tests it against the live points of the
+//     3x3 cells around it.  A wavefront holds up to 512 records of ONE cell (eight per lane) against a
+//     wave-uniform candidate: ballots + traversal-segmented popcounts, one LDS atomic per (candidate,
+//     traversal).  Sparse cells (< 64 records) are packed 64 to a wavefront and walk their own candidates.
+//
+// Exactness: the lattice is only a conservative spatial filter.  Distances are evaluated exactly as V3
+// does -- float32 pre-test, float64 re-test (scipy's predicate) inside a 1.5e-6 band around r^2 -- on
+// coordinates produced by the reference's float32 chain from the scan's OWN relative poses.  Two points
+// within r in a scan's common frame are within r + 2 * 1e-4 m on the lattice (the caller checks every
+// pose against the lattice to 1e-4 m, frame_store.consistent), the lattice cell edge is at least
+// r * (1 + 2^-9) (required below), so their lattice cells differ by at most one per axis.
+#include "pp_frames.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace modest;
+
+namespace {
+
+constexpr int B4_NTF = MODEST_FRAME_NTF;   // tiles per axis of a frame table (128)
+constexpr int B4_NTILE = B4_NTF * B4_NTF;
+constexpr int B4_MAXW = 160;               // block window: at most this many tiles per axis
+constexpr int B4_CH = 4096;                // points per streaming chunk (1024 threads x 4)
+constexpr int B4_SEG = 4096;               // records per sort segment (512 threads x 8)
+constexpr int B4_FG = 32;                  // frames per prefix group
+constexpr int B4_W = 10, B4_W1 = 11;       // window of a tile incl. halo (cells)
+constexpr unsigned B4_HEAVY = 64;          // cells with at least this many records get tasks of their own
+#ifndef B4_CPT_
+#define B4_CPT_ 4
+#endif
+constexpr int B4_CPT = B4_CPT_;                  // 64-record chunks per task
+constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
+#ifndef B4_IT_
+#define B4_IT_ 64
+#endif
+constexpr unsigned B4_IT = B4_IT_;             // tasks per item
+#ifndef B4_WPE_
+#define B4_WPE_ 4
+#endif
+#ifndef B4_JT_
+#define B4_JT_ 256
+#endif
+constexpr int B4_JT = B4_JT_;                 // threads of a join workgroup
+constexpr int B4_LDS_DYN = 36 * 1024;      // live points + counters of a band (4 workgroups per CU)
+constexpr unsigned B4_LANE_MAX = 64;       // packed chunks: lanes with more candidates take the group loop
+constexpr int B4_MAXT = 64;
+constexpr int B4_POSE_LDS_MAX = 640;        // frames whose poses fit the LDS table of a join workgroup
+
+struct UFrame {   // a frame of the union, device side (96 bytes)
+    const float *xyz;
+    const unsigned *tab;
+    int n, TX0, TY0, flags;
+    double lat[8];   // rows x, y of raw frame -> lattice cells (the map the frame was sorted with)
+};
+static_assert(sizeof(UFrame) == 96, "union frame layout");
+static_assert(sizeof(modest_pp_block_frame) == 96 && sizeof(modest_pp_block_scan) == 192, "C ABI layout (frame_store.py mirrors it)");
+
+struct PoseEnt {   // per (scan, union frame): 64 bytes = one cache line
+    float rel[12];
+    int trav;      // traversal of the frame in THIS scan; < 0: the frame is not part of the scan
+    int pad[3];
+};
+static_assert(sizeof(PoseEnt) == 64, "pose entry layout");
+
+struct Blk {   // block-wide device pointers and geometry (kernel argument)
+    const UFrame *frames;
+    const uint2 *chunkTab;
+    unsigned *off, *gtot, *listTotal, *listBase, *segBase, *segList, *segHist, *segOff, *cellOff, *ctrl;
+    float4 *recA, *recB;
+    int U, NG, nchunks, maxSegs;
+    int BX0, BY0, BW, BH, BT, CW, CHc, NCpad, nScanBlk, G;
+};
+
+struct ScanDev {   // per scan (device table)
+    const float *liveXyz;
+    const unsigned *livePerm, *liveTab;
+    unsigned *cellCount, *cellStart, *blockSum, *tileTasks, *ctrl;   // ctrl: [0] items, [1] queue head
+    float4 *tmp, *sorted;
+    uint4 *items;
+    const PoseEnt *pose;
+    int *counts;
+    float *H;
+    double lat[8];
+    float rel[12];
+    int n, TX0, TY0, T, maxItems, pad;
+};
+
+// lattice cell of a raw point: the arithmetic of frame_bin (pp_frames.hip) -- a frame's tile runs were
+// made with exactly this chain, so the tile computed here is the run the point sits in
+__device__ __forceinline__ bool b4_cell(const double *__restrict__ W, float x, float y, float z, long long *cx, long long *cy) {
+    const double lx = fma(W[2], (double)z, fma(W[1], (double)y, W[0] * (double)x)) + W[3];
+    const double ly = fma(W[6], (double)z, fma(W[5], (double)y, W[4] * (double)x)) + W[7];
+    if (!(fabs(lx) < 1.0e9) || !(fabs(ly) < 1.0e9)) return false;
+    *cx = (long long)floor(lx);
+    *cy = (long long)floor(ly);
+    return true;
+}
+
+// ---- list sizes from the frame tables ---------------------------------------------------------
+// thread (block tile b, frame group g): exclusive prefix of the tile's point counts over the group's frames
+__global__ __launch_bounds__(256) void b4_counts(Blk B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B.BT) return;
+    const int g = blockIdx.y;
+    const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
+    const int f1 = min(B.U, (g + 1) * B4_FG);
+    unsigned run = 0;
+    for (int f = g * B4_FG; f < f1; ++f) {
+        const UFrame &F = B.frames[f];   // wave-uniform: scalar loads
+        const int lx = gx - F.TX0, ly = gy - F.TY0;
+        unsigned c = 0;
+        if (lx >= 0 && lx < B4_NTF && ly >= 0 && ly < B4_NTF) {
+            const int k = ly * B4_NTF + lx;
+            c = F.tab[k + 1] - F.tab[k];
+        }
+        B.off[(size_t)f * B.BT + b] = run;
+        run += c;
+    }
+    B.gtot[(size_t)g * B.BT + b] = run;
+}
+
+// thread per block tile: is the tile needed (a live point of any scan in the 3x3 tiles around it)?  group
+// bases; list total (0 for tiles nobody needs: their points are never written)
+__global__ __launch_bounds__(256) void b4_lists(Blk B, const ScanDev *__restrict__ scans) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B.BT) return;
+    const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
+    bool needed = false;
+    for (int s = 0; s < B.G; ++s) {
+        const ScanDev &S = scans[s];
+        if (S.n <= 0) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ly = gy + dy - S.TY0;
+            if (ly < 0 || ly >= B4_NTF) continue;
+            const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
+            if (l0 > l1) continue;
+            needed |= S.liveTab[ly * B4_NTF + l1 + 1] > S.liveTab[ly * B4_NTF + l0];
+        }
+    }
+    unsigned run = 0;
+    for (int g = 0; g < B.NG; ++g) {
+        const unsigned t = B.gtot[(size_t)g * B.BT + b];
+        B.gtot[(size_t)g * B.BT + b] = run;
+        run += t;
+    }
+    B.listTotal[b] = needed ? run : 0u;
+}
+
+// one workgroup: list bases, segment bases, the segment -> list table.  ctrl[0] = records, ctrl[1] = segments
+constexpr int B4_BPT = (B4_MAXW * B4_MAXW + 1023) / 1024;   // tiles per thread
+// (the per-thread tiles are read twice instead of being kept: an indexed register array would live in scratch
+// memory, and a kernel that touches scratch pays ~25 us at dispatch)
+__global__ __launch_bounds__(1024) void b4_bases(Blk B) {
+    __shared__ unsigned wa[16], wb[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned sumT = 0, sumS = 0;
+    for (int j = 0; j < B4_BPT; ++j) {
+        const int b = tid * B4_BPT + j;
+        const unsigned t = b < B.BT ? B.listTotal[b] : 0u;
+        sumT += t;
+        sumS += (t + B4_SEG - 1) / B4_SEG;
+    }
+    unsigned incA = sumT, incB = sumS;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
+        if (lane >= o) {
+            incA += a;
+            incB += c;
+        }
+    }
+    if (lane == 63) {
+        wa[w] = incA;
+        wb[w] = incB;
+    }
+    __syncthreads();
+    unsigned baseA = 0, baseB = 0, allA = 0, allB = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w) {
+            baseA += wa[k];
+            baseB += wb[k];
+        }
+        allA += wa[k];
+        allB += wb[k];
+    }
+    if (tid == 0) {
+        B.ctrl[0] = allA;
+        B.ctrl[1] = min(allB, (unsigned)B.maxSegs);
+    }
+    unsigned tB = baseA + incA - sumT, sB = baseB + incB - sumS;
+    for (int j = 0; j < B4_BPT; ++j) {
+        const int b = tid * B4_BPT + j;
+        if (b >= B.BT) break;
+        const unsigned t = B.listTotal[b], ns = (t + B4_SEG - 1) / B4_SEG;
+        B.listBase[b] = tB;
+        B.segBase[b] = sB;
+        for (unsigned k = 0; k < ns; ++k)
+            if (sB + k < (unsigned)B.maxSegs) B.segList[sB + k] = (unsigned)b;
+        tB += t;
+        sB += ns;
+    }
+}
+
+// ---- the one pass over the union's points ------------------------------------------------------
+// chunk = 4096 points of one frame (wave-uniform frame: scalar loads of its descriptor).  A point goes to
+// listBase[tile] + (points of earlier frames in the tile) + (its rank in its frame's tile run).
+__global__ __launch_bounds__(1024) void b4_scatter(Blk B) {
+    const int tid = threadIdx.x;
+    for (int chunk = blockIdx.x; chunk < B.nchunks; chunk += gridDim.x) {
+        const uint2 ct = B.chunkTab[chunk];
+        const int f = (int)ct.x;
+        const UFrame &F = B.frames[f];
+        const int nin = (int)F.tab[B4_NTILE];   // points inside the frame's table (outliers are parked behind)
+        const int g = f / B4_FG;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (int)ct.y + u * 1024 + tid;
+            if (i >= nin || i >= (int)ct.y + B4_CH) continue;
+            float x = F.xyz[3 * (size_t)i], y = F.xyz[3 * (size_t)i + 1];
+            const float z = F.xyz[3 * (size_t)i + 2];
+            long long cx, cy;
+            if (!b4_cell(F.lat, x, y, z, &cx, &cy)) continue;
+            const long long tx = cx >> 3, ty = cy >> 3;
+            const long long lx = tx - F.TX0, ly = ty - F.TY0;
+            const long long bx = tx - B.BX0, by = ty - B.BY0;
+            if (lx < 0 || lx >= B4_NTF || ly < 0 || ly >= B4_NTF) continue;   // (cannot happen for i < nin)
+            if (bx < 0 || bx >= B.BW || by < 0 || by >= B.BH) continue;
+            const int b = (int)(by * B.BW + bx);
+            if (B.listTotal[b] == 0u) continue;
+            const int k = (int)(ly * B4_NTF + lx);
+            const unsigned dest = B.listBase[b] + B.gtot[(size_t)g * B.BT + b] + B.off[(size_t)f * B.BT + b] +
+                                  ((unsigned)i - F.tab[k]);
+            // remove_center (pre_compute_pp_score.py:48-52,141-142) drops the point before the transform: a NaN
+            // coordinate keeps its slot in the list and never passes a distance test
+            if ((F.flags & F_FLAG_CENTER) && in_center_box(x, y)) x = __int_as_float(0x7fc00000);
+            const int key = (int)((cy & 7) * 8 + (cx & 7));
+            B.recA[dest] = make_float4(x, y, z, __int_as_float(key | (f << 6)));
+        }
+    }
+}
+
+// ---- tile lists -> cell order --------------------------------------------------------------------
+__global__ __launch_bounds__(512) void b4_seg_hist(Blk B) {
+    __shared__ unsigned hist[64];
+    const unsigned seg = blockIdx.x;
+    if (seg >= B.ctrl[1]) return;
+    const int tid = threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    const unsigned b = B.segList[seg];
+    const unsigned lo = B.listBase[b] + (seg - B.segBase[b]) * B4_SEG;
+    const unsigned hi = min(B.listBase[b] + B.listTotal[b], lo + B4_SEG);
+#pragma unroll
+    for (int u = 0; u < B4_SEG / 512; ++u) {
+        const unsigned i = lo + u * 512 + tid;
+        if (i < hi) atomicAdd(&hist[__float_as_int(B.recA[i].w) & 63], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) B.segHist[(size_t)seg * 64 + tid] = hist[tid];
+}
+
+// one wavefront per list, lane = cell: offsets of every (segment, cell) inside its cell run, cell bases
+__global__ __launch_bounds__(256) void b4_seg_scan(Blk B) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B.BT) return;
+    const unsigned total = B.listTotal[b], base = B.listBase[b];
+    const unsigned ns = (total + B4_SEG - 1) / B4_SEG, s0 = B.segBase[b];
+    unsigned run = 0;
+    for (unsigned k = 0; k < ns; ++k) {
+        if (s0 + k >= (unsigned)B.maxSegs) break;
+        const unsigned v = B.segHist[(size_t)(s0 + k) * 64 + lane];
+        B.segOff[(size_t)(s0 + k) * 64 + lane] = run;
+        run += v;
+    }
+    unsigned inc = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    B.cellOff[(size_t)b * 65 + lane] = base + inc - run;
+    if (lane == 63) B.cellOff[(size_t)b * 65 + 64] = base + inc;
+}
+
+__global__ __launch_bounds__(512) void b4_seg_scatter(Blk B) {
+    extern __shared__ __align__(16) unsigned char dynsm[];
+    float4 *srec = reinterpret_cast<float4 *>(dynsm);   // the segment in cell order
+    __shared__ unsigned cur[64], lstart[64], gbase[64];
+    const unsigned seg = blockIdx.x;
+    if (seg >= B.ctrl[1]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned b = B.segList[seg];
+    const unsigned lo = B.listBase[b] + (seg - B.segBase[b]) * B4_SEG;
+    const unsigned hi = min(B.listBase[b] + B.listTotal[b], lo + B4_SEG);
+    const unsigned n = hi - lo;
+    if (tid < 64) {
+        const unsigned v = B.segHist[(size_t)seg * 64 + tid];
+        unsigned inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        cur[tid] = inc - v;
+        lstart[tid] = inc - v;
+        gbase[tid] = B.cellOff[(size_t)b * 65 + tid] + B.segOff[(size_t)seg * 64 + tid];
+    }
+    float4 r[B4_SEG / 512];
+#pragma unroll
+    for (int u = 0; u < B4_SEG / 512; ++u) {
+        const unsigned i = u * 512 + tid;
+        r[u] = i < n ? B.recA[lo + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < B4_SEG / 512; ++u) {
+        const unsigned i = u * 512 + tid;
+        if (i < n) srec[atomicAdd(&cur[__float_as_int(r[u].w) & 63], 1u)] = r[u];
+    }
+    __syncthreads();
+    for (unsigned p = tid; p < n; p += 512) {
+        const float4 v = srec[p];
+        const int key = __float_as_int(v.w) & 63;
+        B.recB[gbase[key] + (p - lstart[key])] = v;
+    }
+}
+
+// ---- live scans on the block's cells ----------------------------------------------------------
+// grid.y = scan.  tmp[i] = (x, y, z in the scan's common frame, cell); the cell counters were cleared
+__global__ __launch_bounds__(256) void b4_live_count(Blk B, const ScanDev *__restrict__ scans) {
+    const ScanDev &S = scans[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S.n) return;
+    const float x = S.liveXyz[3 * (size_t)i], y = S.liveXyz[3 * (size_t)i + 1], z = S.liveXyz[3 * (size_t)i + 2];
+    float o[3];
+    rel_apply(S.rel, x, y, z, o);
+    long long cx = 0, cy = 0;
+    (void)b4_cell(S.lat, x, y, z, &cx, &cy);
+    cx -= 8LL * B.BX0;
+    cy -= 8LL * B.BY0;
+    // (a clean live frame lies inside its own table, which the block window contains: the clamp only keeps a
+    // corrupt input from writing out of bounds)
+    const int bx = (int)min(max(cx, 0LL), (long long)B.CW - 1), by = (int)min(max(cy, 0LL), (long long)B.CHc - 1);
+    const int cell = by * B.CW + bx;
+    atomicAdd(&S.cellCount[cell], 1u);
+    S.tmp[i] = make_float4(o[0], o[1], o[2], __int_as_float(cell));
+}
+
+// exclusive scan of the cell counters (1024 per workgroup); the counters are cleared behind the read: the
+// scatter uses them as cursors
+__global__ __launch_bounds__(1024) void b4_scan_local(Blk B, const ScanDev *__restrict__ scans) {
+    __shared__ unsigned wsum[16];
+    const ScanDev &S = scans[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t i = (size_t)blockIdx.x * 1024 + tid;
+    const unsigned v = S.cellCount[i];
+    S.cellCount[i] = 0u;
+    unsigned inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    S.cellStart[i] = base + inc - v;
+    if (tid == 1023) S.blockSum[blockIdx.x] = base + inc;
+}
+__global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__restrict__ scans) {
+    __shared__ unsigned red[16];
+    const ScanDev &S = scans[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned v = 0;
+    for (unsigned j = tid; j < blockIdx.x; j += 1024) v += S.blockSum[j];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    unsigned off = 0;
+    for (int k = 0; k < 16; ++k) off += red[k];
+    const size_t i = (size_t)blockIdx.x * 1024 + tid;
+    S.cellStart[i] += off;
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023) S.cellStart[B.NCpad] = off + S.blockSum[blockIdx.x];
+}
+__global__ __launch_bounds__(256) void b4_live_scatter(Blk B, const ScanDev *__restrict__ scans) {
+    const ScanDev &S = scans[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S.n) return;
+    const float4 t = S.tmp[i];
+    const int cell = __float_as_int(t.w);
+    const unsigned slot = S.cellStart[cell] + atomicAdd(&S.cellCount[cell], 1u);
+    S.sorted[slot] = make_float4(t.x, t.y, t.z, __int_as_float((int)S.livePerm[i]));
+    // counts are indexed by the ORIGINAL point order of the live frame
+}
+
+// ---- plan ------------------------------------------------------------------------------------------
+// A tile's work for one scan, in TASKS of at most 512 records: a cell with >= 64 records and live points in
+// the 3x3 cells around it ("heavy") gets tasks of its own, ceil(chunks / 8) of them; the records of all other
+// cells with live points nearby are packed ("light" virtual order) into tasks of 512.  One wavefront per
+// tile, lane = cell.
+__device__ __forceinline__ unsigned b4_cell_cand(const unsigned *__restrict__ cellStart, int CW, int CHc, int cx, int cy) {
+    const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
+    unsigned c = 0;
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, CHc - 1); ++yy)
+        c += cellStart[(size_t)yy * CW + xb + 1] - cellStart[(size_t)yy * CW + xa];
+    return c;
+}
+__global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__restrict__ scans) {
+    const ScanDev &S = scans[blockIdx.y];
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B.BT) return;
+    unsigned tasks = 0;
+    if (B.listTotal[b] != 0u) {
+        const unsigned n = B.cellOff[(size_t)b * 65 + lane + 1] - B.cellOff[(size_t)b * 65 + lane];
+        unsigned th = 0, lv = 0;
+        if (n) {
+            const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
+            if (b4_cell_cand(S.cellStart, B.CW, B.CHc, cx, cy)) {
+                if (n >= B4_HEAVY) th = (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT;
+                else lv = n;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            th += __shfl_xor(th, o);
+            lv += __shfl_xor(lv, o);
+        }
+        tasks = th + (lv + B4_TASK - 1) / B4_TASK;
+    }
+    if (lane == 0) S.tileTasks[b] = tasks;
+}
+// one workgroup per scan: items = (tile, first task, end task); the full items (B4_IT tasks) first, then the rest
+__global__ __launch_bounds__(1024) void b4_plan_items(Blk B, const ScanDev *__restrict__ scans) {
+    __shared__ unsigned wa[16], wb[16];
+    const ScanDev &S = scans[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned sumF = 0, sumR = 0;
+    for (int j = 0; j < B4_BPT; ++j) {
+        const int b = tid * B4_BPT + j;
+        const unsigned t = b < B.BT ? S.tileTasks[b] : 0u;
+        sumF += t / B4_IT;
+        sumR += (t % B4_IT) ? 1u : 0u;
+    }
+    unsigned incA = sumF, incB = sumR;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
+        if (lane >= o) {
+            incA += a;
+            incB += c;
+        }
+    }
+    if (lane == 63) {
+        wa[w] = incA;
+        wb[w] = incB;
+    }
+    __syncthreads();
+    unsigned baseA = 0, baseB = 0, allA = 0, allB = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < w) {
+            baseA += wa[k];
+            baseB += wb[k];
+        }
+        allA += wa[k];
+        allB += wb[k];
+    }
+    if (tid == 0) {
+        S.ctrl[0] = min(allA + allB, (unsigned)S.maxItems);
+        S.ctrl[1] = 0u;
+    }
+    unsigned fB = baseA + incA - sumF, rB = allA + baseB + incB - sumR;
+    for (int j = 0; j < B4_BPT; ++j) {
+        const int b = tid * B4_BPT + j;
+        if (b >= B.BT) break;
+        const unsigned t = S.tileTasks[b], full = t / B4_IT;
+        for (unsigned k = 0; k < full; ++k)
+            if (fB + k < (unsigned)S.maxItems) S.items[fB + k] = make_uint4((unsigned)b, k * B4_IT, (k + 1) * B4_IT, 0u);
+        if ((t % B4_IT) && rB < (unsigned)S.maxItems) {
+            S.items[rB] = make_uint4((unsigned)b, full * B4_IT, t, 0u);
+            ++rB;
+        }
+        fB += full;
+    }
+}
+
+// ---- join ------------------------------------------------------------------------------------------
+struct B4Shared {
+    unsigned cst[B4_W * B4_W1];          // cellStart of the window cells
+    unsigned short ctab[B4_W * B4_W1];   // live points of window row r before column cc
+    unsigned segStart[B4_W], rowBase[B4_W1];   // rowBase: of the CURRENT band (LDS index of the first live point of window row r)
+    unsigned colOff[B4_W];                     // ... live points of window row r left of the band
+    unsigned cellRec[65];                // record offsets of the tile's cells
+    unsigned thStart[64];                // first heavy task of cell k
+    unsigned lvStart[64], lvEnd[64];     // packed (light) order: first / end virtual record of cell k
+    unsigned band[64];   // ya | yb << 4 | xa << 8 | xb << 12 | slow << 16 (cell rows / columns 1..8 of the window, inclusive)
+    unsigned long long heavyMask;
+    unsigned nBands, ticket, TH, LV, itemId, nextId;
+    uint4 item, nextItem;
+};
+
+// traversal segment masks of one 64-record chunk: lane t keeps the lanes whose record belongs to traversal t
+__device__ __forceinline__ void b4_segmask(unsigned trv, bool valid, int T, int lq, unsigned *lo, unsigned *hi) {
+    const unsigned sel0 = (lq & 1) ? 0u : ~0u, sel1 = (lq & 2) ? 0u : ~0u;
+    const unsigned sel2 = (lq & 4) ? 0u : ~0u, sel3 = (lq & 8) ? 0u : ~0u, sel4 = (lq & 16) ? 0u : ~0u;
+    unsigned long long seg = __ballot(valid);
+    const unsigned long long B0 = __ballot(trv & 1u), B1 = __ballot(trv & 2u);
+    const unsigned long long B2 = __ballot(trv & 4u), B3 = __ballot(trv & 8u), B4 = __ballot(trv & 16u);
+    const unsigned long long s0 = ((unsigned long long)sel0 << 32) | sel0;
+    const unsigned long long s1 = ((unsigned long long)sel1 << 32) | sel1;
+    const unsigned long long s2 = ((unsigned long long)sel2 << 32) | sel2;
+    const unsigned long long s3 = ((unsigned long long)sel3 << 32) | sel3;
+    const unsigned long long s4 = ((unsigned long long)sel4 << 32) | sel4;
+    seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3) & (B4 ^ s4);
+    if (T > 32) {
+        const unsigned sel5 = (lq & 32) ? 0u : ~0u;
+        seg &= __ballot(trv & 32u) ^ (((unsigned long long)sel5 << 32) | sel5);
+    }
+    *lo = (unsigned)seg;
+    *hi = (unsigned)(seg >> 32);
+}
+
+// pointers that reach a kernel through a device table are generic to the compiler (flat_load: counted against
+// the LDS counter as well, so every LDS wait also waits for them); the join states that they are global
+typedef float v4f __attribute__((ext_vector_type(4)));      // (HIP's float4 is a class: no address-space qualified copies)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#define B4_GLOBAL(T) const __attribute__((address_space(1))) T *
+template <typename T> __device__ __forceinline__ B4_GLOBAL(T) b4_global(const T *p) {
+    return (B4_GLOBAL(T))(p);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// The pair phase of a one-cell task: 2 * NP chunks of 64 records in registers against the live points [ia, ie) of
+// one window row (LDS, wave-uniform).  The chunks are held in PAIRS (v2f: chunk 2p in .x, chunk 2p+1 in .y), so that
+// v_pk_add / v_pk_mul / v_pk_fma_f32 test a candidate against two chunks per instruction.  Counts the pairs with
+// d2 < r2lo and re-tests the pairs inside the band [r2lo, r2hi] exactly (float64, scipy's predicate; practically
+// never).  Lane t adds the hits of traversal t (segment masks sLo / sHi per chunk).
+template <int NP>
+__device__ __forceinline__ unsigned long long b4_pairs(const float4 *__restrict__ live, unsigned *__restrict__ cntw, unsigned ia,
+                                                       unsigned ie, const v2f *hx, const v2f *hy, const v2f *hz,
+                                                       const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi, int Th,
+                                                       int lq, int T) {
+    unsigned long long band = 0;
+#pragma unroll 1
+    for (unsigned i = ia; i < ie; ++i) {
+        const float4 q = live[i];
+        const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+        unsigned acc = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const v2f dx = qx - hx[p], dy = qy - hy[p], dz = qz - hz[p];
+            v2f d2 = dx * dx;
+            d2 = __builtin_elementwise_fma(dy, dy, d2);
+            d2 = __builtin_elementwise_fma(dz, dz, d2);
+            const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
+            const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
+            band |= (hA ^ mA) | (hB ^ mB);
+            acc += __popc((unsigned)hA & sLo[2 * p]) + __popc((unsigned)(hA >> 32) & sHi[2 * p]);
+            acc += __popc((unsigned)hB & sLo[2 * p + 1]) + __popc((unsigned)(hB >> 32) & sHi[2 * p + 1]);
+        }
+        if (lq < T && acc) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], acc << ((lq & 1) * 16));
+    }
+    return band;
+}
+// the pairs inside the band around r^2 (a separate pass over the task's candidates, entered practically never: its
+// float64 temporaries must not live in the registers of the loop above)
+template <int NP>
+__device__ __forceinline__ void b4_pairs_band(const float4 *__restrict__ live, unsigned *__restrict__ cntw, unsigned ia, unsigned ie,
+                                              const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
+                                              const unsigned *sHi, float r2lo, float r2hi, double r2, int Th, int lq, int T) {
+#pragma unroll 1
+    for (unsigned i = ia; i < ie; ++i) {
+        const float4 q = live[i];
+        unsigned acc = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float fx = q.x - hx[p].x, fy = q.y - hy[p].x, fz = q.z - hz[p].x;
+            const float dA = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+            fx = q.x - hx[p].y, fy = q.y - hy[p].y, fz = q.z - hz[p].y;
+            const float dB = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+            const bool bA = !(dA < r2lo) && dA <= r2hi, bB = !(dB < r2lo) && dB <= r2hi;
+            const unsigned long long xA = __ballot(bA && pp_within(hx[p].x, hy[p].x, hz[p].x, q.x, q.y, q.z, r2));
+            const unsigned long long xB = __ballot(bB && pp_within(hx[p].y, hy[p].y, hz[p].y, q.x, q.y, q.z, r2));
+            acc += __popc((unsigned)xA & sLo[2 * p]) + __popc((unsigned)(xA >> 32) & sHi[2 * p]);
+            acc += __popc((unsigned)xB & sLo[2 * p + 1]) + __popc((unsigned)(xB >> 32) & sHi[2 * p + 1]);
+        }
+        if (lq < T && acc) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], acc << ((lq & 1) * 16));
+    }
+}
+template <int NP>
+__device__ __forceinline__ void b4_pairs_rows(const float4 *__restrict__ live, unsigned *__restrict__ cntw, const unsigned *aR,
+                                              const unsigned *nR, const v2f *hx, const v2f *hy, const v2f *hz,
+                                              const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi, double r2, int Th,
+                                              int lq, int T) {
+    unsigned long long band = 0;
+#pragma unroll 1
+    for (int rr = 0; rr < 3; ++rr) {
+        const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]);
+        const unsigned ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
+        band |= b4_pairs<NP>(live, cntw, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, Th, lq, T);
+    }
+    if (band) {
+#pragma unroll 1
+        for (int rr = 0; rr < 3; ++rr) {
+            const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]);
+            const unsigned ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
+            b4_pairs_band<NP>(live, cntw, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
+        }
+    }
+}
+
+// LDS pose table of a join workgroup (persistent: loaded once): 48 bytes of pose + 1 byte of traversal per frame
+__host__ __device__ __forceinline__ unsigned b4_pose_bytes(int U) {
+    return U <= B4_POSE_LDS_MAX ? (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15)) : 0u;
+}
+
+template <bool LPOSE>
+__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg) {
+    extern __shared__ __align__(16) unsigned char dynsm[];
+    __shared__ B4Shared S;
+    const ScanDev &SC = scans[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int T = SC.T, Th = (T + 1) >> 1;
+    const unsigned liveBytes = 16u + 4u * (unsigned)Th;
+    const unsigned lcap = (unsigned)B4_LDS_DYN / liveBytes;
+    const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
+    const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
+    const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
+    float4 *live = reinterpret_cast<float4 *>(dynsm + poseB);
+    unsigned *cntw = reinterpret_cast<unsigned *>(live + lcap);
+    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    B4_GLOBAL(unsigned) cellStart = b4_global(SC.cellStart);
+    B4_GLOBAL(v4f) sorted = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
+    B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
+    B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
+    B4_GLOBAL(unsigned) cellOff = b4_global(B.cellOff);
+    B4_GLOBAL(v4u) items = b4_global(reinterpret_cast<const v4u *>(SC.items));
+    int *counts = SC.counts;
+    const int CW = B.CW, CHc = B.CHc;
+    const unsigned nItems = SC.ctrl[0];
+    int lq = lane;
+    asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
+
+    if (LPOSE) {   // the scan's poses: read once per workgroup (the workgroups are persistent)
+        float4 *pw = reinterpret_cast<float4 *>(dynsm);
+        signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
+        for (int f = tid; f < B.U; f += B4_JT) {
+            const v4f a = pose[4 * (size_t)f], b = pose[4 * (size_t)f + 1], c = pose[4 * (size_t)f + 2], d = pose[4 * (size_t)f + 3];
+            pw[3 * f] = make_float4(a.x, a.y, a.z, a.w);
+            pw[3 * f + 1] = make_float4(b.x, b.y, b.z, b.w);
+            pw[3 * f + 2] = make_float4(c.x, c.y, c.z, c.w);
+            tw[f] = (signed char)__float_as_int(d.x);
+        }
+    }
+    // one record -> the scan's frame (transform_points' float32 chain); records of frames that are not part of the scan
+    // and lanes without a record end up 1e30 away, *trv < 0
+    auto xform = [&](const v4f R, bool valid, float *hx, float *hy, float *hz, int *trv) {
+        const int slot = __float_as_int(R.w) >> 6;
+        float4 p0, p1, p2;
+        int t;
+        if (LPOSE) {
+            p0 = poseL[3 * slot], p1 = poseL[3 * slot + 1], p2 = poseL[3 * slot + 2];
+            t = travL[slot];
+        } else {
+            const v4f a = pose[4 * (size_t)slot], b = pose[4 * (size_t)slot + 1], c = pose[4 * (size_t)slot + 2];
+            p0 = make_float4(a.x, a.y, a.z, a.w), p1 = make_float4(b.x, b.y, b.z, b.w), p2 = make_float4(c.x, c.y, c.z, c.w);
+            t = __float_as_int(pose[4 * (size_t)slot + 3].x);
+        }
+        float ax = R.x * p0.x;
+        ax = fmaf(R.y, p0.y, ax);
+        ax = fmaf(R.z, p0.z, ax);
+        ax = ax + p0.w;
+        float ay = R.x * p1.x;
+        ay = fmaf(R.y, p1.y, ay);
+        ay = fmaf(R.z, p1.z, ay);
+        ay = ay + p1.w;
+        float az = R.x * p2.x;
+        az = fmaf(R.y, p2.y, az);
+        az = fmaf(R.z, p2.z, az);
+        az = az + p2.w;
+        const bool ok = valid && t >= 0;
+        *hx = ok ? ax : 1.0e30f;
+        *hy = ok ? ay : 0.f;
+        *hz = ok ? az : 0.f;
+        *trv = ok ? t : -1;
+    };
+    // a record against the live points around its cell in GLOBAL memory (bands that do not fit the LDS: never on LiDAR)
+    auto slow_walk = [&](float sx, float sy, float sz, int st, int cx, int cy) {
+        const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
+        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, CHc - 1); ++yy) {
+            const unsigned a = cellStart[(size_t)yy * CW + xa], e = cellStart[(size_t)yy * CW + xb + 1];
+            for (unsigned i = a; i < e; ++i) {
+                const v4f qq = sorted[i];
+                if (pp_within(sx, sy, sz, qq.x, qq.y, qq.z, r2)) atomicAdd(&counts[(size_t)__float_as_int(qq.w) * T + st], 1);
+            }
+        }
+    };
+
+    const unsigned rot = nItems ? (blockIdx.y * 7919u) % nItems : 0u;   // the scans of a block walk the tiles in different orders
+    if (tid == 0) {
+        const unsigned first = atomicAdd(&SC.ctrl[1], 1u);
+        S.itemId = first;
+        if (first < nItems) {
+            const v4u w = items[(first + rot) % nItems];
+            S.item = make_uint4(w.x, w.y, w.z, w.w);
+        }
+    }
+    for (;;) {
+        __syncthreads();
+        const unsigned iid = S.itemId;
+        if (iid >= nItems) break;
+        const uint4 it = S.item;
+        __syncthreads();   // everyone holds the item: thread 0 may overwrite the header below
+        if (tid == 0) S.nextId = atomicAdd(&SC.ctrl[1], 1u);   // in flight during the loads below
+        const int b = (int)it.x;
+        const unsigned q0 = it.y, q1 = it.z;
+        const int tbx = b % B.BW, tby = b / B.BW;
+        const int x0 = tbx * 8 - 1, y0 = tby * 8 - 1;
+        const int gx0 = max(x0, 0), gx1 = min(x0 + B4_W, CW);
+        // ---- (a) the window's cell table, the tile's cell offsets ---------------------------------
+        if (tid < B4_W * B4_W1) {
+            const int r = tid / B4_W1, cc = tid - r * B4_W1;
+            const int gy = y0 + r;
+            unsigned val = 0;
+            if (gy >= 0 && gy < CHc) val = cellStart[(size_t)gy * CW + min(max(x0 + cc, gx0), gx1)];
+            S.cst[tid] = val;
+        } else if (tid >= 128 && tid < 128 + 65) {
+            S.cellRec[tid - 128] = cellOff[(size_t)b * 65 + (tid - 128)];
+        }
+        __syncthreads();
+        if (tid == 0 && S.nextId < nItems) {
+            const v4u w = items[(S.nextId + rot) % nItems];
+            S.nextItem = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        // ---- (b) tasks of the tile, window tables, bands ------------------------------------------
+        if (tid < 64) {
+            const int k = tid;
+            const unsigned n = S.cellRec[k + 1] - S.cellRec[k];
+            const int lx = (k & 7) + 1, ly = (k >> 3) + 1;
+            unsigned cand = 0;
+#pragma unroll
+            for (int r = -1; r <= 1; ++r) cand += S.cst[(ly + r) * B4_W1 + lx + 2] - S.cst[(ly + r) * B4_W1 + lx - 1];
+            const bool active = n > 0 && cand > 0, heavy = active && n >= B4_HEAVY;
+            const unsigned th = heavy ? (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT : 0u;
+            const unsigned lv = (active && !heavy) ? n : 0u;
+            unsigned incA = th, incB = lv;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
+                if (lane >= o) {
+                    incA += a;
+                    incB += c;
+                }
+            }
+            S.thStart[k] = incA - th;
+            S.lvStart[k] = incB - lv;
+            S.lvEnd[k] = incB;
+            const unsigned long long hm = __ballot(heavy);
+            if (k == 63) {
+                S.TH = incA;
+                S.LV = incB;
+                S.heavyMask = hm;
+            }
+        } else if (tid < 64 + B4_W * B4_W1) {
+            const int e = tid - 64, r = e / B4_W1;
+            S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * B4_W1], 65535u);
+            if (e == r * B4_W1) S.segStart[r] = S.cst[e];
+        } else if (tid == B4_JT - 1) {
+            // bands: sub-rectangles of the tile whose live window (one cell of halo) fits the LDS budget.  Whole cell
+            // rows first; a single row that does not fit (the dense rings next to the sensor) is cut into column
+            // halves, quarters, single cells; a single cell whose 3x3 neighbourhood does not fit takes the slow path.
+            auto cnt = [&](int r0, int r1, int xa, int xb) {   // live points of window rows r0..r1, columns xa-1..xb+1
+                unsigned c = 0;
+                for (int r = r0; r <= r1; ++r) c += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
+                return c;
+            };
+            unsigned nb = 0;
+            int ya = 1;
+            while (ya <= 8) {
+                if (cnt(ya - 1, ya + 1, 1, 8) <= lcap) {
+                    int yb = ya;
+                    while (yb < 8 && cnt(ya - 1, yb + 2, 1, 8) <= lcap) ++yb;
+                    S.band[nb++] = (unsigned)ya | ((unsigned)yb << 4) | (1u << 8) | (8u << 12);
+                    ya = yb + 1;
+                    continue;
+                }
+                auto emit = [&](int xa, int xb, bool slowCell) {
+                    S.band[nb++] = (unsigned)ya | ((unsigned)ya << 4) | ((unsigned)xa << 8) | ((unsigned)xb << 12) | (slowCell ? 1u << 16 : 0u);
+                };
+                for (int ha = 1; ha <= 8; ha += 4) {
+                    if (cnt(ya - 1, ya + 1, ha, ha + 3) <= lcap) {
+                        emit(ha, ha + 3, false);
+                        continue;
+                    }
+                    for (int qa = ha; qa < ha + 4; qa += 2) {
+                        if (cnt(ya - 1, ya + 1, qa, qa + 1) <= lcap) {
+                            emit(qa, qa + 1, false);
+                            continue;
+                        }
+                        for (int c = qa; c < qa + 2; ++c) emit(c, c, cnt(ya - 1, ya + 1, c, c) > lcap);
+                    }
+                }
+                ++ya;
+            }
+            S.nBands = nb;
+        }
+        __syncthreads();
+        const unsigned TH = S.TH, LV = S.LV;
+        const unsigned long long heavyMask = S.heavyMask;
+        const unsigned nBands = S.nBands;
+        for (unsigned bd = 0; bd < nBands; ++bd) {
+            const unsigned bw = S.band[bd];
+            const int ya = (int)(bw & 15u), yb = (int)((bw >> 4) & 15u);   // cell rows / columns of the band (window coordinates 1..8)
+            const int xa = (int)((bw >> 8) & 15u), xb = (int)((bw >> 12) & 15u);
+            const bool slow = (bw >> 16) != 0;
+            __syncthreads();   // previous band's flush complete
+            if (tid <= yb - ya + 2) {   // rows ya-1 .. yb+1 of the window, columns xa-1 .. xb+1
+                unsigned run = 0;
+                for (int r = ya - 1; r < ya - 1 + tid; ++r) run += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
+                const int r = ya - 1 + tid;
+                S.rowBase[r] = run;
+                S.colOff[r] = S.cst[r * B4_W1 + xa - 1] - S.cst[r * B4_W1];
+            }
+            __syncthreads();
+            const unsigned Lb = slow ? 0u : S.rowBase[yb + 1] + (S.cst[(yb + 1) * B4_W1 + xb + 2] - S.cst[(yb + 1) * B4_W1 + xa - 1]);
+            if (!slow) {
+                for (unsigned e = tid; e < Lb; e += B4_JT) {
+                    int r = ya - 1;
+                    while (r < yb + 1 && e >= S.rowBase[r + 1]) ++r;
+                    const v4f w = sorted[S.segStart[r] + S.colOff[r] + (e - S.rowBase[r])];
+                    live[e] = make_float4(w.x, w.y, w.z, w.w);
+                }
+                for (unsigned e = tid; e < Lb * Th; e += B4_JT) cntw[e] = 0;
+            }
+            if (tid == 0) S.ticket = 0;
+            __syncthreads();
+
+            // ---- the tasks of the item, dealt to the wavefronts.  The records of a wavefront's NEXT one-cell task are
+            // requested before the pair phase of the current one: the loads overlap the pair phase ----------------
+            auto fetch = [&]() -> unsigned {
+                unsigned tk = 0;
+                if (lane == 0) tk = atomicAdd(&S.ticket, 1u);
+                return q0 + __builtin_amdgcn_readfirstlane(tk);
+            };
+            int ty = 0, k = 0;   // ty: 0 no task left, 1 one-cell task (records requested), 2 packed task, 3 nothing to do here
+            unsigned start = 0, end = 0, q = 0;
+            v4f R[B4_CPT];
+            auto prep = [&]() {
+                q = fetch();
+                ty = 0;
+                if (q >= q1) return;
+                if (q >= TH) {
+                    ty = (dbg & 2) ? 3 : 2;
+                    return;
+                }
+                ty = 3;
+                if (dbg & 8) return;
+                const bool mineH = ((heavyMask >> lane) & 1ULL) && S.thStart[lane] <= q;
+                k = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)__ballot(mineH)));
+                const int lcx = (k & 7) + 1, lcy = (k >> 3) + 1;
+                if (lcy < ya || lcy > yb || lcx < xa || lcx > xb) return;
+                ty = 1;
+                const unsigned cbeg = S.cellRec[k], cend = S.cellRec[k + 1];
+                start = cbeg + (q - S.thStart[k]) * B4_TASK;
+                end = min(cend, start + B4_TASK);
+                if (!slow) {   // (a lane without a record re-reads the last one: no load sits inside a branch)
+#pragma unroll
+                    for (int u = 0; u < B4_CPT; ++u) R[u] = rec[min(start + u * 64 + lane, end - 1)];
+                }
+            };
+            prep();
+            while (ty != 0) {
+                if (ty == 1) {
+                    const int lcx = (k & 7) + 1, lcy = (k >> 3) + 1;
+                    if (slow) {
+                        const int cx = tbx * 8 + (k & 7), cy = tby * 8 + (k >> 3);
+                        for (unsigned ib = start; ib < end; ib += 64) {
+                            float sx, sy, sz;
+                            int st;
+                            xform(rec[min(ib + lane, end - 1)], ib + lane < end, &sx, &sy, &sz, &st);
+                            if (st >= 0) slow_walk(sx, sy, sz, st, cx, cy);
+                        }
+                        prep();
+                        continue;
+                    }
+                    const int nch = (int)((end - start + 63) >> 6);
+                    v2f hx[B4_CPT / 2], hy[B4_CPT / 2], hz[B4_CPT / 2];   // chunk 2p in .x, chunk 2p+1 in .y
+                    unsigned sLo[B4_CPT], sHi[B4_CPT];
+#pragma unroll
+                    for (int u = 0; u < B4_CPT; ++u) {
+                        int tv;
+                        float ax, ay, az;
+                        xform(R[u], start + u * 64 + lane < end, &ax, &ay, &az, &tv);
+                        if (u & 1) hx[u / 2].y = ax, hy[u / 2].y = ay, hz[u / 2].y = az;
+                        else hx[u / 2].x = ax, hy[u / 2].x = ay, hz[u / 2].x = az;
+                        b4_segmask((unsigned)tv & 63u, tv >= 0, T, lq, &sLo[u], &sHi[u]);
+                    }
+                    const unsigned short *row = S.ctab + (lcy - 1) * B4_W1 + lcx - 1;
+                    const unsigned c00 = row[0], c03 = row[3], c10 = row[B4_W1], c13 = row[B4_W1 + 3];
+                    const unsigned c20 = row[2 * B4_W1], c23 = row[2 * B4_W1 + 3];
+                    const unsigned aR[3] = {S.rowBase[lcy - 1] + c00 - S.colOff[lcy - 1], S.rowBase[lcy] + c10 - S.colOff[lcy],
+                                            S.rowBase[lcy + 1] + c20 - S.colOff[lcy + 1]};
+                    const unsigned nR[3] = {c03 - c00, c13 - c10, c23 - c20};
+                    prep();   // the next task: its record loads are in flight during the pair phase below
+                    if (!(dbg & 1)) {
+                        static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
+                        if (nch <= 2) b4_pairs_rows<1>(live, cntw, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
+                        else b4_pairs_rows<2>(live, cntw, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
+                    }
+                    continue;
+                }
+                if (ty == 3) {
+                    prep();
+                    continue;
+                }
+                // ======== packed records of sparse cells: every lane walks its own candidates ========
+                const unsigned v0 = (q - TH) * B4_TASK, v1 = min(LV, v0 + B4_TASK);
+                prep();
+                for (unsigned vb = v0; vb < v1; vb += 64) {
+                    const unsigned v = vb + lane;
+                    const bool valid = v < v1;
+                    int kc = 0;
+                    if (valid) {   // first cell whose end lies behind v (cells outside the packed order have no extent)
+                        int lo = 0, hi = 63;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (S.lvEnd[mid] > v) hi = mid;
+                            else lo = mid + 1;
+                        }
+                        kc = lo;
+                    }
+                    const int lx = (kc & 7) + 1, ly = (kc >> 3) + 1;
+                    const bool inband = valid && ly >= ya && ly <= yb && lx >= xa && lx <= xb;
+                    if (!__any(inband)) continue;
+                    float hx, hy, hz;
+                    int trv;
+                    xform(rec[S.cellRec[kc] + (valid ? v - S.lvStart[kc] : 0u)], inband, &hx, &hy, &hz, &trv);
+                    const bool on = trv >= 0;
+                    if (slow) {
+                        if (on) slow_walk(hx, hy, hz, trv, tbx * 8 + (kc & 7), tby * 8 + (kc >> 3));
+                        continue;
+                    }
+                    const unsigned short *row = S.ctab + (ly - 1) * B4_W1 + lx - 1;
+                    const unsigned c00 = row[0], c10 = row[B4_W1], c20 = row[2 * B4_W1];
+                    const unsigned n0 = row[3] - c00, n1 = row[B4_W1 + 3] - c10, n2 = row[2 * B4_W1 + 3] - c20;
+                    const int lyc = inband ? ly : ya;   // (lanes outside the band read the band's own tables)
+                    const unsigned a0 = S.rowBase[lyc - 1] + c00 - S.colOff[lyc - 1];
+                    const unsigned n01 = n0 + n1, nAll = n01 + n2;
+                    const unsigned b1 = S.rowBase[lyc] + c10 - S.colOff[lyc] - n0;
+                    const unsigned b2 = S.rowBase[lyc + 1] + c20 - S.colOff[lyc + 1] - n01;
+                    const bool mine = on && nAll <= B4_LANE_MAX;
+                    const unsigned own = mine ? nAll : 0u;
+                    const unsigned cword = ((unsigned)trv & 63u) >> 1, cinc = 1u << ((trv & 1) * 16);
+                    for (unsigned p0 = 0; __any(p0 < own); p0 += 2) {
+                        unsigned bandBits = 0;
+#pragma unroll
+                        for (unsigned u = 0; u < 2; ++u) {
+                            const unsigned p = p0 + u;
+                            const bool act = p < own;
+                            const unsigned i = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
+                            const float4 qq = live[i];
+                            const float fx = qq.x - hx, fy = qq.y - hy, fz = qq.z - hz;
+                            const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                            const bool hit = act && d2 < r2lo;
+                            bandBits |= (act && !hit && d2 <= r2hi) ? (1u << u) : 0u;
+                            if (hit) atomicAdd(&cntw[i * Th + cword], cinc);
+                        }
+                        while (bandBits) {   // practically never: exact float64 re-test
+                            const unsigned u = __ffs((int)bandBits) - 1;
+                            bandBits &= bandBits - 1;
+                            const unsigned p = p0 + u;
+                            const unsigned i = p + (p < n0 ? a0 : (p < n01 ? b1 : b2));
+                            const float4 qq = live[i];
+                            if (pp_within(hx, hy, hz, qq.x, qq.y, qq.z, r2)) atomicAdd(&cntw[i * Th + cword], cinc);
+                        }
+                    }
+                    // lanes with long candidate lists: one cell group at a time, wave-uniform candidates
+                    unsigned long long todo = __ballot(on && !mine);
+                    if (todo) {
+                        unsigned sLo, sHi;
+                        b4_segmask((unsigned)trv & 63u, on, T, lq, &sLo, &sHi);
+                        while (todo) {
+                            const int src = __ffsll((long long)todo) - 1;
+                            const int gk = __builtin_amdgcn_readlane(kc, src);
+                            const unsigned long long grp = __ballot(on && !mine && kc == gk);
+                            todo &= ~grp;
+                            const unsigned ga0 = __builtin_amdgcn_readlane(a0, src), gn0 = __builtin_amdgcn_readlane(n0, src);
+                            const unsigned gb1 = __builtin_amdgcn_readlane(b1, src), gn01 = __builtin_amdgcn_readlane(n01, src);
+                            const unsigned gb2 = __builtin_amdgcn_readlane(b2, src), gnAll = __builtin_amdgcn_readlane(nAll, src);
+                            for (unsigned p = 0; p < gnAll; ++p) {
+                                const unsigned i = p + (p < gn0 ? ga0 : (p < gn01 ? gb1 : gb2));
+                                const float4 qq = live[i];
+                                const float fx = qq.x - hx, fy = qq.y - hy, fz = qq.z - hz;
+                                const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                                unsigned long long hb = __ballot(d2 < r2lo) & grp;
+                                const unsigned long long mb = __ballot(d2 <= r2hi) & grp;
+                                if (hb != mb) {
+                                    const bool inBand = !(d2 < r2lo) && d2 <= r2hi;
+                                    hb |= __ballot(inBand && pp_within(hx, hy, hz, qq.x, qq.y, qq.z, r2)) & grp;
+                                }
+                                if (hb) {
+                                    const unsigned cN = __popc((unsigned)hb & sLo) + __popc((unsigned)(hb >> 32) & sHi);
+                                    if (lane < T && cN) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], cN << ((lq & 1) * 16));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (!slow)
+                for (unsigned e = tid; e < Lb * Th; e += B4_JT) {
+                    const unsigned cw = cntw[e];
+                    if (cw) {
+                        const unsigned pp = e / Th, tp = (e - pp * Th) * 2;
+                        const size_t rowi = (size_t)__float_as_int(live[pp].w) * T;
+                        if (cw & 0xffffu) atomicAdd(&counts[rowi + tp], (int)(cw & 0xffffu));
+                        if (cw >> 16) atomicAdd(&counts[rowi + tp + 1], (int)(cw >> 16));
+                    }
+                }
+        }
+        if (tid == 0) {
+            S.itemId = S.nextId;
+            S.item = S.nextItem;
+        }
+    }
+}
+
+__global__ void b4_entropy(const ScanDev *__restrict__ scans) {
+    const ScanDev &S = scans[blockIdx.y];
+    if (S.H == nullptr || (int)(blockIdx.x * blockDim.x) >= S.n) return;
+    pp_entropy_kernel_body(S.counts, S.n, S.T, S.H, blockIdx.x, gridDim.x);
+}
+
+}  // namespace
+
+extern "C" int modest_pp_block_limits(int32_t *max_window_tiles, int32_t *max_scans, int32_t *max_frames) {
+    if (max_window_tiles) *max_window_tiles = B4_MAXW;
+    if (max_scans) *max_scans = 64;
+    if (max_frames) *max_frames = 1 << 16;
+    return MODEST_OK;
+}
+
+extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_frame *frames, int n_frames,
+                                     const modest_pp_block_scan *scans, int n_scans, int n_trav, double radius,
+                                     double cell, void *stream_) {
+    MODEST_REQUIRE(ctx != nullptr && scans != nullptr, "NULL argument");
+    MODEST_REQUIRE(n_scans >= 1 && n_scans <= 64, "1 <= n_scans <= 64");
+    MODEST_REQUIRE(n_frames >= 0 && n_frames < (1 << 16) && (n_frames == 0 || frames != nullptr), "bad frame table");
+    MODEST_REQUIRE(n_trav >= 1 && n_trav <= B4_MAXT, "1 <= n_trav <= 64 on the block path");
+    MODEST_REQUIRE(radius > 0.0 && radius < 1e6, "radius must be positive and finite");
+    // the lattice cell must leave room for the difference between distances on the lattice and in a scan's frame
+    MODEST_REQUIRE(cell >= radius * (1.0 + 1.0 / 512.0) && cell <= radius * 1.25,
+                   "lattice cell edge must be in [r (1 + 2^-9), 1.25 r]");
+    hipStream_t stream = as_stream(stream_);
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    const int G = n_scans, U = n_frames, T = n_trav;
+    long long ntot = 0, nch = 0;
+    for (int f = 0; f < U; ++f) {
+        MODEST_REQUIRE(frames[f].n >= 0 && frames[f].tab_dev != nullptr, "bad frame");
+        MODEST_REQUIRE(frames[f].n == 0 || frames[f].xyz_dev != nullptr, "NULL frame points");
+        ntot += frames[f].n;
+        nch += (frames[f].n + B4_CH - 1) / B4_CH;
+    }
+    MODEST_REQUIRE(ntot < (1LL << 31) && nch < (1LL << 24), "union of frames too large");
+    int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0, maxN = 0;
+    bool any = false;
+    for (int s = 0; s < G; ++s) {
+        const modest_pp_block_scan &sc = scans[s];
+        MODEST_REQUIRE(sc.n >= 0 && sc.n < (1 << 24), "bad live scan");
+        MODEST_REQUIRE(sc.n == 0 || (sc.xyz_dev && sc.perm_dev && sc.tab_dev), "NULL live buffer");
+        MODEST_REQUIRE(sc.n == 0 || sc.counts_dev || sc.H_dev, "a scan without an output");
+        MODEST_REQUIRE(sc.n_members >= 0 && (sc.n_members == 0 || (sc.member_slot && sc.member_trav && sc.member_rel)),
+                       "bad member list");
+        for (int m = 0; m < sc.n_members; ++m) {
+            MODEST_REQUIRE(sc.member_slot[m] >= 0 && sc.member_slot[m] < U, "member slot out of range");
+            MODEST_REQUIRE(sc.member_trav[m] >= 0 && sc.member_trav[m] < T, "frame traversal out of range");
+        }
+        if (sc.n == 0) continue;
+        if (!any) {
+            bx0 = sc.TX0, by0 = sc.TY0, bx1 = sc.TX0 + B4_NTF, by1 = sc.TY0 + B4_NTF;
+            any = true;
+        } else {
+            bx0 = std::min(bx0, sc.TX0), by0 = std::min(by0, sc.TY0);
+            bx1 = std::max(bx1, sc.TX0 + B4_NTF), by1 = std::max(by1, sc.TY0 + B4_NTF);
+        }
+        maxN = std::max(maxN, sc.n);
+    }
+    if (!any) return MODEST_OK;
+    const int BW = bx1 - bx0, BH = by1 - by0;
+    MODEST_REQUIRE(BW <= B4_MAXW && BH <= B4_MAXW, "the live scans of a block must lie within 32 tiles of each other");
+    const int BT = BW * BH, CW = 8 * BW, CHc = 8 * BH;
+    const int NC = CW * CHc, NCpad = (NC + 1023) & ~1023, nScanBlk = NCpad / 1024;
+    const int NG = (U + B4_FG - 1) / B4_FG;
+    const size_t maxSegs = (size_t)BT + (size_t)(ntot / B4_SEG) + 1;
+    const size_t maxItems = (size_t)(ntot / (B4_TASK * B4_IT)) + (size_t)(ntot / (64 * B4_IT)) + 2 * (size_t)BT + 16;
+
+    // ---- arena ------------------------------------------------------------------------------------
+    size_t need = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = need;
+        need += arena_sz(bytes);
+        return o;
+    };
+    const size_t oOff = take((size_t)std::max(U, 1) * BT * 4), oGtot = take((size_t)std::max(NG, 1) * BT * 4);
+    const size_t oTotal = take((size_t)BT * 4), oBase = take((size_t)BT * 4), oSegBase = take((size_t)BT * 4);
+    const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
+    const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256);
+    const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
+    const size_t oCellCount = take((size_t)G * (NCpad + 1) * 4);   // contiguous over the scans: one memset
+    struct ScanOff {
+        size_t cellStart, blockSum, tileTasks, ctrl, tmp, sorted, items, counts;
+    };
+    std::vector<ScanOff> so((size_t)G);
+    for (int s = 0; s < G; ++s) {
+        const int n = scans[s].n;
+        so[(size_t)s].cellStart = take((size_t)(NCpad + 1) * 4);
+        so[(size_t)s].blockSum = take((size_t)nScanBlk * 4);
+        so[(size_t)s].tileTasks = take((size_t)BT * 4);
+        so[(size_t)s].ctrl = take(256);
+        so[(size_t)s].tmp = take((size_t)std::max(n, 1) * 16);
+        so[(size_t)s].sorted = take((size_t)std::max(n, 1) * 16);
+        so[(size_t)s].items = take(maxItems * 16);
+        so[(size_t)s].counts = take((size_t)std::max(n, 1) * T * 4);
+    }
+    // staged block: [UFrame x U][chunkTab][ScanDev x G][PoseEnt x G x U]
+    const size_t stFrames = 0, stChunks = arena_sz((size_t)std::max(U, 1) * sizeof(UFrame));
+    const size_t stScans = stChunks + arena_sz((size_t)std::max<long long>(nch, 1) * sizeof(uint2));
+    const size_t stPose = stScans + arena_sz((size_t)G * sizeof(ScanDev));
+    const size_t stageB = stPose + arena_sz((size_t)G * std::max(U, 1) * sizeof(PoseEnt));
+    const size_t oStage = take(stageB);
+    int rc = modest_ctx_reserve(ctx, need);
+    if (rc) return rc;
+    char *hs = nullptr;
+    rc = modest_ctx_stage_slot(ctx, stageB, reinterpret_cast<void **>(&hs));
+    if (rc) return rc;
+    char *base = ctx->scratch, *dstage = base + oStage;
+    UFrame *hf = reinterpret_cast<UFrame *>(hs + stFrames);
+    uint2 *hc = reinterpret_cast<uint2 *>(hs + stChunks);
+    ScanDev *hsc = reinterpret_cast<ScanDev *>(hs + stScans);
+    PoseEnt *hp = reinterpret_cast<PoseEnt *>(hs + stPose);
+    size_t kc = 0;
+    for (int f = 0; f < U; ++f) {
+        UFrame &d = hf[f];
+        d.xyz = frames[f].xyz_dev;
+        d.tab = frames[f].tab_dev;
+        d.n = frames[f].n;
+        d.TX0 = frames[f].TX0;
+        d.TY0 = frames[f].TY0;
+        d.flags = frames[f].flags;
+        for (int q = 0; q < 8; ++q) d.lat[q] = frames[f].lat[q];
+        for (int p0 = 0; p0 < frames[f].n; p0 += B4_CH) hc[kc++] = make_uint2((unsigned)f, (unsigned)p0);
+    }
+    for (size_t i = 0; i < (size_t)G * std::max(U, 1); ++i) {
+        memset(&hp[i], 0, sizeof(PoseEnt));
+        hp[i].trav = -1;
+    }
+    for (int s = 0; s < G; ++s) {
+        const modest_pp_block_scan &sc = scans[s];
+        const ScanOff &o = so[(size_t)s];
+        ScanDev &d = hsc[s];
+        memset(&d, 0, sizeof(d));
+        d.liveXyz = sc.xyz_dev;
+        d.livePerm = sc.perm_dev;
+        d.liveTab = sc.tab_dev;
+        d.cellCount = reinterpret_cast<unsigned *>(base + oCellCount) + (size_t)s * (NCpad + 1);
+        d.cellStart = reinterpret_cast<unsigned *>(base + o.cellStart);
+        d.blockSum = reinterpret_cast<unsigned *>(base + o.blockSum);
+        d.tileTasks = reinterpret_cast<unsigned *>(base + o.tileTasks);
+        d.ctrl = reinterpret_cast<unsigned *>(base + o.ctrl);
+        d.tmp = reinterpret_cast<float4 *>(base + o.tmp);
+        d.sorted = reinterpret_cast<float4 *>(base + o.sorted);
+        d.items = reinterpret_cast<uint4 *>(base + o.items);
+        d.pose = reinterpret_cast<const PoseEnt *>(dstage + stPose) + (size_t)s * std::max(U, 1);
+        d.counts = sc.counts_dev ? sc.counts_dev : reinterpret_cast<int *>(base + o.counts);
+        d.H = sc.H_dev;
+        for (int q = 0; q < 8; ++q) d.lat[q] = sc.lat[q];
+        for (int q = 0; q < 12; ++q) d.rel[q] = sc.rel[q];
+        d.n = sc.n;
+        d.TX0 = sc.TX0;
+        d.TY0 = sc.TY0;
+        d.T = T;
+        d.maxItems = (int)maxItems;
+        PoseEnt *pe = hp + (size_t)s * std::max(U, 1);
+        for (int m = 0; m < sc.n_members; ++m) {
+            PoseEnt &e = pe[sc.member_slot[m]];
+            for (int q = 0; q < 12; ++q) e.rel[q] = sc.member_rel[(size_t)m * 12 + q];
+            e.trav = sc.member_trav[m];
+        }
+    }
+    MODEST_HIP_CHECK(hipMemcpyAsync(dstage, hs, stageB, hipMemcpyHostToDevice, stream));
+    rc = modest_ctx_stage_commit(ctx, stream);
+    if (rc) return rc;
+
+    Blk B;
+    memset(&B, 0, sizeof(B));
+    B.frames = reinterpret_cast<const UFrame *>(dstage + stFrames);
+    B.chunkTab = reinterpret_cast<const uint2 *>(dstage + stChunks);
+    B.off = reinterpret_cast<unsigned *>(base + oOff);
+    B.gtot = reinterpret_cast<unsigned *>(base + oGtot);
+    B.listTotal = reinterpret_cast<unsigned *>(base + oTotal);
+    B.listBase = reinterpret_cast<unsigned *>(base + oBase);
+    B.segBase = reinterpret_cast<unsigned *>(base + oSegBase);
+    B.segList = reinterpret_cast<unsigned *>(base + oSegList);
+    B.segHist = reinterpret_cast<unsigned *>(base + oSegHist);
+    B.segOff = reinterpret_cast<unsigned *>(base + oSegOff);
+    B.cellOff = reinterpret_cast<unsigned *>(base + oCellOff);
+    B.ctrl = reinterpret_cast<unsigned *>(base + oCtrl);
+    B.recA = reinterpret_cast<float4 *>(base + oRecA);
+    B.recB = reinterpret_cast<float4 *>(base + oRecB);
+    B.U = U, B.NG = NG, B.nchunks = (int)nch, B.maxSegs = (int)maxSegs;
+    B.BX0 = bx0, B.BY0 = by0, B.BW = BW, B.BH = BH, B.BT = BT, B.CW = CW, B.CHc = CHc, B.NCpad = NCpad;
+    B.nScanBlk = nScanBlk, B.G = G;
+    const ScanDev *dsc = reinterpret_cast<const ScanDev *>(dstage + stScans);
+
+    static bool attr_done[64] = {false};
+    if (!attr_done[ctx->device & 63]) {
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_seg_scatter),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, B4_SEG * 16));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             B4_LDS_DYN + (int)b4_pose_bytes(B4_POSE_LDS_MAX)));
+        attr_done[ctx->device & 63] = true;
+    }
+    modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
+    MODEST_HIP_CHECK(hipMemsetAsync(base + oCellCount, 0, (size_t)G * (NCpad + 1) * 4, stream));
+    // counts start at zero
+    for (int s = 0; s < G; ++s)
+        if (scans[s].n > 0)
+            MODEST_HIP_CHECK(hipMemsetAsync(hsc[s].counts, 0, (size_t)scans[s].n * T * 4, stream));
+    const unsigned gBT = (unsigned)((BT + 255) / 256), gN = (unsigned)((maxN + 255) / 256);
+    if (U > 0 && ntot > 0) {
+        b4_counts<<<dim3(gBT, (unsigned)NG), 256, 0, stream>>>(B);
+        b4_lists<<<gBT, 256, 0, stream>>>(B, dsc);
+        b4_bases<<<1, 1024, 0, stream>>>(B);
+        const int swg = std::min((int)nch, 2 * ctx->num_cus);
+        b4_scatter<<<swg, 1024, 0, stream>>>(B);
+        b4_seg_hist<<<(unsigned)maxSegs, 512, 0, stream>>>(B);
+        b4_seg_scan<<<(unsigned)((BT + 3) / 4), 256, 0, stream>>>(B);
+        b4_seg_scatter<<<(unsigned)maxSegs, 512, B4_SEG * 16, stream>>>(B);
+        b4_live_count<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(B, dsc);
+        b4_scan_local<<<dim3((unsigned)nScanBlk, (unsigned)G), 1024, 0, stream>>>(B, dsc);
+        b4_scan_finish<<<dim3((unsigned)nScanBlk, (unsigned)G), 1024, 0, stream>>>(B, dsc);
+        b4_live_scatter<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(B, dsc);
+        b4_plan_tiles<<<dim3((unsigned)((BT + 3) / 4), (unsigned)G), 256, 0, stream>>>(B, dsc);
+        b4_plan_items<<<(unsigned)G, 1024, 0, stream>>>(B, dsc);
+        const char *jw_env = getenv("MODEST_PP4_JWG");
+        unsigned jx = (unsigned)((jw_env ? atoi(jw_env) : (B4_JT >= 512 ? 2 : 4)) * ctx->num_cus) / (unsigned)G;
+        if (jx < 8) jx = 8;
+        const char *dbg_env = getenv("MODEST_PP4_DBG");
+        const int dbg = dbg_env ? atoi(dbg_env) : 0;
+        const unsigned poseB = b4_pose_bytes(U);
+        if (poseB && B4_JT >= 512 && !(dbg & 256))
+            b4_join<true><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN + poseB, stream>>>(B, dsc, radius * radius, dbg);
+        else
+            b4_join<false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg);
+    }
+    modest_prof_mark(ctx, stream, 1);
+    b4_entropy<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(dsc);
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}

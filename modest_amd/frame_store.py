@@ -41,6 +41,15 @@ assert PP_FRAME.itemsize == 88
 
 REMOVE_CENTER = 1
 
+# modest_pp_block_frame / modest_pp_block_scan (include/modest_hip.h) as numpy records
+BLOCK_FRAME = np.dtype([("xyz_dev", "u8"), ("tab_dev", "u8"), ("n", "i4"), ("TX0", "i4"), ("TY0", "i4"), ("flags", "i4"),
+                        ("lat", "f8", (8,))], align=True)
+assert BLOCK_FRAME.itemsize == 96
+BLOCK_SCAN = np.dtype([("xyz_dev", "u8"), ("perm_dev", "u8"), ("tab_dev", "u8"), ("n", "i4"), ("TX0", "i4"), ("TY0", "i4"),
+                       ("n_members", "i4"), ("lat", "f8", (8,)), ("rel", "f4", (12,)), ("member_slot", "u8"),
+                       ("member_trav", "u8"), ("member_rel", "u8"), ("counts_dev", "u8"), ("H_dev", "u8")], align=True)
+assert BLOCK_SCAN.itemsize == 192
+
 # modest_frame_sort_job as a numpy record: the ingest thread fills a batch of jobs vectorised
 SORT_JOB = np.dtype([("raw_dev", "u8"), ("n", "i4"), ("stride", "i4"), ("TX0", "i4"), ("TY0", "i4"), ("W", "f8", (8,)),
                      ("xyz_dev", "u8"), ("perm_dev", "u8"), ("tab_dev", "u8")], align=True)
@@ -118,7 +127,10 @@ class FrameStore:
     def __init__(self, device, radius: float, capacity_bytes: float = 64 * 2 ** 30, ctx=None):
         self.device = torch.device(device)
         self.radius = float(radius)
-        self.cell = self.radius * (1.0 + 1.0 / 1024.0)
+        # lattice cell edge r (1 + 2^-8): the block path (modest_pp_score_block) uses the lattice as a spatial filter for
+        # distances evaluated in every scan's own frame and needs more slack than r 2^-10 (the single-scan kernels
+        # build their own grid per scan and only use the tile ORDER of a frame)
+        self.cell = self.radius * (1.0 + 1.0 / 256.0)
         self.cap = int(capacity_bytes)
         self.bytes = 0
         self.frames: "OrderedDict[Hashable, StoredFrame]" = OrderedDict()
@@ -138,7 +150,14 @@ class FrameStore:
         # slot tables: the static part of every frame's descriptor, gathered per scan by fancy indexing
         self._rec = np.zeros(1024, dtype=PP_FRAME)
         self._W = np.zeros((1024, 4, 4))
+        self._lat = np.zeros((1024, 8))            # the lattice map every frame was sorted with (block path)
+        self._perm = np.zeros(1024, dtype=np.uint64)   # device address of the frame's perm array
         self._clean = np.zeros(1024, dtype=bool)   # no point outside the table
+        self._checked = np.zeros(1024, dtype=bool)   # ... _clean is known (asynchronous sorts report it later)
+        self._key_of: dict = {}                    # slot -> key
+        lim = (C.c_int32 * 3)()
+        check(load().modest_pp_block_limits(C.byref(lim, 0), C.byref(lim, 4), C.byref(lim, 8)), "modest_pp_block_limits")
+        self.block_window, self.block_max_scans = int(lim[0]), int(lim[1])
         self._free: List[int] = list(range(1023, -1, -1))
         self._slot_index = np.full(1 << 16, -1, dtype=np.int64)   # integer key -> slot (-1: not resident)
 
@@ -163,7 +182,10 @@ class FrameStore:
             old = self._rec.shape[0]
             self._rec = np.concatenate([self._rec, np.zeros(old, dtype=PP_FRAME)])
             self._W = np.concatenate([self._W, np.zeros((old, 4, 4))])
+            self._lat = np.concatenate([self._lat, np.zeros((old, 8))])
+            self._perm = np.concatenate([self._perm, np.zeros(old, dtype=np.uint64)])
             self._clean = np.concatenate([self._clean, np.zeros(old, dtype=bool)])
+            self._checked = np.concatenate([self._checked, np.zeros(old, dtype=bool)])
             self._free = list(range(2 * old - 1, old - 1, -1))
         return self._free.pop()
 
@@ -207,7 +229,7 @@ class FrameStore:
             j.raw_dev, j.n, j.stride, j.TX0, j.TY0 = raw.data_ptr(), n, int(raw.shape[1]), TX0, TY0
             j.W[:] = list(self.lattice_rows(W))
             j.xyz_dev, j.perm_dev, j.tab_dev = xyz.data_ptr(), perm.data_ptr(), tab.data_ptr()
-            made.append((key, xyz, perm, tab, n, TX0, TY0, np.asarray(W, dtype=np.float64).copy()))
+            made.append((key, xyz, perm, tab, n, TX0, TY0, np.asarray(W, dtype=np.float64).copy(), np.array(j.W[:])))
         if blocking:
             inside = (C.c_int32 * len(todo))()
             check(lib.modest_frame_sort(self._ctx(ctx).handle, jobs, len(todo), inside,
@@ -232,11 +254,15 @@ class FrameStore:
             while len(self._inflight) > 2 and self._inflight[0][0].query():
                 self._inflight.popleft()
         with self.lock:
-            for k, (key, xyz, perm, tab, n, TX0, TY0, W) in enumerate(made):
+            for k, (key, xyz, perm, tab, n, TX0, TY0, W, lat) in enumerate(made):
                 sf = StoredFrame(xyz, perm, tab, n, TX0, TY0, inside_of[k], W, self._take_slot())
                 r = self._rec[sf.slot]
                 r["xyz_dev"], r["tab_dev"], r["n"], r["TX0"], r["TY0"] = xyz.data_ptr(), tab.data_ptr(), n, TX0, TY0
                 self._W[sf.slot] = W
+                self._lat[sf.slot] = lat
+                self._perm[sf.slot] = perm.data_ptr()
+                self._key_of[sf.slot] = key
+                self._checked[sf.slot] = isinstance(sf.inside, int)
                 self._clean[sf.slot] = (sf.inside == n) if isinstance(sf.inside, int) else True   # (async: checked on demand)
                 self.frames[key] = sf
                 self.bytes += sf.nbytes
@@ -323,6 +349,11 @@ class FrameStore:
             rec["xyz_dev"][slots], rec["tab_dev"][slots] = jobs["xyz_dev"], jobs["tab_dev"]
             rec["n"][slots], rec["TX0"][slots], rec["TY0"][slots] = jobs["n"], jobs["TX0"], jobs["TY0"]
             self._W[slots] = Ws
+            self._lat[slots] = jobs["W"]
+            self._perm[slots] = jobs["perm_dev"]
+            self._checked[slots] = False
+            for k, key in enumerate(keys):
+                self._key_of[int(slots[k])] = key
             self._clean[slots] = True   # (async: inside-counts are read on demand)
             kmax = int(max(keys))
             if kmax >= self._slot_index.shape[0]:
@@ -475,15 +506,110 @@ class FrameStore:
               "modest_pp_score_frames")
         return (H, counts) if return_counts else H
 
-    def pp_score_batch(self, live_keys, descs, n_trav: int, outs=None, return_counts: bool = False, ctx=None):
-        """PP scores of several scans in ONE chain of launches (modest_pp_score_frames_batch).  live_keys: the live
-        frame of every scan; descs: their tables from describe() (the frames must be resident).  Returns [H] (and
-        [counts]); results are those of separate pp_score calls, bit for bit."""
+    # ------------------------------------------------------------------ several scans per call
+    def _all_clean(self, slots: np.ndarray) -> bool:
+        """no frame of `slots` has points outside its table (asynchronous sorts report that later: read here, once)"""
+        todo = slots[~self._checked[slots]]
+        for sl in np.unique(todo):
+            f = self.frames.get(self._key_of.get(int(sl)))
+            if f is not None and f.slot == sl:
+                self._clean[sl] = f.n_inside == f.n
+                self._checked[sl] = True
+        return bool(self._clean[slots].all())
+
+    def block_tables(self, descs, n_trav: int, force: Optional[bool] = None):
+        """The tables of modest_pp_score_block for these scans, or None when the block path does not apply: more than
+        64 traversals / scans, a frame with points outside its table, poses that disagree with the lattice by more
+        than 1e-4 m, live scans further apart than the block window, mixed remove_center flags -- or (unless forced)
+        too little sharing: the block path bins the UNION of the scans' frames once, which pays when the scans are
+        consecutive scans of a shard (35 of 36 frames per traversal shared, split_traintest.py:64,97)."""
+        env = os.environ.get("MODEST_PP_BLOCK", "")
+        if force is None:
+            force = True if env == "1" else (False if env == "0" else None)
+        if force is False:
+            return None
+        B, T = len(descs), int(n_trav)
+        if B < 1 or B > self.block_max_scans or T > 64:
+            return None
+        with self.lock:
+            hist = [np.asarray(sl[:-1], dtype=np.int64) for _, _, sl in descs]
+            lslots = np.array([int(sl[-1]) for _, _, sl in descs], dtype=np.int64)
+            members = sum(len(h) for h in hist)
+            if members == 0:
+                return None
+            us = np.unique(np.concatenate(hist))
+            if force is None and (B < 2 or members < 1.5 * len(us)):
+                return None
+            if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([us, lslots])):
+                return None
+            lrec = self._rec[lslots]
+            span = self.block_window - self.ntf
+            if (int(lrec["TX0"].max()) - int(lrec["TX0"].min()) > span
+                    or int(lrec["TY0"].max()) - int(lrec["TY0"].min()) > span):
+                return None
+            flags = {int(x) for _, arr, sl in descs if len(sl) > 1 for x in np.unique(arr["flags"])}
+            if len(flags) > 1:
+                return None
+            bottom = np.array([0.0, 0.0, 0.0, 1.0])
+            for (lv, arr, sl), h, ls in zip(descs, hist, lslots):   # every pose against the lattice
+                if not len(h):
+                    continue
+                R = np.concatenate([lv["rel"].reshape(1, 3, 4).astype(np.float64), bottom.reshape(1, 1, 4)], axis=1)[0]
+                A = self._W[ls] @ np.linalg.inv(R)
+                rels = np.concatenate([arr["rel"].reshape(-1, 3, 4).astype(np.float64),
+                                       np.broadcast_to(bottom, (len(h), 1, 4))], axis=1)
+                if not self.consistent(h, rels, A):
+                    return None
+            fr = np.zeros(len(us), dtype=BLOCK_FRAME)
+            ur = self._rec[us]
+            for k in ("xyz_dev", "tab_dev", "n", "TX0", "TY0"):
+                fr[k] = ur[k]
+            fr["flags"] = flags.pop() if flags else 0
+            fr["lat"] = self._lat[us]
+            sc = np.zeros(B, dtype=BLOCK_SCAN)
+            for k in ("xyz_dev", "tab_dev", "n", "TX0", "TY0"):
+                sc[k] = lrec[k]
+            sc["perm_dev"] = self._perm[lslots]
+            sc["lat"] = self._lat[lslots]
+            keep = []
+            for i, ((lv, arr, sl), h) in enumerate(zip(descs, hist)):
+                sc["rel"][i] = lv["rel"][0]
+                ms = np.ascontiguousarray(np.searchsorted(us, h).astype(np.int32))
+                mt = np.ascontiguousarray(arr["trav"][:len(h)].astype(np.int32))
+                mr = np.ascontiguousarray(arr["rel"][:len(h)], dtype=np.float32)
+                keep.append((ms, mt, mr))
+                sc["n_members"][i] = len(h)
+                sc["member_slot"][i], sc["member_trav"][i], sc["member_rel"][i] = ms.ctypes.data, mt.ctypes.data, mr.ctypes.data
+        return fr, sc, keep
+
+    def pp_score_batch(self, live_keys, descs, n_trav: int, outs=None, return_counts: bool = False, ctx=None,
+                       block: Optional[bool] = None):
+        """PP scores of several scans in ONE call.  live_keys: the live frame of every scan; descs: their tables from
+        describe() (the frames must be resident).  Scans that share most of their history frames (consecutive scans of
+        a shard) go through modest_pp_score_block -- the union of their frames is binned once; others through
+        modest_pp_score_frames_batch (one chain of launches, every scan on its own).  `block`: True / False force the
+        choice (MODEST_PP_BLOCK=1 / 0 in the environment does the same).  Returns [H] (and [counts]); results are
+        those of separate pp_score calls, bit for bit."""
         lib = load()
         B, T = len(descs), int(n_trav)
         if T > 64:
             raise ValueError("the batched path takes at most 64 traversals")
         Hs, cs = [], []
+        for i, (lv, arr, slots) in enumerate(descs):
+            N = int(lv["n"][0])
+            H = outs[i] if outs is not None and outs[i] is not None else torch.empty((N,), dtype=torch.float32, device=self.device)
+            Hs.append(H)
+            cs.append(torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None)
+        tabs = self.block_tables(descs, T, force=block)
+        if tabs is not None:
+            fr, sc, keep = tabs
+            sc["H_dev"] = [H.data_ptr() for H in Hs]
+            sc["counts_dev"] = [c.data_ptr() if c is not None else 0 for c in cs]
+            check(lib.modest_pp_score_block(self._ctx(ctx).handle, fr.ctypes.data, len(fr), sc.ctypes.data, B, T,
+                                            self.radius, self.cell, torch.cuda.current_stream().cuda_stream),
+                  "modest_pp_score_block")
+            self.block_calls = getattr(self, "block_calls", 0) + 1
+            return (Hs, cs) if return_counts else Hs
         livep, permp, framep = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
         Hp, cp = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
         nfr = np.zeros(B, dtype=np.int32)
@@ -491,15 +617,10 @@ class FrameStore:
         for i, (lv, arr, slots) in enumerate(descs):
             lv, arr = np.ascontiguousarray(lv), np.ascontiguousarray(arr)
             keep.append((lv, arr))
-            N = int(lv["n"][0])
-            H = outs[i] if outs is not None and outs[i] is not None else torch.empty((N,), dtype=torch.float32, device=self.device)
-            c = torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None
-            Hs.append(H)
-            cs.append(c)
             livep[i], framep[i], nfr[i] = lv.ctypes.data, arr.ctypes.data, len(slots) - 1
             permp[i] = self.frames[live_keys[i]].perm.data_ptr()
-            Hp[i] = H.data_ptr()
-            cp[i] = c.data_ptr() if c is not None else 0
+            Hp[i] = Hs[i].data_ptr()
+            cp[i] = cs[i].data_ptr() if cs[i] is not None else 0
         check(lib.modest_pp_score_frames_batch(self._ctx(ctx).handle, B, livep.ctypes.data, permp.ctypes.data,
                                                framep.ctypes.data, nfr.ctypes.data, T, self.radius,
                                                cp.ctypes.data if return_counts else None, Hp.ctypes.data,

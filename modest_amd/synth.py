@@ -240,6 +240,84 @@ def make_scan(scan_id: int, n_live: int = 30_000, n_trav: int = 10, n_frames: in
                       first_pose=first_pose, l2e=l2e, K=K)
 
 
+@dataclass
+class ShardScan:
+    """One live scan of a synthetic shard: which frames of the shard's traversals are its history."""
+    index: int
+    live_raw: np.ndarray             # (N,4) f32
+    live_W: np.ndarray               # (4,4) f64 raw -> world
+    live_rel: np.ndarray             # (4,4) f32
+    hist: List[Tuple[int, int]]      # (traversal, frame number in the traversal's track), reference order
+    rels: np.ndarray                 # (T*F,4,4) f32 relative poses, same order
+    world_from_ref: np.ndarray       # (4,4) f64 common frame -> world
+    first_pose: np.ndarray = None
+    l2e: np.ndarray = None
+    K: np.ndarray = None
+
+
+@dataclass
+class Shard:
+    """S consecutive live scans of one sequence and the T history traversals they look at: scan i uses frames
+    i .. i+F-1 of every traversal's track, so consecutive scans share F-1 of their F frames per traversal (the
+    structure data_preprocessing/lyft/split_traintest.py:64,97 produces)."""
+    scans: List[ShardScan]
+    tracks: List[List[Tuple[np.ndarray, np.ndarray]]]   # [t][j] = (raw (n,4) f32, W (4,4) f64)
+    nusc: bool = False
+
+    def stacked(self, i: int) -> Tuple[np.ndarray, List[np.ndarray]]:
+        """(live points, per-traversal history) of scan i in its common frame -- what the reference stacks
+        (pre_compute_pp_score.py:132-150), for the oracle"""
+        sc = self.scans[i]
+        T = len(self.tracks)
+        parts = [[] for _ in range(T)]
+        for (t, j), rel in zip(sc.hist, sc.rels):
+            xyz = self.tracks[t][j][0][:, :3]
+            if self.nusc:
+                m = (xyz[:, 0] < 1.75) & (xyz[:, 0] >= -1.15) & (xyz[:, 1] < 0.65) & (xyz[:, 1] >= -0.65)
+                xyz = xyz[~m]
+            parts[t].append(_transform_f32(xyz, rel))
+        return (np.ascontiguousarray(_transform_f32(sc.live_raw[:, :3], sc.live_rel)),
+                [np.concatenate(p).astype(np.float32) for p in parts])
+
+
+def make_shard(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_frames: int = 36, n_per_frame: int | None = None,
+               nusc: bool = False, frame_gap: float = 2.0, seed: int = 0, x0: float = 0.0, world_seed: int = 0,
+               point_order: str = "shuffled") -> Shard:
+    """Seeds: live 7000 + 1000*seed + i, history 9000 + 100000*seed + 1000*t + j."""
+    n_per_frame = n_live if n_per_frame is None else n_per_frame
+    L = n_scans + n_frames - 1
+    world = make_world(world_seed, length=max(400.0, x0 + frame_gap * L + 150.0))
+    K, l2e = kitti2nu(nusc), default_l2e()
+    rngp = np.random.default_rng(60_000 + seed)
+    tracks, poses = [], []
+    for t in range(n_trav):
+        lat, yaw = rngp.uniform(-1.5, 1.5), rngp.uniform(-0.02, 0.02)
+        tr, ps = [], []
+        for j in range(L):
+            pose = _pose_matrix(x0 + frame_gap * j + rngp.uniform(-0.5, 0.5), lat, yaw)
+            raw = sample_frame(world, 9000 + 100_000 * seed + 1000 * t + j, n_per_frame, pose, l2e, nusc, point_order=point_order)
+            tr.append((raw, pose @ l2e @ K))
+            ps.append(pose)
+        tracks.append(tr)
+        poses.append(ps)
+    scans = []
+    for i in range(n_scans):
+        ex = x0 + frame_gap * i
+        live_pose = _pose_matrix(ex, 0.0, 0.01)
+        live_raw = sample_frame(world, 7000 + 1000 * seed + i, n_live, live_pose, l2e, nusc, make_mobiles(1000 * seed + i, ex),
+                                point_order=point_order)
+        first_pose = poses[0][i]
+        hist, rels = [], []
+        for t in range(n_trav):
+            for j in range(i, i + n_frames):
+                hist.append((t, j))
+                rels.append(relative_pose(l2e, first_pose, l2e, poses[t][j], K))
+        scans.append(ShardScan(index=i, live_raw=live_raw, live_W=live_pose @ l2e @ K,
+                               live_rel=relative_pose(l2e, first_pose, l2e, live_pose, K), hist=hist, rels=np.stack(rels),
+                               world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K))
+    return Shard(scans=scans, tracks=tracks, nusc=nusc)
+
+
 CALIB_TXT = (
     "P0: 8.8e+02 0 6.12e+02 0 0 8.8e+02 5.12e+02 0 0 0 1 0\n"
     "P1: 8.8e+02 0 6.12e+02 0 0 8.8e+02 5.12e+02 0 0 0 1 0\n"

@@ -1,0 +1,93 @@
+"""Block path (modest_pp_score_block) against the per-scan chain and the oracle on a synthetic shard; timing.
+    python tools/pp_block_probe.py [--scans 8] [--n 30000] [--trav 10] [--frames 36] [--oracle] [--reps 5]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from modest_amd import _lib, synth   # noqa: E402
+from modest_amd.frame_store import FrameStore   # noqa: E402
+
+
+def load_shard(store, sh, dev, key0=0):
+    items, nf = [], {}
+    for t, tr in enumerate(sh.tracks):
+        for j, (raw, W) in enumerate(tr):
+            nf[(t, j)] = key0 + len(nf)
+            items.append((nf[(t, j)], torch.from_numpy(raw).to(dev), W))
+    lives = []
+    for sc in sh.scans:
+        k = key0 + 100000 + sc.index
+        items.append((k, torch.from_numpy(sc.live_raw).to(dev), sc.live_W))
+        lives.append(k)
+    store.insert_many(items)
+    descs = [store.describe(lives[i], sc.live_rel, [nf[h] for h in sc.hist], [t for t, _ in sc.hist], sc.rels, sh.nusc)
+             for i, sc in enumerate(sh.scans)]
+    return lives, descs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=8)
+    ap.add_argument("--n", type=int, default=30000)
+    ap.add_argument("--trav", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=36)
+    ap.add_argument("--nusc", action="store_true")
+    ap.add_argument("--oracle", action="store_true")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--shards", type=int, default=2, help="distinct shards cycled through in the timing loop")
+    a = ap.parse_args()
+    _lib.load()
+    dev = torch.device("cuda:0")
+    store = FrameStore(dev, 0.3)
+    ctx = _lib.Context(0)
+    shards, tabs = [], []
+    for q in range(a.shards):
+        t0 = time.time()
+        sh = synth.make_shard(a.scans, n_live=a.n, n_trav=a.trav, n_frames=a.frames, nusc=a.nusc, seed=q, x0=40.0 * q)
+        lives, descs = load_shard(store, sh, dev, key0=1000000 * q)
+        shards.append(sh)
+        tabs.append((lives, descs))
+        print(f"shard {q}: generated + loaded in {time.time() - t0:.1f} s", flush=True)
+    T = a.trav
+    ok = True
+    for q, (lives, descs) in enumerate(tabs):
+        Hb, cb = store.pp_score_batch(lives, descs, T, return_counts=True, ctx=ctx, block=True)
+        Hv, cv = store.pp_score_batch(lives, descs, T, return_counts=True, ctx=ctx, block=False)
+        torch.cuda.synchronize()
+        for i in range(len(lives)):
+            same = torch.equal(cb[i], cv[i])
+            if not same:
+                d = (cb[i] != cv[i])
+                print(f"shard {q} scan {i}: counts DIFFER from the per-scan chain: {int(d.sum())} of {d.numel()} "
+                      f"(block sum {int(cb[i].sum())}, chain sum {int(cv[i].sum())})")
+            ok &= same
+            ok &= bool(torch.equal(Hb[i], Hv[i]))
+        if a.oracle:
+            from oracle import pp_score as opp
+            for i in (0, len(lives) - 1):
+                lv, hist = shards[q].stacked(i)
+                Href, cref = opp.pp_score(lv, hist, 0.3, workers=-1)
+                e = np.array_equal(cb[i].cpu().numpy().astype(np.int64), cref)
+                print(f"shard {q} scan {i}: block == oracle: {e}")
+                ok &= e
+    print("PARITY", "OK" if ok else "FAILED", "block calls", getattr(store, "block_calls", 0), flush=True)
+    for mode in (True, False):
+        ctx.profile_begin(a.reps * a.shards + 4)
+        for r in range(a.reps):
+            for lives, descs in tabs:
+                store.pp_score_batch(lives, descs, T, ctx=ctx, block=mode)
+        torch.cuda.synchronize()
+        ms = ctx.profile_collect(a.reps * a.shards + 4)
+        per = float(np.mean(ms[a.shards:])) / a.scans
+        alg = 12 * a.trav * a.frames * a.n + 16 * a.n
+        print(f"{'block' if mode else 'chain'}: {np.mean(ms[a.shards:]):.3f} ms per call of {a.scans} scans = {per * 1e3:.1f} us/scan "
+              f"-> {alg / per / 1e6:.0f} GB/s = {alg / per / 1e6 / 8000 * 100:.1f} % of 8 TB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

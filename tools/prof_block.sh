@@ -1,0 +1,14 @@
+#!/bin/bash
+# per-kernel durations of the block path: rocprofv3 kernel trace of tools/pp_block_probe.py
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_block
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o blk -- python $GRAFT_REPO_ROOT/tools/pp_block_probe.py "$@" > $OUT/run.log 2>&1
+tail -5 $OUT/run.log
+python - <<PY
+import csv, glob, collections
+f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:40]:
+    print(f"{r['Name'][:70]:70s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
+PY
