@@ -68,10 +68,21 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-mask-chain", action="store_true",
                     help="A/B: the mask stage scan by scan (modest_mask_stage) instead of one call per chain of --pp-batch scans")
-    ap.add_argument("--scans", type=int, default=4, help="distinct resident scans per host process, cycled through")
-    ap.add_argument("--pp-batch", type=int, default=4,
-                    help="scans whose PP stage goes through ONE chain of launches (modest_pp_score_frames_batch); "
-                         "clamped to --scans; 1 = one chain per scan")
+    ap.add_argument("--scans", type=int, default=32,
+                    help="resident scans per host process, cycled through: CONSECUTIVE scans of synthetic shards of --shard-scans "
+                         "scans each (consecutive scans of a Lyft shard share 35 of their 36 history frames per traversal)")
+    ap.add_argument("--shard-scans", type=int, default=16, help="consecutive scans per resident shard")
+    ap.add_argument("--pp-batch", type=int, default=16,
+                    help="consecutive scans whose PP stage is ONE call (FrameStore.pp_score_batch: modest_pp_score_block for >= 6 "
+                         "scans that share their frames, modest_pp_score_frames_batch otherwise); clamped to --shard-scans")
+    ap.add_argument("--mask-batch", type=int, default=4, help="scans per chain of stages 2 + 3 (modest_mask_stage_batch)")
+    ap.add_argument("--no-pp-block", action="store_true",
+                    help="A/B: the PP stage through modest_pp_score_frames_batch (every scan streams its own 361 frames) in chains of "
+                         "at most 8 scans, never through modest_pp_score_block")
+    ap.add_argument("--config", choices=("c3", "c5"), default="c3",
+                    help="BASELINE.json configuration: c3 = Lyft shape (30 k live points, 10 traversals x 36 frames); c5 = nuScenes "
+                         "shape (35 k points, 20 traversals x 16 frames, remove_center on the history, plane_estimate.max_hs=-1.3, "
+                         "image_shape=[900,1600]; README.md:62-70).  c5 sets --n-live / --traversals / --frames")
     ap.add_argument("--n-live", type=int, default=30000)
     ap.add_argument("--traversals", type=int, default=10)
     ap.add_argument("--frames", type=int, default=36)
@@ -101,7 +112,11 @@ def parse(argv=None):
     ap.add_argument("--cli-scans", type=int, default=768,
                     help="live scans of the CLI measurement (0 = skip): the three product CLIs on a synthetic KITTI "
                          "tree, 10 history traversals x 36 frames per scan, frames shared between consecutive scans")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    a.nusc = a.config == "c5"
+    if a.nusc:
+        a.n_live, a.traversals, a.frames = 35000, 20, 16
+    return a
 
 
 # --------------------------------------------------------------------------- launcher
@@ -131,52 +146,83 @@ def maybe_relaunch(a, argv) -> None:
 
 
 # --------------------------------------------------------------------------- resident inputs
-class ResidentScan:
-    """One scan as the CLI holds it: frames in the frame store + descriptor table.  For the ingest-inclusive
-    step it also keeps, in pinned host memory, the raw frames a scan of a Lyft shard brings in new (one per
-    traversal + the live scan = 11 of its 361) and the raw pose factors of all of them."""
+GEN_STRIDE = 1 << 20   # the re-inserted copy of a frame (ingest-inclusive step) alternates between two integer keys
 
-    def __init__(self, s, dev, calib, store, key, slot_base):
-        from modest_amd.pre_compute_pp_score import relative_poses
-        self.calib = calib
-        self.live_host = s.live_raw
-        self.live_raw = torch.from_numpy(s.live_raw).to(dev)
-        self.M = int(sum(len(h) for h in s.hist))
-        self.N = int(s.live_xyz.shape[0])
-        self.T = len(s.hist)
-        items, self.hist_keys, rels, Ws = [], [], [], []
-        for t, fr in enumerate(s.frames):
-            for f, (raw, rel, W) in enumerate(fr):
-                k = (key, t, f)
-                items.append((k, torch.from_numpy(raw).to(dev), W))
-                self.hist_keys.append((k, t))
-                rels.append(rel)
-                Ws.append(W)
-        self.live_key = (key, "live")
-        items.append((self.live_key, self.live_raw, s.live_W))
+
+class ResidentShard:
+    """S consecutive scans of a shard as the CLI holds them: every frame once in the frame store, a descriptor table
+    per scan.  Scan i of the shard looks at frames i .. i+F-1 of every traversal's track (synth.make_shard)."""
+
+    def __init__(self, sh, dev, calib, store, base, nusc=False):
+        self.store, self.dev, self.base, self.nusc = store, dev, int(base), bool(nusc)
+        self.T, self.L = len(sh.tracks), len(sh.tracks[0])
+        self.W, self.gen, self.raw_host, items = {}, {}, {}, []
+        for t, tr in enumerate(sh.tracks):
+            for j, (raw, W) in enumerate(tr):
+                fid = self.base + t * self.L + j
+                self.W[fid], self.gen[fid] = W, 0
+                items.append((fid, torch.from_numpy(raw).to(dev), W))
+        self.scans = []
+        for sc in sh.scans:
+            lid = self.base + self.T * self.L + sc.index
+            self.W[lid], self.gen[lid] = sc.live_W, 0
+            items.append((lid, torch.from_numpy(sc.live_raw).to(dev), sc.live_W))
         store.insert_many(items)
-        self.rels = np.stack(rels)
-        self.live_rel, self.A44 = s.live_rel, s.world_from_ref
-        self.desc = store.describe(self.live_key, self.live_rel, [k for k, _ in self.hist_keys],
-                                   [t for _, t in self.hist_keys], self.rels)
-        # ---- ingest-inclusive step: the scan's 11 "new" frames (last frame of every traversal + the live scan)
-        self.W_stack = np.stack(Ws + [s.live_W])                      # raw pose factors E @ L @ K of all 361 frames
-        self.fixed_ego, self.fixed_l2e, self.K = s.first_pose, s.l2e, s.K
+        for sc in sh.scans:
+            self.scans.append(ResidentScan(self, sh, sc, calib))
+
+    def key(self, fid):
+        return fid + GEN_STRIDE * self.gen[fid]
+
+
+class ResidentScan:
+    """One scan of a resident shard.  For the ingest-inclusive step it also keeps, in pinned host memory, the raw frames
+    the scan brings in new (the last frame of every traversal's window + the live scan = 11 of its 361) and the raw pose
+    factors of all of them."""
+
+    def __init__(self, shard, sh, sc, calib):
+        from modest_amd.pre_compute_pp_score import relative_poses
+        self.shard, self.calib = shard, calib
+        self.live_host = sc.live_raw
+        self.live_id = shard.base + shard.T * shard.L + sc.index
+        self.live_raw = torch.from_numpy(sc.live_raw).to(shard.dev)   # file order, for stages 2 + 3
+        self.N, self.T = int(sc.live_raw.shape[0]), shard.T
+        self.hist_ids = [shard.base + t * shard.L + j for t, j in sc.hist]
+        self.travs = [t for t, _ in sc.hist]
+        self.M = int(sum(len(sh.tracks[t][j][0]) for t, j in sc.hist))   # (history points before remove_center)
+        self.rels, self.live_rel, self.A44 = sc.rels, sc.live_rel, sc.world_from_ref
+        self.W_stack = np.stack([shard.W[f] for f in self.hist_ids] + [sc.live_W])   # raw pose factors E @ L @ K of all 361 frames
+        self.fixed_ego, self.fixed_l2e, self.K = sc.first_pose, sc.l2e, sc.K
         assert np.array_equal(relative_poses(self.fixed_l2e, self.fixed_ego, self.W_stack, self.K)[:-1], self.rels)
-        F = len(s.frames[0])
-        self.new_pos = [t * F + (F - 1) for t in range(self.T)]        # positions in hist_keys that are replaced
-        raws = [s.frames[t][F - 1][0] for t in range(self.T)] + [s.live_raw]
-        self.new_W = np.stack([s.frames[t][F - 1][2] for t in range(self.T)] + [s.live_W])
+        F = len(sc.hist) // shard.T
+        # ---- ingest-inclusive step: the scan's 11 "new" frames (last frame of every traversal's window + the live scan)
+        self.new_ids = [self.hist_ids[t * F + F - 1] for t in range(shard.T)] + [self.live_id]
+        raws = [sh.tracks[t][sc.hist[t * F + F - 1][1]][0] for t in range(shard.T)] + [sc.live_raw]
+        self.new_W = np.stack([shard.W[f] for f in self.new_ids])
         self.new_offs = np.cumsum([0] + [len(r) for r in raws])
         self.new_pinned = torch.empty((int(self.new_offs[-1]), 4), dtype=torch.float32, pin_memory=True)
         self.new_pinned.numpy()[:] = np.concatenate(raws)
-        self.slot_base = slot_base    # integer keys of the re-inserted frames: slot_base + 16 * generation parity + j
-        self.gen = 0
+        self.desc = None
+        self.describe()
+
+    @property
+    def live_key(self):
+        return self.shard.key(self.live_id)
+
+    def describe(self, rels=None):
+        """the scan's descriptor table from the store (the frames' current copies)"""
+        sh = self.shard
+        rl = self.rels if rels is None else rels[:-1]
+        lr = self.live_rel if rels is None else rels[-1]
+        self.desc = sh.store.describe(self.live_key, lr, [sh.key(f) for f in self.hist_ids], self.travs, rl, sh.nusc)
+        return self.desc
 
 
 class Runner:
-    """The pipeline of one host process: resident synthetic scans, `n_threads` worker threads with
-    one HIP stream + modest_ctx each."""
+    """The pipeline of one host process: resident synthetic shards, `n_threads` worker threads with one HIP stream +
+    modest_ctx each.  Steps are numbered globally; step i takes resident scan i mod n, a BLOCK is the steps of one
+    multiple of --pp-batch (= consecutive scans of one shard): its PP stage is one call, its stages 2 + 3 run in chains
+    of --mask-batch scans."""
 
     def __init__(self, a, rank, local, slot):
         import threading
@@ -206,123 +252,87 @@ class Runner:
             os.environ["MODEST_NUM_CUS"] = str(a.pp_cus)
         self.ctxs = [_lib.Context(local) for _ in range(self.n_threads)]
         self.prefetch = not (a.no_prefetch or a.pp_only or a.mask_only)
-        self.B = max(1, min(int(a.pp_batch), int(a.scans)))
+        self.S = max(1, min(int(a.shard_scans), int(a.scans)))
+        self.PB = max(1, min(int(a.pp_batch), self.S))
+        while self.S % self.PB:   # blocks never straddle shards
+            self.PB -= 1
+        self.MB = max(1, int(a.mask_batch))
+        self.block = False if a.no_pp_block else None   # None: FrameStore decides (>= 6 scans that share their frames)
         self.mark_batch = [[] for _ in range(self.n_threads)]   # scans per profile mark, per thread
         self.pp_ctxs = self.ctxs
-        # the mask stage of a chain runs every scan in its own context (the thread's + B - 1 more)
-        self.chain_ctxs = [[self.ctxs[w]] + [_lib.Context(local) for _ in range(self.B - 1)] for w in range(self.n_threads)]
+        # the mask stage of a chain runs every scan in its own context (the thread's + MB - 1 more)
+        self.chain_ctxs = [[self.ctxs[w]] + [_lib.Context(local) for _ in range(self.MB - 1)] for w in range(self.n_threads)]
         if shared:
             del os.environ["MODEST_NUM_CUS"]
         self._lib, self.local, self.iso_ctx = _lib, local, None
         with tempfile.TemporaryDirectory() as d:
             open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
             calib = kitti_util.Calibration(os.path.join(d, "c.txt"))
-        self.margs = config.compose("generate_mask", ["data_root=/unused"])
-        self.largs = config.compose("generate_label_files", ["data_root=/unused"])
+        nusc = bool(getattr(a, "nusc", False))
+        self.margs = config.compose("generate_mask", ["data_root=/unused"] + (["plane_estimate.max_hs=-1.3"] if nusc else []))
+        self.largs = config.compose("generate_label_files", ["data_root=/unused"] + (["image_shape=[900,1600]"] if nusc else []))
         self.store = FrameStore(self.dev, 0.3, ctx=self.ctxs[0])
-        self.scans = []
-        for i in range(a.scans):
-            sid = scan_seed(rank, slot, i)
-            s = synth.make_scan(sid, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames, keep_frames=True)
-            self.scans.append(ResidentScan(s, self.dev, calib, self.store, sid, 64 * i))
-            del s
+        self.shards, self.scans = [], []
+        n_sh = max(1, (int(a.scans) + self.S - 1) // self.S)
+        for q in range(n_sh):
+            n_sc = min(self.S, int(a.scans) - q * self.S) if a.scans >= self.S else int(a.scans)
+            sh = synth.make_shard(n_sc, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames, seed=scan_seed(rank, slot, q),
+                                  x0=30.0 * q, nusc=bool(getattr(a, "nusc", False)))
+            rs = ResidentShard(sh, self.dev, calib, self.store, 4096 * 64 * q, nusc)
+            self.shards.append(rs)
+            self.scans.extend(rs.scans)
+            del sh
         self.ingest = False
-        self.scan_locks = [threading.Lock() for _ in self.scans]   # ingest mode re-inserts a scan's frames: one step at a time per scan
+        self.lock = threading.Lock()   # ingest mode re-inserts frames: one block at a time per process
         # every thread (stream + scratch arena + kernel attributes) runs before any clock starts
-        self.n_warm = max(a.warmup, 2 * self.n_threads, self.B * self.n_threads)   # at least one full chain per thread
+        self.n_warm = -(-max(a.warmup, 2 * self.n_threads, self.PB * self.n_threads) // self.PB) * self.PB   # whole blocks
         self.run(0, self.n_warm)
         torch.cuda.synchronize()
 
     def scan_of(self, i):
-        """step -> resident scan: a thread's consecutive steps take distinct scans (a batch never holds one twice)"""
-        return self.scans[(i // self.n_threads + i % self.n_threads) % len(self.scans)]
-
-    def pp(self, sc, ctx, return_counts=False):
-        if self.ingest:
-            return self.pp_with_ingest(sc, ctx)
-        return self.store.pp_score(sc.live_key, sc.live_rel, sc.hist_keys, sc.rels, sc.A44, sc.T, ctx=ctx,
-                                   desc=sc.desc, return_counts=return_counts)
+        return self.scans[i % len(self.scans)]
 
     def pp_many(self, scs, w):
-        """PP stage of several scans: one chain of launches for all of them (B > 1) -> [H]"""
+        """PP stage of the scans of one block: ONE call -> [H]"""
         ctx = self.ctxs[w]
         self.mark_batch[w].append(len(scs))
-        if len(scs) == 1:
-            return [self.pp(scs[0], ctx)]
-        if not self.ingest:
-            return self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx)
-        order = sorted(range(len(scs)), key=lambda q: self.scans.index(scs[q]))
-        locks = [self.scan_locks[self.scans.index(scs[q])] for q in order]
-        for lk in locks:
-            lk.acquire()
-        try:
-            made = self._ingest(scs, ctx)
-            return self.store.pp_score_batch([k for k, _ in made], [d for _, d in made], scs[0].T, ctx=ctx)
-        finally:
-            for lk in reversed(locks):
-                lk.release()
+        return self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx, block=self.block)
 
     def _ingest(self, scs, ctx):
-        """What the scans of a Lyft shard cost before their kernels can start (consecutive scans share 35
-        of 36 frames per traversal): the 11 new frames of every scan travel from pinned host memory to the device and
-        are tile-sorted (one device block and ONE sort launch for the whole chain), the relative poses of all 361 frames
-        are solved from the raw pose factors (get_relative_pose), and the descriptor tables are built from the store --
-        nothing of a scan's table is reused from a previous step.  -> [(live key, descriptor table)]"""
+        """What the scans of a Lyft shard cost before their kernels can start (consecutive scans share 35 of
+        36 frames per traversal): the 11 new frames of every scan travel from pinned host memory to the device and are
+        tile-sorted (one device block and ONE sort launch for the whole block of scans), the relative poses of all 361
+        frames of every scan are solved from the raw pose factors (get_relative_pose), and the descriptor tables are
+        rebuilt from the store -- nothing of a scan's table is reused from a previous step.  A re-inserted frame replaces
+        its resident copy for every scan of the shard (the sharing between the scans is that of the CLI)."""
         from modest_amd.pre_compute_pp_score import relative_poses
+        sh = scs[0].shard
         keys_all, offs, Ws, base = [], [0], [], 0
         dev = torch.empty((sum(int(sc.new_pinned.shape[0]) for sc in scs), 4), dtype=torch.float32, device=self.dev)
-        per = []
+        old = []
         for sc in scs:
-            sc.gen += 1
-            keys = [sc.slot_base + 16 * (sc.gen & 1) + j for j in range(len(sc.new_offs) - 1)]
-            self.store.drop([sc.slot_base + 16 * ((sc.gen + 1) & 1) + j for j in range(len(sc.new_offs) - 1)])
             n = int(sc.new_pinned.shape[0])
             dev[base:base + n].copy_(sc.new_pinned, non_blocking=True)
-            keys_all += keys
+            for j, fid in enumerate(sc.new_ids):
+                old.append(sh.key(fid))
+                sh.gen[fid] ^= 1
+                keys_all.append(sh.key(fid))
             offs += [base + int(o) for o in sc.new_offs[1:]]
             Ws.append(sc.new_W)
             base += n
-            per.append(keys)
+        self.store.drop(old)
         self.store.insert_block(keys_all, dev, np.asarray(offs), np.concatenate(Ws), ctx=ctx)
-        out = []
-        for sc, keys in zip(scs, per):
-            rels = relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K)
-            hist_keys = list(sc.hist_keys)
-            for j, pos in enumerate(sc.new_pos):
-                hist_keys[pos] = (keys[j], hist_keys[pos][1])
-            out.append((keys[-1], self.store.describe(keys[-1], rels[-1], [k for k, _ in hist_keys],
-                                                      [t for _, t in hist_keys], rels[:-1])))
-        return out
-
-    def pp_with_ingest(self, sc, ctx):
-        with self.scan_locks[self.scans.index(sc)]:
-            key, desc = self._ingest([sc], ctx)[0]
-            return self.store.pp_score_batch([key], [desc], sc.T, ctx=ctx)[0]   # one scan: the library takes the single-scan chain
-
-    def step(self, i, w, H=None, after=None):
-        """One scan through the pipeline on thread w (a chain of one).  Returns (H, labels, objs, text)."""
-        return self.steps([i], w, [H], after)[0]
+        for sc in sh.scans:   # every scan of the shard sees the new copies (the block's own scans solve their poses again)
+            sc.describe(relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K) if sc in scs else None)
 
     def steps(self, js, w, Hs, after=None):
-        """The scans of one chain through the pipeline on thread w.  Hs: their PP scores when they were enqueued ahead
-        of time (None: computed here); the mask stage of the chain is ONE library call (generate_mask_chain: the mask /
-        graph / DBSCAN block and the cluster statistics as one launch per kernel for all of them), boxes and labels go
-        scan by scan; after: called (same stream, same context) as soon as the LAST scan has no device work left, i.e.
-        under the host tail of its label stage -- the worker enqueues the PP stage of its next chain there.
-        Returns [(H, labels, objs, text)]."""
-        a, ctx = self.a, self.ctxs[w]
+        """The scans of one chain of stages 2 + 3 on thread w.  Hs: their PP scores (enqueued ahead of time); the mask stage
+        of the chain is ONE library call (generate_mask_chain: the mask / graph / DBSCAN block and the cluster statistics as
+        one launch per kernel for all of them), boxes and labels go scan by scan; after: called (same stream, same
+        context) as soon as the LAST scan has no device work left, i.e. under the host tail of its label stage -- the
+        worker enqueues the PP stage of its next block there.  Returns [(H, labels, objs, text)]."""
+        a = self.a
         scs = [self.scan_of(i) for i in js]
-        Hs = list(Hs)
-        if a.mask_only:   # diagnostic: the PP score of a scan is computed once, steps run stages 2 + 3
-            for q, sc in enumerate(scs):
-                if getattr(sc, "_H", None) is None:
-                    sc._H = self.pp(sc, ctx)
-                Hs[q] = sc._H
-        else:
-            todo = [q for q, H in enumerate(Hs) if H is None]
-            if todo:
-                for q, H in zip(todo, self.pp_many([scs[q] for q in todo], w)):
-                    Hs[q] = H
         if a.pp_only:
             return [(H, None, None, None) for H in Hs]
         # boxes stay (k,8) rows between the stages: the SimpleNamespace objects of the reference exist for its
@@ -341,33 +351,59 @@ class Runner:
                    for q, (r, sc) in enumerate(zip(res, scs))]
         return [(H, labels, objs, text) for H, (labels, objs, _), (text, kept) in zip(Hs, res, lab)]
 
-    def run(self, lo, hi):
-        """steps lo..hi-1, dealt round-robin to the worker threads"""
+    def blocks_of(self, lo, hi):
+        """steps lo..hi-1 cut at the multiples of the block size -> [[step, ...], ...]"""
+        out, i = [], lo
+        while i < hi:
+            e = min(hi, (i // self.PB + 1) * self.PB)
+            out.append(list(range(i, e)))
+            i = e
+        return out
+
+    def run(self, lo, hi, collect=None):
+        """steps lo..hi-1: the blocks are dealt round-robin to the worker threads"""
         errs = []
+        blocks = self.blocks_of(lo, hi)
 
         def worker(w):
             try:
                 torch.cuda.set_device(self.dev)
                 with torch.cuda.stream(self.streams[w]):
-                    idx = list(range(lo + w, hi, self.n_threads))
-                    B, Hq = self.B, {}
-                    cuts = list(range(0, len(idx), B)) + [len(idx)]
-                    end_of = {}
-                    for c0, c1 in zip(cuts[:-1], cuts[1:]):
-                        for k in range(c0, c1):
-                            end_of[k] = c1
+                    mine = blocks[w::self.n_threads]
+                    Hq = {}
 
-                    def enqueue(k0):   # the PP stage of the chain that starts at step idx[k0]: one chain of launches
-                        js = idx[k0:end_of[k0]]
+                    def enqueue(bi):   # the PP stage of block bi: one call
+                        js = mine[bi]
+                        if self.a.mask_only:   # diagnostic: the PP score of a scan is computed once, steps run stages 2 + 3
+                            for j in js:
+                                sc = self.scan_of(j)
+                                if getattr(sc, "_H", None) is None:
+                                    sc._H = self.pp_many([sc], w)[0]
+                                Hq[j] = sc._H
+                            return
                         Hq.update(zip(js, self.pp_many([self.scan_of(j) for j in js], w)))
 
-                    for c0, c1 in zip(cuts[:-1], cuts[1:]):
-                        js = idx[c0:c1]
-                        if not self.a.mask_only and js[0] not in Hq:
-                            enqueue(c0)
-                        # the next chain's PP stage goes out under the label tail of this chain's last scan
-                        hook = (lambda k1=c1: enqueue(k1)) if (self.prefetch and c1 < len(idx)) else None
-                        self.steps(js, w, [Hq.pop(j, None) for j in js], after=hook)
+                    def ingest(bi):   # ingest-inclusive mode: the new frames of block bi (copy + sort + poses + tables)
+                        with self.lock:
+                            self._ingest([self.scan_of(j) for j in mine[bi]], self.ctxs[w])
+
+                    for bi, js in enumerate(mine):
+                        if js[0] not in Hq:
+                            if self.ingest:
+                                ingest(bi)
+                            enqueue(bi)
+                        # like the CLI's ingest thread, the frames of the NEXT block are brought in one block ahead of their
+                        # kernels: by the time its PP stage is enqueued the sort has reported every frame's point count
+                        if self.ingest and bi + 1 < len(mine):
+                            ingest(bi + 1)
+                        chains = [js[c:c + self.MB] for c in range(0, len(js), self.MB)]
+                        for ci, cj in enumerate(chains):
+                            # the next block's PP stage goes out under the label tail of this block's last chain
+                            last = ci == len(chains) - 1
+                            hook = (lambda b1=bi + 1: enqueue(b1)) if (self.prefetch and last and bi + 1 < len(mine)) else None
+                            out = self.steps(cj, w, [Hq.pop(j) for j in cj], after=hook)
+                            if collect is not None:
+                                collect.extend(zip(cj, out))
                     self.streams[w].synchronize()
             except Exception as e:   # surfaced after join
                 errs.append(e)
@@ -386,8 +422,8 @@ class Runner:
     def timed(self, n_steps, ingest=False):
         """n_steps steps -> (seconds, HIP-event times of every PP stage launched)"""
         self.ingest = bool(ingest)
-        if ingest:   # two untimed chains per thread in this mode first (allocator, slab, slot tables)
-            self.run(0, 2 * self.B * self.n_threads)
+        if ingest:   # two untimed blocks per thread in this mode first (allocator, slab, slot tables)
+            self.run(0, 2 * self.PB * self.n_threads)
             torch.cuda.synchronize()
         for w, c_ in enumerate(self.pp_ctxs):
             c_.profile_begin(n_steps + 8)
@@ -397,7 +433,7 @@ class Runner:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         self.ingest = False
-        per_scan = []   # a mark brackets the chain of a whole batch: report it per scan, once per scan
+        per_scan = []   # a mark brackets the PP stage of a whole block: report it per scan, once per scan
         for w, c_ in enumerate(self.pp_ctxs):
             ms = c_.profile_collect(n_steps + 8)
             sizes = self.mark_batch[w][-len(ms):] if len(ms) else []
@@ -406,26 +442,28 @@ class Runner:
         return dt, np.asarray(per_scan, dtype=np.float32)
 
     def isolated_pp_ms(self):
-        """The PP stage alone on the GPU: chains of B scans (all resident scans, >= 4 x 130 MB of distinct
-        history: the 256 MiB Infinity Cache cannot hold the working set), HIP events around every chain.
-        -> (ms per chain, scans per chain)"""
-        B = self.B
-        reps = 8
+        """The PP stage alone on the GPU: one call per block of PB consecutive scans, cycling through all resident shards
+        (their block stores + frames exceed the 256 MiB Infinity Cache), HIP events around every call.
+        -> (ms per call, scans per call, block path used)"""
+        PB, n = self.PB, len(self.scans)
+        nb = max(1, n // PB)
+        reps = max(6, 3 * nb)
         if self.iso_ctx is None:   # alone on the GPU: grids sized for all CUs
             self.iso_ctx = self._lib.Context(self.local)
         ctx = self.iso_ctx
-        ctx.profile_begin(reps + 4)
+        calls0 = getattr(self.store, "block_calls", 0)
+        ctx.profile_begin(8 * reps + 8)
         with torch.cuda.stream(self.streams[0]):
             for i in range(reps):
-                scs = [self.scans[(i * B + q) % len(self.scans)] for q in range(B)]
-                if B == 1:
-                    self.store.pp_score(scs[0].live_key, scs[0].live_rel, scs[0].hist_keys, scs[0].rels, scs[0].A44, scs[0].T,
-                                        ctx=ctx, desc=scs[0].desc)
-                else:
-                    self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx)
+                scs = self.scans[(i % nb) * PB:(i % nb) * PB + PB]
+                self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx, block=self.block)
             self.streams[0].synchronize()
-        iso = ctx.profile_collect(reps + 4)
-        return (float(np.mean(iso[2:])), B) if len(iso) > 2 else None
+        iso = ctx.profile_collect(8 * reps + 8)
+        used_block = getattr(self.store, "block_calls", 0) > calls0
+        if len(iso) > reps:   # (the per-scan chain splits a call of more than 8 scans into several marks)
+            k = len(iso) // reps
+            iso = np.asarray(iso[:k * reps]).reshape(reps, k).sum(axis=1)
+        return (float(np.mean(iso[2:])), len(scs), used_block) if len(iso) > 2 else None
 
 
 def scan_seed(rank, slot, i):
@@ -474,20 +512,28 @@ def helper_count(procs: int, steps: int) -> int:
 # --------------------------------------------------------------------------- CPU baselines
 def _cpu_one_scan(args):
     """best-effort CPU worker: one process per scan, multi-threaded neighbour queries"""
-    sid, n_live, trav, frames, pp_only = args
+    sid, n_live, trav, frames, pp_only, nusc = args
     from modest_amd import synth
     from oracle import labels as ol
     from oracle import mask as om
     from oracle import pp_score as opp
-    s = synth.make_scan(sid, n_live=n_live, n_trav=trav, n_frames=frames)
+    sh = synth.make_shard(1, n_live=n_live, n_trav=trav, n_frames=frames, seed=sid, nusc=nusc)
+    live_xyz, hist = sh.stacked(0)
+    live_raw = sh.scans[0].live_raw
+    del sh
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
         ocalib = ol.Calibration(os.path.join(d, "c.txt"))
     t0 = time.perf_counter()
-    H, _ = opp.pp_score(s.live_xyz, s.hist, 0.3, workers=-1)
+    H, _ = opp.pp_score(live_xyz, hist, 0.3, workers=-1)
     if not pp_only:
-        ref = om.generate_mask_scan(s.live_raw, H, ocalib, random_state=np.random.RandomState(0), n_jobs=-1)
-        ol.gen_label_scan(ref["objs"], ocalib)
+        cfg = None
+        if nusc:
+            import copy
+            cfg = copy.deepcopy(om.DEFAULT_CFG)
+            cfg["plane_estimate"]["max_hs"] = -1.3
+        ref = om.generate_mask_scan(live_raw, H, ocalib, cfg=cfg, random_state=np.random.RandomState(0), n_jobs=-1)
+        ol.gen_label_scan(ref["objs"], ocalib, **({"image_shape": (900, 1600)} if nusc else {}))
     return t0, time.perf_counter()
 
 
@@ -498,7 +544,7 @@ def cpu_best_effort(a):
     n = a.cpu_best_effort
     ctx = mp.get_context("spawn")
     with ctx.Pool(processes=n) as pool:
-        spans = pool.map(_cpu_one_scan, [(5000 + i, a.n_live, a.traversals, a.frames, a.pp_only) for i in range(n)])
+        spans = pool.map(_cpu_one_scan, [(5000 + i, a.n_live, a.traversals, a.frames, a.pp_only, bool(a.nusc)) for i in range(n)])
     t_lo, t_hi = min(s[0] for s in spans), max(s[1] for s in spans)
     return n / (t_hi - t_lo), t_hi - t_lo
 
@@ -686,7 +732,7 @@ def main():
 
     # the same stage with nothing else on the GPU (the timed region has several scans in flight, so its
     # event pairs also see the other scans' kernels): informational, not the reported `achieved`
-    iso_ms, iso_B = None, 1
+    iso_ms, iso_B, iso_block = None, 1, False
     if rank == 0:
         if helpers:
             helpers[0][1].send(("iso", None))
@@ -694,7 +740,7 @@ def main():
         else:
             iso = runner.isolated_pp_ms()
         if iso:
-            iso_ms, iso_B = float(iso[0]), int(iso[1])   # ms per chain of launches, scans per chain
+            iso_ms, iso_B, iso_block = float(iso[0]), int(iso[1]), bool(iso[2])   # ms per call, scans per call, block path
     for p, pc in helpers:
         pc.send(("exit", None))
     for p, pc in helpers:
@@ -710,20 +756,29 @@ def main():
     # the event pairs of the timed region also bracket the other scans' kernels and are reported as `in_pipeline`
     achieved = iso_B * alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms else contended
     traffic, traffic_src = None, None
-    for tname in ("r03_pp_traffic.json", "r02_pp_traffic.json", "r01_pp_traffic.json"):
+    tnames = (("r04_pp_block_traffic.json",) if iso_block else ()) + ("r03_pp_traffic.json", "r02_pp_traffic.json", "r01_pp_traffic.json")
+    for tname in tnames:
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
             tj = json.load(open(tpath))
-            if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes:
+            if int(tj.get("algorithmic_bytes_per_scan", 0)) == alg_bytes and (iso_block == bool(tj.get("block_path", False))):
                 traffic, traffic_src = tj["hbm_bytes_per_scan"] * (iso_B if iso_ms else 1), f"profiles/{tname} (" + tj["source"] + ")"   # per launch, like `achieved`
                 break
-    pp_B = max(1, min(a.pp_batch, a.scans))
+    pp_B = max(1, min(a.pp_batch, a.shard_scans, a.scans))
+    kernel_txt = (f"PP neighbour count of a BLOCK of {iso_B} consecutive scans of a shard, ONE call (modest_pp_score_block): list sizes "
+                  "from the frames' tile tables (b4_counts / b4_lists / b4_bases) + ONE pass over the union of the block's frames "
+                  "(b4_scatter: 36 + 15 frames per traversal instead of 16 x 36) + counting sort of the tile lists by cell "
+                  "(b4_seg_*) + per scan: live index on the lattice (b4_live_*, b4_scan_*), plan (b4_plan_*), sort-free join "
+                  "(b4_join: records read into registers, the scan's float32 pose applied per record, packed-float pair tests): "
+                  "ALL launches of the call, HIP events on the launch stream"
+                  if iso_block else
+                  f"PP neighbour count, ONE chain of launches for {iso_B} scan(s) (modest_pp_score_frames_batch: every "
+                  "kernel takes the scan as blockIdx.y) = live prep (transform + bounding box + clears) + live index "
+                  "build (5 launches) + pp3_stream<count> + pp3_scan + pp3_plan + pp3_stream<scatter> + pp3_join: ALL "
+                  "launches of the stage, HIP events on the launch stream; the history is read from the frame store "
+                  "through the descriptor table (pose fused), not from a stacked copy")
     roofline = {"bound": "hbm",
-                "kernel": f"PP neighbour count, ONE chain of launches for {iso_B} scan(s) (modest_pp_score_frames_batch: every "
-                          "kernel takes the scan as blockIdx.y) = live prep (transform + bounding box + clears) + live index "
-                          "build (5 launches) + pp3_stream<count> + pp3_scan + pp3_plan + pp3_stream<scatter> + pp3_join: ALL "
-                          "launches of the stage, HIP events on the launch stream; the history is read from the frame store "
-                          "through the descriptor table (pose fused), not from a stacked copy",
+                "kernel": kernel_txt, "block_path": iso_block,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -733,9 +788,12 @@ def main():
                 "algorithmic_bytes_per_scan": alg_bytes,
                 "kernel_ms": iso_ms if iso_ms else k_ms,
                 "kernel_ms_per_scan": (iso_ms / iso_B) if iso_ms else k_ms,
-                "measured": (f"HIP events on the launch stream around the chain, one chain at a time on an otherwise idle GPU, "
-                             f"the {a.scans} distinct resident scans (> 256 MiB of history: the Infinity Cache cannot hold "
-                             "them), after the timed region") if iso_ms else "HIP events in the timed region",
+                "measured": (f"HIP events on the launch stream around the call, one call at a time on an otherwise idle GPU, cycling "
+                             f"through the {a.scans} resident scans = {max(1, a.scans // max(1, a.shard_scans))} shard(s) of "
+                             f"{a.shard_scans} consecutive scans (every shard: {(a.frames + a.shard_scans - 1) * a.traversals} "
+                             "history frames; frames + block store of a shard exceed the 256 MiB Infinity Cache), after the timed "
+                             "region; algorithmic bytes = 12 B x the 10.8 M history points of EVERY scan + 16 B x its live points, "
+                             "whether or not consecutive scans share frames") if iso_ms else "HIP events in the timed region",
                 "in_pipeline": {"kernel_ms_per_scan": k_ms, "achieved": contended,
                                 "frac": (contended / HBM_PEAK_GBPS) if contended else None,
                                 "scans_timed": int(len(kernel_ms)), "scans_per_launch": pp_B,
@@ -750,7 +808,7 @@ def main():
     cli = None
     # the CLI leg first: with the CPU baselines (and the joblib worker processes they leave behind) before it, the first CLI
     # phase came out 3-4x slower in two of about ten default runs; stand-alone runs of the same CLI never did
-    if rank == 0 and ws == 1 and a.cli_scans > 0 and not a.pp_only:
+    if rank == 0 and ws == 1 and a.cli_scans > 0 and not a.pp_only and not a.nusc:
         try:
             cli = cli_bench(a, local)
         except Exception as e:
@@ -762,38 +820,47 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             open(os.path.join(d, "c.txt"), "w").write(synth.CALIB_TXT)
             ocalib = ol.Calibration(os.path.join(d, "c.txt"))
-        # the sample = the scans helper 0 (or the rank process) benchmarked: same generator, same seeds
-        host_scans = [synth.make_scan(scan_seed(rank, 0, i), n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames,
-                                      keep_frames=(i == 0))
-                      for i in range(min(a.cpu_scans, a.scans))]
-        n_cpu = len(host_scans)
+        # the sample = the first scans helper 0 (or the rank process) benchmarked: same generator, same seeds
+        n_cpu = min(a.cpu_scans, a.scans, a.shard_scans, max(1, min(a.pp_batch, a.shard_scans, a.scans)))
+        hsh = synth.make_shard(n_cpu, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames, seed=scan_seed(rank, 0, 0), nusc=a.nusc)
+        ocfg = None
+        if a.nusc:
+            import copy
+            ocfg = copy.deepcopy(om.DEFAULT_CFG)
+            ocfg["plane_estimate"]["max_hs"] = -1.3
+        stacked = [hsh.stacked(i) for i in range(n_cpu)]
         refs = []
         tc = time.perf_counter()
         for i in range(n_cpu):
-            s = host_scans[i]
-            Href, cref = opp.pp_score(s.live_xyz, s.hist, 0.3, workers=1)       # reference: single thread
+            live_xyz, hist = stacked[i]
+            Href, cref = opp.pp_score(live_xyz, hist, 0.3, workers=1)       # reference: single thread
             ref = None
             if not a.pp_only:
-                ref = om.generate_mask_scan(s.live_raw, Href, ocalib, random_state=np.random.RandomState(i), n_jobs=-1)
-                ref["text"] = ol.gen_label_scan(ref["objs"], ocalib)
+                ref = om.generate_mask_scan(hsh.scans[i].live_raw, Href, ocalib, random_state=np.random.RandomState(i), n_jobs=-1,
+                                            **({"cfg": ocfg} if ocfg else {}))
+                ref["text"] = ol.gen_label_scan(ref["objs"], ocalib, **({"image_shape": (900, 1600)} if a.nusc else {}))
             refs.append((Href, cref, ref))
         tc = time.perf_counter() - tc
-        # parity of the measured path against the checker on the first sampled scan, outside every timed region
+        del stacked
+        # parity of the measured path against the checker, outside every timed region: the first block of helper 0's first
+        # shard (the scans the CPU sample took are its first ones) through ONE PP call, as the timed region runs it
         pa = argparse.Namespace(**vars(a))
-        pa.scans, pa.warmup, pa.streams = n_cpu, 0, 1
-        pa.pp_batch = min(max(a.pp_batch, 1), n_cpu)
+        pa.scans, pa.warmup, pa.streams = min(a.shard_scans, a.scans), 0, 1
         pr = Runner(pa, rank, local, 0)
-        # every sampled scan through ONE chain of launches, as the timed region runs them
-        Hgs, cgs = pr.store.pp_score_batch([sc.live_key for sc in pr.scans], [sc.desc for sc in pr.scans], pr.scans[0].T,
-                                           ctx=pr.ctxs[0], return_counts=True)
+        nblk = pr.PB
+        Hgs, cgs = pr.store.pp_score_batch([sc.live_key for sc in pr.scans[:nblk]], [sc.desc for sc in pr.scans[:nblk]],
+                                           pr.scans[0].T, ctx=pr.ctxs[0], return_counts=True, block=pr.block)
         Href, cref, ref = refs[0]
         parity = {"pp_counts_equal": bool(all(np.array_equal(cg.cpu().numpy().astype(np.int64), r[1])
                                               for cg, r in zip(cgs, refs))),
                   "pp_max_abs_err": float(max(np.max(np.abs(Hg.cpu().numpy().astype(np.float64) - r[0]))
                                               for Hg, r in zip(Hgs, refs))),
-                  "pp_scans_per_launch": len(cgs)}
+                  "pp_scans_per_call": len(cgs), "pp_scans_checked": n_cpu,
+                  "pp_block_path": getattr(pr.store, "block_calls", 0) > 0}
         if ref is not None:
-            _, labels, objs, text = pr.step(0, 0)
+            got = []
+            pr.run(0, 1, collect=got)
+            _, (_, labels, objs, text) = got[0]
             parity["labels_equal"] = bool(np.array_equal(labels, ref["labels"]))
             parity["n_objs"] = [len(objs), len(ref["objs"])]
             parity["label_text_equal"] = bool(text == ref["text"][0])
@@ -821,15 +888,22 @@ def main():
             "value": value, "unit": "scans/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("C2 PP-score only" if a.pp_only else "C3 full pipeline (PP + RANSAC + DBSCAN + box fit + iou3d NMS + labels)")
-                                   + f", Lyft-shape: {a.n_live} live pts vs {a.traversals} traversals x {a.frames} frames = {M} history pts",
+            "config": {"workload": (("C2 PP-score only" if a.pp_only else
+                                     ("C5 nuScenes-shape stress, full pipeline" if a.nusc else
+                                      "C3 full pipeline (PP + RANSAC + DBSCAN + box fit + iou3d NMS + labels)"))
+                                    + f", {'nuScenes' if a.nusc else 'Lyft'}-shape: {a.n_live} live pts vs {a.traversals} traversals x "
+                                      f"{a.frames} frames = {M} history pts"
+                                    + (" (remove_center on the history, max_hs=-1.3, 900x1600)" if a.nusc else "")),
                        "live_points": a.n_live, "history_points": M, "traversals": a.traversals,
                        "frames_per_traversal": a.frames, "radius": 0.3, "scans_per_rank": a.steps,
                        "history_input": "frame store + descriptor table (no stacked history)",
                        "host_processes_per_gpu": n_procs, "threads_per_process": n_threads,
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
                        "pp_stage_prefetch": (not (a.no_prefetch or a.pp_only or a.mask_only)),
-                       "pp_scans_per_launch": max(1, min(a.pp_batch, a.scans)),
+                       "pp_scans_per_call": pp_B, "mask_scans_per_chain": a.mask_batch,
+                       "resident_scans_per_process": a.scans, "shard_scans": a.shard_scans,
+                       "history_sharing": "consecutive scans of a shard: 35 of 36 frames per traversal shared with the predecessor "
+                                          "(data_preprocessing/lyft/split_traintest.py:64,97; SURVEY 8d C4)",
                        "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
                        "rccl_world_size": rccl_ws,
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},

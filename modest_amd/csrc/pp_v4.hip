@@ -49,7 +49,8 @@ constexpr int B4_MAXW = 160;               // block window: at most this many ti
 constexpr int B4_CH = 4096;                // points per streaming chunk (1024 threads x 4)
 constexpr int B4_SEG = 4096;               // records per sort segment (512 threads x 8)
 constexpr int B4_FG = 32;                  // frames per prefix group
-constexpr int B4_W = 10, B4_W1 = 11;       // window of a tile incl. halo (cells)
+constexpr int B4_QC = 16, B4_NC = B4_QC * B4_QC;   // a join item covers a QUAD of 2x2 tiles = 16x16 cells
+constexpr int B4_W = B4_QC + 2, B4_W1 = B4_W + 1;   // window of a quad incl. halo (cells)
 constexpr unsigned B4_HEAVY = 64;          // cells with at least this many records get tasks of their own
 #ifndef B4_CPT_
 #define B4_CPT_ 4
@@ -67,7 +68,7 @@ constexpr unsigned B4_IT = B4_IT_;             // tasks per item
 #define B4_JT_ 256
 #endif
 constexpr int B4_JT = B4_JT_;                 // threads of a join workgroup
-constexpr int B4_LDS_DYN = 36 * 1024;      // live points + counters of a band (4 workgroups per CU)
+constexpr int B4_LDS_DYN = 30 * 1024;      // live points + counters of a band (4 workgroups per CU)
 constexpr unsigned B4_LANE_MAX = 64;       // packed chunks: lanes with more candidates take the group loop
 constexpr int B4_MAXT = 64;
 constexpr int B4_POSE_LDS_MAX = 640;        // frames whose poses fit the LDS table of a join workgroup
@@ -353,6 +354,10 @@ __global__ __launch_bounds__(512) void b4_seg_scatter(Blk B) {
 __global__ __launch_bounds__(256) void b4_live_count(Blk B, const ScanDev *__restrict__ scans) {
     const ScanDev &S = scans[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    {   // the scan's counts start at zero (one launch for all scans instead of a memset per scan)
+        const size_t nc = (size_t)S.n * S.T;
+        for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < nc; c += (size_t)gridDim.x * 256) S.counts[c] = 0;
+    }
     if (i >= S.n) return;
     const float x = S.liveXyz[3 * (size_t)i], y = S.liveXyz[3 * (size_t)i + 1], z = S.liveXyz[3 * (size_t)i + 2];
     float o[3];
@@ -369,26 +374,28 @@ __global__ __launch_bounds__(256) void b4_live_count(Blk B, const ScanDev *__res
     S.tmp[i] = make_float4(o[0], o[1], o[2], __int_as_float(cell));
 }
 
-// exclusive scan of the cell counters (1024 per workgroup); the counters are cleared behind the read: the
-// scatter uses them as cursors
+// exclusive scan of the cell counters (4096 per workgroup, four per thread); the counters are cleared behind the
+// read: the scatter uses them as cursors
+constexpr int B4_SCAN = 4096;
 __global__ __launch_bounds__(1024) void b4_scan_local(Blk B, const ScanDev *__restrict__ scans) {
     __shared__ unsigned wsum[16];
     const ScanDev &S = scans[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t i = (size_t)blockIdx.x * 1024 + tid;
-    const unsigned v = S.cellCount[i];
-    S.cellCount[i] = 0u;
-    unsigned inc = v;
+    uint4 *cc = reinterpret_cast<uint4 *>(S.cellCount) + (size_t)blockIdx.x * 1024 + tid;
+    const uint4 v = *cc;
+    *cc = make_uint4(0u, 0u, 0u, 0u);
+    const unsigned s4 = v.x + v.y + v.z + v.w;
+    unsigned inc = s4;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = __shfl_up(inc, o);
         if (lane >= o) inc += u;
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    unsigned base = 0;
+    unsigned base = inc - s4;
     for (int k = 0; k < w; ++k) base += wsum[k];
-    S.cellStart[i] = base + inc - v;
-    if (tid == 1023) S.blockSum[blockIdx.x] = base + inc;
+    reinterpret_cast<uint4 *>(S.cellStart)[(size_t)blockIdx.x * 1024 + tid] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+    if (tid == 1023) S.blockSum[blockIdx.x] = base + s4;
 }
 __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__restrict__ scans) {
     __shared__ unsigned red[16];
@@ -401,8 +408,10 @@ __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__r
     __syncthreads();
     unsigned off = 0;
     for (int k = 0; k < 16; ++k) off += red[k];
-    const size_t i = (size_t)blockIdx.x * 1024 + tid;
-    S.cellStart[i] += off;
+    uint4 *cs = reinterpret_cast<uint4 *>(S.cellStart) + (size_t)blockIdx.x * 1024 + tid;
+    uint4 c = *cs;
+    c.x += off, c.y += off, c.z += off, c.w += off;
+    *cs = c;
     if (blockIdx.x == gridDim.x - 1 && tid == 1023) S.cellStart[B.NCpad] = off + S.blockSum[blockIdx.x];
 }
 __global__ __launch_bounds__(256) void b4_live_scatter(Blk B, const ScanDev *__restrict__ scans) {
@@ -432,10 +441,9 @@ __global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__res
     const ScanDev &S = scans[blockIdx.y];
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B.BT) return;
-    unsigned tasks = 0;
+    unsigned th = 0, lv = 0;
     if (B.listTotal[b] != 0u) {
         const unsigned n = B.cellOff[(size_t)b * 65 + lane + 1] - B.cellOff[(size_t)b * 65 + lane];
-        unsigned th = 0, lv = 0;
         if (n) {
             const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
             if (b4_cell_cand(S.cellStart, B.CW, B.CHc, cx, cy)) {
@@ -447,19 +455,35 @@ __global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__res
             th += __shfl_xor(th, o);
             lv += __shfl_xor(lv, o);
         }
-        tasks = th + (lv + B4_TASK - 1) / B4_TASK;
     }
-    if (lane == 0) S.tileTasks[b] = tasks;
+    if (lane == 0) S.tileTasks[b] = (th << 12) | lv;   // lv <= 64 * 63
 }
-// one workgroup per scan: items = (tile, first task, end task); the full items (B4_IT tasks) first, then the rest
+// one workgroup per scan.  An item covers (a part of) a QUAD of 2x2 tiles: the per-item costs of the join (cell table,
+// live window, barriers) are paid once for four tiles.  items = (quad, first task, end task); the full items first.
+constexpr int B4_QPT = ((B4_MAXW / 2) * (B4_MAXW / 2) + 1023) / 1024;   // quads per thread
+__device__ __forceinline__ unsigned b4_quad_tasks(const Blk &B, const unsigned *__restrict__ tileTasks, int qd, int QW) {
+    const int qx = qd % QW, qy = qd / QW;
+    unsigned th = 0, lv = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int tx = 2 * qx + (s & 1), ty = 2 * qy + (s >> 1);
+        if (tx < B.BW && ty < B.BH) {
+            const unsigned w = tileTasks[ty * B.BW + tx];
+            th += w >> 12;
+            lv += w & 4095u;
+        }
+    }
+    return th + (lv + B4_TASK - 1) / B4_TASK;
+}
 __global__ __launch_bounds__(1024) void b4_plan_items(Blk B, const ScanDev *__restrict__ scans) {
     __shared__ unsigned wa[16], wb[16];
     const ScanDev &S = scans[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int QW = (B.BW + 1) / 2, NQ = QW * ((B.BH + 1) / 2);
     unsigned sumF = 0, sumR = 0;
-    for (int j = 0; j < B4_BPT; ++j) {
-        const int b = tid * B4_BPT + j;
-        const unsigned t = b < B.BT ? S.tileTasks[b] : 0u;
+    for (int j = 0; j < B4_QPT; ++j) {
+        const int qd = tid * B4_QPT + j;
+        const unsigned t = qd < NQ ? b4_quad_tasks(B, S.tileTasks, qd, QW) : 0u;
         sumF += t / B4_IT;
         sumR += (t % B4_IT) ? 1u : 0u;
     }
@@ -490,14 +514,14 @@ __global__ __launch_bounds__(1024) void b4_plan_items(Blk B, const ScanDev *__re
         S.ctrl[1] = 0u;
     }
     unsigned fB = baseA + incA - sumF, rB = allA + baseB + incB - sumR;
-    for (int j = 0; j < B4_BPT; ++j) {
-        const int b = tid * B4_BPT + j;
-        if (b >= B.BT) break;
-        const unsigned t = S.tileTasks[b], full = t / B4_IT;
+    for (int j = 0; j < B4_QPT; ++j) {
+        const int qd = tid * B4_QPT + j;
+        if (qd >= NQ) break;
+        const unsigned t = b4_quad_tasks(B, S.tileTasks, qd, QW), full = t / B4_IT;
         for (unsigned k = 0; k < full; ++k)
-            if (fB + k < (unsigned)S.maxItems) S.items[fB + k] = make_uint4((unsigned)b, k * B4_IT, (k + 1) * B4_IT, 0u);
+            if (fB + k < (unsigned)S.maxItems) S.items[fB + k] = make_uint4((unsigned)qd, k * B4_IT, (k + 1) * B4_IT, 0u);
         if ((t % B4_IT) && rB < (unsigned)S.maxItems) {
-            S.items[rB] = make_uint4((unsigned)b, full * B4_IT, t, 0u);
+            S.items[rB] = make_uint4((unsigned)qd, full * B4_IT, t, 0u);
             ++rB;
         }
         fB += full;
@@ -510,11 +534,12 @@ struct B4Shared {
     unsigned short ctab[B4_W * B4_W1];   // live points of window row r before column cc
     unsigned segStart[B4_W], rowBase[B4_W1];   // rowBase: of the CURRENT band (LDS index of the first live point of window row r)
     unsigned colOff[B4_W];                     // ... live points of window row r left of the band
-    unsigned cellRec[65];                // record offsets of the tile's cells
-    unsigned thStart[64];                // first heavy task of cell k
-    unsigned lvStart[64], lvEnd[64];     // packed (light) order: first / end virtual record of cell k
-    unsigned band[64];   // ya | yb << 4 | xa << 8 | xb << 12 | slow << 16 (cell rows / columns 1..8 of the window, inclusive)
-    unsigned long long heavyMask;
+    unsigned recStart[B4_NC], recN[B4_NC];     // records of the quad's cells (cell c = row * 16 + column of the quad)
+    unsigned thEnd[B4_NC];                     // one-cell tasks up to and including cell c
+    unsigned lvStart[B4_NC], lvEnd[B4_NC];     // packed (light) order: first / end virtual record of cell c
+    unsigned band[B4_NC];   // ya | yb << 5 | xa << 10 | xb << 15 | slow << 20 (cell rows / columns 1..16 of the window, inclusive)
+    unsigned wsA[4], wsB[4];
+    uint4 task[B4_IT];   // the item's one-cell tasks, decoded once: (cell, first record, end record, -)
     unsigned nBands, ticket, TH, LV, itemId, nextId;
     uint4 item, nextItem;
 };
@@ -635,12 +660,14 @@ __host__ __device__ __forceinline__ unsigned b4_pose_bytes(int U) {
     return U <= B4_POSE_LDS_MAX ? (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15)) : 0u;
 }
 
-template <bool LPOSE>
-__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg) {
+template <bool LPOSE, bool PROF>
+__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg, unsigned long long *prof) {
     extern __shared__ __align__(16) unsigned char dynsm[];
     __shared__ B4Shared S;
-    const ScanDev &SC = scans[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
+    int lq = lane;
+    asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
+    const ScanDev &SC = scans[blockIdx.y];
     const int T = SC.T, Th = (T + 1) >> 1;
     const unsigned liveBytes = 16u + 4u * (unsigned)Th;
     const unsigned lcap = (unsigned)B4_LDS_DYN / liveBytes;
@@ -659,8 +686,15 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     int *counts = SC.counts;
     const int CW = B.CW, CHc = B.CHc;
     const unsigned nItems = SC.ctrl[0];
-    int lq = lane;
-    asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
+    // PROF: cycles of this wavefront by phase (0 item set-up, 1 band set-up, 2 unit fetch + decode, 3 record wait + transform +
+    // masks, 4 pair phase, 5 packed chunks, 6 wait at the end of a band, 7 flush), counts 8 items 9 bands 10 tasks 11 chunks
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? clock64() : 0ULL;
+#define B4_TICK(kk)                                  \
+    if (PROF) {                                      \
+        const unsigned long long now_ = clock64();   \
+        pacc[kk] += now_ - plast;                    \
+        plast = now_;                                \
+    }
 
     if (LPOSE) {   // the scan's poses: read once per workgroup (the workgroups are persistent)
         float4 *pw = reinterpret_cast<float4 *>(dynsm);
@@ -733,38 +767,50 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         const uint4 it = S.item;
         __syncthreads();   // everyone holds the item: thread 0 may overwrite the header below
         if (tid == 0) S.nextId = atomicAdd(&SC.ctrl[1], 1u);   // in flight during the loads below
-        const int b = (int)it.x;
+        const int qd = (int)it.x;
         const unsigned q0 = it.y, q1 = it.z;
-        const int tbx = b % B.BW, tby = b / B.BW;
+        const int QW = (B.BW + 1) / 2;
+        const int tbx = (qd % QW) * 2, tby = (qd / QW) * 2;   // first tile of the quad
         const int x0 = tbx * 8 - 1, y0 = tby * 8 - 1;
         const int gx0 = max(x0, 0), gx1 = min(x0 + B4_W, CW);
-        // ---- (a) the window's cell table, the tile's cell offsets ---------------------------------
-        if (tid < B4_W * B4_W1) {
-            const int r = tid / B4_W1, cc = tid - r * B4_W1;
+        // ---- (a) the window's cell table, the record offsets of the quad's cells -------------------
+        for (int e = tid; e < B4_W * B4_W1; e += B4_JT) {
+            const int r = e / B4_W1, cc = e - r * B4_W1;
             const int gy = y0 + r;
             unsigned val = 0;
             if (gy >= 0 && gy < CHc) val = cellStart[(size_t)gy * CW + min(max(x0 + cc, gx0), gx1)];
-            S.cst[tid] = val;
-        } else if (tid >= 128 && tid < 128 + 65) {
-            S.cellRec[tid - 128] = cellOff[(size_t)b * 65 + (tid - 128)];
+            S.cst[e] = val;
+        }
+        {
+            static_assert(B4_JT == B4_NC, "one thread per cell of the quad");
+            const int cxq = tid & 15, cyq = tid >> 4;
+            const int tx = tbx + (cxq >> 3), ty = tby + (cyq >> 3);
+            unsigned rs = 0, rn = 0;
+            if (tx < B.BW && ty < B.BH) {
+                const size_t o = (size_t)(ty * B.BW + tx) * 65 + (cyq & 7) * 8 + (cxq & 7);
+                rs = cellOff[o];
+                rn = cellOff[o + 1] - rs;
+            }
+            S.recStart[tid] = rs;
+            S.recN[tid] = rn;
         }
         __syncthreads();
         if (tid == 0 && S.nextId < nItems) {
             const v4u w = items[(S.nextId + rot) % nItems];
             S.nextItem = make_uint4(w.x, w.y, w.z, w.w);
         }
-        // ---- (b) tasks of the tile, window tables, bands ------------------------------------------
-        if (tid < 64) {
-            const int k = tid;
-            const unsigned n = S.cellRec[k + 1] - S.cellRec[k];
-            const int lx = (k & 7) + 1, ly = (k >> 3) + 1;
+        // ---- (b) tasks of the quad, window tables, bands ------------------------------------------
+        unsigned thMine, lvMine, incA, incB;
+        {
+            const int lx = (tid & 15) + 1, ly = (tid >> 4) + 1;
+            const unsigned n = S.recN[tid];
             unsigned cand = 0;
 #pragma unroll
             for (int r = -1; r <= 1; ++r) cand += S.cst[(ly + r) * B4_W1 + lx + 2] - S.cst[(ly + r) * B4_W1 + lx - 1];
             const bool active = n > 0 && cand > 0, heavy = active && n >= B4_HEAVY;
-            const unsigned th = heavy ? (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT : 0u;
-            const unsigned lv = (active && !heavy) ? n : 0u;
-            unsigned incA = th, incB = lv;
+            thMine = heavy ? (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT : 0u;
+            lvMine = (active && !heavy) ? n : 0u;
+            incA = thMine, incB = lvMine;
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
                 if (lane >= o) {
@@ -772,53 +818,65 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                     incB += c;
                 }
             }
-            S.thStart[k] = incA - th;
-            S.lvStart[k] = incB - lv;
-            S.lvEnd[k] = incB;
-            const unsigned long long hm = __ballot(heavy);
-            if (k == 63) {
-                S.TH = incA;
-                S.LV = incB;
-                S.heavyMask = hm;
+            if (lane == 63) {
+                S.wsA[tid >> 6] = incA;
+                S.wsB[tid >> 6] = incB;
             }
-        } else if (tid < 64 + B4_W * B4_W1) {
-            const int e = tid - 64, r = e / B4_W1;
+        }
+        for (int e = tid; e < B4_W * B4_W1; e += B4_JT) {
+            const int r = e / B4_W1;
             S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * B4_W1], 65535u);
             if (e == r * B4_W1) S.segStart[r] = S.cst[e];
-        } else if (tid == B4_JT - 1) {
-            // bands: sub-rectangles of the tile whose live window (one cell of halo) fits the LDS budget.  Whole cell
-            // rows first; a single row that does not fit (the dense rings next to the sensor) is cut into column
-            // halves, quarters, single cells; a single cell whose 3x3 neighbourhood does not fit takes the slow path.
-            auto cnt = [&](int r0, int r1, int xa, int xb) {   // live points of window rows r0..r1, columns xa-1..xb+1
+        }
+        __syncthreads();
+        {
+            unsigned bA = 0, bB = 0;
+            for (int k = 0; k < (tid >> 6); ++k) {
+                bA += S.wsA[k];
+                bB += S.wsB[k];
+            }
+            S.thEnd[tid] = bA + incA;
+            S.lvStart[tid] = bB + incB - lvMine;
+            S.lvEnd[tid] = bB + incB;
+            if (tid == B4_JT - 1) {
+                S.TH = bA + incA;
+                S.LV = bB + incB;
+            }
+        }
+        if (tid == 0) {
+            // bands: sub-rectangles of the quad whose live window (one cell of halo) fits the LDS budget.  Whole cell rows
+            // first; a single row that does not fit (the dense rings next to the sensor) is cut into column halves,
+            // quarters, ...; a single cell whose 3x3 neighbourhood does not fit takes the slow path.
+            auto lenr = [&](int r) { return S.cst[r * B4_W1 + B4_W] - S.cst[r * B4_W1]; };   // live points of window row r
+            auto cnt3 = [&](int ya, int xa, int xb) {   // live points of window rows ya-1..ya+1, columns xa-1..xb+1
                 unsigned c = 0;
-                for (int r = r0; r <= r1; ++r) c += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
+                for (int r = ya - 1; r <= ya + 1; ++r) c += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
                 return c;
             };
             unsigned nb = 0;
             int ya = 1;
-            while (ya <= 8) {
-                if (cnt(ya - 1, ya + 1, 1, 8) <= lcap) {
+            while (ya <= B4_QC) {
+                unsigned sum = lenr(ya - 1) + lenr(ya) + lenr(ya + 1);
+                if (sum <= lcap) {
                     int yb = ya;
-                    while (yb < 8 && cnt(ya - 1, yb + 2, 1, 8) <= lcap) ++yb;
-                    S.band[nb++] = (unsigned)ya | ((unsigned)yb << 4) | (1u << 8) | (8u << 12);
+                    while (yb < B4_QC) {
+                        const unsigned nx = lenr(yb + 2);
+                        if (sum + nx > lcap) break;
+                        sum += nx;
+                        ++yb;
+                    }
+                    S.band[nb++] = (unsigned)ya | ((unsigned)yb << 5) | (1u << 10) | ((unsigned)B4_QC << 15);
                     ya = yb + 1;
                     continue;
                 }
-                auto emit = [&](int xa, int xb, bool slowCell) {
-                    S.band[nb++] = (unsigned)ya | ((unsigned)ya << 4) | ((unsigned)xa << 8) | ((unsigned)xb << 12) | (slowCell ? 1u << 16 : 0u);
-                };
-                for (int ha = 1; ha <= 8; ha += 4) {
-                    if (cnt(ya - 1, ya + 1, ha, ha + 3) <= lcap) {
-                        emit(ha, ha + 3, false);
-                        continue;
-                    }
-                    for (int qa = ha; qa < ha + 4; qa += 2) {
-                        if (cnt(ya - 1, ya + 1, qa, qa + 1) <= lcap) {
-                            emit(qa, qa + 1, false);
-                            continue;
-                        }
-                        for (int c = qa; c < qa + 2; ++c) emit(c, c, cnt(ya - 1, ya + 1, c, c) > lcap);
-                    }
+                int xa = 1, w = B4_QC / 2;   // pieces of width w (a power of two), left to right, as wide as fits
+                while (xa <= B4_QC) {
+                    while (w > 1 && (((xa - 1) & (w - 1)) != 0 || cnt3(ya, xa, xa + w - 1) > lcap)) w >>= 1;
+                    const bool fits = cnt3(ya, xa, xa + w - 1) <= lcap;
+                    S.band[nb++] = (unsigned)ya | ((unsigned)ya << 5) | ((unsigned)xa << 10) | ((unsigned)(xa + w - 1) << 15) |
+                                   (fits ? 0u : 1u << 20);
+                    xa += w;
+                    w = B4_QC / 2;
                 }
                 ++ya;
             }
@@ -826,13 +884,32 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
         __syncthreads();
         const unsigned TH = S.TH, LV = S.LV;
-        const unsigned long long heavyMask = S.heavyMask;
         const unsigned nBands = S.nBands;
+        // the item's units: one-cell tasks [qh0, qh1) and 64-record chunks of the packed order [l0, l1)
+        const unsigned qh0 = min(q0, TH), qh1 = min(q1, TH), nH = qh1 - qh0;
+        const unsigned l0 = (max(q0, TH) - TH) * B4_TASK, l1 = min(LV, (max(q1, TH) - TH) * B4_TASK);
+        const unsigned nUnits = nH + (l1 > l0 ? (l1 - l0 + 63) / 64 : 0u);
+        if (tid < (int)nH) {   // every task decoded once, in parallel: first cell whose task count (inclusive prefix) exceeds q
+            const unsigned q = qh0 + tid;
+            int lo = 0, hi = B4_NC - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (S.thEnd[mid] > q) hi = mid;
+                else lo = mid + 1;
+            }
+            const unsigned cbeg = S.recStart[lo], cn = S.recN[lo];
+            const unsigned nt = (((cn + 63) >> 6) + B4_CPT - 1) / B4_CPT;   // tasks of the cell
+            const unsigned st = cbeg + (q - (S.thEnd[lo] - nt)) * B4_TASK;
+            S.task[tid] = make_uint4((unsigned)lo, st, min(cbeg + cn, st + B4_TASK), 0u);
+        }
+        B4_TICK(0)
+        if (PROF) ++pacc[8];
         for (unsigned bd = 0; bd < nBands; ++bd) {
+            if (PROF) ++pacc[9];
             const unsigned bw = S.band[bd];
-            const int ya = (int)(bw & 15u), yb = (int)((bw >> 4) & 15u);   // cell rows / columns of the band (window coordinates 1..8)
-            const int xa = (int)((bw >> 8) & 15u), xb = (int)((bw >> 12) & 15u);
-            const bool slow = (bw >> 16) != 0;
+            const int ya = (int)(bw & 31u), yb = (int)((bw >> 5) & 31u);   // cell rows / columns of the band (window coordinates 1..16)
+            const int xa = (int)((bw >> 10) & 31u), xb = (int)((bw >> 15) & 31u);
+            const bool slow = (bw >> 20) != 0;
             __syncthreads();   // previous band's flush complete
             if (tid <= yb - ya + 2) {   // rows ya-1 .. yb+1 of the window, columns xa-1 .. xb+1
                 unsigned run = 0;
@@ -857,43 +934,48 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
 
             // ---- the tasks of the item, dealt to the wavefronts.  The records of a wavefront's NEXT one-cell task are
             // requested before the pair phase of the current one: the loads overlap the pair phase ----------------
-            auto fetch = [&]() -> unsigned {
-                unsigned tk = 0;
-                if (lane == 0) tk = atomicAdd(&S.ticket, 1u);
-                return q0 + __builtin_amdgcn_readfirstlane(tk);
-            };
-            int ty = 0, k = 0;   // ty: 0 no task left, 1 one-cell task (records requested), 2 packed task, 3 nothing to do here
-            unsigned start = 0, end = 0, q = 0;
+            int ty = 0, k = 0;   // ty: 0 no unit left, 1 one-cell task (records requested), 2 a chunk of the packed order, 3 not in this band
+            unsigned start = 0, end = 0, v0 = 0, v1 = 0;
             v4f R[B4_CPT];
-            auto prep = [&]() {
-                q = fetch();
+            unsigned tnext = (unsigned)tid >> 6;   // units are dealt round robin to the wavefronts (no ticket: a returning LDS
+            auto prep = [&]() {                     // atomic per unit is a latency of its own in a loop that is all latency)
+                const unsigned t = __builtin_amdgcn_readfirstlane(tnext);
+                tnext += B4_JT / 64;
                 ty = 0;
-                if (q >= q1) return;
-                if (q >= TH) {
-                    ty = (dbg & 2) ? 3 : 2;
+                if (t >= nUnits) return;
+                if (t >= nH) {   // a chunk of the packed order
+                    ty = 2;
+                    v0 = l0 + (t - nH) * 64u;
+                    v1 = min(l1, v0 + 64u);
+                    if (dbg & 2) v1 = v0;
                     return;
                 }
+                const uint4 tk4 = S.task[t];
+                k = __builtin_amdgcn_readfirstlane((int)tk4.x);
+                const int lcx = (k & 15) + 1, lcy = (k >> 4) + 1;
                 ty = 3;
-                if (dbg & 8) return;
-                const bool mineH = ((heavyMask >> lane) & 1ULL) && S.thStart[lane] <= q;
-                k = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)__ballot(mineH)));
-                const int lcx = (k & 7) + 1, lcy = (k >> 3) + 1;
                 if (lcy < ya || lcy > yb || lcx < xa || lcx > xb) return;
                 ty = 1;
-                const unsigned cbeg = S.cellRec[k], cend = S.cellRec[k + 1];
-                start = cbeg + (q - S.thStart[k]) * B4_TASK;
-                end = min(cend, start + B4_TASK);
-                if (!slow) {   // (a lane without a record re-reads the last one: no load sits inside a branch)
+                start = __builtin_amdgcn_readfirstlane(tk4.y);
+                end = __builtin_amdgcn_readfirstlane(tk4.z);
+                if (dbg & 8) end = start;
+                if (!slow && end > start) {   // (a lane without a record re-reads the last one: no load sits inside a branch)
 #pragma unroll
-                    for (int u = 0; u < B4_CPT; ++u) R[u] = rec[min(start + u * 64 + lane, end - 1)];
+                    for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(start + u * 64 + lane, end - 1)]);
                 }
             };
+            B4_TICK(1)
             prep();
+            B4_TICK(2)
             while (ty != 0) {
                 if (ty == 1) {
-                    const int lcx = (k & 7) + 1, lcy = (k >> 3) + 1;
+                    const int lcx = (k & 15) + 1, lcy = (k >> 4) + 1;
+                    if (end <= start) {
+                        prep();
+                        continue;
+                    }
                     if (slow) {
-                        const int cx = tbx * 8 + (k & 7), cy = tby * 8 + (k >> 3);
+                        const int cx = tbx * 8 + (k & 15), cy = tby * 8 + (k >> 4);
                         for (unsigned ib = start; ib < end; ib += 64) {
                             float sx, sy, sz;
                             int st;
@@ -906,6 +988,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                     const int nch = (int)((end - start + 63) >> 6);
                     v2f hx[B4_CPT / 2], hy[B4_CPT / 2], hz[B4_CPT / 2];   // chunk 2p in .x, chunk 2p+1 in .y
                     unsigned sLo[B4_CPT], sHi[B4_CPT];
+                    int lqm = lane;
+                    asm volatile("" : "+v"(lqm));   // (per task: hoisted out of the loops, the mask constants are six registers that spill)
 #pragma unroll
                     for (int u = 0; u < B4_CPT; ++u) {
                         int tv;
@@ -913,7 +997,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                         xform(R[u], start + u * 64 + lane < end, &ax, &ay, &az, &tv);
                         if (u & 1) hx[u / 2].y = ax, hy[u / 2].y = ay, hz[u / 2].y = az;
                         else hx[u / 2].x = ax, hy[u / 2].x = ay, hz[u / 2].x = az;
-                        b4_segmask((unsigned)tv & 63u, tv >= 0, T, lq, &sLo[u], &sHi[u]);
+                        b4_segmask((unsigned)tv & 63u, tv >= 0, T, lqm, &sLo[u], &sHi[u]);
                     }
                     const unsigned short *row = S.ctab + (lcy - 1) * B4_W1 + lcx - 1;
                     const unsigned c00 = row[0], c03 = row[3], c10 = row[B4_W1], c13 = row[B4_W1 + 3];
@@ -921,27 +1005,33 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                     const unsigned aR[3] = {S.rowBase[lcy - 1] + c00 - S.colOff[lcy - 1], S.rowBase[lcy] + c10 - S.colOff[lcy],
                                             S.rowBase[lcy + 1] + c20 - S.colOff[lcy + 1]};
                     const unsigned nR[3] = {c03 - c00, c13 - c10, c23 - c20};
+                    B4_TICK(3)
+                    if (PROF) ++pacc[10];
                     prep();   // the next task: its record loads are in flight during the pair phase below
+                    B4_TICK(2)
                     if (!(dbg & 1)) {
                         static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
                         if (nch <= 2) b4_pairs_rows<1>(live, cntw, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
                         else b4_pairs_rows<2>(live, cntw, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
                     }
+                    B4_TICK(4)
                     continue;
                 }
                 if (ty == 3) {
                     prep();
+                    B4_TICK(2)
                     continue;
                 }
-                // ======== packed records of sparse cells: every lane walks its own candidates ========
-                const unsigned v0 = (q - TH) * B4_TASK, v1 = min(LV, v0 + B4_TASK);
-                prep();
-                for (unsigned vb = v0; vb < v1; vb += 64) {
+                // ======== a chunk of the packed records of sparse cells: every lane walks its own candidates ========
+                do {
+                    const unsigned vb = v0, ve = v1;
+                    if (PROF) ++pacc[11];
+                    if (ve <= vb) break;
                     const unsigned v = vb + lane;
-                    const bool valid = v < v1;
+                    const bool valid = v < ve;
                     int kc = 0;
                     if (valid) {   // first cell whose end lies behind v (cells outside the packed order have no extent)
-                        int lo = 0, hi = 63;
+                        int lo = 0, hi = B4_NC - 1;
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
                             if (S.lvEnd[mid] > v) hi = mid;
@@ -949,16 +1039,16 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                         }
                         kc = lo;
                     }
-                    const int lx = (kc & 7) + 1, ly = (kc >> 3) + 1;
+                    const int lx = (kc & 15) + 1, ly = (kc >> 4) + 1;
                     const bool inband = valid && ly >= ya && ly <= yb && lx >= xa && lx <= xb;
-                    if (!__any(inband)) continue;
+                    if (!__any(inband)) break;
                     float hx, hy, hz;
                     int trv;
-                    xform(rec[S.cellRec[kc] + (valid ? v - S.lvStart[kc] : 0u)], inband, &hx, &hy, &hz, &trv);
+                    xform(rec[S.recStart[kc] + (valid ? v - S.lvStart[kc] : 0u)], inband, &hx, &hy, &hz, &trv);
                     const bool on = trv >= 0;
                     if (slow) {
-                        if (on) slow_walk(hx, hy, hz, trv, tbx * 8 + (kc & 7), tby * 8 + (kc >> 3));
-                        continue;
+                        if (on) slow_walk(hx, hy, hz, trv, tbx * 8 + (kc & 15), tby * 8 + (kc >> 4));
+                        break;
                     }
                     const unsigned short *row = S.ctab + (ly - 1) * B4_W1 + lx - 1;
                     const unsigned c00 = row[0], c10 = row[B4_W1], c20 = row[2 * B4_W1];
@@ -1025,9 +1115,14 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                             }
                         }
                     }
-                }
+                } while (false);
+                B4_TICK(5)
+                prep();   // (after the chunk: requested records of a one-cell task would live across the walk)
+                B4_TICK(2)
             }
+            B4_TICK(5)
             __syncthreads();
+            B4_TICK(6)
             if (!slow)
                 for (unsigned e = tid; e < Lb * Th; e += B4_JT) {
                     const unsigned cw = cntw[e];
@@ -1039,11 +1134,15 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                     }
                 }
         }
+        B4_TICK(7)
         if (tid == 0) {
             S.itemId = S.nextId;
             S.item = S.nextItem;
         }
     }
+    if (PROF && lane == 0)
+        for (int kk = 0; kk < 12; ++kk) atomicAdd(&prof[kk], pacc[kk]);
+#undef B4_TICK
 }
 
 __global__ void b4_entropy(const ScanDev *__restrict__ scans) {
@@ -1107,10 +1206,13 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         maxN = std::max(maxN, sc.n);
     }
     if (!any) return MODEST_OK;
+    // one more tile on every side: a live point in the outermost cells of its table still finds the history points of the
+    // cells next to it (b4_scatter drops what lies outside the window)
+    bx0 -= 1, by0 -= 1, bx1 += 1, by1 += 1;
     const int BW = bx1 - bx0, BH = by1 - by0;
-    MODEST_REQUIRE(BW <= B4_MAXW && BH <= B4_MAXW, "the live scans of a block must lie within 32 tiles of each other");
+    MODEST_REQUIRE(BW <= B4_MAXW && BH <= B4_MAXW, "the live scans of a block must lie within 30 tiles of each other");
     const int BT = BW * BH, CW = 8 * BW, CHc = 8 * BH;
-    const int NC = CW * CHc, NCpad = (NC + 1023) & ~1023, nScanBlk = NCpad / 1024;
+    const int NC = CW * CHc, NCpad = (NC + B4_SCAN - 1) / B4_SCAN * B4_SCAN, nScanBlk = NCpad / B4_SCAN;
     const int NG = (U + B4_FG - 1) / B4_FG;
     const size_t maxSegs = (size_t)BT + (size_t)(ntot / B4_SEG) + 1;
     const size_t maxItems = (size_t)(ntot / (B4_TASK * B4_IT)) + (size_t)(ntot / (64 * B4_IT)) + 2 * (size_t)BT + 16;
@@ -1127,14 +1229,14 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
     const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
-    const size_t oCellCount = take((size_t)G * (NCpad + 1) * 4);   // contiguous over the scans: one memset
+    const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
         size_t cellStart, blockSum, tileTasks, ctrl, tmp, sorted, items, counts;
     };
     std::vector<ScanOff> so((size_t)G);
     for (int s = 0; s < G; ++s) {
         const int n = scans[s].n;
-        so[(size_t)s].cellStart = take((size_t)(NCpad + 1) * 4);
+        so[(size_t)s].cellStart = take((size_t)(NCpad + 4) * 4);
         so[(size_t)s].blockSum = take((size_t)nScanBlk * 4);
         so[(size_t)s].tileTasks = take((size_t)BT * 4);
         so[(size_t)s].ctrl = take(256);
@@ -1183,7 +1285,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.liveXyz = sc.xyz_dev;
         d.livePerm = sc.perm_dev;
         d.liveTab = sc.tab_dev;
-        d.cellCount = reinterpret_cast<unsigned *>(base + oCellCount) + (size_t)s * (NCpad + 1);
+        d.cellCount = reinterpret_cast<unsigned *>(base + oCellCount) + (size_t)s * (NCpad + 4);
         d.cellStart = reinterpret_cast<unsigned *>(base + o.cellStart);
         d.blockSum = reinterpret_cast<unsigned *>(base + o.blockSum);
         d.tileTasks = reinterpret_cast<unsigned *>(base + o.tileTasks);
@@ -1237,19 +1339,17 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     if (!attr_done[ctx->device & 63]) {
         MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_seg_scatter),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, B4_SEG * 16));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false>),
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_DYN));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true>),
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_DYN));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              B4_LDS_DYN + (int)b4_pose_bytes(B4_POSE_LDS_MAX)));
         attr_done[ctx->device & 63] = true;
     }
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
-    MODEST_HIP_CHECK(hipMemsetAsync(base + oCellCount, 0, (size_t)G * (NCpad + 1) * 4, stream));
-    // counts start at zero
-    for (int s = 0; s < G; ++s)
-        if (scans[s].n > 0)
-            MODEST_HIP_CHECK(hipMemsetAsync(hsc[s].counts, 0, (size_t)scans[s].n * T * 4, stream));
+    MODEST_HIP_CHECK(hipMemsetAsync(base + oCellCount, 0, (size_t)G * (NCpad + 4) * 4, stream));
     const unsigned gBT = (unsigned)((BT + 255) / 256), gN = (unsigned)((maxN + 255) / 256);
     if (U > 0 && ntot > 0) {
         b4_counts<<<dim3(gBT, (unsigned)NG), 256, 0, stream>>>(B);
@@ -1272,10 +1372,24 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         const char *dbg_env = getenv("MODEST_PP4_DBG");
         const int dbg = dbg_env ? atoi(dbg_env) : 0;
         const unsigned poseB = b4_pose_bytes(U);
-        if (poseB && B4_JT >= 512 && !(dbg & 256))
-            b4_join<true><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN + poseB, stream>>>(B, dsc, radius * radius, dbg);
+        if (dbg & 512) {   // MODEST_PP4_DBG=512: per-phase wavefront cycles of the join (blocking; diagnostics only)
+            unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[12];
+            MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));
+            b4_join<false, true><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg, dprof);
+            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+            MODEST_HIP_CHECK(hipMemcpy(hprof, dprof, sizeof(hprof), hipMemcpyDeviceToHost));
+            const double wv = (double)jx * G * (B4_JT / 64), us = 1.0 / 100.0;   // s_memtime ticks at 100 MHz
+            fprintf(stderr, "[b4_join] per wavefront, us: item set-up %.1f | band set-up %.1f | fetch+decode %.1f | record wait+transform %.1f | "
+                            "pairs %.1f | packed %.1f | band-end wait %.1f | flush %.1f || per scan: items %.0f bands %.0f tasks %.0f chunks %.0f\n",
+                    hprof[0] * us / wv, hprof[1] * us / wv, hprof[2] * us / wv, hprof[3] * us / wv, hprof[4] * us / wv, hprof[5] * us / wv,
+                    hprof[6] * us / wv, hprof[7] * us / wv, hprof[8] / 4.0 / G, hprof[9] / 4.0 / G, (double)hprof[10] / G, (double)hprof[11] / G);
+        } else if (poseB && B4_JT >= 512 && !(dbg & 256))
+            b4_join<true, false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN + poseB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
         else
-            b4_join<false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg);
+            b4_join<false, false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg, nullptr);
+    } else {   // no history: every count is zero
+        for (int sc = 0; sc < G; ++sc)
+            if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * T * 4, stream));
     }
     modest_prof_mark(ctx, stream, 1);
     b4_entropy<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(dsc);

@@ -407,10 +407,13 @@ def main(args):
     # the ingest / writer threads hand the GIL back and forth with this loop: CPython's default forced-switch
     # interval (5 ms) is longer than a whole scan
     sys.setswitchinterval(float(os.environ.get("MODEST_SWITCH_INTERVAL", "0.0002")))
-    # pp_batch consecutive scans go through ONE chain of launches (modest_pp_score_frames_batch): the loop below
-    # collects their descriptor tables and flushes; the ingest window must hold a whole batch plus the scans ahead
-    n_batch = max(1, int(args.get("pp_batch", 4)))
-    pipe = IngestPipeline(loader, plans(), device, depth=int(args.get("ingest_depth", 4)) + (n_batch - 1),
+    # pp_batch consecutive scans go through ONE call (FrameStore.pp_score_batch: modest_pp_score_block for scans that share
+    # their history frames, modest_pp_score_frames_batch otherwise): the loop below collects their descriptor tables and
+    # flushes; the ingest window must hold a whole batch plus the scans ahead -- at least one scan ahead, whatever
+    # ingest_depth says (a window smaller than a batch would leave this loop waiting for a scan the ingest thread may
+    # not load)
+    n_batch = max(1, int(args.get("pp_batch", 16)))
+    pipe = IngestPipeline(loader, plans(), device, depth=max(1, int(args.get("ingest_depth", 4))) + (n_batch - 1),
                           own_stream=not os.environ.get("MODEST_WORKER"))
     writer = OutputWriter(1 << 16)
     pend = []   # (live frame, descriptor table, output path, scan id, traversals) of the scans waiting for the flush

@@ -288,9 +288,9 @@ def make_shard(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_frames: i
     L = n_scans + n_frames - 1
     world = make_world(world_seed, length=max(400.0, x0 + frame_gap * L + 150.0))
     K, l2e = kitti2nu(nusc), default_l2e()
-    rngp = np.random.default_rng(60_000 + seed)
     tracks, poses = [], []
     for t in range(n_trav):
+        rngp = np.random.default_rng([60_000 + seed, t])   # per traversal: a longer shard extends the tracks of a shorter one
         lat, yaw = rngp.uniform(-1.5, 1.5), rngp.uniform(-0.02, 0.02)
         tr, ps = [], []
         for j in range(L):

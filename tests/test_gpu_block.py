@@ -1,0 +1,141 @@
+"""Block path of the PP neighbour count (modest_pp_score_block, csrc/pp_v4.hip): consecutive scans of a shard in ONE
+call -- the union of their frames binned once on the world lattice -- against the oracle (scipy cKDTree on the stacked,
+transformed history: pre_compute_pp_score.py:132-150,188-193) and against the per-scan chain, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(store, sh, dev, torch, key0=0):
+    items, ids = [], {}
+    for t, tr in enumerate(sh.tracks):
+        for j, (raw, W) in enumerate(tr):
+            ids[(t, j)] = key0 + len(ids)
+            items.append((ids[(t, j)], torch.from_numpy(raw).to(dev), W))
+    lives = []
+    for sc in sh.scans:
+        k = key0 + 100000 + sc.index
+        items.append((k, torch.from_numpy(sc.live_raw).to(dev), sc.live_W))
+        lives.append(k)
+    store.insert_many(items)
+    descs = [store.describe(lives[i], sc.live_rel, [ids[h] for h in sc.hist], [t for t, _ in sc.hist], sc.rels, sh.nusc)
+             for i, sc in enumerate(sh.scans)]
+    return lives, descs, ids
+
+
+def _oracle_counts(sh, i, radius=0.3):
+    from oracle import pp_score as opp
+    lv, hist = sh.stacked(i)
+    return opp.pp_score(lv, hist, radius, workers=-1)
+
+
+@pytest.mark.parametrize("nusc,T,F,S", [(False, 3, 6, 7), (True, 4, 5, 6), (False, 33, 2, 6)])
+def test_block_equals_oracle_and_chain(gpu, nusc, T, F, S):
+    """Lyft shape, nuScenes shape (remove_center on the history, KITTI2NU = rot-z pi/2) and more than 32 traversals (the sixth
+    traversal bit of the segmented popcount): counts == oracle, H <= 1e-6, block == per-scan chain."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    sh = synth.make_shard(S, n_live=5000, n_trav=T, n_frames=F, nusc=nusc, seed=3)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, _ = _load(store, sh, gpu, torch)
+    Hb, cb = store.pp_score_batch(lives, descs, T, return_counts=True, block=True)
+    assert getattr(store, "block_calls", 0) == 1
+    Hv, cv = store.pp_score_batch(lives, descs, T, return_counts=True, block=False)
+    for i in range(S):
+        Href, cref = _oracle_counts(sh, i)
+        assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), cref), i
+        assert np.max(np.abs(Hb[i].cpu().numpy().astype(np.float64) - Href)) <= 1e-6   # tolerance of compute_ephe_score (measured 0)
+        assert torch.equal(cb[i], cv[i]) and torch.equal(Hb[i], Hv[i])
+    assert int(sum(int(c.sum()) for c in cb)) > 0
+
+
+def test_block_choice_and_fallbacks(gpu):
+    """The store takes the block path on its own from six scans that share their frames; scans without shared frames, a frame
+    with points outside its table, poses that disagree with the lattice and a radius other than the store's all take the
+    per-scan chain -- with identical results."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    sh = synth.make_shard(8, n_live=3000, n_trav=3, n_frames=5, seed=5)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, ids = _load(store, sh, gpu, torch)
+    ref = store.pp_score_batch(lives, descs, 3, return_counts=True, block=False)[1]
+    n0 = getattr(store, "block_calls", 0)
+    got = store.pp_score_batch(lives, descs, 3, return_counts=True)[1]   # automatic: 8 scans sharing 4 of 5 frames
+    assert getattr(store, "block_calls", 0) == n0 + 1 and all(torch.equal(a, b) for a, b in zip(got, ref))
+    got = store.pp_score_batch(lives[:3], descs[:3], 3, return_counts=True)[1]   # too few scans for the block to pay
+    assert getattr(store, "block_calls", 0) == n0 + 1 and all(torch.equal(a, b) for a, b in zip(got, ref[:3]))
+    # a pose that disagrees with the lattice (a caller may hand in anything): the per-scan chain takes it
+    lv, arr, sl = descs[2]
+    arr2 = arr.copy()
+    arr2["rel"][0][3] += 0.01
+    bad = [descs[0], descs[1], (lv, arr2, sl)] + list(descs[3:])
+    assert store.block_tables(bad, 3, force=True) is None
+    # a frame with points outside its table (200 m from the sensor): known to the store, the block path declines
+    raw = sh.tracks[0][0][0].copy()
+    raw[:50, 0] += 400.0
+    store.insert_many([(777777, torch.from_numpy(raw).to(gpu), sh.tracks[0][0][1])])
+    lv, arr, sl = descs[0]
+    sl2 = sl.copy()
+    sl2[0] = store.frames[777777].slot
+    arr3 = arr.copy()
+    arr3["xyz_dev"][0], arr3["tab_dev"][0] = store.frames[777777].xyz.data_ptr(), store.frames[777777].tab.data_ptr()
+    assert store.block_tables([(lv, arr3, sl2)] + list(descs[1:]), 3, force=True) is None
+
+
+def test_block_ragged(gpu):
+    """Scans of different sizes, a scan without history, a scan without live points, frames shared by some scans only, and
+    a block of ONE scan: every scan equals its own per-scan call."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore, PP_FRAME
+    sh = synth.make_shard(6, n_live=2500, n_trav=3, n_frames=4, seed=9)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, ids = _load(store, sh, gpu, torch)
+    # scan 1 loses a whole traversal and a few frames, scan 4 has no history at all
+    lv, arr, sl = descs[1]
+    keep = np.array([k for k in range(len(arr)) if arr["trav"][k] != 1 and k % 5 != 0])
+    a1 = arr[keep].copy()
+    a1["trav"] = np.where(a1["trav"] == 2, 1, a1["trav"])
+    descs[1] = (lv, a1, np.concatenate([sl[:-1][keep], sl[-1:]]))
+    lv4, arr4, sl4 = descs[4]
+    descs[4] = (lv4, np.zeros(1, dtype=PP_FRAME), sl4[-1:])
+    ref = []
+    for k, d in zip(lives, descs):
+        T = 2 if d is descs[1] else 3
+        ref.append(store.pp_score_batch([k], [d], T, return_counts=True, block=False)[1][0])
+    # (one traversal count per call: scan 1 is checked in its own block of one)
+    idx = [0, 2, 3, 4, 5]
+    got = store.pp_score_batch([lives[i] for i in idx], [descs[i] for i in idx], 3, return_counts=True, block=True)[1]
+    for g, i in zip(got, idx):
+        assert torch.equal(g, ref[i]), i
+    assert int(ref[4].abs().sum()) == 0 and int(ref[0].sum()) > 0
+    one = store.pp_score_batch([lives[1]], [descs[1]], 2, return_counts=True, block=True)[1][0]
+    assert torch.equal(one, ref[1])
+
+
+def test_block_dense_window_bands(gpu):
+    """Live points piled up next to the sensor (hundreds per lattice cell: more than a join workgroup keeps in LDS for three
+    cell rows) exercise the column-split bands and the global-memory walk of a single overfull cell."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    sh = synth.make_shard(6, n_live=6000, n_trav=3, n_frames=4, seed=11)
+    rng = np.random.default_rng(0)
+    for sc in sh.scans:   # 3000 live points inside half a metre, 1500 of them inside one cell
+        sc.live_raw[:3000, :2] = rng.uniform(-0.25, 0.25, (3000, 2)).astype(np.float32) + np.float32(3.0)
+        sc.live_raw[:1500, :2] = rng.uniform(-0.1, 0.1, (1500, 2)).astype(np.float32) + np.float32(3.0)
+        sc.live_raw[:3000, 2] = rng.uniform(-1.8, -1.6, 3000).astype(np.float32)
+    for tr in sh.tracks:   # ... and history there
+        for raw, W in tr:
+            raw[:800, :2] = rng.uniform(-0.4, 0.4, (800, 2)).astype(np.float32) + np.float32(3.0)
+            raw[:800, 2] = rng.uniform(-1.8, -1.6, 800).astype(np.float32)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, _ = _load(store, sh, gpu, torch)
+    cb = store.pp_score_batch(lives, descs, 3, return_counts=True, block=True)[1]
+    cv = store.pp_score_batch(lives, descs, 3, return_counts=True, block=False)[1]
+    assert all(torch.equal(a, b) for a, b in zip(cb, cv))
+    _, cref = _oracle_counts(sh, 2)
+    assert np.array_equal(cb[2].cpu().numpy().astype(np.int64), cref) and cref.max() > 200

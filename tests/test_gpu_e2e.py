@@ -271,10 +271,11 @@ def test_bench_contract_json_line(gpu):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["in_pipeline"]["scans_timed"] == 16 and rf["isolated"]["kernel_ms"] > 0
-    # two resident scans -> chains of two scans per launch: bytes per launch and per scan must say so
+    # two resident scans (consecutive scans of one shard) -> two scans per PP call: bytes per call and per scan must say so
     assert rf["scans_per_launch"] == 2 and rf["algorithmic_bytes_per_launch"] == 2 * rf["algorithmic_bytes_per_scan"]
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
-    assert d["parity"]["pp_scans_per_launch"] == 1   # one CPU sample scan
+    assert rf["block_path"] is False   # fewer than 6 scans per call: every scan streams its own frames
+    assert d["parity"]["pp_scans_checked"] == 1 and d["parity"]["pp_scans_per_call"] == 2   # one CPU sample scan
     assert d["config"]["host_processes_per_gpu"] == 2 and d["config"]["rccl_world_size"] == 1
     # 8 steps per helper: the pool was used whole; fewer than 24 per helper: the steady-state figure is added
     assert d["steady_state"]["host_processes_per_gpu"] == 2 and d["steady_state"]["value"] > 0
