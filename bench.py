@@ -628,6 +628,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(torch.device("cuda", local))
     rccl_ws = torch.distributed.get_world_size() if (ws > 1 and torch.distributed.is_initialized()) else 1
+    rccl_check = dist.selfcheck()   # backend / world size / ranks counted by an all-reduce of ones (not read from the environment)
 
     helpers, note, M = [], None, None
     n_procs = helper_count(a.procs, a.steps)
@@ -905,7 +906,8 @@ def main():
                        "history_sharing": "consecutive scans of a shard: 35 of 36 frames per traversal shared with the predecessor "
                                           "(data_preprocessing/lyft/split_traintest.py:64,97; SURVEY 8d C4)",
                        "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
-                       "rccl_world_size": rccl_ws,
+                       "rccl_world_size": rccl_ws, "rccl_ranks_seen": rccl_check["ranks_seen"],
+                       "process_group_backend": rccl_check["backend"],
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli, "steady_state": steady,
             "value_with_ingest": with_ingest,

@@ -129,6 +129,7 @@ int modest_ransac_trials_phase(modest_ctx *ctx, const float *cand, int n_cand, c
                                double *syy, void *stream, int phase);
 int modest_ransac_refit_phase(modest_ctx *ctx, const float *cand, int n_cand, const float *model_host, float thr,
                               double *out_model, int32_t *n_inliers, void *stream, int phase);
+size_t modest_ransac_scratch_bound(int n_cand, int K);   // plane.hip: arena bytes of a trial batch / refit, see there
 int modest_mask_cluster_phase(modest_ctx *ctx, const float *pts, int n, int stride, const float *pp,
                               const double *plane4, double offset, const double *only_range4,
                               const double *limit_range4, int neighbor_type, int affinity_type, int k_neighbors,

@@ -1040,6 +1040,18 @@ extern "C" int modest_ransac_trials(modest_ctx *ctx, const float *cand, int n_ca
                                       stream_, 3);
 }
 
+// Device scratch a trial batch of K trials or a refit over at most n_cand candidates carves from the context arena.  A
+// driver that RECORDS launches (scan_driver.hip: a refit of fit A and the first batch of fit B go out together) reserves
+// this bound before the first recording: a later modest_ctx_reserve that had to grow the arena would free the block a
+// recorded launch still points into.
+size_t modest_ransac_scratch_bound(int n_cand, int K) {
+    const size_t nb = ((size_t)(n_cand > 0 ? n_cand : 1) + SCORE_PTS - 1) / SCORE_PTS, nrows = nb * SCORE_WAVES;
+    const size_t trials = arena_sz((size_t)K * 12) + arena_sz(8) + arena_sz(nrows * (size_t)K * 32);
+    const size_t nbr = ((size_t)(n_cand > 0 ? n_cand : 1) + SCORE_THREADS - 1) / SCORE_THREADS;
+    const size_t refit = arena_sz(nbr * REFIT_NV * 8);
+    return trials > refit ? trials : refit;
+}
+
 int modest_ransac_refit_phase(modest_ctx *ctx, const float *cand, int n_cand, const float *model_host, float thr,
                               double *out_model, int32_t *n_inliers, void *stream_, int phase) {
     MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");

@@ -104,6 +104,8 @@ extern "C" int modest_mask_stage(modest_ctx *ctx, const float *pts, int n, int s
     //    it between an enqueue and its read-back would free results.
     rc = modest_ctx_reserve_pinned(ctx, 16384);
     if (rc) return rc;
+    rc = modest_ctx_reserve(ctx, modest_ransac_scratch_bound(n_cand[0] > n_cand[1] ? n_cand[0] : n_cand[1], P->batch > 64 ? P->batch : 64));   // (ditto: the arena)
+    if (rc) return rc;
     Mt19937 g;
     memcpy(g.key, mt_key624, sizeof(g.key));
     g.pos = *mt_pos;
@@ -260,6 +262,12 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         Run &r = R[(size_t)s];
         q.info_out[4] = n_cand[(size_t)2 * s];
         q.info_out[5] = n_cand[(size_t)2 * s + 1];
+        {   // the arena of the scan's context holds any batch or refit of either fit BEFORE a launch is recorded: a
+            // reserve that grows it later would free the block a recorded launch points into
+            const int big = n_cand[(size_t)2 * s] > n_cand[(size_t)2 * s + 1] ? n_cand[(size_t)2 * s] : n_cand[(size_t)2 * s + 1];
+            int rc = modest_ctx_reserve(q.ctx, modest_ransac_scratch_bound(big, P->batch > 64 ? P->batch : 64));
+            if (rc) return rc;
+        }
         if (n_cand[(size_t)2 * s] <= 300 || n_cand[(size_t)2 * s + 1] <= 300) {
             q.info_out[3] = MODEST_STAGE_SMALL_SET;
             continue;

@@ -423,9 +423,17 @@ extern "C" int modest_label_lines(const double *objs8, const double *cossin_ry, 
         }
         const double alpha = -std::atan2(t0, t2) + ry;
         const double f[12] = {alpha, lo_u, lo_v, hi_u, hi_v, h, w, l, t0, t1, t2, ry};
-        char line[512];
+        // a projected corner next to the image plane prints hundreds of digits with %.4f: 12 x (1 + 309 + 5) + the prefix
+        char line[4096];
         int p = snprintf(line, sizeof(line), "%sDynamic -1 -1", nk ? "\n" : "");
-        for (int q = 0; q < 12; ++q) p += snprintf(line + p, sizeof(line) - (size_t)p, " %.4f", f[q]);
+        for (int q = 0; q < 12; ++q) {
+            const int w_ = snprintf(line + p, sizeof(line) - (size_t)p, " %.4f", f[q]);
+            if (w_ < 0 || (size_t)(p + w_) >= sizeof(line)) {   // (cannot happen for finite doubles; never read past the buffer)
+                modest_set_error("modest_label_lines: a label line does not fit %zu bytes", sizeof(line));
+                return MODEST_ERR_CAPACITY;
+            }
+            p += w_;
+        }
         if (len + p + 1 > text_cap) {
             modest_set_error("modest_label_lines: text buffer of %d bytes is too small", text_cap);
             return MODEST_ERR_CAPACITY;

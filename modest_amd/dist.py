@@ -26,9 +26,13 @@ def world() -> tuple:
 
 
 def init(backend: Optional[str] = None) -> tuple:
-    """Initialise torch.distributed when launched with WORLD_SIZE > 1."""
+    """Initialise torch.distributed when launched with WORLD_SIZE > 1 -- or, with MODEST_DIST_FORCE=1, at world size 1
+    too: the RCCL branches of barrier() / reduce_counters() (device_ids, CUDA tensors) then run on a box with a single
+    GPU exactly as they do on a node (a launcher must have set MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE, or the
+    defaults below apply).  A forced run prints the result of selfcheck() on stderr."""
     rank, ws, local = world()
-    if ws > 1 and not torch.distributed.is_initialized():
+    force = os.environ.get("MODEST_DIST_FORCE", "") == "1"
+    if (ws > 1 or force) and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -41,7 +45,22 @@ def init(backend: Optional[str] = None) -> tuple:
                                    "visible); set MODEST_DIST_BACKEND=gloo to let ranks share devices")
             torch.cuda.set_device(local)
         torch.distributed.init_process_group(backend=backend, rank=rank, world_size=ws)
+        if force:
+            import sys
+            print("[dist] " + " ".join(f"{k}={v}" for k, v in selfcheck().items()), file=sys.stderr, flush=True)
     return rank, ws, local
+
+
+def selfcheck() -> Dict[str, object]:
+    """What the process group actually does (not what the environment says): backend, world size, a barrier, and an
+    all-reduce of one 1 per rank -- `ranks_seen` must equal the world size.  Without a process group: ranks_seen = 1,
+    backend = none."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return dict(backend="none", world_size=1, ranks_seen=1, barrier="skipped")
+    barrier()
+    seen = reduce_counters(dict(ones=1.0))["ones"]
+    return dict(backend=torch.distributed.get_backend(), world_size=torch.distributed.get_world_size(),
+                ranks_seen=int(round(seen)), barrier="ok")
 
 
 def device_index(local: int, ws: int, cfg) -> int:
@@ -116,6 +135,10 @@ def scans_of(idx_list, cfg, rank: int, ws: int, name: str):
     per-rank split (`work_queue: static`, the default) or the chunked dynamic queue shared by the ranks
     (`work_queue: dynamic`, `queue_chunk`), then -- inside a worker -- the worker's piece."""
     mode = str(cfg.get("work_queue", "static"))
+    if mode == "dynamic" and ws > 1 and int(cfg.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER") and rank == 0:
+        import sys
+        print(f"[{name}] work_queue=dynamic is ignored with workers > 1 (the workers of a rank take contiguous pieces of the "
+              "rank's static share): static split", file=sys.stderr, flush=True)
     if mode == "dynamic" and ws > 1 and not os.environ.get("MODEST_WORKER") and int(cfg.get("workers", 1) or 1) <= 1:
         part = shard(idx_list, cfg.total_part, cfg.part, rank=0, ws=1)
         return WorkQueue(part, rank, ws, "dynamic", int(cfg.get("queue_chunk", 32)), name)

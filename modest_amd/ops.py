@@ -620,10 +620,15 @@ def label_lines(objs8: np.ndarray, order: Optional[np.ndarray], iou: Optional[np
     kept = np.zeros(k, dtype=np.int32)
     nk, tl = C.c_int32(0), C.c_int32(0)
     cap = 256 * k + 16
-    buf = C.create_string_buffer(cap)
-    check(lib.modest_label_lines(_np_ptr(objs8), _np_ptr(cs), k, _np_ptr(order) if nms_enable else None,
-                                 _np_ptr(iou) if nms_enable else None, C.byref(Q), _np_ptr(kept), C.byref(nk), buf, cap,
-                                 C.byref(tl)), "modest_label_lines")
+    for _ in range(2):   # 256 bytes per line hold every sane box; a corner next to the image plane prints longer numbers
+        buf = C.create_string_buffer(cap)
+        rc = lib.modest_label_lines(_np_ptr(objs8), _np_ptr(cs), k, _np_ptr(order) if nms_enable else None,
+                                    _np_ptr(iou) if nms_enable else None, C.byref(Q), _np_ptr(kept), C.byref(nk), buf, cap,
+                                    C.byref(tl))
+        if rc != -3 or cap >= 4096 * k + 16:   # MODEST_ERR_CAPACITY: once more with the library's own line bound
+            break
+        cap = 4096 * k + 16
+    check(rc, "modest_label_lines")
     return buf.raw[: tl.value].decode("ascii"), kept[: nk.value]
 
 

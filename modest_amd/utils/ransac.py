@@ -25,14 +25,54 @@ from __future__ import annotations
 
 import numpy as np
 import torch
-from sklearn.utils import check_random_state
-from sklearn.utils.random import sample_without_replacement
+import numbers
 
 from .. import ops
 from .._lib import ModestHipError
 
 _EPSILON = np.spacing(1)
 NATIVE_DRIVER = True   # tests switch it off to compare the library's trial loop with the Python statement below
+
+
+def check_random_state(seed):
+    """sklearn.utils.check_random_state: None / np.random -> numpy's global RandomState, an int seeds a fresh one, a
+    RandomState is passed through."""
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, numbers.Integral):
+        return np.random.RandomState(seed)
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError("%r cannot be used to seed a numpy.random.RandomState instance" % seed)
+
+
+def sample_without_replacement(n_population: int, n_samples: int, random_state) -> np.ndarray:
+    """What sklearn.utils.random.sample_without_replacement(..., method="auto") draws from a RandomState
+    (sklearn/utils/_random.pyx): for 0.01 < n_samples / n_population < 0.99 the first n_samples entries of
+    `permutation(n_population)`; below 0.2 otherwise "tracking selection" -- `randint(n_population)` until the value is
+    new; else reservoir sampling.  The library's modest_mt19937_triplets makes the same draws for large populations;
+    this is the statement for all of them (tests/test_abi_and_host.py compares values AND generator state with
+    sklearn's)."""
+    rs = check_random_state(random_state)
+    ratio = n_samples / n_population if n_population != 0 else 1.0
+    if 0.01 < ratio < 0.99:
+        return rs.permutation(n_population)[:n_samples]
+    out = np.empty(n_samples, dtype=np.int64)
+    if ratio < 0.2:
+        seen = set()
+        for i in range(n_samples):
+            j = int(rs.randint(n_population))
+            while j in seen:
+                j = int(rs.randint(n_population))
+            seen.add(j)
+            out[i] = j
+        return out
+    out[:] = np.arange(n_samples)
+    for i in range(n_samples, n_population):
+        j = int(rs.randint(0, i + 1))
+        if j < n_samples:
+            out[j] = i
+    return out
 
 
 def dynamic_max_trials(n_inliers, n_samples, min_samples, probability):
@@ -89,7 +129,7 @@ def draw_triplets(rs, n_population, n_trials):
     three distinct values are found; that stream is consumed here in one vectorised call
     (tests/test_abi_and_host.py checks triplets AND generator state against sklearn).
     Returns (triplets (B,3) int64, draws consumed after each trial (B,) or None)."""
-    if 3.0 / n_population >= 0.01:    # small populations use other sklearn methods: call it directly
+    if 3.0 / n_population >= 0.01:    # small populations: sklearn's permutation / reservoir methods (statement above)
         return np.stack([sample_without_replacement(n_population, 3, random_state=rs)
                          for _ in range(n_trials)]), None
     state = rs.get_state()

@@ -120,6 +120,26 @@ def test_vectorised_triplet_stream_equals_sklearn():
                 assert np.array_equal(b.get_state()[1], c.get_state()[1]) and b.get_state()[2] == c.get_state()[2]
 
 
+def test_sample_without_replacement_statement_equals_sklearn():
+    """modest_amd.utils.ransac no longer imports sklearn: its statement of sample_without_replacement(method="auto") --
+    permutation for 0.01 < ratio < 0.99, tracking selection below, reservoir sampling at ratio >= 0.99 -- makes sklearn's
+    draws and leaves the generator in sklearn's state, for every population size up to the library's own method."""
+    from sklearn.utils.random import sample_without_replacement as ref_swr
+    from modest_amd.utils.ransac import check_random_state, sample_without_replacement
+    for n_pop in list(range(3, 40)) + [100, 299, 300, 301, 302, 500, 5000]:
+        a, b = np.random.RandomState(n_pop), np.random.RandomState(n_pop)
+        for _ in range(25):
+            assert np.array_equal(ref_swr(n_pop, 3, random_state=a), sample_without_replacement(n_pop, 3, b)), n_pop
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:], n_pop
+    np.random.seed(7)
+    g = check_random_state(None)
+    assert g is np.random.mtrand._rand and check_random_state(g) is g and isinstance(check_random_state(3), np.random.RandomState)
+    import modest_amd.utils.ransac as mr
+    src = open(mr.__file__).read()
+    assert "import sklearn" not in src and "from sklearn" not in src
+
+
 def test_library_mt19937_triplets_equal_sklearn():
     """The generator half of modest_ransac_plane (host code of the library): triplets AND the generator
     state after them equal sklearn's sample_without_replacement on numpy's legacy RandomState, incl. a

@@ -102,3 +102,33 @@ def test_three_clis_two_ranks_one_gpu(gpu, tmp_path):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "multirank_report.json"), "w") as f:
         json.dump(dict(scans=N_SCANS, world_size=2, note="both ranks on GPU 0, gloo collectives", per_cli=report), f, indent=1)
+
+
+def test_rccl_process_group_at_world_size_one(gpu, tmp_path):
+    """The RCCL branches of dist.init / barrier(device_ids) / reduce_counters (CUDA tensors) on the hardware there is: the PP
+    CLI under `torch.distributed.run --nproc-per-node 1` with MODEST_DIST_FORCE=1 initialises an `nccl` process group
+    of one rank, passes the barrier, counts its ranks with an all-reduce of ones -- and writes the files of a plain run
+    (the sharding the group serves: pre_compute_pp_score.py:114-116)."""
+    from modest_amd import synth
+    root, meta = str(tmp_path / "data"), str(tmp_path / "meta")
+    n = 12
+    paths = synth.write_kitti_tree(root, meta, n_seq=3, n_frames=n + 5, n_pts=3000, origins=tuple(range(n)), hist_frames=5,
+                                   max_range=60.0)
+    train = os.path.join(root, "training")
+    plain, forced = str(tmp_path / "plain"), str(tmp_path / "forced")
+    _run("pre_compute_pp_score", _overrides(train, paths, plain), 1, 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", MODEST_DIST_FORCE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MODEST_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "-m", "modest_amd.pre_compute_pp_score"] + _overrides(train, paths, forced)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stderr.splitlines() if l.startswith("[dist] ")]
+    assert line, r.stderr[-2000:]
+    got = dict(kv.split("=") for kv in line[0][len("[dist] "):].split())
+    assert got == {"backend": "nccl", "world_size": "1", "ranks_seen": "1", "barrier": "ok"}, got
+    fa = sorted(os.listdir(os.path.join(plain, "pp")))
+    assert fa == sorted(os.listdir(os.path.join(forced, "pp"))) and len(fa) == n
+    match, mismatch, err = filecmp.cmpfiles(os.path.join(plain, "pp"), os.path.join(forced, "pp"), fa, shallow=False)
+    assert not mismatch and not err
