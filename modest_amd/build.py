@@ -53,6 +53,63 @@ def sources():
     return sorted(CSRC.glob("*.hip"))
 
 
+# ---- the ordering the last-block reductions rest on, checked in the machine code ----------------------------------
+# plane.hip / boxfit.hip publish per-block partial results with agent-scope (sc1, write-through) stores and take a ticket;
+# the block that draws the last ticket reads the partials.  What orders the stores before the ticket is NOT the HIP memory
+# model but `modest_drain_stores()` (common.h: an inline `s_waitcnt vmcnt(0)`) ahead of the workgroup barrier that
+# precedes the ticket -- rounds 1-2 shipped without it (0.08 % wrong planes / boxes under load).  A compiler upgrade may
+# move or drop that wait, so the build disassembles those translation units and refuses to produce a library in which,
+# in any kernel, the last sc1 store ahead of a returning atomic add (the ticket) is not followed by `s_waitcnt vmcnt(0)`
+# before the ticket -- and before the workgroup barrier, where one lies between them (the ticket is then taken by
+# another wavefront than the one that stored).
+DRAIN_SOURCES = ("plane.hip", "boxfit.hip")
+
+
+def ticket_drain_violations(asm: str) -> list:
+    """[(kernel, line number of the ticket atomic, reason)] for device assembly text (hipcc -S --cuda-device-only)."""
+    import re
+    bad, kernel, body, start = [], None, [], 0
+    lines = asm.splitlines()
+
+    def check(name, rows, first):
+        for t, row in enumerate(rows):
+            if not (re.search(r"\b(global|flat)_atomic_add(_u32)?\b", row) and re.search(r"\bsc0\b", row)):
+                continue   # a returning 32-bit atomic add = a ticket
+            stores = [i for i in range(t) if re.search(r"\b(global|flat)_store_\w+", rows[i]) and re.search(r"\bsc1\b", rows[i])]
+            if not stores:
+                continue   # a ticket without published partials (compaction cursors): nothing to order
+            s = stores[-1]
+            wait = next((i for i in range(s + 1, t) if re.search(r"\bs_waitcnt\b.*\bvmcnt\(0\)", rows[i])), None)
+            barrier = next((i for i in range(s + 1, t) if re.search(r"\bs_barrier\b", rows[i])), None)
+            if wait is None:
+                bad.append((name, first + t + 1, "no s_waitcnt vmcnt(0) between the last sc1 store and the ticket"))
+            elif barrier is not None and wait > barrier:
+                bad.append((name, first + t + 1, "the s_waitcnt vmcnt(0) comes after the barrier that precedes the ticket: another "
+                                                  "wavefront's store may still be in flight"))
+
+    for n, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            if kernel:
+                check(kernel, body, start)
+            kernel, body, start = m.group(1), [], n + 1
+        elif kernel is not None:
+            body.append(line)
+            if re.search(r"\bs_endpgm\b", line):
+                check(kernel, body, start)
+                kernel, body = None, []
+    return bad
+
+
+def device_asm(src: Path, out: Path) -> str:
+    """gfx950 assembly of one translation unit (seconds)."""
+    cmd = [_hipcc(), *[f for f in CXXFLAGS if f not in ("-fPIC",)], "-S", "--cuda-device-only", str(src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed on {src.name}:\n{r.stderr}")
+    return out.read_text()
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
     srcs = sources()
     hdrs = sorted(CSRC.glob("*.h")) + sorted((ROOT / "include").glob("*.h"))
@@ -98,8 +155,17 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             print("\n".join(diag), file=sys.stderr)
         return obj
 
+    def drain_check(src: Path):
+        bad = ticket_drain_violations(device_asm(src, OBJDIR / (src.stem + ".gfx950.s")))
+        if bad:
+            raise RuntimeError(f"{src.name}: a last-block reduction publishes its partial results without draining them before "
+                               f"the ticket (common.h: modest_drain_stores): {bad}")
+
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        checks = [ex.submit(drain_check, x) for x in srcs if x.name in DRAIN_SOURCES]
         objs = list(ex.map(compile_one, srcs))
+        for c in checks:
+            c.result()
     (LIBDIR / "kernel_resources.json").write_text(json.dumps(resources, indent=1, sort_keys=True))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     if verbose:

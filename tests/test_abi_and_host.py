@@ -295,3 +295,30 @@ def test_batched_relative_poses_equal_per_frame_calls(golden_dir):
     # WorldTable gathers what the per-frame dictionary held
     wt = pcs.WorldTable({5: np.eye(4) * 2, 9: np.eye(4) * 3}).freeze()
     assert np.array_equal(wt.stack([9, 5, 9]), np.stack([np.eye(4) * 3, np.eye(4) * 2, np.eye(4) * 3]))
+
+
+def test_last_block_reductions_drain_their_stores_before_the_ticket(tmp_path):
+    """common.h: the partial results of the last-block reductions (score_kernel, refit_kernel, closeness_tree_kernel,
+    lowest_kernel and their chained forms) are ordered before the ticket by an inline `s_waitcnt vmcnt(0)`, not by the HIP
+    memory model (rounds 1-2 shipped without it: 0.08 % wrong planes / boxes under load).  The build checks the machine
+    code of every such kernel (build.ticket_drain_violations); here: the shipped assembly passes, and the check FAILS
+    when modest_drain_stores() is removed from any one of its four call sites."""
+    import re
+    from modest_amd import build
+    build.build(verbose=False)
+    for name in build.DRAIN_SOURCES:
+        asm = (build.OBJDIR / (name.replace(".hip", "") + ".gfx950.s")).read_text()
+        assert build.ticket_drain_violations(asm) == []
+        assert len(re.findall(r"ASMSTART\s+s_waitcnt vmcnt\(0\)", asm)) >= 2, name   # the drains are there at all
+    sites = 0
+    for name in build.DRAIN_SOURCES:
+        src = (build.CSRC / name).read_text()
+        calls = [m.start() for m in re.finditer(r"modest_drain_stores\(\);", src)]
+        for k, pos in enumerate(calls):
+            broken = src[:pos] + "/* removed */" + src[pos + len("modest_drain_stores();"):]
+            f = tmp_path / f"{k}_{name}"
+            f.write_text(broken)
+            bad = build.ticket_drain_violations(build.device_asm(f, tmp_path / f"{k}_{name}.s"))
+            assert bad, (name, k)
+            sites += 1
+    assert sites == 4
