@@ -52,27 +52,28 @@ def test_block_equals_oracle_and_chain(gpu, nusc, T, F, S):
 
 
 def test_block_choice_and_fallbacks(gpu):
-    """The store takes the block path on its own from six scans that share their frames; scans without shared frames, a frame
+    """The store takes the block path on its own from eight scans that share most of their frames (long windows: >= 24
+    frames per traversal); short windows, few scans, a frame
     with points outside its table, poses that disagree with the lattice and a radius other than the store's all take the
     per-scan chain -- with identical results."""
     import torch
     from modest_amd import synth
     from modest_amd.frame_store import FrameStore
-    sh = synth.make_shard(8, n_live=3000, n_trav=3, n_frames=5, seed=5)
+    sh = synth.make_shard(8, n_live=1500, n_trav=2, n_frames=24, n_per_frame=1500, seed=5)
     store = FrameStore(gpu, 0.3)
     lives, descs, ids = _load(store, sh, gpu, torch)
-    ref = store.pp_score_batch(lives, descs, 3, return_counts=True, block=False)[1]
+    ref = store.pp_score_batch(lives, descs, 2, return_counts=True, block=False)[1]
     n0 = getattr(store, "block_calls", 0)
-    got = store.pp_score_batch(lives, descs, 3, return_counts=True)[1]   # automatic: 8 scans sharing 4 of 5 frames
+    got = store.pp_score_batch(lives, descs, 2, return_counts=True)[1]   # automatic: 8 scans sharing 23 of 24 frames
     assert getattr(store, "block_calls", 0) == n0 + 1 and all(torch.equal(a, b) for a, b in zip(got, ref))
-    got = store.pp_score_batch(lives[:3], descs[:3], 3, return_counts=True)[1]   # too few scans for the block to pay
+    got = store.pp_score_batch(lives[:3], descs[:3], 2, return_counts=True)[1]   # too few scans for the block to pay
     assert getattr(store, "block_calls", 0) == n0 + 1 and all(torch.equal(a, b) for a, b in zip(got, ref[:3]))
     # a pose that disagrees with the lattice (a caller may hand in anything): the per-scan chain takes it
     lv, arr, sl = descs[2]
     arr2 = arr.copy()
     arr2["rel"][0][3] += 0.01
     bad = [descs[0], descs[1], (lv, arr2, sl)] + list(descs[3:])
-    assert store.block_tables(bad, 3, force=True) is None
+    assert store.block_tables(bad, 2, force=True) is None
     # a frame with points outside its table (200 m from the sensor): known to the store, the block path declines
     raw = sh.tracks[0][0][0].copy()
     raw[:50, 0] += 400.0
@@ -82,7 +83,7 @@ def test_block_choice_and_fallbacks(gpu):
     sl2[0] = store.frames[777777].slot
     arr3 = arr.copy()
     arr3["xyz_dev"][0], arr3["tab_dev"][0] = store.frames[777777].xyz.data_ptr(), store.frames[777777].tab.data_ptr()
-    assert store.block_tables([(lv, arr3, sl2)] + list(descs[1:]), 3, force=True) is None
+    assert store.block_tables([(lv, arr3, sl2)] + list(descs[1:]), 2, force=True) is None
 
 
 def test_block_ragged(gpu):
