@@ -75,7 +75,7 @@ def parse(argv=None):
     ap.add_argument("--pp-batch", type=int, default=16,
                     help="consecutive scans whose PP stage is ONE call (FrameStore.pp_score_batch: modest_pp_score_block for >= 6 "
                          "scans that share their frames, modest_pp_score_frames_batch otherwise); clamped to --shard-scans")
-    ap.add_argument("--mask-batch", type=int, default=4, help="scans per chain of stages 2 + 3 (modest_mask_stage_batch)")
+    ap.add_argument("--mask-batch", type=int, default=16, help="scans per chain of stages 2 + 3 (modest_mask_stage_batch)")
     ap.add_argument("--no-pp-block", action="store_true",
                     help="A/B: the PP stage through modest_pp_score_frames_batch (every scan streams its own 361 frames) in chains of "
                          "at most 8 scans, never through modest_pp_score_block")
@@ -419,6 +419,20 @@ class Runner:
         if errs:
             raise errs[0]
 
+    def rehearse(self, n_steps):
+        """Untimed, before the clock: one pass over the SHAPES the timed region will run (its first block and its last,
+        possibly partial, one).  A block of fewer than 8 scans takes the per-scan chain, whose scratch arena differs from the
+        block path's; an arena that grows inside the timed region costs a device synchronise + hipFree + hipMalloc under
+        eight processes (measured: 40 steps in 0.45 s instead of 0.01 s)."""
+        if n_steps <= 0 or n_steps in getattr(self, "_rehearsed", set()):
+            return
+        blocks = self.blocks_of(self.n_warm, self.n_warm + n_steps)
+        shapes = {len(b): b for b in blocks}
+        for b in shapes.values():
+            self.run(b[0], b[-1] + 1)
+        torch.cuda.synchronize()
+        self._rehearsed = getattr(self, "_rehearsed", set()) | {n_steps}
+
     def timed(self, n_steps, ingest=False):
         """n_steps steps -> (seconds, HIP-event times of every PP stage launched)"""
         self.ingest = bool(ingest)
@@ -484,6 +498,7 @@ def _helper_main(conn, a, rank, local, slot, flag):
             cmd, arg = conn.recv()
             if cmd == "arm":
                 n, gen, ingest = arg
+                r.rehearse(int(n))
                 conn.send(("armed", None))
                 while flag.value != gen:
                     pass
@@ -692,6 +707,7 @@ def main():
     if helpers:
         dt, kernel_ms = timed_region(helpers[:n_procs], _split(a.steps, n_procs))
     else:
+        runner.rehearse(a.steps)
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
