@@ -186,7 +186,10 @@ int modest_pp_score_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_f
  * modest_pp_score_frames, bit for bit.
  *
  * frames_host [host] (n_frames): the union, each frame once.  lat = the 2x4 float64 map the frame was
- *   sorted with (modest_frame_sort_job::W); flags: MODEST_FRAME_REMOVE_CENTER (all or none).
+ *   sorted with (modest_frame_sort_job::W); flags: MODEST_FRAME_REMOVE_CENTER (all or none).  The ORDER of the table is
+ *   the caller's: a scan reads, cell by cell, the records of the table range [its first frame, its last frame] (and masks
+ *   the frames in between that are not its own), so an order in which every scan's frames are contiguous -- for the
+ *   sliding windows of a shard: by (first scan, last scan) that uses the frame -- saves the other scans' records.
  * scans_host [host] (n_scans): the live frame of the store (xyz / perm / tab, lat as above, rel = its float32
  *   relative pose), the scan's history frames as (member_slot = index into frames_host, member_trav,
  *   member_rel = rows 0..2 of the frame's float32 relative pose IN THIS SCAN), outputs as above.

@@ -93,6 +93,7 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
     const UFrame *frames;
     const uint2 *chunkTab;
     unsigned *off, *gtot, *listTotal, *listBase, *segBase, *segList, *segHist, *segOff, *cellOff, *ctrl;
+    uint2 *segRange;   // smallest / largest frame slot among a segment's records
     float4 *recA, *recB;
     int U, NG, nchunks, maxSegs;
     int BX0, BY0, BW, BH, BT, CW, CHc, NCpad, nScanBlk, G;
@@ -102,6 +103,7 @@ struct ScanDev {   // per scan (device table)
     const float *liveXyz;
     const unsigned *livePerm, *liveTab;
     unsigned *cellCount, *cellStart, *blockSum, *tileTasks, *ctrl;   // ctrl: [0] items, [1] queue head
+    uint2 *cellRange;   // per (tile with tasks, cell): first record and count of the part of the cell this scan reads
     float4 *tmp, *sorted;
     uint4 *items;
     const PoseEnt *pose;
@@ -110,6 +112,7 @@ struct ScanDev {   // per scan (device table)
     double lat[8];
     float rel[12];
     int n, TX0, TY0, T, maxItems, pad;
+    int slotLo, slotHi;   // the scan's frames lie in [slotLo, slotHi] of the block's frame table
 };
 
 // lattice cell of a raw point: the arithmetic of frame_bin (pp_frames.hip) -- a frame's tile runs were
@@ -267,22 +270,38 @@ __global__ __launch_bounds__(1024) void b4_scatter(Blk B) {
 
 // ---- tile lists -> cell order --------------------------------------------------------------------
 __global__ __launch_bounds__(512) void b4_seg_hist(Blk B) {
-    __shared__ unsigned hist[64];
+    __shared__ unsigned hist[64], smin, smax;
     const unsigned seg = blockIdx.x;
     if (seg >= B.ctrl[1]) return;
     const int tid = threadIdx.x;
     if (tid < 64) hist[tid] = 0;
+    if (tid == 64) smin = 0xffffffffu, smax = 0u;
     __syncthreads();
+    unsigned mn = 0xffffffffu, mx = 0u;
     const unsigned b = B.segList[seg];
     const unsigned lo = B.listBase[b] + (seg - B.segBase[b]) * B4_SEG;
     const unsigned hi = min(B.listBase[b] + B.listTotal[b], lo + B4_SEG);
 #pragma unroll
     for (int u = 0; u < B4_SEG / 512; ++u) {
         const unsigned i = lo + u * 512 + tid;
-        if (i < hi) atomicAdd(&hist[__float_as_int(B.recA[i].w) & 63], 1u);
+        if (i < hi) {
+            const unsigned m = (unsigned)__float_as_int(B.recA[i].w);
+            atomicAdd(&hist[m & 63], 1u);
+            mn = min(mn, m >> 6);
+            mx = max(mx, m >> 6);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    }
+    if ((tid & 63) == 0) {
+        atomicMin(&smin, mn);
+        atomicMax(&smax, mx);
     }
     __syncthreads();
     if (tid < 64) B.segHist[(size_t)seg * 64 + tid] = hist[tid];
+    if (tid == 0) B.segRange[seg] = make_uint2(smin, smax);   // (a tile list is in frame order: the ranges of its segments ascend)
 }
 
 // one wavefront per list, lane = cell: offsets of every (segment, cell) inside its cell run, cell bases
@@ -442,11 +461,35 @@ __global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__res
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B.BT) return;
     unsigned th = 0, lv = 0;
-    if (B.listTotal[b] != 0u) {
-        const unsigned n = B.cellOff[(size_t)b * 65 + lane + 1] - B.cellOff[(size_t)b * 65 + lane];
+    const unsigned total = B.listTotal[b];
+    if (total != 0u) {
+        // The part of every cell this scan reads.  The tile list is in the order of the block's frame table and its
+        // segments were sorted one by one, so a cell's records are [run of segment 0 | run of segment 1 | ...] with ascending
+        // frame slots from run to run: the runs of the segments that overlap [slotLo, slotHi] hold every record of the
+        // scan's own frames (and, in the two boundary runs, some of the block's other scans' frames: masked per lane).
+        const unsigned ns = (total + B4_SEG - 1) / B4_SEG, s0 = B.segBase[b];
+        unsigned kf = ns, kl = 0;
+        bool any = false;
+        for (unsigned k = 0; k < ns; ++k) {   // (wave-uniform: scalar loads)
+            const uint2 r = B.segRange[s0 + k];
+            if (r.y >= (unsigned)S.slotLo && r.x <= (unsigned)S.slotHi) {
+                kf = min(kf, k);
+                kl = k;
+                any = true;
+            }
+        }
+        unsigned start = 0, n = 0;
+        if (any) {
+            const unsigned base = B.cellOff[(size_t)b * 65 + lane];
+            start = base + B.segOff[(size_t)(s0 + kf) * 64 + lane];
+            const unsigned end = kl + 1 < ns ? base + B.segOff[(size_t)(s0 + kl + 1) * 64 + lane] : B.cellOff[(size_t)b * 65 + lane + 1];
+            n = end - start;
+        }
+        bool active = false;
         if (n) {
             const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
             if (b4_cell_cand(S.cellStart, B.CW, B.CHc, cx, cy)) {
+                active = true;
                 if (n >= B4_HEAVY) th = (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT;
                 else lv = n;
             }
@@ -455,6 +498,7 @@ __global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__res
             th += __shfl_xor(th, o);
             lv += __shfl_xor(lv, o);
         }
+        if (th + lv) S.cellRange[(size_t)b * 64 + lane] = make_uint2(start, active ? n : 0u);   // (only tiles with work are read back)
     }
     if (lane == 0) S.tileTasks[b] = (th << 12) | lv;   // lv <= 64 * 63
 }
@@ -569,6 +613,7 @@ __device__ __forceinline__ void b4_segmask(unsigned trv, bool valid, int T, int 
 // the LDS counter as well, so every LDS wait also waits for them); the join states that they are global
 typedef float v4f __attribute__((ext_vector_type(4)));      // (HIP's float4 is a class: no address-space qualified copies)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #define B4_GLOBAL(T) const __attribute__((address_space(1))) T *
 template <typename T> __device__ __forceinline__ B4_GLOBAL(T) b4_global(const T *p) {
     return (B4_GLOBAL(T))(p);
@@ -681,7 +726,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     B4_GLOBAL(v4f) sorted = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
     B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
     B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
-    B4_GLOBAL(unsigned) cellOff = b4_global(B.cellOff);
+    B4_GLOBAL(unsigned) tileTasks = b4_global(SC.tileTasks);
+    B4_GLOBAL(v2u) cellRange = b4_global(reinterpret_cast<const v2u *>(SC.cellRange));
     B4_GLOBAL(v4u) items = b4_global(reinterpret_cast<const v4u *>(SC.items));
     int *counts = SC.counts;
     const int CW = B.CW, CHc = B.CHc;
@@ -787,9 +833,12 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             const int tx = tbx + (cxq >> 3), ty = tby + (cyq >> 3);
             unsigned rs = 0, rn = 0;
             if (tx < B.BW && ty < B.BH) {
-                const size_t o = (size_t)(ty * B.BW + tx) * 65 + (cyq & 7) * 8 + (cxq & 7);
-                rs = cellOff[o];
-                rn = cellOff[o + 1] - rs;
+                const int bt = ty * B.BW + tx;
+                if (tileTasks[bt] != 0u) {   // (the plan wrote the ranges of the tiles that have work for this scan)
+                    const v2u r2_ = cellRange[(size_t)bt * 64 + (cyq & 7) * 8 + (cxq & 7)];
+                    rs = r2_.x;
+                    rn = r2_.y;
+                }
             }
             S.recStart[tid] = rs;
             S.recN[tid] = rn;
@@ -1227,11 +1276,11 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oOff = take((size_t)std::max(U, 1) * BT * 4), oGtot = take((size_t)std::max(NG, 1) * BT * 4);
     const size_t oTotal = take((size_t)BT * 4), oBase = take((size_t)BT * 4), oSegBase = take((size_t)BT * 4);
     const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
-    const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256);
+    const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256), oSegRange = take(maxSegs * 8);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
-        size_t cellStart, blockSum, tileTasks, ctrl, tmp, sorted, items, counts;
+        size_t cellStart, blockSum, tileTasks, ctrl, tmp, sorted, items, counts, cellRange;
     };
     std::vector<ScanOff> so((size_t)G);
     for (int s = 0; s < G; ++s) {
@@ -1244,6 +1293,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         so[(size_t)s].sorted = take((size_t)std::max(n, 1) * 16);
         so[(size_t)s].items = take(maxItems * 16);
         so[(size_t)s].counts = take((size_t)std::max(n, 1) * T * 4);
+        so[(size_t)s].cellRange = take((size_t)BT * 64 * 8);
     }
     // staged block: [UFrame x U][chunkTab][ScanDev x G][PoseEnt x G x U]
     const size_t stFrames = 0, stChunks = arena_sz((size_t)std::max(U, 1) * sizeof(UFrame));
@@ -1293,6 +1343,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.tmp = reinterpret_cast<float4 *>(base + o.tmp);
         d.sorted = reinterpret_cast<float4 *>(base + o.sorted);
         d.items = reinterpret_cast<uint4 *>(base + o.items);
+        d.cellRange = reinterpret_cast<uint2 *>(base + o.cellRange);
         d.pose = reinterpret_cast<const PoseEnt *>(dstage + stPose) + (size_t)s * std::max(U, 1);
         d.counts = sc.counts_dev ? sc.counts_dev : reinterpret_cast<int *>(base + o.counts);
         d.H = sc.H_dev;
@@ -1304,6 +1355,12 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.T = T;
         d.maxItems = (int)maxItems;
         PoseEnt *pe = hp + (size_t)s * std::max(U, 1);
+        d.slotLo = U, d.slotHi = -1;
+        for (int m = 0; m < sc.n_members; ++m) {
+            d.slotLo = std::min(d.slotLo, sc.member_slot[m]);
+            d.slotHi = std::max(d.slotHi, sc.member_slot[m]);
+        }
+        if (d.slotHi < 0) d.slotLo = 0, d.slotHi = 0;
         for (int m = 0; m < sc.n_members; ++m) {
             PoseEnt &e = pe[sc.member_slot[m]];
             for (int q = 0; q < 12; ++q) e.rel[q] = sc.member_rel[(size_t)m * 12 + q];
@@ -1327,6 +1384,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     B.segHist = reinterpret_cast<unsigned *>(base + oSegHist);
     B.segOff = reinterpret_cast<unsigned *>(base + oSegOff);
     B.cellOff = reinterpret_cast<unsigned *>(base + oCellOff);
+    B.segRange = reinterpret_cast<uint2 *>(base + oSegRange);
     B.ctrl = reinterpret_cast<unsigned *>(base + oCtrl);
     B.recA = reinterpret_cast<float4 *>(base + oRecA);
     B.recB = reinterpret_cast<float4 *>(base + oRecB);

@@ -566,6 +566,18 @@ class FrameStore:
                                        np.broadcast_to(bottom, (len(h), 1, 4))], axis=1)
                 if not self.consistent(h, rels, A):
                     return None
+            # the block's frame table in the order (first scan that uses the frame, last scan that uses it): the frames of every
+            # scan of a sliding window are then one contiguous range of the table, and the join skips -- run by run of the
+            # cell-sorted store -- the records of the frames a scan does not use (modest_hip.h)
+            first = np.full(len(us), B, dtype=np.int64)
+            last = np.full(len(us), -1, dtype=np.int64)
+            for i, h in enumerate(hist):
+                p = np.searchsorted(us, h)
+                np.minimum.at(first, p, i)
+                np.maximum.at(last, p, i)
+            us = us[np.lexsort((last, first))]
+            pos = np.empty(int(us.max()) + 1 if len(us) else 1, dtype=np.int32)
+            pos[us] = np.arange(len(us), dtype=np.int32)
             fr = np.zeros(len(us), dtype=BLOCK_FRAME)
             ur = self._rec[us]
             for k in ("xyz_dev", "tab_dev", "n", "TX0", "TY0"):
@@ -580,7 +592,7 @@ class FrameStore:
             keep = []
             for i, ((lv, arr, sl), h) in enumerate(zip(descs, hist)):
                 sc["rel"][i] = lv["rel"][0]
-                ms = np.ascontiguousarray(np.searchsorted(us, h).astype(np.int32))
+                ms = np.ascontiguousarray(pos[h])
                 mt = np.ascontiguousarray(arr["trav"][:len(h)].astype(np.int32))
                 mr = np.ascontiguousarray(arr["rel"][:len(h)], dtype=np.float32)
                 keep.append((ms, mt, mr))
