@@ -410,6 +410,7 @@ typedef struct modest_mask_params {
 #define MODEST_STAGE_NO_CONSENSUS 2
 #define MODEST_STAGE_DEGENERATE 3
 #define MODEST_STAGE_TOO_FEW_KEPT 4
+#define MODEST_STAGE_HOST_RULE 5   /* a RANSAC trial bound on a rounding boundary: the host loop (host libm) decides */
 int modest_mask_stage(modest_ctx *ctx, const float *pts_dev, int n, int stride, const float *pp_dev,
                       const modest_mask_params *params, uint32_t *mt_key624, int32_t *mt_pos,
                       double *plane1_out, double *plane2_out, int64_t *labels_out, int32_t *info_out,

@@ -1331,13 +1331,22 @@ struct MCB {
     unsigned *isroot, *rank;
     int *deg, *adj;
     unsigned *h_res;
+    const double *plane_dev;   // when set: the plane of the mask is read from here (written earlier in the stream)
     int n, stride, nblk, m, nb, nw, nbA, pad;
 };
 
 __global__ __launch_bounds__(1024) void mcb_mask_count(const MCB *__restrict__ tab) {
     const MCB &S = tab[blockIdx.y];
     if ((int)blockIdx.x >= S.nblk) return;
-    mask_count_kernel_body(S.pts, S.n, S.stride, S.P, S.G, S.g, S.cnt, S.labels, S.kept, S.kept_idx, S.state, S.h_kept,
+    MaskParams P = S.P;
+    if (S.plane_dev) {   // (mask_params_fill's plane part)
+        P.n0 = S.plane_dev[0];
+        P.n1 = S.plane_dev[1];
+        P.n2 = S.plane_dev[2];
+        P.d = S.plane_dev[3];
+        P.norm = sqrt((P.n0 * P.n0 + P.n1 * P.n1) + P.n2 * P.n2);
+    }
+    mask_count_kernel_body(S.pts, S.n, S.stride, P, S.G, S.g, S.cnt, S.labels, S.kept, S.kept_idx, S.state, S.h_kept,
                            blockIdx.x, (unsigned)S.nblk);
 }
 template <bool CELLS>
@@ -1436,7 +1445,7 @@ int modest_mask_chain_count(modest_mask_chain_scan *S, int B, double offset, con
         memset(&b, 0, sizeof(b));
         q.n_kept = q.n_clusters = 0;
         q.alone = 0;
-        MODEST_REQUIRE(q.ctx && q.pts && q.pp && q.labels && q.plane4 && q.n >= 1 && (q.stride == 3 || q.stride == 4),
+        MODEST_REQUIRE(q.ctx && q.pts && q.pp && q.labels && (q.plane4 || q.plane4_dev) && q.n >= 1 && (q.stride == 3 || q.stride == 4),
                        "bad scan of the chain");
         modest_ctx *ctx = q.ctx;
         const size_t own = arena_sz((size_t)q.n * 12) + arena_sz((size_t)q.n * 4) + arena_sz(sizeof(CGrid));
@@ -1456,7 +1465,9 @@ int modest_mask_chain_count(modest_mask_chain_scan *S, int B, double offset, con
         ctx->zwords_dirty = 1;
         ctx->zwords_live = 1;
         b.cnt = cnt;
-        mask_params_fill(b.P, q.plane4, offset, only_range4, limit_range4);
+        const double no_plane[4] = {0.0, 0.0, 1.0, 0.0};
+        mask_params_fill(b.P, q.plane4_dev ? no_plane : q.plane4, offset, only_range4, limit_range4);
+        b.plane_dev = q.plane4_dev;
         double cx = 0.5 * ((double)b.P.lx0 + (double)b.P.lx1), cy = 0.5 * ((double)b.P.ly0 + (double)b.P.ly1);
         if (!(fabs(cx) <= 1e30)) cx = 0.0;
         if (!(fabs(cy) <= 1e30)) cy = 0.0;

@@ -9,6 +9,7 @@ struct modest_mask_chain_scan {
     int n, stride;
     const float *pp;        // [dev] (n) PP scores
     const double *plane4;   // [host] the plane of the mask
+    const double *plane4_dev;   // [dev] or NULL; when set the plane is read from here in the stream (plane4 is ignored)
     int32_t *labels;        // [dev] (n) int32
     int32_t n_kept, n_clusters;
     int alone;              // set when the scan has to be finished by the single-scan calls
@@ -44,6 +45,27 @@ int modest_cluster_stats_chain(modest_stats_chain_scan *S, int B, double quantil
 int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts, const int *n, const int *stride, int B,
                                const float *specs10, float *const *candA, float *const *candB, int32_t *n_cand2_host,
                                float *mad2_host, hipStream_t stream);
+
+// The two ground fits of every scan of a chain with their trial loops ON THE DEVICE (plane.hip: rsd_*): selection,
+// thresholds, triplets from the scan's own MT19937 state, all trials, sklearn's accept rule, the refits -- enqueue only,
+// no synchronise.  work_dev[s]: modest_rsd_work_bytes(n[s], max_trials) bytes of device memory that stay untouched until
+// the stream has passed the launches; res_host[s]: pinned host memory, valid after the caller's synchronise.
+// plane1_dev_out[s]: where the first fit's plane (4 doubles) will be on the device (the mask kernel of the chain reads it).
+struct modest_rsd_result {
+    int32_t n_cand[2];
+    float mad[2];
+    int32_t n_trials[2];
+    int32_t status;      // 0 or MODEST_STAGE_*: the scan goes back to the host statement, generator untouched
+    int32_t mt_pos;
+    double plane1[4], plane2[4];
+    uint32_t mt_key[624];   // the generator behind the executed trials of both fits (status 0 only)
+};
+constexpr int MODEST_RSD_MAX_TRIALS = 128;
+size_t modest_rsd_work_bytes(int n, int max_trials);
+int modest_rsd_enqueue(modest_ctx *const *ctxs, const float *const *pts, const int *n, const int *stride, int B,
+                       const float *specs10, float *const *candA, float *const *candB, const uint32_t *const *mt_key624,
+                       const int32_t *mt_pos, int max_trials, double stop_probability, char *const *work_dev,
+                       modest_rsd_result *const *res_host, const double **plane1_dev_out, hipStream_t stream);
 
 // lowest point inside each box footprint, boxes of several scans in one launch (boxfit.hip)
 int modest_lowest_point_multi(modest_ctx *ctx, const double *const *pts_rect, const int *n_pts, const double *boxes6_host,

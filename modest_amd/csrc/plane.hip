@@ -11,6 +11,7 @@
 // caller (modest_ransac_trials / _refit with its own triplets).
 #include "common.h"
 #include "compact.h"
+#include "mask_chain.h"
 #include "mask_pred.h"
 #include "ransac_host.h"
 #include <algorithm>
@@ -401,12 +402,12 @@ struct TripArg {
 constexpr int SCORE_PPT = 4;
 constexpr int SCORE_PTS = SCORE_THREADS * SCORE_PPT;
 constexpr int SCORE_KG = 8;
-template <bool FUSED>
-__device__ __forceinline__ void score_kernel_body(const float *__restrict__ cand, int n,
+template <bool FUSED, class TRIP>
+__device__ __forceinline__ bool score_kernel_body(const float *__restrict__ cand, int n,
                                                               const float *__restrict__ models,
                                                               int K, const float *__restrict__ thr_ptr,
                                                               float thr_val /* used when thr_ptr is NULL */,
-                                                              double *partial, const TripArg &trip,
+                                                              double *partial, const TRIP &trip,
                                                               float *__restrict__ models_host, unsigned *ticket,
                                                               double *__restrict__ out /* K*4, may be pinned host memory */,
                                                               const float *__restrict__ thr_src,
@@ -486,7 +487,7 @@ __device__ __forceinline__ void score_kernel_body(const float *__restrict__ cand
     __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gx * gy - 1 ? 1u : 0u;
     __syncthreads();
-    if (!last_s) return;
+    if (!last_s) return false;
     const int nrows = gx;
     for (int id = threadIdx.x; id < K * 4; id += SCORE_THREADS) {
         double s = 0.0;
@@ -504,6 +505,7 @@ __device__ __forceinline__ void score_kernel_body(const float *__restrict__ cand
     }
     if (threadIdx.x < 2 && thr_dst) thr_dst[threadIdx.x] = thr_src[threadIdx.x];
     if (threadIdx.x == 0) *ticket = 0u;
+    return true;   // (the block that wrote the totals)
 }
 template <bool FUSED>
 __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float *__restrict__ cand, int n,
@@ -545,7 +547,7 @@ __global__ void fit_kernel(const float *__restrict__ cand, int n, const int *__r
 // the block that finishes last (ticket, left at zero) adds the partials in block order and writes
 // the totals to pinned host memory.
 constexpr int REFIT_NV = 9;   // n, Sx, Sy, Sz, Sxx, Sxy, Syy, Sxz, Syz
-__device__ __forceinline__ void refit_kernel_body(const float *__restrict__ cand, int n, float c0, float c1, float b,
+__device__ __forceinline__ bool refit_kernel_body(const float *__restrict__ cand, int n, float c0, float c1, float b,
                                                   float thr, double *partial, unsigned *ticket,
                                                   double *__restrict__ out_host, const unsigned bx, const unsigned gx) {
     __shared__ double red[SCORE_WAVES][REFIT_NV];
@@ -584,7 +586,7 @@ __device__ __forceinline__ void refit_kernel_body(const float *__restrict__ cand
     __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == gx - 1 ? 1u : 0u;
     __syncthreads();
-    if (!last_s || w != 0) return;
+    if (!last_s || w != 0) return false;
     double s[REFIT_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int bb = lane; bb < (int)gx; bb += 64) {
         double t[REFIT_NV];
@@ -601,6 +603,7 @@ __device__ __forceinline__ void refit_kernel_body(const float *__restrict__ cand
         for (int q = 0; q < REFIT_NV; ++q) out_host[q] = s[q];
         *ticket = 0u;
     }
+    return lane == 0;   // (the lane that wrote the totals)
 }
 __global__ __launch_bounds__(SCORE_THREADS) void refit_kernel(const float *__restrict__ cand, int n, float c0, float c1,
                                                               float b, float thr, double *partial, unsigned *ticket,
@@ -637,6 +640,326 @@ __global__ __launch_bounds__(SCORE_THREADS) void scb_refit(const RefitLaunch *__
     const RefitLaunch &S = tab[blockIdx.y];
     if ((int)blockIdx.x >= S.gx) return;
     refit_kernel_body(S.cand, S.n, S.c0, S.c1, S.b, S.thr, S.partial, S.ticket, S.out_host, blockIdx.x, (unsigned)S.gx);
+}
+
+// ---- the trial loops on the device (chains of scans, scan_driver.hip) ------------------------------------------
+// sklearn's RANSAC loop has three data dependent steps that used to cost a host round trip each: how many trials run
+// (_dynamic_max_trials after every accepted model), which triplets they use (the generator is consumed by the
+// EXECUTED trials only, and the second fit continues where the first one stopped) and the refit of the winner.  Here
+// all of it stays in the stream: rsd_draw runs numpy's MT19937 (masked rejection, tracking selection: ransac_host.h)
+// for max_trials triplets and remembers the generator position behind each, rsd_score scores all of them (the block
+// that finishes last replays the sequential accept rule and fits the winner), rsd_refit sums the consensus set (its
+// last block solves the plane), the second fit starts from the generator position behind the first fit's last
+// executed trial, rsd_final writes the advanced generator and the results to pinned host memory.  Results are those
+// of the host loop, bit for bit; a trial bound that sits within 1e-7 of an integer (libm of host and device could
+// round it to different sides) hands the scan back to the host (MODEST_STAGE_HOST_RULE).
+constexpr int RSD_KMAX = 128;
+struct RsdFit {   // device work area of one fit
+    int trip[3 * RSD_KMAX];
+    unsigned used[RSD_KMAX];        // generator words consumed up to and including triplet k (from the fit's start)
+    float models[3 * RSD_KMAX];
+    double sums[4 * RSD_KMAX];
+    double refit[REFIT_NV + 1];
+    double plane4[4];
+    float best[3];
+    int n_trials, status, drawn;
+    unsigned words;                 // generator words consumed by the executed trials
+};
+struct RsdScan {   // one scan of the chain (device table, uploaded per call)
+    const float *cand[2];
+    const int *n_dev;         // [2] candidate counts (written by the selection kernel)
+    const float *mad_dev;     // [2][2] (median, MAD) of the two sets
+    RsdFit *fit;              // [2]
+    double *partial[2];
+    unsigned *ticket;
+    modest_rsd_result *res;   // pinned host memory
+    double stop_probability;
+    int pos0, max_trials;
+    unsigned key0[624];
+};
+struct PtrTrip {
+    const int *t;
+};
+
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+// one regeneration of the 624 state words by a workgroup of 256 threads: the serial recurrence reads key[kk + 1] (old)
+// and key[kk + 397 mod 624] (old for kk < 227, new after), so three sweeps of independent elements + the last word
+__device__ __forceinline__ void mt_refill(unsigned *key, int tid) {
+    const unsigned U = 0x80000000u, L = 0x7fffffffu, A = 0x9908b0dfu;
+    const int lo[3] = {0, 227, 454}, hi[3] = {227, 454, 623};
+#pragma unroll
+    for (int sw = 0; sw < 3; ++sw) {
+        const int kk = lo[sw] + tid;
+        unsigned v = 0;
+        if (kk < hi[sw]) {
+            const unsigned y = (key[kk] & U) | (key[kk + 1] & L);
+            v = key[sw == 0 ? kk + 397 : kk - 227] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        __syncthreads();
+        if (kk < hi[sw]) key[kk] = v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned y = (key[623] & U) | (key[0] & L);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+    }
+    __syncthreads();
+}
+// the generator `words` draws further: numpy's (key, pos), pos = 624 meaning "regenerate before the next draw"
+__device__ __forceinline__ int mt_advance(unsigned *key, int pos, unsigned words, int tid) {
+    const unsigned total = (unsigned)pos + words;
+    const unsigned r = total >= 1u ? (total - 1u) / 624u : 0u;
+    for (unsigned q = 0; q < r; ++q) mt_refill(key, tid);
+    return (int)(total - 624u * r);
+}
+
+// max_trials triplets of fit `which` of every scan: sample_without_replacement(n, 3) by tracking selection =
+// RandomState.randint(n) until three distinct indices are found; randint = next word & mask until the value is < n.
+// The workgroup tempers and filters 256 words at a time (order kept), until 3 K values are there; triplet k is then
+// values 3k..3k+2 -- unless some triplet holds a repeated index (probability ~ 3/n each): then one thread walks the
+// values in order, as the generator's consumer does.
+constexpr int RSD_VALS = 3 * RSD_KMAX + 512;
+__global__ __launch_bounds__(256) void rsd_draw(RsdScan *__restrict__ tab, int which) {
+    __shared__ unsigned key[624];
+    __shared__ unsigned vals[RSD_VALS], vpos[RSD_VALS], wtot[4];
+    __shared__ int s_ntrip, s_stop;
+    RsdScan &S = tab[blockIdx.x];
+    RsdFit &F = S.fit[which];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = S.n_dev[which];
+    if (tid == 0) {
+        int st = 0;
+        if (which == 1 && S.fit[0].status != 0) st = -1;                  // the first fit ended the scan
+        else if (S.n_dev[0] <= 300 || S.n_dev[1] <= 300) st = MODEST_STAGE_SMALL_SET;   // sklearn's other selection methods: host
+        F.status = st;
+        F.n_trials = 0;
+        F.words = 0u;
+        F.drawn = 0;
+        s_stop = st;
+        s_ntrip = 0;
+    }
+    for (int i = tid; i < 624; i += 256) key[i] = S.key0[i];
+    __syncthreads();
+    if (s_stop != 0) return;
+    int pos = S.pos0;
+    if (which == 1) pos = mt_advance(key, pos, S.fit[0].words, tid);
+    const int K = min(S.max_trials, RSD_KMAX);
+    const unsigned rng = (unsigned)n - 1u;
+    unsigned mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    unsigned consumed = 0;
+    int nv = 0, need = 3 * K;
+    bool first = true;
+    for (;;) {
+        while (nv < need && nv + 256 <= RSD_VALS) {
+            if (pos >= 624) {
+                mt_refill(key, tid);
+                pos = 0;
+            }
+            const int m = min(256, 624 - pos);
+            unsigned v = 0;
+            bool ok = false;
+            if (tid < m) {
+                v = mt_temper(key[pos + tid]) & mask;
+                ok = v <= rng;
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (lane == 0) wtot[w] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned base = 0, all = 0;
+            for (int q = 0; q < 4; ++q) {
+                if (q < w) base += wtot[q];
+                all += wtot[q];
+            }
+            if (ok) {
+                const unsigned at = (unsigned)nv + base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                vals[at] = v;
+                vpos[at] = consumed + (unsigned)tid + 1u;
+            }
+            __syncthreads();
+            nv += (int)all;
+            pos += m;
+            consumed += (unsigned)m;
+        }
+        if (nv < need) {   // (more repeated indices than the value buffer has room for: never; the host loop takes the scan)
+            if (tid == 0) F.status = MODEST_STAGE_HOST_RULE;
+            return;
+        }
+        if (first) {
+            unsigned a = 0, b = 1, c = 2;
+            if (tid < K) a = vals[3 * tid], b = vals[3 * tid + 1], c = vals[3 * tid + 2];
+            if (!__syncthreads_or(a == b || a == c || b == c)) {
+                if (tid < K) {
+                    F.trip[3 * tid] = (int)a;
+                    F.trip[3 * tid + 1] = (int)b;
+                    F.trip[3 * tid + 2] = (int)c;
+                    F.used[tid] = vpos[3 * tid + 2];
+                }
+                break;
+            }
+            first = false;
+        }
+        if (tid == 0) {   // in order, skipping the repeats
+            int have = 0, ntrip = 0, t3[3] = {0, 0, 0};
+            for (int i = 0; i < nv && ntrip < K; ++i) {
+                const int j = (int)vals[i];
+                bool dup = false;
+                for (int q = 0; q < have; ++q) dup = dup || t3[q] == j;
+                if (dup) continue;
+                t3[have++] = j;
+                if (have == 3) {
+                    F.trip[3 * ntrip] = t3[0];
+                    F.trip[3 * ntrip + 1] = t3[1];
+                    F.trip[3 * ntrip + 2] = t3[2];
+                    F.used[ntrip] = vpos[i];
+                    ++ntrip;
+                    have = 0;
+                }
+            }
+            s_ntrip = ntrip;
+        }
+        __syncthreads();
+        if (s_ntrip >= K) break;
+        need = nv + 3 * (K - s_ntrip);   // (every repeat costs one more value)
+        __syncthreads();
+    }
+    if (tid == 0) F.drawn = K;
+}
+
+// all drawn trials of fit `which` of every scan (blockIdx.z) in one launch; the block that finishes last replays
+// sklearn's sequential accept rule over the totals (ransac_host.h: RansacFit::finish_batch) and fits the winner
+__global__ __launch_bounds__(SCORE_THREADS) void rsd_score(RsdScan *__restrict__ tab, int which) {
+    RsdScan &S = tab[blockIdx.z];
+    RsdFit &F = S.fit[which];
+    if (F.status != 0) return;
+    const int n = S.n_dev[which], K = F.drawn;
+    const int gx = (n + SCORE_PTS - 1) / SCORE_PTS, gy = (K + SCORE_KG - 1) / SCORE_KG;
+    if ((int)blockIdx.x >= gx || (int)blockIdx.y >= gy) return;
+    const PtrTrip trip{F.trip};
+    const bool last = score_kernel_body<true>(S.cand[which], n, nullptr, K, S.mad_dev + 2 * which + 1, 0.f, S.partial[which], trip,
+                                              F.models, S.ticket, F.sums, nullptr, nullptr, blockIdx.x, blockIdx.y, (unsigned)gx,
+                                              (unsigned)gy);
+    if (!last) return;
+    // every trial's r2 score and the trial bound it would set if it were accepted, in parallel; then one thread replays the
+    // sequential rule over them (compares only)
+    __shared__ double s_score[RSD_KMAX], s_dyn[RSD_KMAX];
+    __shared__ int s_nk[RSD_KMAX];
+    __shared__ unsigned char s_amb[RSD_KMAX];
+    __syncthreads();   // the totals of this block's threads
+    for (int k = threadIdx.x; k < K; k += SCORE_THREADS) {
+        const int nk = (int)F.sums[4 * k];
+        s_nk[k] = nk;
+        s_score[k] = ransac_r2_from_sums(nk, F.sums[4 * k + 1], F.sums[4 * k + 2], F.sums[4 * k + 3]);
+        s_dyn[k] = ransac_dynamic_max_trials(nk, n, S.stop_probability);
+        // _dynamic_max_trials: the quotient before the ceil decides; next to an integer the host's libm has the word
+        const double eps = 2.220446049250313e-16;
+        const double ratio = (double)nk / (double)n;
+        const double nom = fmax(eps, 1.0 - S.stop_probability), denom = fmax(eps, 1.0 - pow(ratio, 3.0));
+        bool amb = false;
+        if (nom != 1.0 && denom != 1.0) {
+            const double q = log(nom) / log(denom);
+            amb = fabs(q) < (double)S.max_trials + 1.0 && fabs(q - rint(q)) < 1e-7 * fmax(1.0, fabs(q));
+        }
+        s_amb[k] = amb ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int n_best = 1, n_trials = 0, kbest = -1, status = 0;
+    double score_best = -INFINITY, limit = (double)S.max_trials;
+    for (int k = 0; k < K; ++k) {
+        if (!((double)n_trials < limit)) break;
+        ++n_trials;
+        const int nk = s_nk[k];
+        if (nk < n_best) continue;
+        const double score = s_score[k];
+        if (nk == n_best && score < score_best) continue;
+        n_best = nk;
+        score_best = score;
+        kbest = k;
+        if (s_amb[k]) status = MODEST_STAGE_HOST_RULE;
+        limit = fmin(limit, s_dyn[k]);
+    }
+    F.n_trials = n_trials;
+    F.words = n_trials > 0 ? F.used[n_trials - 1] : 0u;
+    if (kbest < 0 && status == 0) status = MODEST_STAGE_NO_CONSENSUS;
+    if (kbest >= 0) fit_triplet(S.cand[which], n, F.trip[3 * kbest], F.trip[3 * kbest + 1], F.trip[3 * kbest + 2], &F.best[0], &F.best[1], &F.best[2]);
+    F.status = status;
+}
+
+// the consensus set of the winner: moments (refit_kernel), the plane from them by the block that finishes last
+// (modest_ransac_refit_phase's read-back half + scan_driver.hip: plane_from_model)
+__global__ __launch_bounds__(SCORE_THREADS) void rsd_refit(RsdScan *__restrict__ tab, int which) {
+    RsdScan &S = tab[blockIdx.y];
+    RsdFit &F = S.fit[which];
+    if (F.status != 0) return;
+    const int n = S.n_dev[which];
+    const int gx = (n + SCORE_THREADS - 1) / SCORE_THREADS;
+    if ((int)blockIdx.x >= gx) return;
+    const float b = F.best[2];
+    if (!refit_kernel_body(S.cand[which], n, F.best[0], F.best[1], b, S.mad_dev[2 * which + 1], S.partial[which], S.ticket, F.refit,
+                           blockIdx.x, (unsigned)gx))
+        return;
+    const double *h = F.refit;   // (written by this lane)
+    const double cnt = h[0];
+    const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
+    const double mx = h[1] * inv, my = h[2] * inv, mzs = h[3] * inv;
+    const double sxx = h[4] - h[1] * mx, sxy = h[5] - h[1] * my, syy = h[6] - h[2] * my;
+    const double sxz = h[7] - h[1] * mzs, syz = h[8] - h[2] * mzs;
+    const double mz = mzs + (double)b;
+    const double det = sxx * syy - sxy * sxy;
+    if (!(cnt >= 3.0) || !(fabs(det) > 1e-12 * fmax(sxx * syy, 1e-300))) {
+        F.status = MODEST_STAGE_DEGENERATE;
+        return;
+    }
+    const double a0 = (sxz * syy - syz * sxy) / det;
+    const double a1 = (syz * sxx - sxz * sxy) / det;
+    const double m2 = mz - a0 * mx - a1 * my;
+    const double c0 = (double)(float)a0, c1 = (double)(float)a1;   // LinearRegression stores float32
+    const float b32 = (float)m2;
+    const double norm = sqrt((c0 * c0 + c1 * c1) + 1.0);
+    F.plane4[0] = -(c0 / norm);
+    F.plane4[1] = -(c1 / norm);
+    F.plane4[2] = -(-1.0 / norm);
+    F.plane4[3] = -((double)b32 / norm);
+}
+
+// results + the generator behind the executed trials of both fits -> pinned host memory
+__global__ __launch_bounds__(256) void rsd_final(RsdScan *__restrict__ tab) {
+    __shared__ unsigned key[624];
+    RsdScan &S = tab[blockIdx.x];
+    const RsdFit &A = S.fit[0], &B = S.fit[1];
+    modest_rsd_result *R = S.res;
+    const int tid = threadIdx.x;
+    const int status = A.status != 0 ? A.status : B.status;
+    if (tid == 0) {
+        R->n_cand[0] = S.n_dev[0];
+        R->n_cand[1] = S.n_dev[1];
+        R->mad[0] = S.mad_dev[1];
+        R->mad[1] = S.mad_dev[3];
+        R->n_trials[0] = A.n_trials;
+        R->n_trials[1] = B.n_trials;
+        R->status = status;
+        for (int q = 0; q < 4; ++q) {
+            R->plane1[q] = A.plane4[q];
+            R->plane2[q] = B.plane4[q];
+        }
+    }
+    if (status != 0) return;   // (the caller's generator stays where it was: the host statement starts over)
+    for (int i = tid; i < 624; i += 256) key[i] = S.key0[i];
+    __syncthreads();
+    const int pos = mt_advance(key, S.pos0, A.words + B.words, tid);
+    for (int i = tid; i < 624; i += 256) R->mt_key[i] = key[i];
+    if (tid == 0) R->mt_pos = pos;
 }
 
 // ---- above_plane + range mask ----------------------------------------------------
@@ -806,6 +1129,104 @@ int modest_plane_prepare_chain(modest_ctx *const *ctxs, const float *const *pts,
         mad2_host[2 * s] = h_mad[1];
         mad2_host[2 * s + 1] = h_mad[3];
     }
+    return MODEST_OK;
+}
+
+static size_t rsd_partial_bytes(int n, int K) {
+    const size_t nb = ((size_t)(n > 0 ? n : 1) + SCORE_PTS - 1) / SCORE_PTS;
+    const size_t nbr = ((size_t)(n > 0 ? n : 1) + SCORE_THREADS - 1) / SCORE_THREADS;
+    return std::max(arena_sz(nb * (size_t)K * 32), arena_sz(nbr * REFIT_NV * 8));
+}
+size_t modest_rsd_work_bytes(int n, int max_trials) {   // [counts 256 | thresholds 256 | RsdFit x 2 | partial A | partial B]
+    return 512 + arena_sz(2 * sizeof(RsdFit)) + 2 * rsd_partial_bytes(n, std::min(max_trials, RSD_KMAX));
+}
+static_assert(RSD_KMAX == MODEST_RSD_MAX_TRIALS, "mask_chain.h states the bound");
+
+int modest_rsd_enqueue(modest_ctx *const *ctxs, const float *const *pts, const int *n, const int *stride, int B,
+                       const float *specs10, float *const *candA, float *const *candB, const uint32_t *const *mt_key624,
+                       const int32_t *mt_pos, int max_trials, double stop_probability, char *const *work_dev,
+                       modest_rsd_result *const *res_host, const double **plane1_dev_out, hipStream_t stream) {
+    MODEST_REQUIRE(ctxs && pts && n && stride && specs10 && candA && candB && mt_key624 && mt_pos && work_dev && res_host &&
+                       plane1_dev_out && B >= 1, "bad chain");
+    MODEST_REQUIRE(max_trials >= 1 && max_trials <= RSD_KMAX, "max_trials");
+    CandSpec SA{specs10[0], specs10[1], specs10[2], specs10[3], specs10[4]};
+    CandSpec SB{specs10[5], specs10[6], specs10[7], specs10[8], specs10[9]};
+    std::vector<CandLaunch> sel((size_t)B);
+    std::vector<RsdScan> tab((size_t)B);
+    std::vector<std::pair<MadArgs, int>> mads;
+    MadArgs M{};
+    int used = 0, maxblk = 1, maxgx = 1, maxgr = 1;
+    for (int s = 0; s < B; ++s) {
+        modest_ctx *ctx = ctxs[s];
+        MODEST_REQUIRE(ctx && pts[s] && candA[s] && candB[s] && n[s] >= 1 && work_dev[s] && res_host[s] && mt_key624[s] &&
+                           mt_pos[s] >= 0 && mt_pos[s] <= 624, "bad scan of the chain");
+        const int nblk = (n[s] + 1023) / 1024;
+        unsigned long long *state = nullptr;
+        int rc = modest_ctx_compact_state(ctx, 2 * (size_t)nblk + 2, stream, &state);
+        if (rc) return rc;
+        unsigned *zw = nullptr;
+        rc = modest_ctx_zero_words(ctx, stream, &zw);
+        if (rc) return rc;
+        char *w = work_dev[s];
+        int *d_n = reinterpret_cast<int *>(w);
+        float *d_mad = reinterpret_cast<float *>(w + 256);
+        RsdFit *fit = reinterpret_cast<RsdFit *>(w + 512);
+        const size_t bp = rsd_partial_bytes(n[s], max_trials);
+        char *part = w + 512 + arena_sz(2 * sizeof(RsdFit));
+        CandLaunch &L = sel[(size_t)s];
+        L.pts = pts[s], L.candA = candA[s], L.candB = candB[s], L.stateA = state, L.stateB = state + 2 + nblk, L.n_out = d_n;
+        L.n = n[s], L.stride = stride[s], L.nblk = nblk, L.pad = 0;
+        maxblk = std::max(maxblk, nblk);
+        if (used + 2 > MAD_SETS) {
+            mads.push_back({M, used});
+            M = MadArgs{};
+            used = 0;
+        }
+        M.cand[used] = candA[s];
+        M.cand[used + 1] = candB[s];
+        M.n_dev[used] = d_n;
+        M.n_dev[used + 1] = d_n + 1;
+        M.out[used] = d_mad;
+        M.out[used + 1] = d_mad + 2;
+        used += 2;
+        RsdScan &R = tab[(size_t)s];
+        R.cand[0] = candA[s], R.cand[1] = candB[s];
+        R.n_dev = d_n, R.mad_dev = d_mad, R.fit = fit;
+        R.partial[0] = reinterpret_cast<double *>(part), R.partial[1] = reinterpret_cast<double *>(part + bp);
+        R.ticket = modest_tickets(zw);
+        R.res = res_host[s];
+        R.stop_probability = stop_probability;
+        R.pos0 = mt_pos[s], R.max_trials = max_trials;
+        memcpy(R.key0, mt_key624[s], sizeof(R.key0));
+        res_host[s]->status = -1;
+        plane1_dev_out[s] = fit[0].plane4;
+        maxgx = std::max(maxgx, (n[s] + SCORE_PTS - 1) / SCORE_PTS);
+        maxgr = std::max(maxgr, (n[s] + SCORE_THREADS - 1) / SCORE_THREADS);
+    }
+    if (used) mads.push_back({M, used});
+    char *d = nullptr, *h = nullptr;
+    const size_t bSel = arena_sz(sel.size() * sizeof(CandLaunch)), bTab = tab.size() * sizeof(RsdScan);
+    int rc = modest_ctx_chain_tab(ctxs[0], bSel + bTab, &d);
+    if (rc) return rc;
+    rc = modest_ctx_stage_slot(ctxs[0], bSel + bTab, reinterpret_cast<void **>(&h));
+    if (rc) return rc;
+    memcpy(h, sel.data(), sel.size() * sizeof(CandLaunch));
+    memcpy(h + bSel, tab.data(), bTab);
+    MODEST_HIP_CHECK(hipMemcpyAsync(d, h, bSel + bTab, hipMemcpyHostToDevice, stream));
+    rc = modest_ctx_stage_commit(ctxs[0], stream);
+    if (rc) return rc;
+    RsdScan *dt = reinterpret_cast<RsdScan *>(d + bSel);
+    const unsigned Bu = (unsigned)B;
+    const unsigned gy = (unsigned)((std::min(max_trials, RSD_KMAX) + SCORE_KG - 1) / SCORE_KG);
+    cdb_candidates2<<<dim3((unsigned)maxblk, Bu), 1024, 0, stream>>>(reinterpret_cast<const CandLaunch *>(d), SA, SB);
+    for (auto &m : mads) mad_kernel<<<m.second, 1024, 0, stream>>>(m.first);
+    for (int which = 0; which < 2; ++which) {
+        rsd_draw<<<Bu, 256, 0, stream>>>(dt, which);
+        rsd_score<<<dim3((unsigned)maxgx, gy, Bu), SCORE_THREADS, 0, stream>>>(dt, which);
+        rsd_refit<<<dim3((unsigned)maxgr, Bu), SCORE_THREADS, 0, stream>>>(dt, which);
+    }
+    rsd_final<<<Bu, 256, 0, stream>>>(dt);
+    MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
 

@@ -65,7 +65,7 @@ struct Mt19937 {
     }
 };
 
-inline double ransac_dynamic_max_trials(int n_inliers, int n_samples, double probability) {   // sklearn _dynamic_max_trials, min_samples = 3
+__host__ __device__ inline double ransac_dynamic_max_trials(int n_inliers, int n_samples, double probability) {   // sklearn _dynamic_max_trials, min_samples = 3
     const double eps = 2.220446049250313e-16;
     const double ratio = (double)n_inliers / (double)n_samples;
     const double nom = fmax(eps, 1.0 - probability);
@@ -75,7 +75,7 @@ inline double ransac_dynamic_max_trials(int n_inliers, int n_samples, double pro
     return fabs(ceil(log(nom) / log(denom)));
 }
 
-inline double ransac_r2_from_sums(int n, double sse, double sy, double syy) {   // r2_score over the inliers
+__host__ __device__ inline double ransac_r2_from_sums(int n, double sse, double sy, double syy) {   // r2_score over the inliers
     if (n < 2) return NAN;
     const double den = syy - sy * sy / n;
     if (den <= 0.0) return sse == 0.0 ? 1.0 : 0.0;

@@ -227,6 +227,13 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
     std::vector<float *> cA((size_t)n_scans), cB((size_t)n_scans);
     std::vector<int32_t> n_cand((size_t)2 * n_scans);
     std::vector<float> mad((size_t)2 * n_scans);
+    // the trial loops of the fits on the device (plane.hip: rsd_*): no round trip until the mask kernel has run
+    const bool dev_loop = P->max_trials >= 1 && P->max_trials <= MODEST_RSD_MAX_TRIALS && !getenv("MODEST_RANSAC_HOST");
+    std::vector<char *> work((size_t)n_scans, nullptr);
+    std::vector<modest_rsd_result *> res((size_t)n_scans, nullptr);
+    std::vector<const uint32_t *> keys((size_t)n_scans, nullptr);
+    std::vector<int32_t> poss((size_t)n_scans, 0);
+    std::vector<const double *> plane1_dev((size_t)n_scans, nullptr);
     for (int s = 0; s < n_scans; ++s) {
         const modest_mask_stage_scan &q = scans[s];
         Run &r = R[(size_t)s];
@@ -236,7 +243,8 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         MODEST_HIP_CHECK(hipSetDevice(ctx->device));
         for (int k = 0; k < 8; ++k) q.info_out[k] = 0;
         const size_t b_cand = arena_sz((size_t)q.n * 12), b_lab = arena_sz((size_t)q.n * 4);
-        int rc = modest_ctx_reserve_hold(ctx, 2 * b_cand + b_lab, b_lab);
+        const size_t b_work = dev_loop ? arena_sz(modest_rsd_work_bytes(q.n, P->max_trials)) : 0;
+        int rc = modest_ctx_reserve_hold(ctx, 2 * b_cand + b_lab + b_work, b_lab + arena_sz(sizeof(modest_rsd_result)));
         if (rc) return rc;
         rc = modest_ctx_reserve_pinned(ctx, 16384);   // sized once: growing it between an enqueue and its read-back would free results
         if (rc) return rc;
@@ -244,11 +252,21 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         cB[(size_t)s] = reinterpret_cast<float *>(ctx->hold + b_cand);
         r.labels_dev = reinterpret_cast<int32_t *>(ctx->hold + 2 * b_cand);
         r.labels_h = reinterpret_cast<int32_t *>(ctx->hold_pinned);
+        work[(size_t)s] = ctx->hold + 2 * b_cand + b_lab;
+        res[(size_t)s] = reinterpret_cast<modest_rsd_result *>(ctx->hold_pinned + b_lab);
+        keys[(size_t)s] = q.mt_key624;
+        poss[(size_t)s] = *q.mt_pos;
         ctxs[(size_t)s] = ctx;
         ptsv[(size_t)s] = q.pts_dev;
         nv[(size_t)s] = q.n;
         sv[(size_t)s] = q.stride;
     }
+    if (dev_loop) {
+        int rc = modest_rsd_enqueue(ctxs.data(), ptsv.data(), nv.data(), sv.data(), n_scans, specs, cA.data(), cB.data(), keys.data(),
+                                    poss.data(), P->max_trials, P->stop_probability, work.data(), res.data(), plane1_dev.data(), stream);
+        if (rc) return rc;
+        for (int s = 0; s < n_scans; ++s) R[(size_t)s].alive = true;
+    } else {
     {
         int rc = modest_plane_prepare_chain(ctxs.data(), ptsv.data(), nv.data(), sv.data(), n_scans, specs, cA.data(), cB.data(),
                                             n_cand.data(), mad.data(), stream);
@@ -397,6 +415,7 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         int rc = modest_ransac_capture_launch(ctx0, capB, stream);   // the second refits of all scans: one launch
         if (rc) return rc;
     }
+    }   // (host trial loops)
     // 3. the mask kernel of every scan that got this far, one launch
     std::vector<modest_mask_chain_scan> C;
     std::vector<int> who;
@@ -410,6 +429,7 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
             c.stride = q.stride;
             c.pp = q.pp_dev;
             c.plane4 = q.plane1_out;
+            c.plane4_dev = plane1_dev[(size_t)s];
             c.labels = R[(size_t)s].labels_dev;
             C.push_back(c);
             who.push_back(s);
@@ -429,6 +449,22 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
     for (int i = 0; i < B; ++i) {
         const modest_mask_stage_scan &q = scans[who[(size_t)i]];
         Run &r = R[(size_t)who[(size_t)i]];
+        if (dev_loop) {   // everything of the two fits arrived with this synchronise
+            const modest_rsd_result &z = *res[(size_t)who[(size_t)i]];
+            MODEST_REQUIRE(z.status >= 0, "the fits of a scan did not finish");
+            q.info_out[4] = z.n_cand[0], q.info_out[5] = z.n_cand[1];
+            q.info_out[6] = z.n_trials[0], q.info_out[7] = z.n_trials[1];
+            if (z.status != 0) {
+                q.info_out[3] = z.status;
+                C[(size_t)i].alone = 1;
+                continue;
+            }
+            memcpy(q.plane1_out, z.plane1, sizeof(z.plane1));
+            memcpy(q.plane2_out, z.plane2, sizeof(z.plane2));
+            memcpy(q.mt_key624, z.mt_key, sizeof(z.mt_key));
+            *q.mt_pos = z.mt_pos;
+            continue;
+        }
         double model64[3];
         int32_t n_in = 0;
         bool degenerate = false;

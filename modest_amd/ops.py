@@ -389,7 +389,8 @@ class MaskParams(C.Structure):
                 ("batch", C.c_int32), ("stop_probability", C.c_double)]
 
 
-STAGE_STATUS = {1: "small candidate set", 2: "no consensus set", 3: "degenerate consensus set", 4: "too few kept rows"}
+STAGE_STATUS = {1: "small candidate set", 2: "no consensus set", 3: "degenerate consensus set", 4: "too few kept rows",
+                5: "RANSAC trial bound on a rounding boundary (the host loop decides)"}
 
 
 def mask_stage(pts: torch.Tensor, pp: torch.Tensor, params: MaskParams, rs: np.random.RandomState,

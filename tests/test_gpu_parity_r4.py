@@ -1,0 +1,92 @@
+"""Round-4 parity: the RANSAC trial loops of a chain of scans run on the device (plane.hip: rsd_draw / rsd_score /
+rsd_refit / rsd_final -- numpy's MT19937 by a workgroup, sklearn's accept rule and _dynamic_max_trials by the last block);
+everything they produce equals the host loop's (ransac_host.h, which the round-3 tests pin to sklearn), bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scans(gpu):
+    import torch
+    from modest_amd import synth
+    out = []
+    rng = np.random.default_rng(2026)
+    for k, n_live in enumerate([30000, 9000, 21000, 30000, 14000, 26000]):
+        raw = np.ascontiguousarray(synth.make_scan(300 + k, n_live=n_live, n_trav=2, n_frames=1).live_raw)
+        out.append(raw)
+    for k in range(10):   # rough, tilted, layered ground with clutter: consensus sets from a third to all of the candidates
+        n = int(rng.integers(4000, 28000))
+        x, y = rng.uniform(-40, 40, n), rng.uniform(-15, 15, n)
+        tilt = rng.uniform(-0.03, 0.03, 2)
+        z = -1.7 + tilt[0] * x + tilt[1] * y + rng.normal(0, rng.uniform(0.005, 0.2), n)
+        lay = rng.random(n) < rng.uniform(0.0, 0.5)
+        z[lay] -= rng.uniform(0.1, 0.8)                     # a second level (kerb / ditch)
+        clutter = rng.random(n) < rng.uniform(0.0, 0.4)
+        z[clutter] = rng.uniform(-3.0, 1.5, int(clutter.sum()))
+        out.append(np.ascontiguousarray(np.c_[x, y, z, rng.uniform(0, 1, n)].astype(np.float32)))
+    for k in range(6):   # candidate sets just above sklearn's 300: most of these draw a triplet with a repeated index
+        n = int(rng.integers(330, 520))
+        g = np.c_[rng.uniform(2, 38, n), rng.uniform(-14, 14, n), rng.normal(-1.7, 0.02, n), rng.uniform(0, 1, n)]
+        up = np.c_[rng.uniform(5, 30, 400), rng.uniform(-10, 10, 400), rng.uniform(-1.0, 1.0, 400), rng.uniform(0, 1, 400)]
+        out.append(np.ascontiguousarray(np.r_[g, up].astype(np.float32)))
+    pps = [np.clip(0.5 + 0.5 * np.sin(r[:, 0] * 0.3), 0, 1).astype(np.float32) for r in out]
+    return [(r, p, torch.from_numpy(r).to(gpu), torch.from_numpy(p).to(gpu)) for r, p in zip(out, pps)]
+
+
+@pytest.mark.parametrize("max_trials,stop_probability", [(100, 0.99), (100, 0.999999), (37, 0.99), (128, 0.9999)])
+def test_device_trial_loops_equal_the_host_loop(gpu, max_trials, stop_probability):
+    from modest_amd import config, generate_mask as gm, ops
+    args = config.compose("generate_mask", ["data_root=/unused"])
+    params = gm._stage_params(args)
+    params.max_trials, params.stop_probability = max_trials, stop_probability
+    scans = _scans(gpu)
+    trials, small = [], 0
+    for lo in range(0, len(scans), 8):
+        grp = list(range(lo, min(lo + 8, len(scans))))
+        res = {}
+        for mode in ("host", "device"):
+            if mode == "host":
+                os.environ["MODEST_RANSAC_HOST"] = "1"
+            else:
+                os.environ.pop("MODEST_RANSAC_HOST", None)
+            try:
+                rss = [np.random.RandomState(1000 + 7 * k) for k in grp]
+                out = ops.mask_stage_batch([(scans[k][2], scans[k][3], rs) for k, rs in zip(grp, rss)], params)
+            finally:
+                os.environ.pop("MODEST_RANSAC_HOST", None)
+            res[mode] = (out, [rs.get_state() for rs in rss])
+        for k, h, d, sh, sd in zip(grp, res["host"][0], res["device"][0], res["host"][1], res["device"][1]):
+            assert (h is None) == (d is None), k
+            assert sh[2] == sd[2] and np.array_equal(sh[1], sd[1]), k          # the generator behind the executed trials
+            if h is None:
+                continue
+            assert np.array_equal(h[0], d[0]), k                               # labels_filtered
+            assert np.array_equal(h[1], d[1]) and np.array_equal(h[2], d[2]), k   # both planes, every bit
+            assert np.array_equal(h[3][:2], d[3][:2]) and np.array_equal(h[3][4:8], d[3][4:8]), (k, h[3], d[3])
+            trials += [int(h[3][6]), int(h[3][7])]
+            small += int(h[3][4]) < 600
+    assert small >= 3   # (the scans whose triplets repeat an index went through the fits, not back to the host)
+    assert len(trials) >= 16 and min(trials) >= 1 and max(trials) <= max_trials
+    assert len(set(trials)) >= 3   # fits that stop early and fits that run longer
+
+
+def test_device_trial_loops_hand_small_sets_back(gpu):
+    """a scan with 300 or fewer ground candidates uses sklearn's other selection methods: handed back, generator untouched"""
+    import torch
+    from modest_amd import config, generate_mask as gm, ops, synth
+    args = config.compose("generate_mask", ["data_root=/unused"])
+    params = gm._stage_params(args)
+    raws = [np.ascontiguousarray(synth.make_scan(40 + k, n_live=n, n_trav=2, n_frames=1).live_raw) for k, n in enumerate([500, 20000, 700])]
+    items, states = [], []
+    for k, r in enumerate(raws):
+        rs = np.random.RandomState(k)
+        states.append(rs.get_state())
+        items.append((torch.from_numpy(r).to(gpu), torch.from_numpy(np.full(len(r), 0.5, np.float32)).to(gpu), rs))
+    out = ops.mask_stage_batch(items, params)
+    assert out[1] is not None and (out[0] is None or out[2] is None)
+    for o, (_, _, rs), st in zip(out, items, states):
+        if o is None:
+            assert rs.get_state()[2] == st[2] and np.array_equal(rs.get_state()[1], st[1])

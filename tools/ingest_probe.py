@@ -32,3 +32,9 @@ tb = r.store.block_tables([sc.desc for sc in scs], scs[0].T)
 print(f"block_tables {1e3*(time.perf_counter()-tabs0):.2f} ms", tb is not None)
 t0 = time.perf_counter(); r.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx); t1 = time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
 print(f"pp_score_batch host {1e3*(t1-t0):.2f} ms, device tail {1e3*(t2-t1):.2f} ms")
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20):
+    r.store.block_tables([sc.desc for sc in scs], scs[0].T)
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)
