@@ -283,6 +283,7 @@ class Runner:
             self.scans.extend(rs.scans)
             del sh
         self.ingest = False
+        self.h_ring = {}   # per thread: two pinned host buffers for the scores of a block (pp_many)
         self.lock = threading.Lock()   # ingest mode re-inserts frames: one block at a time per process
         # every thread (stream + scratch arena + kernel attributes) runs before any clock starts
         self.n_warm = -(-max(a.warmup, 2 * self.n_threads, self.PB * self.n_threads) // self.PB) * self.PB   # whole blocks
@@ -296,7 +297,35 @@ class Runner:
         """PP stage of the scans of one block: ONE call -> [H]"""
         ctx = self.ctxs[w]
         self.mark_batch[w].append(len(scs))
-        return self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx, block=self.block)
+        if getattr(self, "trace", None) is not None:
+            t0 = time.perf_counter()
+            self.trace, keep = None, self.trace
+            try:
+                return self.pp_many(scs, w)
+            finally:
+                self.trace = keep
+                keep.append((f"pp[{len(scs)}]", time.perf_counter() - t0))
+        # the scores of a block live in ONE device tensor and travel to the host as ONE asynchronous copy into pinned memory
+        # right behind the kernels (the host statement of stages 2 + 3 wants them only when the library hands a scan back;
+        # the first synchronise of the mask stage is behind this copy): no blocking read-back per scan
+        ns = [int(sc.desc[0]["n"][0]) for sc in scs]
+        if len(set(ns)) != 1 or ns[0] == 0:
+            return self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx, block=self.block)
+        B, N = len(scs), ns[0]
+        Hall = torch.empty((B, N), dtype=torch.float32, device=self.dev)
+        Hs = self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, outs=[Hall[i] for i in range(B)],
+                                       ctx=ctx, block=self.block)
+        ring = self.h_ring.setdefault(w, [None, None, 0])
+        k = ring[2] & 1   # two buffers per thread: the next block's scores arrive while this block's are still referenced
+        ring[2] += 1
+        if ring[k] is None or ring[k].shape[0] < B or ring[k].shape[1] != N:   # (both buffers at once: never inside a clock)
+            ring[0] = torch.empty((max(B, self.PB), N), dtype=torch.float32).pin_memory()
+            ring[1] = torch.empty((max(B, self.PB), N), dtype=torch.float32).pin_memory()
+        ring[k][:B].copy_(Hall, non_blocking=True)
+        host = ring[k].numpy()
+        for i, H in enumerate(Hs):
+            H._host = host[i]
+        return Hs
 
     def _ingest(self, scs, ctx):
         """What the scans of a Lyft shard cost before their kernels can start (consecutive scans share 35 of
@@ -337,18 +366,26 @@ class Runner:
             return [(H, None, None, None) for H in Hs]
         # boxes stay (k,8) rows between the stages: the SimpleNamespace objects of the reference exist for its
         # pickle files, which the CLIs write and this in-memory pipeline does not
-        items = [dict(ptc=sc.live_host, pp_score=H.cpu().numpy(), random_state=np.random.RandomState(i), ptc_dev=sc.live_raw,
+        items = [dict(ptc=sc.live_host, pp_score=getattr(H, "_host", None) if getattr(H, "_host", None) is not None else H.cpu().numpy(),
+                      random_state=np.random.RandomState(i), ptc_dev=sc.live_raw,
                       pp_dev=H) for i, sc, H in zip(js, scs, Hs)]
+        tr = getattr(self, "trace", None)
+        t0 = time.perf_counter()
         if len(items) > 1 and not a.no_mask_chain:
             res = self._generate_mask_chain(items, scs[0].calib, self.margs, as_rows=True, ctxs=self.chain_ctxs[w][:len(items)])
         else:
             res = [self._generate_mask_scan(it["ptc"], it["pp_score"], scs[0].calib, self.margs, random_state=it["random_state"],
                                             ptc_dev=it["ptc_dev"], pp_dev=it["pp_dev"], as_rows=True) for it in items]
+        if tr is not None:
+            tr.append((f"mask[{len(items)}]", time.perf_counter() - t0))
+            t0 = time.perf_counter()
         if len(res) > 1 and not a.no_mask_chain:   # the IoU matrices of the chain's label stage: one launch
             lab = self._gen_label_chain([r[1] for r in res], [sc.calib for sc in scs], self.largs, after_device=after)
         else:
             lab = [self._gen_label_scan(r[1], sc.calib, self.largs, after_device=after if q == len(res) - 1 else None)
                    for q, (r, sc) in enumerate(zip(res, scs))]
+        if tr is not None:
+            tr.append((f"label[{len(items)}]", time.perf_counter() - t0))
         return [(H, labels, objs, text) for H, (labels, objs, _), (text, kept) in zip(Hs, res, lab)]
 
     def blocks_of(self, lo, hi):
@@ -502,7 +539,12 @@ def _helper_main(conn, a, rank, local, slot, flag):
                 conn.send(("armed", None))
                 while flag.value != gen:
                     pass
+                r.trace = [] if os.environ.get("MODEST_BENCH_TRACE") else None
                 dt, kms = r.timed(int(n), ingest=ingest)
+                if r.trace is not None:   # diagnostics: where a helper's share of the timed region went (host wall time)
+                    print(f"[helper {slot}] {n} steps {dt * 1e3:.2f} ms: " + " ".join(f"{k} {v * 1e3:.2f}" for k, v in r.trace),
+                          file=sys.stderr, flush=True)
+                    r.trace = None
                 conn.send(("done", (dt, kms.tolist())))
             elif cmd == "iso":
                 conn.send(("iso", r.isolated_pp_ms()))
