@@ -36,6 +36,7 @@ Nothing here reads /root/reference.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -536,15 +537,24 @@ def _helper_main(conn, a, rank, local, slot, flag):
             if cmd == "arm":
                 n, gen, ingest = arg
                 r.rehearse(int(n))
+                if not os.environ.get("MODEST_BENCH_GC"):
+                    # a generation-2 collection of the interpreter (the process holds its resident shards: millions of objects)
+                    # is a 5-10 ms pause -- the length of the driver's whole 20-step window, in which one paused helper
+                    # halves the number.  Collected here, outside every clock; the collector is off only while the clock runs.
+                    gc.collect()
+                    gc.disable()
                 conn.send(("armed", None))
                 while flag.value != gen:
                     pass
                 r.trace = [] if os.environ.get("MODEST_BENCH_TRACE") else None
+                seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0) if r.trace is not None else 0
                 dt, kms = r.timed(int(n), ingest=ingest)
-                if r.trace is not None:   # diagnostics: where a helper's share of the timed region went (host wall time)
+                if r.trace is not None:
+                    r.trace.append(("torch_segments_allocated_x1000", 1.0 * (torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0)))   # diagnostics: where a helper's share of the timed region went (host wall time)
                     print(f"[helper {slot}] {n} steps {dt * 1e3:.2f} ms: " + " ".join(f"{k} {v * 1e3:.2f}" for k, v in r.trace),
                           file=sys.stderr, flush=True)
                     r.trace = None
+                gc.enable()
                 conn.send(("done", (dt, kms.tolist())))
             elif cmd == "iso":
                 conn.send(("iso", r.isolated_pp_ms()))
@@ -674,8 +684,10 @@ def cli_bench(a, local):
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
+    from modest_amd import dist
+    dist.runtime_defaults()   # (before the first HIP call of this process; the helper processes inherit the environment)
     maybe_relaunch(a, argv)
-    from modest_amd import dist, ops, synth
+    from modest_amd import ops, synth
 
     rank, ws, local = dist.init()
     if ws != a.gpus:
@@ -966,6 +978,9 @@ def main():
                        "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
                        "rccl_world_size": rccl_ws, "rccl_ranks_seen": rccl_check["ranks_seen"],
                        "process_group_backend": rccl_check["backend"],
+                       "ransac_trial_loops": "host" if os.environ.get("MODEST_RANSAC_HOST") else "device",
+                       "runtime_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_INTERRUPT", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                                                      "GPU_MAX_HW_QUEUES")},
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli, "steady_state": steady,
             "value_with_ingest": with_ingest,

@@ -5,6 +5,13 @@
 #include <cstdio>
 #include <new>
 
+// MODEST_ALLOC_TRACE=1: every (re)allocation of a context prints a line -- a grow inside a timed region is a device
+// synchronise + free + allocate, tens of milliseconds when several processes share the GPU
+static void modest_alloc_note(const char *what, size_t bytes) {
+    static const int on = getenv("MODEST_ALLOC_TRACE") != nullptr;
+    if (on) fprintf(stderr, "[modest alloc] %s %zu bytes\n", what, bytes);
+}
+
 static thread_local char g_err[512] = "";
 
 void modest_set_error(const char *fmt, ...) {
@@ -119,6 +126,7 @@ int modest_ctx_compact_state(modest_ctx *ctx, size_t nblocks, hipStream_t stream
         const size_t want = nblocks < 4096 ? 4096 : nblocks + nblocks / 4;
         void *p = nullptr;
         MODEST_HIP_CHECK(hipMalloc(&p, 16 + 8 * want));
+        modest_alloc_note("compaction state", (size_t)(16 + 8 * want));
         MODEST_HIP_CHECK(hipMemsetAsync(p, 0, 16 + 8 * want, stream));
         ctx->cstate = static_cast<unsigned long long *>(p);
         ctx->cstate_blocks = want;
@@ -136,6 +144,7 @@ int modest_ctx_zero_words(modest_ctx *ctx, hipStream_t stream, unsigned **out) {
         ctx->zwords_count = 0;
         void *p = nullptr;
         MODEST_HIP_CHECK(hipMalloc(&p, words * 4));
+        modest_alloc_note("counter words", (size_t)(words * 4));
         ctx->zwords = static_cast<unsigned *>(p);
         ctx->zwords_count = words;
         ctx->zwords_dirty = 1;
@@ -158,6 +167,7 @@ int modest_ctx_reserve(modest_ctx *ctx, size_t bytes) {
     size_t want = bytes + bytes / 4 + (1u << 20);
     void *p = nullptr;
     MODEST_HIP_CHECK(hipMalloc(&p, want));
+    modest_alloc_note("scratch arena", (size_t)(want));
     ctx->scratch = static_cast<char *>(p);
     ctx->scratch_bytes = want;
     return MODEST_OK;
@@ -172,6 +182,7 @@ int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes) {
     size_t want = bytes + bytes / 4 + (64u << 10);
     void *p = nullptr;
     MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    modest_alloc_note("pinned block", (size_t)(want));
     ctx->pinned = static_cast<char *>(p);
     ctx->pinned_bytes = want;
     return MODEST_OK;
@@ -186,6 +197,7 @@ int modest_ctx_reserve_hold(modest_ctx *ctx, size_t dev_bytes, size_t pinned_byt
         const size_t want = dev_bytes + dev_bytes / 4 + (1u << 20);
         void *p = nullptr;
         MODEST_HIP_CHECK(hipMalloc(&p, want));
+        modest_alloc_note("hold (device)", (size_t)(want));
         ctx->hold = static_cast<char *>(p);
         ctx->hold_bytes = want;
     }
@@ -197,6 +209,7 @@ int modest_ctx_reserve_hold(modest_ctx *ctx, size_t dev_bytes, size_t pinned_byt
         const size_t want = pinned_bytes + pinned_bytes / 4 + (64u << 10);
         void *p = nullptr;
         MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        modest_alloc_note("hold (pinned)", (size_t)(want));
         ctx->hold_pinned = static_cast<char *>(p);
         ctx->hold_pinned_bytes = want;
     }
@@ -225,6 +238,7 @@ int modest_ctx_stage_slot(modest_ctx *ctx, size_t bytes, void **out) {
             ctx->stage_bytes[j] = 0;
             void *p = nullptr;
             MODEST_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+            modest_alloc_note("staging ring slot", (size_t)(want));
             ctx->stage[j] = static_cast<char *>(p);
             ctx->stage_bytes[j] = want;
         }
@@ -295,6 +309,7 @@ int modest_ctx_chain_tab(modest_ctx *ctx, size_t bytes, char **out) {
         const size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
         void *p = nullptr;
         MODEST_HIP_CHECK(hipMalloc(&p, want));
+        modest_alloc_note("chain table", (size_t)(want));
         ctx->chain_tab = static_cast<char *>(p);
         ctx->chain_tab_bytes = want;
     }
