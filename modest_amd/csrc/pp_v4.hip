@@ -393,16 +393,14 @@ __global__ __launch_bounds__(256) void b4_live_count(Blk B, const ScanDev *__res
     S.tmp[i] = make_float4(o[0], o[1], o[2], __int_as_float(cell));
 }
 
-// exclusive scan of the cell counters (4096 per workgroup, four per thread); the counters are cleared behind the
-// read: the scatter uses them as cursors
+// exclusive scan of the cell counters (4096 per workgroup, four per thread); the counters stay: the scatter counts
+// them back down to zero (its cursor), which saves a 4-byte store per cell of the window here
 constexpr int B4_SCAN = 4096;
 __global__ __launch_bounds__(1024) void b4_scan_local(Blk B, const ScanDev *__restrict__ scans) {
     __shared__ unsigned wsum[16];
     const ScanDev &S = scans[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint4 *cc = reinterpret_cast<uint4 *>(S.cellCount) + (size_t)blockIdx.x * 1024 + tid;
-    const uint4 v = *cc;
-    *cc = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 v = reinterpret_cast<const uint4 *>(S.cellCount)[(size_t)blockIdx.x * 1024 + tid];
     const unsigned s4 = v.x + v.y + v.z + v.w;
     unsigned inc = s4;
     for (int o = 1; o < 64; o <<= 1) {
@@ -439,7 +437,7 @@ __global__ __launch_bounds__(256) void b4_live_scatter(Blk B, const ScanDev *__r
     if (i >= S.n) return;
     const float4 t = S.tmp[i];
     const int cell = __float_as_int(t.w);
-    const unsigned slot = S.cellStart[cell] + atomicAdd(&S.cellCount[cell], 1u);
+    const unsigned slot = S.cellStart[cell] + (atomicSub(&S.cellCount[cell], 1u) - 1u);   // (the order inside a cell is free)
     S.sorted[slot] = make_float4(t.x, t.y, t.z, __int_as_float((int)S.livePerm[i]));
     // counts are indexed by the ORIGINAL point order of the live frame
 }
