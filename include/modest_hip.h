@@ -422,7 +422,13 @@ int modest_mask_stage(modest_ctx *ctx, const float *pts_dev, int n, int stride, 
  * grid dimension), three round trips per chain instead of three per scan.  Every scan works in its OWN context
  * (scratch, pinned words, persistent counters); arguments per scan as in modest_mask_stage.  Results are those of
  * separate calls, bit for bit; configurations the chain does not cover (k-NN graphs without a radius,
- * 3d_l2_distance) and chains of one scan take the separate calls.  Blocking.                                    */
+ * 3d_l2_distance) and chains of one scan take the separate calls.  Blocking.
+ * The trial loops of the two fits run ON THE DEVICE for max_trials <= 128 (csrc/plane.hip: rsd_*; numpy's MT19937 as
+ * sklearn's sample_without_replacement consumes it, the sequential accept rule, _dynamic_max_trials, refit and plane,
+ * the generator advanced by the executed trials): one synchronise for both fits + the mask kernel.  A scan whose trial
+ * bound sits on a rounding boundary of log / pow comes back with info_out[3] = MODEST_STAGE_HOST_RULE and an untouched
+ * generator, like the other hand-back statuses.  MODEST_RANSAC_HOST=1 in the environment keeps the loops on the host
+ * (batches of params->batch trials per round trip).                                                                */
 typedef struct modest_mask_stage_scan {
     modest_ctx *ctx;
     const float *pts_dev;
