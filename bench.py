@@ -685,11 +685,15 @@ def main():
     argv = sys.argv[1:]
     a = parse(argv)
     from modest_amd import dist
-    dist.runtime_defaults()   # (before the first HIP call of this process; the helper processes inherit the environment)
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and a.gpus <= 1:
+        dist.runtime_defaults()   # (before the first HIP call of this process; the helper processes inherit the environment)
     maybe_relaunch(a, argv)
     from modest_amd import ops, synth
 
     rank, ws, local = dist.init()
+    # a rank of a multi-GPU run keeps the runtime's own wait mode for itself (RCCL); its helper processes, which do the
+    # pipeline's work and are single-rank, poll (dist.runtime_defaults): they inherit the environment as it is from here on
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     if ws != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={ws} rank(s); "
                          f"run `python bench.py --gpus {a.gpus}` (it launches its own ranks) or make them agree")

@@ -43,8 +43,9 @@ def init(backend: Optional[str] = None) -> tuple:
     too: the RCCL branches of barrier() / reduce_counters() (device_ids, CUDA tensors) then run on a box with a single
     GPU exactly as they do on a node (a launcher must have set MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE, or the
     defaults below apply).  A forced run prints the result of selfcheck() on stderr."""
-    runtime_defaults()
     rank, ws, local = world()
+    if ws == 1:   # a rank of a multi-GPU job keeps the runtime's own wait mode for its RCCL traffic (polling under RCCL with
+        runtime_defaults()   # several ranks has not been on hardware yet); its worker / helper processes are single-rank
     force = os.environ.get("MODEST_DIST_FORCE", "") == "1"
     if (ws > 1 or force) and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
