@@ -59,11 +59,12 @@ assert SORT_JOB.itemsize == C.sizeof(SortJob)
 class BlockFrame:
     """A stored frame that is a slice of a batch's blocks (insert_block): the tensor views are made on demand
     (the compute path only needs the addresses, which sit in the store's descriptor records)."""
-    __slots__ = ("_xyz", "_perm", "_tab", "a", "b", "k", "n", "TX0", "TY0", "inside", "W", "slot")
+    __slots__ = ("_xyz", "_perm", "_tab", "a", "b", "k", "n", "TX0", "TY0", "inside", "W", "slot", "slabs")
 
-    def __init__(self, xyz_all, perm_all, tab_all, a, b, k, TX0, TY0, inside, W, slot):
+    def __init__(self, xyz_all, perm_all, tab_all, a, b, k, TX0, TY0, inside, W, slot, slabs=()):
         self._xyz, self._perm, self._tab, self.a, self.b, self.k = xyz_all, perm_all, tab_all, a, b, k
         self.n, self.TX0, self.TY0, self.inside, self.W, self.slot = b - a, TX0, TY0, inside, W, slot
+        self.slabs = slabs   # ids of the store's slabs the frame's block was carved from
 
     xyz = property(lambda self: self._xyz[self.a:self.b])
     perm = property(lambda self: self._perm[self.a:self.b])
@@ -147,6 +148,15 @@ class FrameStore:
         # in 20 MB segments, i.e. one driver call every two or three scans once its cache is used up (measured:
         # the PP CLI dropped from 810 to 290 scans/s at that point)
         self._slab, self._slab_off, self.slab_bytes = None, 0, 256 << 20
+        # Capacity is counted in what the store really holds: whole slabs -- a slab goes back to the allocator only when its
+        # last frame is gone -- plus the tensors of frames inserted one by one (`bytes` stays the payload of the resident
+        # frames, for reports).  A slab is allocated on the ingest stream and read by kernels of other streams: every stream
+        # that reads frames is recorded on every slab (note_reader), so a slab handed back is not reused before the work
+        # queued on those streams at that time has finished.
+        self._slabs: dict = {}    # id -> [tensor, bytes, resident frames carved from it]
+        self._slab_id = -1        # the slab being carved
+        self._loose = 0
+        self._readers: dict = {}
         # slot tables: the static part of every frame's descriptor, gathered per scan by fancy indexing
         self._rec = np.zeros(1024, dtype=PP_FRAME)
         self._W = np.zeros((1024, 4, 4))
@@ -266,34 +276,65 @@ class FrameStore:
                 self._clean[sf.slot] = (sf.inside == n) if isinstance(sf.inside, int) else True   # (async: checked on demand)
                 self.frames[key] = sf
                 self.bytes += sf.nbytes
+                self._loose += sf.nbytes
                 if isinstance(key, (int, np.integer)) and key >= 0:
                     if key >= self._slot_index.shape[0]:
                         grown = np.full(max(2 * self._slot_index.shape[0], int(key) + 1), -1, dtype=np.int64)
                         grown[: self._slot_index.shape[0]] = self._slot_index
                         self._slot_index = grown
                     self._slot_index[key] = sf.slot
-            if self.bytes > self.cap:
+            if self.footprint() > self.cap:
                 keep = set(protect) if protect is not None else set()
                 keep.update(k for k, *_ in made)
-                for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first
-                    if self.bytes <= self.cap:
-                        break
-                    old = self.frames.pop(key)
-                    self.bytes -= old.nbytes
-                    self._free.append(old.slot)
-                    if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
-                        self._slot_index[key] = -1
+                self._evict(keep)
 
     def reserve(self, nbytes: int) -> None:
         """take `nbytes` of device memory for future block insertions in ONE driver call"""
         nbytes = int(min(max(nbytes, 0), self.cap))
         if nbytes > 0 and (self._slab is None or self._slab.shape[0] - self._slab_off < nbytes):
-            self._slab, self._slab_off = torch.empty((nbytes,), dtype=torch.uint8, device=self.device), 0
+            self._slab, self._slab_off = self._new_slab(nbytes), 0
+
+    def _new_slab(self, nbytes: int) -> torch.Tensor:
+        t = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
+        for st in self._readers.values():
+            t.record_stream(st)
+        with self.lock:
+            old = self._slabs.get(self._slab_id)
+            if old is not None and old[2] == 0:   # nothing resident was carved from the slab that is being replaced
+                del self._slabs[self._slab_id]
+            self._slab_id += 1
+            self._slabs[self._slab_id] = [t, int(nbytes), 0]
+        return t
+
+    def _release(self, old) -> None:
+        """a frame left the store (call under the lock): its slabs go back to the allocator with their last frame"""
+        if not isinstance(old, BlockFrame):
+            self._loose -= old.nbytes
+            return
+        for sid in old.slabs:
+            ent = self._slabs.get(sid)
+            if ent is not None:
+                ent[2] -= 1
+                if ent[2] <= 0 and sid != self._slab_id:
+                    del self._slabs[sid]
+
+    def note_reader(self, stream=None) -> None:
+        """`stream` (default: the current one) reads frames of the store"""
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        if st.cuda_stream not in self._readers:
+            with self.lock:
+                self._readers[st.cuda_stream] = st
+                for ent in self._slabs.values():
+                    ent[0].record_stream(st)
+
+    def footprint(self) -> int:
+        """device bytes held: whole slabs + the tensors of frames inserted one by one"""
+        return self._loose + sum(ent[1] for ent in self._slabs.values())
 
     def _carve(self, nbytes: int) -> torch.Tensor:
         nbytes = (int(nbytes) + 255) & ~255
         if self._slab is None or self._slab.shape[0] - self._slab_off < nbytes:
-            self._slab, self._slab_off = torch.empty((max(self.slab_bytes, nbytes),), dtype=torch.uint8, device=self.device), 0
+            self._slab, self._slab_off = self._new_slab(max(self.slab_bytes, nbytes)), 0
         out = self._slab[self._slab_off:self._slab_off + nbytes]
         self._slab_off += nbytes
         return out
@@ -314,9 +355,14 @@ class FrameStore:
                 self.anchor = np.floor(Ws[0, :3, 3])
         tw = self.ntf * self.ntf + 1
         P = int(offs[-1])
+        slabs = set()
         xyz_all = self._carve(12 * P)[:12 * P].view(torch.float32).view(P, 3)
+        slabs.add(self._slab_id)
         perm_all = self._carve(4 * P)[:4 * P].view(torch.int32)
+        slabs.add(self._slab_id)
         tab_all = self._carve(4 * tw * nf)[:4 * tw * nf].view(torch.int32).view(nf, tw)
+        slabs.add(self._slab_id)
+        slabs = tuple(sorted(slabs))
         a, b = np.asarray(offs[:-1], dtype=np.int64), np.asarray(offs[1:], dtype=np.int64)
         o = (Ws[:, :2, 3] - self.anchor[:2]) / self.cell
         T0 = np.floor(o / 8.0).astype(np.int64) - self.ntf // 2
@@ -364,9 +410,11 @@ class FrameStore:
             fr = self.frames
             for k, key in enumerate(keys):
                 fr[key] = BlockFrame(xyz_all, perm_all, tab_all, int(a[k]), int(b[k]), k, int(T0[k, 0]), int(T0[k, 1]),
-                                     (pin, k, ev), Ws[k], int(slots[k]))
+                                     (pin, k, ev), Ws[k], int(slots[k]), slabs)
+            for sid in slabs:
+                self._slabs[sid][2] += nf
             self.bytes += 16 * P + 4 * tw * nf
-            if self.bytes > self.cap:
+            if self.footprint() > self.cap:
                 self._evict(set(protect) | set(keys) if protect is not None else set(keys))
 
     def drop(self, keys) -> None:
@@ -377,16 +425,18 @@ class FrameStore:
                 if old is None:
                     continue
                 self.bytes -= old.nbytes
+                self._release(old)
                 self._free.append(old.slot)
                 if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
                     self._slot_index[key] = -1
 
     def _evict(self, keep) -> None:
         for key in [k for k in self.frames if k not in keep]:   # LRU order, oldest first (call under the lock)
-            if self.bytes <= self.cap:
+            if self.footprint() <= self.cap:
                 break
             old = self.frames.pop(key)
             self.bytes -= old.nbytes
+            self._release(old)
             self._free.append(old.slot)
             if isinstance(key, (int, np.integer)) and 0 <= key < self._slot_index.shape[0]:
                 self._slot_index[key] = -1
@@ -480,6 +530,7 @@ class FrameStore:
         frame -> world.  Returns H (N,) float32 in the live frame's file order (and counts (N,T)).
         `desc` = a table from describe() reused across calls (the frames must still be resident)."""
         lib = load()
+        self.note_reader()
         live = self.frames[live_key]
         F = len(hist)
         rels = np.ascontiguousarray(np.asarray(rels, dtype=np.float32).reshape(F, 4, 4))
@@ -609,6 +660,7 @@ class FrameStore:
         choice (MODEST_PP_BLOCK=1 / 0 in the environment does the same).  Returns [H] (and [counts]); results are
         those of separate pp_score calls, bit for bit."""
         lib = load()
+        self.note_reader()
         B, T = len(descs), int(n_trav)
         if T > 64:
             raise ValueError("the batched path takes at most 64 traversals")

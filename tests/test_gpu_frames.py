@@ -173,3 +173,30 @@ def test_batched_chain_equals_separate_calls(gpu):
             assert torch.equal(c, single[i][1]), i
             assert torch.equal(H, single[i][0]), i
     assert any(int(c.sum()) > 0 for _, c in single)
+
+
+def test_store_capacity_counts_slabs_and_reader_streams(gpu):
+    """the store's capacity is what it really holds -- whole slabs, which go back to the allocator only when
+    their last frame is gone -- and a slab freed by eviction is not reused before the kernels of the streams that read its
+    frames have finished (every reading stream is recorded on every slab)."""
+    import torch
+    from modest_amd.frame_store import FrameStore
+    rng = np.random.default_rng(5)
+    store = FrameStore(gpu, 0.3, capacity_bytes=3 << 20)
+    store.slab_bytes = 1 << 20   # small slabs: ~2 blocks of 3 frames each
+    def block(base):
+        raws = [np.c_[rng.uniform(-30, 30, 9000), rng.uniform(-30, 30, 9000), rng.uniform(-2, 1, 9000), np.zeros(9000)].astype(np.float32)
+                for _ in range(3)]
+        offs = np.cumsum([0] + [len(r) for r in raws])
+        Ws = np.stack([np.eye(4) for _ in raws])
+        store.insert_block([base + k for k in range(3)], torch.from_numpy(np.concatenate(raws)).to(gpu), offs, Ws)
+    side = torch.cuda.Stream(device=gpu)
+    store.note_reader(side)
+    for b in range(12):
+        block(10 * b)
+        assert store.footprint() <= store.cap + store.slab_bytes   # never more than one slab over (the one being carved)
+    assert side.cuda_stream in store._readers and len(store.frames) < 36 and len(store.frames) >= 3
+    assert store.footprint() == sum(ent[1] for ent in store._slabs.values()) and store.bytes <= store.footprint()
+    torch.cuda.synchronize()
+    for key, f in store.frames.items():   # the survivors are intact
+        assert f.n_inside == f.n == 9000
