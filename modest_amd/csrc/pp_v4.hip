@@ -832,11 +832,12 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             unsigned rs = 0, rn = 0;
             if (tx < B.BW && ty < B.BH) {
                 const int bt = ty * B.BW + tx;
-                if (tileTasks[bt] != 0u) {   // (the plan wrote the ranges of the tiles that have work for this scan)
-                    const v2u r2_ = cellRange[(size_t)bt * 64 + (cyq & 7) * 8 + (cxq & 7)];
-                    rs = r2_.x;
-                    rn = r2_.y;
-                }
+                // the plan wrote the ranges of the tiles that have work for this scan; both words are requested at once (the
+                // range of a tile without work is whatever the arena held: read, not used -- one round trip instead of two)
+                const unsigned tt = tileTasks[bt];
+                const v2u r2_ = cellRange[(size_t)bt * 64 + (cyq & 7) * 8 + (cxq & 7)];
+                rs = tt != 0u ? r2_.x : 0u;
+                rn = tt != 0u ? r2_.y : 0u;
             }
             S.recStart[tid] = rs;
             S.recN[tid] = rn;
