@@ -58,7 +58,7 @@ constexpr unsigned B4_HEAVY = 64;          // cells with at least this many reco
 constexpr int B4_CPT = B4_CPT_;                  // 64-record chunks per task
 constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
 #ifndef B4_IT_
-#define B4_IT_ 64
+#define B4_IT_ 24
 #endif
 constexpr unsigned B4_IT = B4_IT_;             // tasks per item
 #ifndef B4_WPE_
