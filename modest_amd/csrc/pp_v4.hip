@@ -732,7 +732,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const unsigned nItems = SC.ctrl[0];
     // PROF: cycles of this wavefront by phase (0 item set-up, 1 band set-up, 2 unit fetch + decode, 3 record wait + transform +
     // masks, 4 pair phase, 5 packed chunks, 6 wait at the end of a band, 7 flush), counts 8 items 9 bands 10 tasks 11 chunks
-    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? clock64() : 0ULL;
+    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? clock64() : 0ULL;
 #define B4_TICK(kk)                                  \
     if (PROF) {                                      \
         const unsigned long long now_ = clock64();   \
@@ -795,12 +795,11 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
     };
 
-    const unsigned rot = nItems ? (blockIdx.y * 7919u) % nItems : 0u;   // the scans of a block walk the tiles in different orders
     if (tid == 0) {
         const unsigned first = atomicAdd(&SC.ctrl[1], 1u);
         S.itemId = first;
         if (first < nItems) {
-            const v4u w = items[(first + rot) % nItems];
+            const v4u w = items[first];
             S.item = make_uint4(w.x, w.y, w.z, w.w);
         }
     }
@@ -843,8 +842,9 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             S.recN[tid] = rn;
         }
         __syncthreads();
+        B4_TICK(12)
         if (tid == 0 && S.nextId < nItems) {
-            const v4u w = items[(S.nextId + rot) % nItems];
+            const v4u w = items[S.nextId];
             S.nextItem = make_uint4(w.x, w.y, w.z, w.w);
         }
         // ---- (b) tasks of the quad, window tables, bands ------------------------------------------
@@ -877,6 +877,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             if (e == r * B4_W1) S.segStart[r] = S.cst[e];
         }
         __syncthreads();
+        B4_TICK(13)
         {
             unsigned bA = 0, bB = 0;
             for (int k = 0; k < (tid >> 6); ++k) {
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             S.nBands = nb;
         }
         __syncthreads();
+        B4_TICK(14)
         const unsigned TH = S.TH, LV = S.LV;
         const unsigned nBands = S.nBands;
         // the item's units: one-cell tasks [qh0, qh1) and 64-record chunks of the packed order [l0, l1)
@@ -1189,7 +1191,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
     }
     if (PROF && lane == 0)
-        for (int kk = 0; kk < 12; ++kk) atomicAdd(&prof[kk], pacc[kk]);
+        for (int kk = 0; kk < 16; ++kk) atomicAdd(&prof[kk], pacc[kk]);
 #undef B4_TICK
 }
 
@@ -1430,16 +1432,16 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         const int dbg = dbg_env ? atoi(dbg_env) : 0;
         const unsigned poseB = b4_pose_bytes(U);
         if (dbg & 512) {   // MODEST_PP4_DBG=512: per-phase wavefront cycles of the join (blocking; diagnostics only)
-            unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[12];
+            unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[16];
             MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));
             b4_join<false, true><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg, dprof);
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hprof, dprof, sizeof(hprof), hipMemcpyDeviceToHost));
             const double wv = (double)jx * G * (B4_JT / 64), us = 1.0 / 100.0;   // s_memtime ticks at 100 MHz
-            fprintf(stderr, "[b4_join] per wavefront, us: item set-up %.1f | band set-up %.1f | fetch+decode %.1f | record wait+transform %.1f | "
-                            "pairs %.1f | packed %.1f | band-end wait %.1f | flush %.1f || per scan: items %.0f bands %.0f tasks %.0f chunks %.0f\n",
+            fprintf(stderr, "[b4_join] per wavefront, us: item set-up (decode) %.1f | band set-up %.1f | fetch+decode %.1f | record wait+transform %.1f | "
+                            "pairs %.1f | packed %.1f | band-end wait %.1f | flush %.1f (item set-up = %.1f to the tables' barrier + %.1f prefix / window tables + %.1f band search + decode) || per scan: items %.0f bands %.0f tasks %.0f chunks %.0f\n",
                     hprof[0] * us / wv, hprof[1] * us / wv, hprof[2] * us / wv, hprof[3] * us / wv, hprof[4] * us / wv, hprof[5] * us / wv,
-                    hprof[6] * us / wv, hprof[7] * us / wv, hprof[8] / 4.0 / G, hprof[9] / 4.0 / G, (double)hprof[10] / G, (double)hprof[11] / G);
+                    hprof[6] * us / wv, hprof[7] * us / wv, hprof[12] * us / wv, hprof[13] * us / wv, hprof[14] * us / wv, hprof[8] / 4.0 / G, hprof[9] / 4.0 / G, (double)hprof[10] / G, (double)hprof[11] / G);
         } else if (poseB && B4_JT >= 512 && !(dbg & 256))
             b4_join<true, false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN + poseB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
         else
