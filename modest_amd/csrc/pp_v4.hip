@@ -807,8 +807,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         __syncthreads();
         const unsigned iid = S.itemId;
         if (iid >= nItems) break;
-        const uint4 it = S.item;
-        __syncthreads();   // everyone holds the item: thread 0 may overwrite the header below
+        const uint4 it = S.item;   // (the header is rewritten at the end of the item only: behind the barriers below)
         if (tid == 0) S.nextId = atomicAdd(&SC.ctrl[1], 1u);   // in flight during the loads below
         const int qd = (int)it.x;
         const unsigned q0 = it.y, q1 = it.z;
@@ -871,28 +870,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 S.wsB[tid >> 6] = incB;
             }
         }
-        for (int e = tid; e < B4_W * B4_W1; e += B4_JT) {
-            const int r = e / B4_W1;
-            S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * B4_W1], 65535u);
-            if (e == r * B4_W1) S.segStart[r] = S.cst[e];
-        }
-        __syncthreads();
-        B4_TICK(13)
-        {
-            unsigned bA = 0, bB = 0;
-            for (int k = 0; k < (tid >> 6); ++k) {
-                bA += S.wsA[k];
-                bB += S.wsB[k];
-            }
-            S.thEnd[tid] = bA + incA;
-            S.lvStart[tid] = bB + incB - lvMine;
-            S.lvEnd[tid] = bB + incB;
-            if (tid == B4_JT - 1) {
-                S.TH = bA + incA;
-                S.LV = bB + incB;
-            }
-        }
-        if (tid == 0) {
+        if (tid == 64) {   // (a lane of the second wavefront: next to the prefix sums and the window tables of the others)
             // bands: sub-rectangles of the quad whose live window (one cell of halo) fits the LDS budget.  Whole cell rows
             // first; a single row that does not fit (the dense rings next to the sensor) is cut into column halves,
             // quarters, ...; a single cell whose 3x3 neighbourhood does not fit takes the slow path.
@@ -931,6 +909,27 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             }
             S.nBands = nb;
         }
+        for (int e = tid; e < B4_W * B4_W1; e += B4_JT) {
+            const int r = e / B4_W1;
+            S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * B4_W1], 65535u);
+            if (e == r * B4_W1) S.segStart[r] = S.cst[e];
+        }
+        __syncthreads();
+        B4_TICK(13)
+        {
+            unsigned bA = 0, bB = 0;
+            for (int k = 0; k < (tid >> 6); ++k) {
+                bA += S.wsA[k];
+                bB += S.wsB[k];
+            }
+            S.thEnd[tid] = bA + incA;
+            S.lvStart[tid] = bB + incB - lvMine;
+            S.lvEnd[tid] = bB + incB;
+            if (tid == B4_JT - 1) {
+                S.TH = bA + incA;
+                S.LV = bB + incB;
+            }
+        }
         __syncthreads();
         B4_TICK(14)
         const unsigned TH = S.TH, LV = S.LV;
@@ -960,7 +959,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             const int ya = (int)(bw & 31u), yb = (int)((bw >> 5) & 31u);   // cell rows / columns of the band (window coordinates 1..16)
             const int xa = (int)((bw >> 10) & 31u), xb = (int)((bw >> 15) & 31u);
             const bool slow = (bw >> 20) != 0;
-            __syncthreads();   // previous band's flush complete
+            if (bd > 0) __syncthreads();   // previous band's flush complete (the item's first band: the barriers of the set-up)
             if (tid <= yb - ya + 2) {   // rows ya-1 .. yb+1 of the window, columns xa-1 .. xb+1
                 unsigned run = 0;
                 for (int r = ya - 1; r < ya - 1 + tid; ++r) run += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
