@@ -624,6 +624,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // v_pk_add / v_pk_mul / v_pk_fma_f32 test a candidate against two chunks per instruction.  Counts the pairs with
 // d2 < r2lo and re-tests the pairs inside the band [r2lo, r2hi] exactly (float64, scipy's predicate; practically
 // never).  Lane t adds the hits of traversal t (segment masks sLo / sHi per chunk).
+// popcount(x) + acc in ONE instruction (the compiler prefers independent popcounts and a three-operand add tree: three more
+// VALU instructions per candidate in a loop that is bound by them)
+__device__ __forceinline__ unsigned b4_bcnt(unsigned x, unsigned acc) {
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 template <int NP>
 __device__ __forceinline__ unsigned long long b4_pairs(const float4 *__restrict__ live, unsigned *__restrict__ cntw, unsigned ia,
                                                        unsigned ie, const v2f *hx, const v2f *hy, const v2f *hz,
@@ -644,8 +651,10 @@ __device__ __forceinline__ unsigned long long b4_pairs(const float4 *__restrict_
             const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
             const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
             band |= (hA ^ mA) | (hB ^ mB);
-            acc += __popc((unsigned)hA & sLo[2 * p]) + __popc((unsigned)(hA >> 32) & sHi[2 * p]);
-            acc += __popc((unsigned)hB & sLo[2 * p + 1]) + __popc((unsigned)(hB >> 32) & sHi[2 * p + 1]);
+            acc = b4_bcnt((unsigned)hA & sLo[2 * p], acc);
+            acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * p], acc);
+            acc = b4_bcnt((unsigned)hB & sLo[2 * p + 1], acc);
+            acc = b4_bcnt((unsigned)(hB >> 32) & sHi[2 * p + 1], acc);
         }
         if (lq < T && acc) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], acc << ((lq & 1) * 16));
     }
