@@ -590,12 +590,13 @@ class FrameStore:
                 return None
             us = np.unique(np.concatenate(hist))
             if force is None:
-                # measured (tools/pp_block_probe.py): the block pays when the union of the scans' frames is not much more
-                # than one scan's own (its join reads every record of the union: Lyft shape, 36 frames per traversal,
-                # 16 scans -> 1.42 x, 150 against 197 us per scan; nuScenes shape, 16 frames per traversal -> 1.94 x,
-                # 340 against 265 us) and there are enough scans to share the binning
+                # measured (bench.py, whole pipeline, 8 processes): the block pays when there are enough scans to share the
+                # binning (>= 8) and the windows are not too short -- Lyft shape, 36 frames per traversal, 16 scans: union
+                # 1.42 x a scan's frames, 137 against 191 us per scan alone on the GPU; nuScenes shape, 16 frames per
+                # traversal: union 1.94 x, 281 against 263 us alone, but 3 400 against 2 790 scans/s in the pipeline (one
+                # sequence of large launches instead of sixteen chains of small ones next to seven other processes)
                 per_scan = members / B
-                if B < 8 or len(us) > 1.5 * per_scan or per_scan < 24 * T:
+                if B < 8 or len(us) > 2.0 * per_scan or per_scan < 12 * T:
                     return None
             if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([us, lslots])):
                 return None
