@@ -1,6 +1,8 @@
 // Context, error string and arena management for libmodest_hip.so.
 #include "common.h"
 #include <cstdlib>
+#include <ctime>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <new>
@@ -9,7 +11,11 @@
 // synchronise + free + allocate, tens of milliseconds when several processes share the GPU
 static void modest_alloc_note(const char *what, size_t bytes) {
     static const int on = getenv("MODEST_ALLOC_TRACE") != nullptr;
-    if (on) fprintf(stderr, "[modest alloc] %s %zu bytes\n", what, bytes);
+    if (on) {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        fprintf(stderr, "[modest alloc] t=%.3f s pid %d: %s %zu bytes\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, (int)getpid(), what, bytes);
+    }
 }
 
 static thread_local char g_err[512] = "";
