@@ -200,3 +200,11 @@ def test_store_capacity_counts_slabs_and_reader_streams(gpu):
     torch.cuda.synchronize()
     for key, f in store.frames.items():   # the survivors are intact
         assert f.n_inside == f.n == 9000
+    # an insertion whose first carve nearly fills a fresh slab: its other carves open the next slab while the first one
+    # has no counted frame yet (it must stay in the table)
+    store = FrameStore(gpu, 0.3, capacity_bytes=64 << 20)
+    store.slab_bytes = 340 << 10   # 27 000 points x 12 bytes = 324 KB
+    for b in range(3):
+        block(10 * b)
+    assert len(store.frames) == 9 and all(f.n_inside == 9000 for f in store.frames.values())
+    assert store.footprint() == sum(ent[1] for ent in store._slabs.values()) >= store.bytes
