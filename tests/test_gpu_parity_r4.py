@@ -40,7 +40,7 @@ def _scans(gpu):
 def test_device_trial_loops_equal_the_host_loop(gpu, max_trials, stop_probability):
     from modest_amd import config, generate_mask as gm, ops
     args = config.compose("generate_mask", ["data_root=/unused"])
-    params = gm._stage_params(args)
+    params = ops.MaskParams.from_buffer_copy(gm._stage_params(args))   # (a copy: _stage_params caches its block by config values)
     params.max_trials, params.stop_probability = max_trials, stop_probability
     scans = _scans(gpu)
     trials, small = [], 0

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shards", type=int, default=2, help="distinct shards cycled through in the timing loop")
+    ap.add_argument("--stream", action="store_true", help="run on a created stream instead of the null stream")
     a = ap.parse_args()
     _lib.load()
     dev = torch.device("cuda:0")
@@ -76,11 +77,13 @@ def main():
                 print(f"shard {q} scan {i}: block == oracle: {e}")
                 ok &= e
     print("PARITY", "OK" if ok else "FAILED", "block calls", getattr(store, "block_calls", 0), flush=True)
+    side = torch.cuda.Stream(device=dev) if a.stream else torch.cuda.current_stream(dev)
     for mode in (True, False):
         ctx.profile_begin(a.reps * a.shards + 4)
-        for r in range(a.reps):
-            for lives, descs in tabs:
-                store.pp_score_batch(lives, descs, T, ctx=ctx, block=mode)
+        with torch.cuda.stream(side):
+            for r in range(a.reps):
+                for lives, descs in tabs:
+                    store.pp_score_batch(lives, descs, T, ctx=ctx, block=mode)
         torch.cuda.synchronize()
         ms = ctx.profile_collect(a.reps * a.shards + 4)
         per = float(np.mean(ms[a.shards:])) / a.scans
