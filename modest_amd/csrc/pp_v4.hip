@@ -92,7 +92,7 @@ static_assert(sizeof(PoseEnt) == 64, "pose entry layout");
 struct Blk {   // block-wide device pointers and geometry (kernel argument)
     const UFrame *frames;
     const uint2 *chunkTab;
-    unsigned *off, *gtot, *listTotal, *listBase, *segBase, *segList, *segHist, *segOff, *cellOff, *ctrl;
+    unsigned *off, *gtot, *listTotal, *listBase, *segBase, *segList, *segHist, *segOff, *cellOff, *ctrl, *baseSum;
     uint2 *segRange;   // smallest / largest frame slot among a segment's records
     float4 *recA, *recB;
     int U, NG, nchunks, maxSegs;
@@ -176,21 +176,15 @@ __global__ __launch_bounds__(256) void b4_lists(Blk B, const ScanDev *__restrict
     B.listTotal[b] = needed ? run : 0u;
 }
 
-// one workgroup: list bases, segment bases, the segment -> list table.  ctrl[0] = records, ctrl[1] = segments
-constexpr int B4_BPT = (B4_MAXW * B4_MAXW + 1023) / 1024;   // tiles per thread
-// (the per-thread tiles are read twice instead of being kept: an indexed register array would live in scratch
-// memory, and a kernel that touches scratch pays ~25 us at dispatch)
-__global__ __launch_bounds__(1024) void b4_bases(Blk B) {
+// list bases, segment bases, the segment -> list table; ctrl[0] = records, ctrl[1] = segments.  Two launches of a few
+// workgroups (a tile per thread): local prefix sums + workgroup totals, then every workgroup adds the totals in front of it
+// (at most 25 workgroups: a loop).  One workgroup walking all tiles took 41 us.
+__global__ __launch_bounds__(1024) void b4_bases_local(Blk B) {
     __shared__ unsigned wa[16], wb[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    unsigned sumT = 0, sumS = 0;
-    for (int j = 0; j < B4_BPT; ++j) {
-        const int b = tid * B4_BPT + j;
-        const unsigned t = b < B.BT ? B.listTotal[b] : 0u;
-        sumT += t;
-        sumS += (t + B4_SEG - 1) / B4_SEG;
-    }
-    unsigned incA = sumT, incB = sumS;
+    const int b = blockIdx.x * 1024 + tid;
+    const unsigned t = b < B.BT ? B.listTotal[b] : 0u, ns = (t + B4_SEG - 1) / B4_SEG;
+    unsigned incA = t, incB = ns;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
         if (lane >= o) {
@@ -212,22 +206,34 @@ __global__ __launch_bounds__(1024) void b4_bases(Blk B) {
         allA += wa[k];
         allB += wb[k];
     }
+    if (b < B.BT) {
+        B.listBase[b] = baseA + incA - t;   // (local to the workgroup until b4_bases_finish)
+        B.segBase[b] = baseB + incB - ns;
+    }
     if (tid == 0) {
-        B.ctrl[0] = allA;
-        B.ctrl[1] = min(allB, (unsigned)B.maxSegs);
+        B.baseSum[2 * blockIdx.x] = allA;
+        B.baseSum[2 * blockIdx.x + 1] = allB;
     }
-    unsigned tB = baseA + incA - sumT, sB = baseB + incB - sumS;
-    for (int j = 0; j < B4_BPT; ++j) {
-        const int b = tid * B4_BPT + j;
-        if (b >= B.BT) break;
-        const unsigned t = B.listTotal[b], ns = (t + B4_SEG - 1) / B4_SEG;
-        B.listBase[b] = tB;
-        B.segBase[b] = sB;
-        for (unsigned k = 0; k < ns; ++k)
-            if (sB + k < (unsigned)B.maxSegs) B.segList[sB + k] = (unsigned)b;
-        tB += t;
-        sB += ns;
+}
+__global__ __launch_bounds__(1024) void b4_bases_finish(Blk B) {
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x * 1024 + tid;
+    unsigned offA = 0, offB = 0;
+    for (unsigned k = 0; k < blockIdx.x; ++k) {   // (wave-uniform: scalar loads)
+        offA += B.baseSum[2 * k];
+        offB += B.baseSum[2 * k + 1];
     }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        B.ctrl[0] = offA + B.baseSum[2 * blockIdx.x];
+        B.ctrl[1] = min(offB + B.baseSum[2 * blockIdx.x + 1], (unsigned)B.maxSegs);
+    }
+    if (b >= B.BT) return;
+    const unsigned t = B.listTotal[b], ns = (t + B4_SEG - 1) / B4_SEG;
+    const unsigned tB = B.listBase[b] + offA, sB = B.segBase[b] + offB;
+    B.listBase[b] = tB;
+    B.segBase[b] = sB;
+    for (unsigned k = 0; k < ns; ++k)
+        if (sB + k < (unsigned)B.maxSegs) B.segList[sB + k] = (unsigned)b;
 }
 
 // ---- the one pass over the union's points ------------------------------------------------------
@@ -1311,6 +1317,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oTotal = take((size_t)BT * 4), oBase = take((size_t)BT * 4), oSegBase = take((size_t)BT * 4);
     const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
     const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256), oSegRange = take(maxSegs * 8);
+    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
@@ -1420,6 +1427,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     B.cellOff = reinterpret_cast<unsigned *>(base + oCellOff);
     B.segRange = reinterpret_cast<uint2 *>(base + oSegRange);
     B.ctrl = reinterpret_cast<unsigned *>(base + oCtrl);
+    B.baseSum = reinterpret_cast<unsigned *>(base + oBaseSum);
     B.recA = reinterpret_cast<float4 *>(base + oRecA);
     B.recB = reinterpret_cast<float4 *>(base + oRecB);
     B.U = U, B.NG = NG, B.nchunks = (int)nch, B.maxSegs = (int)maxSegs;
@@ -1446,7 +1454,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     if (U > 0 && ntot > 0) {
         b4_counts<<<dim3(gBT, (unsigned)NG), 256, 0, stream>>>(B);
         b4_lists<<<gBT, 256, 0, stream>>>(B, dsc);
-        b4_bases<<<1, 1024, 0, stream>>>(B);
+        b4_bases_local<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
+        b4_bases_finish<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
         const int swg = std::min((int)nch, 2 * ctx->num_cus);
         b4_scatter<<<swg, 1024, 0, stream>>>(B);
         b4_seg_hist<<<(unsigned)maxSegs, 512, 0, stream>>>(B);
