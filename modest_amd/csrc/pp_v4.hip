@@ -156,15 +156,17 @@ __global__ __launch_bounds__(256) void b4_lists(Blk B, const ScanDev *__restrict
     if (b >= B.BT) return;
     const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
     bool needed = false;
+#pragma unroll 4
     for (int s = 0; s < B.G; ++s) {
         const ScanDev &S = scans[s];
-        if (S.n <= 0) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
+        const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {   // (the loads are unconditional on clamped indices: nothing waits inside a branch)
             const int ly = gy + dy - S.TY0;
-            if (ly < 0 || ly >= B4_NTF) continue;
-            const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
-            if (l0 > l1) continue;
-            needed |= S.liveTab[ly * B4_NTF + l1 + 1] > S.liveTab[ly * B4_NTF + l0];
+            const bool in = S.n > 0 && ly >= 0 && ly < B4_NTF && l0 <= l1;
+            const int row = in ? ly * B4_NTF : 0, a = in ? l0 : 0, e = in ? l1 + 1 : 0;
+            const unsigned t0 = S.liveTab[row + a], t1 = S.liveTab[row + e];
+            needed |= in && t1 > t0;
         }
     }
     unsigned run = 0;
