@@ -478,8 +478,14 @@ __device__ __forceinline__ unsigned b4_cell_cand(const unsigned *__restrict__ ce
                                                  int cx, int cy) {
     const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
     unsigned c = 0;
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, CHc - 1); ++yy)
-        c += b4_cs(cellStart, blockOff, (size_t)yy * CW + xb + 1) - b4_cs(cellStart, blockOff, (size_t)yy * CW + xa);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {   // (three rows, all loads issued: rows outside the window read the cell's own row and count nothing)
+        const int yy = cy + dy;
+        const bool in = yy >= 0 && yy < CHc;
+        const size_t row = (size_t)(in ? yy : cy) * CW;
+        const unsigned a = b4_cs(cellStart, blockOff, row + xa), e = b4_cs(cellStart, blockOff, row + xb + 1);
+        c += in ? e - a : 0u;
+    }
     return c;
 }
 __global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__restrict__ scans) {
@@ -504,21 +510,21 @@ __global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__res
                 any = true;
             }
         }
-        unsigned start = 0, n = 0;
-        if (any) {
-            const unsigned base = B.cellOff[(size_t)b * 65 + lane];
-            start = base + B.segOff[(size_t)(s0 + kf) * 64 + lane];
-            const unsigned end = kl + 1 < ns ? base + B.segOff[(size_t)(s0 + kl + 1) * 64 + lane] : B.cellOff[(size_t)b * 65 + lane + 1];
-            n = end - start;
-        }
-        bool active = false;
-        if (n) {
-            const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
-            if (b4_cell_cand(S.cellStart, S.blockSum, B.CW, B.CHc, cx, cy)) {
-                active = true;
-                if (n >= B4_HEAVY) th = (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT;
-                else lv = n;
-            }
+        // (every load below is issued whether or not its value is used: the compiler waits for a load inside the branch
+        // that holds it, and this kernel is nothing but dependent loads)
+        if (!any) kf = 0, kl = 0;
+        const unsigned base = B.cellOff[(size_t)b * 65 + lane], next = B.cellOff[(size_t)b * 65 + lane + 1];
+        const unsigned oFirst = B.segOff[(size_t)(s0 + kf) * 64 + lane];
+        const unsigned oEnd = B.segOff[(size_t)(s0 + min(kl + 1, ns - 1)) * 64 + lane];
+        const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
+        const unsigned cand = b4_cell_cand(S.cellStart, S.blockSum, B.CW, B.CHc, cx, cy);
+        const unsigned start = base + oFirst;
+        const unsigned end = kl + 1 < ns ? base + oEnd : next;
+        const unsigned n = any ? end - start : 0u;
+        const bool active = n != 0u && cand != 0u;
+        if (active) {
+            if (n >= B4_HEAVY) th = (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT;
+            else lv = n;
         }
         for (int o = 32; o > 0; o >>= 1) {
             th += __shfl_xor(th, o);
