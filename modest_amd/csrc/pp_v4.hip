@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024) void b4_bases_finish(Blk B) {
 // ---- the one pass over the union's points ------------------------------------------------------
 // chunk = 4096 points of one frame (wave-uniform frame: scalar loads of its descriptor).  A point goes to
 // listBase[tile] + (points of earlier frames in the tile) + (its rank in its frame's tile run).
-__global__ __launch_bounds__(1024) void b4_scatter(Blk B) {
+__global__ __launch_bounds__(512) void b4_scatter(Blk B) {
     const int tid = threadIdx.x;
     for (int chunk = blockIdx.x; chunk < B.nchunks; chunk += gridDim.x) {
         const uint2 ct = B.chunkTab[chunk];
@@ -249,29 +249,52 @@ __global__ __launch_bounds__(1024) void b4_scatter(Blk B) {
         const UFrame &F = B.frames[f];
         const int nin = (int)F.tab[B4_NTILE];   // points inside the frame's table (outliers are parked behind)
         const int g = f / B4_FG;
+        // Four points per thread, every load issued whether or not the point turns out to be written (a lane without a
+        // point reads the frame's first one; tiles outside the window read the table entries of tile 0): the kernel is two
+        // dependent rounds of loads per point, and with the loads inside the `if`s of a point the compiler waited for each
+        // round of each point in turn (185 us per block; 4 x 2 rounds in flight instead of 1).
+#pragma unroll 1
+        for (int half = 0; half < B4_CH / 2048; ++half) {   // (512 threads x 4 points; 68 registers: three workgroups per CU)
+        float x[4], y[4], z[4];
+        bool valid[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = (int)ct.y + u * 1024 + tid;
-            if (i >= nin || i >= (int)ct.y + B4_CH) continue;
-            float x = F.xyz[3 * (size_t)i], y = F.xyz[3 * (size_t)i + 1];
-            const float z = F.xyz[3 * (size_t)i + 2];
-            long long cx, cy;
-            if (!b4_cell(F.lat, x, y, z, &cx, &cy)) continue;
+            const int i = (int)ct.y + (half * 4 + u) * 512 + tid;
+            valid[u] = i < nin && i < (int)ct.y + B4_CH;
+            const size_t ii = valid[u] ? (size_t)i : 0;   // (a chunk exists only for a frame with points)
+            x[u] = F.xyz[3 * ii], y[u] = F.xyz[3 * ii + 1], z[u] = F.xyz[3 * ii + 2];
+        }
+        unsigned lt[4], lb[4], gt[4], of[4], tb[4];
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            long long cx = 0, cy = 0;
+            const bool okc = b4_cell(F.lat, x[u], y[u], z[u], &cx, &cy);
             const long long tx = cx >> 3, ty = cy >> 3;
             const long long lx = tx - F.TX0, ly = ty - F.TY0;
             const long long bx = tx - B.BX0, by = ty - B.BY0;
-            if (lx < 0 || lx >= B4_NTF || ly < 0 || ly >= B4_NTF) continue;   // (cannot happen for i < nin)
-            if (bx < 0 || bx >= B.BW || by < 0 || by >= B.BH) continue;
-            const int b = (int)(by * B.BW + bx);
-            if (B.listTotal[b] == 0u) continue;
-            const int k = (int)(ly * B4_NTF + lx);
-            const unsigned dest = B.listBase[b] + B.gtot[(size_t)g * B.BT + b] + B.off[(size_t)f * B.BT + b] +
-                                  ((unsigned)i - F.tab[k]);
+            const bool in = okc && lx >= 0 && lx < B4_NTF && ly >= 0 && ly < B4_NTF   // (the first two cannot fail for i < nin)
+                            && bx >= 0 && bx < B.BW && by >= 0 && by < B.BH;
+            valid[u] = valid[u] && in;
+            const int b = in ? (int)(by * B.BW + bx) : 0, k = in ? (int)(ly * B4_NTF + lx) : 0;
+            lt[u] = B.listTotal[b];
+            lb[u] = B.listBase[b];
+            gt[u] = B.gtot[(size_t)g * B.BT + b];
+            of[u] = B.off[(size_t)f * B.BT + b];
+            tb[u] = F.tab[k];
+            key[u] = (int)((cy & 7) * 8 + (cx & 7));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!valid[u] || lt[u] == 0u) continue;
+            const int i = (int)ct.y + (half * 4 + u) * 512 + tid;
+            const unsigned dest = lb[u] + gt[u] + of[u] + ((unsigned)i - tb[u]);
             // remove_center (pre_compute_pp_score.py:48-52,141-142) drops the point before the transform: a NaN
             // coordinate keeps its slot in the list and never passes a distance test
-            if ((F.flags & F_FLAG_CENTER) && in_center_box(x, y)) x = __int_as_float(0x7fc00000);
-            const int key = (int)((cy & 7) * 8 + (cx & 7));
-            B.recA[dest] = make_float4(x, y, z, __int_as_float(key | (f << 6)));
+            float xs = x[u];
+            if ((F.flags & F_FLAG_CENTER) && in_center_box(x[u], y[u])) xs = __int_as_float(0x7fc00000);
+            B.recA[dest] = make_float4(xs, y[u], z[u], __int_as_float(key[u] | (f << 6)));
+        }
         }
     }
 }
@@ -1464,8 +1487,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         b4_lists<<<gBT, 256, 0, stream>>>(B, dsc);
         b4_bases_local<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
         b4_bases_finish<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
-        const int swg = std::min((int)nch, 2 * ctx->num_cus);
-        b4_scatter<<<swg, 1024, 0, stream>>>(B);
+        const int swg = std::min((int)nch, 3 * ctx->num_cus);
+        b4_scatter<<<swg, 512, 0, stream>>>(B);
         b4_seg_hist<<<(unsigned)maxSegs, 512, 0, stream>>>(B);
         b4_seg_scan<<<(unsigned)((BT + 3) / 4), 256, 0, stream>>>(B);
         b4_seg_scatter<<<(unsigned)maxSegs, 512, B4_SEG * 16, stream>>>(B);
