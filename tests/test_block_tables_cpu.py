@@ -1,0 +1,115 @@
+"""Host logic of the block path without a GPU: FrameStore.block_tables on a store whose slot tables are filled by hand
+(no device memory is touched: the tables only carry addresses).  What is checked: the block's frame table is ordered by
+(first, last) scan that uses a frame, so that every scan's members are ONE range of slots; member slots / traversals /
+poses arrive per scan as the C ABI expects them; the rule that decides between the block and the per-scan chain; poses
+that disagree with the lattice and frames with points outside their table are refused."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from modest_amd import frame_store as fs
+
+
+def _store(n_slots, T, L):
+    """a FrameStore shell: slot s = frame (t, j) -> s = t * L + j, live frames behind; identity lattice, W = translation"""
+    st = object.__new__(fs.FrameStore)
+    st.lock = threading.RLock()
+    st.block_window, st.block_max_scans, st.ntf = 160, 64, 128
+    st._rec = np.zeros(n_slots, dtype=fs.PP_FRAME)
+    st._rec["xyz_dev"] = 0x10000 + 4096 * np.arange(n_slots)
+    st._rec["tab_dev"] = 0x9000000 + 4096 * np.arange(n_slots)
+    st._rec["n"] = 1000
+    st._W = np.tile(np.eye(4), (n_slots, 1, 1))
+    st._lat = np.zeros((n_slots, 8))
+    st._perm = (0x5000000 + 4096 * np.arange(n_slots)).astype(np.uint64)
+    st._clean = np.ones(n_slots, dtype=bool)
+    st._checked = np.ones(n_slots, dtype=bool)
+    st._key_of, st.frames = {}, {}
+    return st
+
+
+def _descs(st, B, T, F, L, shift=1.0, bad_pose=None):
+    """B consecutive scans: scan i looks at frames i .. i+F-1 of every traversal; frame (t, j) sits at x = j * shift"""
+    live0 = T * L
+    for t in range(T):
+        for j in range(L):
+            st._W[t * L + j, 0, 3] = j * shift
+    out = []
+    for i in range(B):
+        ls = live0 + i
+        st._W[ls, 0, 3] = (i + F) * shift
+        slots = np.array([t * L + (i + j) for t in range(T) for j in range(F)] + [ls], dtype=np.int64)
+        arr = st._rec[slots[:-1]].copy()
+        arr["trav"] = np.repeat(np.arange(T), F)
+        rel = np.linalg.inv(st._W[ls])[None] @ st._W[slots[:-1]]          # frame -> live frame
+        if bad_pose is not None and i == bad_pose:
+            rel[3, 0, 3] += 0.01
+        arr["rel"] = rel[:, :3, :].reshape(-1, 12).astype(np.float32)
+        lv = st._rec[[ls]].copy()
+        lv["rel"] = np.eye(4)[:3].reshape(1, 12).astype(np.float32)        # the common frame IS the live frame
+        out.append((lv, arr, slots))
+    return out
+
+
+def _read(ptr, n, ctype):
+    return np.ctypeslib.as_array((ctype * n).from_address(int(ptr))).copy()
+
+
+@pytest.mark.parametrize("B,T,F", [(16, 10, 36), (8, 2, 24), (16, 20, 16)])
+def test_block_tables_order_members_and_layout(B, T, F):
+    L = F + B - 1
+    st = _store(T * L + B, T, L)
+    descs = _descs(st, B, T, F, L)
+    fr, sc, keep = st.block_tables(descs, T)
+    assert len(fr) == T * L and len(sc) == B
+    pos_of = {int(a): k for k, a in enumerate(fr["xyz_dev"])}              # table position of every frame (by its address)
+    for i, (lv, arr, slots) in enumerate(descs):
+        n = int(sc["n_members"][i])
+        assert n == T * F
+        ms = _read(sc["member_slot"][i], n, C.c_int32)
+        mt = _read(sc["member_trav"][i], n, C.c_int32)
+        mr = _read(sc["member_rel"][i], 12 * n, C.c_float).reshape(n, 12)
+        assert np.array_equal(ms, [pos_of[int(a)] for a in arr["xyz_dev"]])   # the member table names the scan's own frames
+        assert np.array_equal(mt, arr["trav"]) and np.array_equal(mr, arr["rel"])
+        # ... and they are ONE range of the block's table, holes only for frames another scan of the block uses
+        lo, hi = int(ms.min()), int(ms.max())
+        inside = set(range(lo, hi + 1)) - set(ms.tolist())
+        used_by = {}
+        for q, (_, a2, _) in enumerate(descs):
+            for a in a2["xyz_dev"]:
+                used_by.setdefault(pos_of[int(a)], set()).add(q)
+        assert all(i not in used_by[p] for p in inside)
+        assert hi - lo + 1 <= T * L
+        assert sc["xyz_dev"][i] == lv["xyz_dev"][0] and sc["perm_dev"][i] == st._perm[int(slots[-1])]
+    # (first, last) order: the first scan that uses a frame never decreases along the table
+    first = np.array([min(q for q in range(B) if int(a) in set(descs[q][1]["xyz_dev"].tolist())) for a in fr["xyz_dev"]])
+    assert np.all(np.diff(first) >= 0)
+
+
+def test_block_tables_rule_and_refusals():
+    T, F, B = 4, 36, 16
+    L = F + B - 1
+    st = _store(T * L + B, T, L)
+    descs = _descs(st, B, T, F, L)
+    assert st.block_tables(descs, T) is not None
+    assert st.block_tables(descs[:7], T) is None                       # fewer than eight scans: the chain (unless forced)
+    assert st.block_tables(descs[:7], T, force=True) is not None
+    assert st.block_tables(descs, T, force=False) is None
+    # windows shorter than 12 frames per traversal, or scans that share too little: the chain
+    st2 = _store(T * 27 + 16, T, 27)
+    assert st2.block_tables(_descs(st2, 16, T, 8, 27), T) is None
+    # a pose that disagrees with the lattice by a centimetre, a frame with points outside its table: refused even when forced
+    st3 = _store(T * L + B, T, L)
+    assert st3.block_tables(_descs(st3, B, T, F, L, bad_pose=5), T, force=True) is None
+    st4 = _store(T * L + B, T, L)
+    d4 = _descs(st4, B, T, F, L)
+    st4._clean[3] = False
+    assert st4.block_tables(d4, T, force=True) is None
+    # live scans further apart than the block window
+    st5 = _store(T * L + B, T, L)
+    d5 = _descs(st5, B, T, F, L)
+    st5._rec["TX0"][T * L + 9] = 400
+    d5[9][0]["TX0"] = 400
+    assert st5.block_tables(d5, T, force=True) is None
