@@ -185,7 +185,10 @@ int modest_pp_score_frames_batch(modest_ctx *ctx, int n_scans, const modest_pp_f
  * neighbours are counted with scipy's float64 predicate (:54-60).  Results are those of
  * modest_pp_score_frames, bit for bit.
  *
- * frames_host [host] (n_frames): the union, each frame once.  lat = the 2x4 float64 map the frame was
+ * frames_host [host] (n_frames): the union, one entry per (frame, occurrence): a frame that a scan's index list names
+ *   k times (split_traintest.py:86-101; the reference stacks it k times, pre_compute_pp_score.py:132-150) is k entries
+ *   with the same buffers, and that scan's member list names each of them once -- a member list that names one entry
+ *   twice is refused (MODEST_ERR_ARG).  lat = the 2x4 float64 map the frame was
  *   sorted with (modest_frame_sort_job::W); flags: MODEST_FRAME_REMOVE_CENTER (all or none).  The ORDER of the table is
  *   the caller's: a scan reads, cell by cell, the records of the table range [its first frame, its last frame] (and masks
  *   the frames in between that are not its own), so an order in which every scan's frames are contiguous -- for the

@@ -1304,6 +1304,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     MODEST_REQUIRE(ntot < (1LL << 31) && nch < (1LL << 24), "union of frames too large");
     int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0, maxN = 0;
     bool any = false;
+    std::vector<int> seenBy((size_t)std::max(U, 1), -1);   // the last scan that named a union slot
     for (int s = 0; s < G; ++s) {
         const modest_pp_block_scan &sc = scans[s];
         MODEST_REQUIRE(sc.n >= 0 && sc.n < (1 << 24), "bad live scan");
@@ -1314,6 +1315,10 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         for (int m = 0; m < sc.n_members; ++m) {
             MODEST_REQUIRE(sc.member_slot[m] >= 0 && sc.member_slot[m] < U, "member slot out of range");
             MODEST_REQUIRE(sc.member_trav[m] >= 0 && sc.member_trav[m] < T, "frame traversal out of range");
+            // one pose entry per (scan, union slot): a frame a scan lists twice (pre_compute_pp_score.py:132-150 stacks it
+            // twice) must come as two union entries -- FrameStore.block_tables gives every occurrence a slot of its own
+            MODEST_REQUIRE(seenBy[(size_t)sc.member_slot[m]] != s, "a scan names a union slot twice: repeated frames need a union entry per occurrence");
+            seenBy[(size_t)sc.member_slot[m]] = s;
         }
         if (sc.n == 0) continue;
         if (!any) {

@@ -297,9 +297,9 @@ class FrameStore:
 
     def _new_slab(self, nbytes: int) -> torch.Tensor:
         t = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
-        for st in self._readers.values():
-            t.record_stream(st)
-        with self.lock:
+        with self.lock:   # (note_reader inserts into _readers and walks _slabs under the same lock: no reader is missed)
+            for st in self._readers.values():
+                t.record_stream(st)
             old = self._slabs.get(self._slab_id)
             if old is not None and old[2] == 0 and self._slab_id not in self._pinned:
                 del self._slabs[self._slab_id]   # nothing resident (or being inserted) was carved from the slab that is replaced
@@ -592,7 +592,18 @@ class FrameStore:
                 return None
             allh = np.concatenate([np.asarray(sl[:-1], dtype=np.int64) for _, _, sl in descs])
             sid = np.repeat(np.arange(B, dtype=np.int64), lens)   # the scan of every member, ascending
-            us, first_idx = np.unique(allh, return_index=True)
+            # A scan may list a frame more than once (split_traintest.py:86-101: two distance thresholds select the same
+            # pose), and the reference stacks it as often as it is listed (pre_compute_pp_score.py:132-150).  The union is
+            # therefore one of (frame, occurrence): the k-th listing of a frame inside a scan is union entry (frame, k), the
+            # scatter writes that frame's points k times, and every member keeps a pose entry of its own.
+            srt = np.argsort(sid * (int(allh.max()) + 1) + allh, kind="stable")
+            ks = (sid * (int(allh.max()) + 1) + allh)[srt]
+            run0 = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+            occ = np.empty(members, dtype=np.int64)
+            occ[srt] = np.arange(members) - np.repeat(run0, np.diff(np.concatenate([run0, [members]])))
+            K = int(occ.max()) + 1
+            ukey = allh * K + occ
+            us, first_idx = np.unique(ukey, return_index=True)
             if force is None:
                 # measured (bench.py, whole pipeline, 8 processes): the block pays when there are enough scans to share the
                 # binning (>= 8) and the windows are not too short -- Lyft shape, 36 frames per traversal, 16 scans: union
@@ -602,7 +613,11 @@ class FrameStore:
                 per_scan = members / B
                 if B < 8 or len(us) > 2.0 * per_scan or per_scan < 12 * T:
                     return None
-            if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([us, lslots])):
+            if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([np.unique(allh), lslots])):
+                return None
+            # the lattice is a conservative filter only while two points within r of each other (pose error < 1e-4 m checked
+            # below, float32 evaluation < 4e-5 m, per point) stay within one cell: cell - r >= 2 (1e-4 + 4e-5)
+            if self.cell - self.radius < 2.0 * (1e-4 + 4e-5):
                 return None
             lrec = self._rec[lslots]
             span = self.block_window - self.ntf - 2   # (the library pads the window by one tile on every side)
@@ -634,24 +649,24 @@ class FrameStore:
             # scan of a sliding window are then one contiguous range of the table, and the join skips -- run by run of the
             # cell-sorted store -- the records of the frames a scan does not use (modest_hip.h)
             first = sid[first_idx]
-            _, last_idx = np.unique(allh[::-1], return_index=True)
+            _, last_idx = np.unique(ukey[::-1], return_index=True)
             last = sid[::-1][last_idx]
             us = us[np.lexsort((last, first))]
             pos = np.empty(int(us.max()) + 1, dtype=np.int32)
             pos[us] = np.arange(len(us), dtype=np.int32)
             fr = np.zeros(len(us), dtype=BLOCK_FRAME)
-            ur = self._rec[us]
+            ur = self._rec[us // K]
             for k in ("xyz_dev", "tab_dev", "n", "TX0", "TY0"):
                 fr[k] = ur[k]
             fr["flags"] = int(flags[0]) if len(flags) else 0
-            fr["lat"] = self._lat[us]
+            fr["lat"] = self._lat[us // K]
             sc = np.zeros(B, dtype=BLOCK_SCAN)
             for k in ("xyz_dev", "tab_dev", "n", "TX0", "TY0"):
                 sc[k] = lrec[k]
             sc["perm_dev"] = self._perm[lslots]
             sc["lat"] = self._lat[lslots]
             sc["rel"] = live_rel
-            ms_all = np.ascontiguousarray(pos[allh])   # (int32) the members of all scans, scan after scan
+            ms_all = np.ascontiguousarray(pos[ukey])   # (int32) the members of all scans, scan after scan: distinct inside a scan
             offs = (np.cumsum(lens) - lens).astype(np.uint64)
             sc["n_members"] = lens
             sc["member_slot"] = np.uint64(ms_all.ctypes.data) + np.uint64(4) * offs

@@ -16,7 +16,7 @@ from __future__ import annotations
 import os
 import pickle
 from dataclasses import dataclass, field
-from typing import Dict, List, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 from scipy.spatial.transform import Rotation as R
@@ -316,6 +316,92 @@ def make_shard(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_frames: i
                                live_rel=relative_pose(l2e, first_pose, l2e, live_pose, K), hist=hist, rels=np.stack(rels),
                                world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K))
     return Shard(scans=scans, tracks=tracks, nusc=nusc)
+
+
+DIS_CHOICE_LYFT = np.arange(2, 71, 2)            # data_preprocessing/lyft/split_traintest.py:64
+DIS_CHOICE_NUSC = np.linspace(0, 30, 16)[1:]     # data_preprocessing/nuscenes/split_traintest.py:74
+
+
+def match_history(origin_pose: np.ndarray, track_poses: Sequence[np.ndarray], dis_choice=DIS_CHOICE_LYFT,
+                  max_allow_dist: float = 3.0):
+    """The history frames one traversal contributes to one live scan, by the reference's rule
+    (data_preprocessing/lyft/split_traintest.py:79-101 with only_forward, nuscenes/split_traintest.py:90-113): the closest
+    pose of the track (refused beyond max_allow_dist), then for every distance threshold the FIRST frame behind it, in the
+    origin's driving direction, that lies further than the threshold from the origin.  Thresholds that select the same
+    frame repeat it in the list -- the reference stacks it as often.  None: the traversal does not qualify."""
+    loc = np.array([p[:2, 3] for p in track_poses])
+    distance = np.linalg.norm(loc - origin_pose[:2, 3], axis=1)
+    k0 = int(np.argmin(distance))
+    if distance[k0] > max_allow_dist:
+        return None
+    forward = origin_pose[0, :3] @ track_poses[k0][0, :3] > 0
+    indices = [k0]
+    for dis in dis_choice:
+        temp = np.where(distance > dis)[0]
+        side = temp[temp > k0] if forward else temp[temp < k0]
+        if len(side) == 0:
+            return None
+        indices.append(int(side.min() if forward else side.max()))
+    return indices
+
+
+def make_shard_matched(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_per_frame: int | None = None, nusc: bool = False,
+                       live_speed: float = 8.0, hist_speeds=(3.0, 15.0), hz: float = 5.0, seed: int = 0, x0: float = 0.0,
+                       world_seed: int = 0, point_order: str = "shuffled", opposite: int = 0) -> Shard:
+    """A shard whose history windows are chosen as the reference chooses them (match_history): the live vehicle drives at
+    `live_speed` m/s, traversal t at a speed drawn from `hist_speeds` (a (lo, hi) range, or one value per traversal), all
+    sampled at `hz`; the last `opposite` traversals drive the other way.  Fast traversals (> 2 m per frame: > 10 m/s at 5 Hz)
+    repeat frames inside a window, slow ones advance by less than a frame per live scan -- how many frames consecutive
+    scans share follows from the speeds instead of being 35 of 36.  Only the frames some scan names are sampled."""
+    n_per_frame = n_live if n_per_frame is None else n_per_frame
+    dis = DIS_CHOICE_NUSC if nusc else DIS_CHOICE_LYFT
+    reach = float(dis[-1]) + 6.0
+    dt = 1.0 / hz
+    span = live_speed * dt * n_scans
+    world = make_world(world_seed, length=max(400.0, x0 + span + reach + 150.0))
+    K, l2e = kitti2nu(nusc), default_l2e()
+    rngs = np.random.default_rng([61_000 + seed, n_trav])
+    speeds = (np.asarray(hist_speeds, dtype=np.float64) if len(hist_speeds) == n_trav and n_trav != 2
+              else rngs.uniform(hist_speeds[0], hist_speeds[1], n_trav))
+    live_poses = [_pose_matrix(x0 + live_speed * dt * i, 0.0, 0.01) for i in range(n_scans)]
+    poses = []
+    for t in range(n_trav):
+        rngp = np.random.default_rng([62_000 + seed, t])
+        lat, yaw = rngp.uniform(-1.5, 1.5), rngp.uniform(-0.02, 0.02)
+        step = speeds[t] * dt
+        back = t >= n_trav - opposite
+        lo, hi = (x0 - reach - 2 * step, x0 + span + 5.0) if back else (x0 - 5.0, x0 + span + reach + 2 * step)
+        xs = np.arange(lo, hi, step) + rngp.uniform(-0.1, 0.1, int(np.ceil((hi - lo) / step)))[: len(np.arange(lo, hi, step))] * step
+        if back:
+            xs = xs[::-1]
+        poses.append([_pose_matrix(x, lat, yaw + (np.pi if back else 0.0)) for x in xs])
+    picks = [[match_history(lp, poses[t], dis) for t in range(n_trav)] for lp in live_poses]
+    assert all(ix is not None for row in picks for ix in row), "a traversal does not cover the shard"
+    used = [sorted({j for row in picks for j in row[t]}) for t in range(n_trav)]
+    renum = [{j: k for k, j in enumerate(u)} for u in used]
+    tracks = [[(sample_frame(world, 9000 + 100_000 * seed + 1000 * t + j, n_per_frame, poses[t][j], l2e, nusc, point_order=point_order),
+                poses[t][j] @ l2e @ K) for j in used[t]] for t in range(n_trav)]
+    scans = []
+    for i, lp in enumerate(live_poses):
+        live_raw = sample_frame(world, 7000 + 1000 * seed + i, n_live, lp, l2e, nusc, make_mobiles(1000 * seed + i, lp[0, 3]),
+                                point_order=point_order)
+        first_pose = poses[0][picks[i][0][0]]
+        hist = [(t, renum[t][j]) for t in range(n_trav) for j in picks[i][t]]
+        rels = np.stack([relative_pose(l2e, first_pose, l2e, poses[t][j], K) for t in range(n_trav) for j in picks[i][t]])
+        scans.append(ShardScan(index=i, live_raw=live_raw, live_W=lp @ l2e @ K, live_rel=relative_pose(l2e, first_pose, l2e, lp, K),
+                               hist=hist, rels=rels, world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K))
+    return Shard(scans=scans, tracks=tracks, nusc=nusc)
+
+
+def sharing_stats(sh: Shard, block: int = 16) -> dict:
+    """how much consecutive scans of a shard share: members per scan, distinct frames per scan, repeats, union of a block"""
+    mem = np.array([len(sc.hist) for sc in sh.scans])
+    dist = np.array([len(set(sc.hist)) for sc in sh.scans])
+    unions = [len(set(h for sc in sh.scans[b:b + block] for h in sc.hist)) for b in range(0, len(sh.scans), block)]
+    shared = [len(set(a.hist) & set(b.hist)) / max(len(set(b.hist)), 1) for a, b in zip(sh.scans[:-1], sh.scans[1:])]
+    return dict(members_per_scan=float(mem.mean()), distinct_per_scan=float(dist.mean()), repeats_per_scan=float((mem - dist).mean()),
+                union_per_block=float(np.mean(unions)), union_over_members=float(np.mean(unions) / mem.mean()),
+                shared_with_previous=float(np.mean(shared)) if shared else 1.0)
 
 
 CALIB_TXT = (

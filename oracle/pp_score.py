@@ -115,3 +115,35 @@ def pp_score(live_xyz, hist_list, max_neighbor_dist=0.3, workers=1):
     pre_compute_pp_score.py:193-196."""
     c = count_neighbors(live_xyz, hist_list, max_neighbor_dist, workers=workers)
     return compute_ephe_score(c).astype(np.float32), c
+
+
+def load_pose(oxts_txt: str) -> np.ndarray:
+    """pre_compute_pp_score.py:92-101: oxts line "x y z roll pitch yaw" -> 4x4 float32 ego pose."""
+    from scipy.spatial.transform import Rotation as R
+    info = np.array([float(x) for x in oxts_txt.split()])
+    trans = np.eye(4)
+    trans[:3, 3] = info[:3]
+    trans[:3, :3] = R.from_euler("xyz", info[3:]).as_matrix()
+    return trans.astype(np.float32)
+
+
+def stack_history(traversals, track_list, load_frame, poses, l2es, nusc=False):
+    """pre_compute_pp_score.py:126-150: the stacked, transformed history of one scan -- ``for seq_id, indices in
+    valid_idx[origin][2]: for frame in indices:`` load, (remove_center), relative pose to the FIRST listed frame,
+    transform, append.  A frame is stacked AS OFTEN AS ``indices`` names it (split_traintest.py:86-101 produces such
+    repeats whenever two distance thresholds select the same pose).  ``load_frame(file id) -> (n,>=3) float32``;
+    ``poses[seq][frame]`` float32 ego pose, ``l2es[seq][frame]``.  Returns ([stack per traversal], first_pose, first_l2e)."""
+    K = kitti2nu(nusc)
+    seq_id, indices = traversals[0]
+    first_pose, first_l2e = poses[seq_id][indices[0]], l2es[seq_id][indices[0]]
+    stacks = []
+    for seq_id, indices in traversals:
+        queue = []
+        for frame in indices:
+            ptc = load_frame(track_list[seq_id][frame])[:, :3]
+            if nusc:
+                ptc = remove_center(ptc)
+            rel = get_relative_pose(first_l2e, first_pose, l2es[seq_id][frame], poses[seq_id][frame], K)
+            queue.append(transform_points(ptc, rel))
+        stacks.append(np.concatenate(queue).astype(np.float32))
+    return stacks, first_pose, first_l2e

@@ -17,6 +17,7 @@ def _store(n_slots, T, L):
     st = object.__new__(fs.FrameStore)
     st.lock = threading.RLock()
     st.block_window, st.block_max_scans, st.ntf = 160, 64, 128
+    st.radius, st.cell = 0.3, 0.3 * (1.0 + 1.0 / 256.0)
     st._rec = np.zeros(n_slots, dtype=fs.PP_FRAME)
     st._rec["xyz_dev"] = 0x10000 + 4096 * np.arange(n_slots)
     st._rec["tab_dev"] = 0x9000000 + 4096 * np.arange(n_slots)
@@ -113,3 +114,34 @@ def test_block_tables_rule_and_refusals():
     st5._rec["TX0"][T * L + 9] = 400
     d5[9][0]["TX0"] = 400
     assert st5.block_tables(d5, T, force=True) is None
+
+
+def test_block_tables_repeated_frames_get_a_union_entry_per_occurrence():
+    """A scan that lists a frame k times (pre_compute_pp_score.py:132-150 stacks it k times; split_traintest.py:86-101 produces
+    such lists) gets k union entries with the same buffers; its member list names every union slot at most once, so that
+    every occurrence keeps its own pose entry in modest_pp_score_block."""
+    T, F, B = 4, 36, 16
+    L = F + B - 1
+    st = _store(T * L + B, T, L)
+    descs = _descs(st, B, T, F, L)
+    # scan 3: member 1 := member 0 (twice in a row); scan 5: one frame three times and the window's first frame again at its end
+    for i, edits in ((3, {1: 0}), (5, {40: 38, 39: 38, F - 1: 0})):
+        lv, arr, slots = descs[i]
+        arr, slots = arr.copy(), slots.copy()
+        for dst, src in edits.items():
+            arr[dst] = arr[src]
+            slots[dst] = slots[src]
+        descs[i] = (lv, arr, slots)
+    fr, sc, keep = st.block_tables(descs, T)
+    distinct = len(np.unique(np.concatenate([sl[:-1] for _, _, sl in descs])))
+    assert len(fr) == distinct + 1 + 2 + 1          # one extra entry per extra occurrence (frame 38 of scan 5: two extras)
+    for i, (lv, arr, slots) in enumerate(descs):
+        n = int(sc["n_members"][i])
+        assert n == T * F                                               # a repeated frame stays a member
+        ms = _read(sc["member_slot"][i], n, C.c_int32)
+        assert len(np.unique(ms)) == n                                  # ... with a union slot of its own
+        assert np.array_equal(fr["xyz_dev"][ms], arr["xyz_dev"])        # ... that carries the frame's buffers
+        assert np.array_equal(_read(sc["member_rel"][i], 12 * n, C.c_float).reshape(n, 12), arr["rel"])
+    # a lattice cell with less slack than pose error + float32 rounding needs: the block path is refused (radius < 0.072 m)
+    st.radius, st.cell = 0.05, 0.05 * (1.0 + 1.0 / 256.0)
+    assert st.block_tables(descs, T, force=True) is None

@@ -140,3 +140,110 @@ def test_block_dense_window_bands(gpu):
     assert all(torch.equal(a, b) for a, b in zip(cb, cv))
     _, cref = _oracle_counts(sh, 2)
     assert np.array_equal(cb[2].cpu().numpy().astype(np.int64), cref) and cref.max() > 200
+
+
+def _tree_descs(store, g, gpu, torch):
+    """the descriptor tables the CLI builds (modest_amd/pre_compute_pp_score.py: plans + relative_poses + describe) for every origin
+    of an unpacked golden tree"""
+    import pickle
+    from modest_amd import pre_compute_pp_score as pps
+    from oracle import pp_score as opp
+    off = g["bin_offsets"]
+    bins = [g["bins"][off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    track, valid = pickle.loads(g["track"].tobytes()), pickle.loads(g["valid"].tobytes())
+    poses = [[opp.load_pose(str(g["oxts"][i])) for i in seq] for seq in track]
+    l2es = [[g["l2e"][i] for i in seq] for seq in track]
+    K = pps._KITTI2NU_lyft
+    world = pps.frame_world_matrices(track, poses, l2es, K)
+    store.insert_many([(i, torch.from_numpy(np.ascontiguousarray(b)).to(gpu), world[i]) for i, b in enumerate(bins)])
+    lives, descs = [], []
+    for o in g["origins"]:
+        seq0, fr0, trav = valid[int(o)]
+        hist_ids = [track[s][f] for s, ix in trav for f in ix]
+        travs = [t for t, (s, ix) in enumerate(trav) for _ in ix]
+        live = track[seq0][fr0]
+        fs, fi = trav[0]
+        rels = pps.relative_poses(l2es[fs][fi[0]], poses[fs][fi[0]], world.stack(hist_ids + [live]), K)
+        lives.append(live)
+        descs.append(store.describe(live, rels[-1], hist_ids, travs, rels[:-1], False))
+    return lives, descs
+
+
+def test_repeated_frames_block_chain_and_golden(gpu, golden_dir):
+    """A history frame counts as often as the scan's index list names it (pre_compute_pp_score.py:132-150; lists with repeats:
+    split_traintest.py:86-101).  tests/golden/pp_repeats.npz = the reference's own main + count_neighbors on eight
+    consecutive scans whose lists repeat a frame once / three times / at the first and last position: the block path
+    (one union entry per occurrence), the per-scan chain and the single-scan call all reproduce its counts bit for bit."""
+    import torch
+    from modest_amd.frame_store import FrameStore
+    g = np.load(f"{golden_dir}/pp_repeats.npz")
+    store = FrameStore(gpu, 0.3)
+    lives, descs = _tree_descs(store, g, gpu, torch)
+    assert all(len(np.unique(sl[:-1])) < len(sl) - 1 for _, _, sl in descs)   # every scan repeats frames
+    n0 = getattr(store, "block_calls", 0)
+    Hb, cb = store.pp_score_batch(lives, descs, 3, return_counts=True, block=True)
+    assert getattr(store, "block_calls", 0) == n0 + 1
+    Hv, cv = store.pp_score_batch(lives, descs, 3, return_counts=True, block=False)
+    for i, o in enumerate(g["origins"]):
+        assert np.array_equal(cb[i].cpu().numpy(), g[f"counts_{o}"]), ("block", int(o))
+        assert np.array_equal(cv[i].cpu().numpy(), g[f"counts_{o}"]), ("chain", int(o))
+        assert np.max(np.abs(Hb[i].cpu().numpy() - g[f"pp_{o}"])) <= 1e-6 and torch.equal(Hb[i], Hv[i])
+    one = store.pp_score_batch(lives[3:4], descs[3:4], 3, return_counts=True, block=False)[1][0]
+    assert np.array_equal(one.cpu().numpy(), g[f"counts_{g['origins'][3]}"])
+
+
+def test_repeated_frames_on_a_shard(gpu):
+    """make_shard windows with repeats spliced in (a frame twice in a row, a frame three times, the window's first frame again
+    at its end; different scans repeat different frames): block == chain == oracle, and the union holds an entry per
+    occurrence."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    T, F, S = 3, 6, 8
+    sh = synth.make_shard(S, n_live=4000, n_trav=T, n_frames=F, seed=21)
+    for sc in sh.scans:
+        hist, rels = list(sc.hist), list(sc.rels)
+        per = [[k for k, (t, _) in enumerate(hist) if t == tt] for tt in range(T)]
+        new = []
+        for tt, ks in enumerate(per):
+            if tt == 0:
+                ks = ks[:2] + [ks[1]] + ks[2:]                    # once (only on even scans: the union mixes both kinds)
+                if sc.index % 2:
+                    ks = per[tt]
+            elif tt == 1:
+                ks = ks[:3] + [ks[2], ks[2]] + ks[3:]             # three times
+            else:
+                ks = ks + [ks[0]]                                 # first == last
+            new += ks
+        sc.hist = [hist[k] for k in new]
+        sc.rels = np.stack([rels[k] for k in new])
+    store = FrameStore(gpu, 0.3)
+    lives, descs, _ = _load(store, sh, gpu, torch)
+    tabs = store.block_tables(descs, T, force=True)
+    assert tabs is not None
+    fr, sc_, _ = tabs
+    assert len(fr) > len(np.unique(np.concatenate([sl[:-1] for _, _, sl in descs])))   # occurrences, not frames
+    Hb, cb = store.pp_score_batch(lives, descs, T, return_counts=True, block=True)
+    Hv, cv = store.pp_score_batch(lives, descs, T, return_counts=True, block=False)
+    for i in range(S):
+        Href, cref = _oracle_counts(sh, i)
+        assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), cref), i
+        assert torch.equal(cb[i], cv[i]) and torch.equal(Hb[i], Hv[i])
+
+
+def test_block_refuses_a_member_list_that_names_a_slot_twice(gpu):
+    """the C ABI's own guard (a caller other than FrameStore): one pose entry exists per (scan, union slot)"""
+    import torch
+    from modest_amd import synth, _lib
+    from modest_amd.frame_store import FrameStore
+    sh = synth.make_shard(2, n_live=1000, n_trav=2, n_frames=3, seed=2)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, _ = _load(store, sh, gpu, torch)
+    fr, sc, keep = store.block_tables(descs, 2, force=True)
+    keep[0][1] = keep[0][0]   # scan 0 now names its first union slot twice
+    H = [torch.empty((1000,), dtype=torch.float32, device=gpu) for _ in range(2)]
+    sc["H_dev"] = [h.data_ptr() for h in H]
+    lib = _lib.load()
+    rc = lib.modest_pp_score_block(store._ctx().handle, fr.ctypes.data, len(fr), sc.ctypes.data, 2, 2, 0.3, store.cell,
+                                   torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"twice" in lib.modest_last_error()

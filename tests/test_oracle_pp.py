@@ -82,3 +82,35 @@ def test_kitti2nu_against_independent_rotation():
         E[:3, 3] = rng.uniform(-50, 50, 3)
         assert np.array_equal(opp.get_relative_pose(np.eye(4), np.eye(4), np.eye(4), E, K),
                               opp.get_relative_pose(np.eye(4), np.eye(4), np.eye(4), E, ref))
+
+
+def _repeat_tree(golden_dir):
+    import pickle
+    g = np.load(f"{golden_dir}/pp_repeats.npz")
+    off = g["bin_offsets"]
+    bins = [g["bins"][off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    track, valid = pickle.loads(g["track"].tobytes()), pickle.loads(g["valid"].tobytes())
+    poses = [[opp.load_pose(str(g["oxts"][i])) for i in seq] for seq in track]
+    l2es = [[g["l2e"][i] for i in seq] for seq in track]
+    return g, bins, track, valid, poses, l2es
+
+
+def test_repeated_history_frames_are_stacked_as_often_as_listed(golden_dir):
+    """tests/golden/pp_repeats.npz (tools/make_golden_pp_repeats.py: the reference's own main + count_neighbors on a tree whose
+    index lists repeat a frame once, three times, and at the first and last position): the oracle's stacking follows the
+    list, and dropping the repeats changes the counts."""
+    g, bins, track, valid, poses, l2es = _repeat_tree(golden_dir)
+    changed = 0
+    for o in g["origins"]:
+        seq0, fr0, trav = valid[int(o)]
+        assert any(len(set(ix)) < len(ix) for _, ix in trav)
+        stacks, fp, fl = opp.stack_history(trav, track, lambda i: bins[i], poses, l2es)
+        assert [len(s) for s in stacks] == list(g[f"stack_sizes_{o}"])
+        rel = opp.get_relative_pose(fl, fp, l2es[seq0][fr0], poses[seq0][fr0], opp.kitti2nu(False))
+        live = opp.transform_points(bins[track[seq0][fr0]][:, :3], rel)
+        H, c = opp.pp_score(live, stacks, 0.3)
+        assert np.array_equal(c, g[f"counts_{o}"]) and np.array_equal(H, g[f"pp_{o}"])
+        dedup = [(s, list(dict.fromkeys(ix))) for s, ix in trav]
+        stacks1, _, _ = opp.stack_history(dedup, track, lambda i: bins[i], poses, l2es)
+        changed += int(not np.array_equal(opp.count_neighbors(live, stacks1, 0.3), c))
+    assert changed == len(g["origins"])   # a set-semantics implementation fails this fixture on every scan
