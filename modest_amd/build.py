@@ -30,7 +30,7 @@ ARCH = "gfx950"
 CXXFLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fno-fast-math", "-Wall", "-Wno-unused-function", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-]
+] + os.environ.get("MODEST_EXTRA_CXXFLAGS", "").split()   # (experiments: -DB4_JT_=640 ...; part of the build digest)
 
 
 def _hipcc() -> str:

@@ -18,13 +18,15 @@
 //     tables: no atomics); tiles no scan of the chain has a live point near are skipped;
 //   * b4_seg_hist / b4_seg_scan / b4_seg_scatter order every tile list by cell (counting sort over 4096-record
 //     segments), so that the records of a cell are CONTIGUOUS in HBM for the whole chain;
-//   * per scan: the live scan is cell-sorted on the same lattice (b4_live_*), b4_plan_* cuts the work into
-//     items, and b4_join reads the records of the cells that have live points nearby straight into
-//     registers -- no slice sort, no LDS staging of records -- applies the scan's own float32 pose to every
-//     record (transform_points' rounding, per (scan, frame)) and tests it against the live points of the
-//     3x3 cells around it.  A wavefront holds up to 512 records of ONE cell (eight per lane) against a
-//     wave-uniform candidate: ballots + traversal-segmented popcounts, one LDS atomic per (candidate,
-//     traversal).  Sparse cells (< 64 records) are packed 64 to a wavefront and walk their own candidates.
+//   * per scan: the live scan is cell-sorted on the same lattice (b4_live_*), b4_plan writes a flat list of
+//     self-contained tasks (<= 256 records of ONE cell + the three runs of live points around it), and b4_join
+//     -- every wavefront on its own, no workgroup barrier, no LDS window -- reads a task's records straight into
+//     registers, applies the scan's own float32 pose to every record (transform_points' rounding, per (scan,
+//     frame)) and tests them against one wave-uniform candidate per step (read with a scalar load: the live
+//     point arrives in SGPRs): ballots + traversal-segmented popcounts, one global atomic per (candidate,
+//     task).  Sparse cells (< 64 records) are packed 64 to a wavefront and walk their own candidates.
+//     (Round 4 dealt ITEMS of 24 tasks to whole workgroups, with the live window of a quad of tiles in LDS: four
+//     barriers and four dependent rounds of loads per item -- 34 of the join's 99 us per scan went there.)
 //
 // Exactness: the lattice is only a conservative spatial filter.  Distances are evaluated exactly as V3
 // does -- float32 pre-test, float64 re-test (scipy's predicate) inside a 1.5e-6 band around r^2 -- on
@@ -49,29 +51,21 @@ constexpr int B4_MAXW = 160;               // block window: at most this many ti
 constexpr int B4_CH = 4096;                // points per streaming chunk (1024 threads x 4)
 constexpr int B4_SEG = 4096;               // records per sort segment (512 threads x 8)
 constexpr int B4_FG = 32;                  // frames per prefix group
-constexpr int B4_QC = 16, B4_NC = B4_QC * B4_QC;   // a join item covers a QUAD of 2x2 tiles = 16x16 cells
-constexpr int B4_W = B4_QC + 2, B4_W1 = B4_W + 1;   // window of a quad incl. halo (cells)
 constexpr unsigned B4_HEAVY = 64;          // cells with at least this many records get tasks of their own
 #ifndef B4_CPT_
 #define B4_CPT_ 4
 #endif
 constexpr int B4_CPT = B4_CPT_;                  // 64-record chunks per task
 constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
-#ifndef B4_IT_
-#define B4_IT_ 24
-#endif
-constexpr unsigned B4_IT = B4_IT_;             // tasks per item
 #ifndef B4_WPE_
 #define B4_WPE_ 4
 #endif
 #ifndef B4_JT_
-#define B4_JT_ 256
+#define B4_JT_ 1024
 #endif
 constexpr int B4_JT = B4_JT_;                 // threads of a join workgroup
-constexpr int B4_LDS_DYN = 30 * 1024;      // live points + counters of a band (4 workgroups per CU)
-constexpr unsigned B4_LANE_MAX = 64;       // packed chunks: lanes with more candidates take the group loop
 constexpr int B4_MAXT = 64;
-constexpr int B4_POSE_LDS_MAX = 640;        // frames whose poses fit the LDS table of a join workgroup
+constexpr int B4_POSE_LDS_MAX = 1024;       // union frames whose poses fit the LDS table of a join workgroup (50 KB)
 
 struct UFrame {   // a frame of the union, device side (96 bytes)
     const float *xyz;
@@ -93,6 +87,7 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
     const UFrame *frames;
     const uint2 *chunkTab;
     unsigned *off, *gtot, *listTotal, *listBase, *segBase, *segList, *segHist, *segOff, *cellOff, *ctrl, *baseSum;
+    unsigned *needList;   // the tiles some scan of the block needs, in no particular order; ctrl[2] = their number
     uint2 *segRange;   // smallest / largest frame slot among a segment's records
     float4 *recA, *recB;
     int U, NG, nchunks, maxSegs;
@@ -102,16 +97,17 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
 struct ScanDev {   // per scan (device table)
     const float *liveXyz;
     const unsigned *livePerm, *liveTab;
-    unsigned *cellCount, *cellStart, *blockSum, *tileTasks, *ctrl;   // ctrl: [0] items, [1] queue head
+    unsigned *cellCount, *cellStart, *blockSum, *ctrl;   // ctrl: [0] one-cell tasks, [1] packed chunks (b4_plan's cursors)
     uint2 *cellRange;   // per (tile with tasks, cell): first record and count of the part of the cell this scan reads
     float4 *tmp, *sorted;
-    uint4 *items;
+    void *tasks;       // B4Task x maxTasks
+    uint2 *lchunks;    // (tile, group of four chunks) x maxLight
     const PoseEnt *pose;
     int *counts;
     float *H;
     double lat[8];
     float rel[12];
-    int n, TX0, TY0, T, maxItems, pad;
+    int n, TX0, TY0, T, maxTasks, maxLight;
     int slotLo, slotHi;   // the scan's frames lie in [slotLo, slotHi] of the block's frame table
 };
 
@@ -130,6 +126,7 @@ __device__ __forceinline__ bool b4_cell(const double *__restrict__ W, float x, f
 // thread (block tile b, frame group g): exclusive prefix of the tile's point counts over the group's frames
 __global__ __launch_bounds__(256) void b4_counts(Blk B) {
     const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b == 0 && blockIdx.y == 0) B.ctrl[2] = 0u;   // cursor of b4_lists' tile list
     if (b >= B.BT) return;
     const int g = blockIdx.y;
     const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
@@ -176,6 +173,7 @@ __global__ __launch_bounds__(256) void b4_lists(Blk B, const ScanDev *__restrict
         run += t;
     }
     B.listTotal[b] = needed ? run : 0u;
+    if (needed && run != 0u) B.needList[atomicAdd(&B.ctrl[2], 1u)] = (unsigned)b;   // b4_plan walks this list instead of the window
 }
 
 // list bases, segment bases, the segment -> list table; ctrl[0] = records, ctrl[1] = segments.  Two launches of a few
@@ -475,6 +473,7 @@ __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__r
     if (tid == 0) {
         S.blockSum[B.nScanBlk] = run;
         S.cellStart[B.NCpad] = 0u;
+        S.ctrl[0] = 0u, S.ctrl[1] = 0u;   // b4_plan's cursors
     }
 }
 // start of cell `c` in the scan's cell-sorted live points
@@ -493,194 +492,130 @@ __global__ __launch_bounds__(256) void b4_live_scatter(Blk B, const ScanDev *__r
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
-// A tile's work for one scan, in TASKS of at most 512 records: a cell with >= 64 records and live points in
-// the 3x3 cells around it ("heavy") gets tasks of its own, ceil(chunks / 8) of them; the records of all other
-// cells with live points nearby are packed ("light" virtual order) into tasks of 512.  One wavefront per
-// tile, lane = cell.
-__device__ __forceinline__ unsigned b4_cell_cand(const unsigned *__restrict__ cellStart, const unsigned *__restrict__ blockOff, int CW, int CHc,
-                                                 int cx, int cy) {
+// The join's work for one scan is a flat list of self-contained TASKS.  A one-cell task: at most 256 records of ONE cell
+// of the block store that has live points in the 3x3 cells around it ("heavy" cell: >= 64 records of the scan's own frames)
+// together with its candidates -- three runs of the scan's cell-sorted live points (the cell rows cy-1, cy, cy+1; a row's
+// three cells are contiguous).  The records of all other cells with live points nearby ("light") are packed, tile by tile,
+// into chunks of 64 (a list entry = (tile, group of four chunks)).  One wavefront per tile, lane = cell; list positions come from two atomic
+// counters per scan: the order of the list is free, every count is an integer sum.
+struct B4Task {   // 32 bytes
+    unsigned recStart, recEnd;           // records [recStart, recEnd) of the block store
+    unsigned a0, n0, a1, n1, a2, n2;     // candidates: live points [a, a + n) of the scan's sorted array, per cell row
+};
+static_assert(sizeof(B4Task) == 32, "task layout");
+
+// the live points around cell (cx, cy), row by row
+__device__ __forceinline__ void b4_cell_segs(const unsigned *__restrict__ cellStart, const unsigned *__restrict__ blockOff, int CW, int CHc,
+                                             int cx, int cy, unsigned *a, unsigned *n) {
     const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
-    unsigned c = 0;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {   // (three rows, all loads issued: rows outside the window read the cell's own row and count nothing)
         const int yy = cy + dy;
         const bool in = yy >= 0 && yy < CHc;
         const size_t row = (size_t)(in ? yy : cy) * CW;
-        const unsigned a = b4_cs(cellStart, blockOff, row + xa), e = b4_cs(cellStart, blockOff, row + xb + 1);
-        c += in ? e - a : 0u;
+        const unsigned s = b4_cs(cellStart, blockOff, row + xa), e = b4_cs(cellStart, blockOff, row + xb + 1);
+        a[dy + 1] = s;
+        n[dy + 1] = in ? e - s : 0u;
     }
-    return c;
 }
-__global__ __launch_bounds__(256) void b4_plan_tiles(Blk B, const ScanDev *__restrict__ scans) {
+__global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict__ scans) {
     const ScanDev &S = scans[blockIdx.y];
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (b >= B.BT) return;
-    unsigned th = 0, lv = 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned nNeed = B.ctrl[2];
+    // (a wavefront per tile of the list, eight wavefronts per SIMD: the window has four times as many tiles as the list, and a
+    // launch over all of them spent more time starting wavefronts that leave at once than on the tiles with work)
+#pragma unroll 1
+    for (unsigned it = blockIdx.x * 4 + (threadIdx.x >> 6); it < nNeed; it += gridDim.x * 4) {
+    const int b = (int)B.needList[it];
     const unsigned total = B.listTotal[b];
-    if (total != 0u) {
-        // The part of every cell this scan reads.  The tile list is in the order of the block's frame table and its
-        // segments were sorted one by one, so a cell's records are [run of segment 0 | run of segment 1 | ...] with ascending
-        // frame slots from run to run: the runs of the segments that overlap [slotLo, slotHi] hold every record of the
-        // scan's own frames (and, in the two boundary runs, some of the block's other scans' frames: masked per lane).
-        const unsigned ns = (total + B4_SEG - 1) / B4_SEG, s0 = B.segBase[b];
-        unsigned kf = ns, kl = 0;
-        bool any = false;
-        for (unsigned k = 0; k < ns; ++k) {   // (wave-uniform: scalar loads)
-            const uint2 r = B.segRange[s0 + k];
-            if (r.y >= (unsigned)S.slotLo && r.x <= (unsigned)S.slotHi) {
-                kf = min(kf, k);
-                kl = k;
-                any = true;
-            }
-        }
-        // (every load below is issued whether or not its value is used: the compiler waits for a load inside the branch
-        // that holds it, and this kernel is nothing but dependent loads)
-        if (!any) kf = 0, kl = 0;
-        const unsigned base = B.cellOff[(size_t)b * 65 + lane], next = B.cellOff[(size_t)b * 65 + lane + 1];
-        const unsigned oFirst = B.segOff[(size_t)(s0 + kf) * 64 + lane];
-        const unsigned oEnd = B.segOff[(size_t)(s0 + min(kl + 1, ns - 1)) * 64 + lane];
-        const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
-        const unsigned cand = b4_cell_cand(S.cellStart, S.blockSum, B.CW, B.CHc, cx, cy);
-        const unsigned start = base + oFirst;
-        const unsigned end = kl + 1 < ns ? base + oEnd : next;
-        const unsigned n = any ? end - start : 0u;
-        const bool active = n != 0u && cand != 0u;
-        if (active) {
-            if (n >= B4_HEAVY) th = (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT;
-            else lv = n;
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            th += __shfl_xor(th, o);
-            lv += __shfl_xor(lv, o);
-        }
-        if (th + lv) S.cellRange[(size_t)b * 64 + lane] = make_uint2(start, active ? n : 0u);   // (only tiles with work are read back)
-    }
-    if (lane == 0) S.tileTasks[b] = (th << 12) | lv;   // lv <= 64 * 63
-}
-// one workgroup per scan.  An item covers (a part of) a QUAD of 2x2 tiles: the per-item costs of the join (cell table,
-// live window, barriers) are paid once for four tiles.  items = (quad, first task, end task); the full items first.
-constexpr int B4_QPT = ((B4_MAXW / 2) * (B4_MAXW / 2) + 1023) / 1024;   // quads per thread
-__device__ __forceinline__ unsigned b4_quad_tasks(const Blk &B, const unsigned *__restrict__ tileTasks, int qd, int QW) {
-    const int qx = qd % QW, qy = qd / QW;
-    unsigned th = 0, lv = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int tx = 2 * qx + (s & 1), ty = 2 * qy + (s >> 1);
-        if (tx < B.BW && ty < B.BH) {
-            const unsigned w = tileTasks[ty * B.BW + tx];
-            th += w >> 12;
-            lv += w & 4095u;
+    // The part of every cell this scan reads.  The tile list is in the order of the block's frame table and its
+    // segments were sorted one by one, so a cell's records are [run of segment 0 | run of segment 1 | ...] with ascending
+    // frame slots from run to run: the runs of the segments that overlap [slotLo, slotHi] hold every record of the
+    // scan's own frames (and, in the two boundary runs, some of the block's other scans' frames: masked per lane).
+    const unsigned ns = (total + B4_SEG - 1) / B4_SEG, s0 = B.segBase[b];
+    unsigned kf = ns, kl = 0;
+    bool any = false;
+    for (unsigned k0 = 0; k0 < ns; k0 += 64) {   // (lane = segment: one round of loads for up to 64 segments)
+        const unsigned k = k0 + (unsigned)lane;
+        const uint2 r = B.segRange[s0 + min(k, ns - 1)];
+        const unsigned long long hit = __ballot(k < ns && r.y >= (unsigned)S.slotLo && r.x <= (unsigned)S.slotHi);
+        if (hit) {
+            if (!any) kf = k0 + (unsigned)__ffsll((long long)hit) - 1u;
+            kl = k0 + 63u - (unsigned)__clzll((long long)hit);
+            any = true;
         }
     }
-    return th + (lv + B4_TASK - 1) / B4_TASK;
-}
-__global__ __launch_bounds__(1024) void b4_plan_items(Blk B, const ScanDev *__restrict__ scans) {
-    __shared__ unsigned wa[16], wb[16];
-    const ScanDev &S = scans[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int QW = (B.BW + 1) / 2, NQ = QW * ((B.BH + 1) / 2);
-    unsigned sumF = 0, sumR = 0;
-    for (int j = 0; j < B4_QPT; ++j) {
-        const int qd = tid * B4_QPT + j;
-        const unsigned t = qd < NQ ? b4_quad_tasks(B, S.tileTasks, qd, QW) : 0u;
-        sumF += t / B4_IT;
-        sumR += (t % B4_IT) ? 1u : 0u;
-    }
-    unsigned incA = sumF, incB = sumR;
+    // (every load below is issued whether or not its value is used: the compiler waits for a load inside the branch
+    // that holds it, and this kernel is nothing but dependent loads)
+    if (!any) kf = 0, kl = 0;
+    const unsigned base = B.cellOff[(size_t)b * 65 + lane], next = B.cellOff[(size_t)b * 65 + lane + 1];
+    const unsigned oFirst = B.segOff[(size_t)(s0 + kf) * 64 + lane];
+    const unsigned oEnd = B.segOff[(size_t)(s0 + min(kl + 1, ns - 1)) * 64 + lane];
+    const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
+    unsigned sa[3], sn[3];
+    b4_cell_segs(S.cellStart, S.blockSum, B.CW, B.CHc, cx, cy, sa, sn);
+    const unsigned cand = sn[0] + sn[1] + sn[2];
+    const unsigned start = base + oFirst;
+    const unsigned end = kl + 1 < ns ? base + oEnd : next;
+    const unsigned n = any ? end - start : 0u;
+    const bool active = n != 0u && cand != 0u;
+    const unsigned th = (active && n >= B4_HEAVY) ? (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT : 0u;
+    const unsigned lv = (active && n < B4_HEAVY) ? n : 0u;
+    unsigned incT = th, incL = lv;
     for (int o = 1; o < 64; o <<= 1) {
-        const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
+        const unsigned x = __shfl_up(incT, o), y = __shfl_up(incL, o);
         if (lane >= o) {
-            incA += a;
-            incB += c;
+            incT += x;
+            incL += y;
         }
     }
-    if (lane == 63) {
-        wa[w] = incA;
-        wb[w] = incB;
+    const unsigned TH = __shfl(incT, 63), LV = __shfl(incL, 63);
+    if (TH + LV == 0u) continue;
+    S.cellRange[(size_t)b * 64 + lane] = make_uint2(start, active ? n : 0u);   // (only tiles with work are read back: the light path)
+    const unsigned nL = (((LV + 63) >> 6) + 3) >> 2;   // units of four chunks (b4_join_light's B4_LCH), <= 16
+    unsigned tb = 0, lb = 0;
+    if (lane == 0) {
+        if (TH) tb = atomicAdd(&S.ctrl[0], TH);
+        if (nL) lb = atomicAdd(&S.ctrl[1], nL);
     }
-    __syncthreads();
-    unsigned baseA = 0, baseB = 0, allA = 0, allB = 0;
-    for (int k = 0; k < 16; ++k) {
-        if (k < w) {
-            baseA += wa[k];
-            baseB += wb[k];
+    tb = __shfl(tb, 0), lb = __shfl(lb, 0);
+    if ((unsigned)lane < nL && lb + lane < (unsigned)S.maxLight) S.lchunks[lb + lane] = make_uint2((unsigned)b, (unsigned)lane);
+    uint4 *out = reinterpret_cast<uint4 *>(S.tasks);
+    const unsigned first = tb + incT - th;
+    for (unsigned k = 0; k < th; ++k) {
+        const unsigned idx = first + k;
+        if (idx < (unsigned)S.maxTasks) {
+            const unsigned st = start + k * B4_TASK;
+            out[2 * (size_t)idx] = make_uint4(st, min(start + n, st + B4_TASK), sa[0], sn[0]);
+            out[2 * (size_t)idx + 1] = make_uint4(sa[1], sn[1], sa[2], sn[2]);
         }
-        allA += wa[k];
-        allB += wb[k];
     }
-    if (tid == 0) {
-        S.ctrl[0] = min(allA + allB, (unsigned)S.maxItems);
-        S.ctrl[1] = 0u;
-    }
-    unsigned fB = baseA + incA - sumF, rB = allA + baseB + incB - sumR;
-    for (int j = 0; j < B4_QPT; ++j) {
-        const int qd = tid * B4_QPT + j;
-        if (qd >= NQ) break;
-        const unsigned t = b4_quad_tasks(B, S.tileTasks, qd, QW), full = t / B4_IT;
-        for (unsigned k = 0; k < full; ++k)
-            if (fB + k < (unsigned)S.maxItems) S.items[fB + k] = make_uint4((unsigned)qd, k * B4_IT, (k + 1) * B4_IT, 0u);
-        if ((t % B4_IT) && rB < (unsigned)S.maxItems) {
-            S.items[rB] = make_uint4((unsigned)qd, full * B4_IT, t, 0u);
-            ++rB;
-        }
-        fB += full;
     }
 }
 
 // ---- join ------------------------------------------------------------------------------------------
-struct B4Shared {
-    unsigned cst[B4_W * B4_W1];          // cellStart of the window cells
-    unsigned short ctab[B4_W * B4_W1];   // live points of window row r before column cc
-    unsigned segStart[B4_W], rowBase[B4_W1];   // rowBase: of the CURRENT band (LDS index of the first live point of window row r)
-    unsigned colOff[B4_W];                     // ... live points of window row r left of the band
-    unsigned recStart[B4_NC], recN[B4_NC];     // records of the quad's cells (cell c = row * 16 + column of the quad)
-    unsigned thEnd[B4_NC];                     // one-cell tasks up to and including cell c
-    unsigned lvStart[B4_NC], lvEnd[B4_NC];     // packed (light) order: first / end virtual record of cell c
-    unsigned band[B4_NC];   // ya | yb << 5 | xa << 10 | xb << 15 | slow << 20 (cell rows / columns 1..16 of the window, inclusive)
-    unsigned wsA[4], wsB[4];
-    uint4 task[B4_IT];   // the item's one-cell tasks, decoded once: (cell, first record, end record, -)
-    unsigned nBands, ticket, TH, LV, itemId, nextId;
-    uint4 item, nextItem;
-};
-
-// traversal segment masks of one 64-record chunk: lane t keeps the lanes whose record belongs to traversal t
-__device__ __forceinline__ void b4_segmask(unsigned trv, bool valid, int T, int lq, unsigned *lo, unsigned *hi) {
-    const unsigned sel0 = (lq & 1) ? 0u : ~0u, sel1 = (lq & 2) ? 0u : ~0u;
-    const unsigned sel2 = (lq & 4) ? 0u : ~0u, sel3 = (lq & 8) ? 0u : ~0u, sel4 = (lq & 16) ? 0u : ~0u;
-    unsigned long long seg = __ballot(valid);
-    const unsigned long long B0 = __ballot(trv & 1u), B1 = __ballot(trv & 2u);
-    const unsigned long long B2 = __ballot(trv & 4u), B3 = __ballot(trv & 8u), B4 = __ballot(trv & 16u);
-    const unsigned long long s0 = ((unsigned long long)sel0 << 32) | sel0;
-    const unsigned long long s1 = ((unsigned long long)sel1 << 32) | sel1;
-    const unsigned long long s2 = ((unsigned long long)sel2 << 32) | sel2;
-    const unsigned long long s3 = ((unsigned long long)sel3 << 32) | sel3;
-    const unsigned long long s4 = ((unsigned long long)sel4 << 32) | sel4;
-    seg &= (B0 ^ s0) & (B1 ^ s1) & (B2 ^ s2) & (B3 ^ s3) & (B4 ^ s4);
-    if (T > 32) {
-        const unsigned sel5 = (lq & 32) ? 0u : ~0u;
-        seg &= __ballot(trv & 32u) ^ (((unsigned long long)sel5 << 32) | sel5);
-    }
-    *lo = (unsigned)seg;
-    *hi = (unsigned)(seg >> 32);
-}
-
 // pointers that reach a kernel through a device table are generic to the compiler (flat_load: counted against
-// the LDS counter as well, so every LDS wait also waits for them); the join states that they are global
+// the LDS counter as well, so every LDS wait also waits for them); the join states that they are global -- and, for what
+// an earlier kernel of the call wrote and this one only reads through wave-uniform addresses (task descriptors, the scan's
+// sorted live points), CONSTANT: those become scalar loads (s_load: the candidate of a pair step arrives in SGPRs)
 typedef float v4f __attribute__((ext_vector_type(4)));      // (HIP's float4 is a class: no address-space qualified copies)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #define B4_GLOBAL(T) const __attribute__((address_space(1))) T *
+#define B4_CONST(T) const __attribute__((address_space(4))) T *
+typedef __attribute__((address_space(1))) int *B4_CNT;   // the scan's counts: global atomics, no return value
+__device__ __forceinline__ void b4_count_add(B4_CNT p, int v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <typename T> __device__ __forceinline__ B4_GLOBAL(T) b4_global(const T *p) {
     return (B4_GLOBAL(T))(p);
+}
+template <typename T> __device__ __forceinline__ B4_CONST(T) b4_const(const T *p) {
+    return (B4_CONST(T))(p);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// The pair phase of a one-cell task: 2 * NP chunks of 64 records in registers against the live points [ia, ie) of
-// one window row (LDS, wave-uniform).  The chunks are held in PAIRS (v2f: chunk 2p in .x, chunk 2p+1 in .y), so that
-// v_pk_add / v_pk_mul / v_pk_fma_f32 test a candidate against two chunks per instruction.  Counts the pairs with
-// d2 < r2lo and re-tests the pairs inside the band [r2lo, r2hi] exactly (float64, scipy's predicate; practically
-// never).  Lane t adds the hits of traversal t (segment masks sLo / sHi per chunk).
 // popcount(x) + acc in ONE instruction (the compiler prefers independent popcounts and a three-operand add tree: three more
 // VALU instructions per candidate in a loop that is bound by them)
 __device__ __forceinline__ unsigned b4_bcnt(unsigned x, unsigned acc) {
@@ -688,44 +623,71 @@ __device__ __forceinline__ unsigned b4_bcnt(unsigned x, unsigned acc) {
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
     return r;
 }
+// The pair phase of a one-cell task: 2 * NP chunks of 64 records in registers against the live points [ia, ie) of the scan's
+// sorted array -- one candidate per step, read with a SCALAR load one step ahead (wave-uniform address: the point arrives in
+// SGPRs; no LDS window, no barrier).  The chunks are held in PAIRS (v2f: chunk 2p in .x, chunk 2p+1 in .y), so that
+// v_pk_add / v_pk_mul / v_pk_fma_f32 test a candidate against two chunks per instruction.  Counts the pairs with
+// d2 < r2lo and reports the pairs inside the band [r2lo, r2hi] (re-tested exactly by b4_pairs_band; practically never).
+// Lane t adds the hits of traversal t (segment masks sLo / sHi per chunk) to counts[live point][t]: one global atomic
+// instruction per (candidate, task), at most T lanes of it active.
+typedef float v8f __attribute__((ext_vector_type(8)));
+// one candidate (q: wave-uniform, in SGPRs) against the task's chunks: hit counts of this lane's traversal; ORs the pairs
+// inside the band into *band
 template <int NP>
-__device__ __forceinline__ unsigned long long b4_pairs(const float4 *__restrict__ live, unsigned *__restrict__ cntw, unsigned ia,
-                                                       unsigned ie, const v2f *hx, const v2f *hy, const v2f *hz,
-                                                       const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi, int Th,
-                                                       int lq, int T) {
-    unsigned long long band = 0;
-#pragma unroll 1
-    for (unsigned i = ia; i < ie; ++i) {
-        const float4 q = live[i];
-        const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
-        unsigned acc = 0;
+__device__ __forceinline__ unsigned b4_pair_step(float qx_, float qy_, float qz_, const v2f *hx, const v2f *hy, const v2f *hz,
+                                                 const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi,
+                                                 unsigned long long *band) {
+    const v2f qx = {qx_, qx_}, qy = {qy_, qy_}, qz = {qz_, qz_};
+    unsigned acc = 0;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const v2f dx = qx - hx[p], dy = qy - hy[p], dz = qz - hz[p];
-            v2f d2 = dx * dx;
-            d2 = __builtin_elementwise_fma(dy, dy, d2);
-            d2 = __builtin_elementwise_fma(dz, dz, d2);
-            const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
-            const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
-            band |= (hA ^ mA) | (hB ^ mB);
-            acc = b4_bcnt((unsigned)hA & sLo[2 * p], acc);
-            acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * p], acc);
-            acc = b4_bcnt((unsigned)hB & sLo[2 * p + 1], acc);
-            acc = b4_bcnt((unsigned)(hB >> 32) & sHi[2 * p + 1], acc);
-        }
-        if (lq < T && acc) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], acc << ((lq & 1) * 16));
+    for (int p = 0; p < NP; ++p) {
+        const v2f dx = qx - hx[p], dy = qy - hy[p], dz = qz - hz[p];
+        v2f d2 = dx * dx;
+        d2 = __builtin_elementwise_fma(dy, dy, d2);
+        d2 = __builtin_elementwise_fma(dz, dz, d2);
+        const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
+        const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
+        *band |= (hA ^ mA) | (hB ^ mB);
+        acc = b4_bcnt((unsigned)hA & sLo[2 * p], acc);
+        acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * p], acc);
+        acc = b4_bcnt((unsigned)hB & sLo[2 * p + 1], acc);
+        acc = b4_bcnt((unsigned)(hB >> 32) & sHi[2 * p + 1], acc);
     }
+    return acc;
+}
+template <int NP>
+__device__ __forceinline__ unsigned long long b4_pairs(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie,
+                                                       const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
+                                                       const unsigned *sHi, float r2lo, float r2hi, int lq, int T) {
+    unsigned long long band = 0;
+    if (ia >= ie) return band;
+    // two candidates per trip: ONE 32-byte scalar load a trip ahead (the run is contiguous; its last trip may read one point
+    // past the run: the array is allocated with a spare element), two independent dependency chains in the loop body
+    B4_CONST(v8f) two = (B4_CONST(v8f))(sorted);
+    v8f q = *(B4_CONST(v8f))(sorted + ia);
+#pragma unroll 1
+    for (unsigned i = ia; i < ie; i += 2) {
+        const v8f qn = *(B4_CONST(v8f))(sorted + min(i + 2, ie - 1));   // the next two candidates: in flight during this trip
+        const unsigned accA = b4_pair_step<NP>(q[0], q[1], q[2], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
+        if (lq < T && accA) b4_count_add(&counts[(size_t)__float_as_int(q[3]) * T + lq], (int)accA);
+        if (i + 1 < ie) {
+            const unsigned accB = b4_pair_step<NP>(q[4], q[5], q[6], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
+            if (lq < T && accB) b4_count_add(&counts[(size_t)__float_as_int(q[7]) * T + lq], (int)accB);
+        }
+        q = qn;
+    }
+    (void)two;
     return band;
 }
 // the pairs inside the band around r^2 (a separate pass over the task's candidates, entered practically never: its
 // float64 temporaries must not live in the registers of the loop above)
 template <int NP>
-__device__ __forceinline__ void b4_pairs_band(const float4 *__restrict__ live, unsigned *__restrict__ cntw, unsigned ia, unsigned ie,
-                                              const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
-                                              const unsigned *sHi, float r2lo, float r2hi, double r2, int Th, int lq, int T) {
+__device__ __forceinline__ void b4_pairs_band(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie, const v2f *hx,
+                                              const v2f *hy, const v2f *hz, const unsigned *sLo, const unsigned *sHi, float r2lo,
+                                              float r2hi, double r2, int lq, int T) {
 #pragma unroll 1
     for (unsigned i = ia; i < ie; ++i) {
-        const float4 q = live[i];
+        const v4f q = sorted[i];
         unsigned acc = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -739,75 +701,70 @@ __device__ __forceinline__ void b4_pairs_band(const float4 *__restrict__ live, u
             acc += __popc((unsigned)xA & sLo[2 * p]) + __popc((unsigned)(xA >> 32) & sHi[2 * p]);
             acc += __popc((unsigned)xB & sLo[2 * p + 1]) + __popc((unsigned)(xB >> 32) & sHi[2 * p + 1]);
         }
-        if (lq < T && acc) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], acc << ((lq & 1) * 16));
+        if (lq < T && acc) b4_count_add(&counts[(size_t)__float_as_int(q.w) * T + lq], (int)acc);
     }
 }
 template <int NP>
-__device__ __forceinline__ void b4_pairs_rows(const float4 *__restrict__ live, unsigned *__restrict__ cntw, const unsigned *aR,
-                                              const unsigned *nR, const v2f *hx, const v2f *hy, const v2f *hz,
-                                              const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi, double r2, int Th,
-                                              int lq, int T) {
+__device__ __forceinline__ void b4_pairs_rows(B4_CONST(v4f) sorted, B4_CNT counts, const unsigned *aR, const unsigned *nR,
+                                              const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
+                                              const unsigned *sHi, float r2lo, float r2hi, double r2, int lq, int T) {
     unsigned long long band = 0;
 #pragma unroll 1
     for (int rr = 0; rr < 3; ++rr) {
-        const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]);
-        const unsigned ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
-        band |= b4_pairs<NP>(live, cntw, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, Th, lq, T);
+        const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
+        band |= b4_pairs<NP>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, lq, T);
     }
     if (band) {
 #pragma unroll 1
         for (int rr = 0; rr < 3; ++rr) {
-            const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]);
-            const unsigned ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
-            b4_pairs_band<NP>(live, cntw, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
+            const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
+            b4_pairs_band<NP>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
         }
     }
 }
 
-// LDS pose table of a join workgroup (persistent: loaded once): 48 bytes of pose + 1 byte of traversal per frame
+constexpr int B4_JW = B4_JT / 64;   // wavefronts of a join workgroup: they share the scan's pose table and nothing else
+// LDS of a join workgroup: [pose table of the scan: 48 bytes of pose + 1 byte of traversal per union frame | per wavefront:
+// traversal masks of a task's chunks (B4_CPT x T words of 64 bits)]
 __host__ __device__ __forceinline__ unsigned b4_pose_bytes(int U) {
-    return U <= B4_POSE_LDS_MAX ? (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15)) : 0u;
+    return (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15));
 }
-
-template <bool LPOSE, bool PROF>
-__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg, unsigned long long *prof) {
+__host__ __device__ __forceinline__ unsigned b4_join_lds(int U, int T, bool lpose) {
+    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8);
+}
+// Every wavefront works on its own: a static deal of the scan's task list (wavefront w of W takes tasks w, w + W, ...),
+// no workgroup barrier after the pose table is in place, no LDS window of live points.  A workgroup is as large as a CU holds
+// wavefronts of this kernel (1024 threads at 128 registers): one pose table per CU.
+template <bool LPOSE>
+__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg) {
     extern __shared__ __align__(16) unsigned char dynsm[];
-    __shared__ B4Shared S;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int lq = lane;
     asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
     const ScanDev &SC = scans[blockIdx.y];
-    const int T = SC.T, Th = (T + 1) >> 1;
-    const unsigned liveBytes = 16u + 4u * (unsigned)Th;
-    const unsigned lcap = (unsigned)B4_LDS_DYN / liveBytes;
+    const int T = SC.T;
     const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
     const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
-    float4 *live = reinterpret_cast<float4 *>(dynsm + poseB);
-    unsigned *cntw = reinterpret_cast<unsigned *>(live + lcap);
+    unsigned long long *smask = reinterpret_cast<unsigned long long *>(dynsm + poseB) + (size_t)wv * (B4_CPT * T);
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
     B4_GLOBAL(unsigned) cellStart = b4_global(SC.cellStart);
     B4_GLOBAL(unsigned) blockOff = b4_global(SC.blockSum);   // (b4_scan_finish: offsets of the 4096-cell scan blocks)
-    B4_GLOBAL(v4f) sorted = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
+    B4_GLOBAL(v4f) sortedG = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
+    B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
     B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
     B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
-    B4_GLOBAL(unsigned) tileTasks = b4_global(SC.tileTasks);
     B4_GLOBAL(v2u) cellRange = b4_global(reinterpret_cast<const v2u *>(SC.cellRange));
-    B4_GLOBAL(v4u) items = b4_global(reinterpret_cast<const v4u *>(SC.items));
-    int *counts = SC.counts;
+    B4_CONST(v4u) tasks = b4_const(reinterpret_cast<const v4u *>(SC.tasks));
+    B4_CONST(v2u) lchunks = b4_const(reinterpret_cast<const v2u *>(SC.lchunks));
+    B4_CNT counts = (B4_CNT)(SC.counts);
     const int CW = B.CW, CHc = B.CHc;
-    const unsigned nItems = SC.ctrl[0];
-    // PROF: cycles of this wavefront by phase (0 item set-up, 1 band set-up, 2 unit fetch + decode, 3 record wait + transform +
-    // masks, 4 pair phase, 5 packed chunks, 6 wait at the end of a band, 7 flush), counts 8 items 9 bands 10 tasks 11 chunks
-    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? clock64() : 0ULL;
-#define B4_TICK(kk)                                  \
-    if (PROF) {                                      \
-        const unsigned long long now_ = clock64();   \
-        pacc[kk] += now_ - plast;                    \
-        plast = now_;                                \
-    }
+    const unsigned nH = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[0], (unsigned)SC.maxTasks));
+    const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
+    const unsigned W = gridDim.x * B4_JW;
+    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * B4_JW + (unsigned)wv));   // (wave-uniform: task descriptors and candidates are scalar loads)
 
-    if (LPOSE) {   // the scan's poses: read once per workgroup (the workgroups are persistent)
+    if (LPOSE) {   // the scan's poses: read once per workgroup
         float4 *pw = reinterpret_cast<float4 *>(dynsm);
         signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
         for (int f = tid; f < B.U; f += B4_JT) {
@@ -817,6 +774,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             pw[3 * f + 2] = make_float4(c.x, c.y, c.z, c.w);
             tw[f] = (signed char)__float_as_int(d.x);
         }
+        __syncthreads();
     }
     // one record -> the scan's frame (transform_points' float32 chain); records of frames that are not part of the scan
     // and lanes without a record end up 1e30 away, *trv < 0
@@ -850,419 +808,265 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         *hz = ok ? az : 0.f;
         *trv = ok ? t : -1;
     };
-    // a record against the live points around its cell in GLOBAL memory (bands that do not fit the LDS: never on LiDAR)
-    auto slow_walk = [&](float sx, float sy, float sz, int st, int cx, int cy) {
-        const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
-        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, CHc - 1); ++yy) {
-            const size_t ia_ = (size_t)yy * CW + xa, ie_ = (size_t)yy * CW + xb + 1;
-            const unsigned a = cellStart[ia_] + blockOff[ia_ / B4_SCAN], e = cellStart[ie_] + blockOff[ie_ / B4_SCAN];
-            for (unsigned i = a; i < e; ++i) {
-                const v4f qq = sorted[i];
-                if (pp_within(sx, sy, sz, qq.x, qq.y, qq.z, r2)) atomicAdd(&counts[(size_t)__float_as_int(qq.w) * T + st], 1);
-            }
-        }
-    };
 
-    if (tid == 0) {
-        const unsigned first = atomicAdd(&SC.ctrl[1], 1u);
-        S.itemId = first;
-        if (first < nItems) {
-            const v4u w = items[first];
-            S.item = make_uint4(w.x, w.y, w.z, w.w);
+    // ======== one-cell tasks: the records of the NEXT task are requested before the pair phase of the current one ========
+    if (!(dbg & 8)) {
+        unsigned t = w0;
+        v4u c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, n0 = {0, 0, 0, 0}, n1 = {0, 0, 0, 0};
+        v4f R[B4_CPT];
+        if (t < nH) {
+            c0 = tasks[2 * (size_t)t], c1 = tasks[2 * (size_t)t + 1];
+            const unsigned start = c0.x, end = c0.y;
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(start + u * 64 + lane, end - 1)]);
+            if (t + W < nH) n0 = tasks[2 * (size_t)(t + W)], n1 = tasks[2 * (size_t)(t + W) + 1];
+        }
+        while (t < nH) {
+            const unsigned start = c0.x, end = c0.y;
+            const int nch = (int)((end - start + 63) >> 6);
+            v2f hx[B4_CPT / 2], hy[B4_CPT / 2], hz[B4_CPT / 2];   // chunk 2p in .x, chunk 2p+1 in .y
+            unsigned sLo[B4_CPT], sHi[B4_CPT];
+            int tv[B4_CPT];
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u) {
+                float ax, ay, az;
+                xform(R[u], start + u * 64 + lane < end, &ax, &ay, &az, &tv[u]);
+                if (u & 1) hx[u / 2].y = ax, hy[u / 2].y = ay, hz[u / 2].y = az;
+                else hx[u / 2].x = ax, hy[u / 2].x = ay, hz[u / 2].x = az;
+            }
+            // traversal masks of the chunks through LDS: every record ORs its lane bit into the word of its traversal, lane t
+            // reads the word of traversal t (the LDS executes a wavefront's instructions in order; three rounds for the four
+            // chunks: clear, OR, read)
+            if (lq < T) {
+#pragma unroll
+                for (int u = 0; u < B4_CPT; ++u) smask[u * T + lq] = 0ULL;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u)
+                if (tv[u] >= 0) atomicOr(&smask[u * T + tv[u]], 1ULL << lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u) {
+                const unsigned long long mv = lq < T ? smask[u * T + lq] : 0ULL;
+                sLo[u] = (unsigned)mv;
+                sHi[u] = (unsigned)(mv >> 32);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned aR[3] = {c0.z, c1.x, c1.z}, nR[3] = {c0.w, c1.y, c1.w};
+            // the next task: its record loads are in flight during the pair phase below; the task after it: its descriptor
+            const unsigned tn = t + W;
+            if (tn < nH) {
+                const unsigned s2 = n0.x, e2 = n0.y;
+#pragma unroll
+                for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(s2 + u * 64 + lane, e2 - 1)]);
+            }
+            v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+            if (tn + W < nH) f0 = tasks[2 * (size_t)(tn + W)], f1 = tasks[2 * (size_t)(tn + W) + 1];
+            if (!(dbg & 1)) {
+                static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
+                if (nch <= 2) b4_pairs_rows<1>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+                else b4_pairs_rows<2>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+            }
+            t = tn;
+            c0 = n0, c1 = n1;
+            n0 = f0, n1 = f1;
         }
     }
-    for (;;) {
-        __syncthreads();
-        const unsigned iid = S.itemId;
-        if (iid >= nItems) break;
-        const uint4 it = S.item;   // (the header is rewritten at the end of the item only: behind the barriers below)
-        if (tid == 0) S.nextId = atomicAdd(&SC.ctrl[1], 1u);   // in flight during the loads below
-        const int qd = (int)it.x;
-        const unsigned q0 = it.y, q1 = it.z;
-        const int QW = (B.BW + 1) / 2;
-        const int tbx = (qd % QW) * 2, tby = (qd / QW) * 2;   // first tile of the quad
-        const int x0 = tbx * 8 - 1, y0 = tby * 8 - 1;
-        const int gx0 = max(x0, 0), gx1 = min(x0 + B4_W, CW);
-        // ---- (a) the window's cell table, the record offsets of the quad's cells -------------------
-        for (int e = tid; e < B4_W * B4_W1; e += B4_JT) {
-            const int r = e / B4_W1, cc = e - r * B4_W1;
-            const int gy = y0 + r;
-            unsigned val = 0;
-            if (gy >= 0 && gy < CHc) {
-                const size_t ci = (size_t)gy * CW + min(max(x0 + cc, gx0), gx1);
-                val = cellStart[ci] + blockOff[ci / B4_SCAN];
-            }
-            S.cst[e] = val;
-        }
-        {
-            static_assert(B4_JT == B4_NC, "one thread per cell of the quad");
-            const int cxq = tid & 15, cyq = tid >> 4;
-            const int tx = tbx + (cxq >> 3), ty = tby + (cyq >> 3);
-            unsigned rs = 0, rn = 0;
-            if (tx < B.BW && ty < B.BH) {
-                const int bt = ty * B.BW + tx;
-                // the plan wrote the ranges of the tiles that have work for this scan; both words are requested at once (the
-                // range of a tile without work is whatever the arena held: read, not used -- one round trip instead of two)
-                const unsigned tt = tileTasks[bt];
-                const v2u r2_ = cellRange[(size_t)bt * 64 + (cyq & 7) * 8 + (cxq & 7)];
-                rs = tt != 0u ? r2_.x : 0u;
-                rn = tt != 0u ? r2_.y : 0u;
-            }
-            S.recStart[tid] = rs;
-            S.recN[tid] = rn;
-        }
-        __syncthreads();
-        B4_TICK(12)
-        if (tid == 0 && S.nextId < nItems) {
-            const v4u w = items[S.nextId];
-            S.nextItem = make_uint4(w.x, w.y, w.z, w.w);
-        }
-        // ---- (b) tasks of the quad, window tables, bands ------------------------------------------
-        unsigned thMine, lvMine, incA, incB;
-        {
-            const int lx = (tid & 15) + 1, ly = (tid >> 4) + 1;
-            const unsigned n = S.recN[tid];
-            unsigned cand = 0;
-#pragma unroll
-            for (int r = -1; r <= 1; ++r) cand += S.cst[(ly + r) * B4_W1 + lx + 2] - S.cst[(ly + r) * B4_W1 + lx - 1];
-            const bool active = n > 0 && cand > 0, heavy = active && n >= B4_HEAVY;
-            thMine = heavy ? (((n + 63) >> 6) + B4_CPT - 1) / B4_CPT : 0u;
-            lvMine = (active && !heavy) ? n : 0u;
-            incA = thMine, incB = lvMine;
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned a = __shfl_up(incA, o), c = __shfl_up(incB, o);
-                if (lane >= o) {
-                    incA += a;
-                    incB += c;
-                }
-            }
-            if (lane == 63) {
-                S.wsA[tid >> 6] = incA;
-                S.wsB[tid >> 6] = incB;
-            }
-        }
-        if (tid == 64) {   // (a lane of the second wavefront: next to the prefix sums and the window tables of the others)
-            // bands: sub-rectangles of the quad whose live window (one cell of halo) fits the LDS budget.  Whole cell rows
-            // first; a single row that does not fit (the dense rings next to the sensor) is cut into column halves,
-            // quarters, ...; a single cell whose 3x3 neighbourhood does not fit takes the slow path.
-            auto lenr = [&](int r) { return S.cst[r * B4_W1 + B4_W] - S.cst[r * B4_W1]; };   // live points of window row r
-            auto cnt3 = [&](int ya, int xa, int xb) {   // live points of window rows ya-1..ya+1, columns xa-1..xb+1
-                unsigned c = 0;
-                for (int r = ya - 1; r <= ya + 1; ++r) c += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
-                return c;
-            };
-            unsigned nb = 0;
-            int ya = 1;
-            while (ya <= B4_QC) {
-                unsigned sum = lenr(ya - 1) + lenr(ya) + lenr(ya + 1);
-                if (sum <= lcap) {
-                    int yb = ya;
-                    while (yb < B4_QC) {
-                        const unsigned nx = lenr(yb + 2);
-                        if (sum + nx > lcap) break;
-                        sum += nx;
-                        ++yb;
-                    }
-                    S.band[nb++] = (unsigned)ya | ((unsigned)yb << 5) | (1u << 10) | ((unsigned)B4_QC << 15);
-                    ya = yb + 1;
-                    continue;
-                }
-                int xa = 1, w = B4_QC / 2;   // pieces of width w (a power of two), left to right, as wide as fits
-                while (xa <= B4_QC) {
-                    while (w > 1 && (((xa - 1) & (w - 1)) != 0 || cnt3(ya, xa, xa + w - 1) > lcap)) w >>= 1;
-                    const bool fits = cnt3(ya, xa, xa + w - 1) <= lcap;
-                    S.band[nb++] = (unsigned)ya | ((unsigned)ya << 5) | ((unsigned)xa << 10) | ((unsigned)(xa + w - 1) << 15) |
-                                   (fits ? 0u : 1u << 20);
-                    xa += w;
-                    w = B4_QC / 2;
-                }
-                ++ya;
-            }
-            S.nBands = nb;
-        }
-        for (int e = tid; e < B4_W * B4_W1; e += B4_JT) {
-            const int r = e / B4_W1;
-            S.ctab[e] = (unsigned short)min(S.cst[e] - S.cst[r * B4_W1], 65535u);
-            if (e == r * B4_W1) S.segStart[r] = S.cst[e];
-        }
-        __syncthreads();
-        B4_TICK(13)
-        {
-            unsigned bA = 0, bB = 0;
-            for (int k = 0; k < (tid >> 6); ++k) {
-                bA += S.wsA[k];
-                bB += S.wsB[k];
-            }
-            S.thEnd[tid] = bA + incA;
-            S.lvStart[tid] = bB + incB - lvMine;
-            S.lvEnd[tid] = bB + incB;
-            if (tid == B4_JT - 1) {
-                S.TH = bA + incA;
-                S.LV = bB + incB;
-            }
-        }
-        __syncthreads();
-        B4_TICK(14)
-        const unsigned TH = S.TH, LV = S.LV;
-        const unsigned nBands = S.nBands;
-        // the item's units: one-cell tasks [qh0, qh1) and 64-record chunks of the packed order [l0, l1)
-        const unsigned qh0 = min(q0, TH), qh1 = min(q1, TH), nH = qh1 - qh0;
-        const unsigned l0 = (max(q0, TH) - TH) * B4_TASK, l1 = min(LV, (max(q1, TH) - TH) * B4_TASK);
-        const unsigned nUnits = nH + (l1 > l0 ? (l1 - l0 + 63) / 64 : 0u);
-        if (tid < (int)nH) {   // every task decoded once, in parallel: first cell whose task count (inclusive prefix) exceeds q
-            const unsigned q = qh0 + tid;
-            int lo = 0, hi = B4_NC - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (S.thEnd[mid] > q) hi = mid;
-                else lo = mid + 1;
-            }
-            const unsigned cbeg = S.recStart[lo], cn = S.recN[lo];
-            const unsigned nt = (((cn + 63) >> 6) + B4_CPT - 1) / B4_CPT;   // tasks of the cell
-            const unsigned st = cbeg + (q - (S.thEnd[lo] - nt)) * B4_TASK;
-            S.task[tid] = make_uint4((unsigned)lo, st, min(cbeg + cn, st + B4_TASK), 0u);
-        }
-        B4_TICK(0)
-        if (PROF) ++pacc[8];
-        for (unsigned bd = 0; bd < nBands; ++bd) {
-            if (PROF) ++pacc[9];
-            const unsigned bw = S.band[bd];
-            const int ya = (int)(bw & 31u), yb = (int)((bw >> 5) & 31u);   // cell rows / columns of the band (window coordinates 1..16)
-            const int xa = (int)((bw >> 10) & 31u), xb = (int)((bw >> 15) & 31u);
-            const bool slow = (bw >> 20) != 0;
-            if (bd > 0) __syncthreads();   // previous band's flush complete (the item's first band: the barriers of the set-up)
-            if (tid <= yb - ya + 2) {   // rows ya-1 .. yb+1 of the window, columns xa-1 .. xb+1
-                unsigned run = 0;
-                for (int r = ya - 1; r < ya - 1 + tid; ++r) run += S.cst[r * B4_W1 + xb + 2] - S.cst[r * B4_W1 + xa - 1];
-                const int r = ya - 1 + tid;
-                S.rowBase[r] = run;
-                S.colOff[r] = S.cst[r * B4_W1 + xa - 1] - S.cst[r * B4_W1];
-            }
-            __syncthreads();
-            const unsigned Lb = slow ? 0u : S.rowBase[yb + 1] + (S.cst[(yb + 1) * B4_W1 + xb + 2] - S.cst[(yb + 1) * B4_W1 + xa - 1]);
-            if (!slow) {
-                for (unsigned e = tid; e < Lb; e += B4_JT) {
-                    int r = ya - 1;
-                    while (r < yb + 1 && e >= S.rowBase[r + 1]) ++r;
-                    const v4f w = sorted[S.segStart[r] + S.colOff[r] + (e - S.rowBase[r])];
-                    live[e] = make_float4(w.x, w.y, w.z, w.w);
-                }
-                for (unsigned e = tid; e < Lb * Th; e += B4_JT) cntw[e] = 0;
-            }
-            if (tid == 0) S.ticket = 0;
-            __syncthreads();
+}
 
-            // ---- the tasks of the item, dealt to the wavefronts.  The records of a wavefront's NEXT one-cell task are
-            // requested before the pair phase of the current one: the loads overlap the pair phase ----------------
-            int ty = 0, k = 0;   // ty: 0 no unit left, 1 one-cell task (records requested), 2 a chunk of the packed order, 3 not in this band
-            unsigned start = 0, end = 0, v0 = 0, v1 = 0;
-            v4f R[B4_CPT];
-            unsigned tnext = (unsigned)tid >> 6;   // units are dealt round robin to the wavefronts (no ticket: a returning LDS
-            auto prep = [&]() {                     // atomic per unit is a latency of its own in a loop that is all latency)
-                const unsigned t = __builtin_amdgcn_readfirstlane(tnext);
-                tnext += B4_JT / 64;
-                ty = 0;
-                if (t >= nUnits) return;
-                if (t >= nH) {   // a chunk of the packed order
-                    ty = 2;
-                    v0 = l0 + (t - nH) * 64u;
-                    v1 = min(l1, v0 + 64u);
-                    if (dbg & 2) v1 = v0;
-                    return;
-                }
-                const uint4 tk4 = S.task[t];
-                k = __builtin_amdgcn_readfirstlane((int)tk4.x);
-                const int lcx = (k & 15) + 1, lcy = (k >> 4) + 1;
-                ty = 3;
-                if (lcy < ya || lcy > yb || lcx < xa || lcx > xb) return;
-                ty = 1;
-                start = __builtin_amdgcn_readfirstlane(tk4.y);
-                end = __builtin_amdgcn_readfirstlane(tk4.z);
-                if (dbg & 8) end = start;
-                if (!slow && end > start) {   // (a lane without a record re-reads the last one: no load sits inside a branch)
-#pragma unroll
-                    for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(start + u * 64 + lane, end - 1)]);
-                }
-            };
-            B4_TICK(1)
-            prep();
-            B4_TICK(2)
-            while (ty != 0) {
-                if (ty == 1) {
-                    const int lcx = (k & 15) + 1, lcy = (k >> 4) + 1;
-                    if (end <= start) {
-                        prep();
-                        continue;
-                    }
-                    if (slow) {
-                        const int cx = tbx * 8 + (k & 15), cy = tby * 8 + (k >> 4);
-                        for (unsigned ib = start; ib < end; ib += 64) {
-                            float sx, sy, sz;
-                            int st;
-                            xform(rec[min(ib + lane, end - 1)], ib + lane < end, &sx, &sy, &sz, &st);
-                            if (st >= 0) slow_walk(sx, sy, sz, st, cx, cy);
-                        }
-                        prep();
-                        continue;
-                    }
-                    const int nch = (int)((end - start + 63) >> 6);
-                    v2f hx[B4_CPT / 2], hy[B4_CPT / 2], hz[B4_CPT / 2];   // chunk 2p in .x, chunk 2p+1 in .y
-                    unsigned sLo[B4_CPT], sHi[B4_CPT];
-                    int lqm = lane;
-                    asm volatile("" : "+v"(lqm));   // (per task: hoisted out of the loops, the mask constants are six registers that spill)
-#pragma unroll
-                    for (int u = 0; u < B4_CPT; ++u) {
-                        int tv;
-                        float ax, ay, az;
-                        xform(R[u], start + u * 64 + lane < end, &ax, &ay, &az, &tv);
-                        if (u & 1) hx[u / 2].y = ax, hy[u / 2].y = ay, hz[u / 2].y = az;
-                        else hx[u / 2].x = ax, hy[u / 2].x = ay, hz[u / 2].x = az;
-                        b4_segmask((unsigned)tv & 63u, tv >= 0, T, lqm, &sLo[u], &sHi[u]);
-                    }
-                    const unsigned short *row = S.ctab + (lcy - 1) * B4_W1 + lcx - 1;
-                    const unsigned c00 = row[0], c03 = row[3], c10 = row[B4_W1], c13 = row[B4_W1 + 3];
-                    const unsigned c20 = row[2 * B4_W1], c23 = row[2 * B4_W1 + 3];
-                    const unsigned aR[3] = {S.rowBase[lcy - 1] + c00 - S.colOff[lcy - 1], S.rowBase[lcy] + c10 - S.colOff[lcy],
-                                            S.rowBase[lcy + 1] + c20 - S.colOff[lcy + 1]};
-                    const unsigned nR[3] = {c03 - c00, c13 - c10, c23 - c20};
-                    B4_TICK(3)
-                    if (PROF) ++pacc[10];
-                    prep();   // the next task: its record loads are in flight during the pair phase below
-                    B4_TICK(2)
-                    if (!(dbg & 1)) {
-                        static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
-                        if (nch <= 2) b4_pairs_rows<1>(live, cntw, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
-                        else b4_pairs_rows<2>(live, cntw, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, Th, lq, T);
-                    }
-                    B4_TICK(4)
-                    continue;
-                }
-                if (ty == 3) {
-                    prep();
-                    B4_TICK(2)
-                    continue;
-                }
-                // ======== a chunk of the packed records of sparse cells: every lane walks its own candidates ========
-                do {
-                    const unsigned vb = v0, ve = v1;
-                    if (PROF) ++pacc[11];
-                    if (ve <= vb) break;
-                    const unsigned v = vb + lane;
-                    const bool valid = v < ve;
-                    int kc = 0;
-                    if (valid) {   // first cell whose end lies behind v (cells outside the packed order have no extent)
-                        int lo = 0, hi = B4_NC - 1;
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (S.lvEnd[mid] > v) hi = mid;
-                            else lo = mid + 1;
-                        }
-                        kc = lo;
-                    }
-                    const int lx = (kc & 15) + 1, ly = (kc >> 4) + 1;
-                    const bool inband = valid && ly >= ya && ly <= yb && lx >= xa && lx <= xb;
-                    if (!__any(inband)) break;
-                    float hx, hy, hz;
-                    int trv;
-                    xform(rec[S.recStart[kc] + (valid ? v - S.lvStart[kc] : 0u)], inband, &hx, &hy, &hz, &trv);
-                    const bool on = trv >= 0;
-                    if (slow) {
-                        if (on) slow_walk(hx, hy, hz, trv, tbx * 8 + (kc & 15), tby * 8 + (kc >> 4));
-                        break;
-                    }
-                    const unsigned short *row = S.ctab + (ly - 1) * B4_W1 + lx - 1;
-                    const unsigned c00 = row[0], c10 = row[B4_W1], c20 = row[2 * B4_W1];
-                    const unsigned n0 = row[3] - c00, n1 = row[B4_W1 + 3] - c10, n2 = row[2 * B4_W1 + 3] - c20;
-                    const int lyc = inband ? ly : ya;   // (lanes outside the band read the band's own tables)
-                    const unsigned a0 = S.rowBase[lyc - 1] + c00 - S.colOff[lyc - 1];
-                    const unsigned n01 = n0 + n1, nAll = n01 + n2;
-                    const unsigned b1 = S.rowBase[lyc] + c10 - S.colOff[lyc] - n0;
-                    const unsigned b2 = S.rowBase[lyc + 1] + c20 - S.colOff[lyc + 1] - n01;
-                    const bool mine = on && nAll <= B4_LANE_MAX;
-                    const unsigned own = mine ? nAll : 0u;
-                    const unsigned cword = ((unsigned)trv & 63u) >> 1, cinc = 1u << ((trv & 1) * 16);
-                    for (unsigned p0 = 0; __any(p0 < own); p0 += 2) {
-                        unsigned bandBits = 0;
-#pragma unroll
-                        for (unsigned u = 0; u < 2; ++u) {
-                            const unsigned p = p0 + u;
-                            const bool act = p < own;
-                            const unsigned i = act ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u;
-                            const float4 qq = live[i];
-                            const float fx = qq.x - hx, fy = qq.y - hy, fz = qq.z - hz;
-                            const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                            const bool hit = act && d2 < r2lo;
-                            bandBits |= (act && !hit && d2 <= r2hi) ? (1u << u) : 0u;
-                            if (hit) atomicAdd(&cntw[i * Th + cword], cinc);
-                        }
-                        while (bandBits) {   // practically never: exact float64 re-test
-                            const unsigned u = __ffs((int)bandBits) - 1;
-                            bandBits &= bandBits - 1;
-                            const unsigned p = p0 + u;
-                            const unsigned i = p + (p < n0 ? a0 : (p < n01 ? b1 : b2));
-                            const float4 qq = live[i];
-                            if (pp_within(hx, hy, hz, qq.x, qq.y, qq.z, r2)) atomicAdd(&cntw[i * Th + cword], cinc);
-                        }
-                    }
-                    // lanes with long candidate lists: one cell group at a time, wave-uniform candidates
-                    unsigned long long todo = __ballot(on && !mine);
-                    if (todo) {
-                        unsigned sLo, sHi;
-                        b4_segmask((unsigned)trv & 63u, on, T, lq, &sLo, &sHi);
-                        while (todo) {
-                            const int src = __ffsll((long long)todo) - 1;
-                            const int gk = __builtin_amdgcn_readlane(kc, src);
-                            const unsigned long long grp = __ballot(on && !mine && kc == gk);
-                            todo &= ~grp;
-                            const unsigned ga0 = __builtin_amdgcn_readlane(a0, src), gn0 = __builtin_amdgcn_readlane(n0, src);
-                            const unsigned gb1 = __builtin_amdgcn_readlane(b1, src), gn01 = __builtin_amdgcn_readlane(n01, src);
-                            const unsigned gb2 = __builtin_amdgcn_readlane(b2, src), gnAll = __builtin_amdgcn_readlane(nAll, src);
-                            for (unsigned p = 0; p < gnAll; ++p) {
-                                const unsigned i = p + (p < gn0 ? ga0 : (p < gn01 ? gb1 : gb2));
-                                const float4 qq = live[i];
-                                const float fx = qq.x - hx, fy = qq.y - hy, fz = qq.z - hz;
-                                const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                                unsigned long long hb = __ballot(d2 < r2lo) & grp;
-                                const unsigned long long mb = __ballot(d2 <= r2hi) & grp;
-                                if (hb != mb) {
-                                    const bool inBand = !(d2 < r2lo) && d2 <= r2hi;
-                                    hb |= __ballot(inBand && pp_within(hx, hy, hz, qq.x, qq.y, qq.z, r2)) & grp;
-                                }
-                                if (hb) {
-                                    const unsigned cN = __popc((unsigned)hb & sLo) + __popc((unsigned)(hb >> 32) & sHi);
-                                    if (lane < T && cN) atomicAdd(&cntw[i * Th + ((unsigned)lq >> 1)], cN << ((lq & 1) * 16));
-                                }
-                            }
-                        }
-                    }
-                } while (false);
-                B4_TICK(5)
-                prep();   // (after the chunk: requested records of a one-cell task would live across the walk)
-                B4_TICK(2)
-            }
-            B4_TICK(5)
-            __syncthreads();
-            B4_TICK(6)
-            if (!slow)
-                for (unsigned e = tid; e < Lb * Th; e += B4_JT) {
-                    const unsigned cw = cntw[e];
-                    if (cw) {
-                        const unsigned pp = e / Th, tp = (e - pp * Th) * 2;
-                        const size_t rowi = (size_t)__float_as_int(live[pp].w) * T;
-                        if (cw & 0xffffu) atomicAdd(&counts[rowi + tp], (int)(cw & 0xffffu));
-                        if (cw >> 16) atomicAdd(&counts[rowi + tp + 1], (int)(cw >> 16));
-                    }
-                }
+// ======== the packed records of sparse cells, 64 at a time: every lane walks its own candidates ========
+// A kernel of its own: this path is a chain of dependent loads (cell table of the tile -> record -> pose -> live points)
+// with little arithmetic.  Eight wavefronts per SIMD (64 registers) hide one another's round trips, which the one-cell
+// tasks' kernel (128 registers) cannot; a unit is up to four chunks of ONE tile, so that the tile's cell table and the live
+// points of its window (8x8 cells + one cell of halo: ten runs of the sorted array, copied to LDS) are fetched once for them;
+// the scan's pose table sits in LDS as in b4_join.
+constexpr unsigned B4_LWIN = 128;   // live points of a tile's window kept in LDS per wavefront (more: read from memory)
+constexpr int B4_LCH = 4;           // chunks per unit
+__host__ __device__ __forceinline__ unsigned b4_light_lds(int U, bool lpose) {
+    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (64 * 4 + B4_LWIN * 16);
+}
+template <bool LPOSE>
+__global__ __launch_bounds__(B4_JT, 8) void b4_join_light(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg) {
+    extern __shared__ __align__(16) unsigned char dynsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const ScanDev &SC = scans[blockIdx.y];
+    const int T = SC.T;
+    const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
+    const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
+    const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
+    unsigned *lsearch = reinterpret_cast<unsigned *>(dynsm + poseB) + wv * 64;
+    float4 *lwin = reinterpret_cast<float4 *>(dynsm + poseB + (size_t)B4_JW * 64 * 4) + (size_t)wv * B4_LWIN;
+    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    B4_GLOBAL(unsigned) cellStart = b4_global(SC.cellStart);
+    B4_GLOBAL(unsigned) blockOff = b4_global(SC.blockSum);
+    B4_GLOBAL(v4f) sortedG = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
+    B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
+    B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
+    B4_GLOBAL(v2u) cellRange = b4_global(reinterpret_cast<const v2u *>(SC.cellRange));
+    B4_CONST(v2u) lchunks = b4_const(reinterpret_cast<const v2u *>(SC.lchunks));
+    B4_CNT counts = (B4_CNT)(SC.counts);
+    const int CW = B.CW, CHc = B.CHc;
+    const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
+    const unsigned W = gridDim.x * B4_JW;
+    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * B4_JW + (unsigned)wv));
+    if (LPOSE) {   // the scan's poses: read once per workgroup
+        float4 *pw = reinterpret_cast<float4 *>(dynsm);
+        signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
+        for (int f = tid; f < B.U; f += B4_JT) {
+            const v4f a = pose[4 * (size_t)f], b = pose[4 * (size_t)f + 1], c = pose[4 * (size_t)f + 2], d = pose[4 * (size_t)f + 3];
+            pw[3 * f] = make_float4(a.x, a.y, a.z, a.w);
+            pw[3 * f + 1] = make_float4(b.x, b.y, b.z, b.w);
+            pw[3 * f + 2] = make_float4(c.x, c.y, c.z, c.w);
+            tw[f] = (signed char)__float_as_int(d.x);
         }
-        B4_TICK(7)
-        if (tid == 0) {
-            S.itemId = S.nextId;
-            S.item = S.nextItem;
+        __syncthreads();
+    }
+    if (dbg & 2) return;
+#pragma unroll 1
+    for (unsigned id = w0; id < nL; id += W) {
+        const v2u ck = lchunks[id];
+        const int b = (int)ck.x;
+        const v2u cr = cellRange[(size_t)b * 64 + lane];   // lane = cell of the tile
+        const unsigned lv = (cr.y > 0u && cr.y < B4_HEAVY) ? cr.y : 0u;
+        const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
+        unsigned sa[3], sn[3];
+        {
+            const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = cy + dy;
+                const bool in = yy >= 0 && yy < CHc;
+                const size_t ia_ = (size_t)(in ? yy : cy) * CW + xa, ie_ = (size_t)(in ? yy : cy) * CW + xb + 1;
+                const unsigned s_ = cellStart[ia_] + blockOff[ia_ / B4_SCAN], e_ = cellStart[ie_] + blockOff[ie_ / B4_SCAN];
+                sa[dy + 1] = s_;
+                sn[dy + 1] = in ? e_ - s_ : 0u;
+            }
+        }
+        // the window's ten rows: lane r < 10 holds row r (first live point in the sorted array, length)
+        unsigned rowG = 0, rowN = 0;
+        {
+            const int r = min(lane, 9);
+            const int yy = (b / B.BW) * 8 - 1 + r;
+            const int xlo = max((b % B.BW) * 8 - 1, 0), xhi = min((b % B.BW) * 8 + 8, CW - 1);
+            const bool in = yy >= 0 && yy < CHc && lane < 10;
+            const size_t ia_ = (size_t)(in ? yy : 0) * CW + xlo, ie_ = (size_t)(in ? yy : 0) * CW + xhi + 1;
+            const unsigned s_ = cellStart[ia_] + blockOff[ia_ / B4_SCAN], e_ = cellStart[ie_] + blockOff[ie_ / B4_SCAN];
+            rowG = s_;
+            rowN = in ? e_ - s_ : 0u;
+        }
+        unsigned inc = lv;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned x = __shfl_up(inc, o);
+            if (lane >= o) inc += x;
+        }
+        const unsigned LV = __shfl(inc, 63);
+        unsigned rowInc = rowN;
+        for (int o = 1; o < 16; o <<= 1) {
+            const unsigned x = __shfl_up(rowInc, o);
+            if (lane >= o) rowInc += x;
+        }
+        const unsigned L = __shfl(rowInc, 9);
+        const bool inLds = L <= B4_LWIN;
+        const unsigned rowDelta = (rowInc - rowN) - rowG;   // LDS index = index in the sorted array + delta of its window row
+        __builtin_amdgcn_wave_barrier();   // (the previous unit of this wavefront has been walked by every lane)
+        lsearch[lane] = inc;   // end of cell `lane` in the packed order
+        if (inLds) {
+#pragma unroll 1
+            for (int r = 0; r < 10; ++r) {
+                const unsigned g = __builtin_amdgcn_readlane(rowG, r), nr = __builtin_amdgcn_readlane(rowN, r);
+                const unsigned d = __builtin_amdgcn_readlane(rowDelta, r);
+                for (unsigned e = lane; e < nr; e += 64) {
+                    const v4f w = sortedG[g + e];
+                    lwin[g + e + d] = make_float4(w.x, w.y, w.z, w.w);
+                }
+            }
+            // a cell's three candidate runs as LDS indices: the window row of cell row (lane >> 3) + dy is (lane >> 3) + dy + 1
+#pragma unroll
+            for (int d3 = 0; d3 < 3; ++d3) sa[d3] += __shfl(rowDelta, (lane >> 3) + d3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned vEnd = (dbg & 64) ? 0u : min(LV, (ck.y + 1u) * (64u * B4_LCH));
+#pragma unroll 1
+        for (unsigned vb = ck.y * (64u * B4_LCH); vb < vEnd; vb += 64) {
+            const unsigned v = vb + (unsigned)lane;
+            const bool valid = v < LV;
+            int kc = 0;
+            if (valid) {   // first cell whose end lies behind v (cells outside the packed order have no extent)
+                int lo = 0, hi = 63;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (lsearch[mid] > v) hi = mid;
+                    else lo = mid + 1;
+                }
+                kc = lo;
+            }
+            // the cell's table row lives in lane kc's registers
+            const unsigned kEnd = __shfl(inc, kc), kLv = __shfl(lv, kc), kRec = __shfl(cr.x, kc);
+            const unsigned a0 = __shfl(sa[0], kc), n0 = __shfl(sn[0], kc), a1 = __shfl(sa[1], kc), n1 = __shfl(sn[1], kc);
+            const unsigned a2 = __shfl(sa[2], kc), n2 = __shfl(sn[2], kc);
+            const v4f R = rec[valid ? kRec + (v - (kEnd - kLv)) : 0u];
+            const int slot = __float_as_int(R.w) >> 6;
+            float4 p0, p1, p2;
+            int tp;
+            if (LPOSE) {
+                p0 = poseL[3 * slot], p1 = poseL[3 * slot + 1], p2 = poseL[3 * slot + 2];
+                tp = travL[slot];
+            } else {
+                const v4f a = pose[4 * (size_t)slot], bq = pose[4 * (size_t)slot + 1], c = pose[4 * (size_t)slot + 2];
+                p0 = make_float4(a.x, a.y, a.z, a.w), p1 = make_float4(bq.x, bq.y, bq.z, bq.w), p2 = make_float4(c.x, c.y, c.z, c.w);
+                tp = __float_as_int(pose[4 * (size_t)slot + 3].x);
+            }
+            float hx = R.x * p0.x;
+            hx = fmaf(R.y, p0.y, hx);
+            hx = fmaf(R.z, p0.z, hx);
+            hx = hx + p0.w;
+            float hy = R.x * p1.x;
+            hy = fmaf(R.y, p1.y, hy);
+            hy = fmaf(R.z, p1.z, hy);
+            hy = hy + p1.w;
+            float hz = R.x * p2.x;
+            hz = fmaf(R.y, p2.y, hz);
+            hz = fmaf(R.z, p2.z, hz);
+            hz = hz + p2.w;
+            const bool on = valid && tp >= 0;   // (a NaN coordinate -- remove_center -- passes no test below)
+            const unsigned n01 = n0 + n1, nAll = n01 + n2;
+            const unsigned b1 = a1 - n0, b2 = a2 - n01;
+            const unsigned own = (on && !(dbg & 16)) ? nAll : 0u;
+            const size_t crow = (size_t)(on ? tp : 0);
+            for (unsigned p0_ = 0; __any(p0_ < own); p0_ += 4) {
+                float4 qq[4];
+                bool act[4];
+                if (inLds) {
+#pragma unroll
+                    for (unsigned u = 0; u < 4; ++u) {
+                        const unsigned p = p0_ + u;
+                        act[u] = p < own;
+                        qq[u] = lwin[act[u] ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u];
+                    }
+                } else {
+#pragma unroll
+                    for (unsigned u = 0; u < 4; ++u) {   // four candidates per step: four loads in flight
+                        const unsigned p = p0_ + u;
+                        act[u] = p < own;
+                        const v4f w = sortedG[act[u] ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u];
+                        qq[u] = make_float4(w.x, w.y, w.z, w.w);
+                    }
+                }
+#pragma unroll
+                for (unsigned u = 0; u < 4; ++u) {
+                    const float fx = qq[u].x - hx, fy = qq[u].y - hy, fz = qq[u].z - hz;
+                    const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                    bool hit = act[u] && d2 < r2lo;
+                    if (act[u] && !hit && d2 <= r2hi) hit = pp_within(hx, hy, hz, qq[u].x, qq[u].y, qq[u].z, r2);   // practically never: exact float64 re-test
+                    if (hit && !(dbg & 32)) b4_count_add(&counts[(size_t)__float_as_int(qq[u].w) * T + crow], 1);
+                }
+            }
         }
     }
-    if (PROF && lane == 0)
-        for (int kk = 0; kk < 16; ++kk) atomicAdd(&prof[kk], pacc[kk]);
-#undef B4_TICK
 }
 
 __global__ void b4_entropy(const ScanDev *__restrict__ scans) {
@@ -1340,7 +1144,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const int NC = CW * CHc, NCpad = (NC + B4_SCAN - 1) / B4_SCAN * B4_SCAN, nScanBlk = NCpad / B4_SCAN;
     const int NG = (U + B4_FG - 1) / B4_FG;
     const size_t maxSegs = (size_t)BT + (size_t)(ntot / B4_SEG) + 1;
-    const size_t maxItems = (size_t)(ntot / (B4_TASK * B4_IT)) + (size_t)(ntot / (64 * B4_IT)) + 2 * (size_t)BT + 16;
+    // a cell with n >= 64 records of the scan gives ceil(ceil(n / 64) / 4) <= n / 64 tasks; one packed entry per tile
+    const size_t maxTasks = (size_t)(ntot / 64) + 16, maxLight = (size_t)(ntot / 64) + (size_t)BT + 16;
 
     // ---- arena ------------------------------------------------------------------------------------
     size_t need = 0;
@@ -1353,22 +1158,22 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oTotal = take((size_t)BT * 4), oBase = take((size_t)BT * 4), oSegBase = take((size_t)BT * 4);
     const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
     const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256), oSegRange = take(maxSegs * 8);
-    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8);
+    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8), oNeed = take((size_t)BT * 4);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
-        size_t cellStart, blockSum, tileTasks, ctrl, tmp, sorted, items, counts, cellRange;
+        size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, lchunks, counts, cellRange;
     };
     std::vector<ScanOff> so((size_t)G);
     for (int s = 0; s < G; ++s) {
         const int n = scans[s].n;
         so[(size_t)s].cellStart = take((size_t)(NCpad + 4) * 4);
         so[(size_t)s].blockSum = take((size_t)(nScanBlk + 1) * 4);
-        so[(size_t)s].tileTasks = take((size_t)BT * 4);
         so[(size_t)s].ctrl = take(256);
         so[(size_t)s].tmp = take((size_t)std::max(n, 1) * 16);
-        so[(size_t)s].sorted = take((size_t)std::max(n, 1) * 16);
-        so[(size_t)s].items = take(maxItems * 16);
+        so[(size_t)s].sorted = take((size_t)(std::max(n, 1) + 2) * 16);   // (b4_pairs reads candidates in pairs: up to one point past a run)
+        so[(size_t)s].tasks = take(maxTasks * sizeof(B4Task));
+        so[(size_t)s].lchunks = take(maxLight * sizeof(uint2));
         so[(size_t)s].counts = take((size_t)std::max(n, 1) * T * 4);
         so[(size_t)s].cellRange = take((size_t)BT * 64 * 8);
     }
@@ -1415,11 +1220,11 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.cellCount = reinterpret_cast<unsigned *>(base + oCellCount) + (size_t)s * (NCpad + 4);
         d.cellStart = reinterpret_cast<unsigned *>(base + o.cellStart);
         d.blockSum = reinterpret_cast<unsigned *>(base + o.blockSum);
-        d.tileTasks = reinterpret_cast<unsigned *>(base + o.tileTasks);
         d.ctrl = reinterpret_cast<unsigned *>(base + o.ctrl);
         d.tmp = reinterpret_cast<float4 *>(base + o.tmp);
         d.sorted = reinterpret_cast<float4 *>(base + o.sorted);
-        d.items = reinterpret_cast<uint4 *>(base + o.items);
+        d.tasks = base + o.tasks;
+        d.lchunks = reinterpret_cast<uint2 *>(base + o.lchunks);
         d.cellRange = reinterpret_cast<uint2 *>(base + o.cellRange);
         d.pose = reinterpret_cast<const PoseEnt *>(dstage + stPose) + (size_t)s * std::max(U, 1);
         d.counts = sc.counts_dev ? sc.counts_dev : reinterpret_cast<int *>(base + o.counts);
@@ -1430,7 +1235,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.TX0 = sc.TX0;
         d.TY0 = sc.TY0;
         d.T = T;
-        d.maxItems = (int)maxItems;
+        d.maxTasks = (int)maxTasks;
+        d.maxLight = (int)maxLight;
         PoseEnt *pe = hp + (size_t)s * std::max(U, 1);
         d.slotLo = U, d.slotHi = -1;
         for (int m = 0; m < sc.n_members; ++m) {
@@ -1464,6 +1270,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     B.segRange = reinterpret_cast<uint2 *>(base + oSegRange);
     B.ctrl = reinterpret_cast<unsigned *>(base + oCtrl);
     B.baseSum = reinterpret_cast<unsigned *>(base + oBaseSum);
+    B.needList = reinterpret_cast<unsigned *>(base + oNeed);
     B.recA = reinterpret_cast<float4 *>(base + oRecA);
     B.recB = reinterpret_cast<float4 *>(base + oRecB);
     B.U = U, B.NG = NG, B.nchunks = (int)nch, B.maxSegs = (int)maxSegs;
@@ -1475,13 +1282,14 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     if (!attr_done[ctx->device & 63]) {
         MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_seg_scatter),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, B4_SEG * 16));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_DYN));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_DYN));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             B4_LDS_DYN + (int)b4_pose_bytes(B4_POSE_LDS_MAX)));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)b4_join_lds(B4_POSE_LDS_MAX, B4_MAXT, true)));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)b4_join_lds(0, B4_MAXT, false)));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join_light<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)b4_light_lds(B4_POSE_LDS_MAX, true)));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join_light<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)b4_light_lds(0, false)));
         attr_done[ctx->device & 63] = true;
     }
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
@@ -1501,29 +1309,22 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         b4_scan_local<<<dim3((unsigned)nScanBlk, (unsigned)G), 1024, 0, stream>>>(B, dsc);
         b4_scan_finish<<<(unsigned)G, 1024, 0, stream>>>(B, dsc);
         b4_live_scatter<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(B, dsc);
-        b4_plan_tiles<<<dim3((unsigned)((BT + 3) / 4), (unsigned)G), 256, 0, stream>>>(B, dsc);
-        b4_plan_items<<<(unsigned)G, 1024, 0, stream>>>(B, dsc);
+        b4_plan<<<dim3(std::max(8u, (unsigned)(8 * ctx->num_cus) / (unsigned)G), (unsigned)G), 256, 0, stream>>>(B, dsc);
         const char *jw_env = getenv("MODEST_PP4_JWG");
-        unsigned jx = (unsigned)((jw_env ? atoi(jw_env) : (B4_JT >= 512 ? 2 : 4)) * ctx->num_cus) / (unsigned)G;
-        if (jx < 8) jx = 8;
-        const char *dbg_env = getenv("MODEST_PP4_DBG");
+        unsigned jx = (unsigned)((jw_env ? atoi(jw_env) : 1) * ctx->num_cus) / (unsigned)G;   // one workgroup of 16 wavefronts per CU
+        if (jx < 2) jx = 2;
+        const char *dbg_env = getenv("MODEST_PP4_DBG");   // ablations: 1 no pair loop, 2 no packed chunks, 8 no one-cell tasks
         const int dbg = dbg_env ? atoi(dbg_env) : 0;
-        const unsigned poseB = b4_pose_bytes(U);
-        if (dbg & 512) {   // MODEST_PP4_DBG=512: per-phase wavefront cycles of the join (blocking; diagnostics only)
-            unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[16];
-            MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));
-            b4_join<false, true><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg, dprof);
-            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
-            MODEST_HIP_CHECK(hipMemcpy(hprof, dprof, sizeof(hprof), hipMemcpyDeviceToHost));
-            const double wv = (double)jx * G * (B4_JT / 64), us = 1.0 / 100.0;   // s_memtime ticks at 100 MHz
-            fprintf(stderr, "[b4_join] per wavefront, us: item set-up (decode) %.1f | band set-up %.1f | fetch+decode %.1f | record wait+transform %.1f | "
-                            "pairs %.1f | packed %.1f | band-end wait %.1f | flush %.1f (item set-up = %.1f to the tables' barrier + %.1f prefix / window tables + %.1f band search + decode) || per scan: items %.0f bands %.0f tasks %.0f chunks %.0f\n",
-                    hprof[0] * us / wv, hprof[1] * us / wv, hprof[2] * us / wv, hprof[3] * us / wv, hprof[4] * us / wv, hprof[5] * us / wv,
-                    hprof[6] * us / wv, hprof[7] * us / wv, hprof[12] * us / wv, hprof[13] * us / wv, hprof[14] * us / wv, hprof[8] / 4.0 / G, hprof[9] / 4.0 / G, (double)hprof[10] / G, (double)hprof[11] / G);
-        } else if (poseB && B4_JT >= 512 && !(dbg & 256))
-            b4_join<true, false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN + poseB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
-        else
-            b4_join<false, false><<<dim3(jx, (unsigned)G), B4_JT, B4_LDS_DYN, stream>>>(B, dsc, radius * radius, dbg, nullptr);
+        const bool lpose = U <= B4_POSE_LDS_MAX && !(dbg & 256);
+        const unsigned ldsB = b4_join_lds(U, T, lpose);
+        if (lpose) b4_join<true><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg);
+        else b4_join<false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg);
+        const char *lw_env = getenv("MODEST_PP4_LWG");
+        unsigned lx = (unsigned)((lw_env ? atoi(lw_env) : 2) * ctx->num_cus) / (unsigned)G;   // two workgroups of sixteen wavefronts per CU
+        if (lx < 2) lx = 2;
+        const unsigned lldsB = b4_light_lds(U, lpose);
+        if (lpose) b4_join_light<true><<<dim3(lx, (unsigned)G), B4_JT, lldsB, stream>>>(B, dsc, radius * radius, dbg);
+        else b4_join_light<false><<<dim3(lx, (unsigned)G), B4_JT, lldsB, stream>>>(B, dsc, radius * radius, dbg);
     } else {   // no history: every count is zero
         for (int sc = 0; sc < G; ++sc)
             if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * T * 4, stream));

@@ -370,8 +370,9 @@ def make_shard_matched(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_p
         lat, yaw = rngp.uniform(-1.5, 1.5), rngp.uniform(-0.02, 0.02)
         step = speeds[t] * dt
         back = t >= n_trav - opposite
-        lo, hi = (x0 - reach - 2 * step, x0 + span + 5.0) if back else (x0 - 5.0, x0 + span + reach + 2 * step)
-        xs = np.arange(lo, hi, step) + rngp.uniform(-0.1, 0.1, int(np.ceil((hi - lo) / step)))[: len(np.arange(lo, hi, step))] * step
+        lo, hi = x0 - 5.0, x0 + span + reach + 2 * step   # (either way the window lies AHEAD of the live vehicle)
+        xs = np.arange(lo, hi, step)
+        xs = xs + rngp.uniform(-0.1, 0.1, len(xs)) * step
         if back:
             xs = xs[::-1]
         poses.append([_pose_matrix(x, lat, yaw + (np.pi if back else 0.0)) for x in xs])

@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shards", type=int, default=2, help="distinct shards cycled through in the timing loop")
     ap.add_argument("--stream", action="store_true", help="run on a created stream instead of the null stream")
+    ap.add_argument("--matched", type=str, default="", help="live_speed,hist_lo,hist_hi: windows chosen by the reference's rule "
+                    "(synth.make_shard_matched, split_traintest.py:79-101) instead of frames i..i+F-1")
     a = ap.parse_args()
     _lib.load()
     dev = torch.device("cuda:0")
@@ -49,7 +51,13 @@ def main():
     shards, tabs = [], []
     for q in range(a.shards):
         t0 = time.time()
-        sh = synth.make_shard(a.scans, n_live=a.n, n_trav=a.trav, n_frames=a.frames, nusc=a.nusc, seed=q, x0=40.0 * q)
+        if a.matched:
+            ls, h0, h1 = (float(x) for x in a.matched.split(","))
+            sh = synth.make_shard_matched(a.scans, n_live=a.n, n_trav=a.trav, nusc=a.nusc, live_speed=ls, hist_speeds=(h0, h1),
+                                          seed=q, x0=40.0 * q)
+            print("sharing:", {k: round(v, 2) for k, v in synth.sharing_stats(sh, a.scans).items()}, flush=True)
+        else:
+            sh = synth.make_shard(a.scans, n_live=a.n, n_trav=a.trav, n_frames=a.frames, nusc=a.nusc, seed=q, x0=40.0 * q)
         lives, descs = load_shard(store, sh, dev, key0=1000000 * q)
         shards.append(sh)
         tabs.append((lives, descs))
@@ -87,7 +95,8 @@ def main():
         torch.cuda.synchronize()
         ms = ctx.profile_collect(a.reps * a.shards + 4)
         per = float(np.mean(ms[a.shards:])) / a.scans
-        alg = 12 * a.trav * a.frames * a.n + 16 * a.n
+        members = float(np.mean([len(sc.hist) for sh in shards for sc in sh.scans]))
+        alg = 12 * members * a.n + 16 * a.n   # (a repeated frame is stacked, and counted, as often as it is listed)
         print(f"{'block' if mode else 'chain'}: {np.mean(ms[a.shards:]):.3f} ms per call of {a.scans} scans = {per * 1e3:.1f} us/scan "
               f"-> {alg / per / 1e6:.0f} GB/s = {alg / per / 1e6 / 8000 * 100:.1f} % of 8 TB/s", flush=True)
 
