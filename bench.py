@@ -74,7 +74,7 @@ def parse(argv=None):
                          "scans each (consecutive scans of a Lyft shard share 35 of their 36 history frames per traversal)")
     ap.add_argument("--shard-scans", type=int, default=16, help="consecutive scans per resident shard")
     ap.add_argument("--pp-batch", type=int, default=16,
-                    help="consecutive scans whose PP stage is ONE call (FrameStore.pp_score_batch: modest_pp_score_block for >= 6 "
+                    help="consecutive scans whose PP stage is ONE call (FrameStore.pp_score_batch: modest_pp_score_block for >= 4 "
                          "scans that share their frames, modest_pp_score_frames_batch otherwise); clamped to --shard-scans")
     ap.add_argument("--mask-batch", type=int, default=16, help="scans per chain of stages 2 + 3 (modest_mask_stage_batch)")
     ap.add_argument("--no-pp-block", action="store_true",
@@ -258,7 +258,7 @@ class Runner:
         while self.S % self.PB:   # blocks never straddle shards
             self.PB -= 1
         self.MB = max(1, int(a.mask_batch))
-        self.block = False if a.no_pp_block else None   # None: FrameStore decides (>= 6 scans that share their frames)
+        self.block = False if a.no_pp_block else None   # None: FrameStore decides (>= 4 scans that share their frames)
         self.mark_batch = [[] for _ in range(self.n_threads)]   # scans per profile mark, per thread
         self.pp_ctxs = self.ctxs
         # the mask stage of a chain runs every scan in its own context (the thread's + MB - 1 more)
@@ -273,6 +273,10 @@ class Runner:
         self.margs = config.compose("generate_mask", ["data_root=/unused"] + (["plane_estimate.max_hs=-1.3"] if nusc else []))
         self.largs = config.compose("generate_label_files", ["data_root=/unused"] + (["image_shape=[900,1600]"] if nusc else []))
         self.store = FrameStore(self.dev, 0.3, ctx=self.ctxs[0])
+        # as the CLI does (pre_compute_pp_score.py: frame_prealloc_gb): device memory for the frames the ingest-inclusive steps will
+        # bring in, taken from the driver in ONE call before any clock (a 256 MB slab on demand every third block otherwise: a
+        # hipMalloc under eight processes costs tens of milliseconds -- 97 ms of the 256-step ingest region in round 5's first runs)
+        self.store.reserve(float(os.environ.get("MODEST_BENCH_PREALLOC_GB", "3")) * 2 ** 30)
         self.shards, self.scans = [], []
         n_sh = max(1, (int(a.scans) + self.S - 1) // self.S)
         for q in range(n_sh):
@@ -297,7 +301,6 @@ class Runner:
     def pp_many(self, scs, w):
         """PP stage of the scans of one block: ONE call -> [H]"""
         ctx = self.ctxs[w]
-        self.mark_batch[w].append(len(scs))
         if getattr(self, "trace", None) is not None:
             t0 = time.perf_counter()
             self.trace, keep = None, self.trace
@@ -309,6 +312,7 @@ class Runner:
         # the scores of a block live in ONE device tensor and travel to the host as ONE asynchronous copy into pinned memory
         # right behind the kernels (the host statement of stages 2 + 3 wants them only when the library hands a scan back;
         # the first synchronise of the mask stage is behind this copy): no blocking read-back per scan
+        self.mark_batch[w].append(len(scs))
         ns = [int(sc.desc[0]["n"][0]) for sc in scs]
         if len(set(ns)) != 1 or ns[0] == 0:
             return self.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx, block=self.block)
@@ -422,8 +426,11 @@ class Runner:
                         Hq.update(zip(js, self.pp_many([self.scan_of(j) for j in js], w)))
 
                     def ingest(bi):   # ingest-inclusive mode: the new frames of block bi (copy + sort + poses + tables)
+                        t_in = time.perf_counter()
                         with self.lock:
                             self._ingest([self.scan_of(j) for j in mine[bi]], self.ctxs[w])
+                        if getattr(self, "trace", None) is not None:
+                            self.trace.append((f"ingest[{len(mine[bi])}]", time.perf_counter() - t_in))
 
                     for bi, js in enumerate(mine):
                         if js[0] not in Hq:
@@ -471,20 +478,33 @@ class Runner:
         torch.cuda.synchronize()
         self._rehearsed = getattr(self, "_rehearsed", set()) | {n_steps}
 
+    def rehearse_ingest(self):
+        """Untimed, before the clock of the ingest-inclusive region (like rehearse for the contract region): two blocks per
+        thread in that mode (allocator, slab, slot tables, the sort's scratch)."""
+        if getattr(self, "_ingest_rehearsed", False):
+            return
+        self.ingest = True
+        self.run(0, 2 * self.PB * self.n_threads)
+        torch.cuda.synchronize()
+        self.ingest = False
+        self._ingest_rehearsed = True
+
     def timed(self, n_steps, ingest=False):
         """n_steps steps -> (seconds, HIP-event times of every PP stage launched)"""
         self.ingest = bool(ingest)
-        if ingest:   # two untimed blocks per thread in this mode first (allocator, slab, slot tables)
-            self.run(0, 2 * self.PB * self.n_threads)
-            torch.cuda.synchronize()
         for w, c_ in enumerate(self.pp_ctxs):
             c_.profile_begin(n_steps + 8)
             self.mark_batch[w] = []
+        calls0 = (getattr(self.store, "block_calls", 0), getattr(self.store, "chain_calls", 0))
         t0 = time.perf_counter()
         self.run(self.n_warm, self.n_warm + n_steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         self.ingest = False
+        # which PP path ran INSIDE the clock: calls of modest_pp_score_block / modest_pp_score_frames_batch and their scans
+        self.last_paths = dict(block_calls=getattr(self.store, "block_calls", 0) - calls0[0],
+                               chain_calls=getattr(self.store, "chain_calls", 0) - calls0[1],
+                               scans_per_call=[int(b) for w in range(self.n_threads) for b in self.mark_batch[w]])
         per_scan = []   # a mark brackets the PP stage of a whole block: report it per scan, once per scan
         for w, c_ in enumerate(self.pp_ctxs):
             ms = c_.profile_collect(n_steps + 8)
@@ -537,6 +557,8 @@ def _helper_main(conn, a, rank, local, slot, flag):
             if cmd == "arm":
                 n, gen, ingest = arg
                 r.rehearse(int(n))
+                if ingest:
+                    r.rehearse_ingest()
                 if not os.environ.get("MODEST_BENCH_GC"):
                     # a generation-2 collection of the interpreter (the process holds its resident shards: millions of objects)
                     # is a 5-10 ms pause -- the length of the driver's whole 20-step window, in which one paused helper
@@ -555,7 +577,7 @@ def _helper_main(conn, a, rank, local, slot, flag):
                           file=sys.stderr, flush=True)
                     r.trace = None
                 gc.enable()
-                conn.send(("done", (dt, kms.tolist())))
+                conn.send(("done", (dt, kms.tolist(), r.last_paths)))
             elif cmd == "iso":
                 conn.send(("iso", r.isolated_pp_ms()))
             else:
@@ -752,18 +774,21 @@ def main():
         t0 = time.perf_counter()
         generation[0] += 1
         flag.value = generation[0]          # every armed helper starts now
-        kms = []
+        kms, paths = [], []
         for p, pc in active:
             tag, msg = pc.recv()            # a helper synchronises its streams before it answers
             if tag != "done":
                 raise RuntimeError(f"helper process failed: {msg}")
             kms.append(np.asarray(msg[1], dtype=np.float32))
+            paths.append(msg[2])
         torch.cuda.synchronize()
         dist.barrier()
+        timed_region.paths = paths
         return time.perf_counter() - t0, np.concatenate(kms)
 
     if helpers:
         dt, kernel_ms = timed_region(helpers[:n_procs], _split(a.steps, n_procs))
+        paths = timed_region.paths
     else:
         runner.rehearse(a.steps)
         torch.cuda.synchronize()
@@ -773,6 +798,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         dt = time.perf_counter() - t0
+        paths = [runner.last_paths]
     red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
     dt_max, total_scans = red["max_seconds"], red["scans"]
     steady = None
@@ -791,6 +817,7 @@ def main():
         if helpers:
             dt_wi, _ = timed_region(helpers, _split(n_wi, n_pool), ingest=True)
         else:
+            runner.rehearse_ingest()
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
@@ -840,6 +867,11 @@ def main():
                 traffic, traffic_src = tj["hbm_bytes_per_scan"] * (iso_B if iso_ms else 1), f"profiles/{tname} (" + tj["source"] + ")"   # per launch, like `achieved`
                 break
     pp_B = max(1, min(a.pp_batch, a.shard_scans, a.scans))
+    # what ran inside the contract clock (counted by the helpers' frame stores between the two barriers)
+    n_block = sum(p["block_calls"] for p in paths)
+    n_chain = sum(p["chain_calls"] for p in paths)
+    spc = [b for p in paths for b in p["scans_per_call"]]
+    pp_path = "block" if n_block and not n_chain else ("chain" if n_chain and not n_block else ("mixed" if n_block else "none"))
     kernel_txt = (f"PP neighbour count of a BLOCK of {iso_B} consecutive scans of a shard, ONE call (modest_pp_score_block): list sizes "
                   "from the frames' tile tables (b4_counts / b4_lists / b4_bases) + ONE pass over the union of the block's frames "
                   "(b4_scatter: 36 + 15 frames per traversal instead of 16 x 36) + counting sort of the tile lists by cell "
@@ -871,7 +903,9 @@ def main():
                              "whether or not consecutive scans share frames") if iso_ms else "HIP events in the timed region",
                 "in_pipeline": {"kernel_ms_per_scan": k_ms, "achieved": contended,
                                 "frac": (contended / HBM_PEAK_GBPS) if contended else None,
-                                "scans_timed": int(len(kernel_ms)), "scans_per_launch": pp_B,
+                                "scans_timed": int(len(kernel_ms)),
+                                "scans_per_launch": (float(np.mean(spc)) if spc else None),   # measured: scans per PP call inside the clock
+                                "pp_calls": {"modest_pp_score_block": n_block, "modest_pp_score_frames_batch": n_chain},
                                 "note": "the same event pairs inside the timed region, divided by the scans of their chain: "
                                         "several chains are in flight on grids sized for part of the GPU, a pair also brackets "
                                         "the other processes' kernels"},
@@ -976,6 +1010,9 @@ def main():
                        "scans_in_flight_per_gpu": n_procs * n_threads, "note": note,
                        "pp_stage_prefetch": (not (a.no_prefetch or a.pp_only or a.mask_only)),
                        "pp_scans_per_call": pp_B, "mask_scans_per_chain": a.mask_batch,
+                       "pp_path_in_timed_region": pp_path,
+                       "pp_calls_in_timed_region": {"modest_pp_score_block": n_block, "modest_pp_score_frames_batch": n_chain,
+                                                    "scans_per_call": spc},
                        "resident_scans_per_process": a.scans, "shard_scans": a.shard_scans,
                        "history_sharing": "consecutive scans of a shard: 35 of 36 frames per traversal shared with the predecessor "
                                           "(data_preprocessing/lyft/split_traintest.py:64,97; SURVEY 8d C4)",

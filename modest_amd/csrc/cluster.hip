@@ -993,7 +993,14 @@ __global__ void scatter_kth(const double *__restrict__ kthS, const int *__restri
 
 // Rounds of min-root hooking before the exact union pass.  Measured on a 9 k-point scan
 // (hook + flatten 14 us per round): union_adj takes 305 / 220 / 59 / 19 us after 0 / 1 / 2 / 3 rounds.
-constexpr int HOOK_ROUNDS = 3;
+static int hook_rounds() {   // hooking rounds ahead of the exact union pass (accelerators only: the union pass makes any number exact)
+    static const int v = [] {
+        const char *e = getenv("MODEST_HOOK_ROUNDS");
+        return e ? atoi(e) : 3;
+    }();
+    return v;
+}
+#define HOOK_ROUNDS hook_rounds()
 
 namespace {
 

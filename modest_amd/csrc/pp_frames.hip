@@ -43,7 +43,9 @@ struct SortJob {
     unsigned *perm;
     unsigned *tab;
     int *n_inside;   // one word per job, contiguous: read back with a single copy
+    long long at;    // first point of the job in the batch's scratch arrays (rank / tile of every point)
 };
+static_assert(sizeof(SortJob) == MODEST_FRAME_SORT_JOB_BYTES, "job layout (callers size their job buffers with the header's constant)");
 
 __device__ __forceinline__ int frame_bin(const Map24 &W, float x, float y, float z, int TX0, int TY0) {
     const double lx = fma(W.a[2], (double)z, fma(W.a[1], (double)y, W.a[0] * (double)x)) + W.a[3];
@@ -55,10 +57,96 @@ __device__ __forceinline__ int frame_bin(const Map24 &W, float x, float y, float
     return (int)(ty * F_NTF + tx);
 }
 
-// One workgroup per frame: LDS histogram over the tiles, scan, scatter.  The order inside a tile
-// is the arrival order of the atomics (irrelevant: counts are order independent, `perm` maps back).
+// The sort of a batch of frames is four small launches over a GRID of point chunks (round 5; one workgroup per frame took
+// 235-485 us for a scan's 11 new frames: eleven workgroups on 256 CUs): clear the tables | every point adds itself to its
+// tile's counter in the frame's table (global atomic, returning its rank in the tile) | per frame: exclusive prefix over the
+// 16 385 counters, in place | every point goes to table[tile] + rank.  The order inside a tile is the arrival order of
+// the atomics (irrelevant: counts are order independent, `perm` maps back).
+constexpr int SORT_CH = 2048;   // points per workgroup of the two point passes
+__global__ __launch_bounds__(256) void frame_clear_kernel(const SortJob *__restrict__ jobs) {
+    const SortJob &J = jobs[blockIdx.y];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b <= F_NTILE) J.tab[b] = 0u;
+}
+__global__ __launch_bounds__(256) void frame_rank_kernel(const SortJob *__restrict__ jobs, const uint2 *__restrict__ chunks,
+                                                         unsigned *__restrict__ rankAll, unsigned short *__restrict__ binAll) {
+    const uint2 ck = chunks[blockIdx.x];   // (job, first point)
+    const SortJob &J = jobs[ck.x];
+    unsigned *rank = rankAll + J.at;         // rank of point i inside its tile
+    unsigned short *binOf = binAll + J.at;   // tile of point i (F_NTILE: outside the table)
+    float x[SORT_CH / 256], y[SORT_CH / 256], z[SORT_CH / 256];
+#pragma unroll
+    for (int u = 0; u < SORT_CH / 256; ++u) {   // (every load issued before the first use)
+        const int i = (int)ck.y + u * 256 + threadIdx.x;
+        const float *p = J.raw + (size_t)min(i, J.n - 1) * J.stride;
+        x[u] = p[0], y[u] = p[1], z[u] = p[2];
+    }
+#pragma unroll
+    for (int u = 0; u < SORT_CH / 256; ++u) {
+        const int i = (int)ck.y + u * 256 + threadIdx.x;
+        if (i < J.n) {
+            const int bin = frame_bin(J.W, x[u], y[u], z[u], J.TX0, J.TY0);
+            binOf[i] = (unsigned short)bin;
+            rank[i] = atomicAdd(&J.tab[bin], 1u);
+        }
+    }
+}
 constexpr int SORT_PER = (F_NTILE + 1 + 1023) / 1024;
-__global__ __launch_bounds__(1024) void frame_sort_kernel(const SortJob *__restrict__ jobs) {
+__global__ __launch_bounds__(1024) void frame_scan_kernel(const SortJob *__restrict__ jobs) {
+    __shared__ unsigned wsum[16];
+    const SortJob &J = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned loc[SORT_PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < SORT_PER; ++k) {
+        const int b = tid * SORT_PER + k;
+        loc[k] = b <= F_NTILE ? J.tab[b] : 0u;
+        s += loc[k];
+    }
+    unsigned inc = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned run = inc - s;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < SORT_PER; ++k) {
+        const int b = tid * SORT_PER + k;
+        if (b <= F_NTILE) {
+            J.tab[b] = run;   // tab[F_NTILE] = points inside the table = start of the outliers
+            if (b == F_NTILE) *J.n_inside = (int)run;
+        }
+        run += loc[k];
+    }
+}
+__global__ __launch_bounds__(256) void frame_place_kernel(const SortJob *__restrict__ jobs, const uint2 *__restrict__ chunks,
+                                                          const unsigned *__restrict__ rankAll, const unsigned short *__restrict__ binAll) {
+    const uint2 ck = chunks[blockIdx.x];
+    const SortJob &J = jobs[ck.x];
+    const unsigned *rank = rankAll + J.at;
+    const unsigned short *binOf = binAll + J.at;
+#pragma unroll
+    for (int u = 0; u < SORT_CH / 256; ++u) {
+        const int i = (int)ck.y + u * 256 + threadIdx.x;
+        const int ii = min(i, J.n - 1);
+        const float *p = J.raw + (size_t)ii * J.stride;
+        const float x = p[0], y = p[1], z = p[2];
+        const unsigned pos = J.tab[binOf[ii]] + rank[ii];
+        if (i < J.n) {
+            J.xyz[3 * (size_t)pos] = x;
+            J.xyz[3 * (size_t)pos + 1] = y;
+            J.xyz[3 * (size_t)pos + 2] = z;
+            J.perm[pos] = (unsigned)i;
+        }
+    }
+}
+
+// Large batches (a cold scan: 361 frames) keep the one-workgroup-per-frame form -- LDS histogram over the tiles, scan,
+// scatter: with more frames than CUs its LDS atomics beat the grid form's global ones (372 against 850 us for 361 frames).
+__global__ __launch_bounds__(1024) void frame_sort_wg_kernel(const SortJob *__restrict__ jobs) {
     extern __shared__ unsigned hist[];   // F_NTILE + 1 bins (+ the outlier bin)
     __shared__ unsigned wsum[16];
     const SortJob J = jobs[blockIdx.x];
@@ -132,6 +220,53 @@ int fill_jobs(modest_ctx *ctx, const modest_frame_sort_job *jobs, int n_jobs, So
     }
     return MODEST_OK;
 }
+// scratch of a batch behind `head` bytes of the context's arena: [rank u32 x points][bin u16 x points][chunk table]
+struct SortPlan {
+    size_t oRank, oBin, oChunks, bytes;
+    long long points, chunks;
+};
+SortPlan sort_plan(const modest_frame_sort_job *jobs, int n_jobs, size_t head) {
+    SortPlan p;
+    p.points = 0, p.chunks = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        p.points += jobs[k].n;
+        p.chunks += (jobs[k].n + SORT_CH - 1) / SORT_CH;
+    }
+    p.oRank = arena_sz(head);
+    p.oBin = p.oRank + arena_sz((size_t)std::max<long long>(p.points, 1) * 4);
+    p.oChunks = p.oBin + arena_sz((size_t)std::max<long long>(p.points, 1) * 2);
+    p.bytes = p.oChunks + arena_sz((size_t)std::max<long long>(p.chunks, 1) * sizeof(uint2));
+    return p;
+}
+// fills the jobs' scratch pointers and the chunk table (host side, staged with the job table)
+void sort_assign(const modest_frame_sort_job *jobs, int n_jobs, SortJob *hj, uint2 *hc) {
+    long long at = 0, c = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        hj[k].at = at;
+        for (int p0 = 0; p0 < jobs[k].n; p0 += SORT_CH) hc[c++] = make_uint2((unsigned)k, (unsigned)p0);
+        at += jobs[k].n;
+    }
+}
+constexpr int SORT_WG_FROM = 96;   // jobs per batch from which the one-workgroup-per-frame kernel is used
+int sort_launch(const SortJob *dj, const uint2 *dc, int n_jobs, long long chunks, char *arena, const SortPlan &p, hipStream_t stream) {
+    if (n_jobs >= SORT_WG_FROM) {
+        const size_t lds = (size_t)(F_NTILE + 1) * 4;
+        // per call: the attribute is per device, a process may hold contexts on several (cheap)
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(frame_sort_wg_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        frame_sort_wg_kernel<<<n_jobs, 1024, lds, stream>>>(dj);
+        MODEST_HIP_CHECK(hipGetLastError());
+        return MODEST_OK;
+    }
+    unsigned *rank = reinterpret_cast<unsigned *>(arena + p.oRank);
+    unsigned short *bin = reinterpret_cast<unsigned short *>(arena + p.oBin);
+    frame_clear_kernel<<<dim3((F_NTILE + 1 + 255) / 256, (unsigned)n_jobs), 256, 0, stream>>>(dj);
+    if (chunks > 0) frame_rank_kernel<<<(unsigned)chunks, 256, 0, stream>>>(dj, dc, rank, bin);
+    frame_scan_kernel<<<(unsigned)n_jobs, 1024, 0, stream>>>(dj);
+    if (chunks > 0) frame_place_kernel<<<(unsigned)chunks, 256, 0, stream>>>(dj, dc, rank, bin);
+    MODEST_HIP_CHECK(hipGetLastError());
+    return MODEST_OK;
+}
 }  // namespace
 
 extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *jobs, int n_jobs,
@@ -143,23 +278,27 @@ extern "C" int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *j
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
     static_assert(sizeof(SortJob) % 8 == 0, "job layout");
-    int rc = modest_ctx_reserve(ctx, arena_sz((size_t)n_jobs * sizeof(SortJob)) + arena_sz((size_t)n_jobs * 4));
+    const size_t head = arena_sz((size_t)n_jobs * sizeof(SortJob)) + arena_sz((size_t)n_jobs * 4);
+    const SortPlan sp = sort_plan(jobs, n_jobs, head);
+    MODEST_REQUIRE(sp.points < (1LL << 31), "too many points in one batch");
+    int rc = modest_ctx_reserve(ctx, sp.bytes);
     if (rc) return rc;
-    rc = modest_ctx_reserve_pinned(ctx, (size_t)n_jobs * (sizeof(SortJob) + 4));
+    const size_t stageB = (size_t)n_jobs * sizeof(SortJob) + (size_t)std::max<long long>(sp.chunks, 1) * sizeof(uint2);
+    rc = modest_ctx_reserve_pinned(ctx, stageB + (size_t)n_jobs * 4);
     if (rc) return rc;
     // the pinned staging area is reused by the next call: this entry point is blocking
     SortJob *hj = reinterpret_cast<SortJob *>(ctx->pinned);
-    int32_t *hin = reinterpret_cast<int32_t *>(ctx->pinned + (size_t)n_jobs * sizeof(SortJob));
+    uint2 *hc = reinterpret_cast<uint2 *>(ctx->pinned + (size_t)n_jobs * sizeof(SortJob));
+    int32_t *hin = reinterpret_cast<int32_t *>(ctx->pinned + stageB);
     rc = fill_jobs(ctx, jobs, n_jobs, hj, reinterpret_cast<int *>(ctx->scratch + arena_sz((size_t)n_jobs * sizeof(SortJob))));
     if (rc) return rc;
+    sort_assign(jobs, n_jobs, hj, hc);
     SortJob *dj = reinterpret_cast<SortJob *>(ctx->scratch);
+    uint2 *dc = reinterpret_cast<uint2 *>(ctx->scratch + sp.oChunks);
     MODEST_HIP_CHECK(hipMemcpyAsync(dj, hj, (size_t)n_jobs * sizeof(SortJob), hipMemcpyHostToDevice, stream));
-    const size_t lds = (size_t)(F_NTILE + 1) * 4;
-    // per call: the attribute is per device, a process may hold contexts on several (cheap)
-    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(frame_sort_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    frame_sort_kernel<<<n_jobs, 1024, lds, stream>>>(dj);
-    MODEST_HIP_CHECK(hipGetLastError());
+    if (sp.chunks > 0) MODEST_HIP_CHECK(hipMemcpyAsync(dc, hc, (size_t)sp.chunks * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    rc = sort_launch(dj, dc, n_jobs, sp.chunks, ctx->scratch, sp, stream);
+    if (rc) return rc;
     MODEST_HIP_CHECK(hipMemcpyAsync(hin, ctx->scratch + arena_sz((size_t)n_jobs * sizeof(SortJob)), (size_t)n_jobs * 4,
                                     hipMemcpyDeviceToHost, stream));
     MODEST_HIP_CHECK(hipStreamSynchronize(stream));
@@ -180,24 +319,28 @@ extern "C" int modest_frame_sort_async(modest_ctx *ctx, const modest_frame_sort_
     MODEST_REQUIRE(n_jobs >= 0, "n_jobs < 0");
     if (n_jobs == 0) return MODEST_OK;
     MODEST_REQUIRE(jobs && jobs_scratch_dev && n_inside_pinned, "NULL argument");
-    static_assert(sizeof(SortJob) <= MODEST_FRAME_SORT_JOB_BYTES, "header and kernel disagree on the job size");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    SortJob *hj = nullptr;
-    int rc = modest_ctx_stage_slot(ctx, (size_t)n_jobs * sizeof(SortJob), reinterpret_cast<void **>(&hj));
+    const SortPlan sp = sort_plan(jobs, n_jobs, 0);
+    MODEST_REQUIRE(sp.points < (1LL << 31), "too many points in one batch");
+    int rc = modest_ctx_reserve(ctx, sp.bytes);   // (rank / tile of every point + the chunk table: the context's arena, in stream order)
     if (rc) return rc;
+    char *hs = nullptr;
+    const size_t jobB = (size_t)n_jobs * sizeof(SortJob), stageB = jobB + (size_t)std::max<long long>(sp.chunks, 1) * sizeof(uint2);
+    rc = modest_ctx_stage_slot(ctx, stageB, reinterpret_cast<void **>(&hs));
+    if (rc) return rc;
+    SortJob *hj = reinterpret_cast<SortJob *>(hs);
+    uint2 *hc = reinterpret_cast<uint2 *>(hs + jobB);
     rc = fill_jobs(ctx, jobs, n_jobs, hj, reinterpret_cast<int *>(n_inside_pinned));
     if (rc) return rc;
+    sort_assign(jobs, n_jobs, hj, hc);
     SortJob *dj = reinterpret_cast<SortJob *>(jobs_scratch_dev);
-    MODEST_HIP_CHECK(hipMemcpyAsync(dj, hj, (size_t)n_jobs * sizeof(SortJob), hipMemcpyHostToDevice, stream));
+    uint2 *dc = reinterpret_cast<uint2 *>(ctx->scratch + sp.oChunks);
+    MODEST_HIP_CHECK(hipMemcpyAsync(dj, hj, jobB, hipMemcpyHostToDevice, stream));
+    if (sp.chunks > 0) MODEST_HIP_CHECK(hipMemcpyAsync(dc, hc, (size_t)sp.chunks * sizeof(uint2), hipMemcpyHostToDevice, stream));
     rc = modest_ctx_stage_commit(ctx, stream);
     if (rc) return rc;
-    const size_t lds = (size_t)(F_NTILE + 1) * 4;
-    MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(frame_sort_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    frame_sort_kernel<<<n_jobs, 1024, lds, stream>>>(dj);
-    MODEST_HIP_CHECK(hipGetLastError());
-    return MODEST_OK;
+    return sort_launch(dj, dc, n_jobs, sp.chunks, ctx->scratch, sp, stream);
 }
 
 extern "C" int modest_pp_score_frames(modest_ctx *ctx, const modest_pp_frame *live, const uint32_t *live_perm_dev,

@@ -574,7 +574,7 @@ class FrameStore:
         """The tables of modest_pp_score_block for these scans, or None when the block path does not apply: more than
         64 traversals / scans, a frame with points outside its table, poses that disagree with the lattice by more
         than 1e-4 m, live scans further apart than the block window, mixed remove_center flags -- or (unless forced)
-        too little sharing: the block path bins the UNION of the scans' frames once, which pays when the scans are
+        too little sharing (fewer than 4 scans, union > 2 x a scan's frames): the block path bins the UNION of the scans' frames once, which pays when the scans are
         consecutive scans of a shard (35 of 36 frames per traversal shared, split_traintest.py:64,97)."""
         env = os.environ.get("MODEST_PP_BLOCK", "")
         if force is None:
@@ -610,8 +610,10 @@ class FrameStore:
                 # 1.42 x a scan's frames, 137 against 191 us per scan alone on the GPU; nuScenes shape, 16 frames per
                 # traversal: union 1.94 x, 281 against 263 us alone, but 3 400 against 2 790 scans/s in the pipeline (one
                 # sequence of large launches instead of sixteen chains of small ones next to seven other processes)
+                # round 5 (wave-independent join, tools/pp_block_probe.py --scans B): block 185 / 157 / 142 / 127 us per scan at
+                # B = 4 / 5 / 6 / 8 against 210 / 206 / 206 / 197 for the chain; B = 3: 229 against 220
                 per_scan = members / B
-                if B < 8 or len(us) > 2.0 * per_scan or per_scan < 12 * T:
+                if B < 4 or len(us) > 2.0 * per_scan or per_scan < 12 * T:
                     return None
             if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([np.unique(allh), lslots])):
                 return None
@@ -715,6 +717,7 @@ class FrameStore:
             permp[i] = self.frames[live_keys[i]].perm.data_ptr()
             Hp[i] = Hs[i].data_ptr()
             cp[i] = cs[i].data_ptr() if cs[i] is not None else 0
+        self.chain_calls = getattr(self, "chain_calls", 0) + 1
         check(lib.modest_pp_score_frames_batch(self._ctx(ctx).handle, B, livep.ctypes.data, permp.ctypes.data,
                                                framep.ctypes.data, nfr.ctypes.data, T, self.radius,
                                                cp.ctypes.data if return_counts else None, Hp.ctypes.data,

@@ -95,8 +95,9 @@ def test_block_tables_rule_and_refusals():
     st = _store(T * L + B, T, L)
     descs = _descs(st, B, T, F, L)
     assert st.block_tables(descs, T) is not None
-    assert st.block_tables(descs[:7], T) is None                       # fewer than eight scans: the chain (unless forced)
-    assert st.block_tables(descs[:7], T, force=True) is not None
+    assert st.block_tables(descs[:7], T) is not None                   # (round 5: the block pays from four scans on)
+    assert st.block_tables(descs[:3], T) is None                       # fewer than four scans: the chain (unless forced)
+    assert st.block_tables(descs[:3], T, force=True) is not None
     assert st.block_tables(descs, T, force=False) is None
     # windows shorter than 12 frames per traversal, or scans that share too little: the chain
     st2 = _store(T * 27 + 16, T, 27)
