@@ -339,7 +339,7 @@ class Runner:
         frames of every scan are solved from the raw pose factors (get_relative_pose), and the descriptor tables are
         rebuilt from the store -- nothing of a scan's table is reused from a previous step.  A re-inserted frame replaces
         its resident copy for every scan of the shard (the sharing between the scans is that of the CLI)."""
-        from modest_amd.pre_compute_pp_score import relative_poses
+        from modest_amd.pre_compute_pp_score import relative_poses_block
         sh = scs[0].shard
         keys_all, offs, Ws, base = [], [0], [], 0
         dev = torch.empty((sum(int(sc.new_pinned.shape[0]) for sc in scs), 4), dtype=torch.float32, device=self.dev)
@@ -356,8 +356,16 @@ class Runner:
             base += n
         self.store.drop(old)
         self.store.insert_block(keys_all, dev, np.asarray(offs), np.concatenate(Ws), ctx=ctx)
-        for sc in sh.scans:   # every scan of the shard sees the new copies (the block's own scans solve their poses again)
-            sc.describe(relative_poses(sc.fixed_l2e, sc.fixed_ego, sc.W_stack, sc.K) if sc in scs else None)
+        # every scan of the shard sees the new copies; the block's own scans solve their poses again (a few scans per thread:
+        # LAPACK releases the interpreter lock) and their tables come out of ONE gather from the store's slot tables
+        rels = relative_poses_block([sc.fixed_l2e for sc in scs], [sc.fixed_ego for sc in scs], [sc.W_stack for sc in scs], scs[0].K)
+        descs = self.store.describe_many([sc.live_key for sc in scs], [r[-1] for r in rels], [[sh.key(f) for f in sc.hist_ids] for sc in scs],
+                                         [sc.travs for sc in scs], [r[:-1] for r in rels], sh.nusc)
+        for sc, d in zip(scs, descs):
+            sc.desc = d
+        for sc in sh.scans:
+            if sc not in scs:
+                sc.describe()
 
     def steps(self, js, w, Hs, after=None):
         """The scans of one chain of stages 2 + 3 on thread w.  Hs: their PP scores (enqueued ahead of time); the mask stage

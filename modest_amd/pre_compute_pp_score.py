@@ -305,6 +305,24 @@ def relative_poses(fixed_l2e, fixed_ego, world_stack, K):
     return X.reshape(4, F, 4).transpose(1, 0, 2).astype(np.float32)
 
 
+_POSE_POOL = None
+
+
+def relative_poses_block(fixed_l2es, fixed_egos, world_stacks, K, threads: int = 4):
+    """relative_poses for the scans of a block, a few scans per thread: the 4x4 solves against 4 F right-hand sides are
+    ~90 us of LAPACK per scan (dgetrs over 1 444 columns; numpy's stacked solve runs them one after another), LAPACK releases
+    the interpreter lock, and a block of 16 scans is 1.5 ms on one thread.  Per scan exactly relative_poses (bit-identical
+    by construction).  fixed_l2es / fixed_egos: sequences of (4,4); world_stacks: sequence of (F_i,4,4) -> [(F_i,4,4) float32]."""
+    global _POSE_POOL
+    n = len(world_stacks)
+    if n <= 2 or threads <= 1:
+        return [relative_poses(fixed_l2es[i], fixed_egos[i], world_stacks[i], K) for i in range(n)]
+    if _POSE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POSE_POOL = ThreadPoolExecutor(max_workers=threads)
+    return list(_POSE_POOL.map(lambda i: relative_poses(fixed_l2es[i], fixed_egos[i], world_stacks[i], K), range(n)))
+
+
 def save_npy_atomic(path, arr):
     """np.save through a temporary file + os.replace: a killed rank never leaves a truncated .npy
     that the skip-if-exists test would count as done."""
@@ -416,19 +434,24 @@ def main(args):
     pipe = IngestPipeline(loader, plans(), device, depth=max(1, int(args.get("ingest_depth", 4))) + (n_batch - 1),
                           own_stream=not os.environ.get("MODEST_WORKER"))
     writer = OutputWriter(1 << 16)
-    pend = []   # (live frame, descriptor table, output path, scan id, traversals) of the scans waiting for the flush
+    pend = []   # the scans waiting for the flush: (live frame, history ids, traversal of every frame, raw pose factors of the
+    #             history frames + the live scan, fixed l2e, fixed ego, output path, scan id, traversals)
+    pose_threads = max(1, int(args.get("pose_threads", 4)))
+    flushed = False
 
     def flush():
         if not pend:
             return
-        if len(pend) == 1:   # the library would take the single-scan chain anyway
-            Hs = store.pp_score_batch([pend[0][0]], [pend[0][1]], pend[0][4])
-        else:
-            Hs = store.pp_score_batch([q[0] for q in pend], [q[1] for q in pend], pend[0][4])
+        # the relative poses of the whole batch (get_relative_pose :27-28 per frame; a few scans per thread) and its descriptor
+        # tables (one gather from the store's slot tables) -- then ONE PP call
+        rels = relative_poses_block([q[4] for q in pend], [q[5] for q in pend], [q[3] for q in pend], K, threads=pose_threads)
+        descs = store.describe_many([q[0] for q in pend], [r[-1] for r in rels], [q[1] for q in pend], [q[2] for q in pend],
+                                    [r[:-1] for r in rels], bool(args.nusc))
+        Hs = store.pp_score_batch([q[0] for q in pend], descs, pend[0][8])
         for q, H in zip(pend, Hs):
-            _tr("M.enq", q[3])
-            writer.submit(H, q[2])
-            _tr("M.sub", q[3])
+            _tr("M.enq", q[7])
+            writer.submit(H, q[6])
+            _tr("M.sub", q[7])
         for _ in pend:
             pipe.done()
         pend.clear()
@@ -438,6 +461,29 @@ def main(args):
         live_id, hist_ids, travs = plan["live"], plan["hist"], plan["travs"]
         first_seq, first_indices = traversals[0]
         first_pose, first_l2e = poses[first_seq][first_indices[0]], l2es[first_seq][first_indices[0]]
+        n_trav = len(traversals)
+        if args.limit_traversals > 1:   # (:181-186)
+            n_trav = min(n_trav, int(args.limit_traversals))
+        dumps = dp.load_save_precomputed_trans_mat is not None or dp.load_precomputed_lidars is not None
+        batched = not (args.add_random_noise > 0) and n_trav <= 64 and not dumps and not args.skip_ephe
+        if batched:   # the default path: poses and tables wait for the flush
+            if pend and pend[0][8] != n_trav:
+                flush()
+            keep = [k for k, t in enumerate(travs) if t < n_trav] if n_trav < len(traversals) else None
+            h_ids = hist_ids if keep is None else [hist_ids[k] for k in keep]
+            h_tr = travs if keep is None else [travs[k] for k in keep]
+            pend.append((live_id, h_ids, h_tr, world.stack(h_ids + [live_id]), first_l2e, first_pose, out_path, origin_idx, n_trav))
+            done += 1
+            pts += store.points_of(h_ids)
+            # the FIRST batch of a process is short: its kernels start once four scans' files are in, not sixteen (a cold
+            # worker reads 361 frames for its first scan alone); four is where the block path starts to pay
+            if len(pend) >= (n_batch if flushed else min(4, n_batch)):
+                flush()
+                flushed = True
+            if trace and (done <= 4 or done % 8 == 0):
+                eprint("[pp_score trace] scan %d submitted at %.1f ms" % (done, 1e3 * (time.perf_counter() - t0)))
+            continue
+        flush()   # scans leave the ingest window in plan order
         rels = relative_poses(first_l2e, first_pose, world.stack(plan["frames"]), K)
         trans_mat = rels[-1]
         if dp.load_save_precomputed_trans_mat is not None:
@@ -451,28 +497,10 @@ def main(args):
                 combined[sq] = np.concatenate(parts) if parts else np.zeros((0, 3), np.float32)
             pickle.dump(combined, open(osp.join(dp.load_precomputed_lidars, f"{origin_idx:06d}.pkl"), "wb"))
         if args.skip_ephe:
-            flush()
             pipe.done()
             continue
-        n_trav = len(traversals)
-        if args.limit_traversals > 1:   # (:181-186)
-            n_trav = min(n_trav, int(args.limit_traversals))
         keep = [k for k, t in enumerate(travs) if t < n_trav]
         hist = [(hist_ids[k], travs[k]) for k in keep]
-        batched = not (args.add_random_noise > 0) and n_trav <= 64
-        if batched:
-            if pend and pend[0][4] != n_trav:
-                flush()
-            pend.append((live_id, store.describe(live_id, trans_mat, [i for i, _ in hist], [t for _, t in hist], rels[keep],
-                                                 bool(args.nusc)), out_path, origin_idx, n_trav))
-            done += 1
-            pts += store.points_of([i for i, _ in hist])
-            if len(pend) >= n_batch:
-                flush()
-            if trace and (done <= 4 or done % 8 == 0):
-                eprint("[pp_score trace] scan %d submitted at %.1f ms" % (done, 1e3 * (time.perf_counter() - t0)))
-            continue
-        flush()   # scans leave the ingest window in plan order
         if args.add_random_noise > 0:            # (:175-179) host draw, same numpy expressions; stacked path
             noise = np.random.randn(3)
             noise /= np.linalg.norm(noise)

@@ -324,3 +324,23 @@ def test_last_block_reductions_drain_their_stores_before_the_ticket(tmp_path):
             assert bad, (name, k)
             sites += 1
     assert sites == 4
+
+
+def test_relative_poses_block_is_the_per_scan_solve():
+    """the batch's pose solves run a few scans per thread: per scan they ARE relative_poses (get_relative_pose,
+    pre_compute_pp_score.py:27-28, batched over the frames) -- same values bit for bit, ragged frame counts included"""
+    from modest_amd import synth
+    from modest_amd.pre_compute_pp_score import _KITTI2NU_lyft as K, get_relative_pose, relative_poses, relative_poses_block
+    rng = np.random.default_rng(3)
+    egos = [synth._pose_matrix(rng.uniform(0, 900), rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-.05, .05),
+                               rng.uniform(-.05, .05)).astype(np.float32) for _ in range(7)]
+    l2es = [synth.default_l2e() for _ in range(7)]
+    stacks = [np.stack([synth._pose_matrix(rng.uniform(0, 900), rng.uniform(-3, 3), rng.uniform(-3, 3)) @ synth.default_l2e() @ K
+                        for _ in range(f)]) for f in (361, 361, 5, 1, 361, 40, 361)]
+    got = relative_poses_block(l2es, egos, stacks, K, threads=3)
+    for i in range(7):
+        assert got[i].dtype == np.float32 and np.array_equal(got[i], relative_poses(l2es[i], egos[i], stacks[i], K))
+    # ... and relative_poses is the reference's per-frame call
+    E, L = np.linalg.inv(stacks[0][3] @ np.linalg.inv(K) @ np.linalg.inv(l2es[0])), l2es[0]   # any ego pose with W = E @ L @ K
+    one = get_relative_pose(l2es[0], egos[0], L, np.linalg.inv(E), K)
+    assert one.shape == (4, 4) and one.dtype == np.float32
