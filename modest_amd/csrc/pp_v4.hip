@@ -65,6 +65,9 @@ constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
 #endif
 constexpr int B4_JT = B4_JT_;                 // threads of a join workgroup
 constexpr int B4_MAXT = 64;
+#ifndef B4_LIGHT_TASKS
+#define B4_LIGHT_TASKS 1   // sparse cells as four-cell tasks of b4_join (0: the packed order walked lane by lane in b4_join_light)
+#endif
 constexpr int B4_POSE_LDS_MAX = 1024;       // union frames whose poses fit the LDS table of a join workgroup (50 KB)
 
 struct UFrame {   // a frame of the union, device side (96 bytes)
@@ -101,7 +104,9 @@ struct ScanDev {   // per scan (device table)
     uint2 *cellRange;   // per (tile with tasks, cell): first record and count of the part of the cell this scan reads
     float4 *tmp, *sorted;
     void *tasks;       // B4Task x maxTasks
-    uint2 *lchunks;    // (tile, group of four chunks) x maxLight
+    uint2 *lchunks;    // (tile, group of four chunks) x maxLight (B4_LIGHT_TASKS 0)
+    uint4 *ltHead;     // four-cell tasks: (first record, records) x 4 per task = 2 x uint4, x maxLight
+    uint4 *ltSegs;     // ... (a0, n0, a1, n1), (a2, n2, -, -) per cell = 8 x uint4 per task
     const PoseEnt *pose;
     int *counts;
     float *H;
@@ -571,15 +576,42 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     }
     const unsigned TH = __shfl(incT, 63), LV = __shfl(incL, 63);
     if (TH + LV == 0u) continue;
+#if B4_LIGHT_TASKS
+    // sparse cells: FOUR cells to a task (a cell per 64-lane chunk of the wavefront, each with its own three candidate runs)
+    const bool isL = lv != 0u;
+    const unsigned long long lmask = __ballot(isL);
+    const unsigned nLc = (unsigned)__popcll(lmask), li = (unsigned)__popcll(lmask & ((1ULL << lane) - 1ULL));
+    const unsigned nL = (nLc + 3) >> 2;   // <= 16
+#else
     S.cellRange[(size_t)b * 64 + lane] = make_uint2(start, active ? n : 0u);   // (only tiles with work are read back: the light path)
     const unsigned nL = (((LV + 63) >> 6) + 3) >> 2;   // units of four chunks (b4_join_light's B4_LCH), <= 16
+#endif
     unsigned tb = 0, lb = 0;
     if (lane == 0) {
         if (TH) tb = atomicAdd(&S.ctrl[0], TH);
         if (nL) lb = atomicAdd(&S.ctrl[1], nL);
     }
     tb = __shfl(tb, 0), lb = __shfl(lb, 0);
+#if B4_LIGHT_TASKS
+    {
+        unsigned *head = reinterpret_cast<unsigned *>(S.ltHead);
+        if (isL) {
+            const unsigned task = lb + (li >> 2), slot = li & 3u;
+            if (task < (unsigned)S.maxLight) {
+                *reinterpret_cast<uint2 *>(head + (size_t)task * 8 + slot * 2) = make_uint2(start, n);
+                S.ltSegs[((size_t)task * 4 + slot) * 2] = make_uint4(sa[0], sn[0], sa[1], sn[1]);
+                S.ltSegs[((size_t)task * 4 + slot) * 2 + 1] = make_uint4(sa[2], sn[2], 0u, 0u);
+            }
+        }
+        const unsigned padN = nL * 4 - nLc;   // empty cells of the tile's last task
+        if ((unsigned)lane < padN) {
+            const unsigned q = nLc + (unsigned)lane, task = lb + (q >> 2);
+            if (task < (unsigned)S.maxLight) *reinterpret_cast<uint2 *>(head + (size_t)task * 8 + (q & 3u) * 2) = make_uint2(0u, 0u);
+        }
+    }
+#else
     if ((unsigned)lane < nL && lb + lane < (unsigned)S.maxLight) S.lchunks[lb + lane] = make_uint2((unsigned)b, (unsigned)lane);
+#endif
     uint4 *out = reinterpret_cast<uint4 *>(S.tasks);
     const unsigned first = tb + incT - th;
     for (unsigned k = 0; k < th; ++k) {
@@ -720,6 +752,52 @@ __device__ __forceinline__ void b4_pairs_rows(B4_CONST(v4f) sorted, B4_CNT count
             const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
             b4_pairs_band<NP>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
         }
+    }
+}
+
+// one chunk (a sparse cell: < 64 records) against the live points [ia, ie): the candidate in SGPRs, one per trip
+__device__ __forceinline__ unsigned long long b4_pairs1(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie, float hx, float hy,
+                                                        float hz, unsigned sLo, unsigned sHi, float r2lo, float r2hi, int lq, int T) {
+    unsigned long long band = 0;
+    if (ia >= ie) return band;
+    v4f q = sorted[ia];
+#pragma unroll 1
+    for (unsigned i = ia; i < ie; ++i) {
+        const v4f qn = sorted[min(i + 1, ie - 1)];
+        const float dx = q.x - hx, dy = q.y - hy, dz = q.z - hz;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const unsigned long long hA = __ballot(d2 < r2lo), mA = __ballot(d2 <= r2hi);
+        band |= hA ^ mA;
+        unsigned acc = b4_bcnt((unsigned)hA & sLo, 0u);
+        acc = b4_bcnt((unsigned)(hA >> 32) & sHi, acc);
+        if (lq < T && acc) b4_count_add(&counts[(size_t)__float_as_int(q.w) * T + lq], (int)acc);
+        q = qn;
+    }
+    return band;
+}
+__device__ __forceinline__ void b4_pairs1_band(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie, float hx, float hy, float hz,
+                                               unsigned sLo, unsigned sHi, float r2lo, float r2hi, double r2, int lq, int T) {
+#pragma unroll 1
+    for (unsigned i = ia; i < ie; ++i) {
+        const v4f q = sorted[i];
+        const float fx = q.x - hx, fy = q.y - hy, fz = q.z - hz;
+        const float dA = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+        const bool bA = !(dA < r2lo) && dA <= r2hi;
+        const unsigned long long xA = __ballot(bA && pp_within(hx, hy, hz, q.x, q.y, q.z, r2));
+        const unsigned acc = __popc((unsigned)xA & sLo) + __popc((unsigned)(xA >> 32) & sHi);
+        if (lq < T && acc) b4_count_add(&counts[(size_t)__float_as_int(q.w) * T + lq], (int)acc);
+    }
+}
+// a sparse cell of a four-cell task: its three candidate runs
+__device__ __forceinline__ void b4_cell_rows(B4_CONST(v4f) sorted, B4_CNT counts, v4u g0, v4u g1, float hx, float hy, float hz, unsigned sLo,
+                                             unsigned sHi, float r2lo, float r2hi, double r2, int lq, int T) {
+    const unsigned aR[3] = {g0.x, g0.z, g1.x}, nR[3] = {g0.y, g0.w, g1.y};
+    unsigned long long band = 0;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) band |= b4_pairs1(sorted, counts, aR[rr], aR[rr] + nR[rr], hx, hy, hz, sLo, sHi, r2lo, r2hi, lq, T);
+    if (band) {
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) b4_pairs1_band(sorted, counts, aR[rr], aR[rr] + nR[rr], hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
     }
 }
 
@@ -875,6 +953,68 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             n0 = f0, n1 = f1;
         }
     }
+#if B4_LIGHT_TASKS
+    // ======== sparse cells (< 64 records of the scan): four cells to a task, a cell per chunk, each with its own candidates ========
+    if (!(dbg & 2)) {
+        B4_CONST(v4u) lhead = b4_const(reinterpret_cast<const v4u *>(SC.ltHead));
+        B4_CONST(v4u) lsegs = b4_const(reinterpret_cast<const v4u *>(SC.ltSegs));
+        unsigned t = w0;
+        v4u h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
+        v4f R[B4_CPT];
+        auto request = [&](const v4u a, const v4u b) {   // a lane without a record re-reads the cell's last one (an empty cell: record 0)
+            R[0] = __builtin_nontemporal_load(&rec[a.x + min((unsigned)lane, max(a.y, 1u) - 1u)]);
+            R[1] = __builtin_nontemporal_load(&rec[a.z + min((unsigned)lane, max(a.w, 1u) - 1u)]);
+            R[2] = __builtin_nontemporal_load(&rec[b.x + min((unsigned)lane, max(b.y, 1u) - 1u)]);
+            R[3] = __builtin_nontemporal_load(&rec[b.z + min((unsigned)lane, max(b.w, 1u) - 1u)]);
+        };
+        if (t < nL) {
+            h0 = lhead[2 * (size_t)t], h1 = lhead[2 * (size_t)t + 1];
+            request(h0, h1);
+            if (t + W < nL) m0 = lhead[2 * (size_t)(t + W)], m1 = lhead[2 * (size_t)(t + W) + 1];
+        }
+        while (t < nL) {
+            const unsigned nn[B4_CPT] = {h0.y, h0.w, h1.y, h1.w};
+            float hx[B4_CPT], hy[B4_CPT], hz[B4_CPT];
+            unsigned sLo[B4_CPT], sHi[B4_CPT];
+            int tv[B4_CPT];
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u) xform(R[u], (unsigned)lane < nn[u], &hx[u], &hy[u], &hz[u], &tv[u]);
+            if (lq < T) {
+#pragma unroll
+                for (int u = 0; u < B4_CPT; ++u) smask[u * T + lq] = 0ULL;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u)
+                if (tv[u] >= 0) atomicOr(&smask[u * T + tv[u]], 1ULL << lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < B4_CPT; ++u) {
+                const unsigned long long mv = lq < T ? smask[u * T + lq] : 0ULL;
+                sLo[u] = (unsigned)mv;
+                sHi[u] = (unsigned)(mv >> 32);
+            }
+            __builtin_amdgcn_wave_barrier();
+            v4u g[2 * B4_CPT];
+#pragma unroll
+            for (int u = 0; u < 2 * B4_CPT; ++u) g[u] = lsegs[8 * (size_t)t + u];
+            const unsigned tn = t + W;
+            if (tn < nL) request(m0, m1);
+            v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+            if (tn + W < nL) f0 = lhead[2 * (size_t)(tn + W)], f1 = lhead[2 * (size_t)(tn + W) + 1];
+            if (!(dbg & 1)) {
+#pragma unroll
+                for (int u = 0; u < B4_CPT; ++u)
+                    if (nn[u]) b4_cell_rows(sortedC, counts, g[2 * u], g[2 * u + 1], hx[u], hy[u], hz[u], sLo[u], sHi[u], r2lo, r2hi, r2, lq, T);
+            }
+            t = tn;
+            h0 = m0, h1 = m1;
+            m0 = f0, m1 = f1;
+        }
+    }
+#endif
 }
 
 // ======== the packed records of sparse cells, 64 at a time: every lane walks its own candidates ========
@@ -1145,7 +1285,14 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const int NG = (U + B4_FG - 1) / B4_FG;
     const size_t maxSegs = (size_t)BT + (size_t)(ntot / B4_SEG) + 1;
     // a cell with n >= 64 records of the scan gives ceil(ceil(n / 64) / 4) <= n / 64 tasks; one packed entry per tile
-    const size_t maxTasks = (size_t)(ntot / 64) + 16, maxLight = (size_t)(ntot / 64) + (size_t)BT + 16;
+    const size_t maxTasks = (size_t)(ntot / 64) + 16;
+#if B4_LIGHT_TASKS
+    // a sparse cell has a live point in the 3x3 cells around it: at most 9 cells per live point, four cells to a task (+ one partly
+    // filled task per tile)
+    const size_t maxLight = std::min<size_t>((size_t)(ntot / 4), (size_t)9 * (size_t)maxN / 4) + (size_t)BT + 16;
+#else
+    const size_t maxLight = (size_t)(ntot / 64) + (size_t)BT + 16;
+#endif
 
     // ---- arena ------------------------------------------------------------------------------------
     size_t need = 0;
@@ -1162,7 +1309,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
-        size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, lchunks, counts, cellRange;
+        size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, lchunks, ltHead, ltSegs, counts, cellRange;
     };
     std::vector<ScanOff> so((size_t)G);
     for (int s = 0; s < G; ++s) {
@@ -1173,7 +1320,14 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         so[(size_t)s].tmp = take((size_t)std::max(n, 1) * 16);
         so[(size_t)s].sorted = take((size_t)(std::max(n, 1) + 2) * 16);   // (b4_pairs reads candidates in pairs: up to one point past a run)
         so[(size_t)s].tasks = take(maxTasks * sizeof(B4Task));
+#if B4_LIGHT_TASKS
+        so[(size_t)s].lchunks = 0;
+        so[(size_t)s].ltHead = take(maxLight * 32);
+        so[(size_t)s].ltSegs = take(maxLight * 128);
+#else
         so[(size_t)s].lchunks = take(maxLight * sizeof(uint2));
+        so[(size_t)s].ltHead = so[(size_t)s].ltSegs = 0;
+#endif
         so[(size_t)s].counts = take((size_t)std::max(n, 1) * T * 4);
         so[(size_t)s].cellRange = take((size_t)BT * 64 * 8);
     }
@@ -1225,6 +1379,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.sorted = reinterpret_cast<float4 *>(base + o.sorted);
         d.tasks = base + o.tasks;
         d.lchunks = reinterpret_cast<uint2 *>(base + o.lchunks);
+        d.ltHead = reinterpret_cast<uint4 *>(base + o.ltHead);
+        d.ltSegs = reinterpret_cast<uint4 *>(base + o.ltSegs);
         d.cellRange = reinterpret_cast<uint2 *>(base + o.cellRange);
         d.pose = reinterpret_cast<const PoseEnt *>(dstage + stPose) + (size_t)s * std::max(U, 1);
         d.counts = sc.counts_dev ? sc.counts_dev : reinterpret_cast<int *>(base + o.counts);
@@ -1322,9 +1478,13 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         const char *lw_env = getenv("MODEST_PP4_LWG");
         unsigned lx = (unsigned)((lw_env ? atoi(lw_env) : 2) * ctx->num_cus) / (unsigned)G;   // two workgroups of sixteen wavefronts per CU
         if (lx < 2) lx = 2;
+#if !B4_LIGHT_TASKS
         const unsigned lldsB = b4_light_lds(U, lpose);
         if (lpose) b4_join_light<true><<<dim3(lx, (unsigned)G), B4_JT, lldsB, stream>>>(B, dsc, radius * radius, dbg);
         else b4_join_light<false><<<dim3(lx, (unsigned)G), B4_JT, lldsB, stream>>>(B, dsc, radius * radius, dbg);
+#else
+        (void)lx;
+#endif
     } else {   // no history: every count is zero
         for (int sc = 0; sc < G; ++sc)
             if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * T * 4, stream));
