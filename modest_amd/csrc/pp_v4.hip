@@ -24,7 +24,7 @@
 //     registers, applies the scan's own float32 pose to every record (transform_points' rounding, per (scan,
 //     frame)) and tests them against one wave-uniform candidate per step (read with a scalar load: the live
 //     point arrives in SGPRs): ballots + traversal-segmented popcounts, one global atomic per (candidate,
-//     task).  Sparse cells (< 64 records) are packed 64 to a wavefront and walk their own candidates.
+//     task).  Sparse cells (< 64 records) go four to a task, a cell per 64-lane chunk, each against its own candidates.
 //     (Round 4 dealt ITEMS of 24 tasks to whole workgroups, with the live window of a quad of tiles in LDS: four
 //     barriers and four dependent rounds of loads per item -- 34 of the join's 99 us per scan went there.)
 //
@@ -65,9 +65,6 @@ constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
 #endif
 constexpr int B4_JT = B4_JT_;                 // threads of a join workgroup
 constexpr int B4_MAXT = 64;
-#ifndef B4_LIGHT_TASKS
-#define B4_LIGHT_TASKS 1   // sparse cells as four-cell tasks of b4_join (0: the packed order walked lane by lane in b4_join_light)
-#endif
 constexpr int B4_POSE_LDS_MAX = 1024;       // union frames whose poses fit the LDS table of a join workgroup (50 KB)
 
 struct UFrame {   // a frame of the union, device side (96 bytes)
@@ -100,11 +97,9 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
 struct ScanDev {   // per scan (device table)
     const float *liveXyz;
     const unsigned *livePerm, *liveTab;
-    unsigned *cellCount, *cellStart, *blockSum, *ctrl;   // ctrl: [0] one-cell tasks, [1] packed chunks (b4_plan's cursors)
-    uint2 *cellRange;   // per (tile with tasks, cell): first record and count of the part of the cell this scan reads
+    unsigned *cellCount, *cellStart, *blockSum, *ctrl;   // ctrl: [0] one-cell tasks, [1] four-cell tasks (b4_plan's cursors)
     float4 *tmp, *sorted;
     void *tasks;       // B4Task x maxTasks
-    uint2 *lchunks;    // (tile, group of four chunks) x maxLight (B4_LIGHT_TASKS 0)
     uint4 *ltHead;     // four-cell tasks: (first record, records) x 4 per task = 2 x uint4, x maxLight
     uint4 *ltSegs;     // ... (a0, n0, a1, n1), (a2, n2, -, -) per cell = 8 x uint4 per task
     const PoseEnt *pose;
@@ -500,9 +495,10 @@ __global__ __launch_bounds__(256) void b4_live_scatter(Blk B, const ScanDev *__r
 // The join's work for one scan is a flat list of self-contained TASKS.  A one-cell task: at most 256 records of ONE cell
 // of the block store that has live points in the 3x3 cells around it ("heavy" cell: >= 64 records of the scan's own frames)
 // together with its candidates -- three runs of the scan's cell-sorted live points (the cell rows cy-1, cy, cy+1; a row's
-// three cells are contiguous).  The records of all other cells with live points nearby ("light") are packed, tile by tile,
-// into chunks of 64 (a list entry = (tile, group of four chunks)).  One wavefront per tile, lane = cell; list positions come from two atomic
-// counters per scan: the order of the list is free, every count is an integer sum.
+// three cells are contiguous).  All other cells with live points nearby ("light": < 64 records) go FOUR to a task -- a cell per
+// 64-lane chunk, each with its own three candidate runs (header: first record + count per cell; body: the runs).  One
+// wavefront per tile of the block's needed-tile list, lane = cell; list positions come from two atomic counters per scan:
+// the order of the lists is free, every count is an integer sum.
 struct B4Task {   // 32 bytes
     unsigned recStart, recEnd;           // records [recStart, recEnd) of the block store
     unsigned a0, n0, a1, n1, a2, n2;     // candidates: live points [a, a + n) of the scan's sorted array, per cell row
@@ -576,23 +572,17 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     }
     const unsigned TH = __shfl(incT, 63), LV = __shfl(incL, 63);
     if (TH + LV == 0u) continue;
-#if B4_LIGHT_TASKS
     // sparse cells: FOUR cells to a task (a cell per 64-lane chunk of the wavefront, each with its own three candidate runs)
     const bool isL = lv != 0u;
     const unsigned long long lmask = __ballot(isL);
     const unsigned nLc = (unsigned)__popcll(lmask), li = (unsigned)__popcll(lmask & ((1ULL << lane) - 1ULL));
     const unsigned nL = (nLc + 3) >> 2;   // <= 16
-#else
-    S.cellRange[(size_t)b * 64 + lane] = make_uint2(start, active ? n : 0u);   // (only tiles with work are read back: the light path)
-    const unsigned nL = (((LV + 63) >> 6) + 3) >> 2;   // units of four chunks (b4_join_light's B4_LCH), <= 16
-#endif
     unsigned tb = 0, lb = 0;
     if (lane == 0) {
         if (TH) tb = atomicAdd(&S.ctrl[0], TH);
         if (nL) lb = atomicAdd(&S.ctrl[1], nL);
     }
     tb = __shfl(tb, 0), lb = __shfl(lb, 0);
-#if B4_LIGHT_TASKS
     {
         unsigned *head = reinterpret_cast<unsigned *>(S.ltHead);
         if (isL) {
@@ -609,9 +599,6 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
             if (task < (unsigned)S.maxLight) *reinterpret_cast<uint2 *>(head + (size_t)task * 8 + (q & 3u) * 2) = make_uint2(0u, 0u);
         }
     }
-#else
-    if ((unsigned)lane < nL && lb + lane < (unsigned)S.maxLight) S.lchunks[lb + lane] = make_uint2((unsigned)b, (unsigned)lane);
-#endif
     uint4 *out = reinterpret_cast<uint4 *>(S.tasks);
     const unsigned first = tb + incT - th;
     for (unsigned k = 0; k < th; ++k) {
@@ -813,8 +800,8 @@ __host__ __device__ __forceinline__ unsigned b4_join_lds(int U, int T, bool lpos
 // Every wavefront works on its own: a static deal of the scan's task list (wavefront w of W takes tasks w, w + W, ...),
 // no workgroup barrier after the pose table is in place, no LDS window of live points.  A workgroup is as large as a CU holds
 // wavefronts of this kernel (1024 threads at 128 registers): one pose table per CU.
-template <bool LPOSE>
-__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg) {
+template <bool LPOSE, bool PROF>
+__global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg, unsigned long long *prof) {
     extern __shared__ __align__(16) unsigned char dynsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int lq = lane;
@@ -826,22 +813,25 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
     unsigned long long *smask = reinterpret_cast<unsigned long long *>(dynsm + poseB) + (size_t)wv * (B4_CPT * T);
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
-    B4_GLOBAL(unsigned) cellStart = b4_global(SC.cellStart);
-    B4_GLOBAL(unsigned) blockOff = b4_global(SC.blockSum);   // (b4_scan_finish: offsets of the 4096-cell scan blocks)
-    B4_GLOBAL(v4f) sortedG = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
     B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
     B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
     B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
-    B4_GLOBAL(v2u) cellRange = b4_global(reinterpret_cast<const v2u *>(SC.cellRange));
     B4_CONST(v4u) tasks = b4_const(reinterpret_cast<const v4u *>(SC.tasks));
-    B4_CONST(v2u) lchunks = b4_const(reinterpret_cast<const v2u *>(SC.lchunks));
     B4_CNT counts = (B4_CNT)(SC.counts);
-    const int CW = B.CW, CHc = B.CHc;
     const unsigned nH = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[0], (unsigned)SC.maxTasks));
     const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
     const unsigned W = gridDim.x * B4_JW;
     const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * B4_JW + (unsigned)wv));   // (wave-uniform: task descriptors and candidates are scalar loads)
 
+    // PROF (MODEST_PP4_DBG=512): wall time of this wavefront by phase -- 0 pose table, 1 one-cell tasks: transform (incl. the wait
+    // for the records), 2 masks, 3 pair phase, 4 four-cell tasks: segs + transform, 5 masks, 6 pair phase; 8 / 9 task counts
+    unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? __builtin_readcyclecounter() : 0ULL;
+#define B4_TICK(kk)                                                 \
+    if (PROF) {                                                     \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pacc[kk] += now_ - plast;                                   \
+        plast = now_;                                               \
+    }
     if (LPOSE) {   // the scan's poses: read once per workgroup
         float4 *pw = reinterpret_cast<float4 *>(dynsm);
         signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
@@ -854,6 +844,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
         __syncthreads();
     }
+    B4_TICK(0)
     // one record -> the scan's frame (transform_points' float32 chain); records of frames that are not part of the scan
     // and lanes without a record end up 1e30 away, *trv < 0
     auto xform = [&](const v4f R, bool valid, float *hx, float *hy, float *hz, int *trv) {
@@ -912,6 +903,11 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 if (u & 1) hx[u / 2].y = ax, hy[u / 2].y = ay, hz[u / 2].y = az;
                 else hx[u / 2].x = ax, hy[u / 2].x = ay, hz[u / 2].x = az;
             }
+            if (PROF) {   // (the transform's results exist: the wait for the records ends here)
+                asm volatile("" ::"v"(hx[0].x), "v"(hx[1].y));
+                ++pacc[8];
+            }
+            B4_TICK(1)
             // traversal masks of the chunks through LDS: every record ORs its lane bit into the word of its traversal, lane t
             // reads the word of traversal t (the LDS executes a wavefront's instructions in order; three rounds for the four
             // chunks: clear, OR, read)
@@ -933,6 +929,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 sHi[u] = (unsigned)(mv >> 32);
             }
             __builtin_amdgcn_wave_barrier();
+            if (PROF) asm volatile("" ::"v"(sLo[0]), "v"(sHi[3]));
+            B4_TICK(2)
             const unsigned aR[3] = {c0.z, c1.x, c1.z}, nR[3] = {c0.w, c1.y, c1.w};
             // the next task: its record loads are in flight during the pair phase below; the task after it: its descriptor
             const unsigned tn = t + W;
@@ -948,12 +946,12 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 if (nch <= 2) b4_pairs_rows<1>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
                 else b4_pairs_rows<2>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
             }
+            B4_TICK(3)
             t = tn;
             c0 = n0, c1 = n1;
             n0 = f0, n1 = f1;
         }
     }
-#if B4_LIGHT_TASKS
     // ======== sparse cells (< 64 records of the scan): four cells to a task, a cell per chunk, each with its own candidates ========
     if (!(dbg & 2)) {
         B4_CONST(v4u) lhead = b4_const(reinterpret_cast<const v4u *>(SC.ltHead));
@@ -979,6 +977,11 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             int tv[B4_CPT];
 #pragma unroll
             for (int u = 0; u < B4_CPT; ++u) xform(R[u], (unsigned)lane < nn[u], &hx[u], &hy[u], &hz[u], &tv[u]);
+            if (PROF) {
+                asm volatile("" ::"v"(hx[0]), "v"(hx[3]));
+                ++pacc[9];
+            }
+            B4_TICK(4)
             if (lq < T) {
 #pragma unroll
                 for (int u = 0; u < B4_CPT; ++u) smask[u * T + lq] = 0ULL;
@@ -997,6 +1000,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 sHi[u] = (unsigned)(mv >> 32);
             }
             __builtin_amdgcn_wave_barrier();
+            if (PROF) asm volatile("" ::"v"(sLo[0]), "v"(sHi[3]));
+            B4_TICK(5)
             v4u g[2 * B4_CPT];
 #pragma unroll
             for (int u = 0; u < 2 * B4_CPT; ++u) g[u] = lsegs[8 * (size_t)t + u];
@@ -1009,204 +1014,15 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 for (int u = 0; u < B4_CPT; ++u)
                     if (nn[u]) b4_cell_rows(sortedC, counts, g[2 * u], g[2 * u + 1], hx[u], hy[u], hz[u], sLo[u], sHi[u], r2lo, r2hi, r2, lq, T);
             }
+            B4_TICK(6)
             t = tn;
             h0 = m0, h1 = m1;
             m0 = f0, m1 = f1;
         }
     }
-#endif
-}
-
-// ======== the packed records of sparse cells, 64 at a time: every lane walks its own candidates ========
-// A kernel of its own: this path is a chain of dependent loads (cell table of the tile -> record -> pose -> live points)
-// with little arithmetic.  Eight wavefronts per SIMD (64 registers) hide one another's round trips, which the one-cell
-// tasks' kernel (128 registers) cannot; a unit is up to four chunks of ONE tile, so that the tile's cell table and the live
-// points of its window (8x8 cells + one cell of halo: ten runs of the sorted array, copied to LDS) are fetched once for them;
-// the scan's pose table sits in LDS as in b4_join.
-constexpr unsigned B4_LWIN = 128;   // live points of a tile's window kept in LDS per wavefront (more: read from memory)
-constexpr int B4_LCH = 4;           // chunks per unit
-__host__ __device__ __forceinline__ unsigned b4_light_lds(int U, bool lpose) {
-    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (64 * 4 + B4_LWIN * 16);
-}
-template <bool LPOSE>
-__global__ __launch_bounds__(B4_JT, 8) void b4_join_light(Blk B, const ScanDev *__restrict__ scans, double r2, int dbg) {
-    extern __shared__ __align__(16) unsigned char dynsm[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const ScanDev &SC = scans[blockIdx.y];
-    const int T = SC.T;
-    const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
-    const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
-    const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
-    unsigned *lsearch = reinterpret_cast<unsigned *>(dynsm + poseB) + wv * 64;
-    float4 *lwin = reinterpret_cast<float4 *>(dynsm + poseB + (size_t)B4_JW * 64 * 4) + (size_t)wv * B4_LWIN;
-    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
-    B4_GLOBAL(unsigned) cellStart = b4_global(SC.cellStart);
-    B4_GLOBAL(unsigned) blockOff = b4_global(SC.blockSum);
-    B4_GLOBAL(v4f) sortedG = b4_global(reinterpret_cast<const v4f *>(SC.sorted));
-    B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
-    B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
-    B4_GLOBAL(v2u) cellRange = b4_global(reinterpret_cast<const v2u *>(SC.cellRange));
-    B4_CONST(v2u) lchunks = b4_const(reinterpret_cast<const v2u *>(SC.lchunks));
-    B4_CNT counts = (B4_CNT)(SC.counts);
-    const int CW = B.CW, CHc = B.CHc;
-    const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
-    const unsigned W = gridDim.x * B4_JW;
-    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * B4_JW + (unsigned)wv));
-    if (LPOSE) {   // the scan's poses: read once per workgroup
-        float4 *pw = reinterpret_cast<float4 *>(dynsm);
-        signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
-        for (int f = tid; f < B.U; f += B4_JT) {
-            const v4f a = pose[4 * (size_t)f], b = pose[4 * (size_t)f + 1], c = pose[4 * (size_t)f + 2], d = pose[4 * (size_t)f + 3];
-            pw[3 * f] = make_float4(a.x, a.y, a.z, a.w);
-            pw[3 * f + 1] = make_float4(b.x, b.y, b.z, b.w);
-            pw[3 * f + 2] = make_float4(c.x, c.y, c.z, c.w);
-            tw[f] = (signed char)__float_as_int(d.x);
-        }
-        __syncthreads();
-    }
-    if (dbg & 2) return;
-#pragma unroll 1
-    for (unsigned id = w0; id < nL; id += W) {
-        const v2u ck = lchunks[id];
-        const int b = (int)ck.x;
-        const v2u cr = cellRange[(size_t)b * 64 + lane];   // lane = cell of the tile
-        const unsigned lv = (cr.y > 0u && cr.y < B4_HEAVY) ? cr.y : 0u;
-        const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
-        unsigned sa[3], sn[3];
-        {
-            const int xa = max(cx - 1, 0), xb = min(cx + 1, CW - 1);
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int yy = cy + dy;
-                const bool in = yy >= 0 && yy < CHc;
-                const size_t ia_ = (size_t)(in ? yy : cy) * CW + xa, ie_ = (size_t)(in ? yy : cy) * CW + xb + 1;
-                const unsigned s_ = cellStart[ia_] + blockOff[ia_ / B4_SCAN], e_ = cellStart[ie_] + blockOff[ie_ / B4_SCAN];
-                sa[dy + 1] = s_;
-                sn[dy + 1] = in ? e_ - s_ : 0u;
-            }
-        }
-        // the window's ten rows: lane r < 10 holds row r (first live point in the sorted array, length)
-        unsigned rowG = 0, rowN = 0;
-        {
-            const int r = min(lane, 9);
-            const int yy = (b / B.BW) * 8 - 1 + r;
-            const int xlo = max((b % B.BW) * 8 - 1, 0), xhi = min((b % B.BW) * 8 + 8, CW - 1);
-            const bool in = yy >= 0 && yy < CHc && lane < 10;
-            const size_t ia_ = (size_t)(in ? yy : 0) * CW + xlo, ie_ = (size_t)(in ? yy : 0) * CW + xhi + 1;
-            const unsigned s_ = cellStart[ia_] + blockOff[ia_ / B4_SCAN], e_ = cellStart[ie_] + blockOff[ie_ / B4_SCAN];
-            rowG = s_;
-            rowN = in ? e_ - s_ : 0u;
-        }
-        unsigned inc = lv;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned x = __shfl_up(inc, o);
-            if (lane >= o) inc += x;
-        }
-        const unsigned LV = __shfl(inc, 63);
-        unsigned rowInc = rowN;
-        for (int o = 1; o < 16; o <<= 1) {
-            const unsigned x = __shfl_up(rowInc, o);
-            if (lane >= o) rowInc += x;
-        }
-        const unsigned L = __shfl(rowInc, 9);
-        const bool inLds = L <= B4_LWIN;
-        const unsigned rowDelta = (rowInc - rowN) - rowG;   // LDS index = index in the sorted array + delta of its window row
-        __builtin_amdgcn_wave_barrier();   // (the previous unit of this wavefront has been walked by every lane)
-        lsearch[lane] = inc;   // end of cell `lane` in the packed order
-        if (inLds) {
-#pragma unroll 1
-            for (int r = 0; r < 10; ++r) {
-                const unsigned g = __builtin_amdgcn_readlane(rowG, r), nr = __builtin_amdgcn_readlane(rowN, r);
-                const unsigned d = __builtin_amdgcn_readlane(rowDelta, r);
-                for (unsigned e = lane; e < nr; e += 64) {
-                    const v4f w = sortedG[g + e];
-                    lwin[g + e + d] = make_float4(w.x, w.y, w.z, w.w);
-                }
-            }
-            // a cell's three candidate runs as LDS indices: the window row of cell row (lane >> 3) + dy is (lane >> 3) + dy + 1
-#pragma unroll
-            for (int d3 = 0; d3 < 3; ++d3) sa[d3] += __shfl(rowDelta, (lane >> 3) + d3);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned vEnd = (dbg & 64) ? 0u : min(LV, (ck.y + 1u) * (64u * B4_LCH));
-#pragma unroll 1
-        for (unsigned vb = ck.y * (64u * B4_LCH); vb < vEnd; vb += 64) {
-            const unsigned v = vb + (unsigned)lane;
-            const bool valid = v < LV;
-            int kc = 0;
-            if (valid) {   // first cell whose end lies behind v (cells outside the packed order have no extent)
-                int lo = 0, hi = 63;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (lsearch[mid] > v) hi = mid;
-                    else lo = mid + 1;
-                }
-                kc = lo;
-            }
-            // the cell's table row lives in lane kc's registers
-            const unsigned kEnd = __shfl(inc, kc), kLv = __shfl(lv, kc), kRec = __shfl(cr.x, kc);
-            const unsigned a0 = __shfl(sa[0], kc), n0 = __shfl(sn[0], kc), a1 = __shfl(sa[1], kc), n1 = __shfl(sn[1], kc);
-            const unsigned a2 = __shfl(sa[2], kc), n2 = __shfl(sn[2], kc);
-            const v4f R = rec[valid ? kRec + (v - (kEnd - kLv)) : 0u];
-            const int slot = __float_as_int(R.w) >> 6;
-            float4 p0, p1, p2;
-            int tp;
-            if (LPOSE) {
-                p0 = poseL[3 * slot], p1 = poseL[3 * slot + 1], p2 = poseL[3 * slot + 2];
-                tp = travL[slot];
-            } else {
-                const v4f a = pose[4 * (size_t)slot], bq = pose[4 * (size_t)slot + 1], c = pose[4 * (size_t)slot + 2];
-                p0 = make_float4(a.x, a.y, a.z, a.w), p1 = make_float4(bq.x, bq.y, bq.z, bq.w), p2 = make_float4(c.x, c.y, c.z, c.w);
-                tp = __float_as_int(pose[4 * (size_t)slot + 3].x);
-            }
-            float hx = R.x * p0.x;
-            hx = fmaf(R.y, p0.y, hx);
-            hx = fmaf(R.z, p0.z, hx);
-            hx = hx + p0.w;
-            float hy = R.x * p1.x;
-            hy = fmaf(R.y, p1.y, hy);
-            hy = fmaf(R.z, p1.z, hy);
-            hy = hy + p1.w;
-            float hz = R.x * p2.x;
-            hz = fmaf(R.y, p2.y, hz);
-            hz = fmaf(R.z, p2.z, hz);
-            hz = hz + p2.w;
-            const bool on = valid && tp >= 0;   // (a NaN coordinate -- remove_center -- passes no test below)
-            const unsigned n01 = n0 + n1, nAll = n01 + n2;
-            const unsigned b1 = a1 - n0, b2 = a2 - n01;
-            const unsigned own = (on && !(dbg & 16)) ? nAll : 0u;
-            const size_t crow = (size_t)(on ? tp : 0);
-            for (unsigned p0_ = 0; __any(p0_ < own); p0_ += 4) {
-                float4 qq[4];
-                bool act[4];
-                if (inLds) {
-#pragma unroll
-                    for (unsigned u = 0; u < 4; ++u) {
-                        const unsigned p = p0_ + u;
-                        act[u] = p < own;
-                        qq[u] = lwin[act[u] ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u];
-                    }
-                } else {
-#pragma unroll
-                    for (unsigned u = 0; u < 4; ++u) {   // four candidates per step: four loads in flight
-                        const unsigned p = p0_ + u;
-                        act[u] = p < own;
-                        const v4f w = sortedG[act[u] ? p + (p < n0 ? a0 : (p < n01 ? b1 : b2)) : 0u];
-                        qq[u] = make_float4(w.x, w.y, w.z, w.w);
-                    }
-                }
-#pragma unroll
-                for (unsigned u = 0; u < 4; ++u) {
-                    const float fx = qq[u].x - hx, fy = qq[u].y - hy, fz = qq[u].z - hz;
-                    const float d2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                    bool hit = act[u] && d2 < r2lo;
-                    if (act[u] && !hit && d2 <= r2hi) hit = pp_within(hx, hy, hz, qq[u].x, qq[u].y, qq[u].z, r2);   // practically never: exact float64 re-test
-                    if (hit && !(dbg & 32)) b4_count_add(&counts[(size_t)__float_as_int(qq[u].w) * T + crow], 1);
-                }
-            }
-        }
-    }
+    if (PROF && lane == 0)
+        for (int kk = 0; kk < 10; ++kk) atomicAdd(&prof[kk], pacc[kk]);
+#undef B4_TICK
 }
 
 __global__ void b4_entropy(const ScanDev *__restrict__ scans) {
@@ -1284,15 +1100,11 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const int NC = CW * CHc, NCpad = (NC + B4_SCAN - 1) / B4_SCAN * B4_SCAN, nScanBlk = NCpad / B4_SCAN;
     const int NG = (U + B4_FG - 1) / B4_FG;
     const size_t maxSegs = (size_t)BT + (size_t)(ntot / B4_SEG) + 1;
-    // a cell with n >= 64 records of the scan gives ceil(ceil(n / 64) / 4) <= n / 64 tasks; one packed entry per tile
+    // a cell with n >= 64 records of the scan gives ceil(ceil(n / 64) / 4) <= n / 64 tasks
     const size_t maxTasks = (size_t)(ntot / 64) + 16;
-#if B4_LIGHT_TASKS
     // a sparse cell has a live point in the 3x3 cells around it: at most 9 cells per live point, four cells to a task (+ one partly
     // filled task per tile)
     const size_t maxLight = std::min<size_t>((size_t)(ntot / 4), (size_t)9 * (size_t)maxN / 4) + (size_t)BT + 16;
-#else
-    const size_t maxLight = (size_t)(ntot / 64) + (size_t)BT + 16;
-#endif
 
     // ---- arena ------------------------------------------------------------------------------------
     size_t need = 0;
@@ -1309,7 +1121,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
-        size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, lchunks, ltHead, ltSegs, counts, cellRange;
+        size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, ltHead, ltSegs, counts;
     };
     std::vector<ScanOff> so((size_t)G);
     for (int s = 0; s < G; ++s) {
@@ -1320,16 +1132,9 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         so[(size_t)s].tmp = take((size_t)std::max(n, 1) * 16);
         so[(size_t)s].sorted = take((size_t)(std::max(n, 1) + 2) * 16);   // (b4_pairs reads candidates in pairs: up to one point past a run)
         so[(size_t)s].tasks = take(maxTasks * sizeof(B4Task));
-#if B4_LIGHT_TASKS
-        so[(size_t)s].lchunks = 0;
         so[(size_t)s].ltHead = take(maxLight * 32);
         so[(size_t)s].ltSegs = take(maxLight * 128);
-#else
-        so[(size_t)s].lchunks = take(maxLight * sizeof(uint2));
-        so[(size_t)s].ltHead = so[(size_t)s].ltSegs = 0;
-#endif
         so[(size_t)s].counts = take((size_t)std::max(n, 1) * T * 4);
-        so[(size_t)s].cellRange = take((size_t)BT * 64 * 8);
     }
     // staged block: [UFrame x U][chunkTab][ScanDev x G][PoseEnt x G x U]
     const size_t stFrames = 0, stChunks = arena_sz((size_t)std::max(U, 1) * sizeof(UFrame));
@@ -1378,10 +1183,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.tmp = reinterpret_cast<float4 *>(base + o.tmp);
         d.sorted = reinterpret_cast<float4 *>(base + o.sorted);
         d.tasks = base + o.tasks;
-        d.lchunks = reinterpret_cast<uint2 *>(base + o.lchunks);
         d.ltHead = reinterpret_cast<uint4 *>(base + o.ltHead);
         d.ltSegs = reinterpret_cast<uint4 *>(base + o.ltSegs);
-        d.cellRange = reinterpret_cast<uint2 *>(base + o.cellRange);
         d.pose = reinterpret_cast<const PoseEnt *>(dstage + stPose) + (size_t)s * std::max(U, 1);
         d.counts = sc.counts_dev ? sc.counts_dev : reinterpret_cast<int *>(base + o.counts);
         d.H = sc.H_dev;
@@ -1438,14 +1241,12 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     if (!attr_done[ctx->device & 63]) {
         MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_seg_scatter),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, B4_SEG * 16));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)b4_join_lds(B4_POSE_LDS_MAX, B4_MAXT, true)));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)b4_join_lds(0, B4_MAXT, false)));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join_light<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)b4_light_lds(B4_POSE_LDS_MAX, true)));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join_light<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)b4_light_lds(0, false)));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)b4_join_lds(B4_POSE_LDS_MAX, B4_MAXT, true)));
         attr_done[ctx->device & 63] = true;
     }
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
@@ -1469,22 +1270,23 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         const char *jw_env = getenv("MODEST_PP4_JWG");
         unsigned jx = (unsigned)((jw_env ? atoi(jw_env) : 1) * ctx->num_cus) / (unsigned)G;   // one workgroup of 16 wavefronts per CU
         if (jx < 2) jx = 2;
-        const char *dbg_env = getenv("MODEST_PP4_DBG");   // ablations: 1 no pair loop, 2 no packed chunks, 8 no one-cell tasks
+        const char *dbg_env = getenv("MODEST_PP4_DBG");   // ablations: 1 no pair phase, 2 no four-cell tasks, 8 no one-cell tasks, 256 poses from memory, 512 phase times
         const int dbg = dbg_env ? atoi(dbg_env) : 0;
         const bool lpose = U <= B4_POSE_LDS_MAX && !(dbg & 256);
         const unsigned ldsB = b4_join_lds(U, T, lpose);
-        if (lpose) b4_join<true><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg);
-        else b4_join<false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg);
-        const char *lw_env = getenv("MODEST_PP4_LWG");
-        unsigned lx = (unsigned)((lw_env ? atoi(lw_env) : 2) * ctx->num_cus) / (unsigned)G;   // two workgroups of sixteen wavefronts per CU
-        if (lx < 2) lx = 2;
-#if !B4_LIGHT_TASKS
-        const unsigned lldsB = b4_light_lds(U, lpose);
-        if (lpose) b4_join_light<true><<<dim3(lx, (unsigned)G), B4_JT, lldsB, stream>>>(B, dsc, radius * radius, dbg);
-        else b4_join_light<false><<<dim3(lx, (unsigned)G), B4_JT, lldsB, stream>>>(B, dsc, radius * radius, dbg);
-#else
-        (void)lx;
-#endif
+        if ((dbg & 512) && lpose) {   // MODEST_PP4_DBG=512: wall time of the join's wavefronts by phase (blocking; diagnostics only)
+            unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[10];
+            MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));
+            b4_join<true, true><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, dprof);
+            MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+            MODEST_HIP_CHECK(hipMemcpy(hprof, dprof, sizeof(hprof), hipMemcpyDeviceToHost));
+            const double wv = (double)jx * G * B4_JW, us = 1.0 / 100.0;   // s_memtime ticks at 100 MHz
+            fprintf(stderr, "[b4_join] per wavefront, us: pose table %.1f | one-cell tasks: records + transform %.1f, masks %.1f, pairs %.1f | "
+                            "four-cell tasks: records + transform %.1f, masks %.1f, pairs %.1f || per scan: one-cell tasks %.0f, four-cell tasks %.0f\n",
+                    hprof[0] * us / wv, hprof[1] * us / wv, hprof[2] * us / wv, hprof[3] * us / wv, hprof[4] * us / wv, hprof[5] * us / wv,
+                    hprof[6] * us / wv, (double)hprof[8] / G, (double)hprof[9] / G);
+        } else if (lpose) b4_join<true, false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
+        else b4_join<false, false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
     } else {   // no history: every count is zero
         for (int sc = 0; sc < G; ++sc)
             if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * T * 4, stream));

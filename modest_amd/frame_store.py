@@ -597,7 +597,7 @@ class FrameStore:
         """The tables of modest_pp_score_block for these scans, or None when the block path does not apply: more than
         64 traversals / scans, a frame with points outside its table, poses that disagree with the lattice by more
         than 1e-4 m, live scans further apart than the block window, mixed remove_center flags -- or (unless forced)
-        too little sharing (fewer than 4 scans, union > 2 x a scan's frames): the block path bins the UNION of the scans' frames once, which pays when the scans are
+        too little sharing (fewer than 4 scans, union > 3 x a scan's frames): the block path bins the UNION of the scans' frames once, which pays when the scans are
         consecutive scans of a shard (35 of 36 frames per traversal shared, split_traintest.py:64,97)."""
         env = os.environ.get("MODEST_PP_BLOCK", "")
         if force is None:
@@ -636,7 +636,9 @@ class FrameStore:
                 # round 5 (wave-independent join, tools/pp_block_probe.py --scans B): block 185 / 157 / 142 / 127 us per scan at
                 # B = 4 / 5 / 6 / 8 against 210 / 206 / 206 / 197 for the chain; B = 3: 229 against 220
                 per_scan = members / B
-                if B < 4 or len(us) > 2.0 * per_scan or per_scan < 12 * T:
+                # ... and on windows chosen by the reference's rule (synth.make_shard_matched; profiles/r05_sharing_sensitivity.json):
+                # union 0.94 / 1.89 / 1.92 / 2.07 / 2.52 x a scan's frames -> 106 / 120 / 130 / 123 / 151 us against 193-200
+                if B < 4 or len(us) > 3.0 * per_scan or per_scan < 12 * T:
                     return None
             if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([np.unique(allh), lslots])):
                 return None

@@ -53,7 +53,7 @@ def test_block_equals_oracle_and_chain(gpu, nusc, T, F, S):
 
 def test_block_choice_and_fallbacks(gpu):
     """The store takes the block path on its own from four scans that share most of their frames (>= 12 frames per
-    traversal, union <= 2 x a scan's frames); shorter windows, few scans, a frame
+    traversal, union <= 3 x a scan's frames); shorter windows, few scans, a frame
     with points outside its table, poses that disagree with the lattice and a radius other than the store's all take the
     per-scan chain -- with identical results."""
     import torch

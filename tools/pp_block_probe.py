@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shards", type=int, default=2, help="distinct shards cycled through in the timing loop")
     ap.add_argument("--stream", action="store_true", help="run on a created stream instead of the null stream")
+    ap.add_argument("--json-out", type=str, default="", help="append one JSON line with the run's numbers to this file")
     ap.add_argument("--matched", type=str, default="", help="live_speed,hist_lo,hist_hi: windows chosen by the reference's rule "
                     "(synth.make_shard_matched, split_traintest.py:79-101) instead of frames i..i+F-1")
     a = ap.parse_args()
@@ -86,19 +87,32 @@ def main():
                 ok &= e
     print("PARITY", "OK" if ok else "FAILED", "block calls", getattr(store, "block_calls", 0), flush=True)
     side = torch.cuda.Stream(device=dev) if a.stream else torch.cuda.current_stream(dev)
+    report = dict(scans=a.scans, n_live=a.n, traversals=a.trav, nusc=bool(a.nusc), matched=a.matched or None, parity_ok=bool(ok),
+                  sharing=(synth.sharing_stats(shards[0], a.scans) if a.matched else
+                           dict(members_per_scan=a.trav * a.frames, union_over_members=(a.frames + a.scans - 1) / a.frames)))
     for mode in (True, False):
-        ctx.profile_begin(a.reps * a.shards + 4)
+        ctx.profile_begin(8 * a.reps * a.shards + 4)
         with torch.cuda.stream(side):
             for r in range(a.reps):
                 for lives, descs in tabs:
                     store.pp_score_batch(lives, descs, T, ctx=ctx, block=mode)
         torch.cuda.synchronize()
-        ms = ctx.profile_collect(a.reps * a.shards + 4)
+        ms = np.asarray(ctx.profile_collect(8 * a.reps * a.shards + 4))
+        calls = a.reps * a.shards
+        if len(ms) > calls and len(ms) % calls == 0:   # (the per-scan chain splits a call of more than 8 scans into several marks)
+            ms = ms.reshape(calls, -1).sum(axis=1)
         per = float(np.mean(ms[a.shards:])) / a.scans
         members = float(np.mean([len(sc.hist) for sh in shards for sc in sh.scans]))
         alg = 12 * members * a.n + 16 * a.n   # (a repeated frame is stacked, and counted, as often as it is listed)
         print(f"{'block' if mode else 'chain'}: {np.mean(ms[a.shards:]):.3f} ms per call of {a.scans} scans = {per * 1e3:.1f} us/scan "
               f"-> {alg / per / 1e6:.0f} GB/s = {alg / per / 1e6 / 8000 * 100:.1f} % of 8 TB/s", flush=True)
+        report["block_us_per_scan" if mode else "chain_us_per_scan"] = per * 1e3
+        report["block_frac" if mode else "chain_frac"] = alg / per / 1e6 / 8000
+        report["algorithmic_bytes_per_scan"] = alg
+    if a.json_out:
+        import json
+        with open(a.json_out, "a") as fh:
+            fh.write(json.dumps(report) + "\n")
 
 
 if __name__ == "__main__":
