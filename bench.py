@@ -58,7 +58,7 @@ HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s sp
 # 1 580-1 650, 5 x 4 1 520-1 710, 4 x 5 1 340-1 610), so the whole pool is used; a run with fewer than
 # STEADY_STEPS_PER_HELPER steps per helper also reports `steady_state`: the same pool over 24 steps per
 # helper, measured after the contract region with its own barrier / synchronise bracket.
-MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "2"))
+MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "4"))
 STEADY_STEPS_PER_HELPER = 24
 
 
