@@ -145,3 +145,60 @@ def test_ransac_deviation_does_not_change_labels(gpu):
             if not np.array_equal(labels, ref["labels"]) or len(objs) != len(ref["objs"]):
                 bad.append((sid, seed))
     assert not bad, bad
+
+
+def _block_full_size(gpu, n_live, T, F, nusc, matched=None):
+    """16 consecutive scans of a shard at the benchmarked size through ONE modest_pp_score_block call (what the CLI and
+    bench.py run, FrameStore.pp_score_batch(block=True)); counts of scans 0 / 7 / 15 against scipy's cKDTree on the stacked,
+    transformed history (pre_compute_pp_score.py:132-150,188-193; all host threads)."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    from oracle import pp_score as opp
+    S = 16
+    if matched is None:
+        sh = synth.make_shard(S, n_live=n_live, n_trav=T, n_frames=F, nusc=nusc, seed=4)
+    else:
+        sh = synth.make_shard_matched(S, n_live=n_live, n_trav=T, nusc=nusc, live_speed=matched[0], hist_speeds=matched[1:], seed=4)
+    store = FrameStore(gpu, 0.3)
+    items, ids = [], {}
+    for t, tr in enumerate(sh.tracks):
+        for j, (raw, W) in enumerate(tr):
+            ids[(t, j)] = len(ids)
+            items.append((ids[(t, j)], torch.from_numpy(raw).to(gpu), W))
+    lives = []
+    for sc in sh.scans:
+        items.append((10 ** 6 + sc.index, torch.from_numpy(sc.live_raw).to(gpu), sc.live_W))
+        lives.append(10 ** 6 + sc.index)
+    store.insert_many(items)
+    descs = [store.describe(lives[i], sc.live_rel, [ids[h] for h in sc.hist], [t for t, _ in sc.hist], sc.rels, nusc)
+             for i, sc in enumerate(sh.scans)]
+    n0 = getattr(store, "block_calls", 0)
+    Hs, cs = store.pp_score_batch(lives, descs, T, return_counts=True, block=True)
+    assert getattr(store, "block_calls", 0) == n0 + 1, "the block path declined the benchmarked shape"
+    torch.cuda.synchronize()
+    for i in (0, 7, 15):
+        lv, hist = sh.stacked(i)
+        Href, cref = opp.pp_score(lv, hist, 0.3, workers=-1)
+        assert np.array_equal(cs[i].cpu().numpy().astype(np.int64), cref), i
+        assert np.max(np.abs(Hs[i].cpu().numpy().astype(np.float64) - Href)) <= 1e-6   # compute_ephe_score's tolerance (measured 0)
+        assert int(cref.sum()) > 1_000_000
+    return sh
+
+
+def test_config3_block_of_16_scans_full_size(gpu):
+    """BASELINE config 3 through the block path: 16 consecutive scans x (30 000 live points vs 10 x 36 frames)."""
+    sh = _block_full_size(gpu, 30_000, 10, 36, False)
+    assert sum(len(sh.tracks[t][j][0]) for t, j in sh.scans[0].hist) == 10_800_000
+
+
+def test_config5_block_of_16_scans_full_size(gpu):
+    """BASELINE config 5 through the block path: nuScenes shape, remove_center on the history, 35 k x 20 x 16."""
+    _block_full_size(gpu, 35_000, 20, 16, True)
+
+
+def test_config3_block_on_reference_rule_windows_full_size(gpu):
+    """... and on windows chosen as the reference chooses them (split_traintest.py:79-101: repeated frames at the fast traversals,
+    a third of the frames shared at the slow ones; live 8 m/s, history 3-15 m/s)."""
+    sh = _block_full_size(gpu, 30_000, 10, 36, False, matched=(8.0, 3.0, 15.0))
+    assert any(len(set(sc.hist)) < len(sc.hist) for sc in sh.scans)   # the lists do repeat frames

@@ -132,3 +132,33 @@ def test_rccl_process_group_at_world_size_one(gpu, tmp_path):
     assert fa == sorted(os.listdir(os.path.join(forced, "pp"))) and len(fa) == n
     match, mismatch, err = filecmp.cmpfiles(os.path.join(plain, "pp"), os.path.join(forced, "pp"), fa, shallow=False)
     assert not mismatch and not err
+
+
+def test_bench_two_ranks_two_helpers_one_gpu(gpu):
+    """bench.py's multi-rank path without a multi-GPU node: `--gpus 2 --procs 2` under its own
+    torch.distributed.run launch, both ranks and their four helper processes on GPU 0 (MODEST_DIST_BACKEND=gloo).  One JSON
+    line from rank 0, both ranks counted by an all-reduce, whole-job throughput over the max of the ranks' clocks; the line
+    carries every helper's start-up seconds and peak resident set (what an 8 x 8 run multiplies by 64: DESIGN section 6)."""
+    import time
+    env = dict(os.environ, MODEST_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--procs", "2", "--steps", "8", "--warmup", "2", "--scans", "8",
+           "--shard-scans", "8", "--n-live", "3000", "--frames", "4", "--traversals", "3", "--cli-scans", "0", "--cpu-scans", "0"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["rccl_world_size"] == 2 and cfg["rccl_ranks_seen"] == 2 and cfg["process_group_backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["steps"] == 8 and d["value"] > 0
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]   # whole job: both ranks' scans over the slower rank's clock
+    assert cfg["host_processes_per_gpu"] == 2 and len(cfg["startup"]["helper_seconds"]) == 2
+    assert max(cfg["startup"]["helper_peak_rss_mb"]) < 16 * 1024
+    assert wall < 300, wall
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu.json"), "w") as f:
+        json.dump(dict(wall_seconds=wall, line=d), f, indent=1)
