@@ -48,6 +48,13 @@ int modest_ctx_destroy(modest_ctx *ctx);
  * live index build and the last join) -- is bracketed by a HIP event pair on the launch stream; collect
  * returns the elapsed milliseconds of up to `cap` calls since begin and
  * disables the hook.                                                          */
+/* The context's scratch arena grows on demand (a grow = device synchronise + free + allocate: tens of milliseconds when several
+ * processes share the GPU).  A caller that knows what is coming -- the CLI before its first batch, which is shorter than the
+ * later ones -- takes the arena in ONE driver call up front.  No reference counterpart (the reference allocates per call).  */
+int modest_ctx_reserve_arena(modest_ctx *ctx, uint64_t bytes);
+/* Loads the library's device code now (the HIP runtime loads a translation unit's code object at the first launch of one of its
+ * kernels: ~0.1 s spread over the first scan of a process otherwise).  The CLIs call it before their loop clocks start.        */
+int modest_warmup(modest_ctx *ctx);
 int modest_ctx_profile_begin(modest_ctx *ctx, int capacity);
 int modest_ctx_profile_collect(modest_ctx *ctx, float *ms_out_host, int cap,
                                int *n_out_host);

@@ -27,6 +27,8 @@ SIGNATURES = {
     "modest_device_count": (C.c_int, []),
     "modest_ctx_create": (C.c_int, [C.c_int, C.POINTER(VP)]),
     "modest_ctx_destroy": (C.c_int, [VP]),
+    "modest_ctx_reserve_arena": (C.c_int, [VP, C.c_uint64]),
+    "modest_warmup": (C.c_int, [VP]),
     "modest_ctx_profile_begin": (C.c_int, [VP, C.c_int]),
     "modest_ctx_profile_collect": (C.c_int, [VP, VP, C.c_int, VP]),
     "modest_transform_points": (C.c_int, [VP, VP, C.c_int64, C.c_int, VP, C.c_int, VP, VP, VP]),
@@ -138,6 +140,14 @@ class Context:
         if getattr(self, "_counter", None) is None:
             self._counter = torch.zeros((16,), dtype=torch.int32).pin_memory()
         return self._counter
+
+    def warmup(self) -> None:
+        """load the library's device code now instead of at the first launch of every translation unit"""
+        check(load().modest_warmup(self._h), "modest_warmup")
+
+    def reserve_arena(self, nbytes: int) -> None:
+        """take the scratch arena in one driver call (it grows on demand otherwise: synchronise + free + allocate)"""
+        check(load().modest_ctx_reserve_arena(self._h, int(nbytes)), "modest_ctx_reserve_arena")
 
     def profile_begin(self, capacity: int = 4096) -> None:
         check(load().modest_ctx_profile_begin(self._h, int(capacity)), "modest_ctx_profile_begin")

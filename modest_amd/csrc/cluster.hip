@@ -1599,3 +1599,9 @@ int modest_mask_chain_cluster(modest_mask_chain_scan *S, int B, modest_mask_chai
     }
     return MODEST_OK;
 }
+
+// modest_warmup (ctx.hip): resolving one kernel of this translation unit makes the runtime load its code object now
+extern "C" void modest_warm_cluster(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(cg_count));
+}

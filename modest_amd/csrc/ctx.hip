@@ -179,6 +179,40 @@ int modest_ctx_reserve(modest_ctx *ctx, size_t bytes) {
     return MODEST_OK;
 }
 
+extern "C" void modest_warm_boxfilter(void);
+extern "C" void modest_warm_boxfit(void);
+extern "C" void modest_warm_cluster(void);
+extern "C" void modest_warm_cluster_stats(void);
+extern "C" void modest_warm_iou3d(void);
+extern "C" void modest_warm_plane(void);
+extern "C" void modest_warm_pp_count(void);
+extern "C" void modest_warm_pp_frames(void);
+extern "C" void modest_warm_pp_v4(void);
+extern "C" void modest_warm_transform(void);
+extern "C" int modest_warmup(modest_ctx *ctx) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    modest_warm_boxfilter();
+    modest_warm_boxfit();
+    modest_warm_cluster();
+    modest_warm_cluster_stats();
+    modest_warm_iou3d();
+    modest_warm_plane();
+    modest_warm_pp_count();
+    modest_warm_pp_frames();
+    modest_warm_pp_v4();
+    modest_warm_transform();
+    (void)hipGetLastError();
+    return MODEST_OK;
+}
+
+extern "C" int modest_ctx_reserve_arena(modest_ctx *ctx, uint64_t bytes) {
+    MODEST_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MODEST_REQUIRE(bytes < (1ULL << 40), "absurd arena size");
+    MODEST_HIP_CHECK(hipSetDevice(ctx->device));
+    return modest_ctx_reserve(ctx, (size_t)bytes);
+}
+
 int modest_ctx_reserve_pinned(modest_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->pinned_bytes) return MODEST_OK;
     MODEST_HIP_CHECK(hipDeviceSynchronize());

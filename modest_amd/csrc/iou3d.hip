@@ -458,3 +458,9 @@ extern "C" int modest_boxes_iou_bev_host(modest_ctx *ctx, const float *a_host, i
     memcpy(out_host, pout, (size_t)na * nb * 4);
     return MODEST_OK;
 }
+
+// modest_warmup (ctx.hip): resolving one kernel of this translation unit makes the runtime load its code object now
+extern "C" void modest_warm_iou3d(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(nms_trig));
+}

@@ -957,3 +957,9 @@ extern "C" int modest_pp_score(modest_ctx *ctx, const float *live, int n_live, c
     const int32_t *cN = counts ? counts : static_cast<const int32_t *>(tail);
     return modest_pp_entropy(ctx, cN, n_live, n_trav, H, stream_);
 }
+
+// modest_warmup (ctx.hip): resolving one kernel of this translation unit makes the runtime load its code object now
+extern "C" void modest_warm_pp_count(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(pp_live_scatter));
+}

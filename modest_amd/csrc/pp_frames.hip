@@ -393,3 +393,9 @@ extern "C" int modest_pp_score_frames_batch(modest_ctx *ctx, int n_scans, const 
     return modest_pp3_frames_batch(ctx, n_scans, live, live_perm_dev, frames, n_frames, n_trav, radius, counts_dev, H_dev,
                                    as_stream(stream_));
 }
+
+// modest_warmup (ctx.hip): resolving one kernel of this translation unit makes the runtime load its code object now
+extern "C" void modest_warm_pp_frames(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(frame_clear_kernel));
+}

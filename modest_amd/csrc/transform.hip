@@ -234,3 +234,9 @@ extern "C" int modest_project_velo_to_rect(modest_ctx *ctx, const float *pts, in
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }
+
+// modest_warmup (ctx.hip): resolving one kernel of this translation unit makes the runtime load its code object now
+extern "C" void modest_warm_transform(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(transform_kernel));
+}

@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import config, dist, ops
+from . import _lib, config, dist, ops
 from .utils import kitti_util
 from .utils.clustering_utils import FILTER_PLANE_SPEC, compact_labels, filter_labels, members_sorted, relabel_after_drop
 from .utils.pointcloud_utils import estimate_plane, get_objs, load_velo_scan, prepare_planes, to_device
@@ -270,6 +270,7 @@ def main(args):
     if pooled:
         return _pooled(args, rank, ws, local)
     seed = int(args.get("ransac_seed", 0))
+    _lib.default_context(torch.cuda.current_device()).warmup()   # (the library's device code: loaded before the clock)
     t0, done = time.perf_counter(), 0
     dist.barrier()
     # mask_batch scans go through the stage as ONE chain of kernel launches (generate_mask_chain); the reads of a

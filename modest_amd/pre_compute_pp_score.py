@@ -87,31 +87,49 @@ class FrameLoader:
     The missing frames of a scan travel as ONE batch: reader threads fill one pinned buffer (readinto
     releases the GIL), one asynchronous copy takes it to the device, one launch sorts all of them."""
 
-    def __init__(self, velodyne_dir, store: FrameStore, world, readers: int = 4, ctx=None):
+    def __init__(self, velodyne_dir, store: FrameStore, world, readers: int = 4, ctx=None, frame_bytes: int = 0):
         from concurrent.futures import ThreadPoolExecutor
         self.dir, self.store, self.world, self.ctx = velodyne_dir, store, world, ctx
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(readers)))
-        self.pinned = [None, None, None]      # ring: a buffer is refilled only after its last upload has run
-        self.pinned_ev = [None, None, None]
-        self.turn = 0
         self.chunk = 32   # frames per staged piece
+        self.slots = 3    # ring: a slot is refilled only after its last upload AND the sort that read it have run
+        self.turn = 0
         self.read_bytes = 0
         self.t_read = self.t_insert = self.t_touch = 0.0   # seconds of the ingest thread, by phase
         self.n_frames = 0
+        # Staging, host (pinned) and device, taken ONCE here -- outside every loop clock, in two driver calls: a cold scan
+        # brings 361 frames in twelve pieces, and with the buffers allocated on first use 145 of its 182 ms went into
+        # hipHostMalloc / hipMalloc (three pinned buffers, twelve device blocks; under eight workers those calls serialise).
+        # `frame_bytes`: size of a typical .bin (0: the buffers are made on first use, as before).
+        self.cap = 0
+        self.pinned_all = self.dev_all = None
+        self.slot_ev = [None] * self.slots
+        if frame_bytes > 0:
+            self._make_staging(int(self.chunk * (frame_bytes // 16) * 1.15) + 1024)
+
+    def _make_staging(self, points: int):
+        """(re)allocate the ring for pieces of up to `points` points: one pinned and one device tensor, `slots` views each"""
+        for ev in self.slot_ev:
+            if ev is not None:
+                ev.synchronize()
+        self.cap = int(points)
+        self.pinned_all = torch.empty((self.slots, self.cap, 4), dtype=torch.float32, pin_memory=True)
+        self.dev_all = torch.empty((self.slots, self.cap, 4), dtype=torch.float32, device=self.store.device)
+        self.slot_ev = [None] * self.slots
 
     def _read_batch(self, ids):
-        """the .bin files of `ids` -> one pinned float32 buffer; returns (buffer (P,4), point offsets)"""
+        """the .bin files of `ids` -> one pinned float32 buffer; returns (slot, buffer (P,4), point offsets)"""
         paths = [osp.join(self.dir, f"{i:06d}.bin") for i in ids]
         sizes = [os.path.getsize(p) for p in paths]
         assert all(sz % 16 == 0 for sz in sizes), "velodyne .bin files hold (n,4) float32 rows"
         offs = np.cumsum([0] + [sz // 16 for sz in sizes])
         need = int(offs[-1])
-        r = self.turn = (self.turn + 1) % len(self.pinned)
-        if self.pinned_ev[r] is not None:
-            self.pinned_ev[r].synchronize()
-        if self.pinned[r] is None or self.pinned[r].shape[0] < need:
-            self.pinned[r] = torch.empty((max(need, 1 << 16), 4), dtype=torch.float32, pin_memory=True)
-        host = self.pinned[r].numpy()
+        if need > self.cap:
+            self._make_staging(max(need + need // 8, 1 << 16))
+        r = self.turn = (self.turn + 1) % self.slots
+        if self.slot_ev[r] is not None:
+            self.slot_ev[r].synchronize()
+        host = self.pinned_all[r].numpy()
 
         def rd(k):
             with open(paths[k], "rb", buffering=0) as f:
@@ -120,7 +138,7 @@ class FrameLoader:
                 raise IOError(f"short read of {paths[k]}")
         list(self.pool.map(rd, range(len(ids))))
         self.read_bytes += int(sum(sizes))
-        return self.pinned[r][:need], offs
+        return r, self.pinned_all[r][:need], offs
 
     def ensure(self, file_ids, protect=None, blocking=True):
         """Read + upload + sort (one copy, one launch) every frame of `file_ids` that is not resident, on
@@ -133,9 +151,9 @@ class FrameLoader:
         # and the first piece is uploading while the next one is read
         for c0 in range(0, len(todo), self.chunk):
             missing = todo[c0:c0 + self.chunk]
-            host, offs = self._read_batch(missing)
+            r, host, offs = self._read_batch(missing)
             t1 = time.perf_counter()
-            dev = torch.empty(host.shape, dtype=torch.float32, device=self.store.device)
+            dev = self.dev_all[r][:host.shape[0]]
             dev.copy_(host, non_blocking=True)
             if blocking:
                 items = [(i, dev[offs[k]:offs[k + 1]], self.world[i]) for k, i in enumerate(missing)]
@@ -144,11 +162,13 @@ class FrameLoader:
                 self.store.insert_block(missing, dev, offs, self.world.stack(missing), ctx=self.ctx,
                                         protect=protect if protect is not None else file_ids)
             ev = torch.cuda.Event()
-            ev.record()
-            self.pinned_ev[self.turn] = ev
+            ev.record()   # behind the copy AND the sort that reads the device slot
+            self.slot_ev[r] = ev
             t2 = time.perf_counter()
             self.t_read += t1 - t0
             self.t_insert += t2 - t1
+            if os.environ.get("MODEST_PP_TRACE") and self.n_frames < 400:
+                eprint("[pp_score ingest] %d frames: read %.2f ms, copy + insert %.2f ms" % (len(missing), 1e3 * (t1 - t0), 1e3 * (t2 - t1)))
             self.n_frames += len(missing)
             t0 = t2
         self.store.touch(file_ids)   # LRU order + hit statistics
@@ -163,7 +183,7 @@ class IngestPipeline:
     `done()` releases the window behind a finished scan.  Frames named by a scan inside the window are never
     evicted."""
 
-    def __init__(self, loader: FrameLoader, plans, device, depth: int = 4, own_stream: bool = True):
+    def __init__(self, loader: FrameLoader, plans, device, depth: int = 4, own_stream: bool = True, stream=None):
         import collections
         import queue
         import threading
@@ -171,7 +191,7 @@ class IngestPipeline:
         # own_stream=False: uploads and sorts are enqueued on the compute stream itself (the hand-over of a plan
         # already orders them before the scan's kernels).  A GPU shared by several worker processes has 8
         # hardware queues in all: a second stream per worker halves everybody's rate.
-        self.stream = torch.cuda.Stream(device=device) if own_stream else torch.cuda.current_stream(device)
+        self.stream = stream if stream is not None else (torch.cuda.Stream(device=device) if own_stream else torch.cuda.current_stream(device))
         self.window = threading.Semaphore(self.depth)
         self.inflight = collections.deque()
         self.lock = threading.Lock()
@@ -182,19 +202,41 @@ class IngestPipeline:
     def _run(self):
         try:
             torch.cuda.set_device(self.device)
+            group = max(1, int(os.environ.get("MODEST_INGEST_GROUP", "4")))
+            it, held, first = iter(self.plans), None, True
             with torch.cuda.stream(self.stream):
-                for plan in self.plans:
-                    _tr("L.want", plan["origin"])
-                    self.window.acquire()
-                    _tr("L.start", plan["origin"])
+                while True:
+                    # up to `group` scans whose window slots are free RIGHT NOW travel as one read round + one copy + one sort
+                    # launch (a scan's 11 new files alone keep four reader threads busy for a fraction of the round trip through
+                    # the pool); the first scan of a group waits for its slot, the others only join if theirs is free.  The
+                    # first scan of the process goes alone: it is the cold one.
+                    batch = []
+                    while len(batch) < (1 if first else group):
+                        plan = held if held is not None else next(it, None)
+                        held = None
+                        if plan is None:
+                            break
+                        _tr("L.want", plan["origin"])
+                        if not batch:
+                            self.window.acquire()
+                        elif not self.window.acquire(blocking=False):
+                            held = plan
+                            break
+                        batch.append(plan)
+                    if not batch:
+                        break
+                    first = False
                     with self.lock:
-                        self.inflight.append(plan["frames"])
+                        for plan in batch:
+                            self.inflight.append(plan["frames"])
                         protect = [i for ids in self.inflight for i in ids]
-                    self.loader.ensure(plan["frames"], protect=protect, blocking=False)
+                    _tr("L.start", batch[0]["origin"])
+                    self.loader.ensure([i for plan in batch for i in plan["frames"]], protect=protect, blocking=False)
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
-                    _tr("L.done", plan["origin"])
-                    self.q.put((plan, ev))
+                    for plan in batch:
+                        _tr("L.done", plan["origin"])
+                        self.q.put((plan, ev))
             self.q.put(None)
         except BaseException as e:   # surfaced by the iterator
             self.q.put(e)
@@ -387,6 +429,18 @@ def main(args):
     # slabs of 256 MB on demand)
     try:
         n_all = sum(len(seq) for seq in track_list)
+        try:   # ... of this process's share of the scans (a worker of workers=N holds an N-th of the data set, not all of it)
+            mine = getattr(shard, "mine", None)   # (a static share; a dynamic queue hands out chunks: reserve for the data set)
+            if mine is not None and 0 < len(mine) <= 4096:
+                named = set()
+                for o in mine:
+                    s0, f0, trav = valid_idx[int(o)]
+                    named.add(track_list[s0][f0])
+                    for sq, ix in trav:
+                        named.update(track_list[sq][f] for f in ix)
+                n_all = min(n_all, len(named) + 64)
+        except (TypeError, KeyError, IndexError):
+            pass
         per = os.path.getsize(osp.join(args.data_root, "velodyne", f"{track_list[0][0]:06d}.bin")) + 4 * (store.ntf ** 2 + 1) + 512
         store.reserve(min(n_all * per * 1.05, float(args.get("frame_prealloc_gb", 16.0)) * 2 ** 30))
     except (OSError, IndexError):
@@ -394,8 +448,12 @@ def main(args):
     world = frame_world_matrices(track_list, poses, l2es, K)
     # ingest: reader threads -> pinned buffer -> one copy + one sort launch per scan, `ingest_depth` scans ahead
     # of the kernels (own stream, own library context); scores leave through a writer thread
+    try:
+        frame_bytes = os.path.getsize(osp.join(args.data_root, "velodyne", f"{track_list[0][0]:06d}.bin"))
+    except (OSError, IndexError):
+        frame_bytes = 0
     loader = FrameLoader(osp.join(args.data_root, "velodyne"), store, world, readers=int(args.get("ingest_readers", 4)),
-                         ctx=_lib.Context(device.index or 0))
+                         ctx=_lib.Context(device.index or 0), frame_bytes=frame_bytes)
 
     def plans():
         for origin_idx in shard:
@@ -419,6 +477,29 @@ def main(args):
             yield dict(origin=origin_idx, out=out_path, traversals=traversals, live=live_id, hist=hist_ids, travs=travs,
                        frames=hist_ids + [live_id])
 
+    # the scratch arena of a full batch on the block path, taken once, before the clock: the first batch of a process is short
+    # (below) and a later grow is a device synchronise + free + allocate -- 100 ms alone on the GPU, several times that under
+    # eight workers.  Estimate: 32 B per point of the batch's union of frames (two copies of the 16-byte records) + ~45 MB per scan
+    # (live index over the block window, task lists, counts); an underestimate only means the arena grows as before.
+    n_batch = max(1, int(args.get("pp_batch", 16)))
+    _lib.default_context(device.index or 0).warmup()   # (device code of the library: loaded before the clock, not inside the first scan)
+    try:
+        mine = getattr(shard, "mine", getattr(shard, "items", []))
+        first = valid_idx[int(mine[0])][2] if len(mine) else []
+        if first and n_batch > 1 and not args.skip_ephe:
+            per_frame = frame_bytes // 16
+            union_frames = sum(len(ix) + n_batch - 1 for _, ix in first)
+            _lib.default_context(device.index or 0).reserve_arena(int(1.1 * 32 * per_frame * union_frames) + n_batch * (45 << 20))
+    except (KeyError, IndexError, TypeError) as e:
+        if os.environ.get("MODEST_ALLOC_TRACE"):
+            eprint("[pp_score] arena reservation skipped: %r" % (e,))
+    # the ingest stream exists, and has carried one copy, before the clock: the FIRST host-to-device copy of a stream sets up
+    # its hardware queue and the copy engine's signals (142 ms of the 170 ms a cold scan's ingest took on the host)
+    ingest_stream = torch.cuda.current_stream(device) if os.environ.get("MODEST_WORKER") else torch.cuda.Stream(device=device)
+    if loader.pinned_all is not None:
+        with torch.cuda.stream(ingest_stream):
+            loader.dev_all[0][:64].copy_(loader.pinned_all[0][:64], non_blocking=True)
+        ingest_stream.synchronize()
     t0, done, pts = time.perf_counter(), 0, 0
     trace = bool(os.environ.get("MODEST_PP_TRACE")) and os.environ.get("MODEST_WORKER", "0/1").startswith("0/")
     dist.barrier()
@@ -430,9 +511,8 @@ def main(args):
     # flushes; the ingest window must hold a whole batch plus the scans ahead -- at least one scan ahead, whatever
     # ingest_depth says (a window smaller than a batch would leave this loop waiting for a scan the ingest thread may
     # not load)
-    n_batch = max(1, int(args.get("pp_batch", 16)))
     pipe = IngestPipeline(loader, plans(), device, depth=max(1, int(args.get("ingest_depth", 4))) + (n_batch - 1),
-                          own_stream=not os.environ.get("MODEST_WORKER"))
+                          stream=ingest_stream)
     writer = OutputWriter(1 << 16)
     pend = []   # the scans waiting for the flush: (live frame, history ids, traversal of every frame, raw pose factors of the
     #             history frames + the live scan, fixed l2e, fixed ego, output path, scan id, traversals)

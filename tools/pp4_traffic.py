@@ -3,7 +3,7 @@
 Calibration on kernels whose traffic is known: b4_seg_hist reads every record of the block store once (16 B x R) with wide
 coalesced loads, b4_seg_scatter writes every record once (16 B x R) -- so write factor = 1 by construction of R, and the
 fetch factor follows (MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of a wide coalesced streaming read on gfx950).
-Writes gpurun_out/pp4_traffic.json (copied to profiles/r04_pp_block_traffic.json, which bench.py reads)."""
+Writes gpurun_out/pp4_traffic.json (copied to profiles/r05_pp_block_traffic.json, which bench.py reads)."""
 import json
 import os
 import sys
