@@ -449,6 +449,10 @@ typedef struct modest_mask_stage_scan {
     double *plane1_out, *plane2_out;
     int64_t *labels_out;
     int32_t *info_out;
+    /* optional (NULL: not wanted): the indices, ascending, of the points whose labels_out is > 0 (capacity n) and their number --
+     * what the box tail (modest_boxes_scan::members) walks instead of all n points                                            */
+    int32_t *members_out;
+    int32_t *n_members_out;
 } modest_mask_stage_scan;
 int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int n_scans, const modest_mask_params *params,
                             void *stream);
@@ -504,6 +508,10 @@ typedef struct modest_boxes_scan {
     int32_t n_lab;
     double *objs_out;
     int32_t *keep_out, *info_out;
+    /* optional (NULL: every point is looked at): the indices, ascending, of the points with labels_inout > 0, as the mask stage
+     * reports them (modest_mask_stage_scan::members_out); the host passes then touch the members only                    */
+    const int32_t *members;
+    int32_t n_members;
 } modest_boxes_scan;
 int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_scans, const modest_boxes_params *params, void *stream);
 /* objs_nms' boxes [t0, t2, 0, l, w, h, -ry] as float32 (pointcloud_utils.py:322-324) and their BEV IoU

@@ -825,10 +825,10 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
 
     // PROF (MODEST_PP4_DBG=512): wall time of this wavefront by phase -- 0 pose table, 1 one-cell tasks: transform (incl. the wait
     // for the records), 2 masks, 3 pair phase, 4 four-cell tasks: segs + transform, 5 masks, 6 pair phase; 8 / 9 task counts
-    unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? __builtin_readcyclecounter() : 0ULL;
+    unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? wall_clock64() : 0ULL;
 #define B4_TICK(kk)                                                 \
     if (PROF) {                                                     \
-        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        const unsigned long long now_ = wall_clock64(); \
         pacc[kk] += now_ - plast;                                   \
         plast = now_;                                               \
     }

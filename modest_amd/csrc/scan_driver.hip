@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 using namespace modest;
@@ -35,7 +36,7 @@ void plane_from_model(const double *model64, double *plane4) {
 // is_valid_cluster (clustering_utils.py:94-117) + relabelling (:131-135) as one table look-up:
 // table[l + 1] = rank of label l among the surviving values; -1 survives iff it occurs or a cluster is dropped
 void finish_labels(const modest_mask_params *P, int n, int n_clusters, const std::vector<double> &st, const int32_t *labels_h,
-                   int64_t *labels_out, int32_t *info_out) {
+                   int64_t *labels_out, int32_t *info_out, int32_t *members_out = nullptr, int32_t *n_members_out = nullptr) {
     std::vector<int64_t> table((size_t)n_clusters + 1, 0);
     bool has_neg = false;
     for (int i = 0; i < n && !has_neg; ++i) has_neg = labels_h[i] < 0;
@@ -57,7 +58,19 @@ void finish_labels(const modest_mask_params *P, int n, int n_clusters, const std
     int64_t next = has_neg ? 1 : 0;
     for (int c = 0; c < n_clusters; ++c)
         if (valid[c]) table[(size_t)c + 1] = next++;
-    for (int i = 0; i < n; ++i) labels_out[i] = table[(size_t)(labels_h[i] + 1)];
+    if (members_out && n_clusters > 0) {   // the same pass also lists the points of the surviving clusters (for the box tail)
+        int32_t m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t l = table[(size_t)(labels_h[i] + 1)];
+            labels_out[i] = l;
+            members_out[m] = i;
+            m += l > 0;
+        }
+        *n_members_out = m;
+    } else {
+        for (int i = 0; i < n; ++i) labels_out[i] = table[(size_t)(labels_h[i] + 1)];
+        if (n_members_out) *n_members_out = members_out ? 0 : -1;
+    }
     info_out[2] = n_valid > 0 ? (int32_t)(next - 1) : 0;   // largest final label = number of box candidates
     if (n_clusters == 0) {   // compact_labels of the raw labels: all -1 -> all 0
         for (int i = 0; i < n; ++i) labels_out[i] = 0;
@@ -234,6 +247,17 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
     std::vector<const uint32_t *> keys((size_t)n_scans, nullptr);
     std::vector<int32_t> poss((size_t)n_scans, 0);
     std::vector<const double *> plane1_dev((size_t)n_scans, nullptr);
+    for (int s = 0; s < n_scans; ++s)
+        if (scans[s].n_members_out) *scans[s].n_members_out = -1;   // (-1: no member list; set by finish_labels)
+    // the raw cluster labels of ALL scans of the chain live in one device block and one pinned block of the first scan's context:
+    // they travel to the host as ONE copy (sixteen copies of 120 KB cost 14 us of stream time each)
+    size_t tot_lab = 0;
+    std::vector<size_t> lab_off((size_t)n_scans, 0);
+    for (int s = 0; s < n_scans; ++s) {
+        lab_off[(size_t)s] = tot_lab;
+        tot_lab += arena_sz((size_t)(scans[s].n > 0 ? scans[s].n : 1) * 4);
+    }
+    char *chain_lab_dev = nullptr, *chain_lab_h = nullptr;
     for (int s = 0; s < n_scans; ++s) {
         const modest_mask_stage_scan &q = scans[s];
         Run &r = R[(size_t)s];
@@ -244,14 +268,19 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         for (int k = 0; k < 8; ++k) q.info_out[k] = 0;
         const size_t b_cand = arena_sz((size_t)q.n * 12), b_lab = arena_sz((size_t)q.n * 4);
         const size_t b_work = dev_loop ? arena_sz(modest_rsd_work_bytes(q.n, P->max_trials)) : 0;
-        int rc = modest_ctx_reserve_hold(ctx, 2 * b_cand + b_lab + b_work, b_lab + arena_sz(sizeof(modest_rsd_result)));
+        const size_t extra = s == 0 ? tot_lab : 0;
+        int rc = modest_ctx_reserve_hold(ctx, 2 * b_cand + b_lab + b_work + extra, b_lab + arena_sz(sizeof(modest_rsd_result)) + extra);
         if (rc) return rc;
         rc = modest_ctx_reserve_pinned(ctx, 16384);   // sized once: growing it between an enqueue and its read-back would free results
         if (rc) return rc;
+        if (s == 0) {
+            chain_lab_dev = ctx->hold + 2 * b_cand + b_lab + b_work;
+            chain_lab_h = ctx->hold_pinned + b_lab + arena_sz(sizeof(modest_rsd_result));
+        }
         cA[(size_t)s] = reinterpret_cast<float *>(ctx->hold);
         cB[(size_t)s] = reinterpret_cast<float *>(ctx->hold + b_cand);
-        r.labels_dev = reinterpret_cast<int32_t *>(ctx->hold + 2 * b_cand);
-        r.labels_h = reinterpret_cast<int32_t *>(ctx->hold_pinned);
+        r.labels_dev = reinterpret_cast<int32_t *>(chain_lab_dev + lab_off[(size_t)s]);
+        r.labels_h = reinterpret_cast<int32_t *>(chain_lab_h + lab_off[(size_t)s]);
         work[(size_t)s] = ctx->hold + 2 * b_cand + b_lab;
         res[(size_t)s] = reinterpret_cast<modest_rsd_result *>(ctx->hold_pinned + b_lab);
         keys[(size_t)s] = q.mt_key624;
@@ -499,7 +528,6 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         }
         q.info_out[0] = C[(size_t)i].n_kept;
         q.info_out[1] = C[(size_t)i].n_clusters;
-        MODEST_HIP_CHECK(hipMemcpyAsync(r.labels_h, r.labels_dev, (size_t)q.n * 4, hipMemcpyDeviceToHost, stream));
         st[(size_t)i].assign((size_t)(C[(size_t)i].n_clusters > 0 ? C[(size_t)i].n_clusters : 1) * 6, 0.0);
         t.ctx = q.ctx;
         t.pts = q.pts_dev;
@@ -511,13 +539,21 @@ extern "C" int modest_mask_stage_batch(const modest_mask_stage_scan *scans, int 
         t.plane4 = q.plane2_out;
         t.out_host = st[(size_t)i].data();
     }
+    MODEST_HIP_CHECK(hipMemcpyAsync(chain_lab_h, chain_lab_dev, tot_lab, hipMemcpyDeviceToHost, stream));   // every scan's labels: one copy
     T[0].ctx = T[0].ctx ? T[0].ctx : scans[who[0]].ctx;   // the chain table lives in the first scan's context
     rc = modest_cluster_stats_chain(T.data(), B, P->quantile, stream);
     if (rc) return rc;
+    timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int i = 0; i < B; ++i) {
         if (C[(size_t)i].alone) continue;
         const modest_mask_stage_scan &q = scans[who[(size_t)i]];
-        finish_labels(P, q.n, C[(size_t)i].n_clusters, st[(size_t)i], R[(size_t)who[(size_t)i]].labels_h, q.labels_out, q.info_out);
+        finish_labels(P, q.n, C[(size_t)i].n_clusters, st[(size_t)i], R[(size_t)who[(size_t)i]].labels_h, q.labels_out, q.info_out,
+                      q.members_out, q.n_members_out);
+    }
+    if (getenv("MODEST_CHAIN_TRACE")) {
+        clock_gettime(CLOCK_MONOTONIC, &ts1);
+        fprintf(stderr, "[mask_stage_batch %d scans] finish_labels %.3f ms\n", B, 1e3 * (double)(ts1.tv_sec - ts0.tv_sec) + 1e-6 * (double)(ts1.tv_nsec - ts0.tv_nsec));
     }
     return MODEST_OK;
 }

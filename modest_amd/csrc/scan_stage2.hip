@@ -25,6 +25,9 @@
 #include "mask_chain.h"
 #include <algorithm>
 #include <cmath>
+#include <ctime>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -63,6 +66,8 @@ struct BoxRun {
     const float *pts_dev = nullptr, *pts_host = nullptr;
     int n = 0, stride = 0, n_lab = 0;
     int64_t *labels = nullptr;
+    const int32_t *members = nullptr;   // indices of the points with a label > 0 (NULL: look at all n)
+    int n_members = 0;
     double *objs_out = nullptr;
     int32_t *keep_out = nullptr, *info_out = nullptr;
     // state
@@ -78,9 +83,17 @@ int boxes_begin(BoxRun &r, const modest_boxes_params *P, void *stream_, bool def
     const int n = r.n, n_lab = r.n_lab, stride = r.stride;
     r.info_out[0] = r.info_out[1] = 0;
     r.off.assign((size_t)n_lab + 2, 0);
-    for (int i = 0; i < n; ++i) {
+    const bool listed = r.members != nullptr;
+    const int walk = listed ? r.n_members : n;   // (with a member list the passes touch the members only)
+    if (listed) {
+        MODEST_REQUIRE(r.n_members >= 0 && r.n_members <= n, "bad member list");
+        r.any_zero = r.n_members < n;
+    }
+    for (int k = 0; k < walk; ++k) {
+        const int i = listed ? r.members[k] : k;
+        MODEST_REQUIRE(i >= 0 && i < n, "member index out of range");
         const int64_t l = r.labels[i];
-        MODEST_REQUIRE(l >= 0 && l <= n_lab, "label out of range");
+        MODEST_REQUIRE(l >= 0 && l <= n_lab && !(listed && l == 0), "label out of range");
         if (l > 0) ++r.off[(size_t)l + 1];
         else r.any_zero = true;
     }
@@ -95,7 +108,8 @@ int boxes_begin(BoxRun &r, const modest_boxes_params *P, void *stream_, bool def
     r.miny.assign((size_t)n_lab, INFINITY);
     {
         std::vector<int32_t> cur(r.off.begin(), r.off.end());
-        for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < walk; ++k) {
+            const int i = listed ? r.members[k] : k;
             const int64_t l = r.labels[i];
             if (l <= 0) continue;
             double q[3];
@@ -193,7 +207,11 @@ void boxes_finish(BoxRun &r, const modest_boxes_params *P, const double *bottom)
     int64_t next = has_zero ? 1 : 0;
     for (int c = 0; c < n_lab; ++c)
         if (r.keep_out[c]) table[(size_t)c + 1] = next++;
-    for (int i = 0; i < r.n; ++i) r.labels[i] = table[(size_t)r.labels[i]];
+    if (r.members) {   // (labels outside the list are 0 and stay 0)
+        for (int k = 0; k < r.n_members; ++k) r.labels[r.members[k]] = table[(size_t)r.labels[r.members[k]]];
+    } else {
+        for (int i = 0; i < r.n; ++i) r.labels[i] = table[(size_t)r.labels[i]];
+    }
     r.info_out[0] = n_keep;
 }
 }  // namespace
@@ -234,6 +252,13 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
                                        void *stream_) {
     MODEST_REQUIRE(scans && P && n_scans >= 1 && n_scans <= 64, "bad chain");
     MODEST_REQUIRE(P->angles && P->cossin && P->cossin90 && P->n_angles >= 1, "angle tables missing");
+    static const bool trace = getenv("MODEST_CHAIN_TRACE") != nullptr;
+    auto now = [] {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+    };
+    double tt[6] = {now(), 0, 0, 0, 0, 0};
     std::vector<BoxRun> R((size_t)n_scans);
     int total_lab = 0, total_m = 0;
     for (int s = 0; s < n_scans; ++s) {
@@ -245,6 +270,7 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
         BoxRun &r = R[(size_t)s];
         r.ctx = q.ctx, r.pts_dev = q.pts_dev, r.pts_host = q.pts_host, r.n = q.n, r.stride = q.stride, r.n_lab = q.n_lab;
         r.labels = q.labels_inout, r.objs_out = q.objs_out, r.keep_out = q.keep_out, r.info_out = q.info_out;
+        r.members = q.members, r.n_members = q.n_members;
         int rc = boxes_begin(r, P, stream_, true);
         if (rc) return rc;
         if (r.active) {
@@ -253,6 +279,7 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
         }
     }
     if (total_lab == 0) return MODEST_OK;
+    tt[1] = now();
     {   // the rect-frame copies of all active scans: one launch
         std::vector<const float *> ins;
         std::vector<double *> outs;
@@ -288,8 +315,10 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
             ctx0 = r.ctx;
             break;
         }
+    tt[2] = now();
     int rc = modest_fit_boxes_closeness_host(ctx0, xz.data(), coff.data(), total_lab, P->cossin, P->n_angles, P->d0, best.data(),
                                              P->cossin90, ext.data(), stream_);
+    tt[3] = now();
     if (rc) {   // a cluster too large for the extents kernel somewhere: every scan reports it, the caller goes scan by scan
         for (BoxRun &r : R)
             if (r.active) r.info_out[1] = 1;
@@ -312,8 +341,10 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
             c0 += r.n_lab;
         }
     }
+    tt[4] = now();
     rc = modest_lowest_point_multi(ctx0, src.data(), nsrc.data(), boxes6.data(), total_lab, bottom.data(), stream_);
     if (rc) return rc;
+    tt[5] = now();
     {
         int c0 = 0;
         for (BoxRun &r : R) {
@@ -322,6 +353,9 @@ extern "C" int modest_scan_boxes_batch(const modest_boxes_scan *scans, int n_sca
             c0 += r.n_lab;
         }
     }
+    if (trace)
+        fprintf(stderr, "[scan_boxes_batch %d scans, %d clusters, %d members] begin %.3f | rect + pack %.3f | closeness %.3f | tail %.3f | lowest %.3f | finish %.3f ms\n",
+                n_scans, total_lab, total_m, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], now() - tt[5]);
     return MODEST_OK;
 }
 

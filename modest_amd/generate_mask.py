@@ -79,7 +79,7 @@ def generate_mask_scan(ptc, pp_score, calib, args, random_state=None, planes=Non
                 staged = ops.mask_stage(ptc_dev, pp_dev, _stage_params(args), rs)
     # else: the stage ran in a chain of scans (generate_mask_chain): its result, or None = host statement
     if staged is not None:
-        labels_filtered, plane, _, info = staged
+        labels_filtered, plane, _, info = staged[:4]
         n_kept = int(info[0])
     else:
         labels_filtered, plane, n_kept = _mask_stage_host(ptc, pp_score, args, random_state, planes, ptc_dev, pp_dev)
@@ -152,9 +152,9 @@ def generate_mask_chain(scans, calib, args, as_rows=False, ctxs=None):
         items, who = [], []
         for i in same:
             labels_filtered = staged[i][0]
-            n_lab = int(labels_filtered.max()) if labels_filtered.size else 0
+            n_lab = int(staged[i][3][2]) if labels_filtered.size else 0   # (info[2]: the largest final label = labels_filtered.max())
             if _native_boxes_ok(scans[i]["ptc"], n_lab, args):
-                items.append((scans[i]["ptc_dev"], scans[i]["ptc"], labels_filtered, n_lab))
+                items.append((scans[i]["ptc_dev"], scans[i]["ptc"], labels_filtered, n_lab, staged[i][4] if len(staged[i]) > 4 else None))
                 who.append(i)
         if len(items) > 1:
             from .utils.pointcloud_utils import _angles, _angles90

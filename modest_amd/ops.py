@@ -425,7 +425,7 @@ class MaskStageScan(C.Structure):
     """modest_mask_stage_scan (include/modest_hip.h)"""
     _fields_ = [("ctx", C.c_void_p), ("pts_dev", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32), ("pp_dev", C.c_void_p),
                 ("mt_key624", C.c_void_p), ("mt_pos", C.c_void_p), ("plane1_out", C.c_void_p), ("plane2_out", C.c_void_p),
-                ("labels_out", C.c_void_p), ("info_out", C.c_void_p)]
+                ("labels_out", C.c_void_p), ("info_out", C.c_void_p), ("members_out", C.c_void_p), ("n_members_out", C.c_void_p)]
 
 
 _CHAIN_CTXS = {}
@@ -467,20 +467,23 @@ def mask_stage_batch(items, params: MaskParams, ctxs=None):
         plane1, plane2 = np.zeros(4, dtype=np.float64), np.zeros(4, dtype=np.float64)
         labels = np.empty(n, dtype=np.int64)
         info = np.zeros(8, dtype=np.int32)
-        keep.append((st, key, pos, plane1, plane2, labels, info))
+        members, n_mem = np.empty(n, dtype=np.int32), np.full(1, -1, dtype=np.int32)
+        keep.append((st, key, pos, plane1, plane2, labels, info, members, n_mem))
         a = arr[i]
         a.ctx = C.cast(ctxs[i].handle, C.c_void_p).value
         a.pts_dev, a.n, a.stride, a.pp_dev = pts.data_ptr(), n, pts.shape[1], pp.data_ptr()
         a.mt_key624, a.mt_pos = _np_ptr(key), _np_ptr(pos)
         a.plane1_out, a.plane2_out, a.labels_out, a.info_out = _np_ptr(plane1), _np_ptr(plane2), _np_ptr(labels), _np_ptr(info)
+        a.members_out, a.n_members_out = _np_ptr(members), _np_ptr(n_mem)
     check(lib.modest_mask_stage_batch(C.byref(arr), B, C.byref(params), _stream()), "modest_mask_stage_batch")
     out = []
-    for (pts, pp, rs), (st, key, pos, plane1, plane2, labels, info) in zip(items, keep):
+    for (pts, pp, rs), (st, key, pos, plane1, plane2, labels, info, members, n_mem) in zip(items, keep):
         if info[3] != 0:
             out.append(None)
             continue
         rs.set_state((st[0], key, int(pos[0]), st[3], st[4]))
-        out.append((labels, plane1, plane2, info))
+        # (a fifth entry: the indices of the points with a label > 0, ascending -- None when the library did not list them)
+        out.append((labels, plane1, plane2, info, members[:int(n_mem[0])] if n_mem[0] >= 0 else None))
     return out
 
 
@@ -532,14 +535,15 @@ class BoxesScan(C.Structure):
     """modest_boxes_scan (include/modest_hip.h)"""
     _fields_ = [("ctx", C.c_void_p), ("pts_dev", C.c_void_p), ("pts_host", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32),
                 ("labels_inout", C.c_void_p), ("n_lab", C.c_int32), ("objs_out", C.c_void_p), ("keep_out", C.c_void_p),
-                ("info_out", C.c_void_p)]
+                ("info_out", C.c_void_p), ("members", C.c_void_p), ("n_members", C.c_int32)]
 
 
 def scan_boxes_batch(items, V2C, R0, angles: np.ndarray, cossin: np.ndarray, cossin90: np.ndarray, d0: float,
                      min_volume: float, max_volume: float, ctxs=None):
     """modest_scan_boxes_batch: the box tail of a CHAIN of scans (one calibration) -- host phases per scan, one
     closeness launch over all clusters, one lowest-point launch over all boxes.  items: [(pts_dev, pts_host,
-    labels_filtered, n_lab)]; returns per scan what scan_boxes returns (None: host statement)."""
+    labels_filtered, n_lab[, members])] -- members: the ascending indices of the points with a label > 0 as mask_stage_batch
+    lists them (the host passes then touch those only); returns per scan what scan_boxes returns (None: host statement)."""
     lib = load()
     B = len(items)
     if B == 0:
@@ -555,22 +559,27 @@ def scan_boxes_batch(items, V2C, R0, angles: np.ndarray, cossin: np.ndarray, cos
     P.d0, P.min_volume, P.max_volume = float(d0), float(min_volume), float(max_volume)
     arr = (BoxesScan * B)()
     keepalive = []
-    for i, (pts_dev, pts_host, labels_filtered, n_lab) in enumerate(items):
+    for i, item in enumerate(items):
+        pts_dev, pts_host, labels_filtered, n_lab = item[:4]
+        members = item[4] if len(item) > 4 else None
         _dev(pts_dev, torch.float32, "pts")
         assert pts_host.dtype == np.float32 and pts_host.flags.c_contiguous and pts_host.shape == tuple(pts_dev.shape)
         labels = np.ascontiguousarray(labels_filtered, dtype=np.int64).copy()
         objs = np.zeros((max(n_lab, 1), 8), dtype=np.float64)
         keep = np.zeros(max(n_lab, 1), dtype=np.int32)
         info = np.zeros(2, dtype=np.int32)
-        keepalive.append((labels, objs, keep, info, int(n_lab)))
+        if members is not None:
+            members = np.ascontiguousarray(members, dtype=np.int32)
+        keepalive.append((labels, objs, keep, info, int(n_lab), members))
         a = arr[i]
         a.ctx = C.cast(ctxs[i].handle, C.c_void_p).value
         a.pts_dev, a.pts_host, a.n, a.stride = pts_dev.data_ptr(), _np_ptr(pts_host), pts_host.shape[0], pts_host.shape[1]
         a.labels_inout, a.n_lab = _np_ptr(labels), int(n_lab)
         a.objs_out, a.keep_out, a.info_out = _np_ptr(objs), _np_ptr(keep), _np_ptr(info)
+        a.members, a.n_members = (_np_ptr(members), int(members.shape[0])) if members is not None else (None, 0)
     check(lib.modest_scan_boxes_batch(C.byref(arr), B, C.byref(P), _stream()), "modest_scan_boxes_batch")
     return [None if info[1] != 0 else (labels, objs[:n_lab], keep[:n_lab].astype(bool))
-            for labels, objs, keep, info, n_lab in keepalive]
+            for labels, objs, keep, info, n_lab, _m in keepalive]
 
 
 def objs_iou(objs8: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
