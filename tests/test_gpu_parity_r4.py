@@ -90,3 +90,34 @@ def test_device_trial_loops_hand_small_sets_back(gpu):
     for o, (_, _, rs), st in zip(out, items, states):
         if o is None:
             assert rs.get_state()[2] == st[2] and np.array_equal(rs.get_state()[1], st[1])
+
+
+def test_device_trial_loops_equal_sklearn_directly(gpu):
+    """The device loops against sklearn's RANSACRegressor itself (the oracle's estimate_plane, utils/pointcloud_utils.py:44-65),
+    not through the host loop: same generator in, same number of trials (`n_trials_`) of both fits, planes within 1e-4
+    relative (float64 fits here, sklearn's float32 LAPACK path there), and the generator state afterwards identical."""
+    from modest_amd import config, generate_mask as gm, ops
+    from modest_amd.utils.clustering_utils import FILTER_PLANE_SPEC
+    from oracle import mask as om
+    args = config.compose("generate_mask", ["data_root=/unused"])
+    params = gm._stage_params(args)
+    scans = _scans(gpu)[:16]
+    rss = [np.random.RandomState(500 + k) for k in range(len(scans))]
+    out = []
+    for lo in range(0, len(scans), 8):
+        out += ops.mask_stage_batch([(scans[k][2], scans[k][3], rss[k]) for k in range(lo, min(lo + 8, len(scans)))], params)
+    checked = 0
+    for k, o in enumerate(out):
+        if o is None:
+            continue
+        ref = np.random.RandomState(500 + k)
+        pe = args.plane_estimate
+        p1, reg1, _ = om.estimate_plane(scans[k][0][:, :3], pe.max_hs, pe.range, random_state=ref, return_reg=True)
+        p2, reg2, _ = om.estimate_plane(scans[k][0], FILTER_PLANE_SPEC[0], FILTER_PLANE_SPEC[1], random_state=ref, return_reg=True)
+        assert int(o[3][6]) == reg1.n_trials_ and int(o[3][7]) == reg2.n_trials_, (k, o[3], reg1.n_trials_, reg2.n_trials_)
+        np.testing.assert_allclose(o[1], p1, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(o[2], p2, rtol=1e-4, atol=1e-6)
+        st, sr = rss[k].get_state(), ref.get_state()
+        assert st[2] == sr[2] and np.array_equal(st[1], sr[1]), k
+        checked += 1
+    assert checked >= 10
