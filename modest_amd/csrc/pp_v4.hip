@@ -35,6 +35,7 @@
 // pose against the lattice to 1e-4 m, frame_store.consistent), the lattice cell edge is at least
 // r * (1 + 2^-9) (required below), so their lattice cells differ by at most one per axis.
 #include "pp_frames.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +50,13 @@ constexpr int B4_NTF = MODEST_FRAME_NTF;   // tiles per axis of a frame table (1
 constexpr int B4_NTILE = B4_NTF * B4_NTF;
 constexpr int B4_MAXW = 160;               // block window: at most this many tiles per axis
 constexpr int B4_CH = 4096;                // points per streaming chunk (1024 threads x 4)
-constexpr int B4_SEG = 4096;               // records per sort segment (512 threads x 8)
+#ifndef B4_SKIP0_
+#define B4_SKIP0_ 0
+#endif
+#ifndef B4_SEG_
+#define B4_SEG_ 4096
+#endif
+constexpr int B4_SEG = B4_SEG_;            // records per sort segment (512 threads x 8)
 constexpr int B4_FG = 32;                  // frames per prefix group
 constexpr unsigned B4_HEAVY = 64;          // cells with at least this many records get tasks of their own
 #ifndef B4_CPT_
@@ -87,7 +94,9 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
     const UFrame *frames;
     const uint2 *chunkTab;
     unsigned *off, *gtot, *listTotal, *listBase, *segBase, *segList, *segHist, *segOff, *cellOff, *ctrl, *baseSum;
-    unsigned *needList;   // the tiles some scan of the block needs, in no particular order; ctrl[2] = their number
+    unsigned *needList;   // the tiles some scan of the block needs AND that hold points, in no particular order; ctrl[2] = their number
+    unsigned *needCand;   // the tiles some scan needs (ctrl[3] of them)
+    unsigned long long *needMask;   // per window tile: the scans with a live point in the 3x3 tiles around it
     uint2 *segRange;   // smallest / largest frame slot among a segment's records
     float4 *recA, *recB;
     int U, NG, nchunks, maxSegs;
@@ -122,41 +131,37 @@ __device__ __forceinline__ bool b4_cell(const double *__restrict__ W, float x, f
     return true;
 }
 
-// ---- list sizes from the frame tables ---------------------------------------------------------
-// thread (block tile b, frame group g): exclusive prefix of the tile's point counts over the group's frames
-__global__ __launch_bounds__(256) void b4_counts(Blk B) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b == 0 && blockIdx.y == 0) B.ctrl[2] = 0u;   // cursor of b4_lists' tile list
-    if (b >= B.BT) return;
-    const int g = blockIdx.y;
-    const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
-    const int f1 = min(B.U, (g + 1) * B4_FG);
-    unsigned run = 0;
-    for (int f = g * B4_FG; f < f1; ++f) {
-        const UFrame &F = B.frames[f];   // wave-uniform: scalar loads
-        const int lx = gx - F.TX0, ly = gy - F.TY0;
-        unsigned c = 0;
-        if (lx >= 0 && lx < B4_NTF && ly >= 0 && ly < B4_NTF) {
-            const int k = ly * B4_NTF + lx;
-            c = F.tab[k + 1] - F.tab[k];
-        }
-        B.off[(size_t)f * B.BT + b] = run;
-        run += c;
-    }
-    B.gtot[(size_t)g * B.BT + b] = run;
+// The live scans are indexed on the cells of the CROP: the bounding box of the block's needed tiles plus one tile on every side,
+// found by b4_need (ctrl[8..11]: maxima of BW - 1 - x, x, BH - 1 - y, y over the needed tiles -- zero-initialised by the call's
+// one memset).  The window (160 x 160 tiles for 16 Lyft scans: the union of the frame tables) is 2.8 x larger than what the live
+// points occupy, and the dense per-scan cell arrays -- counters, starts -- were cleared, scanned and read over all of it.
+struct B4Crop {
+    int x0, y0, CW, CH, nBlk;   // first tile (relative to the window), cells per axis, 4096-cell scan blocks
+};
+__device__ __forceinline__ B4Crop b4_crop(const Blk &B) {
+    const int c0 = (int)B.ctrl[8], c1 = (int)B.ctrl[9], c2 = (int)B.ctrl[10], c3 = (int)B.ctrl[11];
+    int x0 = B.BW - 1 - c0, x1 = c1, y0 = B.BH - 1 - c2, y1 = c3;
+    if (x0 > x1 || y0 > y1) x0 = x1 = y0 = y1 = 0;   // (no needed tile at all)
+    x0 = max(x0 - 1, 0), y0 = max(y0 - 1, 0), x1 = min(x1 + 1, B.BW - 1), y1 = min(y1 + 1, B.BH - 1);
+    B4Crop c;
+    c.x0 = x0, c.y0 = y0, c.CW = 8 * (x1 - x0 + 1), c.CH = 8 * (y1 - y0 + 1);
+    c.nBlk = (c.CW * c.CH + 4095) / 4096;
+    return c;
 }
 
-// thread per block tile: is the tile needed (a live point of any scan in the 3x3 tiles around it)?  group
-// bases; list total (0 for tiles nobody needs: their points are never written)
-__global__ __launch_bounds__(256) void b4_lists(Blk B, const ScanDev *__restrict__ scans) {
+// ---- list sizes from the frame tables ---------------------------------------------------------
+// thread per block tile: is the tile needed (a live point of any scan in the 3x3 tiles around it), and by which scans?  Needed
+// tiles are LISTED (7 k of the window's 25.6 k): the column sums below, the plan and the join only ever look at those.
+__global__ __launch_bounds__(256) void b4_need(Blk B, const ScanDev *__restrict__ scans) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B.BT) return;
     const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
-    bool needed = false;
+    unsigned long long mask = 0ULL;
 #pragma unroll 4
     for (int s = 0; s < B.G; ++s) {
         const ScanDev &S = scans[s];
         const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
+        bool needed = false;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {   // (the loads are unconditional on clamped indices: nothing waits inside a branch)
             const int ly = gy + dy - S.TY0;
@@ -165,15 +170,77 @@ __global__ __launch_bounds__(256) void b4_lists(Blk B, const ScanDev *__restrict
             const unsigned t0 = S.liveTab[row + a], t1 = S.liveTab[row + e];
             needed |= in && t1 > t0;
         }
+        mask |= (unsigned long long)needed << s;
     }
+    B.needMask[b] = mask;
+    B.listTotal[b] = 0u;   // (b4_lists writes the totals of the needed tiles that hold points)
+    // one cursor atomic per wavefront, the wavefront's tiles in order: neighbours in the list are neighbours in a tile row, and the
+    // column sums below read and write neighbouring table entries
+    const unsigned long long bal = __ballot(mask != 0ULL);
+    if (bal) {
+        const int lane = threadIdx.x & 63;
+        {   // the bounding box of the needed tiles (b4_crop)
+            int a = mask ? B.BW - 1 - b % B.BW : 0, c = mask ? b % B.BW : 0, d = mask ? B.BH - 1 - b / B.BW : 0, e = mask ? b / B.BW : 0;
+            for (int o = 32; o > 0; o >>= 1) {
+                a = max(a, __shfl_xor(a, o)), c = max(c, __shfl_xor(c, o));
+                d = max(d, __shfl_xor(d, o)), e = max(e, __shfl_xor(e, o));
+            }
+            if (lane == 0) {
+                atomicMax(&B.ctrl[8], (unsigned)a), atomicMax(&B.ctrl[9], (unsigned)c);
+                atomicMax(&B.ctrl[10], (unsigned)d), atomicMax(&B.ctrl[11], (unsigned)e);
+            }
+        }
+        unsigned pos = 0;
+        if (lane == 0) pos = atomicAdd(&B.ctrl[3], (unsigned)__popcll(bal));
+        pos = __shfl(pos, 0);
+        if (mask) B.needCand[pos + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL))] = (unsigned)b;
+    }
+}
+
+// thread (needed tile, frame group g): exclusive prefix of the tile's point counts over the group's frames
+__global__ __launch_bounds__(256) void b4_counts(Blk B) {
+    const unsigned q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B.ctrl[3]) return;
+    const int b = (int)B.needCand[q];
+    const int g = blockIdx.y;
+    const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
+    const int f1 = min(B.U, (g + 1) * B4_FG);
+    unsigned run = 0;
+    // eight frames per trip, every table entry requested before the first is used (one frame per trip was 32 dependent rounds of a
+    // descriptor load + a table load: 32 us for 7 k tiles)
+    for (int f0 = g * B4_FG; f0 < f1; f0 += 8) {
+        unsigned t0[8], t1[8];
+        bool in[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const UFrame &F = B.frames[min(f0 + u, f1 - 1)];   // wave-uniform: scalar loads
+            const int lx = gx - F.TX0, ly = gy - F.TY0;
+            in[u] = f0 + u < f1 && lx >= 0 && lx < B4_NTF && ly >= 0 && ly < B4_NTF;
+            const int k = in[u] ? ly * B4_NTF + lx : 0;
+            t0[u] = F.tab[k], t1[u] = F.tab[k + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (f0 + u < f1) B.off[(size_t)(f0 + u) * B.BT + b] = run;
+            run += in[u] ? t1[u] - t0[u] : 0u;
+        }
+    }
+    B.gtot[(size_t)g * B.BT + b] = run;
+}
+
+// thread per needed tile: group bases, list total; the tiles with points go to the list b4_plan walks
+__global__ __launch_bounds__(256) void b4_lists(Blk B) {
+    const unsigned q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B.ctrl[3]) return;
+    const int b = (int)B.needCand[q];
     unsigned run = 0;
     for (int g = 0; g < B.NG; ++g) {
         const unsigned t = B.gtot[(size_t)g * B.BT + b];
         B.gtot[(size_t)g * B.BT + b] = run;
         run += t;
     }
-    B.listTotal[b] = needed ? run : 0u;
-    if (needed && run != 0u) B.needList[atomicAdd(&B.ctrl[2], 1u)] = (unsigned)b;   // b4_plan walks this list instead of the window
+    B.listTotal[b] = run;
+    if (run != 0u) B.needList[atomicAdd(&B.ctrl[2], 1u)] = (unsigned)b;   // b4_plan walks this list instead of the window
 }
 
 // list bases, segment bases, the segment -> list table; ctrl[0] = records, ctrl[1] = segments.  Two launches of a few
@@ -398,9 +465,17 @@ __global__ __launch_bounds__(512) void b4_seg_scatter(Blk B) {
 }
 
 // ---- live scans on the block's cells ----------------------------------------------------------
+// grid.y = scan.  The cell counters of the crop start at zero (launched over the window's scan blocks: the workgroups behind the
+// crop leave at once)
+__global__ __launch_bounds__(1024) void b4_zero_cells(Blk B, const ScanDev *__restrict__ scans) {
+    const B4Crop C = b4_crop(B);
+    if ((int)blockIdx.x >= C.nBlk) return;
+    reinterpret_cast<uint4 *>(scans[blockIdx.y].cellCount)[(size_t)blockIdx.x * 1024 + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+}
 // grid.y = scan.  tmp[i] = (x, y, z in the scan's common frame, cell); the cell counters were cleared
 __global__ __launch_bounds__(256) void b4_live_count(Blk B, const ScanDev *__restrict__ scans) {
     const ScanDev &S = scans[blockIdx.y];
+    const B4Crop C = b4_crop(B);
     const int i = blockIdx.x * 256 + threadIdx.x;
     {   // the scan's counts start at zero (one launch for all scans instead of a memset per scan)
         const size_t nc = (size_t)S.n * S.T;
@@ -412,12 +487,11 @@ __global__ __launch_bounds__(256) void b4_live_count(Blk B, const ScanDev *__res
     rel_apply(S.rel, x, y, z, o);
     long long cx = 0, cy = 0;
     (void)b4_cell(S.lat, x, y, z, &cx, &cy);
-    cx -= 8LL * B.BX0;
-    cy -= 8LL * B.BY0;
-    // (a clean live frame lies inside its own table, which the block window contains: the clamp only keeps a
-    // corrupt input from writing out of bounds)
-    const int bx = (int)min(max(cx, 0LL), (long long)B.CW - 1), by = (int)min(max(cy, 0LL), (long long)B.CHc - 1);
-    const int cell = by * B.CW + bx;
+    cx -= 8LL * (B.BX0 + C.x0);
+    cy -= 8LL * (B.BY0 + C.y0);
+    // (a live point's tile is a needed tile, i.e. inside the crop: the clamp only keeps a corrupt input from writing out of bounds)
+    const int bx = (int)min(max(cx, 0LL), (long long)C.CW - 1), by = (int)min(max(cy, 0LL), (long long)C.CH - 1);
+    const int cell = by * C.CW + bx;
     atomicAdd(&S.cellCount[cell], 1u);
     S.tmp[i] = make_float4(o[0], o[1], o[2], __int_as_float(cell));
 }
@@ -428,6 +502,7 @@ constexpr int B4_SCAN = 4096;
 __global__ __launch_bounds__(1024) void b4_scan_local(Blk B, const ScanDev *__restrict__ scans) {
     __shared__ unsigned wsum[16];
     const ScanDev &S = scans[blockIdx.y];
+    if ((int)blockIdx.x >= b4_crop(B).nBlk) return;   // (wave-uniform)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint4 v = reinterpret_cast<const uint4 *>(S.cellCount)[(size_t)blockIdx.x * 1024 + tid];
     const unsigned s4 = v.x + v.y + v.z + v.w;
@@ -450,10 +525,11 @@ __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__r
     __shared__ unsigned wsum[16];
     const ScanDev &S = scans[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nBlk = b4_crop(B).nBlk;
     unsigned run = 0;   // (window of at most 160 x 160 tiles: 400 scan blocks; the loop is for larger constants)
-    for (int base = 0; base < B.nScanBlk; base += 1024) {
+    for (int base = 0; base < nBlk; base += 1024) {
         const int k = base + tid;
-        const unsigned v = k < B.nScanBlk ? S.blockSum[k] : 0u;
+        const unsigned v = k < nBlk ? S.blockSum[k] : 0u;
         unsigned inc = v;
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned u = __shfl_up(inc, o);
@@ -467,13 +543,14 @@ __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__r
             if (q < w) off += wsum[q];
             all += wsum[q];
         }
-        if (k < B.nScanBlk) S.blockSum[k] = off + inc - v;
+        if (k < nBlk) S.blockSum[k] = off + inc - v;
         run += all;
     }
     if (tid == 0) {
-        S.blockSum[B.nScanBlk] = run;
-        S.cellStart[B.NCpad] = 0u;
+        S.blockSum[nBlk] = run;
+        S.cellStart[(size_t)nBlk * B4_SCAN] = 0u;
         S.ctrl[0] = 0u, S.ctrl[1] = 0u;   // b4_plan's cursors
+        S.ctrl[32] = 0u, S.ctrl[48] = 0u;   // b4_join's tickets (one-cell / four-cell tasks)
     }
 }
 // start of cell `c` in the scan's cell-sorted live points
@@ -523,11 +600,13 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     const ScanDev &S = scans[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const unsigned nNeed = B.ctrl[2];
+    const B4Crop C = b4_crop(B);
     // (a wavefront per tile of the list, eight wavefronts per SIMD: the window has four times as many tiles as the list, and a
     // launch over all of them spent more time starting wavefronts that leave at once than on the tiles with work)
 #pragma unroll 1
     for (unsigned it = blockIdx.x * 4 + (threadIdx.x >> 6); it < nNeed; it += gridDim.x * 4) {
     const int b = (int)B.needList[it];
+    if (!((B.needMask[b] >> blockIdx.y) & 1ULL)) continue;   // (no live point of THIS scan around the tile: wave-uniform)
     const unsigned total = B.listTotal[b];
     // The part of every cell this scan reads.  The tile list is in the order of the block's frame table and its
     // segments were sorted one by one, so a cell's records are [run of segment 0 | run of segment 1 | ...] with ascending
@@ -552,9 +631,9 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     const unsigned base = B.cellOff[(size_t)b * 65 + lane], next = B.cellOff[(size_t)b * 65 + lane + 1];
     const unsigned oFirst = B.segOff[(size_t)(s0 + kf) * 64 + lane];
     const unsigned oEnd = B.segOff[(size_t)(s0 + min(kl + 1, ns - 1)) * 64 + lane];
-    const int cx = (b % B.BW) * 8 + (lane & 7), cy = (b / B.BW) * 8 + (lane >> 3);
+    const int cx = (b % B.BW - C.x0) * 8 + (lane & 7), cy = (b / B.BW - C.y0) * 8 + (lane >> 3);   // (on the crop)
     unsigned sa[3], sn[3];
-    b4_cell_segs(S.cellStart, S.blockSum, B.CW, B.CHc, cx, cy, sa, sn);
+    b4_cell_segs(S.cellStart, S.blockSum, C.CW, C.CH, cx, cy, sa, sn);
     const unsigned cand = sn[0] + sn[1] + sn[2];
     const unsigned start = base + oFirst;
     const unsigned end = kl + 1 < ns ? base + oEnd : next;
@@ -626,6 +705,13 @@ typedef __attribute__((address_space(1))) int *B4_CNT;   // the scan's counts: g
 __device__ __forceinline__ void b4_count_add(B4_CNT p, int v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// counts[live point][lane's traversal] += v with the row's address in SGPRs (the live point is wave-uniform) and the lane's byte
+// offset in one VGPR: the compiler's own form adds the scalar row offset to a per-lane 64-bit pointer with a VALU instruction
+// per candidate -- in a loop that is bound by them
+__device__ __forceinline__ void b4_count_add_row(B4_CNT counts, int point, int T, unsigned laneBytes, int v) {
+    B4_CNT row = counts + (size_t)point * (size_t)T;
+    asm volatile("global_atomic_add %0, %1, %2" : : "v"(laneBytes), "v"(v), "s"(row) : "memory");
+}
 template <typename T> __device__ __forceinline__ B4_GLOBAL(T) b4_global(const T *p) {
     return (B4_GLOBAL(T))(p);
 }
@@ -634,6 +720,16 @@ template <typename T> __device__ __forceinline__ B4_CONST(T) b4_const(const T *p
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned *B4_TICKET;
+constexpr unsigned B4_TK = 2;   // tasks per ticket (1: 48 k atomics per scan on ONE word, ~10 ns each -- they serialise with few scans; 4 and more:
+                                // consecutive tasks share a cell and its candidates, i.e. their cost: the balance suffers.  Measured 1 / 2 / 4 / 8 / 16:
+                                // 86.7 / 84.1 / 91.6 / 95.5 / 106.9 us per scan in blocks of 16, 241 / 189 / 193 / 214 / 273 in blocks of 4)
+// one ticket of a scan's task queue (lane 0 asks; the value is read when the wavefront's current batch runs out)
+__device__ __forceinline__ unsigned b4_ticket_request(B4_TICKET p, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
 
 // popcount(x) + acc in ONE instruction (the compiler prefers independent popcounts and a three-operand add tree: three more
 // VALU instructions per candidate in a loop that is bound by them)
@@ -667,10 +763,25 @@ __device__ __forceinline__ unsigned b4_pair_step(float qx_, float qy_, float qz_
         const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
         const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
         *band |= (hA ^ mA) | (hB ^ mB);
+#if B4_SKIP0_ == 1
+        if (hA | hB) {   // (wave-uniform: a chunk pair without a hit skips its eight mask / popcount instructions)
+#elif B4_SKIP0_ == 2
+        if (hA)
+#endif
+        {
         acc = b4_bcnt((unsigned)hA & sLo[2 * p], acc);
         acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * p], acc);
+        }
+#if B4_SKIP0_ == 2
+        if (hB)
+#endif
+        {
         acc = b4_bcnt((unsigned)hB & sLo[2 * p + 1], acc);
         acc = b4_bcnt((unsigned)(hB >> 32) & sHi[2 * p + 1], acc);
+        }
+#if B4_SKIP0_ == 1
+        }
+#endif
     }
     return acc;
 }
@@ -688,10 +799,10 @@ __device__ __forceinline__ unsigned long long b4_pairs(B4_CONST(v4f) sorted, B4_
     for (unsigned i = ia; i < ie; i += 2) {
         const v8f qn = *(B4_CONST(v8f))(sorted + min(i + 2, ie - 1));   // the next two candidates: in flight during this trip
         const unsigned accA = b4_pair_step<NP>(q[0], q[1], q[2], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
-        if (lq < T && accA) b4_count_add(&counts[(size_t)__float_as_int(q[3]) * T + lq], (int)accA);
+        if (lq < T && accA) b4_count_add_row(counts, __float_as_int(q[3]), T, 4u * (unsigned)lq, (int)accA);
         if (i + 1 < ie) {
             const unsigned accB = b4_pair_step<NP>(q[4], q[5], q[6], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
-            if (lq < T && accB) b4_count_add(&counts[(size_t)__float_as_int(q[7]) * T + lq], (int)accB);
+            if (lq < T && accB) b4_count_add_row(counts, __float_as_int(q[7]), T, 4u * (unsigned)lq, (int)accB);
         }
         q = qn;
     }
@@ -720,7 +831,7 @@ __device__ __forceinline__ void b4_pairs_band(B4_CONST(v4f) sorted, B4_CNT count
             acc += __popc((unsigned)xA & sLo[2 * p]) + __popc((unsigned)(xA >> 32) & sHi[2 * p]);
             acc += __popc((unsigned)xB & sLo[2 * p + 1]) + __popc((unsigned)(xB >> 32) & sHi[2 * p + 1]);
         }
-        if (lq < T && acc) b4_count_add(&counts[(size_t)__float_as_int(q.w) * T + lq], (int)acc);
+        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
     }
 }
 template <int NP>
@@ -757,7 +868,7 @@ __device__ __forceinline__ unsigned long long b4_pairs1(B4_CONST(v4f) sorted, B4
         band |= hA ^ mA;
         unsigned acc = b4_bcnt((unsigned)hA & sLo, 0u);
         acc = b4_bcnt((unsigned)(hA >> 32) & sHi, acc);
-        if (lq < T && acc) b4_count_add(&counts[(size_t)__float_as_int(q.w) * T + lq], (int)acc);
+        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
         q = qn;
     }
     return band;
@@ -772,7 +883,7 @@ __device__ __forceinline__ void b4_pairs1_band(B4_CONST(v4f) sorted, B4_CNT coun
         const bool bA = !(dA < r2lo) && dA <= r2hi;
         const unsigned long long xA = __ballot(bA && pp_within(hx, hy, hz, q.x, q.y, q.z, r2));
         const unsigned acc = __popc((unsigned)xA & sLo) + __popc((unsigned)(xA >> 32) & sHi);
-        if (lq < T && acc) b4_count_add(&counts[(size_t)__float_as_int(q.w) * T + lq], (int)acc);
+        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
     }
 }
 // a sparse cell of a four-cell task: its three candidate runs
@@ -795,9 +906,9 @@ __host__ __device__ __forceinline__ unsigned b4_pose_bytes(int U) {
     return (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15));
 }
 __host__ __device__ __forceinline__ unsigned b4_join_lds(int U, int T, bool lpose) {
-    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8);
+    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8) + 16u;   // (+ the workgroup's next scan)
 }
-// Every wavefront works on its own: a static deal of the scan's task list (wavefront w of W takes tasks w, w + W, ...),
+// Every wavefront works on its own: tasks from the scan's queue (a wavefront's first two by position, the others by ticket),
 // no workgroup barrier after the pose table is in place, no LDS window of live points.  A workgroup is as large as a CU holds
 // wavefronts of this kernel (1024 threads at 128 registers): one pose table per CU.
 template <bool LPOSE, bool PROF>
@@ -806,33 +917,44 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int lq = lane;
     asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
-    const ScanDev &SC = scans[blockIdx.y];
-    const int T = SC.T;
+    const int T = scans[blockIdx.y].T;   // (one T per block)
     const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
     const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
     unsigned long long *smask = reinterpret_cast<unsigned long long *>(dynsm + poseB) + (size_t)wv * (B4_CPT * T);
+    int *nextScan = reinterpret_cast<int *>(dynsm + poseB + (size_t)B4_JW * (B4_CPT * T * 8));
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
-    B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
     B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
-    B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
-    B4_CONST(v4u) tasks = b4_const(reinterpret_cast<const v4u *>(SC.tasks));
-    B4_CNT counts = (B4_CNT)(SC.counts);
-    const unsigned nH = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[0], (unsigned)SC.maxTasks));
-    const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
+    const unsigned TK = (dbg >> 16) & 255 ? (unsigned)((dbg >> 16) & 255) : B4_TK;   // (MODEST_PP4_TK: tasks per ticket, experiments)
     const unsigned W = gridDim.x * B4_JW;
     const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * B4_JW + (unsigned)wv));   // (wave-uniform: task descriptors and candidates are scalar loads)
 
     // PROF (MODEST_PP4_DBG=512): wall time of this wavefront by phase -- 0 pose table, 1 one-cell tasks: transform (incl. the wait
     // for the records), 2 masks, 3 pair phase, 4 four-cell tasks: segs + transform, 5 masks, 6 pair phase; 8 / 9 task counts
     unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = PROF ? wall_clock64() : 0ULL;
+    const unsigned long long pstart = plast;
 #define B4_TICK(kk)                                                 \
     if (PROF) {                                                     \
         const unsigned long long now_ = wall_clock64(); \
         pacc[kk] += now_ - plast;                                   \
         plast = now_;                                               \
     }
-    if (LPOSE) {   // the scan's poses: read once per workgroup
+    // A workgroup starts on the scan of its grid row and, once that scan's queues are empty, HELPS the scan with the most tasks
+    // left (a scan's work differs by up to 1.5 x -- the scans in the middle of a block read two boundary segments per cell --, and
+    // a grid row that ends early leaves its CUs idle): the pose table of the new scan replaces the old one, tasks come from
+    // tickets only.
+    int scanIdx = (int)blockIdx.y;
+#pragma unroll 1
+    for (int visit = 0; visit <= B.G; ++visit) {
+    const ScanDev &SC = scans[scanIdx];
+    B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
+    B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
+    B4_CONST(v4u) tasks = b4_const(reinterpret_cast<const v4u *>(SC.tasks));
+    B4_CNT counts = (B4_CNT)(SC.counts);
+    B4_TICKET ticketH = (B4_TICKET)(SC.ctrl + 32), ticketL = (B4_TICKET)(SC.ctrl + 48);
+    const unsigned nH = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[0], (unsigned)SC.maxTasks));
+    const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
+    if (LPOSE) {   // the scan's poses: read once per workgroup and visit
         float4 *pw = reinterpret_cast<float4 *>(dynsm);
         signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
         for (int f = tid; f < B.U; f += B4_JT) {
@@ -880,7 +1002,23 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
 
     // ======== one-cell tasks: the records of the NEXT task are requested before the pair phase of the current one ========
     if (!(dbg & 8)) {
-        unsigned t = w0;
+        // The deal is DYNAMIC: a wavefront's first two tasks are w and w + W, every later one is a ticket of the scan's queue
+        // (2 W + the counter; a ticket is a batch of B4_TK consecutive tasks), asked for a batch ahead.
+        // (A static deal w, w + W, ... left the wavefronts ending anywhere between 50 % and 100 % of the kernel's span: a task's
+        // cost is its number of candidates, and a wavefront's 130 tasks do not average that out.)
+        unsigned bnext = 0, bleft = 0;   // (the rest of the wavefront's current batch)
+        unsigned tk = b4_ticket_request(ticketH, lane);
+        auto next_task = [&]() {
+            if (bleft == 0u) {   // (the ticket was asked for a batch ago)
+                bnext = 2u * W + TK * (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+                bleft = TK;
+                tk = b4_ticket_request(ticketH, lane);
+            }
+            --bleft;
+            return bnext++;
+        };
+        unsigned t = w0, tn = w0 + W;
+        if (visit) t = next_task(), tn = next_task();
         v4u c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, n0 = {0, 0, 0, 0}, n1 = {0, 0, 0, 0};
         v4f R[B4_CPT];
         if (t < nH) {
@@ -888,7 +1026,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             const unsigned start = c0.x, end = c0.y;
 #pragma unroll
             for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(start + u * 64 + lane, end - 1)]);
-            if (t + W < nH) n0 = tasks[2 * (size_t)(t + W)], n1 = tasks[2 * (size_t)(t + W) + 1];
+            if (tn < nH) n0 = tasks[2 * (size_t)tn], n1 = tasks[2 * (size_t)tn + 1];
         }
         while (t < nH) {
             const unsigned start = c0.x, end = c0.y;
@@ -933,21 +1071,21 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             B4_TICK(2)
             const unsigned aR[3] = {c0.z, c1.x, c1.z}, nR[3] = {c0.w, c1.y, c1.w};
             // the next task: its record loads are in flight during the pair phase below; the task after it: its descriptor
-            const unsigned tn = t + W;
             if (tn < nH) {
                 const unsigned s2 = n0.x, e2 = n0.y;
 #pragma unroll
                 for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(s2 + u * 64 + lane, e2 - 1)]);
             }
+            const unsigned tnn = next_task();
             v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-            if (tn + W < nH) f0 = tasks[2 * (size_t)(tn + W)], f1 = tasks[2 * (size_t)(tn + W) + 1];
+            if (tnn < nH) f0 = tasks[2 * (size_t)tnn], f1 = tasks[2 * (size_t)tnn + 1];
             if (!(dbg & 1)) {
                 static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
                 if (nch <= 2) b4_pairs_rows<1>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
                 else b4_pairs_rows<2>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
             }
             B4_TICK(3)
-            t = tn;
+            t = tn, tn = tnn;
             c0 = n0, c1 = n1;
             n0 = f0, n1 = f1;
         }
@@ -956,7 +1094,19 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     if (!(dbg & 2)) {
         B4_CONST(v4u) lhead = b4_const(reinterpret_cast<const v4u *>(SC.ltHead));
         B4_CONST(v4u) lsegs = b4_const(reinterpret_cast<const v4u *>(SC.ltSegs));
-        unsigned t = w0;
+        unsigned bnext = 0, bleft = 0;   // (the same dynamic deal)
+        unsigned tk = b4_ticket_request(ticketL, lane);
+        auto next_task = [&]() {
+            if (bleft == 0u) {
+                bnext = 2u * W + TK * (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+                bleft = TK;
+                tk = b4_ticket_request(ticketL, lane);
+            }
+            --bleft;
+            return bnext++;
+        };
+        unsigned t = w0, tn = w0 + W;
+        if (visit) t = next_task(), tn = next_task();
         v4u h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
         v4f R[B4_CPT];
         auto request = [&](const v4u a, const v4u b) {   // a lane without a record re-reads the cell's last one (an empty cell: record 0)
@@ -968,7 +1118,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         if (t < nL) {
             h0 = lhead[2 * (size_t)t], h1 = lhead[2 * (size_t)t + 1];
             request(h0, h1);
-            if (t + W < nL) m0 = lhead[2 * (size_t)(t + W)], m1 = lhead[2 * (size_t)(t + W) + 1];
+            if (tn < nL) m0 = lhead[2 * (size_t)tn], m1 = lhead[2 * (size_t)tn + 1];
         }
         while (t < nL) {
             const unsigned nn[B4_CPT] = {h0.y, h0.w, h1.y, h1.w};
@@ -1005,23 +1155,47 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             v4u g[2 * B4_CPT];
 #pragma unroll
             for (int u = 0; u < 2 * B4_CPT; ++u) g[u] = lsegs[8 * (size_t)t + u];
-            const unsigned tn = t + W;
             if (tn < nL) request(m0, m1);
+            const unsigned tnn = next_task();
             v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-            if (tn + W < nL) f0 = lhead[2 * (size_t)(tn + W)], f1 = lhead[2 * (size_t)(tn + W) + 1];
+            if (tnn < nL) f0 = lhead[2 * (size_t)tnn], f1 = lhead[2 * (size_t)tnn + 1];
             if (!(dbg & 1)) {
 #pragma unroll
                 for (int u = 0; u < B4_CPT; ++u)
                     if (nn[u]) b4_cell_rows(sortedC, counts, g[2 * u], g[2 * u + 1], hx[u], hy[u], hz[u], sLo[u], sHi[u], r2lo, r2hi, r2, lq, T);
             }
             B4_TICK(6)
-            t = tn;
+            t = tn, tn = tnn;
             h0 = m0, h1 = m1;
             m0 = f0, m1 = f1;
         }
     }
-    if (PROF && lane == 0)
+    // ---- the workgroup's next scan: the one with the most work left in its queues (thread 0 looks, everybody follows) ----
+    if (!LPOSE || (dbg & 1024)) break;   // (MODEST_PP4_DBG=1024: no helping; more than 1 024 union entries: the variant without the LDS table keeps its registers)
+    __syncthreads();   // (every wavefront is done with the pose table)
+    if (tid == 0) {
+        int best = -1;
+        unsigned bestRem = 48u;   // (less than this is not worth a pose table)
+        for (int s = 0; s < B.G; ++s) {
+            const ScanDev &Q = scans[s];
+            const unsigned qH = min(Q.ctrl[0], (unsigned)Q.maxTasks), qL = min(Q.ctrl[1], (unsigned)Q.maxLight);
+            const unsigned gH = 2u * W + TK * __hip_atomic_load(Q.ctrl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned gL = 2u * W + TK * __hip_atomic_load(Q.ctrl + 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned rem = 3u * (qH > gH ? qH - gH : 0u) + (qL > gL ? qL - gL : 0u);
+            if (rem > bestRem) bestRem = rem, best = s;
+        }
+        *nextScan = best;
+    }
+    __syncthreads();
+    scanIdx = __builtin_amdgcn_readfirstlane(*nextScan);
+    if (scanIdx < 0) break;
+    }
+    if (PROF && lane == 0) {
         for (int kk = 0; kk < 10; ++kk) atomicAdd(&prof[kk], pacc[kk]);
+        // (recA is free once the store is sorted: absolute start / end of every wavefront, for the tail statistics)
+        unsigned long long *wt = reinterpret_cast<unsigned long long *>(B.recA) + 2 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * B4_JW + wv);
+        wt[0] = pstart, wt[1] = wall_clock64();
+    }
 #undef B4_TICK
 }
 
@@ -1116,9 +1290,10 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oOff = take((size_t)std::max(U, 1) * BT * 4), oGtot = take((size_t)std::max(NG, 1) * BT * 4);
     const size_t oTotal = take((size_t)BT * 4), oBase = take((size_t)BT * 4), oSegBase = take((size_t)BT * 4);
     const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
-    const size_t oCellOff = take((size_t)BT * 65 * 4), oCtrl = take(256), oSegRange = take(maxSegs * 8);
-    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8), oNeed = take((size_t)BT * 4);
+    const size_t oCellOff = take((size_t)BT * 65 * 4), oSegRange = take(maxSegs * 8);
+    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8), oNeed = take((size_t)BT * 4), oNeedCand = take((size_t)BT * 4), oNeedMask = take((size_t)BT * 8);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
+    const size_t oCtrl = take(256);   // (directly in front of the cell counters: cleared by the same memset)
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
         size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, ltHead, ltSegs, counts;
@@ -1230,6 +1405,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     B.ctrl = reinterpret_cast<unsigned *>(base + oCtrl);
     B.baseSum = reinterpret_cast<unsigned *>(base + oBaseSum);
     B.needList = reinterpret_cast<unsigned *>(base + oNeed);
+    B.needCand = reinterpret_cast<unsigned *>(base + oNeedCand);
+    B.needMask = reinterpret_cast<unsigned long long *>(base + oNeedMask);
     B.recA = reinterpret_cast<float4 *>(base + oRecA);
     B.recB = reinterpret_cast<float4 *>(base + oRecB);
     B.U = U, B.NG = NG, B.nchunks = (int)nch, B.maxSegs = (int)maxSegs;
@@ -1250,11 +1427,12 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         attr_done[ctx->device & 63] = true;
     }
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
-    MODEST_HIP_CHECK(hipMemsetAsync(base + oCellCount, 0, (size_t)G * (NCpad + 4) * 4, stream));
+    MODEST_HIP_CHECK(hipMemsetAsync(base + oCtrl, 0, 256, stream));   // (the block's cursors and crop)
     const unsigned gBT = (unsigned)((BT + 255) / 256), gN = (unsigned)((maxN + 255) / 256);
     if (U > 0 && ntot > 0) {
-        b4_counts<<<dim3(gBT, (unsigned)NG), 256, 0, stream>>>(B);
-        b4_lists<<<gBT, 256, 0, stream>>>(B, dsc);
+        b4_need<<<gBT, 256, 0, stream>>>(B, dsc);
+        b4_counts<<<dim3(gBT, (unsigned)NG), 256, 0, stream>>>(B);   // (over the needed tiles: the workgroups behind them leave at once)
+        b4_lists<<<gBT, 256, 0, stream>>>(B);
         b4_bases_local<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
         b4_bases_finish<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
         const int swg = std::min((int)nch, 3 * ctx->num_cus);
@@ -1262,6 +1440,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         b4_seg_hist<<<(unsigned)maxSegs, 512, 0, stream>>>(B);
         b4_seg_scan<<<(unsigned)((BT + 3) / 4), 256, 0, stream>>>(B);
         b4_seg_scatter<<<(unsigned)maxSegs, 512, B4_SEG * 16, stream>>>(B);
+        b4_zero_cells<<<dim3((unsigned)nScanBlk, (unsigned)G), 1024, 0, stream>>>(B, dsc);
         b4_live_count<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(B, dsc);
         b4_scan_local<<<dim3((unsigned)nScanBlk, (unsigned)G), 1024, 0, stream>>>(B, dsc);
         b4_scan_finish<<<(unsigned)G, 1024, 0, stream>>>(B, dsc);
@@ -1271,7 +1450,8 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         unsigned jx = (unsigned)((jw_env ? atoi(jw_env) : 1) * ctx->num_cus) / (unsigned)G;   // one workgroup of 16 wavefronts per CU
         if (jx < 2) jx = 2;
         const char *dbg_env = getenv("MODEST_PP4_DBG");   // ablations: 1 no pair phase, 2 no four-cell tasks, 8 no one-cell tasks, 256 poses from memory, 512 phase times
-        const int dbg = dbg_env ? atoi(dbg_env) : 0;
+        const char *tk_env = getenv("MODEST_PP4_TK");
+        const int dbg = (dbg_env ? atoi(dbg_env) : 0) | ((tk_env ? atoi(tk_env) & 255 : 0) << 16);
         const bool lpose = U <= B4_POSE_LDS_MAX && !(dbg & 256);
         const unsigned ldsB = b4_join_lds(U, T, lpose);
         if ((dbg & 512) && lpose) {   // MODEST_PP4_DBG=512: wall time of the join's wavefronts by phase (blocking; diagnostics only)
@@ -1280,6 +1460,31 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
             b4_join<true, true><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, dprof);
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hprof, dprof, sizeof(hprof), hipMemcpyDeviceToHost));
+            {   // when do the wavefronts end?  (share of the kernel's span a wavefront is present, per scan and overall)
+                const size_t nw = (size_t)jx * G * B4_JW;
+                const double us = 1.0 / 100.0;   // wall_clock64 ticks at 100 MHz
+                if (nw * 16 <= (size_t)ntot * 16) {
+                    std::vector<unsigned long long> wt(2 * nw);
+                    MODEST_HIP_CHECK(hipMemcpy(wt.data(), base + oRecA, nw * 16, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ULL, t1 = 0;
+                    for (size_t i = 0; i < nw; ++i) t0 = std::min(t0, wt[2 * i]), t1 = std::max(t1, wt[2 * i + 1]);
+                    std::vector<double> en(nw);
+                    double sum = 0, sumStart = 0;
+                    for (size_t i = 0; i < nw; ++i) en[i] = (double)(wt[2 * i + 1] - t0), sum += en[i], sumStart += (double)(wt[2 * i] - t0);
+                    std::sort(en.begin(), en.end());
+                    fprintf(stderr, "[b4_join] span %.1f us; wavefront end: mean %.1f, p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f us; mean start %.1f us\n",
+                            (double)(t1 - t0) * us, sum / nw * us, en[nw / 10] * us, en[nw / 2] * us, en[nw * 9 / 10] * us, en[nw * 99 / 100] * us, sumStart / nw * us);
+                    for (int s = 0; s < G; ++s) {   // per scan: the last wavefront and the mean
+                        double mx = 0, mean = 0;
+                        const size_t per = (size_t)jx * B4_JW;
+                        for (size_t i = 0; i < per; ++i) {
+                            const double e = (double)(wt[2 * ((size_t)s * per + i) + 1] - t0);
+                            mx = std::max(mx, e), mean += e;
+                        }
+                        fprintf(stderr, "[b4_join]   scan %d: wavefronts end at mean %.1f, max %.1f us\n", s, mean / per * us, mx * us);
+                    }
+                }
+            }
             const double wv = (double)jx * G * B4_JW, us = 1.0 / 100.0;   // s_memtime ticks at 100 MHz
             fprintf(stderr, "[b4_join] per wavefront, us: pose table %.1f | one-cell tasks: records + transform %.1f, masks %.1f, pairs %.1f | "
                             "four-cell tasks: records + transform %.1f, masks %.1f, pairs %.1f || per scan: one-cell tasks %.0f, four-cell tasks %.0f\n",
