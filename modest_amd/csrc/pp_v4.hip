@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void b4_need(Blk B, const ScanDev *__restrict_
     if (b >= B.BT) return;
     const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
     unsigned long long mask = 0ULL;
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < B.G; ++s) {
         const ScanDev &S = scans[s];
         const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
@@ -603,16 +603,32 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     const B4Crop C = b4_crop(B);
     // (a wavefront per tile of the list, eight wavefronts per SIMD: the window has four times as many tiles as the list, and a
     // launch over all of them spent more time starting wavefronts that leave at once than on the tiles with work)
+    // Every trip is a chain of dependent load rounds; the first two (the tile, its list header) are requested a trip ahead, and
+    // everything that depends on the tile alone (cell bases, the live runs around every cell) is requested before the round that
+    // finds the scan's segments: three rounds per trip instead of five.
+    const unsigned stride = gridDim.x * 4;
+    unsigned it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned bC = it < nNeed ? B.needList[it] : 0u, bN = it + stride < nNeed ? B.needList[it + stride] : 0u;
+    unsigned long long mC = B.needMask[bC];
+    unsigned tC = B.listTotal[bC], sC = B.segBase[bC];
 #pragma unroll 1
-    for (unsigned it = blockIdx.x * 4 + (threadIdx.x >> 6); it < nNeed; it += gridDim.x * 4) {
-    const int b = (int)B.needList[it];
-    if (!((B.needMask[b] >> blockIdx.y) & 1ULL)) continue;   // (no live point of THIS scan around the tile: wave-uniform)
-    const unsigned total = B.listTotal[b];
+    for (; it < nNeed; it += stride) {
+    const unsigned bNN = it + 2 * stride < nNeed ? B.needList[it + 2 * stride] : 0u;
+    const unsigned long long mN = B.needMask[bN];
+    const unsigned tN = B.listTotal[bN], sN = B.segBase[bN];
+    do {
+    const int b = (int)bC;
+    if (!((mC >> blockIdx.y) & 1ULL)) break;   // (no live point of THIS scan around the tile: wave-uniform)
+    const unsigned total = tC;
+    const unsigned base = B.cellOff[(size_t)b * 65 + lane], next = B.cellOff[(size_t)b * 65 + lane + 1];
+    const int cx = (b % B.BW - C.x0) * 8 + (lane & 7), cy = (b / B.BW - C.y0) * 8 + (lane >> 3);   // (on the crop)
+    unsigned sa[3], sn[3];
+    b4_cell_segs(S.cellStart, S.blockSum, C.CW, C.CH, cx, cy, sa, sn);
     // The part of every cell this scan reads.  The tile list is in the order of the block's frame table and its
     // segments were sorted one by one, so a cell's records are [run of segment 0 | run of segment 1 | ...] with ascending
     // frame slots from run to run: the runs of the segments that overlap [slotLo, slotHi] hold every record of the
     // scan's own frames (and, in the two boundary runs, some of the block's other scans' frames: masked per lane).
-    const unsigned ns = (total + B4_SEG - 1) / B4_SEG, s0 = B.segBase[b];
+    const unsigned ns = (total + B4_SEG - 1) / B4_SEG, s0 = sC;
     unsigned kf = ns, kl = 0;
     bool any = false;
     for (unsigned k0 = 0; k0 < ns; k0 += 64) {   // (lane = segment: one round of loads for up to 64 segments)
@@ -625,15 +641,11 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
             any = true;
         }
     }
-    // (every load below is issued whether or not its value is used: the compiler waits for a load inside the branch
+    // (every load is issued whether or not its value is used: the compiler waits for a load inside the branch
     // that holds it, and this kernel is nothing but dependent loads)
     if (!any) kf = 0, kl = 0;
-    const unsigned base = B.cellOff[(size_t)b * 65 + lane], next = B.cellOff[(size_t)b * 65 + lane + 1];
     const unsigned oFirst = B.segOff[(size_t)(s0 + kf) * 64 + lane];
     const unsigned oEnd = B.segOff[(size_t)(s0 + min(kl + 1, ns - 1)) * 64 + lane];
-    const int cx = (b % B.BW - C.x0) * 8 + (lane & 7), cy = (b / B.BW - C.y0) * 8 + (lane >> 3);   // (on the crop)
-    unsigned sa[3], sn[3];
-    b4_cell_segs(S.cellStart, S.blockSum, C.CW, C.CH, cx, cy, sa, sn);
     const unsigned cand = sn[0] + sn[1] + sn[2];
     const unsigned start = base + oFirst;
     const unsigned end = kl + 1 < ns ? base + oEnd : next;
@@ -650,16 +662,20 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
         }
     }
     const unsigned TH = __shfl(incT, 63), LV = __shfl(incL, 63);
-    if (TH + LV == 0u) continue;
+    if (TH + LV == 0u) break;
     // sparse cells: FOUR cells to a task (a cell per 64-lane chunk of the wavefront, each with its own three candidate runs)
     const bool isL = lv != 0u;
     const unsigned long long lmask = __ballot(isL);
     const unsigned nLc = (unsigned)__popcll(lmask), li = (unsigned)__popcll(lmask & ((1ULL << lane) - 1ULL));
     const unsigned nL = (nLc + 3) >> 2;   // <= 16
+    // ONE cursor atomic per tile: both list positions in a 64-bit word (ctrl[0] one-cell tasks | ctrl[1] four-cell tasks).  The
+    // cursors of a scan are one address for every wavefront of its grid row, and atomics on one address are served one after
+    // the other.  (Ablation, us per block of 16: loads 27, + prefix sums 34, + cursors and descriptor writes 71 -- the loop below
+    // writes a cell's tasks one per trip with only that cell's lane active.)
     unsigned tb = 0, lb = 0;
     if (lane == 0) {
-        if (TH) tb = atomicAdd(&S.ctrl[0], TH);
-        if (nL) lb = atomicAdd(&S.ctrl[1], nL);
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(S.ctrl), (unsigned long long)TH | ((unsigned long long)nL << 32));
+        tb = (unsigned)old, lb = (unsigned)(old >> 32);
     }
     tb = __shfl(tb, 0), lb = __shfl(lb, 0);
     {
@@ -688,6 +704,8 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
             out[2 * (size_t)idx + 1] = make_uint4(sa[1], sn[1], sa[2], sn[2]);
         }
     }
+    } while (false);
+    bC = bN, bN = bNN, mC = mN, tC = tN, sC = sN;
     }
 }
 
@@ -1000,8 +1018,15 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         *trv = ok ? t : -1;
     };
 
+    // The two queues in an order that depends on the wavefront: the first LF wavefronts of a workgroup start with the four-cell
+    // tasks, the others with the one-cell tasks.  Blocks of 16 scans: LF = 0 (measured 0 / 2 / 4 / 6 / 8: 82.8 / 84.6 / 86.7 / 85.1 /
+    // 87.2 us per scan); blocks of 4, where a scan's queues are spread over 64 workgroups: 191 / 192 / 186 / 184 / 177 -> LF = 8.
+    const bool lightFirst = wv < ((dbg >> 24) & 31);
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+    const bool doLight = (ph == 0) == lightFirst;
     // ======== one-cell tasks: the records of the NEXT task are requested before the pair phase of the current one ========
-    if (!(dbg & 8)) {
+    if (!doLight && !(dbg & 8)) {
         // The deal is DYNAMIC: a wavefront's first two tasks are w and w + W, every later one is a ticket of the scan's queue
         // (2 W + the counter; a ticket is a batch of B4_TK consecutive tasks), asked for a batch ahead.
         // (A static deal w, w + W, ... left the wavefronts ending anywhere between 50 % and 100 % of the kernel's span: a task's
@@ -1091,7 +1116,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
     }
     // ======== sparse cells (< 64 records of the scan): four cells to a task, a cell per chunk, each with its own candidates ========
-    if (!(dbg & 2)) {
+    if (doLight && !(dbg & 2)) {
         B4_CONST(v4u) lhead = b4_const(reinterpret_cast<const v4u *>(SC.ltHead));
         B4_CONST(v4u) lsegs = b4_const(reinterpret_cast<const v4u *>(SC.ltSegs));
         unsigned bnext = 0, bleft = 0;   // (the same dynamic deal)
@@ -1169,6 +1194,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             h0 = m0, h1 = m1;
             m0 = f0, m1 = f1;
         }
+    }
     }
     // ---- the workgroup's next scan: the one with the most work left in its queues (thread 0 looks, everybody follows) ----
     if (!LPOSE || (dbg & 1024)) break;   // (MODEST_PP4_DBG=1024: no helping; more than 1 024 union entries: the variant without the LDS table keeps its registers)
@@ -1451,7 +1477,9 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         if (jx < 2) jx = 2;
         const char *dbg_env = getenv("MODEST_PP4_DBG");   // ablations: 1 no pair phase, 2 no four-cell tasks, 8 no one-cell tasks, 256 poses from memory, 512 phase times
         const char *tk_env = getenv("MODEST_PP4_TK");
-        const int dbg = (dbg_env ? atoi(dbg_env) : 0) | ((tk_env ? atoi(tk_env) & 255 : 0) << 16);
+        const char *lf_env = getenv("MODEST_PP4_LF");   // wavefronts of a join workgroup that start with the four-cell tasks
+        const int lf = lf_env ? atoi(lf_env) & 31 : (G <= 6 ? 8 : 0);
+        const int dbg = (dbg_env ? atoi(dbg_env) : 0) | ((tk_env ? atoi(tk_env) & 255 : 0) << 16) | (lf << 24);
         const bool lpose = U <= B4_POSE_LDS_MAX && !(dbg & 256);
         const unsigned ldsB = b4_join_lds(U, T, lpose);
         if ((dbg & 512) && lpose) {   // MODEST_PP4_DBG=512: wall time of the join's wavefronts by phase (blocking; diagnostics only)
