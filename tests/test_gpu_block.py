@@ -247,3 +247,44 @@ def test_block_refuses_a_member_list_that_names_a_slot_twice(gpu):
     rc = lib.modest_pp_score_block(store._ctx().handle, fr.ctypes.data, len(fr), sc.ctypes.data, 2, 2, 0.3, store.cell,
                                    torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"twice" in lib.modest_last_error()
+
+
+def test_block_more_than_1024_union_entries(gpu):
+    """More union entries than the join's LDS pose table holds (1 024): the variant that reads the poses from memory (and keeps
+    to its own scan's queues) == the per-scan chain, and == the oracle on the first and the last scan."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    T, F, S = 40, 20, 8
+    sh = synth.make_shard(S, n_live=2000, n_trav=T, n_frames=F, n_per_frame=400, seed=21)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, _ = _load(store, sh, gpu, torch)
+    tabs = store.block_tables(descs, T, force=True)
+    assert tabs is not None
+    Hb, cb = store.pp_score_batch(lives, descs, T, return_counts=True, block=True)
+    Hv, cv = store.pp_score_batch(lives, descs, T, return_counts=True, block=False)
+    for i in range(S):
+        assert torch.equal(cb[i], cv[i]) and torch.equal(Hb[i], Hv[i]), i
+    for i in (0, S - 1):
+        assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), _oracle_counts(sh, i)[1]), i
+    assert T * (F + S - 1) > 1024 and int(sum(int(c.sum()) for c in cb)) > 0
+
+
+@pytest.mark.parametrize("tk,lf", [(1, 0), (3, 4), (2, 16), (7, 1)])
+def test_block_join_deal_does_not_change_counts(gpu, monkeypatch, tk, lf):
+    """The join deals its tasks dynamically (tickets of MODEST_PP4_TK tasks, MODEST_PP4_LF wavefronts of a workgroup start with
+    the four-cell queue, workgroups help other scans): every count is an integer sum over tasks, whatever the deal."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    sh = synth.make_shard(9, n_live=6000, n_trav=4, n_frames=8, seed=13)
+    store = FrameStore(gpu, 0.3)
+    lives, descs, _ = _load(store, sh, gpu, torch)
+    ref = store.pp_score_batch(lives, descs, 4, return_counts=True, block=False)[1]
+    monkeypatch.setenv("MODEST_PP4_TK", str(tk))
+    monkeypatch.setenv("MODEST_PP4_LF", str(lf))
+    got = store.pp_score_batch(lives, descs, 4, return_counts=True, block=True)[1]
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    monkeypatch.setenv("MODEST_PP4_DBG", "1024")   # no helping
+    got = store.pp_score_batch(lives, descs, 4, return_counts=True, block=True)[1]
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
