@@ -54,9 +54,11 @@ constexpr int B4_CH = 4096;                // points per streaming chunk (1024 t
 #define B4_SKIP0_ 0
 #endif
 #ifndef B4_SEG_
-#define B4_SEG_ 4096
+#define B4_SEG_ 2048
 #endif
-constexpr int B4_SEG = B4_SEG_;            // records per sort segment (512 threads x 8)
+constexpr int B4_SEG = B4_SEG_;            // records per sort segment.  A scan reads whole segments, and the two at the ends of its slot range also
+                                           // hold other scans' frames (masked per lane: 17 % of the join's pair tests at 4096): 4096 / 2048 / 1024 records
+                                           // = 84.5 / 81.7 / ~82 us per scan (the sort passes grow by 6 / 35 us per block)
 constexpr int B4_FG = 32;                  // frames per prefix group
 constexpr unsigned B4_HEAVY = 64;          // cells with at least this many records get tasks of their own
 #ifndef B4_CPT_
@@ -766,7 +768,7 @@ __device__ __forceinline__ unsigned b4_bcnt(unsigned x, unsigned acc) {
 typedef float v8f __attribute__((ext_vector_type(8)));
 // one candidate (q: wave-uniform, in SGPRs) against the task's chunks: hit counts of this lane's traversal; ORs the pairs
 // inside the band into *band
-template <int NP>
+template <int NP, bool ODD>
 __device__ __forceinline__ unsigned b4_pair_step(float qx_, float qy_, float qz_, const v2f *hx, const v2f *hy, const v2f *hz,
                                                  const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi,
                                                  unsigned long long *band) {
@@ -801,9 +803,17 @@ __device__ __forceinline__ unsigned b4_pair_step(float qx_, float qy_, float qz_
         }
 #endif
     }
+    if (ODD) {   // a task of one or three chunks: the last chunk on its own (13 instructions instead of a half-empty pair's 18)
+        const float dx = qx_ - hx[NP].x, dy = qy_ - hy[NP].x, dz = qz_ - hz[NP].x;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const unsigned long long hA = __ballot(d2 < r2lo), mA = __ballot(d2 <= r2hi);
+        *band |= hA ^ mA;
+        acc = b4_bcnt((unsigned)hA & sLo[2 * NP], acc);
+        acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * NP], acc);
+    }
     return acc;
 }
-template <int NP>
+template <int NP, bool ODD>
 __device__ __forceinline__ unsigned long long b4_pairs(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie,
                                                        const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
                                                        const unsigned *sHi, float r2lo, float r2hi, int lq, int T) {
@@ -816,10 +826,10 @@ __device__ __forceinline__ unsigned long long b4_pairs(B4_CONST(v4f) sorted, B4_
 #pragma unroll 1
     for (unsigned i = ia; i < ie; i += 2) {
         const v8f qn = *(B4_CONST(v8f))(sorted + min(i + 2, ie - 1));   // the next two candidates: in flight during this trip
-        const unsigned accA = b4_pair_step<NP>(q[0], q[1], q[2], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
+        const unsigned accA = b4_pair_step<NP, ODD>(q[0], q[1], q[2], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
         if (lq < T && accA) b4_count_add_row(counts, __float_as_int(q[3]), T, 4u * (unsigned)lq, (int)accA);
         if (i + 1 < ie) {
-            const unsigned accB = b4_pair_step<NP>(q[4], q[5], q[6], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
+            const unsigned accB = b4_pair_step<NP, ODD>(q[4], q[5], q[6], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
             if (lq < T && accB) b4_count_add_row(counts, __float_as_int(q[7]), T, 4u * (unsigned)lq, (int)accB);
         }
         q = qn;
@@ -829,7 +839,7 @@ __device__ __forceinline__ unsigned long long b4_pairs(B4_CONST(v4f) sorted, B4_
 }
 // the pairs inside the band around r^2 (a separate pass over the task's candidates, entered practically never: its
 // float64 temporaries must not live in the registers of the loop above)
-template <int NP>
+template <int NP, bool ODD>
 __device__ __forceinline__ void b4_pairs_band(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie, const v2f *hx,
                                               const v2f *hy, const v2f *hz, const unsigned *sLo, const unsigned *sHi, float r2lo,
                                               float r2hi, double r2, int lq, int T) {
@@ -849,10 +859,17 @@ __device__ __forceinline__ void b4_pairs_band(B4_CONST(v4f) sorted, B4_CNT count
             acc += __popc((unsigned)xA & sLo[2 * p]) + __popc((unsigned)(xA >> 32) & sHi[2 * p]);
             acc += __popc((unsigned)xB & sLo[2 * p + 1]) + __popc((unsigned)(xB >> 32) & sHi[2 * p + 1]);
         }
+        if (ODD) {
+            const float fx = q.x - hx[NP].x, fy = q.y - hy[NP].x, fz = q.z - hz[NP].x;
+            const float dA = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+            const bool bA = !(dA < r2lo) && dA <= r2hi;
+            const unsigned long long xA = __ballot(bA && pp_within(hx[NP].x, hy[NP].x, hz[NP].x, q.x, q.y, q.z, r2));
+            acc += __popc((unsigned)xA & sLo[2 * NP]) + __popc((unsigned)(xA >> 32) & sHi[2 * NP]);
+        }
         if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
     }
 }
-template <int NP>
+template <int NP, bool ODD>
 __device__ __forceinline__ void b4_pairs_rows(B4_CONST(v4f) sorted, B4_CNT counts, const unsigned *aR, const unsigned *nR,
                                               const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
                                               const unsigned *sHi, float r2lo, float r2hi, double r2, int lq, int T) {
@@ -860,13 +877,13 @@ __device__ __forceinline__ void b4_pairs_rows(B4_CONST(v4f) sorted, B4_CNT count
 #pragma unroll 1
     for (int rr = 0; rr < 3; ++rr) {
         const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
-        band |= b4_pairs<NP>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, lq, T);
+        band |= b4_pairs<NP, ODD>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, lq, T);
     }
     if (band) {
 #pragma unroll 1
         for (int rr = 0; rr < 3; ++rr) {
             const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
-            b4_pairs_band<NP>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+            b4_pairs_band<NP, ODD>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
         }
     }
 }
@@ -924,7 +941,7 @@ __host__ __device__ __forceinline__ unsigned b4_pose_bytes(int U) {
     return (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15));
 }
 __host__ __device__ __forceinline__ unsigned b4_join_lds(int U, int T, bool lpose) {
-    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8) + 16u;   // (+ the workgroup's next scan)
+    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8);
 }
 // Every wavefront works on its own: tasks from the scan's queue (a wavefront's first two by position, the others by ticket),
 // no workgroup barrier after the pose table is in place, no LDS window of live points.  A workgroup is as large as a CU holds
@@ -940,7 +957,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
     unsigned long long *smask = reinterpret_cast<unsigned long long *>(dynsm + poseB) + (size_t)wv * (B4_CPT * T);
-    int *nextScan = reinterpret_cast<int *>(dynsm + poseB + (size_t)B4_JW * (B4_CPT * T * 8));
     const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
     B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
     const unsigned TK = (dbg >> 16) & 255 ? (unsigned)((dbg >> 16) & 255) : B4_TK;   // (MODEST_PP4_TK: tasks per ticket, experiments)
@@ -957,13 +973,12 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         pacc[kk] += now_ - plast;                                   \
         plast = now_;                                               \
     }
-    // A workgroup starts on the scan of its grid row and, once that scan's queues are empty, HELPS the scan with the most tasks
-    // left (a scan's work differs by up to 1.5 x -- the scans in the middle of a block read two boundary segments per cell --, and
-    // a grid row that ends early leaves its CUs idle): the pose table of the new scan replaces the old one, tasks come from
-    // tickets only.
-    int scanIdx = (int)blockIdx.y;
-#pragma unroll 1
-    for (int visit = 0; visit <= B.G; ++visit) {
+    // (A workgroup that moved on to the scan with the most tasks left once its own queues were empty -- a scan's work differs by up
+    // to 1.5 x inside a block -- balanced the wavefronts' end times to 90 % of the span and changed nothing: the kernel is bound by
+    // instruction issue, not by its tail; it cost 15 registers.  Measured and removed.)
+    const int scanIdx = (int)blockIdx.y;
+    const int visit = 0;
+    {
     const ScanDev &SC = scans[scanIdx];
     B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
     B4_GLOBAL(v4f) pose = b4_global(reinterpret_cast<const v4f *>(SC.pose));
@@ -1106,8 +1121,10 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             if (tnn < nH) f0 = tasks[2 * (size_t)tnn], f1 = tasks[2 * (size_t)tnn + 1];
             if (!(dbg & 1)) {
                 static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
-                if (nch <= 2) b4_pairs_rows<1>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
-                else b4_pairs_rows<2>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+                if (nch == 4) b4_pairs_rows<2, false>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+                else if (nch == 2) b4_pairs_rows<1, false>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+                else if (nch == 3) b4_pairs_rows<1, true>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+                else b4_pairs_rows<0, true>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
             }
             B4_TICK(3)
             t = tn, tn = tnn;
@@ -1196,25 +1213,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
     }
     }
-    // ---- the workgroup's next scan: the one with the most work left in its queues (thread 0 looks, everybody follows) ----
-    if (!LPOSE || (dbg & 1024)) break;   // (MODEST_PP4_DBG=1024: no helping; more than 1 024 union entries: the variant without the LDS table keeps its registers)
-    __syncthreads();   // (every wavefront is done with the pose table)
-    if (tid == 0) {
-        int best = -1;
-        unsigned bestRem = 48u;   // (less than this is not worth a pose table)
-        for (int s = 0; s < B.G; ++s) {
-            const ScanDev &Q = scans[s];
-            const unsigned qH = min(Q.ctrl[0], (unsigned)Q.maxTasks), qL = min(Q.ctrl[1], (unsigned)Q.maxLight);
-            const unsigned gH = 2u * W + TK * __hip_atomic_load(Q.ctrl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned gL = 2u * W + TK * __hip_atomic_load(Q.ctrl + 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned rem = 3u * (qH > gH ? qH - gH : 0u) + (qL > gL ? qL - gL : 0u);
-            if (rem > bestRem) bestRem = rem, best = s;
-        }
-        *nextScan = best;
-    }
-    __syncthreads();
-    scanIdx = __builtin_amdgcn_readfirstlane(*nextScan);
-    if (scanIdx < 0) break;
     }
     if (PROF && lane == 0) {
         for (int kk = 0; kk < 10; ++kk) atomicAdd(&prof[kk], pacc[kk]);
