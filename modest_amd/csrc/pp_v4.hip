@@ -551,7 +551,7 @@ __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__r
     if (tid == 0) {
         S.blockSum[nBlk] = run;
         S.cellStart[(size_t)nBlk * B4_SCAN] = 0u;
-        S.ctrl[0] = 0u, S.ctrl[1] = 0u;   // b4_plan's cursors
+        S.ctrl[0] = 0u, S.ctrl[1] = 0u, S.ctrl[40] = 0u, S.ctrl[41] = 0u;   // b4_plan's cursors (from the front / from the back of the lists)
         S.ctrl[32] = 0u, S.ctrl[48] = 0u;   // b4_join's tickets (one-cell / four-cell tasks)
     }
 }
@@ -676,8 +676,14 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     // writes a cell's tasks one per trip with only that cell's lane active.)
     unsigned tb = 0, lb = 0;
     if (lane == 0) {
-        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(S.ctrl), (unsigned long long)TH | ((unsigned long long)nL << 32));
+        // (... and TWO such words per scan: the tiles with an even list position fill the task lists from the front, the others from the
+        // back -- the lists' capacity is a bound on their sum, so the two ends never meet.  A scan's cursor is ONE address for all the
+        // wavefronts of its grid row, atomics on one address are served one after the other (~14 ns), and 5 k tiles per scan made that
+        // queue this kernel's length whatever the number of scans.)
+        const bool down = it & 1u;
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(S.ctrl + (down ? 40 : 0)), (unsigned long long)TH | ((unsigned long long)nL << 32));
         tb = (unsigned)old, lb = (unsigned)(old >> 32);
+        if (down) tb = (unsigned)S.maxTasks - tb - TH, lb = (unsigned)S.maxLight - lb - nL;
     }
     tb = __shfl(tb, 0), lb = __shfl(lb, 0);
     {
@@ -985,8 +991,14 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     B4_CONST(v4u) tasks = b4_const(reinterpret_cast<const v4u *>(SC.tasks));
     B4_CNT counts = (B4_CNT)(SC.counts);
     B4_TICKET ticketH = (B4_TICKET)(SC.ctrl + 32), ticketL = (B4_TICKET)(SC.ctrl + 48);
-    const unsigned nH = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[0], (unsigned)SC.maxTasks));
-    const unsigned nL = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
+    // the task lists were filled from both ends (b4_plan): queue position -> list position
+    const unsigned nHu = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[0], (unsigned)SC.maxTasks));
+    const unsigned nLu = (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[1], (unsigned)SC.maxLight));
+    const unsigned nH = nHu + (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[40], (unsigned)SC.maxTasks - nHu));
+    const unsigned nL = nLu + (unsigned)__builtin_amdgcn_readfirstlane((int)min(SC.ctrl[41], (unsigned)SC.maxLight - nLu));
+    const unsigned backH = (unsigned)SC.maxTasks - 1u + nHu, backL = (unsigned)SC.maxLight - 1u + nLu;
+    auto posH = [&](unsigned t) { return (size_t)(t < nHu ? t : backH - t); };
+    auto posL = [&](unsigned t) { return (size_t)(t < nLu ? t : backL - t); };
     if (LPOSE) {   // the scan's poses: read once per workgroup and visit
         float4 *pw = reinterpret_cast<float4 *>(dynsm);
         signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
@@ -1062,11 +1074,11 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         v4u c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, n0 = {0, 0, 0, 0}, n1 = {0, 0, 0, 0};
         v4f R[B4_CPT];
         if (t < nH) {
-            c0 = tasks[2 * (size_t)t], c1 = tasks[2 * (size_t)t + 1];
+            c0 = tasks[2 * posH(t)], c1 = tasks[2 * posH(t) + 1];
             const unsigned start = c0.x, end = c0.y;
 #pragma unroll
             for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(start + u * 64 + lane, end - 1)]);
-            if (tn < nH) n0 = tasks[2 * (size_t)tn], n1 = tasks[2 * (size_t)tn + 1];
+            if (tn < nH) n0 = tasks[2 * posH(tn)], n1 = tasks[2 * posH(tn) + 1];
         }
         while (t < nH) {
             const unsigned start = c0.x, end = c0.y;
@@ -1118,7 +1130,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             }
             const unsigned tnn = next_task();
             v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-            if (tnn < nH) f0 = tasks[2 * (size_t)tnn], f1 = tasks[2 * (size_t)tnn + 1];
+            if (tnn < nH) f0 = tasks[2 * posH(tnn)], f1 = tasks[2 * posH(tnn) + 1];
             if (!(dbg & 1)) {
                 static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
                 if (nch == 4) b4_pairs_rows<2, false>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
@@ -1158,9 +1170,9 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             R[3] = __builtin_nontemporal_load(&rec[b.z + min((unsigned)lane, max(b.w, 1u) - 1u)]);
         };
         if (t < nL) {
-            h0 = lhead[2 * (size_t)t], h1 = lhead[2 * (size_t)t + 1];
+            h0 = lhead[2 * posL(t)], h1 = lhead[2 * posL(t) + 1];
             request(h0, h1);
-            if (tn < nL) m0 = lhead[2 * (size_t)tn], m1 = lhead[2 * (size_t)tn + 1];
+            if (tn < nL) m0 = lhead[2 * posL(tn)], m1 = lhead[2 * posL(tn) + 1];
         }
         while (t < nL) {
             const unsigned nn[B4_CPT] = {h0.y, h0.w, h1.y, h1.w};
@@ -1196,11 +1208,11 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             B4_TICK(5)
             v4u g[2 * B4_CPT];
 #pragma unroll
-            for (int u = 0; u < 2 * B4_CPT; ++u) g[u] = lsegs[8 * (size_t)t + u];
+            for (int u = 0; u < 2 * B4_CPT; ++u) g[u] = lsegs[8 * posL(t) + u];
             if (tn < nL) request(m0, m1);
             const unsigned tnn = next_task();
             v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-            if (tnn < nL) f0 = lhead[2 * (size_t)tnn], f1 = lhead[2 * (size_t)tnn + 1];
+            if (tnn < nL) f0 = lhead[2 * posL(tnn)], f1 = lhead[2 * posL(tnn) + 1];
             if (!(dbg & 1)) {
 #pragma unroll
                 for (int u = 0; u < B4_CPT; ++u)
