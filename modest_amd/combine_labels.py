@@ -101,7 +101,7 @@ def display_args(args):
 
 @config.main(config_name="combine_labels.yaml")
 def main(args):
-    rank, ws, local = dist.init()
+    rank, ws, local = dist.init(poll_wait=bool(args.get("poll_wait", True)))
     if rank == 0:
         display_args(args)
     torch.cuda.set_device(torch.device("cuda", local if ws > 1 else int(args.get("device", 0))))

@@ -741,6 +741,9 @@ __global__ __launch_bounds__(256) void rsd_draw(RsdScan *__restrict__ tab, int w
         F.n_trials = 0;
         F.words = 0u;
         F.drawn = 0;
+        // a fit that ends without a plane (small set, no consensus, degenerate refit) leaves a DEFINED one behind: the chain's mask
+        // kernel reads fit[0].plane4 of every scan before the host has seen the status and dropped the scan
+        F.plane4[0] = 0.0, F.plane4[1] = 0.0, F.plane4[2] = 1.0, F.plane4[3] = 0.0;
         s_stop = st;
         s_ntrip = 0;
     }

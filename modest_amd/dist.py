@@ -38,13 +38,14 @@ def runtime_defaults() -> None:
         os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 
-def init(backend: Optional[str] = None) -> tuple:
+def init(backend: Optional[str] = None, poll_wait: bool = True) -> tuple:
     """Initialise torch.distributed when launched with WORLD_SIZE > 1 -- or, with MODEST_DIST_FORCE=1, at world size 1
     too: the RCCL branches of barrier() / reduce_counters() (device_ids, CUDA tensors) then run on a box with a single
     GPU exactly as they do on a node (a launcher must have set MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE, or the
     defaults below apply).  A forced run prints the result of selfcheck() on stderr."""
     rank, ws, local = world()
-    if ws == 1:   # a rank of a multi-GPU job keeps the runtime's own wait mode for its RCCL traffic (polling under RCCL with
+    if ws == 1 and poll_wait:   # (config key `poll_wait: false`: a host without a spare core per waiting process keeps interrupt waits)
+        # a rank of a multi-GPU job keeps the runtime's own wait mode for its RCCL traffic (polling under RCCL with
         runtime_defaults()   # several ranks has not been on hardware yet); its worker / helper processes are single-rank
     force = os.environ.get("MODEST_DIST_FORCE", "") == "1"
     if (ws > 1 or force) and not torch.distributed.is_initialized():

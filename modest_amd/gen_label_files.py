@@ -98,7 +98,7 @@ def _pooled(args, rank, ws, local):
 
 @config.main(config_name="generate_label_files.yaml")
 def main(args):
-    rank, ws, local = dist.init()
+    rank, ws, local = dist.init(poll_wait=bool(args.get("poll_wait", True)))
     if rank == 0:
         display_args(args)
     torch.cuda.set_device(torch.device("cuda", dist.device_index(local, ws, args)))
