@@ -53,12 +53,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# Every helper gets at least MIN_STEPS_PER_HELPER steps.  The driver's 20-step run is a ~11 ms window
-# whichever way it is dealt (measured, four runs each: 8 helpers x 2-3 steps 1 640-1 810 scans/s, 6 x 3-4
-# 1 580-1 650, 5 x 4 1 520-1 710, 4 x 5 1 340-1 610), so the whole pool is used; a run with fewer than
-# STEADY_STEPS_PER_HELPER steps per helper also reports `steady_state`: the same pool over 24 steps per
+# Every helper gets at least MIN_STEPS_PER_HELPER steps.  The driver's 20-step run is a 6.5-7.5 ms window whichever way it
+# is dealt: few helpers carry long chains of stages 2 + 3 on their host side, many helpers run many small PP blocks one after
+# the other on the GPU (a block of 4 / 7 / 10 scans costs 0.74 / 0.79 / 0.90 ms).  Measured with the round-5 kernels, three runs
+# each (tools/r05_steps20.sh): 5 x 4 scans 2 620-3 020 scans/s, 4 x 5 2 540-2 770, 3 x 6-7 2 750-3 010, 2 x 10 2 640-2 840.
+# A run with fewer than STEADY_STEPS_PER_HELPER steps per helper also reports `steady_state`: the whole pool over 24 steps per
 # helper, measured after the contract region with its own barrier / synchronise bracket.
-MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "4"))
+MIN_STEPS_PER_HELPER = int(os.environ.get("MODEST_MIN_STEPS_PER_HELPER", "6"))
 STEADY_STEPS_PER_HELPER = 24
 
 
