@@ -11,18 +11,19 @@
 //
 //   * the frame store already keeps every frame sorted by the 8x8-cell tile of a WORLD lattice shared by all
 //     frames (pp_frames.hip), with a prefix table per frame.  The size of every tile list of the UNION of the
-//     chain's frames is therefore known before a single point is read (b4_counts / b4_lists / b4_bases:
-//     a column sum over the frame tables) -- no count pass, no count matrix, no occupancy bitmap;
+//     chain's frames is therefore known before a single point is read (b4_need / b4_counts / b4_lists / b4_bases:
+//     a column sum over the frame tables, for the tiles some scan needs) -- no count pass, no count matrix, no
+//     occupancy bitmap;
 //   * b4_scatter streams the union frames once and copies every point, RAW (frame coordinates) plus its
 //     frame slot and lattice cell, to its final position in its tile list (the position follows from the
 //     tables: no atomics); tiles no scan of the chain has a live point near are skipped;
-//   * b4_seg_hist / b4_seg_scan / b4_seg_scatter order every tile list by cell (counting sort over 4096-record
+//   * b4_seg_hist / b4_seg_scan / b4_seg_scatter order every tile list by cell (counting sort over 2048-record
 //     segments), so that the records of a cell are CONTIGUOUS in HBM for the whole chain;
 //   * per scan: the live scan is cell-sorted on the same lattice (b4_live_*), b4_plan writes a flat list of
 //     self-contained tasks (<= 256 records of ONE cell + the three runs of live points around it), and b4_join
 //     -- every wavefront on its own, no workgroup barrier, no LDS window -- reads a task's records straight into
-//     registers, applies the scan's own float32 pose to every record (transform_points' rounding, per (scan,
-//     frame)) and tests them against one wave-uniform candidate per step (read with a scalar load: the live
+//     registers (tasks dealt by tickets of the scan's queue), applies the scan's own float32 pose to every record
+//     (transform_points' rounding, per (scan, frame)) and tests them against one wave-uniform candidate per step (read with a scalar load: the live
 //     point arrives in SGPRs): ballots + traversal-segmented popcounts, one global atomic per (candidate,
 //     task).  Sparse cells (< 64 records) go four to a task, a cell per 64-lane chunk, each against its own candidates.
 //     (Round 4 dealt ITEMS of 24 tasks to whole workgroups, with the live window of a quad of tiles in LDS: four

@@ -140,7 +140,7 @@ def test_bench_two_ranks_two_helpers_one_gpu(gpu):
     line from rank 0, both ranks counted by an all-reduce, whole-job throughput over the max of the ranks' clocks; the line
     carries every helper's start-up seconds and peak resident set (what an 8 x 8 run multiplies by 64: DESIGN section 6)."""
     import time
-    env = dict(os.environ, MODEST_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MODEST_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MODEST_MIN_STEPS_PER_HELPER="4")   # (8 steps: two helpers per rank)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--procs", "2", "--steps", "8", "--warmup", "2", "--scans", "8",
