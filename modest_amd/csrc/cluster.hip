@@ -37,6 +37,7 @@ namespace {
 constexpr int CG = 128;              // grid is CG x CG cells
 constexpr int CG_CELLS = CG * CG;
 constexpr int WPB = 4;               // wavefronts per block
+constexpr int KNN_KEYS = 1024;       // in-radius candidates of a query whose float32 keys stay in LDS between the radix passes (4 KB per wavefront)
 constexpr double D_INF = __builtin_huge_val();
 
 struct CGrid {
@@ -279,18 +280,50 @@ __device__ __forceinline__ Rows rows_of(const float4 &q, const CGrid *g, const u
 // -- one more pass when the key is unique, a min/count loop over the ties otherwise.
 __device__ __forceinline__ void knn_kth_kernel_body(const float4 *__restrict__ sorted, int n, const CGrid *g, const unsigned *__restrict__ start, int k, double r2, double *__restrict__ kthS, const unsigned bx, const unsigned gx) {
     __shared__ unsigned hist_all[WPB][256];
+    __shared__ unsigned keys_all[WPB][KNN_KEYS];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = bx * WPB + w;
     if (s >= n) return;   // whole wave exits together
     unsigned *hist = hist_all[w];
+    unsigned *keys = keys_all[w];
     const float4 q = sorted[s];
     const Rows R = rows_of(q, g, start);
     unsigned prefix = 0, mask = 0, cntF = 0;
     int kk = k - 1;
     bool enough = true;
+    unsigned nkeys = 0;   // in-radius candidates seen by the first walk (their float32 keys are in LDS while there are at most KNN_KEYS)
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int b = lane; b < 256; b += 64) hist[b] = 0;
         __builtin_amdgcn_wave_barrier();
+        if (shift == 24) {
+            // the first walk computes every distance once and keeps the keys of the candidates inside the radius: the other three
+            // byte passes read those from LDS instead of walking the rows (and their float64 distances) again -- in chains of 16
+            // scans the kernel is bound by that arithmetic, not by the latency of the walk (a single scan was: round 3)
+    #pragma unroll
+    for (int r = 0; r < R.n; ++r)
+            for (unsigned base = R.s[r]; base < R.e[r]; base += 64) {   // wave-uniform trip count
+                const unsigned j = base + lane;
+                bool inr = false;
+                unsigned key = 0;
+                if (j < R.e[r] && (int)j != s) {
+                    const double d2 = dist2(q, sorted[j]);
+                    inr = d2 <= r2;
+                    key = __float_as_uint((float)d2);
+                }
+                const unsigned long long bal = __ballot(inr);
+                if (inr) {
+                    atomicAdd(&hist[(key >> 24) & 255u], 1u);
+                    const unsigned pos = nkeys + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
+                    if (pos < (unsigned)KNN_KEYS) keys[pos] = key;
+                }
+                nkeys += (unsigned)__popcll(bal);
+            }
+        } else if (nkeys <= (unsigned)KNN_KEYS) {
+            for (unsigned i = lane; i < nkeys; i += 64) {
+                const unsigned key = keys[i];
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+        } else {
     #pragma unroll
     for (int r = 0; r < R.n; ++r)
             for (unsigned j = R.s[r] + lane; j < R.e[r]; j += 64) {
@@ -301,6 +334,7 @@ __device__ __forceinline__ void knn_kth_kernel_body(const float4 *__restrict__ s
                     if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
                 }
             }
+        }
         __builtin_amdgcn_wave_barrier();
         // lane l owns bins 4l..4l+3
         const unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2],
@@ -599,15 +633,25 @@ __device__ __forceinline__ void degree_adj_kernel_body(const float4 *__restrict_
     const double kq = kthS[s];
     const Rows R = rows_of(q, g, start);
     unsigned total = 0;
+    // two batches of 64 candidates per trip, all four loads issued (on clamped indices) before the first is used: a row of three
+    // 2 m cells holds a few hundred kept points, and one batch per trip was a chain of dependent load rounds per query
+    // (179 -> 153 us per chain of 16 scans)
 #pragma unroll
     for (int r = 0; r < R.n; ++r)
-        for (unsigned base = R.s[r]; base < R.e[r]; base += 64) {   // wave-uniform trip count
-            const unsigned j = base + lane;
-            const bool e = j < R.e[r] && (int)j != s && edge_ok(q, kq, sorted[j], kthS[j], ep, s, j);
-            const unsigned long long bal = __ballot(e);
-            const unsigned pos = total + __popcll(bal & ((1ULL << lane) - 1ULL));
-            if (e && pos < (unsigned)ADJ) adj[(size_t)s * ADJ + pos] = ORIG ? sidx[j] : (int)j;
-            total += __popcll(bal);
+        for (unsigned base = R.s[r]; base < R.e[r]; base += 128) {   // wave-uniform trip count
+            const unsigned j0 = base + lane, j1 = j0 + 64;
+            const bool in0 = j0 < R.e[r], in1 = j1 < R.e[r];
+            const unsigned a0 = in0 ? j0 : (unsigned)s, a1 = in1 ? j1 : (unsigned)s;
+            const float4 c0 = sorted[a0], c1 = sorted[a1];
+            const double k0 = kthS[a0], k1 = kthS[a1];
+            const bool e0 = in0 && (int)j0 != s && edge_ok(q, kq, c0, k0, ep, s, j0);
+            const bool e1 = in1 && (int)j1 != s && edge_ok(q, kq, c1, k1, ep, s, j1);
+            const unsigned long long b0 = __ballot(e0), b1 = __ballot(e1);
+            const unsigned p0 = total + __popcll(b0 & ((1ULL << lane) - 1ULL));
+            const unsigned p1 = total + __popcll(b0) + __popcll(b1 & ((1ULL << lane) - 1ULL));
+            if (e0 && p0 < (unsigned)ADJ) adj[(size_t)s * ADJ + p0] = ORIG ? sidx[j0] : (int)j0;
+            if (e1 && p1 < (unsigned)ADJ) adj[(size_t)s * ADJ + p1] = ORIG ? sidx[j1] : (int)j1;
+            total += __popcll(b0) + __popcll(b1);
         }
     if (lane == 0) {
         deg[s] = (int)min(total, (unsigned)ADJ);
