@@ -157,11 +157,11 @@ __device__ __forceinline__ B4Crop b4_crop(const Blk &B) {
 // tiles are LISTED (7 k of the window's 25.6 k): the column sums below, the plan and the join only ever look at those.
 __global__ __launch_bounds__(256) void b4_need(Blk B, const ScanDev *__restrict__ scans) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B.BT) return;
+    const bool tile = b < B.BT;   // (no early exit: the wave reductions below want every lane of the last wavefront present)
     const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
     unsigned long long mask = 0ULL;
 #pragma unroll 8
-    for (int s = 0; s < B.G; ++s) {
+    for (int s = 0; s < (tile ? B.G : 0); ++s) {
         const ScanDev &S = scans[s];
         const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
         bool needed = false;
@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void b4_need(Blk B, const ScanDev *__restrict_
         }
         mask |= (unsigned long long)needed << s;
     }
-    B.needMask[b] = mask;
-    B.listTotal[b] = 0u;   // (b4_lists writes the totals of the needed tiles that hold points)
+    if (tile) {
+        B.needMask[b] = mask;
+        B.listTotal[b] = 0u;   // (b4_lists writes the totals of the needed tiles that hold points)
+    }
     // one cursor atomic per wavefront, the wavefront's tiles in order: neighbours in the list are neighbours in a tile row, and the
     // column sums below read and write neighbouring table entries
     const unsigned long long bal = __ballot(mask != 0ULL);
