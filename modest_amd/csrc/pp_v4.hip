@@ -51,9 +51,6 @@ constexpr int B4_NTF = MODEST_FRAME_NTF;   // tiles per axis of a frame table (1
 constexpr int B4_NTILE = B4_NTF * B4_NTF;
 constexpr int B4_MAXW = 160;               // block window: at most this many tiles per axis
 constexpr int B4_CH = 4096;                // points per streaming chunk (1024 threads x 4)
-#ifndef B4_SKIP0_
-#define B4_SKIP0_ 0
-#endif
 #ifndef B4_SEG_
 #define B4_SEG_ 2048
 #endif
@@ -792,25 +789,11 @@ __device__ __forceinline__ unsigned b4_pair_step(float qx_, float qy_, float qz_
         const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
         const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
         *band |= (hA ^ mA) | (hB ^ mB);
-#if B4_SKIP0_ == 1
-        if (hA | hB) {   // (wave-uniform: a chunk pair without a hit skips its eight mask / popcount instructions)
-#elif B4_SKIP0_ == 2
-        if (hA)
-#endif
-        {
+        // (a chunk pair without a hit could skip these eight instructions behind a scalar branch: measured, 5 % slower)
         acc = b4_bcnt((unsigned)hA & sLo[2 * p], acc);
         acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * p], acc);
-        }
-#if B4_SKIP0_ == 2
-        if (hB)
-#endif
-        {
         acc = b4_bcnt((unsigned)hB & sLo[2 * p + 1], acc);
         acc = b4_bcnt((unsigned)(hB >> 32) & sHi[2 * p + 1], acc);
-        }
-#if B4_SKIP0_ == 1
-        }
-#endif
     }
     if (ODD) {   // a task of one or three chunks: the last chunk on its own (13 instructions instead of a half-empty pair's 18)
         const float dx = qx_ - hx[NP].x, dy = qy_ - hy[NP].x, dz = qz_ - hz[NP].x;
@@ -986,7 +969,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     // to 1.5 x inside a block -- balanced the wavefronts' end times to 90 % of the span and changed nothing: the kernel is bound by
     // instruction issue, not by its tail; it cost 15 registers.  Measured and removed.)
     const int scanIdx = (int)blockIdx.y;
-    const int visit = 0;
     {
     const ScanDev &SC = scans[scanIdx];
     B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
@@ -1002,7 +984,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const unsigned backH = (unsigned)SC.maxTasks - 1u + nHu, backL = (unsigned)SC.maxLight - 1u + nLu;
     auto posH = [&](unsigned t) { return (size_t)(t < nHu ? t : backH - t); };
     auto posL = [&](unsigned t) { return (size_t)(t < nLu ? t : backL - t); };
-    if (LPOSE) {   // the scan's poses: read once per workgroup and visit
+    if (LPOSE) {   // the scan's poses: read once per workgroup
         float4 *pw = reinterpret_cast<float4 *>(dynsm);
         signed char *tw = reinterpret_cast<signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
         for (int f = tid; f < B.U; f += B4_JT) {
@@ -1073,7 +1055,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             return bnext++;
         };
         unsigned t = w0, tn = w0 + W;
-        if (visit) t = next_task(), tn = next_task();
         v4u c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, n0 = {0, 0, 0, 0}, n1 = {0, 0, 0, 0};
         v4f R[B4_CPT];
         if (t < nH) {
@@ -1163,7 +1144,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             return bnext++;
         };
         unsigned t = w0, tn = w0 + W;
-        if (visit) t = next_task(), tn = next_task();
         v4u h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
         v4f R[B4_CPT];
         auto request = [&](const v4u a, const v4u b) {   // a lane without a record re-reads the cell's last one (an empty cell: record 0)
