@@ -70,11 +70,11 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-mask-chain", action="store_true",
                     help="A/B: the mask stage scan by scan (modest_mask_stage) instead of one call per chain of --pp-batch scans")
-    ap.add_argument("--scans", type=int, default=32,
+    ap.add_argument("--scans", type=int, default=64,
                     help="resident scans per host process, cycled through: CONSECUTIVE scans of synthetic shards of --shard-scans "
                          "scans each (consecutive scans of a Lyft shard share 35 of their 36 history frames per traversal)")
-    ap.add_argument("--shard-scans", type=int, default=16, help="consecutive scans per resident shard")
-    ap.add_argument("--pp-batch", type=int, default=16,
+    ap.add_argument("--shard-scans", type=int, default=32, help="consecutive scans per resident shard")
+    ap.add_argument("--pp-batch", type=int, default=32,
                     help="consecutive scans whose PP stage is ONE call (FrameStore.pp_score_batch: modest_pp_score_block for >= 4 "
                          "scans that share their frames, modest_pp_score_frames_batch otherwise); clamped to --shard-scans")
     ap.add_argument("--mask-batch", type=int, default=16, help="scans per chain of stages 2 + 3 (modest_mask_stage_batch)")
@@ -943,7 +943,7 @@ def main():
     pp_path = "block" if n_block and not n_chain else ("chain" if n_chain and not n_block else ("mixed" if n_block else "none"))
     kernel_txt = (f"PP neighbour count of a BLOCK of {iso_B} consecutive scans of a shard, ONE call (modest_pp_score_block): list sizes "
                   "from the frames' tile tables (b4_counts / b4_lists / b4_bases) + ONE pass over the union of the block's frames "
-                  "(b4_scatter: 36 + 15 frames per traversal instead of 16 x 36) + counting sort of the tile lists by cell "
+                  f"(b4_scatter: {a.frames} + {iso_B - 1} frames per traversal instead of {iso_B} x {a.frames}) + counting sort of the tile lists by cell "
                   "(b4_seg_*) + per scan: live index on the lattice (b4_live_*, b4_scan_*), plan (b4_plan_*), sort-free join "
                   "(b4_join: records read into registers, the scan's float32 pose applied per record, packed-float pair tests): "
                   "ALL launches of the call, HIP events on the launch stream"

@@ -122,6 +122,9 @@ class StoredFrame:
         return out
 
 
+SPLIT_BLOCK = "split"   # block_tables: the scans are worth the block path, in two halves
+
+
 class FrameStore:
     """LRU store of tile-sorted frames on one device, for one ``max_neighbor_dist``."""
 
@@ -605,6 +608,8 @@ class FrameStore:
         if force is False:
             return None
         B, T = len(descs), int(n_trav)
+        if B > self.block_max_scans and force is None and T <= 64:
+            return SPLIT_BLOCK
         if B < 1 or B > self.block_max_scans or T > 64:
             return None
         with self.lock:   # (everything below is vectorised over the scans: ~0.4 ms for 16 scans x 360 frames, 1.5 ms scan by scan)
@@ -638,8 +643,14 @@ class FrameStore:
                 per_scan = members / B
                 # ... and on windows chosen by the reference's rule (synth.make_shard_matched; profiles/r05_sharing_sensitivity.json):
                 # union 0.94 / 1.89 / 1.92 / 2.07 / 2.52 x a scan's frames -> 106 / 120 / 130 / 123 / 151 us against 193-200
-                if B < 4 or len(us) > 3.0 * per_scan or per_scan < 12 * T:
+                if B < 4 or per_scan < 12 * T:
                     return None
+                # Large blocks amortise the union's binning further (16 -> 32 Lyft-shape scans: 79 -> 69 us per scan at a union of
+                # 1.42 -> 1.86 x a scan's entries; nuScenes shape, 16 frames per traversal: 111 -> 101 us at 1.94 -> 2.94 x; windows by the
+                # reference's rule: 111 -> 117 at 2.1 -> 2.6 x) -- ONE block beats two of half the scans wherever the block path pays
+                # at all (measured: tools/pp_block_probe.py --auto).  Past 3 x, two halves are tried before the per-scan chain.
+                if len(us) > 3.0 * per_scan:
+                    return SPLIT_BLOCK if B >= 8 else None
             if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([np.unique(allh), lslots])):
                 return None
             # the lattice is a conservative filter only while two points within r of each other (pose error < 1e-4 m checked
@@ -650,7 +661,9 @@ class FrameStore:
             span = self.block_window - self.ntf - 2   # (the library pads the window by one tile on every side)
             if (int(lrec["TX0"].max()) - int(lrec["TX0"].min()) > span
                     or int(lrec["TY0"].max()) - int(lrec["TY0"].min()) > span):
-                return None
+                # (the live scans of the block lie further apart than the block window: 32 scans at more than 11 m/s -- half the
+                # scans span half the distance)
+                return SPLIT_BLOCK if (force is None and B >= 8) else None
             with_hist = [(arr, int(n)) for (_, arr, _), n in zip(descs, lens) if n]
             flags = np.unique(np.concatenate([arr["flags"][:n] for arr, n in with_hist]))
             if len(flags) > 1:
@@ -722,6 +735,11 @@ class FrameStore:
             Hs.append(H)
             cs.append(torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None)
         tabs = self.block_tables(descs, T, force=block)
+        if tabs is SPLIT_BLOCK:   # (the automatic rule: too little sharing for ONE block -- two calls of half the scans)
+            h = B // 2
+            lo = self.pp_score_batch(live_keys[:h], descs[:h], T, outs=Hs[:h], return_counts=return_counts, ctx=ctx, block=block)
+            hi = self.pp_score_batch(live_keys[h:], descs[h:], T, outs=Hs[h:], return_counts=return_counts, ctx=ctx, block=block)
+            return (lo[0] + hi[0], lo[1] + hi[1]) if return_counts else lo + hi
         if tabs is not None:
             fr, sc, keep = tabs
             sc["H_dev"] = [H.data_ptr() for H in Hs]

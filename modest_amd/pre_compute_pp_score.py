@@ -481,7 +481,7 @@ def main(args):
     # (below) and a later grow is a device synchronise + free + allocate -- 100 ms alone on the GPU, several times that under
     # eight workers.  Estimate: 32 B per point of the batch's union of frames (two copies of the 16-byte records) + ~45 MB per scan
     # (live index over the block window, task lists, counts); an underestimate only means the arena grows as before.
-    n_batch = max(1, int(args.get("pp_batch", 16)))
+    n_batch = max(1, int(args.get("pp_batch", 32)))
     _lib.default_context(device.index or 0).warmup()   # (device code of the library: loaded before the clock, not inside the first scan)
     try:
         mine = getattr(shard, "mine", getattr(shard, "items", []))

@@ -146,3 +146,20 @@ def test_block_tables_repeated_frames_get_a_union_entry_per_occurrence():
     # a lattice cell with less slack than pose error + float32 rounding needs: the block path is refused (radius < 0.072 m)
     st.radius, st.cell = 0.05, 0.05 * (1.0 + 1.0 / 256.0)
     assert st.block_tables(descs, T, force=True) is None
+
+
+def test_large_blocks_split_when_the_union_is_large():
+    """32 scans of Lyft shape (36 frames per traversal: union 1.86 x a scan's entries) and of nuScenes shape (16 frames: 2.94 x) stay
+    ONE block; 32 scans with 12 frames per traversal (3.58 x: past the rule's 3 x) are tried in two halves (2.25 x) before the
+    per-scan chain -- unless the caller forces one block."""
+    B, T = 32, 4
+    for F, expect_split in ((36, False), (16, False), (12, True)):
+        L = F + B - 1
+        st = _store(T * L + B, T, L)
+        descs = _descs(st, B, T, F, L)
+        got = st.block_tables(descs, T)
+        assert (got is fs.SPLIT_BLOCK) == expect_split, (F, got if isinstance(got, str) else type(got))
+        forced = st.block_tables(descs, T, force=True)
+        assert forced is not None and forced is not fs.SPLIT_BLOCK and len(forced[0]) == T * L
+        half = st.block_tables(descs[:16], T)   # each half then goes as a block of its own
+        assert half is not None and half is not fs.SPLIT_BLOCK and len(half[1]) == 16

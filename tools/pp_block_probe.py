@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shards", type=int, default=2, help="distinct shards cycled through in the timing loop")
+    ap.add_argument("--auto", action="store_true", help="also time the store's own choice (block=None: the split rule for large blocks)")
     ap.add_argument("--stream", action="store_true", help="run on a created stream instead of the null stream")
     ap.add_argument("--json-out", type=str, default="", help="append one JSON line with the run's numbers to this file")
     ap.add_argument("--matched", type=str, default="", help="live_speed,hist_lo,hist_hi: windows chosen by the reference's rule "
@@ -90,7 +91,8 @@ def main():
     report = dict(scans=a.scans, n_live=a.n, traversals=a.trav, nusc=bool(a.nusc), matched=a.matched or None, parity_ok=bool(ok),
                   sharing=(synth.sharing_stats(shards[0], a.scans) if a.matched else
                            dict(members_per_scan=a.trav * a.frames, union_over_members=(a.frames + a.scans - 1) / a.frames)))
-    for mode in (True, False):
+    for mode in ((True, False, None) if a.auto else (True, False)):
+        c0 = getattr(store, "block_calls", 0)
         ctx.profile_begin(8 * a.reps * a.shards + 4)
         with torch.cuda.stream(side):
             for r in range(a.reps):
@@ -104,10 +106,13 @@ def main():
         per = float(np.mean(ms[a.shards:])) / a.scans
         members = float(np.mean([len(sc.hist) for sh in shards for sc in sh.scans]))
         alg = 12 * members * a.n + 16 * a.n   # (a repeated frame is stacked, and counted, as often as it is listed)
-        print(f"{'block' if mode else 'chain'}: {np.mean(ms[a.shards:]):.3f} ms per call of {a.scans} scans = {per * 1e3:.1f} us/scan "
+        if mode is None:
+            print(f"auto: {(getattr(store, 'block_calls', 0) - c0) / calls:.1f} block calls per call of {a.scans} scans", flush=True)
+        print(f"{'auto' if mode is None else 'block' if mode else 'chain'}: {np.mean(ms[a.shards:]):.3f} ms per call of {a.scans} scans = {per * 1e3:.1f} us/scan "
               f"-> {alg / per / 1e6:.0f} GB/s = {alg / per / 1e6 / 8000 * 100:.1f} % of 8 TB/s", flush=True)
-        report["block_us_per_scan" if mode else "chain_us_per_scan"] = per * 1e3
-        report["block_frac" if mode else "chain_frac"] = alg / per / 1e6 / 8000
+        tag = "auto" if mode is None else "block" if mode else "chain"
+        report[tag + "_us_per_scan"] = per * 1e3
+        report[tag + "_frac"] = alg / per / 1e6 / 8000
         report["algorithmic_bytes_per_scan"] = alg
     if a.json_out:
         import json

@@ -20,10 +20,10 @@ cp gpurun_out/prof_single/bench_kernel_stats.csv $F/bench_full_1proc_kernel_stat
 rm -rf gpurun_out/prof_c5
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5 -o bench -- python bench.py --config c5 --pp-only --cpu-scans 0 --cli-scans 0 --procs 1 --streams 1 --steps 96 --warmup 16 --sharing best > gpurun_out/prof_c5.log 2>&1
 cp gpurun_out/prof_c5/bench_kernel_stats.csv $F/c5_pp_kernel_stats.csv; rm -rf gpurun_out/prof_c5
-PP_BLOCK=16 bash tools/pp4_pmc.sh > $F/pp4_pmc.log 2>&1
-PP_BLOCK=16 python tools/pp4_traffic.py | tee -a $F/pp4_pmc.log
+PP_BLOCK=32 bash tools/pp4_pmc.sh > $F/pp4_pmc.log 2>&1
+PP_BLOCK=32 python tools/pp4_traffic.py | tee -a $F/pp4_pmc.log
 cp gpurun_out/pp4_pmc.json $F/pp_block_pmc_counters.json; cp gpurun_out/pp4_traffic.json $F/pp_block_traffic.json
-MODEST_PP4_DBG=512 python tools/pp_block_probe.py --scans 16 --reps 1 --shards 1 2>&1 | grep "b4_join" | head -1 > $F/pp_block_join_phases.txt
+MODEST_PP4_DBG=512 python tools/pp_block_probe.py --scans 32 --reps 1 --shards 1 2>&1 | grep "b4_join" | head -1 > $F/pp_block_join_phases.txt
 for f in $F/bench_*.json; do python -c "
 import json,sys
 try:
