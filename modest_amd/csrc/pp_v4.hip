@@ -152,13 +152,17 @@ __device__ __forceinline__ B4Crop b4_crop(const Blk &B) {
 // ---- list sizes from the frame tables ---------------------------------------------------------
 // thread per block tile: is the tile needed (a live point of any scan in the 3x3 tiles around it), and by which scans?  Needed
 // tiles are LISTED (7 k of the window's 25.6 k): the column sums below, the plan and the join only ever look at those.
+// (two launches: eight scans per thread and grid row -- one thread walking all 32 scans of a block was 41 us of dependent loads --,
+// then the list)
+constexpr int B4_NEED_SCANS = 8;
 __global__ __launch_bounds__(256) void b4_need(Blk B, const ScanDev *__restrict__ scans) {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    const bool tile = b < B.BT;   // (no early exit: the wave reductions below want every lane of the last wavefront present)
+    if (b >= B.BT) return;
     const int gx = B.BX0 + b % B.BW, gy = B.BY0 + b / B.BW;
     unsigned long long mask = 0ULL;
+    const int s0 = blockIdx.y * B4_NEED_SCANS, s1 = min(B.G, s0 + B4_NEED_SCANS);
 #pragma unroll 8
-    for (int s = 0; s < (tile ? B.G : 0); ++s) {
+    for (int s = s0; s < s1; ++s) {
         const ScanDev &S = scans[s];
         const int l0 = max(gx - 1 - S.TX0, 0), l1 = min(gx + 1 - S.TX0, B4_NTF - 1);
         bool needed = false;
@@ -172,10 +176,13 @@ __global__ __launch_bounds__(256) void b4_need(Blk B, const ScanDev *__restrict_
         }
         mask |= (unsigned long long)needed << s;
     }
-    if (tile) {
-        B.needMask[b] = mask;
-        B.listTotal[b] = 0u;   // (b4_lists writes the totals of the needed tiles that hold points)
-    }
+    if (mask) atomicOr(&B.needMask[b], mask);   // (the masks were cleared with the block's cursors)
+}
+__global__ __launch_bounds__(256) void b4_need_list(Blk B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool tile = b < B.BT;   // (no early exit: the wave reductions below want every lane of the last wavefront present)
+    const unsigned long long mask = tile ? B.needMask[b] : 0ULL;
+    if (tile) B.listTotal[b] = 0u;   // (b4_lists writes the totals of the needed tiles that hold points)
     // one cursor atomic per wavefront, the wavefront's tiles in order: neighbours in the list are neighbours in a tile row, and the
     // column sums below read and write neighbouring table entries
     const unsigned long long bal = __ballot(mask != 0ULL);
@@ -1310,9 +1317,10 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
     const size_t oTotal = take((size_t)BT * 4), oBase = take((size_t)BT * 4), oSegBase = take((size_t)BT * 4);
     const size_t oSegList = take(maxSegs * 4), oSegHist = take(maxSegs * 64 * 4), oSegOff = take(maxSegs * 64 * 4);
     const size_t oCellOff = take((size_t)BT * 65 * 4), oSegRange = take(maxSegs * 8);
-    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8), oNeed = take((size_t)BT * 4), oNeedCand = take((size_t)BT * 4), oNeedMask = take((size_t)BT * 8);
+    const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8), oNeed = take((size_t)BT * 4), oNeedCand = take((size_t)BT * 4);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
-    const size_t oCtrl = take(256);   // (directly in front of the cell counters: cleared by the same memset)
+    const size_t oCtrl = take(256);   // the block's cursors and crop ...
+    const size_t oNeedMask = take((size_t)BT * 8);   // ... and, directly behind them, the tiles' scan masks: one memset clears both
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
     struct ScanOff {
         size_t cellStart, blockSum, ctrl, tmp, sorted, tasks, ltHead, ltSegs, counts;
@@ -1446,10 +1454,11 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         attr_done[ctx->device & 63] = true;
     }
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
-    MODEST_HIP_CHECK(hipMemsetAsync(base + oCtrl, 0, 256, stream));   // (the block's cursors and crop)
+    MODEST_HIP_CHECK(hipMemsetAsync(base + oCtrl, 0, 256 + (size_t)BT * 8, stream));   // (the block's cursors and crop, the tiles' scan masks)
     const unsigned gBT = (unsigned)((BT + 255) / 256), gN = (unsigned)((maxN + 255) / 256);
     if (U > 0 && ntot > 0) {
-        b4_need<<<gBT, 256, 0, stream>>>(B, dsc);
+        b4_need<<<dim3(gBT, (unsigned)((G + B4_NEED_SCANS - 1) / B4_NEED_SCANS)), 256, 0, stream>>>(B, dsc);
+        b4_need_list<<<gBT, 256, 0, stream>>>(B);
         b4_counts<<<dim3(gBT, (unsigned)NG), 256, 0, stream>>>(B);   // (over the needed tiles: the workgroups behind them leave at once)
         b4_lists<<<gBT, 256, 0, stream>>>(B);
         b4_bases_local<<<(unsigned)((BT + 1023) / 1024), 1024, 0, stream>>>(B);
