@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shards", type=int, default=2, help="distinct shards cycled through in the timing loop")
     ap.add_argument("--auto", action="store_true", help="also time the store's own choice (block=None: the split rule for large blocks)")
+    ap.add_argument("--halves", action="store_true", help="also time every shard as TWO forced blocks of half the scans")
     ap.add_argument("--stream", action="store_true", help="run on a created stream instead of the null stream")
     ap.add_argument("--json-out", type=str, default="", help="append one JSON line with the run's numbers to this file")
     ap.add_argument("--matched", type=str, default="", help="live_speed,hist_lo,hist_hi: windows chosen by the reference's rule "
@@ -114,6 +115,19 @@ def main():
         report[tag + "_us_per_scan"] = per * 1e3
         report[tag + "_frac"] = alg / per / 1e6 / 8000
         report["algorithmic_bytes_per_scan"] = alg
+    if a.halves:
+        h = a.scans // 2
+        ctx.profile_begin(16 * a.reps * a.shards + 4)
+        with torch.cuda.stream(side):
+            for r in range(a.reps):
+                for lives, descs in tabs:
+                    store.pp_score_batch(lives[:h], descs[:h], T, ctx=ctx, block=True)
+                    store.pp_score_batch(lives[h:], descs[h:], T, ctx=ctx, block=True)
+        torch.cuda.synchronize()
+        ms = np.asarray(ctx.profile_collect(16 * a.reps * a.shards + 4))
+        per = float(ms[2 * a.shards:].sum()) / ((a.reps - 1) * a.shards) / a.scans
+        print(f"two halves: {per * 1e3:.1f} us/scan", flush=True)
+        report["halves_us_per_scan"] = per * 1e3
     if a.json_out:
         import json
         with open(a.json_out, "a") as fh:
