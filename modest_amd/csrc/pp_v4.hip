@@ -72,7 +72,7 @@ constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
 #endif
 constexpr int B4_JT = B4_JT_;                 // threads of a join workgroup
 constexpr int B4_MAXT = 64;
-constexpr int B4_POSE_LDS_MAX = 1024;       // union frames whose poses fit the LDS table of a join workgroup (50 KB)
+constexpr int B4_POSE_LDS_MAX = 2048;       // union entries whose poses fit the LDS table of a join workgroup (100 KB of the CU's 160: one workgroup per CU)
 
 struct UFrame {   // a frame of the union, device side (96 bytes)
     const float *xyz;

@@ -651,9 +651,10 @@ class FrameStore:
                 # at all (measured: tools/pp_block_probe.py --auto).  Past 3 x, two halves are tried before the per-scan chain.
                 if len(us) > 3.0 * per_scan:
                     return SPLIT_BLOCK if B >= 8 else None
-                # the join keeps a scan's pose table (49 B per union entry) in LDS up to 1 024 entries (pp_v4.hip: B4_POSE_LDS_MAX);
-                # beyond that it reads the poses from memory -- 32 scans with little sharing: 156 us per scan against 127 in two halves
-                if len(us) > 1024 and B >= 8:
+                # the join keeps a scan's pose table (49 B per union entry) in LDS up to 2 048 entries (pp_v4.hip: B4_POSE_LDS_MAX);
+                # beyond that it reads the poses from memory (measured with a table of 1 024: 32 scans with little sharing, 1 113-1 138
+                # entries, 156 us per scan against 127 in two halves)
+                if len(us) > 2048 and B >= 8:
                     return SPLIT_BLOCK
             if len(us) >= (1 << 16) or not self._all_clean(np.concatenate([np.unique(allh), lslots])):
                 return None
