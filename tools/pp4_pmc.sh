@@ -1,10 +1,11 @@
 #!/bin/bash
-# PMC counters of the block path's kernels (separate passes), via tools/pp_block_probe.py
+# PMC counters of the block path's kernels (separate passes), via tools/pp_block_probe.py (PROBE_ARGS: other shapes, e.g. C5:
+# PROBE_ARGS="--nusc --trav 20 --frames 16 --n 35000")
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for pass in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" ; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf gpurun_out/pmc4_$tag
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc4_$tag -o p -- python tools/pp_block_probe.py --scans ${PP_BLOCK:-16} --reps 2 --shards 2 > gpurun_out/pmc4_$tag.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc4_$tag -o p -- python tools/pp_block_probe.py --scans ${PP_BLOCK:-16} --reps 2 --shards 2 $PROBE_ARGS > gpurun_out/pmc4_$tag.log 2>&1
 done
 python - <<'PY'
 import csv,glob,collections,json

@@ -9,7 +9,7 @@ import os
 import sys
 
 G = int(os.environ.get("PP_BLOCK", "16"))
-N_LIVE, T, F = 30_000, 10, 36
+N_LIVE, T, F = (int(os.environ.get(k, d)) for k, d in (("PP_N_LIVE", 30_000), ("PP_TRAV", 10), ("PP_FRAMES", 36)))   # (C5: 35000, 20, 16)
 d = {k: v for k, v in json.load(open("gpurun_out/pp4_pmc.json")).items() if k.startswith("b4_")}
 rec_bytes = d["b4_seg_scatter"]["WRITE_SIZE"] * 1024            # = 16 B x records of the block store (write factor 1)
 f_fac = rec_bytes / (d["b4_seg_hist"]["FETCH_SIZE"] * 1024)
@@ -31,6 +31,6 @@ out = {
     "per_kernel_bytes_per_scan": {k: {"fetch": v.get("FETCH_SIZE", 0.0) * 1024 * f_fac / G, "write": v.get("WRITE_SIZE", 0.0) * 1024 / G}
                                   for k, v in sorted(d.items())},
 }
-json.dump(out, open("gpurun_out/pp4_traffic.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("PP_TRAFFIC_OUT", "gpurun_out/pp4_traffic.json"), "w"), indent=1)
 print("block of %d scans: HBM bytes per scan %.1f MB = %.2f x algorithmic (fetch factor %.3f)" %
       (G, out["hbm_bytes_per_scan"] / 1e6, out["ratio_to_algorithmic"], f_fac))
