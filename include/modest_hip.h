@@ -230,6 +230,14 @@ int modest_pp_block_limits(int32_t *max_window_tiles, int32_t *max_scans, int32_
 int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_frame *frames_host, int n_frames,
                           const modest_pp_block_scan *scans_host, int n_scans, int n_trav, double radius,
                           double cell, void *stream);
+/* The same for scans with DIFFERENT numbers of traversals in one block: n_trav_scan [host] (n_scans), 1..64 each.
+ * The reference accepts a traversal per scan (closest pose within 3 m, data_preprocessing/lyft/split_traintest.py:17,79)
+ * and asks for at least two (:111; pre_compute_pp_score.py:125-126), so T changes along a sequence
+ * (pre_compute_pp_score.py:132-150,181-194 run per scan with that scan's own list).  counts_dev of scan s is
+ * (n, n_trav_scan[s]); member_trav of scan s < n_trav_scan[s]; H of scan s is normalised by ln n_trav_scan[s] (:72).       */
+int modest_pp_score_block_mixed(modest_ctx *ctx, const modest_pp_block_frame *frames_host, int n_frames,
+                                const modest_pp_block_scan *scans_host, int n_scans, const int32_t *n_trav_scan,
+                                double radius, double cell, void *stream);
 
 /* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
  * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).

@@ -42,6 +42,7 @@ SIGNATURES = {
     "modest_pp_score_frames_batch": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, C.c_int, C.c_double, VP, VP, VP]),
     "modest_pp_block_limits": (C.c_int, [VP, VP, VP]),
     "modest_pp_score_block": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_int, C.c_double, C.c_double, VP]),
+    "modest_pp_score_block_mixed": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, C.c_double, C.c_double, VP]),
     "modest_plane_candidates": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, VP, VP, VP, VP]),
     "modest_mad_threshold": (C.c_int, [VP, VP, C.c_int, VP, VP]),

@@ -172,7 +172,12 @@ int modest_ctx_reserve(modest_ctx *ctx, size_t bytes) {
     ctx->scratch_bytes = 0;
     size_t want = bytes + bytes / 4 + (1u << 20);
     void *p = nullptr;
-    MODEST_HIP_CHECK(hipMalloc(&p, want));
+    if (hipMalloc(&p, want) != hipSuccess) {   // the 25 % head room is a convenience: without it the exact size still serves the call
+        (void)hipGetLastError();
+        want = bytes;
+        p = nullptr;
+        MODEST_HIP_CHECK(hipMalloc(&p, want));
+    }
     modest_alloc_note("scratch arena", (size_t)(want));
     ctx->scratch = static_cast<char *>(p);
     ctx->scratch_bytes = want;

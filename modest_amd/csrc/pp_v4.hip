@@ -951,7 +951,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int lq = lane;
     asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
-    const int T = scans[blockIdx.y].T;   // (one T per block)
+    const int T = scans[blockIdx.y].T;   // (the scan's own: a block may mix traversal counts, the LDS is sized with the largest)
     const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
     const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
@@ -1240,20 +1240,46 @@ extern "C" int modest_pp_block_limits(int32_t *max_window_tiles, int32_t *max_sc
     return MODEST_OK;
 }
 
+static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, int n_frames, const modest_pp_block_scan *scans,
+                         int n_scans, const int32_t *Ts, double radius, double cell, void *stream_);
+
 extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_frame *frames, int n_frames,
                                      const modest_pp_block_scan *scans, int n_scans, int n_trav, double radius,
                                      double cell, void *stream_) {
+    MODEST_REQUIRE(n_scans >= 1 && n_scans <= 64, "1 <= n_scans <= 64");
+    int32_t Ts[64];
+    for (int s = 0; s < n_scans; ++s) Ts[s] = n_trav;
+    return pp_block_impl(ctx, frames, n_frames, scans, n_scans, Ts, radius, cell, stream_);
+}
+
+// The scans of a block need not have the same number of traversals: the reference accepts a traversal PER SCAN (closest pose
+// within 3 m, data_preprocessing/lyft/split_traintest.py:17,79) and only asks for two of them (:111), so T changes along a
+// sequence.  Everything per-scan on the device already reads its scan's own T (counts (n, T_s), the entropy's ln T_s, the
+// traversal masks of the join); the join's LDS is sized with the block's largest T.
+extern "C" int modest_pp_score_block_mixed(modest_ctx *ctx, const modest_pp_block_frame *frames, int n_frames,
+                                           const modest_pp_block_scan *scans, int n_scans, const int32_t *n_trav_scan,
+                                           double radius, double cell, void *stream_) {
+    MODEST_REQUIRE(n_trav_scan != nullptr, "NULL argument");
+    return pp_block_impl(ctx, frames, n_frames, scans, n_scans, n_trav_scan, radius, cell, stream_);
+}
+
+static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, int n_frames, const modest_pp_block_scan *scans,
+                         int n_scans, const int32_t *Ts, double radius, double cell, void *stream_) {
     MODEST_REQUIRE(ctx != nullptr && scans != nullptr, "NULL argument");
     MODEST_REQUIRE(n_scans >= 1 && n_scans <= 64, "1 <= n_scans <= 64");
     MODEST_REQUIRE(n_frames >= 0 && n_frames < (1 << 16) && (n_frames == 0 || frames != nullptr), "bad frame table");
-    MODEST_REQUIRE(n_trav >= 1 && n_trav <= B4_MAXT, "1 <= n_trav <= 64 on the block path");
+    int Tmax = 1;
+    for (int s = 0; s < n_scans; ++s) {
+        MODEST_REQUIRE(Ts[s] >= 1 && Ts[s] <= B4_MAXT, "1 <= n_trav <= 64 on the block path");
+        Tmax = std::max(Tmax, (int)Ts[s]);
+    }
     MODEST_REQUIRE(radius > 0.0 && radius < 1e6, "radius must be positive and finite");
     // the lattice cell must leave room for the difference between distances on the lattice and in a scan's frame
     MODEST_REQUIRE(cell >= radius * (1.0 + 1.0 / 512.0) && cell <= radius * 1.25,
                    "lattice cell edge must be in [r (1 + 2^-9), 1.25 r]");
     hipStream_t stream = as_stream(stream_);
     MODEST_HIP_CHECK(hipSetDevice(ctx->device));
-    const int G = n_scans, U = n_frames, T = n_trav;
+    const int G = n_scans, U = n_frames;
     long long ntot = 0, nch = 0;
     for (int f = 0; f < U; ++f) {
         MODEST_REQUIRE(frames[f].n >= 0 && frames[f].tab_dev != nullptr, "bad frame");
@@ -1274,7 +1300,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
                        "bad member list");
         for (int m = 0; m < sc.n_members; ++m) {
             MODEST_REQUIRE(sc.member_slot[m] >= 0 && sc.member_slot[m] < U, "member slot out of range");
-            MODEST_REQUIRE(sc.member_trav[m] >= 0 && sc.member_trav[m] < T, "frame traversal out of range");
+            MODEST_REQUIRE(sc.member_trav[m] >= 0 && sc.member_trav[m] < Ts[s], "frame traversal out of range");
             // one pose entry per (scan, union slot): a frame a scan lists twice (pre_compute_pp_score.py:132-150 stacks it
             // twice) must come as two union entries -- FrameStore.block_tables gives every occurrence a slot of its own
             MODEST_REQUIRE(seenBy[(size_t)sc.member_slot[m]] != s, "a scan names a union slot twice: repeated frames need a union entry per occurrence");
@@ -1336,7 +1362,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         so[(size_t)s].tasks = take(maxTasks * sizeof(B4Task));
         so[(size_t)s].ltHead = take(maxLight * 32);
         so[(size_t)s].ltSegs = take(maxLight * 128);
-        so[(size_t)s].counts = take((size_t)std::max(n, 1) * T * 4);
+        so[(size_t)s].counts = take((size_t)std::max(n, 1) * Ts[s] * 4);
     }
     // staged block: [UFrame x U][chunkTab][ScanDev x G][PoseEnt x G x U]
     const size_t stFrames = 0, stChunks = arena_sz((size_t)std::max(U, 1) * sizeof(UFrame));
@@ -1395,7 +1421,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         d.n = sc.n;
         d.TX0 = sc.TX0;
         d.TY0 = sc.TY0;
-        d.T = T;
+        d.T = Ts[s];
         d.maxTasks = (int)maxTasks;
         d.maxLight = (int)maxLight;
         PoseEnt *pe = hp + (size_t)s * std::max(U, 1);
@@ -1483,7 +1509,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         const int lf = lf_env ? atoi(lf_env) & 31 : (G <= 6 ? 8 : 0);
         const int dbg = (dbg_env ? atoi(dbg_env) : 0) | ((tk_env ? atoi(tk_env) & 255 : 0) << 16) | (lf << 24);
         const bool lpose = U <= B4_POSE_LDS_MAX && !(dbg & 256);
-        const unsigned ldsB = b4_join_lds(U, T, lpose);
+        const unsigned ldsB = b4_join_lds(U, Tmax, lpose);
         if ((dbg & 512) && lpose) {   // MODEST_PP4_DBG=512: wall time of the join's wavefronts by phase (blocking; diagnostics only)
             unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[10];
             MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));
@@ -1524,7 +1550,7 @@ extern "C" int modest_pp_score_block(modest_ctx *ctx, const modest_pp_block_fram
         else b4_join<false, false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
     } else {   // no history: every count is zero
         for (int sc = 0; sc < G; ++sc)
-            if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * T * 4, stream));
+            if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * Ts[sc] * 4, stream));
     }
     modest_prof_mark(ctx, stream, 1);
     b4_entropy<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(dsc);

@@ -607,7 +607,9 @@ class FrameStore:
             force = True if env == "1" else (False if env == "0" else None)
         if force is False:
             return None
-        B, T = len(descs), int(n_trav)
+        B = len(descs)
+        Ts = np.full(B, int(n_trav), dtype=np.int64) if np.isscalar(n_trav) else np.asarray(n_trav, dtype=np.int64)   # (per scan)
+        T = int(Ts.max()) if B else 0
         if B > self.block_max_scans and force is None and T <= 64:
             return SPLIT_BLOCK
         if B < 1 or B > self.block_max_scans or T > 64:
@@ -643,7 +645,7 @@ class FrameStore:
                 per_scan = members / B
                 # ... and on windows chosen by the reference's rule (synth.make_shard_matched; profiles/r05_sharing_sensitivity.json):
                 # union 0.94 / 1.89 / 1.92 / 2.07 / 2.52 x a scan's frames -> 106 / 120 / 130 / 123 / 151 us against 193-200
-                if B < 4 or per_scan < 12 * T:
+                if B < 4 or members < 12 * int(Ts.sum()):   # (fewer than 12 entries per traversal and scan)
                     return None
                 # Large blocks amortise the union's binning further (16 -> 32 Lyft-shape scans: 79 -> 69 us per scan at a union of
                 # 1.42 -> 1.86 x a scan's entries; nuScenes shape, 16 frames per traversal: 111 -> 101 us at 1.94 -> 2.94 x; windows by the
@@ -720,40 +722,59 @@ class FrameStore:
             keep = [ms_all, mt_all, mr_all]
         return fr, sc, keep
 
-    def pp_score_batch(self, live_keys, descs, n_trav: int, outs=None, return_counts: bool = False, ctx=None,
-                       block: Optional[bool] = None):
+    def pp_score_batch(self, live_keys, descs, n_trav, outs=None, return_counts: bool = False, ctx=None,
+                       block: Optional[bool] = None, _may_split: bool = True, _cs=None):
         """PP scores of several scans in ONE call.  live_keys: the live frame of every scan; descs: their tables from
         describe() (the frames must be resident).  Scans that share most of their history frames (consecutive scans of
         a shard) go through modest_pp_score_block -- the union of their frames is binned once; others through
         modest_pp_score_frames_batch (one chain of launches, every scan on its own).  `block`: True / False force the
         choice (MODEST_PP_BLOCK=1 / 0 in the environment does the same).  Returns [H] (and [counts]); results are
-        those of separate pp_score calls, bit for bit."""
+        those of separate pp_score calls, bit for bit.
+        n_trav: one number, or one per scan -- the reference accepts a traversal per scan (split_traintest.py:17,79,111), so the
+        scans of a sequence differ in T; a block takes them as they come (modest_pp_score_block_mixed), the per-scan chain runs
+        once per run of equal T."""
         lib = load()
         self.note_reader()
-        B, T = len(descs), int(n_trav)
-        if T > 64:
+        B = len(descs)
+        Ts = [int(n_trav)] * B if np.isscalar(n_trav) else [int(t) for t in n_trav]
+        if len(Ts) != B:
+            raise ValueError("n_trav: one number or one per scan")
+        if B and max(Ts) > 64:
             raise ValueError("the batched path takes at most 64 traversals")
         Hs, cs = [], []
         for i, (lv, arr, slots) in enumerate(descs):
             N = int(lv["n"][0])
             H = outs[i] if outs is not None and outs[i] is not None else torch.empty((N,), dtype=torch.float32, device=self.device)
             Hs.append(H)
-            cs.append(torch.empty((N, T), dtype=torch.int32, device=self.device) if return_counts else None)
-        tabs = self.block_tables(descs, T, force=block)
+            cs.append(None if not return_counts else _cs[i] if _cs is not None else torch.empty((N, Ts[i]), dtype=torch.int32, device=self.device))
+        tabs = self.block_tables(descs, Ts, force=block)
+        if tabs is SPLIT_BLOCK and not _may_split:
+            tabs = None   # (ONE level of halving: a half the rule would halve again takes the per-scan chain in one call)
         if tabs is SPLIT_BLOCK:   # (the automatic rule: too little sharing for ONE block -- two calls of half the scans)
             h = B // 2
-            lo = self.pp_score_batch(live_keys[:h], descs[:h], T, outs=Hs[:h], return_counts=return_counts, ctx=ctx, block=block)
-            hi = self.pp_score_batch(live_keys[h:], descs[h:], T, outs=Hs[h:], return_counts=return_counts, ctx=ctx, block=block)
-            return (lo[0] + hi[0], lo[1] + hi[1]) if return_counts else lo + hi
+            lo = self._pp_score_batch_c(live_keys[:h], descs[:h], Ts[:h], Hs[:h], cs[:h], ctx, block, B > self.block_max_scans)
+            hi = self._pp_score_batch_c(live_keys[h:], descs[h:], Ts[h:], Hs[h:], cs[h:], ctx, block, B > self.block_max_scans)
+            return (Hs, cs) if return_counts else Hs
         if tabs is not None:
             fr, sc, keep = tabs
             sc["H_dev"] = [H.data_ptr() for H in Hs]
             sc["counts_dev"] = [c.data_ptr() if c is not None else 0 for c in cs]
-            check(lib.modest_pp_score_block(self._ctx(ctx).handle, fr.ctypes.data, len(fr), sc.ctypes.data, B, T,
-                                            self.radius, self.cell, torch.cuda.current_stream().cuda_stream),
-                  "modest_pp_score_block")
+            tarr = np.asarray(Ts, dtype=np.int32)
+            check(lib.modest_pp_score_block_mixed(self._ctx(ctx).handle, fr.ctypes.data, len(fr), sc.ctypes.data, B, tarr.ctypes.data,
+                                                  self.radius, self.cell, torch.cuda.current_stream().cuda_stream),
+                  "modest_pp_score_block_mixed")
             self.block_calls = getattr(self, "block_calls", 0) + 1
             return (Hs, cs) if return_counts else Hs
+        if len(set(Ts)) > 1:   # the chain of launches takes one T: one call per run of equal T
+            i = 0
+            while i < B:
+                j = i
+                while j < B and Ts[j] == Ts[i]:
+                    j += 1
+                self._pp_score_batch_c(live_keys[i:j], descs[i:j], Ts[i:j], Hs[i:j], cs[i:j], ctx, False, False)
+                i = j
+            return (Hs, cs) if return_counts else Hs
+        T = Ts[0] if B else 0
         livep, permp, framep = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
         Hp, cp = np.zeros(B, dtype=np.uint64), np.zeros(B, dtype=np.uint64)
         nfr = np.zeros(B, dtype=np.int32)
@@ -772,6 +793,12 @@ class FrameStore:
                                                torch.cuda.current_stream().cuda_stream),
               "modest_pp_score_frames_batch")
         return (Hs, cs) if return_counts else Hs
+
+    def _pp_score_batch_c(self, live_keys, descs, Ts, Hs, cs, ctx, block, may_split):
+        """pp_score_batch into given outputs (count tensors included)"""
+        want = any(c is not None for c in cs)
+        return self.pp_score_batch(live_keys, descs, Ts, outs=Hs, return_counts=want, ctx=ctx, block=block, _may_split=may_split,
+                                   _cs=cs if want else None)
 
     def _pp_score_stacked(self, live, live_rel, frames, travs, rels, T, remove_center, return_counts, out, ctx):
         """Stacked path (V3 kernels on a transformed copy) for scans the frame path does not take:

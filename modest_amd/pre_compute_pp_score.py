@@ -489,8 +489,14 @@ def main(args):
         if first and n_batch > 1 and not args.skip_ephe:
             per_frame = frame_bytes // 16
             union_frames = sum(len(ix) + n_batch - 1 for _, ix in first)
-            _lib.default_context(device.index or 0).reserve_arena(int(1.1 * 32 * per_frame * union_frames) + n_batch * (45 << 20))
-    except (KeyError, IndexError, TypeError) as e:
+            want = int(1.1 * 32 * per_frame * union_frames) + n_batch * (45 << 20)
+            # an optimisation must not be able to end the run: never more than this worker's share of what the device has free
+            # (the library adds 25 % head room), and a refused allocation only means the arena grows on demand as before
+            free_b, _total = torch.cuda.mem_get_info(device)
+            n_workers = max(1, int(os.environ.get("MODEST_WORKER", "0/1").split("/")[-1]))
+            want = min(want, int(0.5 * free_b / n_workers / 1.25))
+            _lib.default_context(device.index or 0).reserve_arena(want)
+    except (KeyError, IndexError, TypeError, ValueError, RuntimeError) as e:   # (RuntimeError: _lib.ModestHipError, torch)
         if os.environ.get("MODEST_ALLOC_TRACE"):
             eprint("[pp_score] arena reservation skipped: %r" % (e,))
     # the ingest stream exists, and has carried one copy, before the clock: the FIRST host-to-device copy of a stream sets up
@@ -527,7 +533,9 @@ def main(args):
         rels = relative_poses_block([q[4] for q in pend], [q[5] for q in pend], [q[3] for q in pend], K, threads=pose_threads)
         descs = store.describe_many([q[0] for q in pend], [r[-1] for r in rels], [q[1] for q in pend], [q[2] for q in pend],
                                     [r[:-1] for r in rels], bool(args.nusc))
-        Hs = store.pp_score_batch([q[0] for q in pend], descs, pend[0][8])
+        # (a scan's own number of traversals: the reference accepts a traversal per scan, data_preprocessing/lyft/split_traintest.py:79,111,
+        # so T changes along a sequence -- a block takes the scans as they come)
+        Hs = store.pp_score_batch([q[0] for q in pend], descs, [q[8] for q in pend])
         for q, H in zip(pend, Hs):
             _tr("M.enq", q[7])
             writer.submit(H, q[6])
@@ -547,8 +555,6 @@ def main(args):
         dumps = dp.load_save_precomputed_trans_mat is not None or dp.load_precomputed_lidars is not None
         batched = not (args.add_random_noise > 0) and n_trav <= 64 and not dumps and not args.skip_ephe
         if batched:   # the default path: poses and tables wait for the flush
-            if pend and pend[0][8] != n_trav:
-                flush()
             keep = [k for k, t in enumerate(travs) if t < n_trav] if n_trav < len(traversals) else None
             h_ids = hist_ids if keep is None else [hist_ids[k] for k in keep]
             h_tr = travs if keep is None else [travs[k] for k in keep]

@@ -253,6 +253,33 @@ class ShardScan:
     first_pose: np.ndarray = None
     l2e: np.ndarray = None
     K: np.ndarray = None
+    travs: List[int] = None          # traversal index of every history entry IN THIS SCAN's list (None: the track number) -- a
+    #                                  traversal is accepted per scan (split_traintest.py:17,79), so a track may be traversal 3 of one
+    #                                  scan, traversal 2 of the next and absent from a third
+
+    def trav_list(self) -> List[int]:
+        return [t for t, _ in self.hist] if self.travs is None else list(self.travs)
+
+    @property
+    def n_trav(self) -> int:
+        return max(self.trav_list()) + 1 if self.hist else 0
+
+
+def presence_ramp(n_scans: int, n_trav: int, t_min: int = 2, seed: int = 0) -> List[Tuple[int, int]]:
+    """Per track the scans [i0, i1) it is a traversal of: tracks 0 and 1 always (the reference needs two, split_traintest.py:111),
+    the others enter and leave at seeded scan numbers -- T moves between t_min and n_trav along the shard."""
+    rng = np.random.default_rng([63_000 + seed, n_scans, n_trav])
+    out = [(0, n_scans)] * min(t_min, n_trav)
+    for t in range(t_min, n_trav):
+        a, b = sorted(int(v) for v in rng.integers(1, max(n_scans, 2), 2))
+        kind = t % 3
+        if kind == 0:
+            out.append((0, b))                      # leaves
+        elif kind == 1:
+            out.append((a, n_scans))                # enters
+        else:
+            out.append((a, max(b, a + 1)))          # passes by
+    return out
 
 
 @dataclass
@@ -268,22 +295,23 @@ class Shard:
         """(live points, per-traversal history) of scan i in its common frame -- what the reference stacks
         (pre_compute_pp_score.py:132-150), for the oracle"""
         sc = self.scans[i]
-        T = len(self.tracks)
+        T = sc.n_trav
         parts = [[] for _ in range(T)]
-        for (t, j), rel in zip(sc.hist, sc.rels):
+        for (t, j), tv, rel in zip(sc.hist, sc.trav_list(), sc.rels):
             xyz = self.tracks[t][j][0][:, :3]
             if self.nusc:
                 m = (xyz[:, 0] < 1.75) & (xyz[:, 0] >= -1.15) & (xyz[:, 1] < 0.65) & (xyz[:, 1] >= -0.65)
                 xyz = xyz[~m]
-            parts[t].append(_transform_f32(xyz, rel))
+            parts[tv].append(_transform_f32(xyz, rel))
         return (np.ascontiguousarray(_transform_f32(sc.live_raw[:, :3], sc.live_rel)),
                 [np.concatenate(p).astype(np.float32) for p in parts])
 
 
 def make_shard(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_frames: int = 36, n_per_frame: int | None = None,
                nusc: bool = False, frame_gap: float = 2.0, seed: int = 0, x0: float = 0.0, world_seed: int = 0,
-               point_order: str = "shuffled") -> Shard:
-    """Seeds: live 7000 + 1000*seed + i, history 9000 + 100000*seed + 1000*t + j."""
+               point_order: str = "shuffled", presence=None) -> Shard:
+    """Seeds: live 7000 + 1000*seed + i, history 9000 + 100000*seed + 1000*t + j.
+    presence: per track the scans [i0, i1) that have it as a traversal (presence_ramp); None: every scan has every track."""
     n_per_frame = n_live if n_per_frame is None else n_per_frame
     L = n_scans + n_frames - 1
     world = make_world(world_seed, length=max(400.0, x0 + frame_gap * L + 150.0))
@@ -306,15 +334,19 @@ def make_shard(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_frames: i
         live_pose = _pose_matrix(ex, 0.0, 0.01)
         live_raw = sample_frame(world, 7000 + 1000 * seed + i, n_live, live_pose, l2e, nusc, make_mobiles(1000 * seed + i, ex),
                                 point_order=point_order)
-        first_pose = poses[0][i]
-        hist, rels = [], []
-        for t in range(n_trav):
+        mine = [t for t in range(n_trav) if presence is None or presence[t][0] <= i < presence[t][1]]
+        assert len(mine) >= 2, "a scan needs two traversals (pre_compute_pp_score.py:125-126)"
+        first_pose = poses[mine[0]][i]
+        hist, rels, travs = [], [], []
+        for k, t in enumerate(mine):
             for j in range(i, i + n_frames):
                 hist.append((t, j))
+                travs.append(k)
                 rels.append(relative_pose(l2e, first_pose, l2e, poses[t][j], K))
         scans.append(ShardScan(index=i, live_raw=live_raw, live_W=live_pose @ l2e @ K,
                                live_rel=relative_pose(l2e, first_pose, l2e, live_pose, K), hist=hist, rels=np.stack(rels),
-                               world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K))
+                               world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K,
+                               travs=None if presence is None else travs))
     return Shard(scans=scans, tracks=tracks, nusc=nusc)
 
 
@@ -347,7 +379,7 @@ def match_history(origin_pose: np.ndarray, track_poses: Sequence[np.ndarray], di
 
 def make_shard_matched(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_per_frame: int | None = None, nusc: bool = False,
                        live_speed: float = 8.0, hist_speeds=(3.0, 15.0), hz: float = 5.0, seed: int = 0, x0: float = 0.0,
-                       world_seed: int = 0, point_order: str = "shuffled", opposite: int = 0) -> Shard:
+                       world_seed: int = 0, point_order: str = "shuffled", opposite: int = 0, presence=None) -> Shard:
     """A shard whose history windows are chosen as the reference chooses them (match_history): the live vehicle drives at
     `live_speed` m/s, traversal t at a speed drawn from `hist_speeds` (a (lo, hi) range, or one value per traversal), all
     sampled at `hz`; the last `opposite` traversals drive the other way.  Fast traversals (> 2 m per frame: > 10 m/s at 5 Hz)
@@ -376,7 +408,11 @@ def make_shard_matched(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_p
         if back:
             xs = xs[::-1]
         poses.append([_pose_matrix(x, lat, yaw + (np.pi if back else 0.0)) for x in xs])
-    picks = [[match_history(lp, poses[t], dis) for t in range(n_trav)] for lp in live_poses]
+    # (presence: per track the scans [i0, i1) that accept it as a traversal -- presence_ramp; the reference's 3 m test per scan,
+    # split_traintest.py:17,79, makes traversals enter and leave along a sequence)
+    has = [[presence is None or presence[t][0] <= i < presence[t][1] for t in range(n_trav)] for i in range(n_scans)]
+    assert all(sum(h) >= 2 for h in has), "a scan needs two traversals (pre_compute_pp_score.py:125-126)"
+    picks = [[match_history(lp, poses[t], dis) if has[i][t] else [] for t in range(n_trav)] for i, lp in enumerate(live_poses)]
     assert all(ix is not None for row in picks for ix in row), "a traversal does not cover the shard"
     used = [sorted({j for row in picks for j in row[t]}) for t in range(n_trav)]
     renum = [{j: k for k, j in enumerate(u)} for u in used]
@@ -386,11 +422,14 @@ def make_shard_matched(n_scans: int, n_live: int = 30_000, n_trav: int = 10, n_p
     for i, lp in enumerate(live_poses):
         live_raw = sample_frame(world, 7000 + 1000 * seed + i, n_live, lp, l2e, nusc, make_mobiles(1000 * seed + i, lp[0, 3]),
                                 point_order=point_order)
-        first_pose = poses[0][picks[i][0][0]]
-        hist = [(t, renum[t][j]) for t in range(n_trav) for j in picks[i][t]]
-        rels = np.stack([relative_pose(l2e, first_pose, l2e, poses[t][j], K) for t in range(n_trav) for j in picks[i][t]])
+        mine = [t for t in range(n_trav) if has[i][t]]
+        first_pose = poses[mine[0]][picks[i][mine[0]][0]]
+        hist = [(t, renum[t][j]) for t in mine for j in picks[i][t]]
+        travs = [k for k, t in enumerate(mine) for _ in picks[i][t]]
+        rels = np.stack([relative_pose(l2e, first_pose, l2e, poses[t][j], K) for t in mine for j in picks[i][t]])
         scans.append(ShardScan(index=i, live_raw=live_raw, live_W=lp @ l2e @ K, live_rel=relative_pose(l2e, first_pose, l2e, lp, K),
-                               hist=hist, rels=rels, world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K))
+                               hist=hist, rels=rels, world_from_ref=first_pose @ l2e @ K, first_pose=first_pose, l2e=l2e, K=K,
+                               travs=None if presence is None else travs))
     return Shard(scans=scans, tracks=tracks, nusc=nusc)
 
 

@@ -305,3 +305,41 @@ def test_blocks_of_32_and_the_split_rule(gpu):
         assert all(torch.equal(a, b) for a, b in zip(cb, ref))
         for i in (0, 31):
             assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), _oracle_counts(sh, i)[1]), (F, i)
+
+
+def test_block_with_different_traversal_counts_per_scan(gpu):
+    """The reference accepts a traversal PER SCAN (closest pose within 3 m, data_preprocessing/lyft/split_traintest.py:17,79) and only
+    asks for two (:111; pre_compute_pp_score.py:125-126): T changes along a sequence, and so does the traversal index a track has in a
+    scan's list.  One block of scans with at least three distinct T == the per-scan chain (one call per run of equal T) == the oracle
+    (counts (n, T_scan), H normalised by ln T_scan, pre_compute_pp_score.py:68-75) -- on windows i..i+F-1 and on reference-rule windows."""
+    import torch
+    from modest_amd import synth
+    from modest_amd.frame_store import FrameStore
+    S = 12
+    for matched in (False, True):
+        pr = synth.presence_ramp(S, 7, seed=2)
+        if matched:
+            sh = synth.make_shard_matched(S, n_live=4000, n_trav=7, n_per_frame=4000, live_speed=8.0, hist_speeds=(3.0, 15.0), seed=5, presence=pr)
+        else:
+            sh = synth.make_shard(S, n_live=4000, n_trav=7, n_frames=5, n_per_frame=4000, seed=5, presence=pr)
+        Ts = [sc.n_trav for sc in sh.scans]
+        assert len(set(Ts)) >= 3, Ts
+        store = FrameStore(gpu, 0.3)
+        lives, _, ids = _load(store, sh, gpu, torch)
+        descs = [store.describe(lives[i], sc.live_rel, [ids[h] for h in sc.hist], sc.trav_list(), sc.rels, sh.nusc)
+                 for i, sc in enumerate(sh.scans)]
+        n0 = getattr(store, "block_calls", 0)
+        Hb, cb = store.pp_score_batch(lives, descs, Ts, return_counts=True, block=True)
+        assert getattr(store, "block_calls", 0) == n0 + 1
+        Hv, cv = store.pp_score_batch(lives, descs, Ts, return_counts=True, block=False)
+        assert getattr(store, "block_calls", 0) == n0 + 1
+        for i in range(S):
+            Href, cref = _oracle_counts(sh, i)
+            assert cref.shape[1] == Ts[i] and tuple(cb[i].shape) == cref.shape
+            assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), cref), (matched, i)
+            assert np.max(np.abs(Hb[i].cpu().numpy().astype(np.float64) - Href)) <= 1e-6
+            assert torch.equal(cb[i], cv[i]) and torch.equal(Hb[i], Hv[i]), (matched, i)
+        # a scan alone, with its own T, through the single-scan entry point
+        k = int(np.argmin(Ts))
+        one = store.pp_score_batch(lives[k:k + 1], descs[k:k + 1], Ts[k], return_counts=True, block=False)[1][0]
+        assert torch.equal(one, cb[k])

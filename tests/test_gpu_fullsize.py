@@ -147,19 +147,22 @@ def test_ransac_deviation_does_not_change_labels(gpu):
     assert not bad, bad
 
 
-def _block_full_size(gpu, n_live, T, F, nusc, matched=None):
-    """16 consecutive scans of a shard at the benchmarked size through ONE modest_pp_score_block call (what the CLI and
-    bench.py run, FrameStore.pp_score_batch(block=True)); counts of scans 0 / 7 / 15 against scipy's cKDTree on the stacked,
-    transformed history (pre_compute_pp_score.py:132-150,188-193; all host threads)."""
+def _block_full_size(gpu, n_live, T, F, nusc, matched=None, S=32, presence=None):
+    """S (default 32 = configs/pp_score.yaml pp_batch, bench.py --pp-batch) consecutive scans of a shard at the benchmarked size
+    through ONE block call (what the CLI and bench.py run, FrameStore.pp_score_batch(block=True)) -- and the same scans forced
+    through two blocks of half the scans and through the join variant that reads the poses from memory instead of LDS (what a
+    union of more than 2 048 entries takes): all three identical on every scan, and scans 0 / S/2-1 / S-1 against scipy's
+    cKDTree on the stacked, transformed history (pre_compute_pp_score.py:132-150,188-193; all host threads)."""
+    import os
     import torch
     from modest_amd import synth
     from modest_amd.frame_store import FrameStore
     from oracle import pp_score as opp
-    S = 16
     if matched is None:
-        sh = synth.make_shard(S, n_live=n_live, n_trav=T, n_frames=F, nusc=nusc, seed=4)
+        sh = synth.make_shard(S, n_live=n_live, n_trav=T, n_frames=F, nusc=nusc, seed=4, presence=presence)
     else:
-        sh = synth.make_shard_matched(S, n_live=n_live, n_trav=T, nusc=nusc, live_speed=matched[0], hist_speeds=matched[1:], seed=4)
+        sh = synth.make_shard_matched(S, n_live=n_live, n_trav=T, nusc=nusc, live_speed=matched[0], hist_speeds=matched[1:], seed=4,
+                                      presence=presence)
     store = FrameStore(gpu, 0.3)
     items, ids = [], {}
     for t, tr in enumerate(sh.tracks):
@@ -171,34 +174,72 @@ def _block_full_size(gpu, n_live, T, F, nusc, matched=None):
         items.append((10 ** 6 + sc.index, torch.from_numpy(sc.live_raw).to(gpu), sc.live_W))
         lives.append(10 ** 6 + sc.index)
     store.insert_many(items)
-    descs = [store.describe(lives[i], sc.live_rel, [ids[h] for h in sc.hist], [t for t, _ in sc.hist], sc.rels, nusc)
+    descs = [store.describe(lives[i], sc.live_rel, [ids[h] for h in sc.hist], sc.trav_list(), sc.rels, nusc)
              for i, sc in enumerate(sh.scans)]
+    Ts = [sc.n_trav for sc in sh.scans]
     n0 = getattr(store, "block_calls", 0)
-    Hs, cs = store.pp_score_batch(lives, descs, T, return_counts=True, block=True)
+    Hs, cs = store.pp_score_batch(lives, descs, Ts, return_counts=True, block=True)
     assert getattr(store, "block_calls", 0) == n0 + 1, "the block path declined the benchmarked shape"
     torch.cuda.synchronize()
-    for i in (0, 7, 15):
+    for i in (0, S // 2 - 1, S - 1):
         lv, hist = sh.stacked(i)
         Href, cref = opp.pp_score(lv, hist, 0.3, workers=-1)
+        assert cs[i].shape[1] == Ts[i]
         assert np.array_equal(cs[i].cpu().numpy().astype(np.int64), cref), i
         assert np.max(np.abs(Hs[i].cpu().numpy().astype(np.float64) - Href)) <= 1e-6   # compute_ephe_score's tolerance (measured 0)
         assert int(cref.sum()) > 1_000_000
+    # two blocks of half the scans (what the split rule does past 3 x / 2 048 entries / the block window)
+    h = S // 2
+    lo = store.pp_score_batch(lives[:h], descs[:h], Ts[:h], return_counts=True, block=True)
+    hi = store.pp_score_batch(lives[h:], descs[h:], Ts[h:], return_counts=True, block=True)
+    assert getattr(store, "block_calls", 0) == n0 + 3
+    for i in range(S):
+        Hh, ch = (lo[0][i], lo[1][i]) if i < h else (hi[0][i - h], hi[1][i - h])
+        assert torch.equal(ch, cs[i]) and torch.equal(Hh, Hs[i]), ("halves", i)
+    # the poses read from memory (MODEST_PP4_DBG=256: the kernel instantiation of unions with more than 2 048 entries)
+    old = os.environ.get("MODEST_PP4_DBG")
+    os.environ["MODEST_PP4_DBG"] = "256"
+    try:
+        Hm, cm = store.pp_score_batch(lives, descs, Ts, return_counts=True, block=True)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["MODEST_PP4_DBG"]
+        else:
+            os.environ["MODEST_PP4_DBG"] = old
+    for i in range(S):
+        assert torch.equal(cm[i], cs[i]) and torch.equal(Hm[i], Hs[i]), ("poses from memory", i)
     return sh
 
 
-def test_config3_block_of_16_scans_full_size(gpu):
-    """BASELINE config 3 through the block path: 16 consecutive scans x (30 000 live points vs 10 x 36 frames)."""
+def test_config3_block_of_32_scans_full_size(gpu):
+    """BASELINE config 3 through the block path at the default block size: 32 consecutive scans x (30 000 live points vs 10 x 36
+    frames), 670 union entries."""
     sh = _block_full_size(gpu, 30_000, 10, 36, False)
     assert sum(len(sh.tracks[t][j][0]) for t, j in sh.scans[0].hist) == 10_800_000
 
 
-def test_config5_block_of_16_scans_full_size(gpu):
-    """BASELINE config 5 through the block path: nuScenes shape, remove_center on the history, 35 k x 20 x 16."""
+def test_config3_block_of_16_scans_full_size(gpu):
+    """... and in blocks of 16 (the halves of a split block; rounds 4-5's default)."""
+    _block_full_size(gpu, 30_000, 10, 36, False, S=16)
+
+
+def test_config5_block_of_32_scans_full_size(gpu):
+    """BASELINE config 5 through the block path: nuScenes shape, remove_center on the history, 35 k x 20 x 16 -- 940 union entries."""
     _block_full_size(gpu, 35_000, 20, 16, True)
 
 
 def test_config3_block_on_reference_rule_windows_full_size(gpu):
     """... and on windows chosen as the reference chooses them (split_traintest.py:79-101: repeated frames at the fast traversals,
-    a third of the frames shared at the slow ones; live 8 m/s, history 3-15 m/s)."""
+    a third of the frames shared at the slow ones; live 8 m/s, history 3-15 m/s): ~935 union entries for 32 scans."""
     sh = _block_full_size(gpu, 30_000, 10, 36, False, matched=(8.0, 3.0, 15.0))
     assert any(len(set(sc.hist)) < len(sc.hist) for sc in sh.scans)   # the lists do repeat frames
+
+
+def test_block_of_32_scans_with_traversals_entering_and_leaving_full_size(gpu):
+    """The reference accepts a traversal PER SCAN (closest pose within 3 m, split_traintest.py:17,79) and needs two (:111): T
+    changes along a sequence.  Reference-rule windows, 12 tracks that enter and leave (T between 5 and 11 inside the block)."""
+    from modest_amd import synth
+    pr = synth.presence_ramp(32, 12, seed=3)
+    sh = _block_full_size(gpu, 30_000, 12, 36, False, matched=(8.0, 3.0, 15.0), presence=pr)
+    assert len({sc.n_trav for sc in sh.scans}) >= 3
