@@ -20,7 +20,11 @@ closeness box fit -> BEV IoU NMS -> KITTI label text.  value = scans/s over all 
 every rank processes K scans of its own).  Besides the contract fields the JSON line carries
   roofline     -- the PP neighbour count (the operation SURVEY.md 8d prices at 12*M + 16*N
                   algorithmic bytes per scan; here it is a chain of kernels, so the WHOLE chain is
-                  timed with HIP events, not just its largest kernel) against the 8 TB/s HBM3E peak;
+                  timed with HIP events, not just its largest kernel) against the 8 TB/s HBM3E peak, on a
+                  block of scans whose history windows are what data_preprocessing/lyft/split_traintest.py:79-113
+                  emits: windows by distance thresholds (repeated frames), traversals accepted per scan (T changes
+                  inside the block); `roofline_best_case` = the same measurement on the windows of frames i..i+F-1
+                  every timed region runs on (35 of 36 frames shared with the previous scan);
   cpu_baseline -- the oracle (the reference's own scipy/sklearn calls, same threading as the
                   reference: cKDTree single-threaded, sklearn n_jobs=-1) timed on this host on a
                   bounded sample of the same scans, plus `best_effort` (SURVEY 8d baseline B:
@@ -88,14 +92,15 @@ def parse(argv=None):
     ap.add_argument("--n-live", type=int, default=30000)
     ap.add_argument("--traversals", type=int, default=10)
     ap.add_argument("--frames", type=int, default=36)
-    ap.add_argument("--cpu-scans", type=int, default=2, help="scans of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-scans", type=int, default=5, help="scans of the CPU baseline sample, timed one by one after one untimed warm-up scan: "
+                    "the rate is 1 / their median (BASELINE.md 3; 0 = skip)")
     ap.add_argument("--cpu-best-effort", type=int, default=16,
                     help="scans of the best-effort CPU baseline (one process per scan, workers=-1; 0 = skip)")
     ap.add_argument("--sharing", choices=("best", "realistic"), default="realistic",
-                    help="realistic (default): besides the headline roofline (windows of frames i..i+F-1: 35 of 36 frames shared, the "
-                         "best case) the line carries `roofline_realistic` -- the same isolated measurement on a shard whose history "
-                         "windows are chosen by the reference's rule (split_traintest.py:79-101; live 8 m/s, history 3-15 m/s at 5 Hz: "
-                         "repeated frames, union ~1.9 x a scan's frames).  best: skip it")
+                    help="realistic (default): the line's `roofline` is the isolated measurement on a shard whose history windows are chosen "
+                         "by the reference's rule (split_traintest.py:79-113; live 8 m/s, history 3-15 m/s at 5 Hz: repeated frames, traversals "
+                         "that enter and leave, union ~2.5 x a scan's entries); the windows of frames i..i+F-1 (35 of 36 frames shared: the best "
+                         "case) are `roofline_best_case`.  best: only the latter")
     ap.add_argument("--pp-only", action="store_true", help="config 2: PP-score stage only")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="A/B: do not enqueue the next scan's PP stage under the host tail of the current scan's label stage "
@@ -196,9 +201,9 @@ class ResidentScan:
         self.live_host = sc.live_raw
         self.live_id = shard.base + shard.T * shard.L + sc.index
         self.live_raw = torch.from_numpy(sc.live_raw).to(shard.dev)   # file order, for stages 2 + 3
-        self.N, self.T = int(sc.live_raw.shape[0]), shard.T
+        self.N, self.T = int(sc.live_raw.shape[0]), (sc.n_trav if sc.travs is not None else shard.T)   # (the scan's own number of traversals)
         self.hist_ids = [shard.base + t * shard.L + j for t, j in sc.hist]
-        self.travs = [t for t, _ in sc.hist]
+        self.travs = sc.trav_list()
         self.M = int(sum(len(sh.tracks[t][j][0]) for t, j in sc.hist))   # (history points before remove_center)
         self.rels, self.live_rel, self.A44 = sc.rels, sc.live_rel, sc.world_from_ref
         self.W_stack = np.stack([shard.W[f] for f in self.hist_ids] + [sc.live_W])   # raw pose factors E @ L @ K of all 361 frames
@@ -564,9 +569,17 @@ def realistic_pp(runner):
     from modest_amd import synth
     a = runner.a
     PB = runner.PB
-    sh = synth.make_shard_matched(PB, n_live=a.n_live, n_trav=a.traversals, nusc=bool(getattr(a, "nusc", False)), live_speed=8.0,
-                                  hist_speeds=(3.0, 15.0), seed=77)
+    # what a real valid_idx_info.pkl holds (data_preprocessing/lyft/split_traintest.py:79-113): windows by distance thresholds
+    # (repeated frames at the fast traversals), and a traversal accepted PER SCAN (closest pose within 3 m, :17,79; two needed, :111)
+    # -- tracks enter and leave along the shard, T changes inside the block
+    n_tracks = a.traversals + 3
+    pres = synth.presence_ramp(PB, n_tracks, t_min=max(2, a.traversals - 3), seed=int(getattr(a, "presence_seed", 5)))
+    sh = synth.make_shard_matched(PB, n_live=a.n_live, n_trav=n_tracks, nusc=bool(getattr(a, "nusc", False)), live_speed=8.0,
+                                  hist_speeds=(3.0, 15.0), seed=77, presence=pres)
     stats = synth.sharing_stats(sh, PB)
+    Ts = [sc.n_trav for sc in sh.scans]
+    stats.update(traversals_per_scan_min=int(min(Ts)), traversals_per_scan_max=int(max(Ts)), traversals_per_scan_mean=float(np.mean(Ts)),
+                 distinct_traversal_counts=int(len(set(Ts))), tracks=int(n_tracks))
     rs = ResidentShard(sh, runner.dev, runner.scans[0].calib, runner.store, 4096 * 64 * 40, bool(getattr(a, "nusc", False)), realistic=True)
     if runner.iso_ctx is None:
         runner.iso_ctx = runner._lib.Context(runner.local)
@@ -576,7 +589,7 @@ def realistic_pp(runner):
     ctx.profile_begin(8 * reps + 8)
     with torch.cuda.stream(runner.streams[0]):
         for i in range(reps):
-            runner.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], scs[0].T, ctx=ctx, block=runner.block)
+            runner.store.pp_score_batch([sc.live_key for sc in scs], [sc.desc for sc in scs], [sc.T for sc in scs], ctx=ctx, block=runner.block)
         runner.streams[0].synchronize()
     iso = np.asarray(ctx.profile_collect(8 * reps + 8))
     used_block = getattr(runner.store, "block_calls", 0) > calls0
@@ -846,6 +859,32 @@ def main():
         timed_region.paths = paths
         return time.perf_counter() - t0, np.concatenate(kms)
 
+    def host_cpu_seconds():
+        """user + system seconds of this rank's process and of its helper processes so far"""
+        try:
+            import psutil
+            me = psutil.Process()
+            tot = 0.0
+            for pr_ in [me] + me.children(recursive=True):
+                try:
+                    ct = pr_.cpu_times()
+                    tot += ct.user + ct.system
+                except psutil.Error:
+                    pass
+            return tot
+        except Exception:
+            return time.process_time()
+
+    def host_rss_mb():
+        try:
+            import psutil
+            me = psutil.Process()
+            return sum(pr_.memory_info().rss for pr_ in [me] + me.children(recursive=True)) / 2 ** 20
+        except Exception:
+            import resource
+            return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+    cpu0 = host_cpu_seconds()
     if helpers:
         dt, kernel_ms = timed_region(helpers[:n_procs], _split(a.steps, n_procs))
         paths = timed_region.paths
@@ -859,6 +898,14 @@ def main():
         dist.barrier()
         dt = time.perf_counter() - t0
         paths = [runner.last_paths]
+    # what a rank costs its host (an 8-GPU node carries 8 of these): busy threads = CPU seconds of the rank process and
+    # its helpers inside the contract clock / the clock (a polling helper counts as one whether or not it has work), resident memory
+    mine = dict(rank=rank, busy_threads=round((host_cpu_seconds() - cpu0) / max(dt, 1e-9), 2), rss_mb=round(host_rss_mb(), 1),
+                processes=1 + len(helpers))
+    host_budget = [mine]
+    if ws > 1 and torch.distributed.is_initialized():
+        host_budget = [None] * ws
+        torch.distributed.all_gather_object(host_budget, mine)
     red = dist.reduce_counters(dict(max_seconds=dt, scans=a.steps))
     dt_max, total_scans = red["max_seconds"], red["scans"]
     steady = None
@@ -903,7 +950,7 @@ def main():
             iso = runner.isolated_pp_ms()
         if iso:
             iso_ms, iso_B, iso_block = float(iso[0]), int(iso[1]), bool(iso[2])   # ms per call, scans per call, block path
-        if a.sharing == "realistic" and ws == 1:
+        if a.sharing == "realistic":
             try:
                 if helpers:
                     helpers[0][1].send(("iso_realistic", None))
@@ -997,6 +1044,24 @@ def main():
                                      "profiles/r05_sharing_sensitivity.json has the other speed buckets"}
     elif real:
         roofline_real = real
+    # The line's `roofline` is the REALISTIC figure: windows chosen as split_traintest.py:79-101 chooses them, repeated
+    # frames kept, traversals that enter and leave (T changes inside the block) -- the shape a real valid_idx_info.pkl holds.  The windows
+    # of frames i..i+F-1 that every timed region of this file runs on (35 of 36 frames shared: the best case) stay as `roofline_best_case`.
+    roofline_best = roofline
+    if roofline_real and "error" not in roofline_real:
+        tname = "r06_pp_block_traffic_realistic.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath) and roofline_real.get("block_path"):
+            tj = json.load(open(tpath))
+            roofline_real["traffic"] = tj["hbm_bytes_per_scan"] * roofline_real["scans_per_launch"]   # per launch, like `achieved`
+            roofline_real["traffic_per_scan"] = tj["hbm_bytes_per_scan"]
+            roofline_real["traffic_source"] = f"profiles/{tname} (" + tj["source"] + ")"
+        roofline_real["kernel"] = kernel_txt
+        roofline_real["algorithmic_bytes_per_launch"] = roofline_real["algorithmic_bytes_per_scan"] * roofline_real["scans_per_launch"]
+        roofline = roofline_real
+    else:
+        roofline = dict(roofline_best, note="the realistic-sharing measurement was not taken (--sharing best, or it failed: see roofline_realistic_error); "
+                                            "this is the best-case figure")
     cpu_baseline = None
     parity = None
     cli = None
@@ -1016,25 +1081,29 @@ def main():
             ocalib = ol.Calibration(os.path.join(d, "c.txt"))
         # the sample = the first scans helper 0 (or the rank process) benchmarked: same generator, same seeds
         n_cpu = min(a.cpu_scans, a.scans, a.shard_scans, max(1, min(a.pp_batch, a.shard_scans, a.scans)))
-        hsh = synth.make_shard(n_cpu, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames, seed=scan_seed(rank, 0, 0), nusc=a.nusc)
+        # (+ one warm-up scan, the shard's next one: BASELINE.md section 3 -- 1 warm-up + the median of >= 5 scans)
+        hsh = synth.make_shard(n_cpu + 1, n_live=a.n_live, n_trav=a.traversals, n_frames=a.frames, seed=scan_seed(rank, 0, 0), nusc=a.nusc)
         ocfg = None
         if a.nusc:
             import copy
             ocfg = copy.deepcopy(om.DEFAULT_CFG)
             ocfg["plane_estimate"]["max_hs"] = -1.3
-        stacked = [hsh.stacked(i) for i in range(n_cpu)]
-        refs = []
-        tc = time.perf_counter()
-        for i in range(n_cpu):
+        stacked = [hsh.stacked(i) for i in range(n_cpu + 1)]
+        refs, per_scan = [], []
+        for i in [n_cpu] + list(range(n_cpu)):   # (the warm-up scan first, untimed: page cache, thread pools, joblib workers)
             live_xyz, hist = stacked[i]
+            t1 = time.perf_counter()
             Href, cref = opp.pp_score(live_xyz, hist, 0.3, workers=1)       # reference: single thread
             ref = None
             if not a.pp_only:
                 ref = om.generate_mask_scan(hsh.scans[i].live_raw, Href, ocalib, random_state=np.random.RandomState(i), n_jobs=-1,
                                             **({"cfg": ocfg} if ocfg else {}))
                 ref["text"] = ol.gen_label_scan(ref["objs"], ocalib, **({"image_shape": (900, 1600)} if a.nusc else {}))
-            refs.append((Href, cref, ref))
-        tc = time.perf_counter() - tc
+            if i < n_cpu:
+                per_scan.append(time.perf_counter() - t1)
+                refs.append((Href, cref, ref))
+        tc = float(np.sum(per_scan))
+        t_med = float(np.median(per_scan))
         del stacked
         # parity of the measured path against the checker, outside every timed region: the first block of helper 0's first
         # shard (the scans the CPU sample took are its first ones) through ONE PP call, as the timed region runs it
@@ -1059,8 +1128,10 @@ def main():
             parity["n_objs"] = [len(objs), len(ref["objs"])]
             parity["label_text_equal"] = bool(text == ref["text"][0])
         del pr
-        cpu_baseline = {"value": n_cpu / tc, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
-                        "sample": f"{n_cpu} of the benchmarked scans ({'PP stage only' if a.pp_only else 'full pipeline'}); "
+        cpu_baseline = {"value": 1.0 / t_med, "unit": "scans/s", "cores": os.cpu_count(), "kind": "port",
+                        "seconds_per_scan": [round(x, 3) for x in per_scan], "mean_value": n_cpu / tc,
+                        "sample": f"median of {n_cpu} of the benchmarked scans timed one by one after one untimed warm-up scan "
+                                  f"({'PP stage only' if a.pp_only else 'full pipeline'}); "
                                   "reference threading: cKDTree build+query 1 thread, sklearn n_jobs=-1 on all "
                                   f"{os.cpu_count()} host threads; {tc:.1f} s.  The oracle fills the affinity weights with "
                                   "one vectorised numpy expression where the reference loops over CSR rows in Python "
@@ -1103,13 +1174,19 @@ def main():
                                           "(data_preprocessing/lyft/split_traintest.py:64,97; SURVEY 8d C4)",
                        "pp_grid_cus_per_process": (a.pp_cus if (a.procs > 1 and a.pp_cus > 0 and not note) else "all"),
                        "startup": startup,
-                       "rccl_world_size": rccl_ws, "rccl_ranks_seen": rccl_check["ranks_seen"],
+                       "host_budget_per_rank": host_budget,
+                       # the process group as it ran (dist.selfcheck: an all-reduce of one 1 per rank): `rccl_world_size` is only set when
+                       # the backend IS RCCL ("nccl"); ranks that share one GPU under gloo (tests) report world_size / ranks_seen alone
+                       "world_size": rccl_ws, "ranks_seen": rccl_check["ranks_seen"],
                        "process_group_backend": rccl_check["backend"],
+                       "rccl_world_size": (rccl_ws if rccl_check["backend"] in ("nccl", "none") else None),
                        "ransac_trial_loops": "host" if os.environ.get("MODEST_RANSAC_HOST") else "device",
                        "runtime_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_INTERRUPT", "HSA_ENABLE_IPC_MODE_LEGACY",
                                                                       "GPU_MAX_HW_QUEUES")},
                        "parallelism": f"scan-sharded x{ws} (no data-path collective)"},
-            "roofline": roofline, "roofline_realistic": roofline_real, "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli, "steady_state": steady,
+            "roofline": roofline, "roofline_best_case": roofline_best,
+            "roofline_realistic_error": (roofline_real if (roofline_real and "error" in roofline_real) else None),
+            "cpu_baseline": cpu_baseline, "parity": parity, "cli": cli, "steady_state": steady,
             "value_with_ingest": with_ingest,
             "speedup_vs_cpu": (value / cpu_baseline["value"]) if cpu_baseline else None,
         }

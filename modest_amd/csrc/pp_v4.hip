@@ -98,6 +98,7 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
     unsigned *needCand;   // the tiles some scan needs (ctrl[3] of them)
     unsigned long long *needMask;   // per window tile: the scans with a live point in the 3x3 tiles around it
     uint2 *segRange;   // smallest / largest frame slot among a segment's records
+    unsigned *deal;     // b4_deal: [0, G] first join workgroup of every scan (G: their number), then the scan of every join workgroup
     float4 *recA, *recB;
     int U, NG, nchunks, maxSegs;
     int BX0, BY0, BW, BH, BT, CW, CHc, NCpad, nScanBlk, G;
@@ -363,10 +364,11 @@ __global__ __launch_bounds__(512) void b4_scatter(Blk B) {
             if (!valid[u] || lt[u] == 0u) continue;
             const int i = (int)ct.y + (half * 4 + u) * 512 + tid;
             const unsigned dest = lb[u] + gt[u] + of[u] + ((unsigned)i - tb[u]);
-            // remove_center (pre_compute_pp_score.py:48-52,141-142) drops the point before the transform: a NaN
-            // coordinate keeps its slot in the list and never passes a distance test
+            // remove_center (pre_compute_pp_score.py:48-52,141-142) drops the point before the transform: an x of 1e30 keeps
+            // its slot in the list and never passes a distance test (a rotation has no zero column: some coordinate of the
+            // transformed point is ~1e30, its squared distance overflows to +inf)
             float xs = x[u];
-            if ((F.flags & F_FLAG_CENTER) && in_center_box(x[u], y[u])) xs = __int_as_float(0x7fc00000);
+            if ((F.flags & F_FLAG_CENTER) && in_center_box(x[u], y[u])) xs = 1.0e30f;   // (not a NaN: the join keeps a running minimum of |d2 - r2|)
             B.recA[dest] = make_float4(xs, y[u], z[u], __int_as_float(key[u] | (f << 6)));
         }
         }
@@ -573,8 +575,9 @@ __global__ __launch_bounds__(256) void b4_live_scatter(Blk B, const ScanDev *__r
     const float4 t = S.tmp[i];
     const int cell = __float_as_int(t.w);
     const unsigned slot = b4_cs(S.cellStart, S.blockSum, (size_t)cell) + (atomicSub(&S.cellCount[cell], 1u) - 1u);   // (the order inside a cell is free)
-    S.sorted[slot] = make_float4(t.x, t.y, t.z, __int_as_float((int)S.livePerm[i]));
-    // counts are indexed by the ORIGINAL point order of the live frame
+    // counts are indexed by the ORIGINAL point order of the live frame: w = the BYTE offset of the point's row of counts (n, T) --
+    // the join adds it to the counts pointer with two scalar instructions per atomic (a row number cost a 64-bit multiply and shift)
+    S.sorted[slot] = make_float4(t.x, t.y, t.z, __int_as_float((int)(S.livePerm[i] * (unsigned)S.T * 4u)));
 }
 
 // ---- plan ------------------------------------------------------------------------------------------
@@ -633,6 +636,11 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     const int cx = (b % B.BW - C.x0) * 8 + (lane & 7), cy = (b / B.BW - C.y0) * 8 + (lane >> 3);   // (on the crop)
     unsigned sa[3], sn[3];
     b4_cell_segs(S.cellStart, S.blockSum, C.CW, C.CH, cx, cy, sa, sn);
+    // non-empty runs first: the join streams a task's candidates run after run, the first trip of a run requested during the
+    // last trip of the run before it, and stops at the first empty run
+    if (sn[0] == 0u) sa[0] = sa[1], sn[0] = sn[1], sa[1] = sa[2], sn[1] = sn[2], sn[2] = 0u;
+    if (sn[0] == 0u) sa[0] = sa[1], sn[0] = sn[1], sn[1] = 0u;
+    if (sn[1] == 0u) sa[1] = sa[2], sn[1] = sn[2], sn[2] = 0u;
     // The part of every cell this scan reads.  The tile list is in the order of the block's frame table and its
     // segments were sorted one by one, so a cell's records are [run of segment 0 | run of segment 1 | ...] with ascending
     // frame slots from run to run: the runs of the segments that overlap [slotLo, slotHi] hold every record of the
@@ -724,6 +732,45 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
     }
 }
 
+// ---- which scan a join workgroup works on --------------------------------------------------------
+// The scans of a block differ by up to 1.5 x in work (a scan in the middle of the block reads two boundary segments per cell, the
+// scenery changes along the shard); with the same number of workgroups per scan the grid rows of the light scans ended early and
+// their CUs idled: the wavefronts were present for 88 % of the join's span on average.  One wavefront (lane = scan) shares the NW
+// workgroups out in proportion to the planned work (one-cell and four-cell tasks, weighted by their measured cost), at least one each.
+constexpr int B4_DEAL_WH = 4, B4_DEAL_WL = 5;   // relative cost of a one-cell / a four-cell task (MODEST_PP4_DBG=512: 41 / 50 ns per wavefront)
+__global__ __launch_bounds__(64) void b4_deal(Blk B, const ScanDev *__restrict__ scans, unsigned NW) {
+    const int lane = threadIdx.x, G = B.G;
+    unsigned long long w = 0;
+    if (lane < G) {
+        const ScanDev &S = scans[lane];
+        const unsigned nHu = min(S.ctrl[0], (unsigned)S.maxTasks), nLu = min(S.ctrl[1], (unsigned)S.maxLight);
+        const unsigned nH = nHu + min(S.ctrl[40], (unsigned)S.maxTasks - nHu), nL = nLu + min(S.ctrl[41], (unsigned)S.maxLight - nLu);
+        w = (unsigned long long)nH * B4_DEAL_WH + (unsigned long long)nL * B4_DEAL_WL + 1ULL;
+    }
+    unsigned long long cum = w;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(cum, o);
+        if (lane >= o) cum += u;
+    }
+    const unsigned long long total = __shfl(cum, 63);
+    // end of the scan's range of workgroups: proportional, then strictly increasing (one workgroup each at least) and <= NW
+    long long b = lane < G ? (long long)((cum * NW + total / 2) / total) : (long long)NW;
+    if (lane == G - 1) b = NW;
+    long long c = max(b, 1LL) - lane;   // prefix maximum of (b - lane), + lane: strictly increasing
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long u = __shfl_up(c, o);
+        if (lane >= o) c = max(c, u);
+    }
+    const unsigned end = (unsigned)min(c + lane, (long long)NW - (G - 1 - lane));
+    unsigned first = __shfl_up(end, 1);
+    if (lane == 0) first = 0;
+    if (lane < G) {
+        B.deal[lane] = first;
+        if (lane == G - 1) B.deal[G] = NW;
+        for (unsigned i = first; i < end; ++i) B.deal[65 + i] = (unsigned)lane;
+    }
+}
+
 // ---- join ------------------------------------------------------------------------------------------
 // pointers that reach a kernel through a device table are generic to the compiler (flat_load: counted against
 // the LDS counter as well, so every LDS wait also waits for them); the join states that they are global -- and, for what
@@ -741,8 +788,8 @@ __device__ __forceinline__ void b4_count_add(B4_CNT p, int v) {
 // counts[live point][lane's traversal] += v with the row's address in SGPRs (the live point is wave-uniform) and the lane's byte
 // offset in one VGPR: the compiler's own form adds the scalar row offset to a per-lane 64-bit pointer with a VALU instruction
 // per candidate -- in a loop that is bound by them
-__device__ __forceinline__ void b4_count_add_row(B4_CNT counts, int point, int T, unsigned laneBytes, int v) {
-    B4_CNT row = counts + (size_t)point * (size_t)T;
+__device__ __forceinline__ void b4_count_add_row(B4_CNT counts, int rowBytes, unsigned laneBytes, int v) {
+    B4_CNT row = (B4_CNT)((__attribute__((address_space(1))) char *)counts + (unsigned)rowBytes);
     asm volatile("global_atomic_add %0, %1, %2" : : "v"(laneBytes), "v"(v), "s"(row) : "memory");
 }
 template <typename T> __device__ __forceinline__ B4_GLOBAL(T) b4_global(const T *p) {
@@ -766,6 +813,12 @@ __device__ __forceinline__ unsigned b4_ticket_request(B4_TICKET p, int lane) {
 
 // popcount(x) + acc in ONE instruction (the compiler prefers independent popcounts and a three-operand add tree: three more
 // VALU instructions per candidate in a loop that is bound by them)
+// min(m, |a|, |b|) in ONE instruction (the compiler's fminf(fabsf()) canonicalises both operands first: seven instructions)
+__device__ __forceinline__ float b4_min3abs(float m, float a, float b) {
+    float r;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned b4_bcnt(unsigned x, unsigned acc) {
     unsigned r;
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
@@ -779,110 +832,114 @@ __device__ __forceinline__ unsigned b4_bcnt(unsigned x, unsigned acc) {
 // Lane t adds the hits of traversal t (segment masks sLo / sHi per chunk) to counts[live point][t]: one global atomic
 // instruction per (candidate, task), at most T lanes of it active.
 typedef float v8f __attribute__((ext_vector_type(8)));
-// one candidate (q: wave-uniform, in SGPRs) against the task's chunks: hit counts of this lane's traversal; ORs the pairs
-// inside the band into *band
+// One candidate (q: wave-uniform, in SGPRs) against the task's chunks.  e = |q - h|^2 - r^2 comes out of the fused chain
+// fma(dz, dz, fma(dy, dy, fma(dx, dx, -r2f))) (three packed fma per chunk pair: the threshold costs no instruction), a pair
+// with e < -eps is a neighbour for certain (float32 evaluation is within 3.6e-7 r^2 of the float64 value scipy's predicate
+// compares -- the subtraction's, the three fma's and r2f's roundings -- and eps = 2e-6 r^2), a pair with e > eps is none, and the
+// pairs in between are found by ONE per-lane minimum of |e| per chunk pair (v_min3_f32 with |.| modifiers: no second compare,
+// no scalar mask logic per candidate) that is looked at once per task: b4_pairs_band then re-tests, exactly, every pair the loop
+// did not count.  Returns the hit count of this lane's traversal.
 template <int NP, bool ODD>
 __device__ __forceinline__ unsigned b4_pair_step(float qx_, float qy_, float qz_, const v2f *hx, const v2f *hy, const v2f *hz,
-                                                 const unsigned *sLo, const unsigned *sHi, float r2lo, float r2hi,
-                                                 unsigned long long *band) {
+                                                 const unsigned *sLo, const unsigned *sHi, v2f nr2, float neps, float *bm) {
     const v2f qx = {qx_, qx_}, qy = {qy_, qy_}, qz = {qz_, qz_};
     unsigned acc = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const v2f dx = qx - hx[p], dy = qy - hy[p], dz = qz - hz[p];
-        v2f d2 = dx * dx;
-        d2 = __builtin_elementwise_fma(dy, dy, d2);
-        d2 = __builtin_elementwise_fma(dz, dz, d2);
-        const unsigned long long hA = __ballot(d2.x < r2lo), mA = __ballot(d2.x <= r2hi);
-        const unsigned long long hB = __ballot(d2.y < r2lo), mB = __ballot(d2.y <= r2hi);
-        *band |= (hA ^ mA) | (hB ^ mB);
+        v2f e = __builtin_elementwise_fma(dx, dx, nr2);
+        e = __builtin_elementwise_fma(dy, dy, e);
+        e = __builtin_elementwise_fma(dz, dz, e);
+        const unsigned long long hA = __ballot(e.x < neps), hB = __ballot(e.y < neps);
+        *bm = b4_min3abs(*bm, e.x, e.y);
         // (a chunk pair without a hit could skip these eight instructions behind a scalar branch: measured, 5 % slower)
         acc = b4_bcnt((unsigned)hA & sLo[2 * p], acc);
         acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * p], acc);
         acc = b4_bcnt((unsigned)hB & sLo[2 * p + 1], acc);
         acc = b4_bcnt((unsigned)(hB >> 32) & sHi[2 * p + 1], acc);
     }
-    if (ODD) {   // a task of one or three chunks: the last chunk on its own (13 instructions instead of a half-empty pair's 18)
+    if (ODD) {   // a task of one or three chunks: the last chunk on its own
         const float dx = qx_ - hx[NP].x, dy = qy_ - hy[NP].x, dz = qz_ - hz[NP].x;
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        const unsigned long long hA = __ballot(d2 < r2lo), mA = __ballot(d2 <= r2hi);
-        *band |= hA ^ mA;
+        const float e = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, nr2.x)));
+        const unsigned long long hA = __ballot(e < neps);
+        *bm = b4_min3abs(*bm, e, e);
         acc = b4_bcnt((unsigned)hA & sLo[2 * NP], acc);
         acc = b4_bcnt((unsigned)(hA >> 32) & sHi[2 * NP], acc);
     }
     return acc;
 }
-template <int NP, bool ODD>
-__device__ __forceinline__ unsigned long long b4_pairs(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie,
-                                                       const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
-                                                       const unsigned *sHi, float r2lo, float r2hi, int lq, int T) {
-    unsigned long long band = 0;
-    if (ia >= ie) return band;
-    // two candidates per trip: ONE 32-byte scalar load a trip ahead (the run is contiguous; its last trip may read one point
-    // past the run: the array is allocated with a spare element), two independent dependency chains in the loop body
-    B4_CONST(v8f) two = (B4_CONST(v8f))(sorted);
-    v8f q = *(B4_CONST(v8f))(sorted + ia);
-#pragma unroll 1
-    for (unsigned i = ia; i < ie; i += 2) {
-        const v8f qn = *(B4_CONST(v8f))(sorted + min(i + 2, ie - 1));   // the next two candidates: in flight during this trip
-        const unsigned accA = b4_pair_step<NP, ODD>(q[0], q[1], q[2], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
-        if (lq < T && accA) b4_count_add_row(counts, __float_as_int(q[3]), T, 4u * (unsigned)lq, (int)accA);
-        if (i + 1 < ie) {
-            const unsigned accB = b4_pair_step<NP, ODD>(q[4], q[5], q[6], hx, hy, hz, sLo, sHi, r2lo, r2hi, &band);
-            if (lq < T && accB) b4_count_add_row(counts, __float_as_int(q[7]), T, 4u * (unsigned)lq, (int)accB);
-        }
-        q = qn;
-    }
-    (void)two;
-    return band;
+// the pairs the loop above did not count (e >= -eps), exactly: scipy's float64 predicate on those with e <= eps (the others are
+// further than r for certain).  A separate pass over the task's candidates, entered practically never (a few tasks per scan): its
+// float64 temporaries must not live in the registers of the loop above.  e is the SAME float32 chain as above (v_pk_fma_f32 and
+// v_fma_f32 round alike), so the two passes split the pairs without overlap.
+__device__ __forceinline__ bool b4_band_pair(float hx, float hy, float hz, float qx, float qy, float qz, float nr2, float neps, double r2) {
+    const float fx = qx - hx, fy = qy - hy, fz = qz - hz;
+    const float e = fmaf(fz, fz, fmaf(fy, fy, fmaf(fx, fx, nr2)));
+    return !(e < neps) && e <= -neps && pp_within(hx, hy, hz, qx, qy, qz, r2);
 }
-// the pairs inside the band around r^2 (a separate pass over the task's candidates, entered practically never: its
-// float64 temporaries must not live in the registers of the loop above)
 template <int NP, bool ODD>
 __device__ __forceinline__ void b4_pairs_band(B4_CONST(v4f) sorted, B4_CNT counts, unsigned ia, unsigned ie, const v2f *hx,
-                                              const v2f *hy, const v2f *hz, const unsigned *sLo, const unsigned *sHi, float r2lo,
-                                              float r2hi, double r2, int lq, int T) {
+                                              const v2f *hy, const v2f *hz, const unsigned *sLo, const unsigned *sHi, float nr2,
+                                              float neps, double r2, unsigned laneBytes) {
 #pragma unroll 1
     for (unsigned i = ia; i < ie; ++i) {
         const v4f q = sorted[i];
         unsigned acc = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            float fx = q.x - hx[p].x, fy = q.y - hy[p].x, fz = q.z - hz[p].x;
-            const float dA = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-            fx = q.x - hx[p].y, fy = q.y - hy[p].y, fz = q.z - hz[p].y;
-            const float dB = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-            const bool bA = !(dA < r2lo) && dA <= r2hi, bB = !(dB < r2lo) && dB <= r2hi;
-            const unsigned long long xA = __ballot(bA && pp_within(hx[p].x, hy[p].x, hz[p].x, q.x, q.y, q.z, r2));
-            const unsigned long long xB = __ballot(bB && pp_within(hx[p].y, hy[p].y, hz[p].y, q.x, q.y, q.z, r2));
+            const unsigned long long xA = __ballot(b4_band_pair(hx[p].x, hy[p].x, hz[p].x, q.x, q.y, q.z, nr2, neps, r2));
+            const unsigned long long xB = __ballot(b4_band_pair(hx[p].y, hy[p].y, hz[p].y, q.x, q.y, q.z, nr2, neps, r2));
             acc += __popc((unsigned)xA & sLo[2 * p]) + __popc((unsigned)(xA >> 32) & sHi[2 * p]);
             acc += __popc((unsigned)xB & sLo[2 * p + 1]) + __popc((unsigned)(xB >> 32) & sHi[2 * p + 1]);
         }
         if (ODD) {
-            const float fx = q.x - hx[NP].x, fy = q.y - hy[NP].x, fz = q.z - hz[NP].x;
-            const float dA = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-            const bool bA = !(dA < r2lo) && dA <= r2hi;
-            const unsigned long long xA = __ballot(bA && pp_within(hx[NP].x, hy[NP].x, hz[NP].x, q.x, q.y, q.z, r2));
+            const unsigned long long xA = __ballot(b4_band_pair(hx[NP].x, hy[NP].x, hz[NP].x, q.x, q.y, q.z, nr2, neps, r2));
             acc += __popc((unsigned)xA & sLo[2 * NP]) + __popc((unsigned)(xA >> 32) & sHi[2 * NP]);
         }
-        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
+        if (acc) b4_count_add_row(counts, __float_as_int(q.w), laneBytes, (int)acc);
     }
 }
+// The pair phase of a one-cell task: 2 * NP (+ 1) chunks of 64 records in registers -- in PAIRS (v2f: chunk 2p in .x, chunk
+// 2p+1 in .y), so that v_pk_add / v_pk_fma_f32 test a candidate against two chunks per instruction -- against the task's
+// candidates: up to three runs [aR, aR + nR) of the scan's sorted live points, the non-empty ones first (b4_plan).  One
+// candidate per step, two per trip from ONE 32-byte SCALAR load (wave-uniform address: the points arrive in SGPRs; no LDS
+// window, no barrier) requested a trip ahead -- across the runs: the last trip of a run requests the first candidates of the
+// next one, and the task's very first load (q) was issued before the transform.  (Rounds 4-5 started every run with a load
+// the loop then waited for: 2.3 candidates per run on average, i.e. most trips began with a wait.)
+// Lane t adds the hits of traversal t (segment masks sLo / sHi per chunk: zero for lanes >= T) to counts[live point][t]: one
+// global atomic instruction per (candidate, task), at most T lanes of it active.
 template <int NP, bool ODD>
-__device__ __forceinline__ void b4_pairs_rows(B4_CONST(v4f) sorted, B4_CNT counts, const unsigned *aR, const unsigned *nR,
+__device__ __forceinline__ void b4_pairs_rows(B4_CONST(v4f) sorted, B4_CNT counts, v8f q, const unsigned *aR, const unsigned *nR,
                                               const v2f *hx, const v2f *hy, const v2f *hz, const unsigned *sLo,
-                                              const unsigned *sHi, float r2lo, float r2hi, double r2, int lq, int T) {
-    unsigned long long band = 0;
+                                              const unsigned *sHi, float r2f, float eps, double r2, unsigned laneBytes) {
+    const v2f nr2 = {-r2f, -r2f};
+    const float neps = -eps;
+    float bm = 3.0e38f;
 #pragma unroll 1
     for (int rr = 0; rr < 3; ++rr) {
-        const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
-        band |= b4_pairs<NP, ODD>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, lq, T);
+        const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), n = __builtin_amdgcn_readfirstlane(nR[rr]);
+        if (n == 0u) break;
+        const unsigned ie = ia + n;
+        // where the last trip of this run prefetches: the next run's first candidates (the run's own last one if there is none)
+        const unsigned nn = rr < 2 ? __builtin_amdgcn_readfirstlane(nR[rr < 2 ? rr + 1 : 2]) : 0u;
+        const unsigned nxt = nn ? __builtin_amdgcn_readfirstlane(aR[rr < 2 ? rr + 1 : 2]) : ie - 1u;
+#pragma unroll 1
+        for (unsigned i = ia; i < ie; i += 2) {
+            const v8f qn = *(B4_CONST(v8f))(sorted + (i + 2 < ie ? i + 2 : nxt));   // in flight during this trip
+            const unsigned accA = b4_pair_step<NP, ODD>(q[0], q[1], q[2], hx, hy, hz, sLo, sHi, nr2, neps, &bm);
+            if (accA) b4_count_add_row(counts, __float_as_int(q[3]), laneBytes, (int)accA);
+            if (i + 1 < ie) {
+                const unsigned accB = b4_pair_step<NP, ODD>(q[4], q[5], q[6], hx, hy, hz, sLo, sHi, nr2, neps, &bm);
+                if (accB) b4_count_add_row(counts, __float_as_int(q[7]), laneBytes, (int)accB);
+            }
+            q = qn;
+        }
     }
-    if (band) {
+    if (__ballot(bm <= eps)) {
 #pragma unroll 1
         for (int rr = 0; rr < 3; ++rr) {
             const unsigned ia = __builtin_amdgcn_readfirstlane(aR[rr]), ie = ia + __builtin_amdgcn_readfirstlane(nR[rr]);
-            b4_pairs_band<NP, ODD>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+            b4_pairs_band<NP, ODD>(sorted, counts, ia, ie, hx, hy, hz, sLo, sHi, -r2f, neps, r2, laneBytes);
         }
     }
 }
@@ -902,7 +959,7 @@ __device__ __forceinline__ unsigned long long b4_pairs1(B4_CONST(v4f) sorted, B4
         band |= hA ^ mA;
         unsigned acc = b4_bcnt((unsigned)hA & sLo, 0u);
         acc = b4_bcnt((unsigned)(hA >> 32) & sHi, acc);
-        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
+        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), 4u * (unsigned)lq, (int)acc);
         q = qn;
     }
     return band;
@@ -917,7 +974,7 @@ __device__ __forceinline__ void b4_pairs1_band(B4_CONST(v4f) sorted, B4_CNT coun
         const bool bA = !(dA < r2lo) && dA <= r2hi;
         const unsigned long long xA = __ballot(bA && pp_within(hx, hy, hz, q.x, q.y, q.z, r2));
         const unsigned acc = __popc((unsigned)xA & sLo) + __popc((unsigned)(xA >> 32) & sHi);
-        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), T, 4u * (unsigned)lq, (int)acc);
+        if (lq < T && acc) b4_count_add_row(counts, __float_as_int(q.w), 4u * (unsigned)lq, (int)acc);
     }
 }
 // a sparse cell of a four-cell task: its three candidate runs
@@ -951,16 +1008,23 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int lq = lane;
     asm volatile("" : "+v"(lq));   // (an opaque copy of the lane id: keeps the mask constants out of long-lived registers)
-    const int T = scans[blockIdx.y].T;   // (the scan's own: a block may mix traversal counts, the LDS is sized with the largest)
+    const int scanIdx = __builtin_amdgcn_readfirstlane((int)B.deal[65 + blockIdx.x]);   // (b4_deal: workgroups in proportion to the scan's planned work)
+    const unsigned wgFirst = B.deal[scanIdx], wgCount = B.deal[scanIdx + 1] - wgFirst;
+    const int T = scans[scanIdx].T;   // (the scan's own: a block may mix traversal counts, the LDS is sized with the largest)
     const unsigned poseB = LPOSE ? b4_pose_bytes(B.U) : 0u;
     const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
     unsigned long long *smask = reinterpret_cast<unsigned long long *>(dynsm + poseB) + (size_t)wv * (B4_CPT * T);
-    const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));
+    const float r2lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(r2 * (1.0 - 1e-6)))));   // (the four-cell tasks' band)
+    const float r2hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(r2 * (1.0 + 1e-6)))));
+    // (the one-cell tasks': b4_pair_step; wave-uniform values the compiler computes on the vector side -- stated scalar, they
+    // are SGPR operands of the packed fma and the compares instead of three registers per lane)
+    const float r2f = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)r2)));
+    const float epsf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(r2 * 2e-6))));
     B4_GLOBAL(v4f) rec = b4_global(reinterpret_cast<const v4f *>(B.recB));
     const unsigned TK = (dbg >> 16) & 255 ? (unsigned)((dbg >> 16) & 255) : B4_TK;   // (MODEST_PP4_TK: tasks per ticket, experiments)
-    const unsigned W = gridDim.x * B4_JW;
-    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * B4_JW + (unsigned)wv));   // (wave-uniform: task descriptors and candidates are scalar loads)
+    const unsigned W = (unsigned)__builtin_amdgcn_readfirstlane((int)(wgCount * B4_JW));
+    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x - wgFirst) * B4_JW + (unsigned)wv));   // (wave-uniform: task descriptors and candidates are scalar loads)
 
     // PROF (MODEST_PP4_DBG=512): wall time of this wavefront by phase -- 0 pose table, 1 one-cell tasks: transform (incl. the wait
     // for the records), 2 masks, 3 pair phase, 4 four-cell tasks: segs + transform, 5 masks, 6 pair phase; 8 / 9 task counts
@@ -975,7 +1039,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     // (A workgroup that moved on to the scan with the most tasks left once its own queues were empty -- a scan's work differs by up
     // to 1.5 x inside a block -- balanced the wavefronts' end times to 90 % of the span and changed nothing: the kernel is bound by
     // instruction issue, not by its tail; it cost 15 registers.  Measured and removed.)
-    const int scanIdx = (int)blockIdx.y;
     {
     const ScanDev &SC = scans[scanIdx];
     B4_CONST(v4f) sortedC = b4_const(reinterpret_cast<const v4f *>(SC.sorted));
@@ -1040,7 +1103,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     // The two queues in an order that depends on the wavefront: the first LF wavefronts of a workgroup start with the four-cell
     // tasks, the others with the one-cell tasks.  Blocks of 16 scans: LF = 0 (measured 0 / 2 / 4 / 6 / 8: 82.8 / 84.6 / 86.7 / 85.1 /
     // 87.2 us per scan); blocks of 4, where a scan's queues are spread over 64 workgroups: 191 / 192 / 186 / 184 / 177 -> LF = 8.
-    const bool lightFirst = wv < ((dbg >> 24) & 31);
+    const bool lightFirst = __builtin_amdgcn_readfirstlane(wv) < ((dbg >> 24) & 31);   // (wave-uniform: stated, it lives in a scalar register)
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
     const bool doLight = (ph == 0) == lightFirst;
@@ -1074,6 +1137,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         while (t < nH) {
             const unsigned start = c0.x, end = c0.y;
             const int nch = (int)((end - start + 63) >> 6);
+            // the task's first two candidates: requested before the transform and the mask rounds, used after them
+            const v8f q0 = *(B4_CONST(v8f))(sortedC + c0.z);
             v2f hx[B4_CPT / 2], hy[B4_CPT / 2], hz[B4_CPT / 2];   // chunk 2p in .x, chunk 2p+1 in .y
             unsigned sLo[B4_CPT], sHi[B4_CPT];
             int tv[B4_CPT];
@@ -1083,6 +1148,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 xform(R[u], start + u * 64 + lane < end, &ax, &ay, &az, &tv[u]);
                 if (u & 1) hx[u / 2].y = ax, hy[u / 2].y = ay, hz[u / 2].y = az;
                 else hx[u / 2].x = ax, hy[u / 2].x = ay, hz[u / 2].x = az;
+                // (poses from memory: 13 registers per chunk in flight -- two chunks at a time keep the variant free of scratch)
+                if (!LPOSE && u == 1) __builtin_amdgcn_sched_barrier(0);
             }
             if (PROF) {   // (the transform's results exist: the wait for the records ends here)
                 asm volatile("" ::"v"(hx[0].x), "v"(hx[1].y));
@@ -1100,7 +1167,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < B4_CPT; ++u)
-                if (tv[u] >= 0) atomicOr(&smask[u * T + tv[u]], 1ULL << lane);
+                if (tv[u] >= 0) atomicOr(reinterpret_cast<unsigned *>(&smask[u * T + tv[u]]) + (lane >> 5), 1u << (lane & 31));   // (32-bit: the word of the lane's half)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1124,10 +1191,14 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             if (tnn < nH) f0 = tasks[2 * posH(tnn)], f1 = tasks[2 * posH(tnn) + 1];
             if (!(dbg & 1)) {
                 static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
-                if (nch == 4) b4_pairs_rows<2, false>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
-                else if (nch == 2) b4_pairs_rows<1, false>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
-                else if (nch == 3) b4_pairs_rows<1, true>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
-                else b4_pairs_rows<0, true>(sortedC, counts, aR, nR, hx, hy, hz, sLo, sHi, r2lo, r2hi, r2, lq, T);
+                const unsigned laneBytes = 4u * (unsigned)lq;
+                // (the masks' LDS reads and the first candidates' scalar load are waited for HERE: left to the compiler, the wait sits inside
+                // the pair loop -- the counter is shared with the loop's own prefetch, which it would then wait for in the same trip)
+                asm volatile("" ::"v"(sLo[0]), "v"(sLo[1]), "v"(sLo[2]), "v"(sLo[3]), "v"(sHi[0]), "v"(sHi[1]), "v"(sHi[2]), "v"(sHi[3]), "s"(q0[0]));
+                if (nch == 4) b4_pairs_rows<2, false>(sortedC, counts, q0, aR, nR, hx, hy, hz, sLo, sHi, r2f, epsf, r2, laneBytes);
+                else if (nch == 2) b4_pairs_rows<1, false>(sortedC, counts, q0, aR, nR, hx, hy, hz, sLo, sHi, r2f, epsf, r2, laneBytes);
+                else if (nch == 3) b4_pairs_rows<1, true>(sortedC, counts, q0, aR, nR, hx, hy, hz, sLo, sHi, r2f, epsf, r2, laneBytes);
+                else b4_pairs_rows<0, true>(sortedC, counts, q0, aR, nR, hx, hy, hz, sLo, sHi, r2f, epsf, r2, laneBytes);
             }
             B4_TICK(3)
             t = tn, tn = tnn;
@@ -1170,7 +1241,10 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             unsigned sLo[B4_CPT], sHi[B4_CPT];
             int tv[B4_CPT];
 #pragma unroll
-            for (int u = 0; u < B4_CPT; ++u) xform(R[u], (unsigned)lane < nn[u], &hx[u], &hy[u], &hz[u], &tv[u]);
+            for (int u = 0; u < B4_CPT; ++u) {
+                xform(R[u], (unsigned)lane < nn[u], &hx[u], &hy[u], &hz[u], &tv[u]);
+                if (!LPOSE && u == 1) __builtin_amdgcn_sched_barrier(0);
+            }
             if (PROF) {
                 asm volatile("" ::"v"(hx[0]), "v"(hx[3]));
                 ++pacc[9];
@@ -1184,7 +1258,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < B4_CPT; ++u)
-                if (tv[u] >= 0) atomicOr(&smask[u * T + tv[u]], 1ULL << lane);
+                if (tv[u] >= 0) atomicOr(reinterpret_cast<unsigned *>(&smask[u * T + tv[u]]) + (lane >> 5), 1u << (lane & 31));   // (32-bit: the word of the lane's half)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1219,7 +1293,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     if (PROF && lane == 0) {
         for (int kk = 0; kk < 10; ++kk) atomicAdd(&prof[kk], pacc[kk]);
         // (recA is free once the store is sorted: absolute start / end of every wavefront, for the tail statistics)
-        unsigned long long *wt = reinterpret_cast<unsigned long long *>(B.recA) + 2 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * B4_JW + wv);
+        unsigned long long *wt = reinterpret_cast<unsigned long long *>(B.recA) + 2 * ((size_t)blockIdx.x * B4_JW + wv);
         wt[0] = pstart, wt[1] = wall_clock64();
     }
 #undef B4_TICK
@@ -1345,6 +1419,7 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
     const size_t oCellOff = take((size_t)BT * 65 * 4), oSegRange = take(maxSegs * 8);
     const size_t oBaseSum = take((size_t)((BT + 1023) / 1024) * 8), oNeed = take((size_t)BT * 4), oNeedCand = take((size_t)BT * 4);
     const size_t oRecA = take((size_t)std::max<long long>(ntot, 1) * 16), oRecB = take((size_t)std::max<long long>(ntot, 1) * 16);
+    const size_t oDeal = take((size_t)(65 + 4 * ctx->num_cus + 64) * 4);   // b4_deal's tables
     const size_t oCtrl = take(256);   // the block's cursors and crop ...
     const size_t oNeedMask = take((size_t)BT * 8);   // ... and, directly behind them, the tiles' scan masks: one memset clears both
     const size_t oCellCount = take((size_t)G * (NCpad + 4) * 4);   // contiguous over the scans: one memset
@@ -1460,6 +1535,7 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
     B.needList = reinterpret_cast<unsigned *>(base + oNeed);
     B.needCand = reinterpret_cast<unsigned *>(base + oNeedCand);
     B.needMask = reinterpret_cast<unsigned long long *>(base + oNeedMask);
+    B.deal = reinterpret_cast<unsigned *>(base + oDeal);
     B.recA = reinterpret_cast<float4 *>(base + oRecA);
     B.recB = reinterpret_cast<float4 *>(base + oRecB);
     B.U = U, B.NG = NG, B.nchunks = (int)nch, B.maxSegs = (int)maxSegs;
@@ -1501,8 +1577,10 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
         b4_live_scatter<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(B, dsc);
         b4_plan<<<dim3(std::max(8u, (unsigned)(8 * ctx->num_cus) / (unsigned)G), (unsigned)G), 256, 0, stream>>>(B, dsc);
         const char *jw_env = getenv("MODEST_PP4_JWG");
-        unsigned jx = (unsigned)((jw_env ? atoi(jw_env) : 1) * ctx->num_cus) / (unsigned)G;   // one workgroup of 16 wavefronts per CU
+        unsigned jx = (unsigned)((jw_env ? std::min(atoi(jw_env), 4) : 1) * ctx->num_cus) / (unsigned)G;   // one workgroup of 16 wavefronts per CU
         if (jx < 2) jx = 2;
+        const unsigned NW = jx * (unsigned)G;   // (<= 4 * num_cus + 64: the deal table's size)
+        b4_deal<<<1, 64, 0, stream>>>(B, dsc, NW);
         const char *dbg_env = getenv("MODEST_PP4_DBG");   // ablations: 1 no pair phase, 2 no four-cell tasks, 8 no one-cell tasks, 256 poses from memory, 512 phase times
         const char *tk_env = getenv("MODEST_PP4_TK");
         const char *lf_env = getenv("MODEST_PP4_LF");   // wavefronts of a join workgroup that start with the four-cell tasks
@@ -1513,7 +1591,7 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
         if ((dbg & 512) && lpose) {   // MODEST_PP4_DBG=512: wall time of the join's wavefronts by phase (blocking; diagnostics only)
             unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[10];
             MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));
-            b4_join<true, true><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, dprof);
+            b4_join<true, true><<<NW, B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, dprof);
             MODEST_HIP_CHECK(hipStreamSynchronize(stream));
             MODEST_HIP_CHECK(hipMemcpy(hprof, dprof, sizeof(hprof), hipMemcpyDeviceToHost));
             {   // when do the wavefronts end?  (share of the kernel's span a wavefront is present, per scan and overall)
@@ -1530,15 +1608,6 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
                     std::sort(en.begin(), en.end());
                     fprintf(stderr, "[b4_join] span %.1f us; wavefront end: mean %.1f, p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f us; mean start %.1f us\n",
                             (double)(t1 - t0) * us, sum / nw * us, en[nw / 10] * us, en[nw / 2] * us, en[nw * 9 / 10] * us, en[nw * 99 / 100] * us, sumStart / nw * us);
-                    for (int s = 0; s < G; ++s) {   // per scan: the last wavefront and the mean
-                        double mx = 0, mean = 0;
-                        const size_t per = (size_t)jx * B4_JW;
-                        for (size_t i = 0; i < per; ++i) {
-                            const double e = (double)(wt[2 * ((size_t)s * per + i) + 1] - t0);
-                            mx = std::max(mx, e), mean += e;
-                        }
-                        fprintf(stderr, "[b4_join]   scan %d: wavefronts end at mean %.1f, max %.1f us\n", s, mean / per * us, mx * us);
-                    }
                 }
             }
             const double wv = (double)jx * G * B4_JW, us = 1.0 / 100.0;   // s_memtime ticks at 100 MHz
@@ -1546,8 +1615,8 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
                             "four-cell tasks: records + transform %.1f, masks %.1f, pairs %.1f || per scan: one-cell tasks %.0f, four-cell tasks %.0f\n",
                     hprof[0] * us / wv, hprof[1] * us / wv, hprof[2] * us / wv, hprof[3] * us / wv, hprof[4] * us / wv, hprof[5] * us / wv,
                     hprof[6] * us / wv, (double)hprof[8] / G, (double)hprof[9] / G);
-        } else if (lpose) b4_join<true, false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
-        else b4_join<false, false><<<dim3(jx, (unsigned)G), B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
+        } else if (lpose) b4_join<true, false><<<NW, B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
+        else b4_join<false, false><<<NW, B4_JT, ldsB, stream>>>(B, dsc, radius * radius, dbg, nullptr);
     } else {   // no history: every count is zero
         for (int sc = 0; sc < G; ++sc)
             if (scans[sc].n > 0) MODEST_HIP_CHECK(hipMemsetAsync(hsc[sc].counts, 0, (size_t)scans[sc].n * Ts[sc] * 4, stream));

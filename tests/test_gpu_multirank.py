@@ -153,7 +153,7 @@ def test_bench_two_ranks_two_helpers_one_gpu(gpu):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     cfg = d["config"]
-    assert d["n_gpus"] == 2 and cfg["rccl_world_size"] == 2 and cfg["rccl_ranks_seen"] == 2 and cfg["process_group_backend"] == "gloo"
+    assert d["n_gpus"] == 2 and cfg["world_size"] == 2 and cfg["ranks_seen"] == 2 and cfg["process_group_backend"] == "gloo" and cfg["rccl_world_size"] is None
     assert d["scaling"] == "weak" and d["steps"] == 8 and d["value"] > 0
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]   # whole job: both ranks' scans over the slower rank's clock
     assert cfg["host_processes_per_gpu"] == 2 and len(cfg["startup"]["helper_seconds"]) == 2
@@ -162,3 +162,68 @@ def test_bench_two_ranks_two_helpers_one_gpu(gpu):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu.json"), "w") as f:
         json.dump(dict(wall_seconds=wall, line=d), f, indent=1)
+
+
+def test_three_clis_eight_ranks_one_gpu(gpu, tmp_path):
+    """BASELINE config 4's launch shape without the node: WORLD_SIZE = 8, every rank on GPU 0 (gloo: a barrier and
+    a counter all-reduce are the only collectives of the path), a 64-scan tree.  The union of the eight ranks' files == the reference's
+    eight manual `total_part=8 part=i` runs (pre_compute_pp_score.py:114-116, generate_mask.py:35-37, gen_label_files.py:36-38) == one
+    process, byte for byte, for all three CLIs."""
+    from modest_amd import synth
+    n = 64
+    root, meta = str(tmp_path / "data"), str(tmp_path / "meta")
+    paths = synth.write_kitti_tree(root, meta, n_seq=3, n_frames=n + 6, n_pts=3000, origins=tuple(range(n)), hist_frames=6, max_range=60.0)
+    train = os.path.join(root, "training")
+    outs = {k: str(tmp_path / k) for k in ("one", "eight", "parts")}
+    report = {}
+    for m in CLIS:
+        _run(m, _overrides(train, paths, outs["one"]), 1, 0)
+    for i, m in enumerate(CLIS):
+        err = _run(m, _overrides(train, paths, outs["eight"]), 8, 29561 + i)
+        mm = re.search(r"ranks: scans (\d+)\.\.(\d+), busy ([\d.]+)\.\.([\d.]+) s \(imbalance ([\d.]+) %\)", err)
+        assert mm, err[-1500:]
+        assert int(mm.group(1)) == n // 8 and int(mm.group(2)) == n // 8
+        report[m] = dict(rank_scans_min_max=[int(mm.group(1)), int(mm.group(2))], busy_seconds_min_max=[float(mm.group(3)), float(mm.group(4))])
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for m in CLIS:   # the reference's manual split: eight independent processes per CLI (a stage needs the previous stage's files)
+        procs = [subprocess.Popen([sys.executable, "-m", f"modest_amd.{m}"] + _overrides(train, paths, outs["parts"]) + ["total_part=8", f"part={part}"],
+                                  env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True) for part in range(8)]
+        for pr in procs:
+            _, e = pr.communicate(timeout=900)
+            assert pr.returncode == 0, (m, e[-2000:])
+    for k in ("eight", "parts"):
+        for sub in ("pp", "seg", "bbox", "labels"):
+            fa = sorted(f for f in os.listdir(os.path.join(outs["one"], sub)) if f != "configs.yaml")
+            fb = sorted(f for f in os.listdir(os.path.join(outs[k], sub)) if f != "configs.yaml")
+            assert fa == fb and len(fa) == n, (k, sub, len(fa), len(fb))
+            match, mismatch, err = filecmp.cmpfiles(os.path.join(outs["one"], sub), os.path.join(outs[k], sub), fa, shallow=False)
+            assert not mismatch and not err, (k, sub, mismatch[:5], err[:5])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "multirank8_report.json"), "w") as f:
+        json.dump(dict(scans=n, world_size=8, note="eight ranks on GPU 0, gloo collectives", per_cli=report), f, indent=1)
+
+
+def test_bench_eight_ranks_one_gpu(gpu):
+    """bench.py's N = 8 launch path (`--gpus 8 --procs 1`: what the driver's SCALE run starts, one process per rank) on one GPU under
+    gloo: ONE JSON line from rank 0, eight ranks counted by the all-reduce, whole-job throughput = 8 ranks' scans over the slowest rank's
+    clock, and every rank's host cost (busy threads, resident memory) in the line -- DESIGN section 6 multiplies it out."""
+    env = dict(os.environ, MODEST_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--procs", "1", "--steps", "8", "--warmup", "2", "--scans", "8",
+           "--shard-scans", "8", "--n-live", "3000", "--frames", "4", "--traversals", "3", "--cli-scans", "0", "--cpu-scans", "0", "--sharing", "best"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 8 and cfg["world_size"] == 8 and cfg["ranks_seen"] == 8 and cfg["process_group_backend"] == "gloo"
+    assert abs(d["value"] - 8 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
+    hb = cfg["host_budget_per_rank"]
+    assert len(hb) == 8 and sorted(h["rank"] for h in hb) == list(range(8))
+    assert all(h["rss_mb"] > 100 and h["busy_threads"] >= 0 for h in hb)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_eight_ranks_one_gpu.json"), "w") as f:
+        json.dump(d, f, indent=1)
