@@ -1139,6 +1139,10 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             const int nch = (int)((end - start + 63) >> 6);
             // the task's first two candidates: requested before the transform and the mask rounds, used after them
             const v8f q0 = *(B4_CONST(v8f))(sortedC + c0.z);
+            // ... and the descriptor of the task after next
+            const unsigned tnn = next_task();
+            v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+            if (tnn < nH) f0 = tasks[2 * posH(tnn)], f1 = tasks[2 * posH(tnn) + 1];
             v2f hx[B4_CPT / 2], hy[B4_CPT / 2], hz[B4_CPT / 2];   // chunk 2p in .x, chunk 2p+1 in .y
             unsigned sLo[B4_CPT], sHi[B4_CPT];
             int tv[B4_CPT];
@@ -1186,9 +1190,6 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
 #pragma unroll
                 for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(s2 + u * 64 + lane, e2 - 1)]);
             }
-            const unsigned tnn = next_task();
-            v4u f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-            if (tnn < nH) f0 = tasks[2 * posH(tnn)], f1 = tasks[2 * posH(tnn) + 1];
             if (!(dbg & 1)) {
                 static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
                 const unsigned laneBytes = 4u * (unsigned)lq;
@@ -1250,9 +1251,11 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 ++pacc[9];
             }
             B4_TICK(4)
-            if (lq < T) {
+            int lq4 = lane;
+            asm volatile("" : "+v"(lq4));   // (an opaque lane id: the mask words' addresses are formed here, per task, instead of living in registers across the whole kernel)
+            if (lq4 < T) {
 #pragma unroll
-                for (int u = 0; u < B4_CPT; ++u) smask[u * T + lq] = 0ULL;
+                for (int u = 0; u < B4_CPT; ++u) smask[u * T + lq4] = 0ULL;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1263,7 +1266,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < B4_CPT; ++u) {
-                const unsigned long long mv = lq < T ? smask[u * T + lq] : 0ULL;
+                const unsigned long long mv = lq4 < T ? smask[u * T + lq4] : 0ULL;
                 sLo[u] = (unsigned)mv;
                 sHi[u] = (unsigned)(mv >> 32);
             }
