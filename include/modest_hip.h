@@ -145,7 +145,10 @@ int modest_frame_sort(modest_ctx *ctx, const modest_frame_sort_job *jobs_host, i
 /* The same sort, NOT blocking (an ingest thread keeps several batches in flight behind the compute stream's
  * kernels).  jobs_scratch_dev [dev]: n_jobs * MODEST_FRAME_SORT_JOB_BYTES, caller-owned, alive until the
  * launch has run; n_inside_pinned [PINNED host] (n_jobs) int32: written by the kernel itself, readable once
- * `stream` has passed the launch.                                                                     */
+ * `stream` has passed the launch.  The grid sort of small batches also keeps per-point rank / bin words and its chunk
+ * table in the CONTEXT's scratch arena, in stream order (and grows the arena on first use: a device synchronise): `ctx`
+ * must not be shared with calls that run on another stream at the same time -- an ingest thread owns a context of its own
+ * (pre_compute_pp_score.py: FrameLoader).                                                                           */
 #define MODEST_FRAME_SORT_JOB_BYTES 128
 int modest_frame_sort_async(modest_ctx *ctx, const modest_frame_sort_job *jobs_host, int n_jobs,
                             void *jobs_scratch_dev, int32_t *n_inside_pinned_host, void *stream);

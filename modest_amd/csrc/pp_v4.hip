@@ -63,7 +63,9 @@ constexpr unsigned B4_HEAVY = 64;          // cells with at least this many reco
 #define B4_CPT_ 4
 #endif
 constexpr int B4_CPT = B4_CPT_;                  // 64-record chunks per task
-constexpr unsigned B4_TASK = 64 * B4_CPT;  // 512 records
+constexpr unsigned B4_TASK = 64 * B4_CPT;  // 256 records
+// the task lists' capacities in pp_block_impl (ntot / 64 + 16 one-cell tasks, the four-cell bound) are derived for these values
+static_assert(B4_HEAVY == 64 && B4_CPT == 4, "maxTasks / maxLight in pp_block_impl assume cells of >= 64 records in tasks of 4 chunks");
 #ifndef B4_WPE_
 #define B4_WPE_ 4
 #endif
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(1024) void b4_scan_finish(Blk B, const ScanDev *__r
         S.cellStart[(size_t)nBlk * B4_SCAN] = 0u;
         S.ctrl[0] = 0u, S.ctrl[1] = 0u, S.ctrl[40] = 0u, S.ctrl[41] = 0u;   // b4_plan's cursors (from the front / from the back of the lists)
         S.ctrl[32] = 0u, S.ctrl[48] = 0u;   // b4_join's tickets (one-cell / four-cell tasks)
+        S.ctrl[42] = 0u;                    // b4_plan's overflow word
     }
 }
 // start of cell `c` in the scan's cell-sorted live points
@@ -701,6 +704,9 @@ __global__ __launch_bounds__(256) void b4_plan(Blk B, const ScanDev *__restrict_
         if (down) tb = (unsigned)S.maxTasks - tb - TH, lb = (unsigned)S.maxLight - lb - nL;
     }
     tb = __shfl(tb, 0), lb = __shfl(lb, 0);
+    // (the capacities are upper bounds of the lists' lengths; a position beyond them would mean a dropped task and silently wrong counts:
+    // it raises the scan's overflow word, which the host can read back -- MODEST_PP4_CHECK=1 -- and the tests do)
+    if (lane == 0 && (tb + TH > (unsigned)S.maxTasks || lb + nL > (unsigned)S.maxLight || (int)tb < 0 || (int)lb < 0)) atomicOr(&S.ctrl[42], 1u);
     {
         unsigned *head = reinterpret_cast<unsigned *>(S.ltHead);
         if (isL) {
@@ -745,6 +751,7 @@ __global__ __launch_bounds__(64) void b4_deal(Blk B, const ScanDev *__restrict__
         const ScanDev &S = scans[lane];
         const unsigned nHu = min(S.ctrl[0], (unsigned)S.maxTasks), nLu = min(S.ctrl[1], (unsigned)S.maxLight);
         const unsigned nH = nHu + min(S.ctrl[40], (unsigned)S.maxTasks - nHu), nL = nLu + min(S.ctrl[41], (unsigned)S.maxLight - nLu);
+        if (S.ctrl[0] + S.ctrl[40] > (unsigned)S.maxTasks || S.ctrl[1] + S.ctrl[41] > (unsigned)S.maxLight) atomicOr(&S.ctrl[42], 2u);   // (the lists' two ends met)
         w = (unsigned long long)nH * B4_DEAL_WH + (unsigned long long)nL * B4_DEAL_WL + 1ULL;
     }
     unsigned long long cum = w;
@@ -1626,6 +1633,14 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
     }
     modest_prof_mark(ctx, stream, 1);
     b4_entropy<<<dim3(gN, (unsigned)G), 256, 0, stream>>>(dsc);
+    if (const char *chk = getenv("MODEST_PP4_CHECK"); chk && atoi(chk) && U > 0 && ntot > 0) {   // (blocking; tests: no task list overflowed)
+        MODEST_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int sc = 0; sc < G; ++sc) {
+            unsigned ov = 0;
+            MODEST_HIP_CHECK(hipMemcpy(&ov, reinterpret_cast<unsigned *>(base + so[(size_t)sc].ctrl) + 42, 4, hipMemcpyDeviceToHost));
+            MODEST_REQUIRE(ov == 0u, "b4_plan: a task list overflowed its capacity");
+        }
+    }
     MODEST_HIP_CHECK(hipGetLastError());
     return MODEST_OK;
 }

@@ -124,7 +124,7 @@ class FrameLoader:
         assert all(sz % 16 == 0 for sz in sizes), "velodyne .bin files hold (n,4) float32 rows"
         offs = np.cumsum([0] + [sz // 16 for sz in sizes])
         need = int(offs[-1])
-        if need > self.cap:
+        if self.pinned_all is None or need > self.cap:   # (no staging yet: the size probe failed and every file so far was empty)
             self._make_staging(max(need + need // 8, 1 << 16))
         r = self.turn = (self.turn + 1) % self.slots
         if self.slot_ev[r] is not None:
@@ -619,6 +619,8 @@ def main(args):
             if int(os.environ.get("MODEST_PP_TRACE_FROM", "150")) <= int(k) < int(os.environ.get("MODEST_PP_TRACE_FROM", "150")) + 4:
                 eprint("[pp_score trace2] %-8s scan %s at %.3f ms" % (tag, k, 1e3 * (t - base)))
     torch.cuda.synchronize()
+    if os.environ.get("MODEST_PP_TRACE_PATHS"):   # (tests: which neighbour-count path the batches took)
+        eprint("[pp_score] pp paths: block calls %d, chain calls %d" % (getattr(store, "block_calls", 0), getattr(store, "chain_calls", 0)))
     tot = dist.rank_report("pp_score", done, t0, rank, ws, dict(hist_points=pts))
     if rank == 0:
         eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame store %d hits / %d misses; "

@@ -457,11 +457,13 @@ CALIB_TXT = (
 
 def write_kitti_tree(root: str, meta: str, n_seq: int = 3, n_frames: int = 12, n_pts: int = 8000,
                      nusc: bool = False, world_seed: int = 0, origins: Tuple[int, ...] = (2,),
-                     hist_frames: int = 8, max_range: float = 60.0) -> Dict[str, str]:
+                     hist_frames: int = 8, max_range: float = 60.0, presence=None) -> Dict[str, str]:
     """Tiny KITTI-format tree + MODEST meta data (track list, valid idx info,
     idx list) for CLI tests: sequence 0 holds the live scans (with mobile
     objects), sequences 1.. are the historical traversals.
-    File formats: data_preprocessing/lyft/lyft2kitti.py:258-272,365-393."""
+    File formats: data_preprocessing/lyft/lyft2kitti.py:258-272,365-393.
+    presence: per history sequence (index s - 1) the range [k0, k1) of POSITIONS in `origins` whose scans have it as a traversal
+    (presence_ramp; the reference accepts a traversal per scan, split_traintest.py:17,79): T then changes along the idx list."""
     train = os.path.join(root, "training")
     for d in ("velodyne", "oxts", "l2e", "calib"):
         os.makedirs(os.path.join(train, d), exist_ok=True)
@@ -492,8 +494,10 @@ def write_kitti_tree(root: str, meta: str, n_seq: int = 3, n_frames: int = 12, n
             idx += 1
         track.append(seq)
     valid = {}
-    for o in origins:
-        hist = [(s, list(range(o, min(o + hist_frames, n_frames)))) for s in range(1, n_seq)]
+    for k, o in enumerate(origins):
+        hist = [(s, list(range(o, min(o + hist_frames, n_frames)))) for s in range(1, n_seq)
+                if presence is None or presence[s - 1][0] <= k < presence[s - 1][1]]
+        assert len(hist) >= 2, "a scan needs two traversals (pre_compute_pp_score.py:125-126)"
         valid[track[0][o]] = (0, o, hist)
     paths = {
         "track_path": os.path.join(meta, "track_list.pkl"),

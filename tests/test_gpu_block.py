@@ -1,6 +1,9 @@
 """Block path of the PP neighbour count (modest_pp_score_block, csrc/pp_v4.hip): consecutive scans of a shard in ONE
 call -- the union of their frames binned once on the world lattice -- against the oracle (scipy cKDTree on the stacked,
 transformed history: pre_compute_pp_score.py:132-150,188-193) and against the per-scan chain, bit for bit."""
+import os
+
+os.environ.setdefault("MODEST_PP4_CHECK", "1")   # modest_pp_score_block reads back b4_plan's overflow words (blocking): no task list may overflow
 import numpy as np
 import pytest
 

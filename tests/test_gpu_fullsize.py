@@ -8,6 +8,9 @@ import os
 import tempfile
 import types
 
+import os
+
+os.environ.setdefault("MODEST_PP4_CHECK", "1")   # modest_pp_score_block reads back b4_plan's overflow words (blocking): no task list may overflow
 import numpy as np
 import pytest
 

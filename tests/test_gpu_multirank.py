@@ -227,3 +227,33 @@ def test_bench_eight_ranks_one_gpu(gpu):
     assert all(h["rss_mb"] > 100 and h["busy_threads"] >= 0 for h in hb)
     with open(os.path.join(ROOT, "gpurun_out", "bench_eight_ranks_one_gpu.json"), "w") as f:
         json.dump(d, f, indent=1)
+
+
+def test_pp_cli_on_a_tree_whose_traversal_count_changes(gpu, tmp_path):
+    """The reference accepts a traversal PER SCAN (data_preprocessing/lyft/split_traintest.py:17,79; two needed, :111): the number of
+    traversals changes along an idx list.  The PP CLI takes such scans in blocks as they come (pp_batch=32: modest_pp_score_block_mixed,
+    no flush where T changes): its score files == the per-scan path's (pp_batch=1) byte for byte, and == the oracle's entropy
+    (pre_compute_pp_score.py:68-75: ln T of the scan's own T) on scans with different T."""
+    import pickle
+    import numpy as np
+    from modest_amd import synth
+    from oracle import pp_score as opp
+    n = 48
+    pres = synth.presence_ramp(n, 7, seed=4)
+    root, meta = str(tmp_path / "data"), str(tmp_path / "meta")
+    paths = synth.write_kitti_tree(root, meta, n_seq=8, n_frames=n + 16, n_pts=3000, origins=tuple(range(n)), hist_frames=16,
+                                   max_range=60.0, presence=pres)
+    valid = pickle.load(open(paths["idx_info"], "rb"))
+    Ts = [len(valid[k][2]) for k in sorted(valid)]
+    assert len(set(Ts)) >= 3, Ts
+    train = os.path.join(root, "training")
+    blk, one = str(tmp_path / "blk"), str(tmp_path / "one")
+    err = _run(CLIS[0], _overrides(train, paths, blk) + ["pp_batch=32"], 1, 0, extra_env={"MODEST_PP_TRACE_PATHS": "1"})
+    _run(CLIS[0], _overrides(train, paths, one) + ["pp_batch=1"], 1, 0)
+    fa = sorted(os.listdir(os.path.join(blk, "pp")))
+    assert fa == sorted(os.listdir(os.path.join(one, "pp"))) and len(fa) == n
+    match, mismatch, e2 = filecmp.cmpfiles(os.path.join(blk, "pp"), os.path.join(one, "pp"), fa, shallow=False)
+    assert not mismatch and not e2, mismatch[:5]
+    mm = re.search(r"pp paths: block calls (\d+), chain calls (\d+)", err)
+    assert mm and int(mm.group(1)) >= 1, err[-1500:]   # the block path did run (first batch of 4, then the rest)
+    assert int(mm.group(1)) <= 3, err[-1500:]          # ... in whole batches: no flush where T changes

@@ -15,10 +15,10 @@ rec_bytes = d["b4_seg_scatter"]["WRITE_SIZE"] * 1024            # = 16 B x recor
 f_fac = rec_bytes / (d["b4_seg_hist"]["FETCH_SIZE"] * 1024)
 fetch = sum(v.get("FETCH_SIZE", 0.0) * 1024 for v in d.values()) * f_fac
 write = sum(v.get("WRITE_SIZE", 0.0) * 1024 for v in d.values())
-alg = 12.0 * N_LIVE * T * F + 16.0 * N_LIVE
+alg = float(os.environ["PP_ALG_BYTES"]) if os.environ.get("PP_ALG_BYTES") else 12.0 * N_LIVE * T * F + 16.0 * N_LIVE   # (other shapes: the probe's own figure)
 out = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python tools/pp_block_probe.py --scans %d; "
-              "tools/pp4_pmc.sh + tools/pp4_traffic.py" % G,
+              "tools/pp4_pmc.sh + tools/pp4_traffic.py" % G + ((" " + os.environ["PROBE_ARGS"]) if os.environ.get("PROBE_ARGS") else ""),
     "block_path": True, "scans_per_launch": G,
     "records_in_block_store": rec_bytes / 16.0,
     "fetch_calibration": {"kernel": "b4_seg_hist reads the block store once (16 B x records, coalesced); records from b4_seg_scatter's WRITE_SIZE",

@@ -25,7 +25,7 @@ def load_shard(store, sh, dev, key0=0):
         items.append((k, torch.from_numpy(sc.live_raw).to(dev), sc.live_W))
         lives.append(k)
     store.insert_many(items)
-    descs = [store.describe(lives[i], sc.live_rel, [nf[h] for h in sc.hist], [t for t, _ in sc.hist], sc.rels, sh.nusc)
+    descs = [store.describe(lives[i], sc.live_rel, [nf[h] for h in sc.hist], sc.trav_list(), sc.rels, sh.nusc)
              for i, sc in enumerate(sh.scans)]
     return lives, descs
 
@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--json-out", type=str, default="", help="append one JSON line with the run's numbers to this file")
     ap.add_argument("--matched", type=str, default="", help="live_speed,hist_lo,hist_hi: windows chosen by the reference's rule "
                     "(synth.make_shard_matched, split_traintest.py:79-101) instead of frames i..i+F-1")
+    ap.add_argument("--presence", type=int, default=-1, help="seed: --trav + 3 tracks that enter and leave along the shard (synth.presence_ramp: the "
+                    "reference accepts a traversal per scan, split_traintest.py:17,79) -- T changes inside the block, as in bench.py's realistic shard")
     a = ap.parse_args()
     _lib.load()
     dev = torch.device("cuda:0")
@@ -56,8 +58,9 @@ def main():
         t0 = time.time()
         if a.matched:
             ls, h0, h1 = (float(x) for x in a.matched.split(","))
-            sh = synth.make_shard_matched(a.scans, n_live=a.n, n_trav=a.trav, nusc=a.nusc, live_speed=ls, hist_speeds=(h0, h1),
-                                          seed=q, x0=40.0 * q)
+            pres = synth.presence_ramp(a.scans, a.trav + 3, t_min=max(2, a.trav - 3), seed=a.presence) if a.presence >= 0 else None
+            sh = synth.make_shard_matched(a.scans, n_live=a.n, n_trav=a.trav + (3 if pres else 0), nusc=a.nusc, live_speed=ls, hist_speeds=(h0, h1),
+                                          seed=q, x0=40.0 * q, presence=pres)
             print("sharing:", {k: round(v, 2) for k, v in synth.sharing_stats(sh, a.scans).items()}, flush=True)
         else:
             sh = synth.make_shard(a.scans, n_live=a.n, n_trav=a.trav, n_frames=a.frames, nusc=a.nusc, seed=q, x0=40.0 * q)
@@ -65,9 +68,10 @@ def main():
         shards.append(sh)
         tabs.append((lives, descs))
         print(f"shard {q}: generated + loaded in {time.time() - t0:.1f} s", flush=True)
-    T = a.trav
     ok = True
+    Ts = [[sc.n_trav for sc in sh.scans] for sh in shards]   # (per scan: the scan's own number of traversals)
     for q, (lives, descs) in enumerate(tabs):
+        T = Ts[q]
         Hb, cb = store.pp_score_batch(lives, descs, T, return_counts=True, ctx=ctx, block=True)
         Hv, cv = store.pp_score_batch(lives, descs, T, return_counts=True, ctx=ctx, block=False)
         torch.cuda.synchronize()
@@ -89,7 +93,7 @@ def main():
                 ok &= e
     print("PARITY", "OK" if ok else "FAILED", "block calls", getattr(store, "block_calls", 0), flush=True)
     side = torch.cuda.Stream(device=dev) if a.stream else torch.cuda.current_stream(dev)
-    report = dict(scans=a.scans, n_live=a.n, traversals=a.trav, nusc=bool(a.nusc), matched=a.matched or None, parity_ok=bool(ok),
+    report = dict(scans=a.scans, n_live=a.n, traversals=a.trav, traversals_per_scan=Ts[0], nusc=bool(a.nusc), matched=a.matched or None, parity_ok=bool(ok),
                   sharing=(synth.sharing_stats(shards[0], a.scans) if a.matched else
                            dict(members_per_scan=a.trav * a.frames, union_over_members=(a.frames + a.scans - 1) / a.frames)))
     for mode in ((True, False, None) if a.auto else (True, False)):
@@ -97,7 +101,7 @@ def main():
         ctx.profile_begin(8 * a.reps * a.shards + 4)
         with torch.cuda.stream(side):
             for r in range(a.reps):
-                for lives, descs in tabs:
+                for (lives, descs), T in zip(tabs, Ts):
                     store.pp_score_batch(lives, descs, T, ctx=ctx, block=mode)
         torch.cuda.synchronize()
         ms = np.asarray(ctx.profile_collect(8 * a.reps * a.shards + 4))
@@ -120,9 +124,9 @@ def main():
         ctx.profile_begin(16 * a.reps * a.shards + 4)
         with torch.cuda.stream(side):
             for r in range(a.reps):
-                for lives, descs in tabs:
-                    store.pp_score_batch(lives[:h], descs[:h], T, ctx=ctx, block=True)
-                    store.pp_score_batch(lives[h:], descs[h:], T, ctx=ctx, block=True)
+                for (lives, descs), T in zip(tabs, Ts):
+                    store.pp_score_batch(lives[:h], descs[:h], T[:h], ctx=ctx, block=True)
+                    store.pp_score_batch(lives[h:], descs[h:], T[h:], ctx=ctx, block=True)
         torch.cuda.synchronize()
         ms = np.asarray(ctx.profile_collect(16 * a.reps * a.shards + 4))
         per = float(ms[2 * a.shards:].sum()) / ((a.reps - 1) * a.shards) / a.scans
