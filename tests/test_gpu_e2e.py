@@ -267,7 +267,14 @@ def test_bench_contract_json_line(gpu):
     assert d["unit"] == "scans/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and d["value"] > 0
     assert abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000.0
     assert "workload" in d["config"] and "model" not in d["config"]
-    rf = d["roofline"]
+    # `roofline`: the isolated PP measurement on reference-rule windows with traversals that enter and leave (what a real
+    # valid_idx_info.pkl holds); `roofline_best_case`: the same on the windows of frames i..i+F-1 the timed regions run on
+    rr = d["roofline"]
+    assert rr["bound"] == "hbm" and rr["unit"] == "GB/s" and rr["peak"] == 8000.0 and "kernel" in rr
+    assert rr["achieved"] > 0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-12
+    assert abs(rr["achieved"] - rr["algorithmic_bytes_per_launch"] / (rr["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rr["achieved"]
+    assert rr["sharing"]["distinct_traversal_counts"] >= 1 and "split_traintest.py" in rr["sharing"]["rule"]
+    rf = d["roofline_best_case"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["in_pipeline"]["scans_timed"] == 16 and rf["isolated"]["kernel_ms"] > 0
