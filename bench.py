@@ -754,6 +754,28 @@ def cli_bench(a, local):
         out["label_scans_per_s_workers"] = tot["scans"] / tot.get("max_worker_seconds", tot["max_seconds"])
         out["pipeline_scans_per_s_workers"] = 1.0 / (1.0 / out["pp_scans_per_s_workers"] + 1.0 / out["mask_scans_per_s_workers"]
                                                      + 1.0 / max(out["label_scans_per_s_workers"], out["label_scans_per_s"]))
+        # the fused CLI: the three stages per batch in one process (modest_amd/seed_labels.py), every file of the three CLIs written
+        from modest_amd import seed_labels
+
+        def fused(tag, workers):
+            tot = seed_labels.main(argv=[data, f"data_paths.track_path={paths['track_path']}", f"data_paths.idx_info={paths['idx_info']}", idx,
+                                         f"data_paths.pp_score_path={root}/fpp{tag}", f"data_paths.seg_save_dst={root}/fseg{tag}",
+                                         f"data_paths.bbox_info_save_dst={root}/fbbox{tag}", f"data_paths.label_file_save_dst={root}/flabels{tag}",
+                                         f"device={local}", f"workers={workers}"])
+            return tot["scans"] / tot.get("max_worker_seconds", tot["max_seconds"])
+
+        try:
+            out["fused_scans_per_s"] = fused("1", 1)
+            out["fused_scans_per_s_workers"] = fused("W", W)
+            same = True
+            for a_, b_ in (("labels", "flabels1"), ("labels", "flabelsW"), ("seg1", "fseg1"), ("seg1", "fsegW"), ("pp1", "fpp1"), ("pp1", "fppW"),
+                           ("bbox1", "fbbox1"), ("bbox1", "fbboxW")):
+                for f in os.listdir(f"{root}/{a_}"):
+                    if f != "configs.yaml" and open(f"{root}/{a_}/{f}", "rb").read() != open(f"{root}/{b_}/{f}", "rb").read():
+                        same = False
+            out["fused_outputs_identical"] = same
+        except Exception as e:   # noqa: BLE001
+            out["fused_error"] = repr(e)
         out["label_files_identical"] = all(open(f"{root}/labels/{f}").read() == open(f"{root}/labelsW/{f}").read()
                                            for f in os.listdir(f"{root}/labels") if f.endswith(".txt"))
         diff = [f for f in sorted(os.listdir(f"{root}/seg1")) if f.endswith(".npy") and
@@ -765,7 +787,9 @@ def cli_bench(a, local):
     out["note"] = (f"{n_scan} live scans x {T} traversals x {F} frames of {a.n_live} points, one GPU, tree on "
                    + (base or "the default tmp dir") + "; cold: the first scan of a process uploads and sorts all 361 "
                    "frames, later scans 11 new ones; *_workers: max over the workers' own loop clocks; "
-                   "pipeline_scans_per_s_workers takes the label stage in whichever mode is faster (it is 0.1 ms of work per scan)")
+                   "pipeline_scans_per_s_workers takes the label stage in whichever mode is faster (it is 0.1 ms of work per scan); "
+                   "fused_*: python -m modest_amd.seed_labels, the three stages per batch in one process (per worker), all four output trees "
+                   "compared with the separate CLIs' byte for byte")
     return out
 
 

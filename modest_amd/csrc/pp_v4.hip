@@ -103,6 +103,7 @@ struct Blk {   // block-wide device pointers and geometry (kernel argument)
     unsigned *deal;     // b4_deal: [0, G] first join workgroup of every scan (G: their number), then the scan of every join workgroup
     float4 *recA, *recB;
     int U, NG, nchunks, maxSegs;
+    int compact;        // b4_join packs the member records of a one-cell task (LDS: 4 KB per wavefront on top of the pose table and the masks)
     int BX0, BY0, BW, BH, BT, CW, CHc, NCpad, nScanBlk, G;
 };
 
@@ -1003,8 +1004,9 @@ constexpr int B4_JW = B4_JT / 64;   // wavefronts of a join workgroup: they shar
 __host__ __device__ __forceinline__ unsigned b4_pose_bytes(int U) {
     return (unsigned)(((U * 48 + 15) & ~15) + ((U + 15) & ~15));
 }
-__host__ __device__ __forceinline__ unsigned b4_join_lds(int U, int T, bool lpose) {
-    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8);
+constexpr unsigned B4_LDS_LIMIT = 160u * 1024u;   // per workgroup (one per CU)
+__host__ __device__ __forceinline__ unsigned b4_join_lds(int U, int T, bool lpose, bool compact = false) {
+    return (lpose ? b4_pose_bytes(U) : 0u) + (unsigned)B4_JW * (unsigned)(B4_CPT * T * 8) + (compact ? (unsigned)B4_JW * 64u * B4_CPT * 16u : 0u);
 }
 // Every wavefront works on its own: tasks from the scan's queue (a wavefront's first two by position, the others by ticket),
 // no workgroup barrier after the pose table is in place, no LDS window of live points.  A workgroup is as large as a CU holds
@@ -1022,6 +1024,8 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
     const float4 *poseL = reinterpret_cast<const float4 *>(dynsm);
     const signed char *travL = reinterpret_cast<const signed char *>(dynsm + ((B.U * 48 + 15) & ~15));
     unsigned long long *smask = reinterpret_cast<unsigned long long *>(dynsm + poseB) + (size_t)wv * (B4_CPT * T);
+    // the wavefront's slot for packing a task's member records (4 KB; B.compact: the workgroup's LDS has room for 16 of them)
+    float4 *compactL = B.compact ? reinterpret_cast<float4 *>(dynsm + poseB + (size_t)B4_JW * (B4_CPT * T * 8)) + (size_t)wv * (64 * B4_CPT) : nullptr;
     const float r2lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(r2 * (1.0 - 1e-6)))));   // (the four-cell tasks' band)
     const float r2hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(r2 * (1.0 + 1e-6)))));
     // (the one-cell tasks': b4_pair_step; wave-uniform values the compiler computes on the vector side -- stated scalar, they
@@ -1143,7 +1147,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
         }
         while (t < nH) {
             const unsigned start = c0.x, end = c0.y;
-            const int nch = (int)((end - start + 63) >> 6);
+            int nch = (int)((end - start + 63) >> 6);
             // the task's first two candidates: requested before the transform and the mask rounds, used after them
             const v8f q0 = *(B4_CONST(v8f))(sortedC + c0.z);
             // ... and the descriptor of the task after next
@@ -1167,6 +1171,45 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
                 ++pacc[8];
             }
             B4_TICK(1)
+            // Records of frames that are not the scan's own sit between its records wherever windows are chosen as the reference chooses
+            // them (every third frame of a slow traversal, traversals that are absent for this scan: 2.2 x the scan's entries in its
+            // slot range on bench.py's realistic shard, profiles/r06_*): the task's member records are packed into as few chunks as
+            // they need -- through the wavefront's LDS slot, positions by ballot prefix -- and a task without any is left at once.
+            if (compactL != nullptr) {
+                unsigned long long mb[B4_CPT];
+                unsigned total = 0, cb[B4_CPT];
+#pragma unroll
+                for (int u = 0; u < B4_CPT; ++u) {
+                    mb[u] = __ballot(tv[u] >= 0);
+                    cb[u] = total;
+                    total += (unsigned)__popcll(mb[u]);
+                }
+                const int nchNew = (int)((total + 63u) >> 6);
+                if (nchNew < nch) {   // (wave-uniform)
+                    if (nchNew > 0) {
+#pragma unroll
+                        for (int u = 0; u < B4_CPT; ++u) {
+                            const unsigned pos = cb[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(mb[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[u], 0u));
+                            const float x = (u & 1) ? hx[u / 2].y : hx[u / 2].x, y = (u & 1) ? hy[u / 2].y : hy[u / 2].x, z = (u & 1) ? hz[u / 2].y : hz[u / 2].x;
+                            if (tv[u] >= 0) compactL[pos] = make_float4(x, y, z, __int_as_float(tv[u]));
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int u = 0; u < B4_CPT; ++u) {
+                            const unsigned idx = (unsigned)(u * 64 + lane);
+                            const float4 v = compactL[min(idx, total - 1u)];
+                            const bool ok = idx < total;
+                            const float x = ok ? v.x : 1.0e30f, y = ok ? v.y : 0.f, z = ok ? v.z : 0.f;
+                            tv[u] = ok ? __float_as_int(v.w) : -1;
+                            if (u & 1) hx[u / 2].y = x, hy[u / 2].y = y, hz[u / 2].y = z;
+                            else hx[u / 2].x = x, hy[u / 2].x = y, hz[u / 2].x = z;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    nch = nchNew;
+                }
+            }
             // traversal masks of the chunks through LDS: every record ORs its lane bit into the word of its traversal, lane t
             // reads the word of traversal t (the LDS executes a wavefront's instructions in order; three rounds for the four
             // chunks: clear, OR, read)
@@ -1197,7 +1240,7 @@ __global__ __launch_bounds__(B4_JT, B4_WPE_) void b4_join(Blk B, const ScanDev *
 #pragma unroll
                 for (int u = 0; u < B4_CPT; ++u) R[u] = __builtin_nontemporal_load(&rec[min(s2 + u * 64 + lane, e2 - 1)]);
             }
-            if (!(dbg & 1)) {
+            if (!(dbg & 1) && nch > 0) {
                 static_assert(B4_CPT == 4, "one specialisation of the pair loop per number of chunk pairs");
                 const unsigned laneBytes = 4u * (unsigned)lq;
                 // (the masks' LDS reads and the first candidates' scalar load are waited for HERE: left to the compiler, the wait sits inside
@@ -1557,12 +1600,9 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
     if (!attr_done[ctx->device & 63]) {
         MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_seg_scatter),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, B4_SEG * 16));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)b4_join_lds(B4_POSE_LDS_MAX, B4_MAXT, true)));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)b4_join_lds(0, B4_MAXT, false)));
-        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)b4_join_lds(B4_POSE_LDS_MAX, B4_MAXT, true)));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS_LIMIT));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS_LIMIT));
+        MODEST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(b4_join<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS_LIMIT));
         attr_done[ctx->device & 63] = true;
     }
     modest_prof_mark(ctx, stream, 0);   // bench.py: the whole neighbour-count stage of the block
@@ -1597,7 +1637,15 @@ static int pp_block_impl(modest_ctx *ctx, const modest_pp_block_frame *frames, i
         const int lf = lf_env ? atoi(lf_env) & 31 : (G <= 6 ? 8 : 0);
         const int dbg = (dbg_env ? atoi(dbg_env) : 0) | ((tk_env ? atoi(tk_env) & 255 : 0) << 16) | (lf << 24);
         const bool lpose = U <= B4_POSE_LDS_MAX && !(dbg & 256);
-        const unsigned ldsB = b4_join_lds(U, Tmax, lpose);
+        const char *cp_env = getenv("MODEST_PP4_COMPACT");   // (0: no packing of member records -- A/B)
+        // Packing pays where a scan's slot range holds many entries that are not its own (reference-rule windows: every third frame of a
+        // slow traversal, absent traversals; +2 ... +7 % on such shards) and costs 1 % where it holds none (windows of frames i..i+F-1)
+        double rangeSum = 0, memberSum = 0;
+        for (int sc = 0; sc < G; ++sc)
+            if (scans[sc].n_members > 0) rangeSum += hsc[sc].slotHi - hsc[sc].slotLo + 1, memberSum += scans[sc].n_members;
+        const bool sparse = cp_env ? atoi(cp_env) != 0 : rangeSum > 1.2 * memberSum;
+        B.compact = sparse && b4_join_lds(U, Tmax, lpose, true) <= B4_LDS_LIMIT;
+        const unsigned ldsB = b4_join_lds(U, Tmax, lpose, B.compact != 0);
         if ((dbg & 512) && lpose) {   // MODEST_PP4_DBG=512: wall time of the join's wavefronts by phase (blocking; diagnostics only)
             unsigned long long *dprof = reinterpret_cast<unsigned long long *>(base + oCtrl + 64), hprof[10];
             MODEST_HIP_CHECK(hipMemsetAsync(dprof, 0, sizeof(hprof), stream));

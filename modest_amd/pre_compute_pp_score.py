@@ -396,15 +396,17 @@ def _pooled(args, rank, ws, local):
     return tot
 
 
-@config.main(config_name="pp_score.yaml")
-def main(args):
+def run(args, post=None, module="modest_amd.pre_compute_pp_score"):
+    """The PP-score CLI's body.  `post` (modest_amd/seed_labels.py: the fused mode) is an object with
+    done(idx) -> bool (every output of the scan exists: skip it), __call__(batch) (batch = [(idx, live file id, H device tensor)] of one
+    flushed PP batch, in plan order) and close(); None: the reference's stage-by-stage pipeline."""
     rank, ws, local = dist.init(poll_wait=bool(args.get("poll_wait", True)))
     if rank == 0:
         display_args(args)
     device = torch.device("cuda", dist.device_index(local, ws, args))
     torch.cuda.set_device(device)
     dp = args.data_paths
-    if int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER"):
+    if int(args.get("workers", 1) or 1) > 1 and not os.environ.get("MODEST_WORKER") and post is None:   # (the fused CLI pools its own workers)
         os.makedirs(dp.pp_score_path, exist_ok=True)
         return _pooled(args, rank, ws, local)
     track_list = pickle.load(open(dp.track_path, "rb"))
@@ -462,7 +464,7 @@ def main(args):
             # the reference tests the name without ".npy" (:123-124) and so never skips; here finished
             # scans are skipped unless overwrite=True (required after changing max_neighbor_dist,
             # limit_traversals or add_random_noise: the outputs carry no config hash)
-            if osp.exists(out_path) and not args.get("overwrite", False):
+            if osp.exists(out_path) and not args.get("overwrite", False) and (post is None or post.done(origin_idx)):
                 continue
             traversals = valid_idx[origin_idx][2]
             assert len(traversals) > 1, origin_idx
@@ -540,6 +542,8 @@ def main(args):
             _tr("M.enq", q[7])
             writer.submit(H, q[6])
             _tr("M.sub", q[7])
+        if post is not None:   # fused mode: stages 2 + 3 of the batch (deferred by one batch: they run under the NEXT batch's PP kernels)
+            post([(q[7], q[0], H) for q, H in zip(pend, Hs)])
         for _ in pend:
             pipe.done()
         pend.clear()
@@ -605,6 +609,8 @@ def main(args):
             H = store.pp_score(live_id, trans_mat, hist, rels[keep], A44, n_trav, remove_center=bool(args.nusc))
         _tr("M.enq", origin_idx)
         writer.submit(H, out_path)
+        if post is not None:
+            post([(origin_idx, live_id, H)])
         _tr("M.sub", origin_idx)
         done += 1
         if trace and (done <= 4 or done % 8 == 0):
@@ -612,6 +618,8 @@ def main(args):
         pts += store.points_of([i for i, _ in hist])
         pipe.done()
     flush()
+    if post is not None:
+        post.close()
     writer.close()
     if TRACE is not None:
         base = TRACE[0][2]
@@ -629,6 +637,11 @@ def main(args):
                   ws, store.hits, store.misses, loader.n_frames, loader.read_bytes / 1e6, loader.t_read, loader.t_insert,
                   loader.t_touch))
     return tot
+
+
+@config.main(config_name="pp_score.yaml")
+def main(args):
+    return run(args)
 
 
 if __name__ == "__main__":

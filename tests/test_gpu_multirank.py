@@ -258,3 +258,44 @@ def test_pp_cli_on_a_tree_whose_traversal_count_changes(gpu, tmp_path):
     # the block path took every batch (4 + 32 + 12 scans; a batch the sharing rule halves counts twice): no flush where T changes --
     # flushing there left batches of fewer than four scans to the per-scan chain
     assert mm and 3 <= int(mm.group(1)) <= 5 and int(mm.group(2)) == 0, err[-1500:]
+
+
+def test_fused_cli_writes_the_three_clis_files(gpu, tmp_path):
+    """`python -m modest_amd.seed_labels` (PP -> mask -> labels per batch in one process, the PP score staying on the device, stages 2 + 3
+    of a batch under the next batch's PP kernels) writes every file the reference's three CLIs write (README.md:52-70), byte for byte: one
+    process, `workers=2`, and a second run over a half-finished tree (scans whose files all exist are skipped, the others completed)."""
+    from modest_amd import synth
+    n = 44
+    root, meta = str(tmp_path / "data"), str(tmp_path / "meta")
+    paths = synth.write_kitti_tree(root, meta, n_seq=4, n_frames=n + 12, n_pts=4000, origins=tuple(range(n)), hist_frames=12, max_range=60.0)
+    train = os.path.join(root, "training")
+    ref, fused, fw = str(tmp_path / "ref"), str(tmp_path / "fused"), str(tmp_path / "fusedw")
+    for m in CLIS:
+        _run(m, _overrides(train, paths, ref), 1, 0)
+    _run("seed_labels", _overrides(train, paths, fused) + ["mask.mask_batch=8"], 1, 0)
+    _run("seed_labels", _overrides(train, paths, fw) + ["workers=2"], 1, 0)
+
+    def same(a, b):
+        for sub in ("pp", "seg", "bbox", "labels"):
+            fa = sorted(os.listdir(os.path.join(a, sub)))
+            fb = sorted(os.listdir(os.path.join(b, sub)))
+            assert fa == fb and len([f for f in fa if f != "configs.yaml"]) == n, (sub, len(fa), len(fb))
+            match, mismatch, err = filecmp.cmpfiles(os.path.join(a, sub), os.path.join(b, sub), [f for f in fa if f != "configs.yaml"], shallow=False)
+            assert not mismatch and not err, (sub, mismatch[:5], err[:5])
+        import yaml
+        for sub in ("seg", "bbox"):   # the config dump the mask stage leaves behind (generate_mask.py:38-46): the mask stage's own config
+            ca, cb = yaml.safe_load(open(os.path.join(a, sub, "configs.yaml"))), yaml.safe_load(open(os.path.join(b, sub, "configs.yaml")))
+            assert set(ca) == set(cb) and ca["graph"] == cb["graph"] and ca["filtering"] == cb["filtering"], sub
+
+    same(ref, fused)
+    same(ref, fw)
+    # resume: drop a third of the label files and one score file; the second run writes exactly those scans again
+    gone = sorted(f for f in os.listdir(os.path.join(fused, "labels")))[::3]
+    for f in gone:
+        os.remove(os.path.join(fused, "labels", f))
+    os.remove(os.path.join(fused, "pp", "000005.npy"))
+    stamp = {f: os.path.getmtime(os.path.join(fused, "seg", f)) for f in os.listdir(os.path.join(fused, "seg"))}
+    _run("seed_labels", _overrides(train, paths, fused), 1, 0)
+    same(ref, fused)
+    redone = {f for f, t in stamp.items() if os.path.getmtime(os.path.join(fused, "seg", f)) != t}
+    assert redone == {f.replace(".txt", ".npy") for f in gone} | {"000005.npy"}, sorted(redone)[:8]
