@@ -403,7 +403,8 @@ class Runner:
         tr = getattr(self, "trace", None)
         t0 = time.perf_counter()
         if len(items) > 1 and not a.no_mask_chain:
-            res = self._generate_mask_chain(items, scs[0].calib, self.margs, as_rows=True, ctxs=self.chain_ctxs[w][:len(items)])
+            res = self._generate_mask_chain(items, scs[0].calib, self.margs, as_rows=True, ctxs=self.chain_ctxs[w][:len(items)],
+                                            with_iou=bool(self.largs.nms.enable))
         else:
             res = [self._generate_mask_scan(it["ptc"], it["pp_score"], scs[0].calib, self.margs, random_state=it["random_state"],
                                             ptc_dev=it["ptc_dev"], pp_dev=it["pp_dev"], as_rows=True) for it in items]
@@ -411,13 +412,14 @@ class Runner:
             tr.append((f"mask[{len(items)}]", time.perf_counter() - t0))
             t0 = time.perf_counter()
         if len(res) > 1 and not a.no_mask_chain:   # the IoU matrices of the chain's label stage: one launch
-            lab = self._gen_label_chain([r[1] for r in res], [sc.calib for sc in scs], self.largs, after_device=after)
+            lab = self._gen_label_chain([r[1] for r in res], [sc.calib for sc in scs], self.largs, after_device=after,
+                                        ious=[r[3] if len(r) > 3 else None for r in res])
         else:
             lab = [self._gen_label_scan(r[1], sc.calib, self.largs, after_device=after if q == len(res) - 1 else None)
                    for q, (r, sc) in enumerate(zip(res, scs))]
         if tr is not None:
             tr.append((f"label[{len(items)}]", time.perf_counter() - t0))
-        return [(H, labels, objs, text) for H, (labels, objs, _), (text, kept) in zip(Hs, res, lab)]
+        return [(H, r[0], r[1], text) for H, r, (text, kept) in zip(Hs, res, lab)]
 
     def blocks_of(self, lo, hi):
         """steps lo..hi-1 cut at the multiples of the block size -> [[step, ...], ...]"""
@@ -820,6 +822,14 @@ def main():
     helpers, note, M = [], None, None
     startup = {"helper_seconds": [], "helper_peak_rss_mb": []}
     t_start = time.perf_counter()
+    # A rank's helpers cost the host ~6 busy threads each inside the clock (measured: config.host_budget_per_rank -- a polling main
+    # thread, the runtime's signal thread, pose / reader / writer threads): 8 ranks x 8 helpers would want ~400 of this host's threads.
+    # With several ranks the pool is capped so that all ranks' helpers fit the host's hardware threads.
+    if ws > 1 and a.procs > 1:
+        fit = max(2, (os.cpu_count() or 64) // (ws * 6))
+        if fit < a.procs:
+            print(f"[bench] rank {rank}: {a.procs} helper processes x {ws} ranks exceed the host's {os.cpu_count()} threads: {fit} per rank", file=sys.stderr)
+            a.procs = fit
     n_procs = helper_count(a.procs, a.steps)
     n_pool = max(1, a.procs)
     flag = None

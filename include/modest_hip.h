@@ -531,6 +531,32 @@ int modest_objs_iou(modest_ctx *ctx, const double *objs8_host, int k, float *iou
 /* ... of the box sets of a chain of scans: one launch and one round trip for all (k[s] boxes, (k[s],k[s]) out each). */
 int modest_objs_iou_batch(modest_ctx *ctx, const double *const *objs8_host, const int32_t *k, int n_sets,
                           float *const *iou_out_host, void *stream);
+/* ---- stages 2 + 3 of a CHAIN of scans behind one call (generate_mask.py:52-103 + the IoU matrix of gen_label_files.py:44-45,
+ * pointcloud_utils.py:320-327): modest_mask_stage_batch, modest_scan_boxes_batch and modest_objs_iou_batch in sequence, results
+ * leaving the library once.  Per scan (own context, as in those calls): labels_out [host] (n) int64 = the FINAL labels
+ * (generate_mask.py:100-103); objs_out [host] (max_boxes,8): the first info_out[9] rows = the boxes that passed the volume gate,
+ * in label order; iou_out [host]: their (k,k) float32 BEV IoU, row major, packed (NULL when nms_enable == 0);
+ * members_scratch [host] (n) int32.  info_out[12]: [0..7] as modest_mask_stage; [8] clusters before the volume gate; [9] k;
+ * [10] 0 = done, 1 = the mask stage handed the scan back (generator untouched, nothing written), 2 = the box tail handed it
+ * back, 3 = more than max_boxes clusters -- for 2 and 3 labels_out holds `labels_filtered` and the generator is advanced: the
+ * caller runs modest_scan_boxes / its host statement on them.  np.diag(iou).argsort() and the label text stay with the caller
+ * (modest_label_lines).  Blocking.                                                                                          */
+typedef struct modest_seed_scan {
+    modest_ctx *ctx;
+    const float *pts_dev, *pts_host;
+    int32_t n, stride;
+    const float *pp_dev;
+    uint32_t *mt_key624;
+    int32_t *mt_pos;
+    double *plane1_out, *plane2_out;
+    int64_t *labels_out;
+    int32_t *members_scratch;
+    double *objs_out;
+    float *iou_out;
+    int32_t *info_out;
+} modest_seed_scan;
+int modest_seed_chain(const modest_seed_scan *scans, int n_scans, const modest_mask_params *mask_params,
+                      const modest_boxes_params *boxes_params, int max_boxes, int nms_enable, void *stream);
 /* objs_nms' greedy walk (pointcloud_utils.py:329-343) in the caller's `order` -- the reference's
  * np.diag(iou).argsort()[::-1], a numpy call whose tie order is numpy's own --, is_within_fov (:373-379),
  * objs2label (:347-370).  cossin_ry [host] (k,2) = numpy's (cos, sin) of every obj.ry (roty, kitti_util.py:

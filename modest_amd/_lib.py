@@ -78,6 +78,7 @@ SIGNATURES = {
     "modest_nms_normal": (C.c_int, [VP, VP, C.c_int, C.c_float, VP, VP, VP]),
     "modest_boxes_iou_bev_host": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP]),
     "modest_scan_boxes_batch": (C.c_int, [VP, C.c_int, VP, VP]),
+    "modest_seed_chain": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
     "modest_scan_boxes": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP]),
     "modest_objs_iou_batch": (C.c_int, [VP, VP, VP, C.c_int, VP, VP]),
     "modest_objs_iou": (C.c_int, [VP, VP, C.c_int, VP, VP]),

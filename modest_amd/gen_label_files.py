@@ -67,14 +67,20 @@ def gen_label_scan(objs, calib, args, after_device=None, iou=None):
     return objs2label(objs, calib), objs
 
 
-def gen_label_chain(objs_list, calibs, args, after_device=None):
+def gen_label_chain(objs_list, calibs, args, after_device=None, ious=None):
     """gen_label_scan for a CHAIN of scans: the IoU matrices of all of them from ONE launch and one round trip
     (modest_objs_iou_batch), then order, walk, FOV filter and label text scan by scan.  after_device runs once the
     chain has no device work left.  Returns [(text, kept objs)] -- identical to separate calls."""
     calibs = calibs if isinstance(calibs, (list, tuple)) else [calibs] * len(objs_list)
-    ious = [None] * len(objs_list)
+    # (ious: the matrices modest_seed_chain already produced -- generate_mask_chain(with_iou=True); a None entry is computed here)
+    if ious is None:
+        ious = [None] * len(objs_list)
     if NATIVE_LABELS and bool(args.nms.enable) and all(isinstance(o, np.ndarray) for o in objs_list):
-        ious = ops.objs_iou_batch(objs_list)
+        todo = [i for i, m in enumerate(ious) if m is None]
+        if todo:
+            ious = list(ious)
+            for i, m in zip(todo, ops.objs_iou_batch([objs_list[i] for i in todo])):
+                ious[i] = m
     if after_device is not None:
         after_device()
     return [gen_label_scan(o, cb, args, iou=(m if len(o) > 0 else None)) for o, cb, m in zip(objs_list, calibs, ious)]

@@ -121,12 +121,66 @@ def _native_boxes_ok(ptc, n_lab, args) -> bool:
                 and ptc.flags.c_contiguous)
 
 
-def generate_mask_chain(scans, calib, args, as_rows=False, ctxs=None):
-    """generate_mask_scan for a CHAIN of scans: the mask stage of all of them as one library call
-    (modest_mask_stage_batch: one launch per kernel of the mask / graph / DBSCAN block and of the cluster statistics
-    for the whole chain), then boxes per scan.  scans: [dict(ptc=, pp_score=, random_state=, ptc_dev=, pp_dev=)];
-    calib: one Calibration or one per scan.  Returns [generate_mask_scan's result] -- identical to separate calls."""
+ONE_CALL_CHAIN = True   # tests switch it off to compare modest_seed_chain with the three separate chain calls
+
+
+def _one_call_chain(scans, calibs, args, as_rows, ctxs, want_iou):
+    """The chain through modest_seed_chain (mask stage + box tail + IoU matrices of the kept boxes: ONE library call), or None when
+    some scan is not eligible (then the separate calls below decide scan by scan)."""
+    if not (ONE_CALL_CHAIN and NATIVE_STAGE and NATIVE_BOXES and len(scans) > 1 and args.bbox_gen.fit_method == "closeness_to_edge"):
+        return None
+    c0 = calibs[0]
+    if any(not (np.array_equal(c.V2C, c0.V2C) and np.array_equal(c.R0, c0.R0)) for c in calibs[1:]):
+        return None
+    items = []
+    for sc in scans:
+        rs = sc.get("random_state")
+        rs = np.random.mtrand._rand if rs is None else rs
+        p = sc["ptc"]
+        if not (p.shape[0] >= 1 and p.dtype == np.float32 and p.flags.c_contiguous and isinstance(rs, np.random.RandomState)
+                and rs.get_state()[0] == "MT19937"):
+            return None
+        if sc.get("ptc_dev") is None:
+            sc["ptc_dev"] = to_device(p)
+        if sc.get("pp_dev") is None:
+            sc["pp_dev"] = to_device(sc["pp_score"])
+        items.append((sc["ptc_dev"], p, sc["pp_dev"], rs))
+    if len({id(it[3]) for it in items}) != len(items):   # one generator per scan: no draw order between scans
+        return None
+    from .utils.pointcloud_utils import _angles, _angles90
+    ang, cs = _angles(0.1)
+    res = ops.seed_chain(items, _stage_params(args), c0.V2C, c0.R0, ang, cs, _angles90(0.1), 1e-2, args.filtering.min_volume,
+                         args.filtering.max_volume, want_iou, ctxs=ctxs)
+    out = []
+    for sc, cb, (status, labels, rows, iou, plane1, info) in zip(scans, calibs, res):
+        if status == 0:
+            out.append((labels, (rows if as_rows else objs_from_rows(rows)), dict(plane=plane1, n_kept=int(info[0]), dbscan_kept=None), iou))
+            continue
+        # 1: the stage handed the scan back (generator untouched) -> the host statement; 2 / 3: labels_filtered is there, the box tail
+        # takes the separate call / the host statement
+        staged = None if status == 1 else (labels, plane1, None, info[:8])
+        r = generate_mask_scan(sc["ptc"], sc["pp_score"], cb, args, random_state=sc.get("random_state"), ptc_dev=sc.get("ptc_dev"),
+                               pp_dev=sc.get("pp_dev"), as_rows=as_rows, staged=staged)
+        out.append((r[0], r[1], r[2], None))
+    return out
+
+
+def generate_mask_chain(scans, calib, args, as_rows=False, ctxs=None, with_iou=False):
+    """generate_mask_scan for a CHAIN of scans: stages 2 + 3 of all of them behind ONE library call (modest_seed_chain: the mask
+    stage with one launch per kernel for the whole chain, the box tail, and -- `with_iou` -- the BEV IoU matrices the label stage's
+    NMS needs), or, for chains that call does not cover (another fit method, different calibrations, numpy's global generator shared
+    between scans), the mask stage as one call and boxes per scan.  scans: [dict(ptc=, pp_score=, random_state=, ptc_dev=, pp_dev=)];
+    calib: one Calibration or one per scan.  Returns [generate_mask_scan's result] -- identical to separate calls; with_iou:
+    4-tuples whose last entry is the (k,k) float32 IoU matrix of the scan's boxes (None: gen_label_scan computes it)."""
     calibs = calib if isinstance(calib, (list, tuple)) else [calib] * len(scans)
+    one = _one_call_chain(scans, calibs, args, as_rows, ctxs, bool(with_iou))
+    if one is not None:
+        return one if with_iou else [r[:3] for r in one]
+    res = _generate_mask_chain_calls(scans, calibs, args, as_rows, ctxs)
+    return [r + (None,) for r in res] if with_iou else res
+
+
+def _generate_mask_chain_calls(scans, calibs, args, as_rows, ctxs):
     staged = [_UNSET] * len(scans)
     if NATIVE_STAGE and len(scans) > 1:
         items, who = [], []

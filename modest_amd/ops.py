@@ -582,6 +582,88 @@ def scan_boxes_batch(items, V2C, R0, angles: np.ndarray, cossin: np.ndarray, cos
             for labels, objs, keep, info, n_lab, _m in keepalive]
 
 
+class SeedScan(C.Structure):
+    """modest_seed_scan (include/modest_hip.h)"""
+    _fields_ = [("ctx", C.c_void_p), ("pts_dev", C.c_void_p), ("pts_host", C.c_void_p), ("n", C.c_int32), ("stride", C.c_int32),
+                ("pp_dev", C.c_void_p), ("mt_key624", C.c_void_p), ("mt_pos", C.c_void_p), ("plane1_out", C.c_void_p),
+                ("plane2_out", C.c_void_p), ("labels_out", C.c_void_p), ("members_scratch", C.c_void_p), ("objs_out", C.c_void_p),
+                ("iou_out", C.c_void_p), ("info_out", C.c_void_p)]
+
+
+def _boxes_params(V2C, R0, angles, cossin, cossin90, d0, min_volume, max_volume) -> BoxesParams:
+    P = BoxesParams()
+    P.V2C[:] = [float(x) for x in np.asarray(V2C, dtype=np.float64).reshape(12)]
+    P.R0[:] = [float(x) for x in np.asarray(R0, dtype=np.float64).reshape(9)]
+    assert angles.dtype == np.float64 and cossin.dtype == np.float64 and cossin90.dtype == np.float64
+    assert cossin.flags.c_contiguous and cossin90.flags.c_contiguous and angles.flags.c_contiguous
+    P.angles, P.cossin, P.cossin90, P.n_angles = _np_ptr(angles), _np_ptr(cossin), _np_ptr(cossin90), angles.shape[0]
+    P.d0, P.min_volume, P.max_volume = float(d0), float(min_volume), float(max_volume)
+    return P
+
+
+SEED_MAX_BOXES = 96   # clusters per scan the one-call chain has room for (a Lyft-shape scan has 10-40; more: the scan takes the separate calls)
+
+
+def seed_chain(items, mparams: MaskParams, V2C, R0, angles: np.ndarray, cossin: np.ndarray, cossin90: np.ndarray, d0: float,
+               min_volume: float, max_volume: float, nms_enable: bool, ctxs=None):
+    """modest_seed_chain: stages 2 + 3 of a CHAIN of scans (one calibration) behind ONE library call -- mask stage, box tail and the
+    IoU matrices of the kept boxes.  items: [(pts_dev (n,3|4) f32, pts_host (same, numpy), pp_dev (n,) f32, RandomState)].
+    Returns per scan (status, labels (n,) int64, rows (k,8) f64, iou (k,k) f32 | None, plane1, info): status 0 = all of it is final;
+    1 = the mask stage handed the scan back (its generator is untouched: run the host statement); 2 / 3 = labels are
+    `labels_filtered` and the generator is advanced, the box tail is the caller's (scan_boxes / host statement)."""
+    lib = load()
+    B = len(items)
+    if B == 0:
+        return []
+    if ctxs is None:
+        ctxs = chain_contexts(B, items[0][0].device.index or 0)
+    P = _boxes_params(V2C, R0, angles, cossin, cossin90, d0, min_volume, max_volume)
+    K = SEED_MAX_BOXES
+    ns = [int(it[0].shape[0]) for it in items]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    labels_all = np.empty(int(offs[-1]), dtype=np.int64)       # one allocation per kind for the whole chain
+    members_all = np.empty(int(offs[-1]), dtype=np.int32)
+    keys_all = np.empty((B, 624), dtype=np.uint32)
+    pos_all = np.zeros(B, dtype=np.int32)
+    planes_all = np.zeros((B, 2, 4), dtype=np.float64)
+    rows_all = np.zeros((B, K, 8), dtype=np.float64)
+    iou_all = np.zeros((B, K * K), dtype=np.float32) if nms_enable else None
+    info_all = np.zeros((B, 12), dtype=np.int32)
+    arr = (SeedScan * B)()
+    states = []
+    for i, (pts, pts_host, pp, rs) in enumerate(items):
+        _dev(pts, torch.float32, "pts")
+        _dev(pp, torch.float32, "pp")
+        n = ns[i]
+        assert pp.shape[0] == n and n >= 1 and pts_host.dtype == np.float32 and pts_host.flags.c_contiguous and pts_host.shape == tuple(pts.shape)
+        st = rs.get_state()
+        assert st[0] == "MT19937"
+        keys_all[i] = st[1]
+        pos_all[i] = int(st[2])
+        states.append(st)
+        a = arr[i]
+        a.ctx = C.cast(ctxs[i].handle, C.c_void_p).value
+        a.pts_dev, a.pts_host, a.n, a.stride, a.pp_dev = pts.data_ptr(), _np_ptr(pts_host), n, pts.shape[1], pp.data_ptr()
+        a.mt_key624, a.mt_pos = keys_all[i].ctypes.data, pos_all[i:].ctypes.data
+        a.plane1_out, a.plane2_out = planes_all[i, 0].ctypes.data, planes_all[i, 1].ctypes.data
+        a.labels_out, a.members_scratch = labels_all[offs[i]:].ctypes.data, members_all[offs[i]:].ctypes.data
+        a.objs_out = rows_all[i].ctypes.data
+        a.iou_out = iou_all[i].ctypes.data if nms_enable else None
+        a.info_out = info_all[i].ctypes.data
+    check(lib.modest_seed_chain(C.byref(arr), B, C.byref(mparams), C.byref(P), K, int(bool(nms_enable)), _stream()), "modest_seed_chain")
+    out = []
+    for i, (pts, pts_host, pp, rs) in enumerate(items):
+        info = info_all[i]
+        status = int(info[10])
+        if status != 1:
+            st = states[i]
+            rs.set_state((st[0], keys_all[i], int(pos_all[i]), st[3], st[4]))
+        k = int(info[9])
+        out.append((status, labels_all[offs[i]:offs[i + 1]], rows_all[i, :k], (iou_all[i, :k * k].reshape(k, k) if nms_enable else None),
+                    planes_all[i, 0], info))
+    return out
+
+
 def objs_iou(objs8: np.ndarray, ctx: Optional[Context] = None) -> np.ndarray:
     """BEV IoU matrix (k,k) float32 of objs_nms' float32 boxes (modest_objs_iou)."""
     lib = load()

@@ -185,11 +185,11 @@ class FusedStages:
                 q = chunk[0]
                 res = [generate_mask_scan(q["ptc"], q["pp_score"], cal[0], margs, random_state=q["random_state"], pp_dev=q["pp_dev"], as_rows=True)]
             else:
-                res = generate_mask_chain(chunk, cal, margs, as_rows=True)
+                res = generate_mask_chain(chunk, cal, margs, as_rows=True, with_iou=bool(largs.nms.enable))
             rows = [np.asarray(r[1], dtype=np.float64).reshape(-1, 8) for r in res]
-            lab = gen_label_chain(rows, cal, largs)
-            for q, (labels, _r, _), rw, (text, _kept) in zip(chunk, res, rows, lab):
-                self.writer.submit(lambda i=q["idx"], labels=labels, rw=rw, text=text: self._write(i, labels, rw, text))
+            lab = gen_label_chain(rows, cal, largs, ious=[r[3] if len(r) > 3 else None for r in res])
+            for q, r, rw, (text, _kept) in zip(chunk, res, rows, lab):
+                self.writer.submit(lambda i=q["idx"], labels=r[0], rw=rw, text=text: self._write(i, labels, rw, text))
         self.scans += len(batch)
         self.t_host += time.perf_counter() - t0
 

@@ -447,6 +447,52 @@ def test_mask_stage_chain_equals_separate_calls(gpu, tmp_path):
     assert any(len(r[1]) > 0 for r in single)
 
 
+def test_one_call_chain_equals_the_separate_chain_calls(gpu, tmp_path, monkeypatch):
+    """modest_seed_chain (mask stage + box tail + IoU matrices of the kept boxes of a chain behind ONE library call)
+    against the three separate chain calls it replaces: final labels, box rows, planes, generator states, the IoU matrices the label
+    stage's NMS reads and the label text -- with a scan the mask stage hands back inside the chain (a candidate set of <= 300 points)
+    and, with room for two boxes only, scans whose box tail goes back to the separate call."""
+    import torch
+    from modest_amd import config, generate_mask as gm, ops, synth
+    from modest_amd.gen_label_files import gen_label_chain
+    from modest_amd.utils import kitti_util
+    open(tmp_path / "c.txt", "w").write(synth.CALIB_TXT)
+    calib = kitti_util.Calibration(str(tmp_path / "c.txt"))
+    margs = config.compose("generate_mask", ["data_root=/unused"])
+    largs = config.compose("generate_label_files", ["data_root=/unused"])
+    scans = []
+    for k, n_live in enumerate([30000, 12000, 400, 21000, 8000]):
+        s = synth.make_scan(170 + k, n_live=n_live, n_trav=2, n_frames=1)
+        raw = np.ascontiguousarray(s.live_raw)
+        rng = np.random.default_rng(k)
+        pp = np.clip(0.5 + 0.5 * np.sin(raw[:, 0] * 0.3) + rng.normal(0, 0.03, len(raw)), 0, 1).astype(np.float32)
+        scans.append((raw, pp, torch.from_numpy(raw).to(gpu), torch.from_numpy(pp).to(gpu)))
+
+    def run(one_call):
+        monkeypatch.setattr(gm, "ONE_CALL_CHAIN", one_call)
+        rss = [np.random.RandomState(300 + k) for k in range(len(scans))]
+        res = gm.generate_mask_chain([dict(ptc=r, pp_score=p, random_state=rs, ptc_dev=rd, pp_dev=pd) for (r, p, rd, pd), rs in zip(scans, rss)],
+                                     calib, margs, as_rows=True, with_iou=True)
+        lab = gen_label_chain([r[1] for r in res], calib, largs, ious=[r[3] for r in res])
+        return res, lab, [rs.get_state() for rs in rss]
+
+    ref, ref_lab, ref_st = run(False)
+    assert all(r[3] is None for r in ref) and any(len(r[1]) > 2 for r in ref)
+    for cap in (ops.SEED_MAX_BOXES, 2):
+        monkeypatch.setattr(ops, "SEED_MAX_BOXES", cap)
+        got, got_lab, got_st = run(True)
+        n_iou = 0
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (cap, k)
+            assert np.array_equal(a[2]["plane"], b[2]["plane"]) and a[2]["n_kept"] == b[2]["n_kept"], (cap, k)
+            assert ref_st[k][2] == got_st[k][2] and np.array_equal(ref_st[k][1], got_st[k][1]), (cap, k)
+            assert ref_lab[k][0] == got_lab[k][0] and np.array_equal(ref_lab[k][1], got_lab[k][1]), (cap, k)
+            if b[3] is not None and len(b[1]):
+                assert np.array_equal(b[3], ops.objs_iou(b[1])), (cap, k)   # the matrices equal modest_objs_iou's, bit for bit
+                n_iou += 1
+        assert n_iou >= (2 if cap > 2 else 0)
+
+
 def test_label_chain_equals_separate_calls(gpu, tmp_path):
     """gen_label_chain: the IoU matrices of several scans' box sets from one launch (modest_objs_iou_batch); label text
     and kept boxes equal gen_label_scan's, incl. an empty box set inside the chain."""
