@@ -43,3 +43,9 @@ except Exception as e:
     print('$f'.split('/')[-1], 'NO JSON'); sys.exit(0)
 r=d['roofline']; b=d.get('roofline_best_case') or {}; c=d.get('cli') or {}
 print('$f'.split('/')[-1], 'value %.0f ingest %.0f steady %s' % (d['value'], d['value_with_ingest']['value'], ('%.0f' % d['steady_state']['value']) if d.get('steady_state') else '-'), '| roofline %.4f %.3f ms / %d scans block=%s traffic %s' % (r['frac'], r['kernel_ms'], r['scans_per_launch'], r['block_path'], r.get('traffic_per_scan')), '| best case', b.get('frac'), '| path', d['config'].get('pp_path_in_timed_region'), '| cli', {k: round(v) for k,v in c.items() if k.endswith('per_s') or k.endswith('workers') and isinstance(v,(int,float))}, d.get('speedup_vs_cpu'))"; done
+if [ $S = all ] || [ $S = c4 ]; then
+# one rank's share of the Lyft train set (11 873 / 8 = 1 485 scans) through the CLIs, separate and fused
+python bench.py --steps 64 --cpu-scans 0 --cli-scans 1485 --sharing best 2>/dev/null | line > $F/bench_c4_shard.json
+python -c "
+import json; d=json.load(open('$F/bench_c4_shard.json')); c=d['cli']; print('c4 shard', {k:(round(v) if isinstance(v,float) else v) for k,v in c.items() if k!='note'})"
+fi
