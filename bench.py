@@ -920,7 +920,13 @@ def main():
 
     cpu0 = host_cpu_seconds()
     if helpers:
-        dt, kernel_ms = timed_region(helpers[:n_procs], _split(a.steps, n_procs))
+        deal = os.environ.get("MODEST_WINDOW_DEAL")   # (experiments: "8,6,4,2" = the contract region's scans per helper)
+        if deal and sum(int(x) for x in deal.split(",")) == a.steps and len(deal.split(",")) <= n_pool:
+            shares = [int(x) for x in deal.split(",")]
+            n_procs = len(shares)
+        else:
+            shares = _split(a.steps, n_procs)
+        dt, kernel_ms = timed_region(helpers[:n_procs], shares)
         paths = timed_region.paths
     else:
         runner.rehearse(a.steps)
