@@ -339,3 +339,23 @@ def test_relative_poses_block_is_the_per_scan_solve():
     E, L = np.linalg.inv(stacks[0][3] @ np.linalg.inv(K) @ np.linalg.inv(l2es[0])), l2es[0]   # any ego pose with W = E @ L @ K
     one = get_relative_pose(l2es[0], egos[0], L, np.linalg.inv(E), K)
     assert one.shape == (4, 4) and one.dtype == np.float32
+
+
+def test_fused_cli_composes_the_three_stage_configs():
+    """modest_amd.seed_labels: `key=value` goes to every stage config that has the key (data_root, the data_paths group, total_part,
+    workers ...), `pp.` / `mask.` / `labels.` prefixes address one stage; a key no stage has is an error, as Hydra's would be; what the
+    work split reads (workers, device, total_part, part) comes from the PP stage's config; the worker hand-off is a plain container."""
+    from modest_amd import seed_labels as sl
+    c = sl.compose_all(["data_root=/d", "data_paths=nusc.yaml", "nusc=True", "workers=3", "total_part=2", "part=1", "mask.mask_batch=8",
+                        "mask.plane_estimate.max_hs=-1.3", "labels.nms.threshold=0.2", "labels.image_shape=[900,1600]"])
+    assert c.workers == 3 and c.get("total_part") == 2 and c.get("part") == 1 and c.get("nonsense", 7) == 7
+    assert c.pp.nusc is True and c.pp.total_part == 2 and c.mask.total_part == 2 and c.labels.total_part == 2
+    assert c.mask.mask_batch == 8 and c.mask.plane_estimate.max_hs == -1.3 and c.labels.nms.threshold == 0.2
+    assert list(c.labels.image_shape) == [900, 1600] and c.mask.graph.n_neighbors == 70
+    assert "nuscenes" in c.pp.data_paths.track_path and c.mask.ptc_path == "/d/velodyne" and c.labels.calib_path == "/d/calib"
+    d = c.to_container()
+    assert set(d) >= {"pp", "mask", "labels", "workers", "device", "total_part", "part"} and d["mask"]["data_root"] == "/d"
+    with pytest.raises(KeyError):
+        sl.compose_all(["data_root=/d", "no_such_key=1"])
+    with pytest.raises(KeyError):
+        sl.compose_all(["data_root=/d", "mask.no_such_key=1"])

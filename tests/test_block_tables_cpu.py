@@ -163,3 +163,31 @@ def test_large_blocks_split_when_the_union_is_large():
         assert forced is not None and forced is not fs.SPLIT_BLOCK and len(forced[0]) == T * L
         half = st.block_tables(descs[:16], T)   # each half then goes as a block of its own
         assert half is not None and half is not fs.SPLIT_BLOCK and len(half[1]) == 16
+
+
+def test_block_tables_with_a_traversal_count_per_scan():
+    """Scans of one block may have different numbers of traversals (the reference accepts a traversal per scan,
+    data_preprocessing/lyft/split_traintest.py:17,79,111): the rule counts entries against the SUM of the scans' T, the tables carry every
+    scan's own member list, and a traversal index beyond a scan's own T never appears in it."""
+    T, F, L, B = 5, 12, 40, 8
+    st = _store(T * L + B, T, L)
+    descs = _descs(st, B, T, F, L)
+    Ts = [5, 5, 4, 4, 3, 3, 5, 2]
+    cut = []
+    for (lv, arr, slots), t in zip(descs, Ts):   # scan i keeps its first T_i traversals
+        keep = arr["trav"] < t
+        cut.append((lv, arr[keep], np.concatenate([slots[:-1][keep], slots[-1:]])))
+    tabs = st.block_tables(cut, Ts)
+    assert tabs is not None and tabs is not fs.SPLIT_BLOCK
+    fr, sc, keep = tabs
+    for i, t in enumerate(Ts):
+        n = int(sc["n_members"][i])
+        assert n == t * F
+        tr = _read(sc["member_trav"][i], n, C.c_int32)
+        assert tr.min() == 0 and tr.max() == t - 1
+        ms = _read(sc["member_slot"][i], n, C.c_int32)
+        assert len(set(ms.tolist())) == n and ms.min() >= 0 and ms.max() < len(fr)
+    # the rule: fewer than 12 entries per traversal AND scan on average -> the per-scan chain (unless forced)
+    short = [(lv, arr[arr["trav"] < 2][:10], np.concatenate([slots[:-1][arr["trav"] < 2][:10], slots[-1:]])) for lv, arr, slots in descs]
+    assert st.block_tables(short, [2] * B) is None
+    assert st.block_tables(short, [2] * B, force=True) is not None
