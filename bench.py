@@ -1014,7 +1014,7 @@ def main():
     # the event pairs of the timed region also bracket the other scans' kernels and are reported as `in_pipeline`
     achieved = iso_B * alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms else contended
     traffic, traffic_src = None, None
-    tnames = (("r05_pp_block_traffic.json", "r05_c5_pp_block_traffic.json", "r04_pp_block_traffic.json") if iso_block else ()) + ("r03_pp_traffic.json", "r02_pp_traffic.json", "r01_pp_traffic.json")
+    tnames = (("r06_pp_block_traffic.json", "r05_pp_block_traffic.json", "r05_c5_pp_block_traffic.json", "r04_pp_block_traffic.json") if iso_block else ()) + ("r03_pp_traffic.json", "r02_pp_traffic.json", "r01_pp_traffic.json")
     for tname in tnames:
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):   # PMC counters cannot be read from inside the process: separate rocprofv3 --pmc passes
