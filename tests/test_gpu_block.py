@@ -346,3 +346,15 @@ def test_block_with_different_traversal_counts_per_scan(gpu):
         k = int(np.argmin(Ts))
         one = store.pp_score_batch(lives[k:k + 1], descs[k:k + 1], Ts[k], return_counts=True, block=False)[1][0]
         assert torch.equal(one, cb[k])
+
+
+def test_block_path_on_random_shard_shapes(gpu):
+    """tools/r06_block_fuzz.py: random live / frame sizes, traversal counts (constant and per scan), window lengths, block sizes, radii,
+    Lyft and nuScenes shape, sliding and reference-rule windows -- block == per-scan chain on every scan, == the oracle on two scans per
+    shard (profiles/r06_block_fuzz.txt holds a 40-case run)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "r06_block_fuzz.py"), "12", "11"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "12 cases, 0 mismatches" in r.stdout, r.stdout[-3000:]
