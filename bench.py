@@ -360,7 +360,17 @@ class Runner:
         from modest_amd.pre_compute_pp_score import relative_poses_block
         sh = scs[0].shard
         keys_all, offs, Ws, base = [], [0], [], 0
-        dev = torch.empty((sum(int(sc.new_pinned.shape[0]) for sc in scs), 4), dtype=torch.float32, device=self.dev)
+        # one device staging block per thread (= per stream), kept: a fresh 170 MB tensor per block went to the driver for a new segment
+        # every other block -- a hipMalloc inside the clock, tens of milliseconds with eight processes (MODEST_BENCH_TRACE=1:
+        # torch_segments_allocated).  Reuse is safe in stream order: the sort that reads the block is enqueued before the next copy into it.
+        need = sum(int(sc.new_pinned.shape[0]) for sc in scs)
+        stage = getattr(self, "_ingest_stage", None)
+        if stage is None:
+            stage = self._ingest_stage = {}
+        buf = stage.get(id(ctx))
+        if buf is None or buf.shape[0] < need:
+            buf = stage[id(ctx)] = torch.empty((need + need // 8, 4), dtype=torch.float32, device=self.dev)
+        dev = buf[:need]
         old = []
         for sc in scs:
             n = int(sc.new_pinned.shape[0])
@@ -959,7 +969,9 @@ def main():
 
     # the same pool, every step bringing in its 11 new frames and building its descriptor table from raw poses
     with_ingest = None
-    n_wi = max(a.steps, STEADY_STEPS_PER_HELPER * n_pool) if helpers else a.steps
+    # (the region's first block has nothing ahead of it: its PP call waits for its own copy + sort behind whatever the other helpers have
+    # queued -- 20-25 ms once per helper, MODEST_BENCH_TRACE=1 -- so the region is twice the contract region: four to five blocks per helper)
+    n_wi = max(2 * a.steps, STEADY_STEPS_PER_HELPER * n_pool) if helpers else a.steps
     if True:
         if helpers:
             dt_wi, _ = timed_region(helpers, _split(n_wi, n_pool), ingest=True)
