@@ -81,7 +81,10 @@ def parse(argv=None):
     ap.add_argument("--pp-batch", type=int, default=32,
                     help="consecutive scans whose PP stage is ONE call (FrameStore.pp_score_batch: modest_pp_score_block for >= 4 "
                          "scans that share their frames, modest_pp_score_frames_batch otherwise); clamped to --shard-scans")
-    ap.add_argument("--mask-batch", type=int, default=16, help="scans per chain of stages 2 + 3 (modest_mask_stage_batch)")
+    ap.add_argument("--mask-batch", type=int, default=32,
+                    help="scans per chain of stages 2 + 3 (modest_seed_chain).  32 since round 6: with the chain behind one library call the longer "
+                         "chain's GPU efficiency reaches `value` (7 200-7 500 against 6 450-6 550 scans/s at 16; round 5 measured no gain: its host "
+                         "side held the helper twice as long)")
     ap.add_argument("--no-pp-block", action="store_true",
                     help="A/B: the PP stage through modest_pp_score_frames_batch (every scan streams its own 361 frames) in chains of "
                          "at most 8 scans, never through modest_pp_score_block")
