@@ -698,7 +698,11 @@ class FrameStore:
             first = sid[first_idx]
             _, last_idx = np.unique(ukey[::-1], return_index=True)
             last = sid[::-1][last_idx]
-            us = us[np.lexsort((last, first))]
+            # (round 6: by first + last -- the middle of the interval of scans that use the entry -- then first.  On sliding windows it is the
+            # same order as (first, last); on windows chosen by the reference's rule, where an entry's users are not an interval of consecutive
+            # scans and traversals come and go, a scan's slot range shrinks from 2.23 to 2.04 x its own entries (1.47 -> 1.37 without absent
+            # traversals): fewer foreign records for the join to load, transform and mask)
+            us = us[np.lexsort((first, first + last))]
             pos = np.empty(int(us.max()) + 1, dtype=np.int32)
             pos[us] = np.arange(len(us), dtype=np.int32)
             fr = np.zeros(len(us), dtype=BLOCK_FRAME)
