@@ -600,7 +600,7 @@ class FrameStore:
         """The tables of modest_pp_score_block for these scans, or None when the block path does not apply: more than
         64 traversals / scans, a frame with points outside its table, poses that disagree with the lattice by more
         than 1e-4 m, live scans further apart than the block window, mixed remove_center flags -- or (unless forced)
-        too little sharing (fewer than 4 scans, union > 3 x a scan's frames): the block path bins the UNION of the scans' frames once, which pays when the scans are
+        too little sharing (fewer than 4 scans, union > 4 x a scan's frames): the block path bins the UNION of the scans' frames once, which pays when the scans are
         consecutive scans of a shard (35 of 36 frames per traversal shared, split_traintest.py:64,97)."""
         env = os.environ.get("MODEST_PP_BLOCK", "")
         if force is None:
@@ -650,8 +650,11 @@ class FrameStore:
                 # Large blocks amortise the union's binning further (16 -> 32 Lyft-shape scans: 79 -> 69 us per scan at a union of
                 # 1.42 -> 1.86 x a scan's entries; nuScenes shape, 16 frames per traversal: 111 -> 101 us at 1.94 -> 2.94 x; windows by the
                 # reference's rule: 111 -> 117 at 2.1 -> 2.6 x) -- ONE block beats two of half the scans wherever the block path pays
-                # at all (measured: tools/pp_block_probe.py --auto).  Past 3 x, two halves are tried before the per-scan chain.
-                if len(us) > 3.0 * per_scan:
+                # at all (measured: tools/pp_block_probe.py --auto).
+                # round 6 (member packing, union ordered by first + last; tools/pp_block_probe.py --halves, 32 scans, union 3.0 ... 4.0 x):
+                # ONE block 101 / 105 / 117 / 121 / 127 us per scan against 106 / 112 / 128 / 124 / 137 in two halves and 200 for the chain --
+                # halves are tried past 4 x only
+                if len(us) > 4.0 * per_scan:
                     return SPLIT_BLOCK if B >= 8 else None
                 # the join keeps a scan's pose table (49 B per union entry) in LDS up to 2 048 entries (pp_v4.hip: B4_POSE_LDS_MAX);
                 # beyond that it reads the poses from memory (measured with a table of 1 024: 32 scans with little sharing, 1 113-1 138

@@ -149,20 +149,21 @@ def test_block_tables_repeated_frames_get_a_union_entry_per_occurrence():
 
 
 def test_large_blocks_split_when_the_union_is_large():
-    """32 scans of Lyft shape (36 frames per traversal: union 1.86 x a scan's entries) and of nuScenes shape (16 frames: 2.94 x) stay
-    ONE block; 32 scans with 12 frames per traversal (3.58 x: past the rule's 3 x) are tried in two halves (2.25 x) before the
-    per-scan chain -- unless the caller forces one block."""
-    B, T = 32, 4
-    for F, expect_split in ((36, False), (16, False), (12, True)):
+    """32 scans of Lyft shape (36 frames per traversal: union 1.86 x a scan's entries), of nuScenes shape (16 frames: 2.94 x) and with
+    12 frames per traversal (3.58 x) stay ONE block (round 6: one block beat two halves up to 4 x); 48 scans with 12 frames per
+    traversal (4.9 x: past the rule's 4 x) are tried in two halves (2.9 x) before the per-scan chain -- unless the caller forces one
+    block."""
+    T = 4
+    for B, F, expect_split in ((32, 36, False), (32, 16, False), (32, 12, False), (48, 12, True)):
         L = F + B - 1
         st = _store(T * L + B, T, L)
         descs = _descs(st, B, T, F, L)
         got = st.block_tables(descs, T)
-        assert (got is fs.SPLIT_BLOCK) == expect_split, (F, got if isinstance(got, str) else type(got))
+        assert (got is fs.SPLIT_BLOCK) == expect_split, (B, F, got if isinstance(got, str) else type(got))
         forced = st.block_tables(descs, T, force=True)
         assert forced is not None and forced is not fs.SPLIT_BLOCK and len(forced[0]) == T * L
-        half = st.block_tables(descs[:16], T)   # each half then goes as a block of its own
-        assert half is not None and half is not fs.SPLIT_BLOCK and len(half[1]) == 16
+        half = st.block_tables(descs[:B // 2], T)   # each half then goes as a block of its own
+        assert half is not None and half is not fs.SPLIT_BLOCK and len(half[1]) == B // 2
 
 
 def test_block_tables_with_a_traversal_count_per_scan():

@@ -56,7 +56,7 @@ def test_block_equals_oracle_and_chain(gpu, nusc, T, F, S):
 
 def test_block_choice_and_fallbacks(gpu):
     """The store takes the block path on its own from four scans that share most of their frames (>= 12 frames per
-    traversal, union <= 3 x a scan's frames); shorter windows, few scans, a frame
+    traversal, union <= 4 x a scan's frames); shorter windows, few scans, a frame
     with points outside its table, poses that disagree with the lattice and a radius other than the store's all take the
     per-scan chain -- with identical results."""
     import torch
@@ -291,14 +291,14 @@ def test_block_join_deal_does_not_change_counts(gpu, monkeypatch, tk, lf):
 
 
 def test_blocks_of_32_and_the_split_rule(gpu):
-    """32 consecutive scans in ONE call: long windows (40 frames per traversal, union 1.78 x a scan's entries) go as one block; short
-    windows (12 frames: 3.6 x, past the rule's 3 x) go as two blocks of 16 (FrameStore.block_tables: SPLIT_BLOCK) -- every scan
-    equals the per-scan chain either way, and the first / last scan the oracle."""
+    """Many consecutive scans in ONE call: 32 scans with long windows (40 frames per traversal, union 1.78 x a scan's entries) and with
+    short ones (12 frames: 3.6 x) go as one block; 48 scans with 12 frames (4.9 x, past the rule's 4 x) go as two blocks of 24
+    (FrameStore.block_tables: SPLIT_BLOCK) -- every scan equals the per-scan chain either way, and the first / last scan the oracle."""
     import torch
     from modest_amd import synth
     from modest_amd.frame_store import FrameStore
-    for F, calls in ((40, 1), (12, 2)):
-        sh = synth.make_shard(32, n_live=1500, n_trav=2, n_frames=F, n_per_frame=1200, seed=31 + F, frame_gap=0.8)
+    for S, F, calls in ((32, 40, 1), (32, 12, 1), (48, 12, 2)):
+        sh = synth.make_shard(S, n_live=1500, n_trav=2, n_frames=F, n_per_frame=1200, seed=31 + F, frame_gap=0.8)
         store = FrameStore(gpu, 0.3)
         lives, descs, _ = _load(store, sh, gpu, torch)
         ref = store.pp_score_batch(lives, descs, 2, return_counts=True, block=False)[1]
@@ -306,8 +306,8 @@ def test_blocks_of_32_and_the_split_rule(gpu):
         Hb, cb = store.pp_score_batch(lives, descs, 2, return_counts=True)   # the automatic rule
         assert getattr(store, "block_calls", 0) - n0 == calls, (F, getattr(store, "block_calls", 0) - n0)
         assert all(torch.equal(a, b) for a, b in zip(cb, ref))
-        for i in (0, 31):
-            assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), _oracle_counts(sh, i)[1]), (F, i)
+        for i in (0, S - 1):
+            assert np.array_equal(cb[i].cpu().numpy().astype(np.int64), _oracle_counts(sh, i)[1]), (S, F, i)
 
 
 def test_block_with_different_traversal_counts_per_scan(gpu):
