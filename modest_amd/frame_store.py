@@ -688,11 +688,13 @@ class FrameStore:
             R[:, 3, 3] = 1.0
             A = np.zeros((B, 4, 4))
             A[has] = self._W[lslots[has]] @ np.linalg.inv(R[has])
-            rels = np.zeros((members, 4, 4))
-            rels[:, :3, :] = mr_all.reshape(members, 3, 4)
-            rels[:, 3, 3] = 1.0
-            D = A[sid] @ rels - self._W[allh]
-            dev = np.abs(D[:, :2, :3]).sum(axis=2) * 160.0 + np.abs(D[:, :2, 3])
+            # (rows x, y of A_scan @ rel_f - W_f only -- the lattice is two-dimensional --, and rel's last row is (0, 0, 0, 1): a
+            # (2,3) @ (3,4) product per member instead of a (4,4) @ (4,4) one: 5.1 -> 3.4 ms of host time per block of 32 x 360 members)
+            A2 = A[:, :2, :]
+            D = np.matmul(A2[sid][:, :, :3], mr_all.reshape(members, 3, 4).astype(np.float64))
+            D[:, :, 3] += A2[sid][:, :, 3]
+            D -= self._W[allh][:, :2, :]
+            dev = np.abs(D[:, :, :3]).sum(axis=2) * 160.0 + np.abs(D[:, :, 3])
             if not (np.all(np.isfinite(dev)) and dev.max() < 1e-4):
                 return None
             # the block's frame table in the order (first scan that uses the frame, last scan that uses it): the frames of every
