@@ -127,6 +127,10 @@ def parse(argv=None):
     ap.add_argument("--cli-scans", type=int, default=768,
                     help="live scans of the CLI measurement (0 = skip): the three product CLIs on a synthetic KITTI "
                          "tree, 10 history traversals x 36 frames per scan, frames shared between consecutive scans")
+    ap.add_argument("--cli-workers", type=int, default=6,
+                    help="worker processes per GPU of the CLI measurement's workers=N legs (profiles/r06_cli_workers_readers.txt: "
+                         "5-6 workers x 2 reader threads is where the ingest-bound CLIs peak; 8 lose a fifth to the contention of "
+                         "their reads)")
     a = ap.parse_args(argv)
     a.nusc = a.config == "c5"
     if a.nusc:
@@ -727,7 +731,7 @@ def cli_bench(a, local):
     solves, kernels, .npy/.pkl/.txt writes.  Every CLI runs twice: one process, and `workers=N`
     (N child processes on the GPU; their own loop clocks, i.e. without interpreter start-up)."""
     from modest_amd import gen_label_files, generate_mask, pre_compute_pp_score, synth
-    n_scan, F, T, W = int(a.cli_scans), int(a.frames), int(a.traversals), max(2, int(a.procs))
+    n_scan, F, T, W = int(a.cli_scans), int(a.frames), int(a.traversals), max(2, int(a.cli_workers))
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     out = {}
     with tempfile.TemporaryDirectory(dir=base) as root:

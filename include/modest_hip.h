@@ -573,6 +573,16 @@ int modest_label_lines(const double *objs8_host, const double *cossin_ry_host, i
                        const float *iou_host, const modest_labels_params *params, int32_t *kept_out_host,
                        int32_t *n_kept_out_host, char *text_out_host, int32_t text_cap, int32_t *text_len_out_host);
 
+/* ---- host-side ingest: the `.bin` files of a group of scans, back to back into one (pinned) staging buffer -------------
+ * Replaces the per-frame np.fromfile of load_velo_scan (utils/pointcloud_utils.py:22-25; one call per history frame from
+ * pre_compute_pp_score.py:137-146).  paths[k]: NUL-terminated; dst [host] capacity_bytes; sizes_out [host] (n_files) = every
+ * file's size in bytes (file k lands at the sum of the sizes before it); n_threads host threads share the files.
+ * Returns 0 = read; a positive number = the bytes the files need when that exceeds capacity_bytes (or dst is NULL): nothing was
+ * read, sizes_out is filled, call again with a larger buffer; -(k + 2) = file k could not be opened or read (errno holds the
+ * cause); -1 = bad arguments.  Pure host code: no context, no stream, no device.                                              */
+int64_t modest_host_read_files(const char *const *paths, int n_files, void *dst, uint64_t capacity_bytes, uint64_t *sizes_out,
+                               int n_threads);
+
 /* ---- §8f-2 combine_labels.py: filter_by_ppscore (combine_labels.py:41-60) -------
  * For each detector box the reference masks the scan's rect-frame points (offsets from the box
  * centre rotated into the box frame by `ptc_xz @ rot.T`, strict half-extent tests in x and z,

@@ -88,9 +88,9 @@ class FrameLoader:
     releases the GIL), one asynchronous copy takes it to the device, one launch sorts all of them."""
 
     def __init__(self, velodyne_dir, store: FrameStore, world, readers: int = 4, ctx=None, frame_bytes: int = 0):
-        from concurrent.futures import ThreadPoolExecutor
+        from . import _lib
         self.dir, self.store, self.world, self.ctx = velodyne_dir, store, world, ctx
-        self.pool = ThreadPoolExecutor(max_workers=max(1, int(readers)))
+        self.lib, self.readers = _lib.load(), max(1, int(readers))
         self.chunk = 32   # frames per staged piece
         self.slots = 3    # ring: a slot is refilled only after its last upload AND the sort that read it have run
         self.turn = 0
@@ -118,26 +118,32 @@ class FrameLoader:
         self.slot_ev = [None] * self.slots
 
     def _read_batch(self, ids):
-        """the .bin files of `ids` -> one pinned float32 buffer; returns (slot, buffer (P,4), point offsets)"""
-        paths = [osp.join(self.dir, f"{i:06d}.bin") for i in ids]
-        sizes = [os.path.getsize(p) for p in paths]
-        assert all(sz % 16 == 0 for sz in sizes), "velodyne .bin files hold (n,4) float32 rows"
-        offs = np.cumsum([0] + [sz // 16 for sz in sizes])
-        need = int(offs[-1])
-        if self.pinned_all is None or need > self.cap:   # (no staging yet: the size probe failed and every file so far was empty)
-            self._make_staging(max(need + need // 8, 1 << 16))
+        """the .bin files of `ids` -> one pinned float32 buffer; returns (slot, buffer (P,4), point offsets).  One library call
+        (modest_host_read_files: stat + read by `readers` host threads, interpreter lock released for the whole of it)."""
+        import ctypes as C
+        n = len(ids)
+        paths = (C.c_char_p * n)(*[osp.join(self.dir, f"{i:06d}.bin").encode() for i in ids])
+        sizes = np.zeros(n, dtype=np.uint64)
+        if self.pinned_all is None:   # (no staging yet: the size probe failed)
+            need = int(self.lib.modest_host_read_files(paths, n, None, 0, sizes.ctypes.data, self.readers))
+            if need < 0:
+                raise IOError(f"cannot read {paths[-need - 2].decode()}" if need < -1 else "modest_host_read_files: bad arguments")
+            self._make_staging(max(need // 16 + need // 128, 1 << 16))
         r = self.turn = (self.turn + 1) % self.slots
-        if self.slot_ev[r] is not None:
-            self.slot_ev[r].synchronize()
-        host = self.pinned_all[r].numpy()
-
-        def rd(k):
-            with open(paths[k], "rb", buffering=0) as f:
-                got = f.readinto(memoryview(host[offs[k]:offs[k + 1]]).cast("B"))
-            if got != sizes[k]:
-                raise IOError(f"short read of {paths[k]}")
-        list(self.pool.map(rd, range(len(ids))))
-        self.read_bytes += int(sum(sizes))
+        while True:
+            if self.slot_ev[r] is not None:
+                self.slot_ev[r].synchronize()
+            rc = int(self.lib.modest_host_read_files(paths, n, self.pinned_all[r].data_ptr(), self.cap * 16, sizes.ctypes.data, self.readers))
+            if rc == 0:
+                break
+            if rc < 0:
+                raise IOError(f"cannot read {paths[-rc - 2].decode()}" if rc < -1 else "modest_host_read_files: bad arguments")
+            self._make_staging(rc // 16 + rc // 128 + 1024)   # the piece needs a larger ring (rc bytes): rebuild it and read again
+            r = self.turn
+        assert not (sizes % 16).any(), "velodyne .bin files hold (n,4) float32 rows"
+        offs = np.concatenate([[0], np.cumsum(sizes // 16)]).astype(np.int64)
+        need = int(offs[-1])
+        self.read_bytes += int(sizes.sum())
         return r, self.pinned_all[r][:need], offs
 
     def ensure(self, file_ids, protect=None, blocking=True):
@@ -454,7 +460,7 @@ def run(args, post=None, module="modest_amd.pre_compute_pp_score"):
         frame_bytes = os.path.getsize(osp.join(args.data_root, "velodyne", f"{track_list[0][0]:06d}.bin"))
     except (OSError, IndexError):
         frame_bytes = 0
-    loader = FrameLoader(osp.join(args.data_root, "velodyne"), store, world, readers=int(args.get("ingest_readers", 4)),
+    loader = FrameLoader(osp.join(args.data_root, "velodyne"), store, world, readers=int(args.get("ingest_readers", 0) or 0) or (2 if os.environ.get("MODEST_WORKER") else 4),
                          ctx=_lib.Context(device.index or 0), frame_bytes=frame_bytes)
 
     def plans():
@@ -519,36 +525,53 @@ def run(args, post=None, module="modest_amd.pre_compute_pp_score"):
     # flushes; the ingest window must hold a whole batch plus the scans ahead -- at least one scan ahead, whatever
     # ingest_depth says (a window smaller than a batch would leave this loop waiting for a scan the ingest thread may
     # not load)
-    pipe = IngestPipeline(loader, plans(), device, depth=max(1, int(args.get("ingest_depth", 4))) + (n_batch - 1),
+    pipe = IngestPipeline(loader, plans(), device, depth=max(1, int(args.get("ingest_depth", 36))) + (n_batch - 1),
                           stream=ingest_stream)
-    writer = OutputWriter(1 << 16)
+    # (a slot per scan of a batch + the writer's backlog: with fewer slots than scans per PP call the loop waited in submit() for the
+    # batch's own kernels, and the ingest window behind it stayed closed for as long)
+    writer = OutputWriter(1 << 16, slots=int(os.environ.get("MODEST_OUT_SLOTS", str(n_batch + 8))))
     pend = []   # the scans waiting for the flush: (live frame, history ids, traversal of every frame, raw pose factors of the
     #             history frames + the live scan, fixed l2e, fixed ego, output path, scan id, traversals)
     pose_threads = max(1, int(args.get("pose_threads", 4)))
     flushed = False
+    ph = dict(wait=0.0, poses=0.0, tables=0.0, pp=0.0, submit=0.0, post=0.0)   # seconds of THIS thread, by phase (the summary line)
 
     def flush():
         if not pend:
             return
+        f0 = time.perf_counter()
         # the relative poses of the whole batch (get_relative_pose :27-28 per frame; a few scans per thread) and its descriptor
         # tables (one gather from the store's slot tables) -- then ONE PP call
         rels = relative_poses_block([q[4] for q in pend], [q[5] for q in pend], [q[3] for q in pend], K, threads=pose_threads)
+        f1 = time.perf_counter()
         descs = store.describe_many([q[0] for q in pend], [r[-1] for r in rels], [q[1] for q in pend], [q[2] for q in pend],
                                     [r[:-1] for r in rels], bool(args.nusc))
         # (a scan's own number of traversals: the reference accepts a traversal per scan, data_preprocessing/lyft/split_traintest.py:79,111,
         # so T changes along a sequence -- a block takes the scans as they come)
+        f2 = time.perf_counter()
         Hs = store.pp_score_batch([q[0] for q in pend], descs, [q[8] for q in pend])
+        f3 = time.perf_counter()
         for q, H in zip(pend, Hs):
             _tr("M.enq", q[7])
             writer.submit(H, q[6])
             _tr("M.sub", q[7])
+        f4 = time.perf_counter()
         if post is not None:   # fused mode: stages 2 + 3 of the batch (deferred by one batch: they run under the NEXT batch's PP kernels)
             post([(q[7], q[0], H) for q, H in zip(pend, Hs)])
+        f5 = time.perf_counter()
+        for k, v in zip(("poses", "tables", "pp", "submit", "post"), (f1 - f0, f2 - f1, f3 - f2, f4 - f3, f5 - f4)):
+            ph[k] += v
         for _ in pend:
             pipe.done()
         pend.clear()
 
-    for plan in pipe:
+    pipe_it = iter(pipe)
+    while True:
+        w0 = time.perf_counter()
+        plan = next(pipe_it, None)
+        ph["wait"] += time.perf_counter() - w0
+        if plan is None:
+            break
         origin_idx, out_path, traversals = plan["origin"], plan["out"], plan["traversals"]
         live_id, hist_ids, travs = plan["live"], plan["hist"], plan["travs"]
         first_seq, first_indices = traversals[0]
@@ -632,10 +655,11 @@ def run(args, post=None, module="modest_amd.pre_compute_pp_score"):
     tot = dist.rank_report("pp_score", done, t0, rank, ws, dict(hist_points=pts))
     if rank == 0:
         eprint("[pp_score] %d scans, %.3g history points, %.2f s, %.2f scans/s on %d GPU(s); frame store %d hits / %d misses; "
-               "ingest thread of rank 0: %d frames, %.1f MB read in %.3f s, upload + sort %.3f s, bookkeeping %.3f s"
+               "ingest thread of rank 0: %d frames, %.1f MB read in %.3f s, upload + sort %.3f s, bookkeeping %.3f s; "
+               "loop thread: %s"
                % (tot["scans"], tot["hist_points"], tot["max_seconds"], tot["scans"] / max(tot["max_seconds"], 1e-9),
                   ws, store.hits, store.misses, loader.n_frames, loader.read_bytes / 1e6, loader.t_read, loader.t_insert,
-                  loader.t_touch))
+                  loader.t_touch, ", ".join("%s %.3f s" % (k, v) for k, v in ph.items())))
     return tot
 
 

@@ -148,38 +148,56 @@ class FusedStages:
         self.seed = int(margs.get("ransac_seed", 0))
         self.n_chain = max(1, int(margs.get("mask_batch", 4)))
         self.pending = None
+        self.host_scores = [None, None]   # pinned read-back buffers of a batch's scores: one waiting, one being processed
+        self.turn = 0
         self.writer = _FileWriter()
         self.scans = 0
         self.t_host = 0.0
+        self.ph = dict(scores=0.0, files=0.0, mask=0.0, labels=0.0)   # seconds of _process by phase (the summary line)
 
     def done(self, idx: int) -> bool:
         return all(osp.exists(p) for p in (osp.join(self.seg_dst, f"{idx:06d}.npy"), osp.join(self.bbox_dst, f"{idx:06d}.pkl"),
                                             osp.join(self.label_dst, f"{idx:06d}.txt")))
 
     def __call__(self, batch):
-        prev, self.pending = self.pending, batch
+        # The batch's PP scores start their way to the host NOW -- behind the batch's own kernels, ahead of the next batch's -- into a
+        # pinned buffer (the mask stage's host statement and the rare scans the library hands back read them).  Read back inside
+        # _process, one batch later, the copy queued behind the NEXT batch's PP kernels and the loop waited for all of them.
+        Hdev = torch.cat([H for _, _, H in batch])
+        k = self.turn = 1 - self.turn
+        if self.host_scores[k] is None or self.host_scores[k].shape[0] < Hdev.shape[0]:
+            self.host_scores[k] = torch.empty((int(Hdev.shape[0] * 1.25) + 1024,), dtype=Hdev.dtype, pin_memory=True)
+        host = self.host_scores[k][:Hdev.shape[0]]
+        host.copy_(Hdev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        prev, self.pending = self.pending, (batch, host, ev)
         if prev:
-            self._process(prev)
+            self._process(*prev)
 
     def close(self):
         prev, self.pending = self.pending, None
         if prev:
-            self._process(prev)
+            self._process(*prev)
         self.writer.close()
 
-    def _process(self, batch):
+    def _process(self, batch, host, ev):
         t0 = time.perf_counter()
         margs, largs = self.margs, self.largs
-        # the batch's PP scores on the host (the mask stage's host statement and the rare scans the library hands back read them): one copy
-        Hcat = torch.cat([H for _, _, H in batch]).cpu().numpy()
+        ev.synchronize()
+        Hcat = host.numpy()
         offs = np.cumsum([0] + [int(H.shape[0]) for _, _, H in batch])
+        t1 = time.perf_counter()
+        self.ph["scores"] += t1 - t0
         items, calibs = [], []
         for k, (idx, _live, H) in enumerate(batch):
             ptc = load_velo_scan(osp.join(margs.ptc_path, f"{idx:06d}.bin"))
             items.append(dict(idx=idx, ptc=ptc, pp_score=Hcat[offs[k]:offs[k + 1]], pp_dev=H,
                               random_state=np.random.RandomState(self.seed + idx)))
             calibs.append(kitti_util.Calibration(osp.join(margs.calib_path, f"{idx:06d}.txt")))
+        self.ph["files"] += time.perf_counter() - t1
         for c0 in range(0, len(items), self.n_chain):
+            t2 = time.perf_counter()
             chunk, cal = items[c0:c0 + self.n_chain], calibs[c0:c0 + self.n_chain]
             if len(chunk) == 1:
                 q = chunk[0]
@@ -187,9 +205,12 @@ class FusedStages:
             else:
                 res = generate_mask_chain(chunk, cal, margs, as_rows=True, with_iou=bool(largs.nms.enable))
             rows = [np.asarray(r[1], dtype=np.float64).reshape(-1, 8) for r in res]
+            t3 = time.perf_counter()
+            self.ph["mask"] += t3 - t2
             lab = gen_label_chain(rows, cal, largs, ious=[r[3] if len(r) > 3 else None for r in res])
             for q, r, rw, (text, _kept) in zip(chunk, res, rows, lab):
                 self.writer.submit(lambda i=q["idx"], labels=r[0], rw=rw, text=text: self._write(i, labels, rw, text))
+            self.ph["labels"] += time.perf_counter() - t3
         self.scans += len(batch)
         self.t_host += time.perf_counter() - t0
 
@@ -238,8 +259,8 @@ def main(cfg=None, argv: Optional[List[str]] = None):
     post = FusedStages(margs, largs, rank)
     tot = pre_compute_pp_score.run(pargs, post=post)
     if rank == 0:
-        eprint("[seed_labels] stages 2 + 3: %d scans, %.2f s of host time in this process (under the next batch's PP kernels)"
-               % (post.scans, post.t_host))
+        eprint("[seed_labels] stages 2 + 3: %d scans, %.2f s of host time in this process (under the next batch's PP kernels): %s"
+               % (post.scans, post.t_host, ", ".join("%s %.3f s" % kv for kv in post.ph.items())))
     return tot
 
 

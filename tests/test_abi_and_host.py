@@ -359,3 +359,37 @@ def test_fused_cli_composes_the_three_stage_configs():
         sl.compose_all(["data_root=/d", "no_such_key=1"])
     with pytest.raises(KeyError):
         sl.compose_all(["data_root=/d", "mask.no_such_key=1"])
+
+
+def test_host_read_files_packs_files_back_to_back(tmp_path):
+    """modest_host_read_files (the group read of FrameLoader; load_velo_scan's np.fromfile per frame, pointcloud_utils.py:22-25):
+    sizes, order, the too-small-buffer answer, empty files and a missing one."""
+    import ctypes as C
+    from modest_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    blobs = [rng.integers(0, 256, size=n, dtype=np.uint8) for n in (480016, 0, 16, 1 << 20, 33, 7 * 16)]
+    paths = []
+    for k, b in enumerate(blobs):
+        p = tmp_path / f"{k:06d}.bin"
+        b.tofile(p)
+        paths.append(str(p).encode())
+    n = len(paths)
+    arr = (C.c_char_p * n)(*paths)
+    sizes = np.zeros(n, dtype=np.uint64)
+    total = sum(len(b) for b in blobs)
+    for threads in (1, 3, 16):
+        sizes[:] = 0
+        assert lib.modest_host_read_files(arr, n, None, 0, sizes.ctypes.data, threads) == total   # size query
+        assert sizes.tolist() == [len(b) for b in blobs]
+        small = np.full(total - 1, 7, dtype=np.uint8)
+        assert lib.modest_host_read_files(arr, n, small.ctypes.data, small.size, sizes.ctypes.data, threads) == total
+        assert (small == 7).all()   # nothing written
+        dst = np.zeros(total + 64, dtype=np.uint8)
+        assert lib.modest_host_read_files(arr, n, dst.ctypes.data, dst.size, sizes.ctypes.data, threads) == 0
+        assert np.array_equal(dst[:total], np.concatenate(blobs)) and not dst[total:].any()
+    bad = (C.c_char_p * 3)(paths[0], str(tmp_path / "missing.bin").encode(), paths[2])
+    dst = np.zeros(total, dtype=np.uint8)
+    assert lib.modest_host_read_files(bad, 3, dst.ctypes.data, dst.size, sizes.ctypes.data, 2) == -(1 + 2)
+    assert lib.modest_host_read_files(bad, 0, None, 0, None, 2) == 0
+    assert lib.modest_host_read_files(None, 2, None, 0, None, 2) == -1

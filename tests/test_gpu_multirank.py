@@ -8,6 +8,7 @@ import filecmp
 import json
 import os
 import re
+import signal
 import subprocess
 import sys
 
@@ -38,9 +39,21 @@ def _run(module, ov, ranks, port, extra_env=None):
         env["MODEST_DIST_BACKEND"] = "gloo"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", f"modest_amd.{module}"] + ov
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (module, r.stderr[-3000:])
-    return r.stderr
+    # a hung CLI reports where: every process of the run dumps its threads' stacks (faulthandler on SIGABRT) before the test fails
+    env["PYTHONFAULTHANDLER"] = "1"
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=int(os.environ.get("MODEST_TEST_CLI_TIMEOUT", "600")))
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGABRT)
+        try:
+            _, err = p.communicate(timeout=30)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            _, err = p.communicate()
+        raise AssertionError((module, "timed out", err[-12000:]))
+    assert p.returncode == 0, (module, err[-3000:])
+    return err
 
 
 def _same_tree(a, b):
