@@ -4,7 +4,7 @@
 // from pre_compute_pp_score.py:137-146).  Here the files of up to four scans (44 new frames, 361 for a cold scan) are stat'ed and
 // read by a few host threads inside ONE call that the Python side makes with the interpreter lock released: reader threads in the
 // interpreter took the lock three times per file (open / readinto / close) and waited for the scan loop's thread each time --
-// a worker's reads ran 1.7 x slower whenever they overlapped the loop (profiles/r06_cli_phases.txt).
+// a worker's reads ran 1.5-1.7 x slower whenever they overlapped the loop (profiles/r06_cli_slots.txt against r06_cli_slots_creader.txt).
 #include "../../include/modest_hip.h"
 
 #include <atomic>
