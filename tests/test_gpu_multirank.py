@@ -39,21 +39,32 @@ def _run(module, ov, ranks, port, extra_env=None):
         env["MODEST_DIST_BACKEND"] = "gloo"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", f"modest_amd.{module}"] + ov
-    # a hung CLI reports where: every process of the run dumps its threads' stacks (faulthandler on SIGABRT) before the test fails
-    env["PYTHONFAULTHANDLER"] = "1"
+    _, err = _exec(cmd, env, int(os.environ.get("MODEST_TEST_CLI_TIMEOUT", "600")), module)
+    return err
+
+
+class _Done:
+    def __init__(self, returncode, stdout, stderr):
+        self.returncode, self.stdout, self.stderr = returncode, stdout, stderr
+
+
+def _exec(cmd, env, timeout, what="run"):
+    """subprocess.run with a post-mortem: a run that hangs dumps the stacks of every thread of every process of its session
+    (faulthandler on SIGABRT) into the assertion message before it is killed; a non-zero exit code fails with the tail of stderr."""
+    env = dict(env, PYTHONFAULTHANDLER="1")
     p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        _, err = p.communicate(timeout=int(os.environ.get("MODEST_TEST_CLI_TIMEOUT", "600")))
+        out, err = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
         os.killpg(p.pid, signal.SIGABRT)
         try:
-            _, err = p.communicate(timeout=30)
+            out, err = p.communicate(timeout=30)
         except subprocess.TimeoutExpired:
             os.killpg(p.pid, signal.SIGKILL)
-            _, err = p.communicate()
-        raise AssertionError((module, "timed out", err[-12000:]))
-    assert p.returncode == 0, (module, err[-3000:])
-    return err
+            out, err = p.communicate()
+        raise AssertionError((what, "timed out after %d s" % timeout, err[-12000:]))
+    assert p.returncode == 0, (what, err[-3000:])
+    return out, err
 
 
 def _same_tree(a, b):
@@ -135,7 +146,7 @@ def test_rccl_process_group_at_world_size_one(gpu, tmp_path):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", "-m", "modest_amd.pre_compute_pp_score"] + _overrides(train, paths, forced)
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = _Done(0, *_exec(cmd, env, 900))
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stderr.splitlines() if l.startswith("[dist] ")]
     assert line, r.stderr[-2000:]
@@ -159,7 +170,7 @@ def test_bench_two_ranks_two_helpers_one_gpu(gpu):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--procs", "2", "--steps", "8", "--warmup", "2", "--scans", "8",
            "--shard-scans", "8", "--n-live", "3000", "--frames", "4", "--traversals", "3", "--cli-scans", "0", "--cpu-scans", "0"]
     t0 = time.time()
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = _Done(0, *_exec(cmd, env, 600))
     wall = time.time() - t0
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -227,7 +238,7 @@ def test_bench_eight_ranks_one_gpu(gpu):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--procs", "1", "--steps", "8", "--warmup", "2", "--scans", "8",
            "--shard-scans", "8", "--n-live", "3000", "--frames", "4", "--traversals", "3", "--cli-scans", "0", "--cpu-scans", "0", "--sharing", "best"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = _Done(0, *_exec(cmd, env, 900))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
