@@ -16,7 +16,7 @@ def main():
         for j in range(24):
             pose = synth._pose_matrix(2.0 * j, 0.3, 0.01)
             frames.append((torch.from_numpy(synth.sample_frame(world, 100 + j, n_pts, pose, l2e)).to(dev), pose @ l2e @ K))
-        for nb in (11, 361):
+        for nb in (11, 44, 361):
             store = FrameStore(dev, 0.3)
             store.insert_many([(10**6 + k, frames[k % 24][0], frames[k % 24][1]) for k in range(nb)])   # warm: arena, anchor
             ts = []
