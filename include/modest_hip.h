@@ -242,6 +242,42 @@ int modest_pp_score_block_mixed(modest_ctx *ctx, const modest_pp_block_frame *fr
                                 const modest_pp_block_scan *scans_host, int n_scans, const int32_t *n_trav_scan,
                                 double radius, double cell, void *stream);
 
+/* ---- the tables of a block call from a frame store's slot tables (host only) -------------------------------------------
+ * What a caller of modest_pp_score_block[_mixed] has to build from the scans' index lists (valid_idx_info.pkl,
+ * data_preprocessing/lyft/split_traintest.py:79-101; the reference stacks every scan's list anew, pre_compute_pp_score.py:132-150):
+ * the union of the lists as (frame, occurrence) entries ordered by the middle of the interval of scans that use an entry, every scan's
+ * members as indices into it, and the checks listed under modest_pp_score_block (no frame with points outside its table, every pose
+ * within 1e-4 m of the lattice, the live tables within the block window, one remove_center flag).  store: slot -> modest_pp_frame record
+ * (buffers and table origin), W (n_slots,4,4) float64 raw frame -> world, lat (n_slots,8) = modest_frame_sort_job::W, perm_dev
+ * (n_slots) the frames' perm buffers as integers, clean (n_slots) bytes: 1 = no point outside the table.
+ * Per scan s: live_host[s] = the live frame's record with rel = its float32 relative pose; members_host[s] = n_members[s] records
+ * (trav, flags, rel = the frame's float32 relative pose in this scan); slots_host[s] = n_members[s] + 1 store slots: the members',
+ * then the live frame's.  apply_rule != 0: the measured rule between block and chain (>= 4 scans, >= 12 entries per traversal and
+ * scan, union <= 4 x a scan's entries and <= 2048).  Outputs [host]: frames_out (capacity frames_cap entries; *n_frames_out used),
+ * scans_out (n_scans; counts_dev / H_dev left NULL for the caller), member_slot_out / member_trav_out (sum of n_members) and
+ * member_rel_out (12 floats per member), which scans_out points into.
+ * Returns MODEST_BLOCK_TABLES_BLOCK (tables built), _CHAIN (the block path does not apply: use modest_pp_score_frames_batch),
+ * _SPLIT (worth the block path in two halves), -1 = bad arguments.                                                                 */
+#define MODEST_BLOCK_TABLES_BLOCK 0
+#define MODEST_BLOCK_TABLES_CHAIN 1
+#define MODEST_BLOCK_TABLES_SPLIT 2
+typedef struct {
+    const modest_pp_frame *records;
+    const double *W;
+    const double *lat;
+    const uint64_t *perm_dev;
+    const uint8_t *clean;
+    int64_t n_slots;
+    double radius, cell;
+    int32_t window_span;   /* tiles the live tables' origins may differ by (window of modest_pp_block_limits - table - 2) */
+} modest_pp_store_view;
+int modest_pp_block_tables(const modest_pp_store_view *store, int n_scans, const modest_pp_frame *const *live_host,
+                           const modest_pp_frame *const *members_host, const int64_t *const *slots_host,
+                           const int32_t *n_members, const int32_t *n_trav_scan, int apply_rule,
+                           modest_pp_block_frame *frames_out, int32_t frames_cap, int32_t *n_frames_out,
+                           modest_pp_block_scan *scans_out, int32_t *member_slot_out, int32_t *member_trav_out,
+                           float *member_rel_out);
+
 /* ---- a9  estimate_plane / RANSACRegressor inner loops -----------------
  * (utils/pointcloud_utils.py:44-65; sklearn RANSACRegressor defaults).
  * Candidate selection: z<max_hs, xlo<x<xhi, ylo<y<yhi (strict), compacted in

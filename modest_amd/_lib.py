@@ -82,6 +82,7 @@ SIGNATURES = {
     "modest_scan_boxes": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP]),
     "modest_objs_iou_batch": (C.c_int, [VP, VP, VP, C.c_int, VP, VP]),
     "modest_objs_iou": (C.c_int, [VP, VP, C.c_int, VP, VP]),
+    "modest_pp_block_tables": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP, C.c_int, VP, C.c_int32, VP, VP, VP, VP, VP]),
     "modest_host_read_files": (C.c_int64, [VP, C.c_int, VP, C.c_uint64, VP, C.c_int]),
     "modest_label_lines": (C.c_int, [VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, C.c_int32, VP]),
 }

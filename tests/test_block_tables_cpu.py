@@ -192,3 +192,65 @@ def test_block_tables_with_a_traversal_count_per_scan():
     short = [(lv, arr[arr["trav"] < 2][:10], np.concatenate([slots[:-1][arr["trav"] < 2][:10], slots[-1:]])) for lv, arr, slots in descs]
     assert st.block_tables(short, [2] * B) is None
     assert st.block_tables(short, [2] * B, force=True) is not None
+
+
+def _same_tables(a, b):
+    if a is None or b is None or isinstance(a, str) or isinstance(b, str):
+        return a is b or a == b
+    (fa, sa, ka), (fb, sb, kb) = a, b
+    if len(fa) != len(fb) or fa.tobytes() != fb.tobytes():
+        return False
+    if any(not np.array_equal(sa[k], sb[k]) for k in ("xyz_dev", "perm_dev", "tab_dev", "n", "TX0", "TY0", "n_members", "lat", "rel")):
+        return False
+    return all(np.array_equal(x, y) for x, y in zip(ka, kb))   # member slots, traversals, poses (scan after scan)
+
+
+def test_library_tables_equal_the_numpy_statement_on_random_blocks():
+    """modest_pp_block_tables (csrc/block_tables.hip) against the numpy statement it replaced (tests/block_tables_numpy.py): the same
+    union in the same order, the same member tables, the same answer where the block path is refused or halved -- on sliding windows,
+    windows with gaps and reversals (an entry's users are then no interval of scans), repeated frames, a traversal count per scan,
+    scans without history, bad poses, unclean frames and far-apart live scans, with the rule and forced."""
+    from block_tables_numpy import block_tables_numpy
+    rng = np.random.default_rng(11)
+    outcomes = {"block": 0, "chain": 0, "split": 0}
+    for case in range(60):
+        T, F = int(rng.integers(2, 7)), int(rng.choice([6, 12, 16, 36]))
+        B = int(rng.choice([3, 4, 7, 8, 16, 32, 48]))
+        if case % 6 == 5:   # many scans over short windows: the union passes 4 x a scan's entries (two halves)
+            B, F = int(rng.choice([48, 64])), 12
+        L = F + B + 3
+        st = _store(T * L + B, T, L)
+        descs = _descs(st, B, T, F, L, bad_pose=(int(rng.integers(B)) if case % 13 == 5 else None))
+        Ts = [T] * B
+        kind = case % 6
+        out = []
+        for i, (lv, arr, slots) in enumerate(descs):
+            arr, slots = arr.copy(), slots.copy()
+            if kind == 1:      # some scans look at a window of their own (no sharing with the neighbours), in a shuffled order
+                if rng.random() < 0.4:
+                    sh = int(rng.integers(0, L - F - i))
+                    slots[:-1] = np.array([t * L + (sh + j) for t in range(T) for j in range(F)])
+                    rel = np.linalg.inv(st._W[slots[-1]])[None] @ st._W[slots[:-1]]
+                    arr["rel"] = rel[:, :3, :].reshape(-1, 12).astype(np.float32)
+                p = rng.permutation(len(arr))
+                arr, slots = arr[p], np.concatenate([slots[:-1][p], slots[-1:]])
+            elif kind == 2:    # repeated frames (split_traintest.py:86-101 lists a frame once per threshold that selects it)
+                for _ in range(int(rng.integers(0, 4))):
+                    d, s_ = rng.integers(0, len(arr), size=2)
+                    arr[d], slots[d] = arr[s_], slots[s_]
+            elif kind == 3:    # a traversal count per scan
+                t = int(rng.integers(1, T + 1))
+                keep = arr["trav"] < t
+                arr, slots, Ts[i] = arr[keep], np.concatenate([slots[:-1][keep], slots[-1:]]), t
+            elif kind == 4 and rng.random() < 0.2:   # a scan without history
+                arr, slots = np.zeros(1, dtype=fs.PP_FRAME), slots[-1:]
+            out.append((lv, arr, slots))
+        if case % 17 == 3:
+            st._clean[int(rng.integers(T * L))] = False
+        if case % 19 == 7:
+            st._rec["TX0"][T * L + B // 2] = 400
+        for force in (None, True):
+            a, b = st.block_tables(out, Ts, force=force), block_tables_numpy(st, out, Ts, force=force)
+            assert _same_tables(a, b), (case, kind, B, T, F, force, type(a), type(b))
+            outcomes["chain" if a is None else ("split" if a is fs.SPLIT_BLOCK else "block")] += 1
+    assert min(outcomes.values()) >= 5, outcomes   # every answer occurs
