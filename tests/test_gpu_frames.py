@@ -208,3 +208,49 @@ def test_store_capacity_counts_slabs_and_reader_streams(gpu):
         block(10 * b)
     assert len(store.frames) == 9 and all(f.n_inside == 9000 for f in store.frames.values())
     assert store.footprint() == sum(ent[1] for ent in store._slabs.values()) >= store.bytes
+
+
+def test_frame_loader_takes_files_of_any_size(gpu, tmp_path):
+    """FrameLoader (the PP CLI's ingest: modest_host_read_files -> pinned ring -> one copy + one sort launch per group) on `.bin`
+    frames whose sizes differ by a factor of 300 -- the staging ring is sized from ONE probed file (pre_compute_pp_score.py) and has
+    to grow in the middle of a group: every stored frame, put back into file order, is the file's xyz bit for bit (load_velo_scan,
+    utils/pointcloud_utils.py:22-25), on the asynchronous path the ingest thread uses and on the blocking one; a missing file is an
+    IOError that names it."""
+    import torch
+    from modest_amd import _lib
+    from modest_amd.frame_store import FrameStore
+    from modest_amd.pre_compute_pp_score import FrameLoader, WorldTable
+    rng = np.random.default_rng(8)
+    d = tmp_path / "velodyne"
+    d.mkdir()
+    sizes = [40] * 6 + [int(x) for x in rng.integers(16, 12000, size=70)] + [12000, 17, 9000]
+    world = WorldTable()
+    files = {}
+    for i, n in enumerate(sizes):
+        pts = np.concatenate([rng.uniform(-60, 60, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1)), rng.uniform(0, 1, size=(n, 1))], axis=1).astype(np.float32)
+        pts.tofile(d / f"{i:06d}.bin")
+        files[i] = pts
+        W = np.eye(4)
+        W[:2, 3] = rng.uniform(-5, 5, size=2)
+        world[i] = W
+    world.freeze()
+    dev = torch.device("cuda:0")
+    for blocking in (False, True):
+        store = FrameStore(dev, 0.3)
+        loader = FrameLoader(str(d), store, world, readers=3, ctx=_lib.Context(0), frame_bytes=40 * 16)   # (probe = a small file)
+        cap0 = loader.cap
+        ids = list(range(len(sizes)))
+        loader.ensure(ids[:6], blocking=blocking)
+        assert loader.cap == cap0
+        loader.ensure(ids, blocking=blocking)      # 73 new frames in pieces of 32: every piece is larger than the ring
+        loader.ensure(ids[10:20], blocking=blocking)   # (all resident: nothing to read)
+        torch.cuda.synchronize()
+        assert loader.cap > cap0 and loader.n_frames == len(sizes) and loader.read_bytes == 16 * sum(sizes)
+        for i in ids:
+            f = store.frames[i]
+            got = f.original_order().cpu().numpy()
+            assert got.shape == (sizes[i], 3) and np.array_equal(got, files[i][:, :3]), (blocking, i, sizes[i])
+            assert np.array_equal(np.sort(f.perm.cpu().numpy()), np.arange(sizes[i]))
+    world[999] = np.eye(4)
+    with pytest.raises(IOError, match="000999.bin"):
+        loader.ensure([999], blocking=False)
