@@ -11,6 +11,7 @@
 #include <cerrno>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <thread>
@@ -32,7 +33,10 @@ extern "C" int64_t modest_host_read_files(const char *const *paths, int n_files,
     auto run = [&](auto &&body) {
         next.store(0);
         std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(body);
+        try {
+            for (int t = 1; t < nt; ++t) th.emplace_back(body);
+        } catch (const std::exception &) {   // (no more threads to be had: the ones that started and this one share the files)
+        }
         body();
         for (auto &x : th) x.join();
     };
