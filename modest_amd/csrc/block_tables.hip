@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -91,7 +92,11 @@ extern "C" int modest_pp_block_tables(const modest_pp_store_view *st, int n_scan
     std::vector<Uni> un;
     std::vector<int32_t> uni_of;   // key -> index into `un` (direct path)
     const uint64_t n_keys = (uint64_t)st->n_slots * (uint64_t)K;
-    const bool direct = n_keys <= (1ull << 24);
+    // (a key-indexed table costs its own clearing: stores of more than 16 M (slot, occurrence) keys sort the members instead;
+    // MODEST_BLOCK_TABLES_DIRECT_MAX moves the limit -- the tests run both paths)
+    uint64_t direct_max = 1ull << 24;
+    if (const char *e = getenv("MODEST_BLOCK_TABLES_DIRECT_MAX")) direct_max = strtoull(e, nullptr, 10);
+    const bool direct = n_keys <= direct_max;
     if (direct) {   // one pass, no sort of the members: the store has a few thousand slots
         uni_of.assign((size_t)n_keys, -1);
         un.reserve(4096);

@@ -205,12 +205,15 @@ def _same_tables(a, b):
     return all(np.array_equal(x, y) for x, y in zip(ka, kb))   # member slots, traversals, poses (scan after scan)
 
 
-def test_library_tables_equal_the_numpy_statement_on_random_blocks():
+@pytest.mark.parametrize("direct_max", [None, "0"])
+def test_library_tables_equal_the_numpy_statement_on_random_blocks(direct_max, monkeypatch):
     """modest_pp_block_tables (csrc/block_tables.hip) against the numpy statement it replaced (tests/block_tables_numpy.py): the same
     union in the same order, the same member tables, the same answer where the block path is refused or halved -- on sliding windows,
     windows with gaps and reversals (an entry's users are then no interval of scans), repeated frames, a traversal count per scan,
     scans without history, bad poses, unclean frames and far-apart live scans, with the rule and forced."""
     from block_tables_numpy import block_tables_numpy
+    if direct_max is not None:   # the library's path for very large stores (members sorted by key instead of a key-indexed table)
+        monkeypatch.setenv("MODEST_BLOCK_TABLES_DIRECT_MAX", direct_max)
     rng = np.random.default_rng(11)
     outcomes = {"block": 0, "chain": 0, "split": 0}
     for case in range(60):
