@@ -253,8 +253,8 @@ def test_bench_contract_json_line(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--procs", "2", "--scans", "2",
-           "--cpu-scans", "1", "--cpu-best-effort", "2", "--cli-scans", "3", "--n-live", "8000", "--traversals", "3",
-           "--frames", "6"]
+           "--cpu-scans", "1", "--cpu-best-effort", "2", "--cli-scans", "3", "--cli-workers", "2", "--n-live", "8000", "--traversals", "3",
+           "--frames", "6"]   # (two CLI workers for three scans: six would only start interpreters)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
